@@ -1,0 +1,263 @@
+#!/usr/bin/env python3
+"""bench.py -- GF(2^128) sumcheck (round-eval + fold) throughput on MI355X.
+
+Contract (one JSON line on rank 0):
+  python bench.py --gpus N --steps K --warmup W
+  N > 1 is launched by the driver as
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is ONE complete bivariate-product sumcheck over the resident multilinears: for every
+round, the round evaluation (accumulate_kernels -> y_1, y_inf), the host's three XORs / two scalar
+multiplications for the round polynomial and the next challenge, and the fold (extrapolate_line)
+of every multilinear.  Workload at N = 1: BASELINE.json configs[1] -- m = 2 multilinears of 2^24
+BinaryField128b elements (512 MiB), one product claim, 24 rounds.  Inputs are generated once
+(SplitMix64), uploaded before the timed region and never modified (the
+prover's first fold copies, like the reference's PreFold -> PostFold).  Challenges come from a
+fixed SplitMix64 stream instead of a Grøstl transcript (host-side protocol code, out of scope).
+
+N > 1: hypercube sharded on the LAST-bound variables (low index bits under High-to-Low binding,
+SURVEY.md section 8e): rank g owns global indices = g mod N as one contiguous local array, every
+rank runs the same rounds on 2^24 local elements per multilinear (weak scaling: the global
+instance has n = 24 + log2 N variables) and the per-round partial (y_1, y_inf) pairs are combined
+with ONE RCCL all_gather of 32 bytes per round + local XOR (RCCL has no XOR reduction).
+
+value = (elements of all multilinears on all ranks) * K / wall seconds  [elems/s].
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n-vars", type=int, default=24, help="local variables per rank")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-n-vars", type=int, default=0, help="size of the CPU baseline sample (0 = auto)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+
+    import binius_amd
+    from binius_amd.sumcheck import bivariate_product_expr, calculate_round_coeffs_from_evals
+    from binius_amd.distributed import ShardedRoundReducer
+
+    n_vars, m = args.n_vars, 2
+    n = 1 << n_vars
+    log_world = world.bit_length() - 1
+    assert 1 << log_world == world, "number of GPUs must be a power of two"
+
+    # ---- inputs: resident in HBM before the timed region
+    import oracle  # input generation (SplitMix64) and the cpu_baseline leg only
+
+    hal = binius_amd.Context(local_rank, m * n + m * (n // 2) + 4096)
+    hal.set_stream(torch.cuda.current_stream().cuda_stream)
+    alloc = hal.dev_alloc()
+    d_in = []
+    for j in range(m):
+        # rank g holds the elements with global index = g mod world; as a stream that is simply an
+        # independent uniform array per (multilinear, rank)
+        host = oracle.random_b128(0xB1A50000 + j + 0x100 * rank, n)
+        s = alloc.alloc(n)
+        hal.copy_h2d(host, s)
+        d_in.append(s)
+        del host
+    stream = oracle.random_scalars(0xC4A1, n_vars + log_world + 1)
+    batch_coeff, challenges = stream[0], stream[1:]
+    expr = bivariate_product_expr(hal, 0, 1)
+    F = binius_amd.HostField
+    reducer = ShardedRoundReducer(hal, dist, world) if world > 1 else None
+
+    def evaluate_univariate(coeffs, x):
+        e = 0
+        for c in reversed(coeffs):
+            e = F.mul(e, x) ^ c
+        return e
+
+    from binius_amd.sumcheck import calculate_round_evals
+
+    def one_sumcheck(claim):
+        """execute/fold loop of BivariateSumcheckProver (v3/bivariate_product.rs:133-232)."""
+        scope = alloc.subscope_allocator()
+        mls = list(d_in)
+        pre = True
+        running = claim
+        for r in range(n_vars):
+            rem = n_vars - r
+            if reducer is None:
+                evals = calculate_round_evals(hal, rem, [1], mls, [expr])
+            else:
+                evals = reducer.round_evals(rem, mls, expr)
+            coeffs = calculate_round_coeffs_from_evals(running, evals)
+            z = challenges[r]
+            running = evaluate_univariate(coeffs, z)
+            nxt = []
+            for ml in mls:
+                e0, e1 = ml.split_half()
+                if pre:
+                    f = scope.alloc(e0.len)
+                    hal.copy_d2d(e0, f)
+                    e0 = f
+                hal.extrapolate_line(e0, e1, z)
+                nxt.append(e0)
+            mls = nxt
+            pre = False
+        return running, mls
+
+    # the claimed sum (not timed): inner product on the device, combined across ranks
+    claim = hal.inner_product(d_in[0], 7, d_in[1])
+    if reducer is not None:
+        claim = reducer.xor_scalars([claim])[0]
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_sumcheck(claim)
+    barrier()
+    hal.prof_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        running, final = one_sumcheck(claim)
+    barrier()
+    t1 = time.perf_counter()
+    prof = hal.prof_end()
+    elapsed = t1 - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # correctness of what was timed (N = 1: the sumcheck verifier's final check, on the device values)
+    ok = True
+    if world == 1:
+        fa = hal.copy_d2h(final[0])
+        fb = hal.copy_d2h(final[1])
+        ia = int(fa[0, 0]) | (int(fa[0, 1]) << 64)
+        ib = int(fb[0, 0]) | (int(fb[0, 1]) << 64)
+        ok = F.mul(ia, ib) == running
+
+    total_elems = m * n * world
+    value = total_elems * args.steps / elapsed
+    ms_per_step = elapsed * 1e3 / args.steps
+
+    # ---- roofline of the dominant kernel, from hipEvent pairs recorded around every launch in the timed region
+    # algorithmic bytes: round-eval at r remaining vars reads 16*m*2^r;
+    # one fold launch at r reads 16*2^r and writes 8*2^r = 24*2^r.
+    re_bytes = sum(16 * m * (1 << r) for r in range(1, n_vars + 1)) * args.steps
+    fold_bytes = sum(24 * (1 << r) for r in range(1, n_vars + 1)) * m * args.steps
+    re_ms, re_cnt = prof["round_eval"]
+    fo_ms, fo_cnt = prof["fold"]
+    kernels = {
+        "k_bs_prodsum(round_eval)": (re_bytes, re_ms, re_cnt),
+        "k_extrapolate_line(fold)": (fold_bytes, fo_ms, fo_cnt),
+    }
+    dom = max(kernels, key=lambda k: kernels[k][1])
+    b, ms, cnt = kernels[dom]
+    achieved = b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    roofline = {
+        "bound": "hbm",
+        "kernel": dom,
+        "achieved": round(achieved, 2),
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4),
+        "traffic": None,
+        "launches": cnt,
+        "avg_launch_ms": round(ms / cnt, 5) if cnt else None,
+        "algorithmic_bytes_per_launch": b // cnt if cnt else None,
+    }
+    per_kernel = {
+        k: {
+            "GBps": round(v[0] / (v[1] * 1e-3) / 1e9, 2) if v[1] > 0 else None,
+            "frac": round(v[0] / (v[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if v[1] > 0 else None,
+            "total_ms": round(v[1], 3),
+            "launches": v[2],
+        }
+        for k, v in kernels.items()
+    }
+
+    out = {
+        "metric": "GF(2^128) sumcheck-fold elems/sec + achieved HBM GB/s (% of roofline)",
+        "value": value,
+        "unit": "elems/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "gf2^128 (u128 bitwise)",
+        "data": "synthetic",
+        "config": {
+            "workload": "2^%d-var GF(2^128) bivariate-product sumcheck: round-eval + fold every round, m=2 multilinears per GPU"
+            % n_vars,
+            "n_vars_local": n_vars,
+            "n_vars_global": n_vars + log_world,
+            "multilinears": m,
+            "sharding": "low index bits (last-bound variables), one 32-byte RCCL all_gather per round" if world > 1 else "none",
+        },
+        "bit_exact_check": bool(ok),
+        "roofline": roofline,
+        "kernels": per_kernel,
+    }
+
+    # ---- CPU baseline: the oracle's multi-threaded port of the same loop, bounded sample, rank 0 only
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cores = os.cpu_count() or 1
+        cn = args.cpu_n_vars or 18
+        while True:
+            mls = [oracle.random_b128(0xB1A50000 + j, 1 << cn) for j in range(m)]
+            rc, cclaim = oracle.inner_product(mls[0], 7, mls[1])
+            c0 = time.perf_counter()
+            oracle.bivariate_sumcheck_prove(mls, cn, [(0, 1)], [cclaim], batch_coeff, challenges[:cn], threads=cores)
+            dt = time.perf_counter() - c0
+            if args.cpu_n_vars or dt > 4.0 or cn >= 24:
+                break
+            cn += 2 if dt < 1.0 else 1
+        out["cpu_baseline"] = {
+            "value": m * (1 << cn) / dt,
+            "unit": "elems/s",
+            "cores": cores,
+            "kind": "port",
+            "sample": "same sumcheck loop (round-eval + fold every round), m=2, n_vars=%d, oracle C port, %d threads, %.2f s"
+            % (cn, cores, dt),
+        }
+
+    if rank == 0:
+        print(json.dumps(out))
+    hal.close()
+    if dist is not None:
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,22 @@
+"""binius_amd -- MI355X (gfx950) compute backend for the Binius prover hot path.
+
+This package is only the Python-side plumbing (ctypes binding of the C ABI in
+``include/binius_amd.h`` plus small mirrors of the reference's ``ComputeMemory`` /
+``BumpAllocator`` handle types) used by the parity tests, ``bench.py`` and
+``__graft_entry__.py``.  The product is ``libbinius_amd.so``: hand-written HIP kernels behind an
+``extern "C"`` boundary.  There is NO CPU fallback: if the shared library is missing or no GPU is
+visible, loading / context creation fails loudly.
+"""
+from ._ffi import (  # noqa: F401
+    BN_OK,
+    BnError,
+    Context,
+    DevSlice,
+    BumpAllocator,
+    Expr,
+    HostField,
+    lib,
+    lib_path,
+    log_chunks_range,
+    ntt_s_evals,
+)

@@ -1,0 +1,581 @@
+"""ctypes binding of include/binius_amd.h + Python mirrors of the reference's handle types.
+
+Mirrors (names and argument meaning follow the reference so the parity tests read like
+crates/compute_test_utils/src/layer.rs):
+
+  DevSlice        ComputeMemory::FSlice / FSliceMut handle (crates/compute/src/memory.rs:69-234),
+                  ALIGNMENT = 1: (device pointer, length); slice / split_at / split_half are O(1)
+                  host arithmetic, no device calls.
+  BumpAllocator   crates/compute/src/alloc.rs:31-105
+  Context         ComputeLayer + ComputeLayerExecutor (crates/compute/src/layer.rs:22, 100)
+  KernelExec      recording KernelExecutor (layer.rs:518-590): the kernel-spec closure is run once
+                  and its ops are handed to bn_kernel_launch.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+BN_OK, BN_ERR_INPUT_VALIDATION, BN_ERR_ALLOC, BN_ERR_DEVICE, BN_ERR_CORE_LIB = range(5)
+_ERR_NAMES = {1: "InputValidation", 2: "Alloc", 3: "DeviceError", 4: "CoreLibError"}
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libbinius_amd.so")
+MASK64 = (1 << 64) - 1
+NTT_MAX_DIM = 64
+
+
+def lib_path():
+    return _SO
+
+
+class BnError(RuntimeError):
+    """binius_compute::Error (crates/compute/src/layer.rs:706-716)."""
+
+    def __init__(self, code, msg):
+        super().__init__("%s: %s" % (_ERR_NAMES.get(code, code), msg))
+        self.code = code
+        self.kind = _ERR_NAMES.get(code, str(code))
+
+
+class F128(C.Structure):
+    _fields_ = [("lo", C.c_uint64), ("hi", C.c_uint64)]
+
+
+class Step(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("a", C.c_uint32), ("b", C.c_uint64), ("cst", F128)]
+
+
+class MemMap(C.Structure):
+    _fields_ = [
+        ("kind", C.c_uint32),
+        ("log_min_chunk_size", C.c_uint32),
+        ("d_data", C.c_void_p),
+        ("len", C.c_uint64),
+        ("log_size", C.c_uint32),
+    ]
+
+
+class KSlice(C.Structure):
+    _fields_ = [("buf", C.c_uint32), ("off", C.c_uint64), ("len", C.c_uint64)]
+
+
+class KOp(C.Structure):
+    _fields_ = [
+        ("kind", C.c_uint32),
+        ("value", C.c_uint32),
+        ("scalar", F128),
+        ("expr", C.c_void_p),
+        ("n_rows", C.c_uint32),
+        ("rows", C.POINTER(KSlice)),
+        ("src1", KSlice),
+        ("src2", KSlice),
+        ("dst", KSlice),
+    ]
+
+
+STEP_KINDS = {"add": 0, "mul": 1, "pow": 2, "const": 3, "var": 4}
+MAP_CHUNKED, MAP_CHUNKED_MUT, MAP_LOCAL = range(3)
+KOP_DECL_VALUE, KOP_SUM_COMPOSITION, KOP_ADD, KOP_ADD_ASSIGN = range(4)
+
+_lib = None
+
+
+def lib():
+    """Load libbinius_amd.so.  Fails loudly when it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_SO):
+        raise ImportError(
+            "binius_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % _SO
+        )
+    L = C.CDLL(_SO)
+    vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
+    PF = C.POINTER(F128)
+    sig = {
+        "bn_ctx_create": [i32, u64, C.POINTER(vp)],
+        "bn_ctx_destroy": [vp],
+        "bn_arena_base": [vp, C.POINTER(vp), C.POINTER(u64)],
+        "bn_ctx_set_stream": [vp, vp],
+        "bn_sync": [vp],
+        "bn_copy_h2d": [vp, vp, u64, vp, u64],
+        "bn_copy_d2h": [vp, vp, u64, vp, u64],
+        "bn_copy_d2d": [vp, vp, u64, vp, u64],
+        "bn_fill": [vp, vp, u64, PF],
+        "bn_expr_compile": [vp, C.POINTER(Step), u64, C.POINTER(vp)],
+        "bn_expr_free": [vp],
+        "bn_expr_n_vars": [vp, C.POINTER(u32)],
+        "bn_extrapolate_line": [vp, vp, u64, vp, u64, PF],
+        "bn_tensor_expand": [vp, vp, u64, u32, PF, u32],
+        "bn_inner_product": [vp, vp, u64, u32, vp, u64, PF],
+        "bn_fold_left": [vp, vp, u64, u32, vp, u64, vp, u64],
+        "bn_fold_right": [vp, vp, u64, u32, vp, u64, vp, u64],
+        "bn_fri_fold": [vp, C.POINTER(u64), u32, u32, u32, u32, PF, u32, vp, u64, vp, u64],
+        "bn_compute_composite": [vp, C.POINTER(vp), u32, u64, vp, u64, vp],
+        "bn_pairwise_product_reduce": [vp, vp, u64, C.POINTER(vp), C.POINTER(u64), u32],
+        "bn_log_chunks_range": [C.POINTER(MemMap), u32, C.POINTER(u32), C.POINTER(u32)],
+        "bn_pick_log_chunks": [C.POINTER(MemMap), u32, C.POINTER(u32)],
+        "bn_kernel_launch": [vp, C.POINTER(MemMap), u32, C.POINTER(KOp), u32, C.POINTER(u32), u32, u32, PF, vp],
+        "bn_ntt_forward": [vp, vp, u32, u32, C.POINTER(u64), u32, u32, u32, u32, u64, u32, u32],
+        "bn_ntt_inverse": [vp, vp, u32, u32, C.POINTER(u64), u32, u32, u32, u32, u64, u32, u32],
+        "bn_ntt_s_evals": [u32, u32, C.POINTER(u64)],
+        "bn_scalar_mul": [PF, PF, PF],
+        "bn_scalar_invert": [PF, PF],
+        "bn_prof_begin": [vp],
+        "bn_prof_end": [vp, C.POINTER(C.c_double), C.POINTER(u64)],
+        "bn_timer_begin": [vp],
+        "bn_timer_end_ms": [vp, C.POINTER(C.c_float)],
+    }
+    for name, args in sig.items():
+        fn = getattr(L, name)  # AttributeError here == the .so does not export a declared symbol
+        fn.argtypes = args
+        fn.restype = C.c_int
+    L.bn_last_error.restype = C.c_char_p
+    L.bn_version.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+ABI_SYMBOLS = [
+    "bn_last_error", "bn_version", "bn_ctx_create", "bn_ctx_destroy", "bn_arena_base", "bn_ctx_set_stream", "bn_sync",
+    "bn_copy_h2d", "bn_copy_d2h", "bn_copy_d2d", "bn_fill", "bn_expr_compile", "bn_expr_free", "bn_expr_n_vars",
+    "bn_extrapolate_line", "bn_tensor_expand", "bn_inner_product", "bn_fold_left", "bn_fold_right", "bn_fri_fold",
+    "bn_compute_composite", "bn_pairwise_product_reduce", "bn_log_chunks_range", "bn_pick_log_chunks",
+    "bn_kernel_launch", "bn_ntt_forward", "bn_ntt_inverse", "bn_ntt_s_evals", "bn_scalar_mul", "bn_scalar_invert",
+    "bn_timer_begin", "bn_timer_end_ms", "bn_prof_begin", "bn_prof_end",
+]
+
+
+def _check(rc):
+    if rc != BN_OK:
+        raise BnError(rc, lib().bn_last_error().decode())
+
+
+def to_f128(x):
+    x = int(x)
+    return F128(x & MASK64, (x >> 64) & MASK64)
+
+
+def from_f128(f):
+    return int(f.lo) | (int(f.hi) << 64)
+
+
+def _f128_array(vals):
+    arr = (F128 * max(1, len(vals)))()
+    for i, v in enumerate(vals):
+        arr[i] = to_f128(v)
+    return arr
+
+
+def make_steps(steps):
+    out = (Step * max(1, len(steps)))()
+    for i, s in enumerate(steps):
+        k = STEP_KINDS[s[0]]
+        out[i].kind = k
+        if k in (0, 1, 2):
+            out[i].a, out[i].b = s[1], s[2]
+        elif k == 3:
+            out[i].cst = to_f128(s[1])
+        else:
+            out[i].a = s[1]
+    return out
+
+
+class HostField:
+    """O(1)-per-round protocol scalars on the host (bn_scalar_mul / bn_scalar_invert)."""
+
+    @staticmethod
+    def mul(a, b):
+        x, y, o = to_f128(a), to_f128(b), F128()
+        _check(lib().bn_scalar_mul(C.byref(x), C.byref(y), C.byref(o)))
+        return from_f128(o)
+
+    @staticmethod
+    def invert(a):
+        x, o = to_f128(a), F128()
+        _check(lib().bn_scalar_invert(C.byref(x), C.byref(o)))
+        return from_f128(o)
+
+
+# ------------------------------------------------------------------ memory handles
+class DevSlice:
+    """Opaque handle to a slice of F in device memory: (pointer, len).  ALIGNMENT = 1."""
+
+    ALIGNMENT = 1
+    __slots__ = ("ptr", "len")
+
+    def __init__(self, ptr, length):
+        self.ptr = int(ptr)
+        self.len = int(length)
+
+    def __len__(self):
+        return self.len
+
+    def __repr__(self):
+        return "DevSlice(0x%x, len=%d)" % (self.ptr, self.len)
+
+    def slice(self, start=0, end=None):
+        end = self.len if end is None else end
+        assert 0 <= start <= end <= self.len, "slice out of range"
+        return DevSlice(self.ptr + 16 * start, end - start)
+
+    def split_at(self, mid):
+        return self.slice(0, mid), self.slice(mid, self.len)
+
+    def split_half(self):
+        assert self.len > 1 and (self.len & (self.len - 1)) == 0, "data length must be a power of two greater than 1"
+        return self.split_at(self.len // 2)
+
+    def chunks(self, chunk_len):
+        assert self.len % chunk_len == 0
+        return [self.slice(i, i + chunk_len) for i in range(0, self.len, chunk_len)]
+
+
+class BumpAllocator:
+    """crates/compute/src/alloc.rs:31-105 over a DevSlice (or another allocator's remainder)."""
+
+    def __init__(self, buffer):
+        self._buf = buffer
+
+    def alloc(self, n):
+        if self._buf.len < n:
+            raise BnError(BN_ERR_ALLOC, "allocator is out of memory")
+        lhs, rhs = self._buf.split_at(n)
+        self._buf = rhs
+        return lhs
+
+    def capacity(self):
+        return self._buf.len
+
+    def subscope_allocator(self):
+        return BumpAllocator(self._buf.slice())
+
+
+class Expr:
+    """ExprEval: handle returned by compile_expr (layer.rs:57)."""
+
+    def __init__(self, handle, steps):
+        self.handle = handle
+        self.steps = list(steps)
+
+    def n_vars(self):
+        n = C.c_uint32()
+        _check(lib().bn_expr_n_vars(self.handle, C.byref(n)))
+        return n.value
+
+    def free(self):
+        if self.handle:
+            lib().bn_expr_free(self.handle)
+            self.handle = None
+
+
+# ------------------------------------------------------------------ recording KernelExecutor
+class KernelBuffer:
+    """KernelBuffer::{Ref,Mut} (layer.rs:682-704): a chunk-relative view of mapped buffer `buf`."""
+
+    __slots__ = ("buf", "off", "len", "mutable")
+
+    def __init__(self, buf, off, length, mutable):
+        self.buf, self.off, self.len, self.mutable = buf, off, length, mutable
+
+    def __len__(self):
+        return self.len
+
+    def to_ref(self):
+        return KernelBuffer(self.buf, self.off, self.len, False)
+
+    def slice(self, start=0, end=None):
+        end = self.len if end is None else end
+        assert 0 <= start <= end <= self.len
+        return KernelBuffer(self.buf, self.off + start, end - start, self.mutable)
+
+    def triple(self):
+        return (self.buf, self.off, self.len)
+
+
+class KernelValue:
+    __slots__ = ("id",)
+
+    def __init__(self, vid):
+        self.id = vid
+
+
+class KernelExec:
+    """Recording KernelExecutor: collects the ops the kernel-spec closure issues."""
+
+    def __init__(self):
+        self.ops = []
+        self.n_values = 0
+
+    def decl_value(self, init):
+        v = KernelValue(self.n_values)
+        self.n_values += 1
+        self.ops.append({"op": "decl", "value": v.id, "init": int(init)})
+        return v
+
+    def sum_composition_evals(self, inputs, composition, batch_coeff, accumulator):
+        row_len = len(inputs[0]) if inputs else 0
+        for r in inputs:
+            assert len(r) == row_len  # SlicesBatch::new (memory.rs:39-45)
+        self.ops.append(
+            {"op": "sum", "value": accumulator.id, "expr": composition, "coeff": int(batch_coeff), "rows": [r.triple() for r in inputs]}
+        )
+
+    def add(self, log_len, src1, src2, dst):
+        assert len(src1) == 1 << log_len and len(src2) == 1 << log_len and len(dst) == 1 << log_len
+        assert dst.mutable
+        self.ops.append({"op": "add", "src1": src1.triple(), "src2": src2.triple(), "dst": dst.triple()})
+
+    def add_assign(self, log_len, src, dst):
+        assert len(src) == 1 << log_len and len(dst) == 1 << log_len
+        assert dst.mutable
+        self.ops.append({"op": "add_assign", "src": src.triple(), "dst": dst.triple()})
+
+
+def _make_maps(mem_maps):
+    mm = (MemMap * max(1, len(mem_maps)))()
+    for i, m in enumerate(mem_maps):
+        if m[0] == "local":
+            mm[i].kind = MAP_LOCAL
+            mm[i].log_size = m[1]
+        else:
+            mm[i].kind = MAP_CHUNKED if m[0] == "chunked" else MAP_CHUNKED_MUT
+            mm[i].d_data = m[1].ptr
+            mm[i].len = m[1].len
+            mm[i].log_min_chunk_size = m[2]
+    return mm
+
+
+def log_chunks_range(mem_maps):
+    """KernelMemMap::log_chunks_range (layer.rs:617-644). Host only."""
+    mm = _make_maps(mem_maps)
+    s, e = C.c_uint32(), C.c_uint32()
+    _check(lib().bn_log_chunks_range(mm, len(mem_maps), C.byref(s), C.byref(e)))
+    return range(s.value, e.value)
+
+
+def ntt_s_evals(tw_level, log_domain):
+    """OnTheFlyTwiddleAccess::generate for the canonical subspace. Host only."""
+    s = np.zeros(NTT_MAX_DIM * NTT_MAX_DIM, dtype=np.uint64)
+    _check(lib().bn_ntt_s_evals(tw_level, log_domain, s.ctypes.data_as(C.POINTER(C.c_uint64))))
+    return s
+
+
+# ------------------------------------------------------------------ the layer
+class Context:
+    """ComputeLayer + executor over one GPU.  `arena_elems` F elements of device memory are
+    allocated up front (like FastCpuLayerHolder::new(host, dev)); `dev_alloc()` bump-allocates."""
+
+    def __init__(self, device=0, arena_elems=0):
+        self._h = C.c_void_p()
+        _check(lib().bn_ctx_create(device, arena_elems, C.byref(self._h)))
+        self.device = device
+        base, n = C.c_void_p(), C.c_uint64()
+        _check(lib().bn_arena_base(self._h, C.byref(base), C.byref(n)))
+        self.arena = DevSlice(base.value or 0, n.value)
+        self._exprs = []
+
+    def close(self):
+        if self._h:
+            for e in self._exprs:
+                e.free()
+            lib().bn_ctx_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def dev_alloc(self):
+        return BumpAllocator(self.arena.slice())
+
+    def set_stream(self, hip_stream):
+        _check(lib().bn_ctx_set_stream(self._h, hip_stream))
+
+    def sync(self):
+        _check(lib().bn_sync(self._h))
+
+    def timer_begin(self):
+        _check(lib().bn_timer_begin(self._h))
+
+    def timer_end_ms(self):
+        ms = C.c_float()
+        _check(lib().bn_timer_end_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    PROF_CLASSES = ("round_eval", "fold", "tensor_expand", "ntt", "other")
+
+    def prof_begin(self):
+        _check(lib().bn_prof_begin(self._h))
+
+    def prof_end(self):
+        ms = (C.c_double * 5)()
+        cnt = (C.c_uint64 * 5)()
+        _check(lib().bn_prof_end(self._h, ms, cnt))
+        return {k: (ms[i], int(cnt[i])) for i, k in enumerate(self.PROF_CLASSES)}
+
+    # ---- ComputeLayer
+    def copy_h2d(self, src, dst):
+        """src: numpy uint64 array of shape (n, 2)."""
+        src = np.ascontiguousarray(src, dtype=np.uint64).reshape(-1, 2)
+        _check(lib().bn_copy_h2d(self._h, src.ctypes.data, src.shape[0], dst.ptr, dst.len))
+
+    def copy_d2h(self, src, dst=None):
+        if dst is None:
+            dst = np.zeros((src.len, 2), dtype=np.uint64)
+        assert dst.dtype == np.uint64 and dst.flags["C_CONTIGUOUS"]
+        _check(lib().bn_copy_d2h(self._h, src.ptr, src.len, dst.ctypes.data, dst.reshape(-1, 2).shape[0]))
+        return dst
+
+    def copy_d2d(self, src, dst):
+        _check(lib().bn_copy_d2d(self._h, src.ptr, src.len, dst.ptr, dst.len))
+
+    def fill(self, slice_, value):
+        v = to_f128(value)
+        _check(lib().bn_fill(self._h, slice_.ptr, slice_.len, C.byref(v)))
+
+    def compile_expr(self, steps):
+        st = make_steps(steps)
+        h = C.c_void_p()
+        _check(lib().bn_expr_compile(self._h, st, len(steps), C.byref(h)))
+        e = Expr(h, steps)
+        self._exprs.append(e)
+        return e
+
+    # ---- ComputeLayerExecutor
+    def extrapolate_line(self, evals_0, evals_1, z):
+        zz = to_f128(z)
+        _check(lib().bn_extrapolate_line(self._h, evals_0.ptr, evals_0.len, evals_1.ptr, evals_1.len, C.byref(zz)))
+
+    def tensor_expand(self, log_n, coordinates, data):
+        c = _f128_array(list(coordinates))
+        _check(lib().bn_tensor_expand(self._h, data.ptr, data.len, log_n, c, len(coordinates)))
+
+    def inner_product(self, a_in, tower_level, b_in):
+        out = F128()
+        _check(lib().bn_inner_product(self._h, a_in.ptr, a_in.len, tower_level, b_in.ptr, b_in.len, C.byref(out)))
+        return from_f128(out)
+
+    def fold_left(self, mat, tower_level, vec, out):
+        _check(lib().bn_fold_left(self._h, mat.ptr, mat.len, tower_level, vec.ptr, vec.len, out.ptr, out.len))
+
+    def fold_right(self, mat, tower_level, vec, out):
+        _check(lib().bn_fold_right(self._h, mat.ptr, mat.len, tower_level, vec.ptr, vec.len, out.ptr, out.len))
+
+    def fri_fold(self, s_evals, tw_level, log_domain, log_len, log_batch_size, challenges, data_in, data_out):
+        ch = _f128_array(list(challenges))
+        _check(
+            lib().bn_fri_fold(
+                self._h, s_evals.ctypes.data_as(C.POINTER(C.c_uint64)), tw_level, log_domain, log_len, log_batch_size,
+                ch, len(challenges), data_in.ptr, data_in.len, data_out.ptr, data_out.len,
+            )
+        )
+
+    def compute_composite(self, inputs, output, composition):
+        rows = (C.c_void_p * max(1, len(inputs)))(*[r.ptr for r in inputs])
+        row_len = inputs[0].len if inputs else 0
+        for r in inputs:
+            assert r.len == row_len  # SlicesBatch::new
+        _check(lib().bn_compute_composite(self._h, rows, len(inputs), row_len, output.ptr, output.len, composition.handle))
+
+    def pairwise_product_reduce(self, inp, round_outputs):
+        outs = (C.c_void_p * max(1, len(round_outputs)))(*[r.ptr for r in round_outputs])
+        lens = (C.c_uint64 * max(1, len(round_outputs)))(*[r.len for r in round_outputs])
+        _check(lib().bn_pairwise_product_reduce(self._h, inp.ptr, inp.len, outs, lens, len(round_outputs)))
+
+    # ---- accumulate_kernels / map_kernels
+    def pick_log_chunks(self, mem_maps):
+        mm = _make_maps(mem_maps)
+        lc = C.c_uint32()
+        _check(lib().bn_pick_log_chunks(mm, len(mem_maps), C.byref(lc)))
+        return lc.value
+
+    def record(self, map_fn, mem_maps):
+        """Run the kernel-spec closure once against the recording executor."""
+        log_chunks = self.pick_log_chunks(mem_maps)
+        buffers = []
+        for i, m in enumerate(mem_maps):
+            if m[0] == "local":
+                buffers.append(KernelBuffer(i, 0, (1 << m[1]) >> log_chunks, True))
+            else:
+                buffers.append(KernelBuffer(i, 0, m[1].len >> log_chunks, m[0] == "chunked_mut"))
+        ke = KernelExec()
+        rets = map_fn(ke, log_chunks, buffers)
+        return ke.ops, [v.id for v in (rets or [])], log_chunks
+
+    def kernel_launch(self, mem_maps, ops, ret_ids, log_chunks, d_out=None, want_host=True):
+        mm = _make_maps(mem_maps)
+        kops = (KOp * max(1, len(ops)))()
+        keep = []
+        for i, o in enumerate(ops):
+            if o["op"] == "decl":
+                kops[i].kind = KOP_DECL_VALUE
+                kops[i].value = o["value"]
+                kops[i].scalar = to_f128(o["init"])
+            elif o["op"] == "sum":
+                kops[i].kind = KOP_SUM_COMPOSITION
+                kops[i].value = o["value"]
+                kops[i].scalar = to_f128(o["coeff"])
+                kops[i].expr = o["expr"].handle
+                rows = (KSlice * max(1, len(o["rows"])))(*[KSlice(*r) for r in o["rows"]])
+                keep.append(rows)
+                kops[i].rows = rows
+                kops[i].n_rows = len(o["rows"])
+            elif o["op"] == "add":
+                kops[i].kind = KOP_ADD
+                kops[i].src1, kops[i].src2, kops[i].dst = KSlice(*o["src1"]), KSlice(*o["src2"]), KSlice(*o["dst"])
+            else:
+                kops[i].kind = KOP_ADD_ASSIGN
+                kops[i].src1, kops[i].dst = KSlice(*o["src"]), KSlice(*o["dst"])
+        rv = (C.c_uint32 * max(1, len(ret_ids)))(*ret_ids)
+        h_out = (F128 * max(1, len(ret_ids)))()
+        _check(
+            lib().bn_kernel_launch(
+                self._h, mm, len(mem_maps), kops, len(ops), rv, len(ret_ids), log_chunks,
+                h_out if (want_host and ret_ids) else None, d_out,
+            )
+        )
+        return [from_f128(h_out[i]) for i in range(len(ret_ids))] if want_host else None
+
+    def accumulate_kernels(self, map_fn, mem_maps):
+        ops, ret_ids, log_chunks = self.record(map_fn, mem_maps)
+        return self.kernel_launch(mem_maps, ops, ret_ids, log_chunks)
+
+    def map_kernels(self, map_fn, mem_maps):
+        ops, _rets, log_chunks = self.record(map_fn, mem_maps)
+        self.kernel_launch(mem_maps, ops, [], log_chunks)
+
+    # ---- AdditiveNTT
+    def ntt_forward(self, data_ptr, elem_level, tw_level, s_evals, log_domain, log_x, log_y, log_z, coset=0, coset_bits=0, skip_rounds=0):
+        _check(
+            lib().bn_ntt_forward(
+                self._h, data_ptr, elem_level, tw_level, s_evals.ctypes.data_as(C.POINTER(C.c_uint64)), log_domain,
+                log_x, log_y, log_z, coset, coset_bits, skip_rounds,
+            )
+        )
+
+    def ntt_inverse(self, data_ptr, elem_level, tw_level, s_evals, log_domain, log_x, log_y, log_z, coset=0, coset_bits=0, skip_rounds=0):
+        _check(
+            lib().bn_ntt_inverse(
+                self._h, data_ptr, elem_level, tw_level, s_evals.ctypes.data_as(C.POINTER(C.c_uint64)), log_domain,
+                log_x, log_y, log_z, coset, coset_bits, skip_rounds,
+            )
+        )
+
+    # raw byte copies for non-F128 NTT data
+    def copy_bytes_h2d(self, src_np, dst_ptr):
+        n16 = (src_np.nbytes + 15) // 16
+        buf = np.zeros(n16 * 2, dtype=np.uint64)
+        buf.view(np.uint8)[: src_np.nbytes] = src_np.view(np.uint8).reshape(-1)
+        _check(lib().bn_copy_h2d(self._h, buf.ctypes.data, n16, dst_ptr, n16))
+
+    def copy_bytes_d2h(self, src_ptr, dst_np):
+        n16 = (dst_np.nbytes + 15) // 16
+        buf = np.zeros(n16 * 2, dtype=np.uint64)
+        _check(lib().bn_copy_d2h(self._h, src_ptr, n16, buf.ctypes.data, n16))
+        dst_np.view(np.uint8).reshape(-1)[:] = buf.view(np.uint8)[: dst_np.nbytes]
+        return dst_np

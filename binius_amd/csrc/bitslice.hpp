@@ -1,0 +1,130 @@
+// binius_amd/csrc/bitslice.hpp -- bit-sliced binary-tower arithmetic for gfx950 wavefronts.
+//
+// A "plane set" of level K is 2^K 32-bit registers per lane; register p holds bit p of 32
+// independent field elements (one element per bit position).  AND/XOR on registers then act on 32
+// elements at once, which is the only way to get variable x variable GF(2^128) products onto a GPU
+// with no carry-less multiply: the tower recursion of
+// crates/field/src/arch/portable/pairwise_recursive_arithmetic.rs:18-28 becomes ~13k AND/XOR per
+// 32 products (v_bitop3_b32 fuses AND+XOR pairs), i.e. ~400 VALU lane-ops per product instead of
+// the ~6000 of any word-level formulation.
+//
+// Bit positions inside a register are opaque to the arithmetic, so a register may equally hold
+// two 16-element groups (low / high half) that are multiplied "in parallel" -- the round-eval
+// kernel packs the evaluation-at-1 operands in the low half and the evaluation-at-infinity
+// operands in the high half.
+#pragma once
+#include <stdint.h>
+
+#include "gf128.hpp"
+
+namespace bn {
+
+// ---- 32x32 bit-matrix transpose, in registers --------------------------------------------------
+// in : r[e] = 32-bit word of element e            (row e, column = bit index)
+// out: r[p] = plane p, bit e = bit p of element e
+__device__ __forceinline__ void transpose32(uint32_t (&r)[32])
+{
+#pragma unroll
+	for (int k = 0; k < 16; k++) { // j = 16: halves are whole 16-bit lanes -> v_perm_b32 / v_alignbit
+		uint32_t a = r[k], b = r[k + 16];
+		r[k] = (a & 0x0000FFFFu) | (b << 16);
+		r[k + 16] = (a >> 16) | (b & 0xFFFF0000u);
+	}
+#pragma unroll
+	for (int k = 0; k < 32; k++) {
+		if (k & 8) continue;
+		uint32_t a = r[k], b = r[k + 8];
+		r[k] = (a & 0x00FF00FFu) | ((b << 8) & 0xFF00FF00u);
+		r[k + 8] = ((a >> 8) & 0x00FF00FFu) | (b & 0xFF00FF00u);
+	}
+#pragma unroll
+	for (int k = 0; k < 32; k++) {
+		if (k & 4) continue;
+		uint32_t a = r[k], b = r[k + 4];
+		r[k] = (a & 0x0F0F0F0Fu) | ((b << 4) & 0xF0F0F0F0u);
+		r[k + 4] = ((a >> 4) & 0x0F0F0F0Fu) | (b & 0xF0F0F0F0u);
+	}
+#pragma unroll
+	for (int k = 0; k < 32; k++) {
+		if (k & 2) continue;
+		uint32_t a = r[k], b = r[k + 2];
+		r[k] = (a & 0x33333333u) | ((b << 2) & 0xCCCCCCCCu);
+		r[k + 2] = ((a >> 2) & 0x33333333u) | (b & 0xCCCCCCCCu);
+	}
+#pragma unroll
+	for (int k = 0; k < 32; k++) {
+		if (k & 1) continue;
+		uint32_t a = r[k], b = r[k + 1];
+		r[k] = (a & 0x55555555u) | ((b << 1) & 0xAAAAAAAAu);
+		r[k + 1] = ((a >> 1) & 0x55555555u) | (b & 0xAAAAAAAAu);
+	}
+}
+
+// ---- bit-sliced tower arithmetic ---------------------------------------------------------------
+// All functions take pointers into register arrays; after full unrolling every index is a
+// compile-time constant, so nothing touches scratch.
+
+// t = a * X_{K-1} for a level-K plane set: (a0, a1) -> (a1, a0 + a1 * X_{K-2})   (mul_alpha,
+// pairwise_recursive_arithmetic.rs:54-60).  Pure XOR / renaming.  out must not alias a.
+template <int K>
+__device__ __forceinline__ void bs_mul_alpha(const uint32_t *a, uint32_t *out)
+{
+	if constexpr (K == 0) {
+		out[0] = a[0];
+	} else {
+		constexpr int H = 1 << (K - 1);
+		uint32_t t[H];
+		bs_mul_alpha<K - 1>(a + H, t);
+#pragma unroll
+		for (int i = 0; i < H; i++) {
+			out[i] = a[H + i];
+			out[H + i] = a[i] ^ t[i];
+		}
+	}
+}
+
+// out = a * b, level K (2^K planes each).  out must not alias a or b.
+template <int K>
+__device__ __forceinline__ void bs_mul(const uint32_t *a, const uint32_t *b, uint32_t *out)
+{
+	if constexpr (K == 0) {
+		out[0] = a[0] & b[0];
+	} else if constexpr (K == 1) {
+		// GF(4): lo = a0b0 ^ a1b1 ; hi = (a0^a1)(b0^b1) ^ a0b0      (alpha_0 = 1)
+		uint32_t z0 = a[0] & b[0];
+		out[0] = (a[1] & b[1]) ^ z0;
+		out[1] = ((a[0] ^ a[1]) & (b[0] ^ b[1])) ^ z0;
+	} else {
+		constexpr int H = 1 << (K - 1);
+		uint32_t z0[H], z2[H], z1[H], sa[H], sb[H], za[H];
+		bs_mul<K - 1>(a, b, z0);
+		bs_mul<K - 1>(a + H, b + H, z2);
+#pragma unroll
+		for (int i = 0; i < H; i++) {
+			sa[i] = a[i] ^ a[H + i];
+			sb[i] = b[i] ^ b[H + i];
+		}
+		bs_mul<K - 1>(sa, sb, z1);
+		bs_mul_alpha<K - 1>(z2, za);
+#pragma unroll
+		for (int i = 0; i < H; i++) {
+			uint32_t lo = z0[i] ^ z2[i];
+			out[i] = lo;
+			out[H + i] = z1[i] ^ lo ^ za[i];
+		}
+	}
+}
+
+// acc ^= a * b at level K, where acc has 2^K planes.
+template <int K>
+__device__ __forceinline__ void bs_mac(const uint32_t *a, const uint32_t *b, uint32_t *acc)
+{
+	constexpr int N = 1 << K;
+	uint32_t p[N];
+	bs_mul<K>(a, b, p);
+#pragma unroll
+	for (int i = 0; i < N; i++)
+		acc[i] ^= p[i];
+}
+
+} // namespace bn

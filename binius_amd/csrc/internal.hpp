@@ -1,0 +1,120 @@
+// binius_amd/csrc/internal.hpp -- declarations shared between the C-ABI layer (abi.cpp) and the
+// kernel translation units.  Not part of the public interface.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/binius_amd.h"
+#include "gf128.hpp"
+
+struct bn_expr {
+	std::vector<bn_step> steps;
+	uint32_t n_vars = 0;
+	// classification for the specialised kernels
+	enum Shape { GENERIC = 0, PRODUCT = 1 } shape = GENERIC;
+	std::vector<uint32_t> product_vars; // PRODUCT: var indices multiplied together (in order)
+	bn_step *d_steps = nullptr;         // device copy for the interpreter kernels
+	int device = 0;
+};
+
+struct bn_ctx {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	bool own_stream = false;
+	void *arena = nullptr;
+	uint64_t arena_elems = 0;
+	// device scratch owned by the context (partials of reductions, Local kernel buffers, ...)
+	void *scratch = nullptr;
+	size_t scratch_bytes = 0;
+	bn::f128 *d_result = nullptr; // small result mailbox (256 elements)
+	bn::f128 *h_result = nullptr; // pinned host mirror
+	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	int n_cu = 256;
+	// per-class kernel timing (bn_prof_begin / bn_prof_end)
+	bool prof_on = false;
+	struct prof_rec {
+		int cls;
+		hipEvent_t a, b;
+	};
+	std::vector<prof_rec> prof;
+	std::vector<hipEvent_t> ev_pool;
+};
+
+namespace bn {
+
+constexpr int kResultSlots = 256;
+
+void set_error(const std::string &msg);
+int fail(int code, const std::string &msg);
+int hip_fail(hipError_t e, const char *what);
+void *ctx_scratch(bn_ctx *ctx, size_t bytes); // grows on demand; nullptr on failure
+
+#define BN_HIP(expr)                                   \
+	do {                                               \
+		hipError_t _e = (expr);                        \
+		if (_e != hipSuccess)                          \
+			return bn::hip_fail(_e, #expr);            \
+	} while (0)
+
+// ---- kernels_stream.hip
+hipError_t launch_fill(hipStream_t s, void *dst, uint64_t n, f128 v);
+hipError_t launch_add_assign(hipStream_t s, void *dst, const void *src, uint64_t n);
+hipError_t launch_add(hipStream_t s, void *dst, const void *src1, const void *src2, uint64_t n);
+hipError_t launch_extrapolate_line(hipStream_t s, int n_cu, void *evals_0, const void *evals_1, uint64_t n, f128 z);
+hipError_t launch_tensor_expand_pass(hipStream_t s, int n_cu, void *data, uint64_t half, f128 r);
+
+// ---- kernels_roundeval.hip
+struct fin_term {
+	uint32_t value;
+	uint32_t slot;
+	f128 coeff;
+};
+// fused round evaluation of a product composition: for factor j, hi[j] are the evaluations at 1;
+// lo[j] != null means the evaluation at infinity is lo[j]+hi[j], lo[j] == null means the factor is
+// the same at both points (e.g. the eq-indicator).  d_out[0] ^= S_1, d_out[1] ^= S_inf (unscaled).
+hipError_t launch_roundeval_product(hipStream_t s, int n_cu, const void *const *hi, const void *const *lo, uint32_t k,
+                                    uint64_t n, f128 *d_out);
+constexpr int kFinMaxTerms = 32, kFinMaxValues = 8, kFinMaxRets = 8;
+// passed BY VALUE as a kernel argument: no host->device staging copy on the per-round path
+struct fin_args {
+	uint32_t n_terms, n_values, n_ret, pad;
+	fin_term terms[kFinMaxTerms];
+	f128 init[kFinMaxValues];
+	uint32_t ret_ids[kFinMaxRets];
+};
+// values[v] = init[v] ^ XOR_t coeff_t * S[slot_t], then rets[i] = values[ret_ids[i]]
+hipError_t launch_finalize(hipStream_t s, const fin_args &args, const f128 *d_S, f128 *d_rets);
+// raw (unscaled) sums S1 = sum_i a[half+i]*b[half+i], Sinf = sum_i (a[i]+a[half+i])*(b[i]+b[half+i])
+// XOR-accumulated into d_out[0], d_out[1] (caller zeroes them first).
+hipError_t launch_roundeval_product2(hipStream_t s, int n_cu, const void *a, const void *b, uint64_t half, f128 *d_out);
+// generic: sum_i C(rows[0][i], ..) over a circuit, XOR-accumulated into d_out[0]
+hipError_t launch_sum_composition_generic(hipStream_t s, int n_cu, const void *const *d_rows_dev, uint32_t n_rows,
+                                          uint64_t row_len, const bn_step *d_steps, uint32_t n_steps, f128 *d_out);
+// elementwise product sum over k rows (k>=1), bit-sliced: d_out[0] ^= sum_i prod_j rows[j][i]
+hipError_t launch_sum_product(hipStream_t s, int n_cu, const void *const *rows, uint32_t n_rows, uint64_t row_len,
+                              f128 *d_out);
+
+// ---- kernels_misc.hip
+hipError_t launch_inner_product(hipStream_t s, int n_cu, const void *a, uint32_t tower_level, const void *b,
+                                uint64_t b_len, f128 *d_out);
+hipError_t launch_fold_left(hipStream_t s, int n_cu, const void *mat, uint32_t tower_level, const void *vec,
+                            uint64_t vec_len, void *out, uint64_t out_len);
+hipError_t launch_fold_right(hipStream_t s, int n_cu, const void *mat, uint32_t tower_level, const void *vec,
+                             uint64_t vec_len, void *out, uint64_t out_len);
+hipError_t launch_compute_composite_generic(hipStream_t s, const void *const *d_rows_dev, uint32_t n_rows,
+                                            uint64_t row_len, void *out, const bn_step *d_steps, uint32_t n_steps);
+hipError_t launch_mul_elementwise(hipStream_t s, int n_cu, const void *a, const void *b, void *out, uint64_t n,
+                                  uint64_t a_stride, uint64_t b_stride, uint64_t b_off);
+hipError_t launch_fri_fold(hipStream_t s, const uint64_t *d_s_evals, uint32_t tw_level, uint32_t log_domain,
+                           uint32_t log_len, uint32_t log_batch, const f128 *h_challenges, uint32_t n_challenges,
+                           const void *in, void *out, uint64_t out_len, void *scratch);
+
+// ---- kernels_ntt.hip
+hipError_t launch_ntt(hipStream_t s, bool inverse, void *data, uint32_t elem_level, uint32_t tw_level,
+                      const uint64_t *d_s_evals, uint32_t log_domain, uint32_t log_x, uint32_t log_y, uint32_t log_z,
+                      uint64_t coset, uint32_t coset_bits, uint32_t skip_rounds);
+
+} // namespace bn

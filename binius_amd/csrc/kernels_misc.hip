@@ -1,0 +1,253 @@
+// binius_amd/csrc/kernels_misc.hip -- the remaining ComputeLayerExecutor ops:
+// inner_product / fold_left / fold_right (subfield x F, crates/compute/src/layer.rs:263,321,351),
+// element-wise products (pairwise_product_reduce, layer.rs:505) and fri_fold (layer.rs:389).
+//
+// Subfield operands: a SubfieldSlice{slice, tower_level=iota} (crates/compute/src/memory.rs:257)
+// is the same bytes read as 2^(7-iota) limbs of 2^iota bits per 16-byte element, least-significant
+// limb first (iter_bases, crates/field/src/binary_field.rs:633-649).  limb * F is a bilinear walk
+// over only 2^iota bits (gf128.hpp mul_walk<iota>), so small-field matrices cost almost nothing.
+#include <hip/hip_runtime.h>
+
+#include "ctable.hpp"
+#include "internal.hpp"
+
+namespace bn {
+
+__device__ __forceinline__ uint32_t wave_xor32(uint32_t v)
+{
+#pragma unroll
+	for (int m = 32; m >= 1; m >>= 1)
+		v ^= __shfl_xor(v, m, 64);
+	return v;
+}
+
+// XOR-reduce a per-thread f128 over a 256-thread block and atomically XOR it into out[0].
+__device__ __forceinline__ void block_xor_to(f128 acc, f128 *out)
+{
+	__shared__ uint64_t red[4][2];
+	uint32_t w[4] = {(uint32_t)acc.lo, (uint32_t)(acc.lo >> 32), (uint32_t)acc.hi, (uint32_t)(acc.hi >> 32)};
+#pragma unroll
+	for (int t = 0; t < 4; t++)
+		w[t] = wave_xor32(w[t]);
+	const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	if (lane == 0) {
+		red[wave][0] = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
+		red[wave][1] = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
+	}
+	__syncthreads();
+	if (threadIdx.x < 2) {
+		uint64_t v = red[0][threadIdx.x] ^ red[1][threadIdx.x] ^ red[2][threadIdx.x] ^ red[3][threadIdx.x];
+		if (v)
+			atomicXor(reinterpret_cast<unsigned long long *>(out) + threadIdx.x, (unsigned long long)v);
+	}
+}
+
+// limb j (2^IOTA bits) of a packed subfield array
+template <int IOTA>
+__device__ __forceinline__ uint64_t subfield_limb(const uint64_t *words, uint64_t j)
+{
+	if constexpr (IOTA >= 6) {
+		return words[j];
+	} else {
+		constexpr unsigned W = 1u << IOTA;
+		constexpr unsigned PER = 64 / W;
+		const uint64_t word = words[j / PER];
+		return (word >> ((j % PER) * W)) & ((1ull << W) - 1);
+	}
+}
+
+template <int IOTA>
+__device__ __forceinline__ f128 mul_sub(f128 x, const uint64_t *words, uint64_t j)
+{
+	if constexpr (IOTA == 7) {
+		return mul_slow(x, f128{words[2 * j], words[2 * j + 1]});
+	} else {
+		return mul_walk<IOTA>(x, subfield_limb<IOTA>(words, j));
+	}
+}
+
+// inner_product: sum_i b[i] * a_sub[i]
+template <int IOTA>
+__global__ __launch_bounds__(256) void k_inner_product(const uint64_t *a, const uint4 *b, uint64_t n, f128 *out)
+{
+	f128 acc = f128_zero();
+	for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256)
+		acc ^= mul_sub<IOTA>(to_f128(b[i]), a, i);
+	block_xor_to(acc, out);
+}
+
+// fold_right: out[i] = sum_j vec[j] * M[i*|vec| + j];  fold_left: out[i] = sum_j vec[j] * M[j*rows + i]
+template <int IOTA, bool LEFT>
+__global__ __launch_bounds__(256) void k_fold(const uint64_t *mat, const uint4 *vec, uint64_t vec_len, uint4 *out,
+                                              uint64_t out_len)
+{
+	for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < out_len; i += (uint64_t)gridDim.x * 256) {
+		f128 acc = f128_zero();
+		for (uint64_t j = 0; j < vec_len; j++) {
+			const uint64_t idx = LEFT ? (j * out_len + i) : (i * vec_len + j);
+			acc ^= mul_sub<IOTA>(to_f128(vec[j]), mat, idx);
+		}
+		out[i] = to_u4(acc);
+	}
+}
+
+template <template <int> class Launcher, typename... Args>
+static hipError_t dispatch_level(uint32_t level, Args... args)
+{
+	switch (level) {
+	case 0: return Launcher<0>::run(args...);
+	case 3: return Launcher<3>::run(args...);
+	case 4: return Launcher<4>::run(args...);
+	case 5: return Launcher<5>::run(args...);
+	case 6: return Launcher<6>::run(args...);
+	case 7: return Launcher<7>::run(args...);
+	default: return hipErrorInvalidValue;
+	}
+}
+
+template <int IOTA>
+struct ip_launcher {
+	static hipError_t run(hipStream_t s, unsigned g, const void *a, const void *b, uint64_t n, f128 *out)
+	{
+		hipLaunchKernelGGL(k_inner_product<IOTA>, dim3(g), dim3(256), 0, s, (const uint64_t *)a, (const uint4 *)b, n, out);
+		return hipGetLastError();
+	}
+};
+
+hipError_t launch_inner_product(hipStream_t s, int n_cu, const void *a, uint32_t tower_level, const void *b,
+                                uint64_t b_len, f128 *d_out)
+{
+	if (b_len == 0) return hipSuccess;
+	uint64_t want = (b_len + 255) / 256;
+	unsigned g = (unsigned)(want < (uint64_t)n_cu * 8 ? want : (uint64_t)n_cu * 8);
+	return dispatch_level<ip_launcher>(tower_level, s, g, a, b, b_len, d_out);
+}
+
+template <int IOTA>
+struct foldl_launcher {
+	static hipError_t run(hipStream_t s, unsigned g, const void *m, const void *v, uint64_t vl, void *o, uint64_t ol)
+	{
+		hipLaunchKernelGGL((k_fold<IOTA, true>), dim3(g), dim3(256), 0, s, (const uint64_t *)m, (const uint4 *)v, vl,
+		                   (uint4 *)o, ol);
+		return hipGetLastError();
+	}
+};
+template <int IOTA>
+struct foldr_launcher {
+	static hipError_t run(hipStream_t s, unsigned g, const void *m, const void *v, uint64_t vl, void *o, uint64_t ol)
+	{
+		hipLaunchKernelGGL((k_fold<IOTA, false>), dim3(g), dim3(256), 0, s, (const uint64_t *)m, (const uint4 *)v, vl,
+		                   (uint4 *)o, ol);
+		return hipGetLastError();
+	}
+};
+
+hipError_t launch_fold_left(hipStream_t s, int n_cu, const void *mat, uint32_t tower_level, const void *vec,
+                            uint64_t vec_len, void *out, uint64_t out_len)
+{
+	if (out_len == 0) return hipSuccess;
+	uint64_t want = (out_len + 255) / 256;
+	unsigned g = (unsigned)(want < (uint64_t)n_cu * 8 ? want : (uint64_t)n_cu * 8);
+	return dispatch_level<foldl_launcher>(tower_level, s, g, mat, vec, vec_len, out, out_len);
+}
+
+hipError_t launch_fold_right(hipStream_t s, int n_cu, const void *mat, uint32_t tower_level, const void *vec,
+                             uint64_t vec_len, void *out, uint64_t out_len)
+{
+	if (out_len == 0) return hipSuccess;
+	uint64_t want = (out_len + 255) / 256;
+	unsigned g = (unsigned)(want < (uint64_t)n_cu * 8 ? want : (uint64_t)n_cu * 8);
+	return dispatch_level<foldr_launcher>(tower_level, s, g, mat, vec, vec_len, out, out_len);
+}
+
+// out[i] = a[i*a_stride] * b[b_off + i*b_stride]   (pairwise_product_reduce: a = in, strides 2, b_off 1)
+__global__ __launch_bounds__(256) void k_mul_elementwise(const uint4 *a, const uint4 *b, uint4 *out, uint64_t n,
+                                                         uint64_t a_stride, uint64_t b_stride, uint64_t b_off)
+{
+	for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256)
+		out[i] = to_u4(mul_slow(to_f128(a[i * a_stride]), to_f128(b[b_off + i * b_stride])));
+}
+
+hipError_t launch_mul_elementwise(hipStream_t s, int n_cu, const void *a, const void *b, void *out, uint64_t n,
+                                  uint64_t a_stride, uint64_t b_stride, uint64_t b_off)
+{
+	if (n == 0) return hipSuccess;
+	uint64_t want = (n + 255) / 256;
+	unsigned g = (unsigned)(want < (uint64_t)n_cu * 8 ? want : (uint64_t)n_cu * 8);
+	hipLaunchKernelGGL(k_mul_elementwise, dim3(g), dim3(256), 0, s, (const uint4 *)a, (const uint4 *)b, (uint4 *)out, n,
+	                   a_stride, b_stride, b_off);
+	return hipGetLastError();
+}
+
+// ---- fri_fold as halving passes ---------------------------------------------------------------
+// Reference semantics: crates/compute/src/cpu/layer.rs:345-388.  Per output chunk the reference
+// folds 2^b interleaved symbols with the b interleave challenges, then for every fold challenge
+// does an inverse-NTT butterfly + line extrapolation on adjacent pairs.  Pair k of the WHOLE array
+// in fold round with current log_len L uses twiddle get_subspace_eval(L, k) (k = chunk<<(ls-1)|off
+// is simply the global pair index), so every challenge is one streaming pass that halves the array:
+//   interleave pass:  out[k] = x[2k] + (x[2k+1] - x[2k]) * r
+//   fold pass:        u = x[2k], v = x[2k+1]; v += u; u += v*t_k; out[k] = u + (v - u) * r
+// with r launch-constant (LDS nibble tables) and t_k in the small twiddle field (mul_walk).
+template <int TW>
+__global__ __launch_bounds__(256) void k_fri_pass(const uint4 *in, uint4 *out, uint64_t n_out, f128 r, int ntt_pass,
+                                                  const uint64_t *s_row, int n_bits)
+{
+	__shared__ ctable_smem tab;
+	__shared__ uint64_t s_basis[64];
+	ctable_build(tab, r);
+	if (threadIdx.x < 64)
+		s_basis[threadIdx.x] = (ntt_pass && (int)threadIdx.x < n_bits) ? s_row[threadIdx.x] : 0;
+	__syncthreads();
+	for (uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x; k < n_out; k += (uint64_t)gridDim.x * 256) {
+		uint4 u = in[2 * k], v = in[2 * k + 1];
+		if (ntt_pass) {
+			uint64_t t = 0; // OnTheFlyTwiddleAccess::get: subset sum over the bits of k (twiddle.rs:141-168)
+			for (int b = 0; b < n_bits; b++)
+				if ((k >> b) & 1)
+					t ^= s_basis[b];
+			v = xor4(v, u);
+			u = xor4(u, to_u4(mul_walk<TW>(to_f128(v), t)));
+		}
+		out[k] = xor4(u, ctable_mul(tab, xor4(u, v)));
+	}
+}
+
+hipError_t launch_fri_fold(hipStream_t s, const uint64_t *d_s_evals, uint32_t tw_level, uint32_t log_domain,
+                           uint32_t log_len, uint32_t log_batch, const f128 *h_challenges, uint32_t n_challenges,
+                           const void *in, void *out, uint64_t out_len, void *scratch)
+{
+	// scratch holds two ping-pong buffers of in_len/2 elements each
+	const uint64_t in_len = out_len << n_challenges;
+	uint4 *buf0 = (uint4 *)scratch;
+	uint4 *buf1 = buf0 + in_len / 2;
+	const uint4 *src = (const uint4 *)in;
+	uint64_t cur = in_len;
+	uint32_t ll = log_len;
+	for (uint32_t c = 0; c < n_challenges; c++) {
+		const uint64_t n_out = cur / 2;
+		uint4 *dst = (c + 1 == n_challenges) ? (uint4 *)out : ((c & 1) ? buf1 : buf0);
+		const int ntt_pass = c >= log_batch;
+		// twiddles of get_subspace_eval(ll, .) = s_evals[log_domain - ll], which has log_domain-1-(log_domain-ll)=ll-1 bits
+		const uint64_t *row = d_s_evals + (uint64_t)(log_domain - ll) * BN_NTT_MAX_DIM;
+		const int n_bits = ntt_pass ? (int)ll - 1 : 0;
+		uint64_t want = (n_out + 255) / 256;
+		unsigned g = (unsigned)(want < 2048 ? want : 2048);
+		if (g < 1) g = 1;
+		const f128 r = h_challenges[c];
+		switch (tw_level) {
+		case 3: hipLaunchKernelGGL(k_fri_pass<3>, dim3(g), dim3(256), 0, s, src, dst, n_out, r, ntt_pass, row, n_bits); break;
+		case 4: hipLaunchKernelGGL(k_fri_pass<4>, dim3(g), dim3(256), 0, s, src, dst, n_out, r, ntt_pass, row, n_bits); break;
+		case 5: hipLaunchKernelGGL(k_fri_pass<5>, dim3(g), dim3(256), 0, s, src, dst, n_out, r, ntt_pass, row, n_bits); break;
+		case 6: hipLaunchKernelGGL(k_fri_pass<6>, dim3(g), dim3(256), 0, s, src, dst, n_out, r, ntt_pass, row, n_bits); break;
+		default: return hipErrorInvalidValue;
+		}
+		hipError_t e = hipGetLastError();
+		if (e != hipSuccess) return e;
+		if (ntt_pass) ll -= 1;
+		src = dst;
+		cur = n_out;
+	}
+	return hipSuccess;
+}
+
+} // namespace bn

@@ -1,0 +1,133 @@
+// binius_amd/csrc/kernels_stream.hip -- HBM-streaming kernels: fill, add / add_assign,
+// extrapolate_line (the sumcheck fold) and one tensor_expand pass.
+//
+// All of them are bound by HBM bandwidth: 128-bit coalesced loads/stores (one uint4 per lane =
+// 1 KiB per wave instruction), grid-stride loops sized to keep >= 8 waves per SIMD in flight, and
+// the launch-constant multiplier handled by LDS nibble tables (ctable.hpp) so the ALU work per
+// element (~100 VALU + 32 conflict-free ds_read_b128) stays well under the memory time.
+#include <hip/hip_runtime.h>
+
+#include "ctable.hpp"
+#include "internal.hpp"
+
+namespace bn {
+
+static inline unsigned grid_for(uint64_t n_items, unsigned per_block, int n_cu, unsigned blocks_per_cu)
+{
+	uint64_t want = (n_items + per_block - 1) / per_block;
+	uint64_t cap = (uint64_t)n_cu * blocks_per_cu;
+	if (want < 1) want = 1;
+	return (unsigned)(want < cap ? want : cap);
+}
+
+__global__ __launch_bounds__(256) void k_fill(uint4 *dst, uint64_t n, uint4 v)
+{
+	for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256)
+		dst[i] = v;
+}
+
+__global__ __launch_bounds__(256) void k_add_assign(uint4 *dst, const uint4 *src, uint64_t n)
+{
+	for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256)
+		dst[i] = xor4(dst[i], src[i]);
+}
+
+__global__ __launch_bounds__(256) void k_add(uint4 *dst, const uint4 *s1, const uint4 *s2, uint64_t n)
+{
+	for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256)
+		dst[i] = xor4(s1[i], s2[i]);
+}
+
+// extrapolate_line: x0[i] += (x1[i] - x0[i]) * z          (crates/compute/src/layer.rs:421,
+// semantics of crates/compute/src/cpu/layer.rs:393-408).  Algorithmic traffic: read 32 B, write
+// 16 B per output element = 24 B per input element of the multilinear being folded.
+template <int U>
+__global__ __launch_bounds__(256) void k_extrapolate_line(uint4 *__restrict__ x0, const uint4 *__restrict__ x1, uint64_t n,
+                                                          f128 z)
+{
+	__shared__ ctable_smem tab;
+	ctable_build(tab, z);
+	const uint64_t stride = (uint64_t)gridDim.x * 256;
+	uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+	// main body: U independent elements per iteration so U*2 16-byte loads are in flight per lane
+	for (; i + (U - 1) * stride < n; i += U * stride) {
+		uint4 a[U], b[U];
+#pragma unroll
+		for (int u = 0; u < U; u++) {
+			a[u] = x0[i + u * stride];
+			b[u] = x1[i + u * stride];
+		}
+#pragma unroll
+		for (int u = 0; u < U; u++) {
+			uint4 p = ctable_mul(tab, xor4(a[u], b[u]));
+			x0[i + u * stride] = xor4(a[u], p);
+		}
+	}
+	for (; i < n; i += stride) {
+		uint4 a = x0[i], b = x1[i];
+		x0[i] = xor4(a, ctable_mul(tab, xor4(a, b)));
+	}
+}
+
+// one tensor_expand pass: p = x[h]*r ; x[h] -= p ; x[half+h] = p
+// (crates/compute/src/layer.rs:269-296; "y = prod" as in crates/math/src/tensor_prod_eq_ind.rs:35-77)
+__global__ __launch_bounds__(256) void k_tensor_expand_pass(uint4 *__restrict__ x, uint64_t half, f128 r)
+{
+	__shared__ ctable_smem tab;
+	ctable_build(tab, r);
+	const uint64_t stride = (uint64_t)gridDim.x * 256;
+	for (uint64_t h = (uint64_t)blockIdx.x * 256 + threadIdx.x; h < half; h += stride) {
+		uint4 v = x[h];
+		uint4 p = ctable_mul(tab, v);
+		x[h] = xor4(v, p);
+		x[half + h] = p;
+	}
+}
+
+hipError_t launch_fill(hipStream_t s, void *dst, uint64_t n, f128 v)
+{
+	if (n == 0) return hipSuccess;
+	unsigned g = grid_for(n, 256, 256, 8);
+	hipLaunchKernelGGL(k_fill, dim3(g), dim3(256), 0, s, (uint4 *)dst, n,
+	                   uint4{(uint32_t)v.lo, (uint32_t)(v.lo >> 32), (uint32_t)v.hi, (uint32_t)(v.hi >> 32)});
+	return hipGetLastError();
+}
+
+hipError_t launch_add_assign(hipStream_t s, void *dst, const void *src, uint64_t n)
+{
+	if (n == 0) return hipSuccess;
+	unsigned g = grid_for(n, 256, 256, 8);
+	hipLaunchKernelGGL(k_add_assign, dim3(g), dim3(256), 0, s, (uint4 *)dst, (const uint4 *)src, n);
+	return hipGetLastError();
+}
+
+hipError_t launch_add(hipStream_t s, void *dst, const void *src1, const void *src2, uint64_t n)
+{
+	if (n == 0) return hipSuccess;
+	unsigned g = grid_for(n, 256, 256, 8);
+	hipLaunchKernelGGL(k_add, dim3(g), dim3(256), 0, s, (uint4 *)dst, (const uint4 *)src1, (const uint4 *)src2, n);
+	return hipGetLastError();
+}
+
+hipError_t launch_extrapolate_line(hipStream_t s, int n_cu, void *evals_0, const void *evals_1, uint64_t n, f128 z)
+{
+	if (n == 0) return hipSuccess;
+	if (n >= (1u << 16)) {
+		unsigned g = grid_for(n, 256 * 2, n_cu, 8);
+		hipLaunchKernelGGL(k_extrapolate_line<2>, dim3(g), dim3(256), 0, s, (uint4 *)evals_0, (const uint4 *)evals_1, n, z);
+	} else {
+		unsigned g = grid_for(n, 256, n_cu, 8);
+		hipLaunchKernelGGL(k_extrapolate_line<1>, dim3(g), dim3(256), 0, s, (uint4 *)evals_0, (const uint4 *)evals_1, n, z);
+	}
+	return hipGetLastError();
+}
+
+hipError_t launch_tensor_expand_pass(hipStream_t s, int n_cu, void *data, uint64_t half, f128 r)
+{
+	if (half == 0) return hipSuccess;
+	unsigned g = grid_for(half, 256, n_cu, 8);
+	hipLaunchKernelGGL(k_tensor_expand_pass, dim3(g), dim3(256), 0, s, (uint4 *)data, half, r);
+	return hipGetLastError();
+}
+
+} // namespace bn

@@ -1,0 +1,186 @@
+/*
+ * binius_amd.h -- C ABI of the MI355X (gfx950) compute backend for the Binius prover hot path.
+ *
+ * Drop-in boundary: these entry points are what an implementation of the reference's HAL traits
+ *   binius_compute::ComputeLayer          crates/compute/src/layer.rs:22
+ *   binius_compute::ComputeLayerExecutor  crates/compute/src/layer.rs:100
+ *   binius_compute::KernelExecutor        crates/compute/src/layer.rs:518
+ *   binius_ntt::AdditiveNTT               crates/ntt/src/additive_ntt.rs:58
+ * binds over FFI (INTEGRATION.md shows the Rust `extern "C"` block and the trait impl).
+ * Plain pointers and sizes only; no C++ or torch types.
+ *
+ * Conventions
+ *   - F = BinaryField128b = one little-endian u128 = bn_f128 {lo, hi}
+ *     (crates/field/src/binary_field.rs:747); element i of a slice is at byte offset 16*i.
+ *   - Pointers named d_* are device pointers (16-byte aligned); h_* are host pointers.
+ *     All lengths are in field elements unless stated otherwise.
+ *   - Every function returns a bn_status.  Non-zero mirrors binius_compute::Error
+ *     (crates/compute/src/layer.rs:706-716); bn_last_error() gives the message for the calling
+ *     thread.  Precondition violations the reference reports as Error::InputValidation are
+ *     reported as BN_ERR_INPUT_VALIDATION with nothing launched.
+ *   - Ownership: the caller owns every buffer; the library owns its context (stream, scratch).
+ *   - Ordering: work is enqueued on the context's HIP stream in call order, which gives the
+ *     store-to-load ordering the executor contract asks for (layer.rs:92-95).  Functions that
+ *     return scalars to the host synchronise the stream.
+ */
+#ifndef BINIUS_AMD_H
+#define BINIUS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+	uint64_t lo, hi;
+} bn_f128;
+
+typedef enum {
+	BN_OK = 0,
+	BN_ERR_INPUT_VALIDATION = 1, /* Error::InputValidation */
+	BN_ERR_ALLOC = 2,            /* Error::Alloc(OutOfMemory) */
+	BN_ERR_DEVICE = 3,           /* Error::DeviceError (hipError_t) */
+	BN_ERR_CORE_LIB = 4          /* Error::CoreLibError */
+} bn_status;
+
+typedef struct bn_ctx bn_ctx;
+typedef struct bn_expr bn_expr;
+
+const char *bn_last_error(void);
+/* "gfx950" build tag + ABI version, for the loader to check */
+const char *bn_version(void);
+
+/* ---- context = ComputeHolder (layer.rs:732-776; FastCpuLayerHolder::new(host, dev),
+ *      crates/fast_compute/src/layer.rs:905).  arena_elems may be 0 (caller brings its own device
+ *      memory, e.g. a torch allocation); otherwise one arena of arena_elems F is hipMalloc'ed and
+ *      the host side bump-allocates from it (crates/compute/src/alloc.rs:31). */
+int bn_ctx_create(int device, uint64_t arena_elems, bn_ctx **out);
+int bn_ctx_destroy(bn_ctx *ctx);
+int bn_arena_base(bn_ctx *ctx, void **d_base, uint64_t *elems);
+/* run on an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = own stream */
+int bn_ctx_set_stream(bn_ctx *ctx, void *hip_stream);
+int bn_sync(bn_ctx *ctx);
+
+/* ---- ComputeLayer (layer.rs:36-87) ---- */
+int bn_copy_h2d(bn_ctx *ctx, const bn_f128 *h_src, uint64_t src_len, void *d_dst, uint64_t dst_len);
+int bn_copy_d2h(bn_ctx *ctx, const void *d_src, uint64_t src_len, bn_f128 *h_dst, uint64_t dst_len);
+int bn_copy_d2d(bn_ctx *ctx, const void *d_src, uint64_t src_len, void *d_dst, uint64_t dst_len);
+int bn_fill(bn_ctx *ctx, void *d_dst, uint64_t n, const bn_f128 *value);
+
+/* compile_expr (layer.rs:57): ArithCircuitStep list, crates/math/src/arith_expr.rs:200-206 */
+enum { BN_STEP_ADD = 0, BN_STEP_MUL = 1, BN_STEP_POW = 2, BN_STEP_CONST = 3, BN_STEP_VAR = 4 };
+typedef struct {
+	uint32_t kind;
+	uint32_t a;   /* Add/Mul: left step; Pow: base step; Var: variable index */
+	uint64_t b;   /* Add/Mul: right step; Pow: exponent */
+	bn_f128 cst;  /* Const */
+} bn_step;
+int bn_expr_compile(bn_ctx *ctx, const bn_step *steps, uint64_t n_steps, bn_expr **out);
+int bn_expr_free(bn_expr *expr);
+int bn_expr_n_vars(const bn_expr *expr, uint32_t *n_vars);
+
+/* ---- ComputeLayerExecutor ---- */
+/* extrapolate_line (layer.rs:421): evals_0[i] += (evals_1[i] - evals_0[i]) * z */
+int bn_extrapolate_line(bn_ctx *ctx, void *d_evals_0, uint64_t n0, const void *d_evals_1, uint64_t n1,
+                        const bn_f128 *z);
+/* tensor_expand (layer.rs:291): data[..2^(log_n+k)] = data[..2^log_n] (x) (1-r_0,r_0) (x) ... */
+int bn_tensor_expand(bn_ctx *ctx, void *d_data, uint64_t data_len, uint32_t log_n, const bn_f128 *h_coords,
+                     uint32_t k);
+/* inner_product (layer.rs:263): a is a SubfieldSlice{slice, tower_level} (memory.rs:257-281) */
+int bn_inner_product(bn_ctx *ctx, const void *d_a, uint64_t a_len, uint32_t tower_level, const void *d_b,
+                     uint64_t b_len, bn_f128 *h_out);
+/* fold_left / fold_right (layer.rs:321, 351) */
+int bn_fold_left(bn_ctx *ctx, const void *d_mat, uint64_t mat_len, uint32_t tower_level, const void *d_vec,
+                 uint64_t vec_len, void *d_out, uint64_t out_len);
+int bn_fold_right(bn_ctx *ctx, const void *d_mat, uint64_t mat_len, uint32_t tower_level, const void *d_vec,
+                  uint64_t vec_len, void *d_out, uint64_t out_len);
+/* fri_fold (layer.rs:389).  The NTT object is passed as its on-the-fly twiddle basis:
+ * h_s_evals[i*BN_NTT_MAX_DIM + b] = s_evals[i][b] of OnTheFlyTwiddleAccess
+ * (crates/ntt/src/twiddle.rs:93-124), elements of T_tw_level in the low bits of a u64. */
+#define BN_NTT_MAX_DIM 64
+int bn_fri_fold(bn_ctx *ctx, const uint64_t *h_s_evals, uint32_t tw_level, uint32_t log_domain, uint32_t log_len,
+                uint32_t log_batch_size, const bn_f128 *h_challenges, uint32_t n_challenges, const void *d_in,
+                uint64_t in_len, void *d_out, uint64_t out_len);
+/* compute_composite (layer.rs:459) */
+int bn_compute_composite(bn_ctx *ctx, const void *const *d_rows, uint32_t n_rows, uint64_t row_len, void *d_out,
+                         uint64_t out_len, const bn_expr *expr);
+/* pairwise_product_reduce (layer.rs:505) */
+int bn_pairwise_product_reduce(bn_ctx *ctx, const void *d_in, uint64_t n, void *const *d_round_outs,
+                               const uint64_t *round_lens, uint32_t n_rounds);
+
+/* ---- accumulate_kernels / map_kernels (layer.rs:183, 236) + KernelExecutor (layer.rs:518-590).
+ * The kernel-spec closure cannot cross an FFI: the host shim runs it ONCE against a recording
+ * KernelExecutor (the trait allows re-invocation, layer.rs:171-177) and passes the recorded op
+ * list here.  Slices are chunk-relative views of the mapped buffers. */
+enum { BN_MAP_CHUNKED = 0, BN_MAP_CHUNKED_MUT = 1, BN_MAP_LOCAL = 2 }; /* KernelMemMap, layer.rs:595-612 */
+typedef struct {
+	uint32_t kind;
+	uint32_t log_min_chunk_size;
+	void *d_data;     /* Chunked / ChunkedMut */
+	uint64_t len;
+	uint32_t log_size; /* Local: total size over all chunks */
+} bn_memmap;
+
+typedef struct {
+	uint32_t buf;       /* index into the memmap list */
+	uint64_t off, len;  /* within the chunk */
+} bn_kslice;
+
+enum { BN_KOP_DECL_VALUE = 0, BN_KOP_SUM_COMPOSITION = 1, BN_KOP_ADD = 2, BN_KOP_ADD_ASSIGN = 3 };
+typedef struct {
+	uint32_t kind;
+	uint32_t value;          /* DECL_VALUE: id declared; SUM_COMPOSITION: accumulator id */
+	bn_f128 scalar;          /* DECL_VALUE: init; SUM_COMPOSITION: batch_coeff */
+	const bn_expr *expr;     /* SUM_COMPOSITION */
+	uint32_t n_rows;
+	const bn_kslice *rows;   /* SUM_COMPOSITION inputs */
+	bn_kslice src1, src2, dst; /* ADD: dst = src1 + src2; ADD_ASSIGN: dst += src1 */
+} bn_kop;
+
+/* KernelMemMap::log_chunks_range (layer.rs:617-644), ComputeMemory::ALIGNMENT = 1. Host only. */
+int bn_log_chunks_range(const bn_memmap *maps, uint32_t n_maps, uint32_t *start, uint32_t *end);
+/* log_chunks this backend wants the closure recorded with (host only; deterministic). */
+int bn_pick_log_chunks(const bn_memmap *maps, uint32_t n_maps, uint32_t *log_chunks);
+/* Launch.  ops were recorded for `log_chunks`.  n_ret == 0 is map_kernels.  The n_ret returned
+ * values (ids in ret_values) are XOR-accumulated over chunks (cpu/layer.rs:178-188) and written
+ * to h_out (stream is synchronised) and/or left in d_out (n_ret elements, no sync) -- the latter
+ * lets a multi-GPU caller feed them straight into an RCCL collective. */
+int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const bn_kop *ops, uint32_t n_ops,
+                     const uint32_t *ret_values, uint32_t n_ret, uint32_t log_chunks, bn_f128 *h_out, void *d_out);
+
+/* ---- AdditiveNTT (crates/ntt/src/additive_ntt.rs:102, 128): data is 2^(log_x+log_y+log_z)
+ * elements of T_elem_level (elem_level 5 = BinaryField32b ... 7 = BinaryField128b), transform along
+ * y; twiddles in T_tw_level given as the on-the-fly basis (see bn_fri_fold). */
+int bn_ntt_forward(bn_ctx *ctx, void *d_data, uint32_t elem_level, uint32_t tw_level, const uint64_t *h_s_evals,
+                   uint32_t log_domain, uint32_t log_x, uint32_t log_y, uint32_t log_z, uint64_t coset,
+                   uint32_t coset_bits, uint32_t skip_rounds);
+int bn_ntt_inverse(bn_ctx *ctx, void *d_data, uint32_t elem_level, uint32_t tw_level, const uint64_t *h_s_evals,
+                   uint32_t log_domain, uint32_t log_x, uint32_t log_y, uint32_t log_z, uint64_t coset,
+                   uint32_t coset_bits, uint32_t skip_rounds);
+/* OnTheFlyTwiddleAccess::generate for the canonical subspace (twiddle.rs:107-124, 244-306). Host only. */
+int bn_ntt_s_evals(uint32_t tw_level, uint32_t log_domain, uint64_t *h_s_evals);
+
+/* ---- host-only scalar helpers for the O(1)-per-round protocol scalars the host keeps
+ * (evaluate_univariate of the round polynomial, powers of the batch coefficient:
+ * crates/core/src/protocols/sumcheck/v3/bivariate_product.rs:150-156, 339-341).  Same arithmetic
+ * as the kernels (gf128.hpp); never used on hypercube-sized data. */
+int bn_scalar_mul(const bn_f128 *a, const bn_f128 *b, bn_f128 *out);
+int bn_scalar_invert(const bn_f128 *a, bn_f128 *out);
+
+/* ---- measurement plumbing: time the launches enqueued between begin and end with hipEvents on
+ * the context's stream.  Not part of the reference interface. */
+int bn_timer_begin(bn_ctx *ctx);
+int bn_timer_end_ms(bn_ctx *ctx, float *ms);
+/* Per-kernel-class timing without perturbing the stream: while profiling is on, every launch of a
+ * hot kernel is bracketed by two hipEvents recorded on the context's stream (no synchronisation);
+ * bn_prof_end synchronises once and sums the elapsed times per class. */
+enum { BN_PROF_ROUND_EVAL = 0, BN_PROF_FOLD = 1, BN_PROF_TENSOR_EXPAND = 2, BN_PROF_NTT = 3, BN_PROF_OTHER = 4, BN_PROF_N = 5 };
+int bn_prof_begin(bn_ctx *ctx);
+int bn_prof_end(bn_ctx *ctx, double *ms_by_class /*[BN_PROF_N]*/, uint64_t *launches_by_class /*[BN_PROF_N]*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BINIUS_AMD_H */

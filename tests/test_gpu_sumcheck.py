@@ -1,0 +1,171 @@
+"""GPU parity tests for the sumcheck path: round evaluation (accumulate_kernels), fold
+(extrapolate_line) and the full prover loop, vs the CPU oracle -- bit-exact.
+
+Mirrors crates/compute_test_utils/src/bivariate_sumcheck.rs:44-262
+(generic_test_calculate_round_evals, generic_test_bivariate_sumcheck_prove_verify) with the
+transcript replaced by a seeded challenge stream; the "verifier" checks are the sumcheck
+verifier's own: P(0) + P(1) == running sum every round, and the final evaluations equal the
+multilinear extensions at the reversed challenge point (bivariate_sumcheck.rs:257-261).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hal():
+    import binius_amd
+
+    ctx = binius_amd.Context(0, 1 << 23)
+    yield ctx
+    ctx.close()
+
+
+def upload(hal, alloc, arr):
+    d = alloc.alloc(arr.shape[0])
+    hal.copy_h2d(arr, d)
+    return d
+
+
+def powers(oracle, x, n):
+    out, p = [], 1
+    for _ in range(n):
+        out.append(p)
+        p = oracle.mul(p, x)
+    return out
+
+
+@pytest.mark.parametrize("n_vars,m,n_comps", [(1, 2, 1), (2, 2, 1), (5, 3, 2), (8, 8, 8), (11, 2, 1), (13, 4, 3)])
+def test_calculate_round_evals(hal, oracle, n_vars, m, n_comps):
+    from binius_amd.sumcheck import bivariate_product_expr, calculate_round_evals
+
+    alloc = hal.dev_alloc()
+    mls = [oracle.random_b128(0xB1A50000 + j, 1 << n_vars) for j in range(m)]
+    d = [upload(hal, alloc, x) for x in mls]
+    rng = np.random.RandomState(n_vars * 100 + m)
+    comps = [(int(rng.randint(m)), int(rng.randint(m))) for _ in range(n_comps)]
+    batch_coeff = oracle.random_scalars(0xC4A1, 1)[0]
+    exprs = [bivariate_product_expr(hal, i, j) for i, j in comps]
+    got = calculate_round_evals(hal, n_vars, powers(oracle, batch_coeff, n_comps), d, exprs)
+    rc, want = oracle.round_evals(mls, n_vars, comps, batch_coeff)
+    assert rc == 0
+    assert got == want
+
+
+@pytest.mark.parametrize("n_vars,m,n_comps", [(1, 2, 1), (3, 2, 1), (8, 8, 8), (12, 2, 1), (16, 2, 1), (14, 3, 2)])
+def test_bivariate_sumcheck_prove(hal, oracle, n_vars, m, n_comps):
+    from binius_amd.sumcheck import BivariateSumcheckProver
+
+    alloc = hal.dev_alloc()
+    mls = [oracle.random_b128(0xB1A50000 + j, 1 << n_vars) for j in range(m)]
+    d = [upload(hal, alloc, x) for x in mls]
+    rng = np.random.RandomState(n_vars * 7 + m)
+    comps = [(int(rng.randint(m)), int(rng.randint(m))) for _ in range(n_comps)]
+    sums = []
+    for i, j in comps:
+        rc, s = oracle.inner_product(mls[i], 7, mls[j])
+        assert rc == 0
+        sums.append(s)
+    stream = oracle.random_scalars(0xC4A1, n_vars + 1)
+    batch_coeff, challenges = stream[0], stream[1:]
+
+    prover = BivariateSumcheckProver(hal, alloc, n_vars, d, comps, sums)
+    running = oracle.evaluate_univariate(sums, batch_coeff)
+    got_coeffs = []
+    for r in range(n_vars):
+        rc = prover.execute(batch_coeff)
+        # verifier check: P(0) + P(1) == running sum
+        assert rc[0] ^ (rc[0] ^ rc[1] ^ rc[2]) == running
+        running = oracle.evaluate_univariate(rc, challenges[r])
+        got_coeffs.append(rc)
+        prover.fold(challenges[r])
+    final = prover.finish()
+
+    ref_mls = [x.copy() for x in mls]
+    want_coeffs, want_final = oracle.bivariate_sumcheck_prove(ref_mls, n_vars, comps, sums, batch_coeff, challenges)
+    assert got_coeffs == want_coeffs
+    assert final == want_final
+    # final evals == multilinear extensions at the reversed challenges (High-to-Low binding)
+    point = list(reversed(challenges))
+    for j in range(m):
+        assert final[j] == oracle.mle_evaluate(mls[j], n_vars, point)
+    # and the last running sum is the batched composition of the final evals
+    acc, p = 0, 1
+    for i, j in comps:
+        acc ^= oracle.mul(p, oracle.mul(final[i], final[j]))
+        p = oracle.mul(p, batch_coeff)
+    assert acc == running
+    # inputs are untouched (PreFold buffers are read-only: first fold copies, bivariate_product.rs:197-205)
+    for j in range(m):
+        assert np.array_equal(hal.copy_d2h(d[j]), mls[j])
+
+
+def test_mlecheck_round_evals(hal, oracle):
+    """crates/core/src/protocols/sumcheck/v3/bivariate_mlecheck.rs:391-520: product * eq_ind as the
+    last composition variable, eq table of 2^(n-1) entries shared by both evaluation points."""
+    from binius_amd.sumcheck import calculate_round_evals, eq_ind_partial_eval
+
+    alloc = hal.dev_alloc()
+    n_vars, m = 9, 3
+    mls = [oracle.random_b128(0xB1A50000 + j, 1 << n_vars) for j in range(m)]
+    d = [upload(hal, alloc, x) for x in mls]
+    point = oracle.random_scalars(0xE9, n_vars - 1)
+    eq = eq_ind_partial_eval(hal, alloc, point)
+    eq_h = hal.copy_d2h(eq)
+    comps = [(0, 1), (2, 0)]
+    exprs = [hal.compile_expr([("var", i), ("var", j), ("mul", 0, 1), ("var", m), ("mul", 2, 3)]) for i, j in comps]
+    batch_coeff = oracle.random_scalars(0xC4A1, 1)[0]
+    coeffs = powers(oracle, batch_coeff, len(comps))
+    got = calculate_round_evals(hal, n_vars, coeffs, d, exprs, eq_ind=eq)
+    half = 1 << (n_vars - 1)
+    want = [0, 0]
+    for (i, j), cf in zip(comps, coeffs):
+        a, b = mls[i], mls[j]
+        p1 = oracle.mul_vec(oracle.mul_vec(a[half:], b[half:]), eq_h)
+        pinf = oracle.mul_vec(oracle.mul_vec(a[:half] ^ a[half:], b[:half] ^ b[half:]), eq_h)
+        for k, p in enumerate((p1, pinf)):
+            s = int(np.bitwise_xor.reduce(p[:, 0])) | (int(np.bitwise_xor.reduce(p[:, 1])) << 64)
+            want[k] ^= oracle.mul(s, cf)
+    assert got == want
+
+
+def test_sumcheck_full_size_properties(oracle):
+    """BASELINE config 2 size (n = 24, m = 2): size-independent properties -- the sumcheck
+    verifier's round checks and the final product check -- plus oracle spot checks of the first
+    round (multi-threaded CPU port) and of the folded prefix."""
+    import binius_amd
+    from binius_amd.sumcheck import BivariateSumcheckProver
+
+    n_vars, m = 24, 2
+    n = 1 << n_vars
+    hal = binius_amd.Context(0, 3 * n + (1 << 12))
+    try:
+        alloc = hal.dev_alloc()
+        mls = [oracle.random_b128(0xB1A50000 + j, n) for j in range(m)]
+        d = [upload(hal, alloc, x) for x in mls]
+        s = hal.inner_product(d[0], 7, d[1])
+        rc, ev = oracle.round_evals(mls, n_vars, [(0, 1)], 1, threads=8)
+        assert rc == 0
+        stream = oracle.random_scalars(0xC4A1, n_vars + 1)
+        batch_coeff, challenges = stream[0], stream[1:]
+        prover = BivariateSumcheckProver(hal, alloc, n_vars, d, [(0, 1)], [s])
+        running = s
+        for r in range(n_vars):
+            rcf = prover.execute(batch_coeff)
+            if r == 0:
+                assert rcf[2] == ev[1] and (running ^ rcf[0]) == ev[0]  # y_inf, y_1 vs the oracle
+            assert rcf[0] ^ (rcf[0] ^ rcf[1] ^ rcf[2]) == running
+            running = oracle.evaluate_univariate(rcf, challenges[r])
+            prover.fold(challenges[r])
+            if r == 0:
+                # fold spot check: first 4096 folded elements of each multilinear
+                for j in range(m):
+                    got = hal.copy_d2h(prover.multilins[j][1].slice(0, 4096))
+                    e0 = mls[j][:4096].copy()
+                    oracle.extrapolate_line(e0, mls[j][n // 2 : n // 2 + 4096], challenges[0])
+                    assert np.array_equal(got, e0)
+        final = prover.finish()
+        assert oracle.mul(final[0], final[1]) == running
+    finally:
+        hal.close()
