@@ -97,6 +97,12 @@ hipError_t launch_sum_composition_generic(hipStream_t s, int n_cu, const void *c
 hipError_t launch_sum_product(hipStream_t s, int n_cu, const void *const *rows, uint32_t n_rows, uint64_t row_len,
                               f128 *d_out);
 
+// ---- kernels_roundeval9.hip (the hot bivariate-product kernel)
+hipError_t launch_roundeval9_pair(hipStream_t s, int n_cu, const void *a_hi, const void *a_lo, const void *b_hi,
+                                  const void *b_lo, uint64_t n, f128 *d_out);
+hipError_t launch_roundeval9_split(hipStream_t s, int n_cu, const void *a, const void *b, uint64_t n, uint64_t split_off,
+                                   f128 *d_out);
+
 // ---- kernels_misc.hip
 hipError_t launch_inner_product(hipStream_t s, int n_cu, const void *a, uint32_t tower_level, const void *b,
                                 uint64_t b_len, f128 *d_out);

@@ -1,0 +1,246 @@
+// binius_amd/csrc/kernels_roundeval9.hip -- the hot round-evaluation kernel for bivariate products:
+//   S_1 = sum_i a_hi[i]*b_hi[i],   S_inf = sum_i (a_lo[i]+a_hi[i])*(b_lo[i]+b_hi[i])
+// (crates/core/src/protocols/sumcheck/v3/bivariate_product.rs:303-408), one pass over the data.
+//
+// Mapping to a wave64 ("9-lane Karatsuba groups").  Two Karatsuba levels split a GF(2^128) product
+// into 9 GF(2^32) products of limb combinations
+//     {0} {1} {0,1} {2} {3} {2,3} {0,2} {1,3} {0,1,2,3}            (limb = 32-bit word of an element)
+// and every post-processing step of Karatsuba is linear, so it commutes with the sum over i: each
+// lane owns ONE combination, multiplies it bit-sliced (bs_mul<5>, 32 planes, ~1200 VALU) and keeps a
+// private 32-plane accumulator for the whole kernel; the recombination into a field element happens
+// once per workgroup.  A wave holds 7 such groups (63 lanes); a batch is 16 hypercube points per
+// group.  Registers: operands 2x32 + product 32 + accumulator 32 + temporaries -> two waves per SIMD
+// with no scratch, instead of one spilling wave for a monolithic 128-plane product.
+//
+// Per batch and group, 8 lanes each load one 32-bit word column (a or b, word 0..3) of the 16 points
+// -- 16 rows from the hi half and 16 rows from the lo half -- and transpose it in registers
+// (32x32 bit transpose); "lo + hi" is then one shifted XOR per plane, which puts the evaluation-at-1
+// operands in the low 16 bits and the evaluation-at-infinity operands in the high 16 bits of every
+// plane.  The 8 transposed limbs are exchanged through a per-wave LDS tile (no workgroup barrier:
+// a wave's DS operations execute in order), each lane XORs together the limbs of its combination.
+#include <hip/hip_runtime.h>
+
+#include "bitslice.hpp"
+#include "internal.hpp"
+
+namespace bn {
+
+namespace {
+
+constexpr int kGroups = 7;          // 9-lane groups per wave
+constexpr int kPts = 16;            // hypercube points per group per batch
+constexpr int kBatch = kGroups * kPts; // 112 points per wave-batch
+constexpr int kBlkQ = 9;            // LDS uint4 per (limb, group) block: 32 planes + 16 B pad (bank spread)
+constexpr int kZeroBlk = 8 * kGroups; // block of zeros for unused combination slots
+constexpr int kWaveQ = (kZeroBlk + 1) * kBlkQ;
+
+__device__ __forceinline__ uint32_t wave_xor_u32(uint32_t v)
+{
+#pragma unroll
+	for (int m = 32; m >= 1; m >>= 1)
+		v ^= __shfl_xor(v, m, 64);
+	return v;
+}
+
+// (z0, z2, z1') of a Karatsuba level -> the product, for 32-bit pieces: T_6 element from T_5 parts
+// lo = z0 + z2 ; hi = z1' + z0 + z2 + z2 * X_4      (pairwise_recursive_arithmetic.rs:18-28)
+__device__ __forceinline__ uint64_t combine32(uint32_t z0, uint32_t z2, uint32_t z1p)
+{
+	const uint32_t lo = z0 ^ z2;
+	const uint32_t hi = z1p ^ lo ^ (uint32_t)mulx64<4>((uint64_t)z2);
+	return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+
+__device__ __forceinline__ f128 combine64(uint64_t Z0, uint64_t Z2, uint64_t Z1p)
+{
+	const uint64_t lo = Z0 ^ Z2;
+	return f128{lo, Z1p ^ lo ^ mulx64<5>(Z2)};
+}
+
+} // namespace
+
+// SPLIT == false: rows 16..31 come from the lo arrays and planes become [hi | lo^hi]
+// SPLIT == true : rows 16..31 come from the same arrays at +split_off and planes stay [x | y]
+//                 (a plain sum of products over 2n elements, both halves of the register busy)
+template <bool SPLIT>
+__global__ __launch_bounds__(256, 2) void k_roundeval9(const uint32_t *__restrict__ a_hi, const uint32_t *__restrict__ a_lo,
+                                                      const uint32_t *__restrict__ b_hi, const uint32_t *__restrict__ b_lo,
+                                                      uint64_t n, f128 *out)
+{
+	__shared__ uint4 tile[4][kWaveQ];
+	__shared__ uint32_t red[4][2][9][8];
+	__shared__ uint64_t wsum[4][4];
+
+	const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const unsigned g = lane / 9, c = lane - g * 9;
+	const bool live = lane < 63;
+	const bool loader = live && c < 8;
+	uint4 *wt = tile[wave];
+
+	// zero block (read by combination slots a lane does not use)
+	if (lane < kBlkQ)
+		wt[kZeroBlk * kBlkQ + lane] = uint4{0, 0, 0, 0};
+
+	// which words this lane loads: c = 0..3 -> a word c ; c = 4..7 -> b word c-4
+	const unsigned w = c & 3;
+	const uint32_t *p_hi = (c & 4) ? b_hi : a_hi;
+	const uint32_t *p_lo = (c & 4) ? b_lo : a_lo;
+	// combination mask over limbs 0..3
+	unsigned mask;
+	switch (c) {
+	case 0: mask = 1; break;
+	case 1: mask = 2; break;
+	case 2: mask = 3; break;
+	case 3: mask = 4; break;
+	case 4: mask = 8; break;
+	case 5: mask = 12; break;
+	case 6: mask = 5; break;
+	case 7: mask = 10; break;
+	default: mask = 15; break;
+	}
+	if (!live) mask = 0;
+	// LDS offsets (in uint4) of the four a-slots and four b-slots this lane reads
+	unsigned off_a[4], off_b[4];
+#pragma unroll
+	for (int s = 0; s < 4; s++) {
+		const bool use = (mask >> s) & 1;
+		off_a[s] = (use ? (unsigned)(s * kGroups + g) : (unsigned)kZeroBlk) * kBlkQ;
+		off_b[s] = (use ? (unsigned)((4 + s) * kGroups + g) : (unsigned)kZeroBlk) * kBlkQ;
+	}
+	const unsigned off_w = (loader ? (c * kGroups + g) : 0u) * kBlkQ; // where a loader writes its limb
+
+	uint32_t acc[32];
+#pragma unroll
+	for (int p = 0; p < 32; p++)
+		acc[p] = 0;
+
+	const uint64_t n_lane = loader ? n : 0; // non-loader lanes load nothing
+	const uint64_t n_batches = (n + kBatch - 1) / kBatch;
+	const uint64_t wave_global = (uint64_t)blockIdx.x * 4 + wave;
+	const uint64_t n_waves = (uint64_t)gridDim.x * 4;
+
+	for (uint64_t b = wave_global; b < n_batches; b += n_waves) {
+		const uint64_t base = b * kBatch + g; // point j of this group is base + 7*j
+		uint32_t r[32];
+		// one branch-free path: rows beyond n (and the rows of non-loader lanes) read index 0 and are zeroed
+#pragma unroll
+		for (int j = 0; j < 16; j++) {
+			const uint64_t e = base + 7 * j;
+			const bool ok = e < n_lane;
+			const uint64_t idx = ok ? ((e << 2) + w) : 0;
+			const uint32_t vh = p_hi[idx], vl = p_lo[idx];
+			r[j] = ok ? vh : 0u;
+			r[16 + j] = ok ? vl : 0u;
+		}
+		transpose32(r);
+		if (!SPLIT) {
+#pragma unroll
+			for (int p = 0; p < 32; p++)
+				r[p] ^= r[p] << 16;
+		}
+		// publish this limb to the wave's LDS tile
+		if (loader) {
+#pragma unroll
+			for (int q = 0; q < 8; q++)
+				wt[off_w + q] = uint4{r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]};
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		// gather the combination: A = XOR of a-limbs in `mask`, B likewise
+		uint32_t A[32], B[32];
+#pragma unroll
+		for (int q = 0; q < 8; q++) {
+			uint4 x = wt[off_a[0] + q];
+			uint4 y = wt[off_b[0] + q];
+#pragma unroll
+			for (int s = 1; s < 4; s++) {
+				const uint4 xa = wt[off_a[s] + q];
+				const uint4 yb = wt[off_b[s] + q];
+				x.x ^= xa.x; x.y ^= xa.y; x.z ^= xa.z; x.w ^= xa.w;
+				y.x ^= yb.x; y.y ^= yb.y; y.z ^= yb.z; y.w ^= yb.w;
+			}
+			A[4 * q] = x.x; A[4 * q + 1] = x.y; A[4 * q + 2] = x.z; A[4 * q + 3] = x.w;
+			B[4 * q] = y.x; B[4 * q + 1] = y.y; B[4 * q + 2] = y.z; B[4 * q + 3] = y.w;
+			__builtin_amdgcn_sched_barrier(0); // keep at most one quad's 8 reads in flight (register pressure)
+		}
+		// the tile may be overwritten by the next batch only after these reads: DS ops of a wave
+		// execute in order, the fences keep the compiler from reordering across them
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		uint32_t P[32];
+		bs_mul<5>(A, B, P);
+#pragma unroll
+		for (int p = 0; p < 32; p++)
+			acc[p] ^= P[p];
+	}
+
+	// ---- collapse: per lane two GF(2^32) partial sums (low half -> S_1 / first stream, high -> S_inf)
+	uint32_t s_lo = 0, s_hi = 0;
+#pragma unroll
+	for (int p = 0; p < 32; p++) {
+		s_lo |= (__popc(acc[p] & 0xFFFFu) & 1u) << p;
+		s_hi |= (__popc(acc[p] >> 16) & 1u) << p;
+	}
+	if (live) {
+		red[wave][0][c][g] = s_lo;
+		red[wave][1][c][g] = s_hi;
+	}
+	__syncthreads();
+	if (lane < 2) {
+		// lane q of every wave recombines stream q of that wave
+		uint32_t pc[9];
+#pragma unroll
+		for (int cc = 0; cc < 9; cc++) {
+			uint32_t v = 0;
+#pragma unroll
+			for (int gg = 0; gg < kGroups; gg++)
+				v ^= red[wave][lane][cc][gg];
+			pc[cc] = v;
+		}
+		const uint64_t Z0 = combine32(pc[0], pc[1], pc[2]);
+		const uint64_t Z2 = combine32(pc[3], pc[4], pc[5]);
+		const uint64_t Z1p = combine32(pc[6], pc[7], pc[8]);
+		const f128 S = combine64(Z0, Z2, Z1p);
+		wsum[wave][2 * lane] = S.lo;
+		wsum[wave][2 * lane + 1] = S.hi;
+	}
+	__syncthreads();
+	if (threadIdx.x < 4) {
+		const uint64_t v = wsum[0][threadIdx.x] ^ wsum[1][threadIdx.x] ^ wsum[2][threadIdx.x] ^ wsum[3][threadIdx.x];
+		if (v)
+			atomicXor(reinterpret_cast<unsigned long long *>(out) + threadIdx.x, (unsigned long long)v);
+	}
+}
+
+static unsigned grid9(uint64_t n, int n_cu)
+{
+	const uint64_t n_batches = (n + kBatch - 1) / kBatch;
+	uint64_t blocks = (n_batches + 3) / 4;
+	if (blocks < 1) blocks = 1;
+	const uint64_t cap = (uint64_t)n_cu * 2; // two 256-thread blocks per CU = 2 waves per SIMD
+	return (unsigned)(blocks < cap ? blocks : cap);
+}
+
+// d_out[0] ^= sum_i a_hi[i]*b_hi[i] ; d_out[1] ^= sum_i (a_lo[i]^a_hi[i])*(b_lo[i]^b_hi[i])
+hipError_t launch_roundeval9_pair(hipStream_t s, int n_cu, const void *a_hi, const void *a_lo, const void *b_hi,
+                                  const void *b_lo, uint64_t n, f128 *d_out)
+{
+	if (n == 0) return hipSuccess;
+	hipLaunchKernelGGL(k_roundeval9<false>, dim3(grid9(n, n_cu)), dim3(256), 0, s, (const uint32_t *)a_hi,
+	                   (const uint32_t *)a_lo, (const uint32_t *)b_hi, (const uint32_t *)b_lo, n, d_out);
+	return hipGetLastError();
+}
+
+// d_out[0] ^= sum_{i<n} a[i]*b[i] ; d_out[1] ^= sum_{i<n} a[i+split]*b[i+split]
+hipError_t launch_roundeval9_split(hipStream_t s, int n_cu, const void *a, const void *b, uint64_t n, uint64_t split_off,
+                                   f128 *d_out)
+{
+	if (n == 0) return hipSuccess;
+	const char *a2 = (const char *)a + split_off * 16, *b2 = (const char *)b + split_off * 16;
+	hipLaunchKernelGGL(k_roundeval9<true>, dim3(grid9(n, n_cu)), dim3(256), 0, s, (const uint32_t *)a, (const uint32_t *)a2,
+	                   (const uint32_t *)b, (const uint32_t *)b2, n, d_out);
+	return hipGetLastError();
+}
+
+} // namespace bn
