@@ -22,41 +22,54 @@ namespace bn {
 // ---- 32x32 bit-matrix transpose, in registers --------------------------------------------------
 // in : r[e] = 32-bit word of element e            (row e, column = bit index)
 // out: r[p] = plane p, bit e = bit p of element e
+// (a & m) | (b & ~m) in one v_bitop3_b32 (truth table: src0=0xF0, src1=0xCC, src2=0xAA)
+__device__ __forceinline__ uint32_t bitsel(uint32_t a, uint32_t b, uint32_t m)
+{
+	return __builtin_amdgcn_bitop3_b32(a, b, m, 0xE4);
+}
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c)
+{
+	return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+}
+
 __device__ __forceinline__ void transpose32(uint32_t (&r)[32])
 {
+	// j = 16 and j = 8 move whole bytes: one v_perm_b32 per output (selector byte k picks byte k of
+	// the result from {src0 = bytes 7..4, src1 = bytes 3..0})
 #pragma unroll
-	for (int k = 0; k < 16; k++) { // j = 16: halves are whole 16-bit lanes -> v_perm_b32 / v_alignbit
-		uint32_t a = r[k], b = r[k + 16];
-		r[k] = (a & 0x0000FFFFu) | (b << 16);
-		r[k + 16] = (a >> 16) | (b & 0xFFFF0000u);
+	for (int k = 0; k < 16; k++) {
+		const uint32_t a = r[k], b = r[k + 16];
+		r[k] = __builtin_amdgcn_perm(b, a, 0x05040100u);      // (a & 0xFFFF) | (b << 16)
+		r[k + 16] = __builtin_amdgcn_perm(b, a, 0x07060302u); // (a >> 16) | (b & 0xFFFF0000)
 	}
 #pragma unroll
 	for (int k = 0; k < 32; k++) {
 		if (k & 8) continue;
-		uint32_t a = r[k], b = r[k + 8];
-		r[k] = (a & 0x00FF00FFu) | ((b << 8) & 0xFF00FF00u);
-		r[k + 8] = ((a >> 8) & 0x00FF00FFu) | (b & 0xFF00FF00u);
+		const uint32_t a = r[k], b = r[k + 8];
+		r[k] = __builtin_amdgcn_perm(b, a, 0x06020400u);     // bytes a0 b0 a2 b2
+		r[k + 8] = __builtin_amdgcn_perm(b, a, 0x07030501u); // bytes a1 b1 a3 b3
 	}
+	// j = 4, 2, 1: shift + one 3-input bit select per output
 #pragma unroll
 	for (int k = 0; k < 32; k++) {
 		if (k & 4) continue;
-		uint32_t a = r[k], b = r[k + 4];
-		r[k] = (a & 0x0F0F0F0Fu) | ((b << 4) & 0xF0F0F0F0u);
-		r[k + 4] = ((a >> 4) & 0x0F0F0F0Fu) | (b & 0xF0F0F0F0u);
+		const uint32_t a = r[k], b = r[k + 4];
+		r[k] = bitsel(a, b << 4, 0x0F0F0F0Fu);
+		r[k + 4] = bitsel(a >> 4, b, 0x0F0F0F0Fu);
 	}
 #pragma unroll
 	for (int k = 0; k < 32; k++) {
 		if (k & 2) continue;
-		uint32_t a = r[k], b = r[k + 2];
-		r[k] = (a & 0x33333333u) | ((b << 2) & 0xCCCCCCCCu);
-		r[k + 2] = ((a >> 2) & 0x33333333u) | (b & 0xCCCCCCCCu);
+		const uint32_t a = r[k], b = r[k + 2];
+		r[k] = bitsel(a, b << 2, 0x33333333u);
+		r[k + 2] = bitsel(a >> 2, b, 0x33333333u);
 	}
 #pragma unroll
 	for (int k = 0; k < 32; k++) {
 		if (k & 1) continue;
-		uint32_t a = r[k], b = r[k + 1];
-		r[k] = (a & 0x55555555u) | ((b << 1) & 0xAAAAAAAAu);
-		r[k + 1] = ((a >> 1) & 0x55555555u) | (b & 0xAAAAAAAAu);
+		const uint32_t a = r[k], b = r[k + 1];
+		r[k] = bitsel(a, b << 1, 0x55555555u);
+		r[k + 1] = bitsel(a >> 1, b, 0x55555555u);
 	}
 }
 
@@ -110,7 +123,7 @@ __device__ __forceinline__ void bs_mul(const uint32_t *a, const uint32_t *b, uin
 		for (int i = 0; i < H; i++) {
 			uint32_t lo = z0[i] ^ z2[i];
 			out[i] = lo;
-			out[H + i] = z1[i] ^ lo ^ za[i];
+			out[H + i] = xor3(z1[i], lo, za[i]); // one v_bitop3_b32
 		}
 	}
 }
