@@ -63,7 +63,6 @@ def main():
         torch.cuda.set_device(local_rank)
 
     import binius_amd
-    from binius_amd.sumcheck import bivariate_product_expr, calculate_round_coeffs_from_evals
     from binius_amd.distributed import ShardedRoundReducer
 
     n_vars, m = args.n_vars, 2
@@ -88,45 +87,26 @@ def main():
         del host
     stream = oracle.random_scalars(0xC4A1, n_vars + log_world + 1)
     batch_coeff, challenges = stream[0], stream[1:]
-    expr = bivariate_product_expr(hal, 0, 1)
     F = binius_amd.HostField
     reducer = ShardedRoundReducer(hal, dist, world) if world > 1 else None
 
-    def evaluate_univariate(coeffs, x):
-        e = 0
-        for c in reversed(coeffs):
-            e = F.mul(e, x) ^ c
-        return e
+    # The prover loop runs in the compiled C++ host mirror (binius_amd/host/sumcheck.hpp behind
+    # libbinius_amd_host.so): per round one accumulate_kernels, two scalar multiplications and one
+    # extrapolate_line per multilinear through the C ABI -- what a Rust host would do, without
+    # interpreter time between HAL calls.
+    from binius_amd._host import SumcheckPlan
 
-    from binius_amd.sumcheck import calculate_round_evals
+    scratch = alloc.alloc(m * (n // 2))
+    reduce_cb = None
+    d_partial = 0
+    if reducer is not None:
+        d_partial = reducer.local.data_ptr()
 
-    def one_sumcheck(claim):
-        """execute/fold loop of BivariateSumcheckProver (v3/bivariate_product.rs:133-232)."""
-        scope = alloc.subscope_allocator()
-        mls = list(d_in)
-        pre = True
-        running = claim
-        for r in range(n_vars):
-            rem = n_vars - r
-            if reducer is None:
-                evals = calculate_round_evals(hal, rem, [1], mls, [expr])
-            else:
-                evals = reducer.round_evals(rem, mls, expr)
-            coeffs = calculate_round_coeffs_from_evals(running, evals)
-            z = challenges[r]
-            running = evaluate_univariate(coeffs, z)
-            nxt = []
-            for ml in mls:
-                e0, e1 = ml.split_half()
-                if pre:
-                    f = scope.alloc(e0.len)
-                    hal.copy_d2d(e0, f)
-                    e0 = f
-                hal.extrapolate_line(e0, e1, z)
-                nxt.append(e0)
-            mls = nxt
-            pre = False
-        return running, mls
+        def reduce_cb(_user, _d_partial, evals):
+            vals = reducer.gather_local()
+            for k in range(2):
+                evals[k] = binius_amd._ffi.to_f128(vals[k])
+            return 0
 
     # the claimed sum (not timed): inner product on the device, combined across ranks
     claim = hal.inner_product(d_in[0], 7, d_in[1])
@@ -138,13 +118,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    plan = SumcheckPlan(hal, n_vars, d_in, scratch, [(0, 1)], [claim], batch_coeff, challenges[:n_vars], reduce_cb, d_partial)
     for _ in range(args.warmup):
-        one_sumcheck(claim)
+        plan.run()
     barrier()
     hal.prof_begin()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        running, final = one_sumcheck(claim)
+        plan.run()
     barrier()
     t1 = time.perf_counter()
     prof = hal.prof_end()
@@ -157,11 +138,13 @@ def main():
     # correctness of what was timed (N = 1: the sumcheck verifier's final check, on the device values)
     ok = True
     if world == 1:
-        fa = hal.copy_d2h(final[0])
-        fb = hal.copy_d2h(final[1])
-        ia = int(fa[0, 0]) | (int(fa[0, 1]) << 64)
-        ib = int(fb[0, 0]) | (int(fb[0, 1]) << 64)
-        ok = F.mul(ia, ib) == running
+        # sumcheck verifier: P_r(0) + P_r(1) == running sum every round, final product == last sum
+        running = claim
+        for r, (c0, c1, c2) in enumerate(plan.round_coeffs()):
+            ok = ok and (c0 ^ (c0 ^ c1 ^ c2)) == running
+            running = F.mul(F.mul(c2, challenges[r]) ^ c1, challenges[r]) ^ c0
+        fa, fb = plan.final_evals()
+        ok = ok and F.mul(fa, fb) == running
 
     total_elems = m * n * world
     value = total_elems * args.steps / elapsed
@@ -175,7 +158,7 @@ def main():
     re_ms, re_cnt = prof["round_eval"]
     fo_ms, fo_cnt = prof["fold"]
     kernels = {
-        "k_bs_prodsum(round_eval)": (re_bytes, re_ms, re_cnt),
+        "k_roundeval9(round_eval)": (re_bytes, re_ms, re_cnt),
         "k_extrapolate_line(fold)": (fold_bytes, fo_ms, fo_cnt),
     }
     dom = max(kernels, key=lambda k: kernels[k][1])

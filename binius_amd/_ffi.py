@@ -108,6 +108,7 @@ def lib():
         "bn_expr_free": [vp],
         "bn_expr_n_vars": [vp, C.POINTER(u32)],
         "bn_extrapolate_line": [vp, vp, u64, vp, u64, PF],
+        "bn_extrapolate_line_batch": [vp, C.POINTER(vp), C.POINTER(vp), u32, u64, PF],
         "bn_tensor_expand": [vp, vp, u64, u32, PF, u32],
         "bn_inner_product": [vp, vp, u64, u32, vp, u64, PF],
         "bn_fold_left": [vp, vp, u64, u32, vp, u64, vp, u64],
@@ -141,7 +142,7 @@ def lib():
 ABI_SYMBOLS = [
     "bn_last_error", "bn_version", "bn_ctx_create", "bn_ctx_destroy", "bn_arena_base", "bn_ctx_set_stream", "bn_sync",
     "bn_copy_h2d", "bn_copy_d2h", "bn_copy_d2d", "bn_fill", "bn_expr_compile", "bn_expr_free", "bn_expr_n_vars",
-    "bn_extrapolate_line", "bn_tensor_expand", "bn_inner_product", "bn_fold_left", "bn_fold_right", "bn_fri_fold",
+    "bn_extrapolate_line", "bn_extrapolate_line_batch", "bn_tensor_expand", "bn_inner_product", "bn_fold_left", "bn_fold_right", "bn_fri_fold",
     "bn_compute_composite", "bn_pairwise_product_reduce", "bn_log_chunks_range", "bn_pick_log_chunks",
     "bn_kernel_launch", "bn_ntt_forward", "bn_ntt_inverse", "bn_ntt_s_evals", "bn_scalar_mul", "bn_scalar_invert",
     "bn_timer_begin", "bn_timer_end_ms", "bn_prof_begin", "bn_prof_end",

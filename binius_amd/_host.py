@@ -1,0 +1,66 @@
+"""ctypes binding of libbinius_amd_host.so -- the compiled C++ host mirror
+(binius_amd/host/{compute_layer,sumcheck}.hpp): a whole BivariateSumcheckProver run behind one C
+call, i.e. the prover loop driven at compiled-host speed over the same C ABI."""
+import ctypes as C
+import os
+
+from ._ffi import F128, BnError, _f128_array, from_f128, lib, to_f128
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libbinius_amd_host.so")
+_lib = None
+
+REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(F128))
+
+
+def host_lib():
+    global _lib
+    if _lib is None:
+        lib()  # libbinius_amd.so first (dependency, resolved through rpath as well)
+        if not os.path.exists(_SO):
+            raise ImportError("binius_amd: %s is missing -- run __graft_entry__.build()" % _SO)
+        L = C.CDLL(_SO)
+        L.bnh_last_error.restype = C.c_char_p
+        L.bnh_bivariate_sumcheck_prove.restype = C.c_int
+        L.bnh_bivariate_sumcheck_prove.argtypes = [
+            C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p), C.c_void_p, C.c_uint64, C.c_uint32,
+            C.POINTER(C.c_uint32), C.POINTER(F128), C.POINTER(F128), C.POINTER(F128), C.POINTER(F128), C.POINTER(F128),
+            REDUCE_FN, C.c_void_p, C.c_void_p,
+        ]
+        _lib = L
+    return _lib
+
+
+class SumcheckPlan:
+    """Pre-marshalled arguments of one prove so repeated runs have no per-call Python work."""
+
+    def __init__(self, hal, n_vars, multilins, scratch, comps, sums, batch_coeff, challenges, reduce=None, d_partial=0):
+        self.hal = hal
+        self.n_vars = n_vars
+        self.m = len(multilins)
+        self.ptrs = (C.c_void_p * self.m)(*[s.ptr for s in multilins])
+        self.scratch = scratch
+        flat = [i for pair in comps for i in pair]
+        self.n_comps = len(comps)
+        self.comps = (C.c_uint32 * max(1, len(flat)))(*flat)
+        self.sums = _f128_array(list(sums))
+        self.bc = to_f128(batch_coeff)
+        self.ch = _f128_array(list(challenges))
+        self.coeffs = (F128 * (3 * n_vars))()
+        self.final = (F128 * self.m)()
+        self.reduce = REDUCE_FN(reduce) if reduce is not None else C.cast(None, REDUCE_FN)
+        self.d_partial = d_partial
+
+    def run(self):
+        rc = host_lib().bnh_bivariate_sumcheck_prove(
+            self.hal._h, self.n_vars, self.m, self.ptrs, self.scratch.ptr, self.scratch.len, self.n_comps, self.comps,
+            self.sums, C.byref(self.bc), self.ch, self.coeffs, self.final, self.reduce, None, self.d_partial,
+        )
+        if rc != 0:
+            raise BnError(rc, host_lib().bnh_last_error().decode())
+
+    def round_coeffs(self):
+        return [[from_f128(self.coeffs[3 * r + i]) for i in range(3)] for r in range(self.n_vars)]
+
+    def final_evals(self):
+        return [from_f128(self.final[j]) for j in range(self.m)]

@@ -135,6 +135,11 @@ int bn_ctx_create(int device, uint64_t arena_elems, bn_ctx **out)
 	BN_HIP(hipEventCreate(&ctx->ev1));
 	BN_HIP(hipMalloc((void **)&ctx->d_result, sizeof(f128) * bn::kResultSlots));
 	BN_HIP(hipHostMalloc((void **)&ctx->h_result, sizeof(f128) * bn::kResultSlots, hipHostMallocDefault));
+	BN_HIP(hipHostMalloc((void **)&ctx->h_mail, sizeof(f128) * 128, hipHostMallocMapped | hipHostMallocCoherent));
+	std::memset(ctx->h_mail, 0, sizeof(f128) * 128);
+	BN_HIP(hipHostGetDevicePointer((void **)&ctx->d_mail, ctx->h_mail, 0));
+	BN_HIP(hipMemset(ctx->d_result, 0, sizeof(f128) * bn::kResultSlots));
+	ctx->s_clean = true;
 	if (arena_elems) {
 		hipError_t e = hipMalloc(&ctx->arena, arena_elems * sizeof(f128));
 		if (e != hipSuccess) {
@@ -158,6 +163,7 @@ int bn_ctx_destroy(bn_ctx *ctx)
 	if (ctx->scratch) hipFree(ctx->scratch);
 	if (ctx->d_result) hipFree(ctx->d_result);
 	if (ctx->h_result) hipHostFree(ctx->h_result);
+	if (ctx->h_mail) hipHostFree(ctx->h_mail);
 	if (ctx->ev0) hipEventDestroy(ctx->ev0);
 	if (ctx->ev1) hipEventDestroy(ctx->ev1);
 	for (auto &r : ctx->prof) {
@@ -379,6 +385,22 @@ int bn_extrapolate_line(bn_ctx *ctx, void *d_evals_0, uint64_t n0, const void *d
 	return BN_OK;
 }
 
+int bn_extrapolate_line_batch(bn_ctx *ctx, void *const *d_evals_0, const void *const *d_evals_1, uint32_t count, uint64_t n,
+                              const bn_f128 *z)
+{
+	BN_REQUIRE(ctx && z && d_evals_0 && d_evals_1, "null argument");
+	BN_REQUIRE(count <= (uint32_t)bn::kFoldBatchMax, "too many slices in one extrapolate_line batch");
+	if (count == 0) return BN_OK;
+	bn::fold_batch fb{};
+	for (uint32_t i = 0; i < count; i++) {
+		fb.x0[i] = d_evals_0[i];
+		fb.x1[i] = d_evals_1[i];
+	}
+	prof_scope ps(ctx, BN_PROF_FOLD);
+	BN_HIP(bn::launch_extrapolate_line_batch(ctx->stream, ctx->n_cu, fb, count, n, to_f(z)));
+	return BN_OK;
+}
+
 int bn_tensor_expand(bn_ctx *ctx, void *d_data, uint64_t data_len, uint32_t log_n, const bn_f128 *h_coords, uint32_t k)
 {
 	BN_REQUIRE(ctx, "null ctx");
@@ -403,6 +425,7 @@ int bn_inner_product(bn_ctx *ctx, const void *d_a, uint64_t a_len, uint32_t towe
 	BN_REQUIRE(ctx && h_out, "null argument");
 	BN_REQUIRE(tower_level <= 7 && (a_len << (7 - tower_level)) == b_len, "invalid input: inner_product lengths");
 	BN_REQUIRE(valid_tower_level(tower_level), "unsupported value of tower_level");
+	ctx->s_clean = false; // slot 0 of the accumulator area is used as this op's accumulator
 	BN_HIP(hipMemsetAsync(ctx->d_result, 0, sizeof(f128), ctx->stream));
 	BN_HIP(bn::launch_inner_product(ctx->stream, ctx->n_cu, d_a, tower_level, d_b, b_len, ctx->d_result));
 	return read_result(ctx, 1, h_out);
@@ -670,7 +693,9 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 	uint32_t n_slots = 0;
 	f128 *d_S = ctx->d_result;         // [0,64)
 	f128 *d_rets = ctx->d_result + 96;  // [96,128)
-	BN_HIP(hipMemsetAsync(d_S, 0, 64 * sizeof(f128), s));
+	if (!ctx->s_clean)
+		BN_HIP(hipMemsetAsync(d_S, 0, 64 * sizeof(f128), s));
+	ctx->s_clean = false; // until the finalize kernel of THIS call has re-zeroed the slots it used
 
 	for (uint32_t o = 0; o < n_ops; o++) {
 		const bn_kop &op = ops[o];
@@ -865,12 +890,29 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 	for (size_t t = 0; t < terms.size(); t++) fa.terms[t] = terms[t];
 	for (uint32_t v = 0; v < n_values; v++) fa.init[v] = h_values[v];
 	for (uint32_t r = 0; r < n_ret; r++) fa.ret_ids[r] = ret_values[r];
+	fa.n_slots = n_slots;
+	fa.seq = h_out ? ++ctx->mail_seq : 0;
 	f128 *rets = d_out ? (f128 *)d_out : d_rets;
-	BN_HIP(bn::launch_finalize(s, fa, d_S, rets));
+	BN_HIP(bn::launch_finalize(s, fa, d_S, rets, ctx->d_mail));
+	ctx->s_clean = true; // stream-ordered: the next launch on this stream sees zeroed slots
 	if (h_out) {
-		BN_HIP(hipMemcpyAsync(ctx->h_result, rets, n_ret * sizeof(f128), hipMemcpyDeviceToHost, s));
-		BN_HIP(hipStreamSynchronize(s));
-		std::memcpy(h_out, ctx->h_result, n_ret * sizeof(f128));
+		// spin on the sequence word the kernel publishes after the values (fine-grained host memory)
+		volatile uint64_t *seqw = &ctx->h_mail[64].lo;
+		const uint64_t want = fa.seq;
+		uint64_t spins = 0;
+		while (__atomic_load_n(seqw, __ATOMIC_ACQUIRE) != want) {
+			if (++spins > (1ull << 22)) {
+				// not there yet: fall back to a stream sync so device errors surface instead of hanging
+				BN_HIP(hipStreamSynchronize(s));
+				if (__atomic_load_n(seqw, __ATOMIC_ACQUIRE) != want)
+					return bn::fail(BN_ERR_DEVICE, "device error: result mailbox was not published");
+				break;
+			}
+		}
+		for (uint32_t r = 0; r < n_ret; r++) {
+			h_out[r].lo = __atomic_load_n(&ctx->h_mail[r].lo, __ATOMIC_RELAXED);
+			h_out[r].hi = __atomic_load_n(&ctx->h_mail[r].hi, __ATOMIC_RELAXED);
+		}
 	}
 	return BN_OK;
 }

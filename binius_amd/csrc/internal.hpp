@@ -31,6 +31,12 @@ struct bn_ctx {
 	size_t scratch_bytes = 0;
 	bn::f128 *d_result = nullptr; // small result mailbox (256 elements)
 	bn::f128 *h_result = nullptr; // pinned host mirror
+	// zero-copy return path: kernels write returned scalars straight into fine-grained pinned host
+	// memory and publish a sequence number; the host spins on it instead of memcpy + stream sync
+	bn::f128 *h_mail = nullptr;        // host view   [0..64) values, slot 64 = sequence word
+	bn::f128 *d_mail = nullptr;        // device view of the same memory
+	uint64_t mail_seq = 0;
+	bool s_clean = false;              // accumulator slots d_result[0..64) known to be zero
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	int n_cu = 256;
 	// per-class kernel timing (bn_prof_begin / bn_prof_end)
@@ -64,6 +70,12 @@ hipError_t launch_fill(hipStream_t s, void *dst, uint64_t n, f128 v);
 hipError_t launch_add_assign(hipStream_t s, void *dst, const void *src, uint64_t n);
 hipError_t launch_add(hipStream_t s, void *dst, const void *src1, const void *src2, uint64_t n);
 hipError_t launch_extrapolate_line(hipStream_t s, int n_cu, void *evals_0, const void *evals_1, uint64_t n, f128 z);
+constexpr int kFoldBatchMax = 8;
+struct fold_batch {
+	void *x0[kFoldBatchMax];
+	const void *x1[kFoldBatchMax];
+};
+hipError_t launch_extrapolate_line_batch(hipStream_t s, int n_cu, const fold_batch &b, uint32_t count, uint64_t n, f128 z);
 hipError_t launch_tensor_expand_pass(hipStream_t s, int n_cu, void *data, uint64_t half, f128 r);
 
 // ---- kernels_roundeval.hip
@@ -80,13 +92,14 @@ hipError_t launch_roundeval_product(hipStream_t s, int n_cu, const void *const *
 constexpr int kFinMaxTerms = 32, kFinMaxValues = 8, kFinMaxRets = 8;
 // passed BY VALUE as a kernel argument: no host->device staging copy on the per-round path
 struct fin_args {
-	uint32_t n_terms, n_values, n_ret, pad;
+	uint32_t n_terms, n_values, n_ret, n_slots; // n_slots accumulator slots are re-zeroed after use
+	uint64_t seq;                                // != 0: publish rets + seq to the host mailbox
 	fin_term terms[kFinMaxTerms];
 	f128 init[kFinMaxValues];
 	uint32_t ret_ids[kFinMaxRets];
 };
 // values[v] = init[v] ^ XOR_t coeff_t * S[slot_t], then rets[i] = values[ret_ids[i]]
-hipError_t launch_finalize(hipStream_t s, const fin_args &args, const f128 *d_S, f128 *d_rets);
+hipError_t launch_finalize(hipStream_t s, const fin_args &args, f128 *d_S, f128 *d_rets, f128 *d_mail);
 // raw (unscaled) sums S1 = sum_i a[half+i]*b[half+i], Sinf = sum_i (a[i]+a[half+i])*(b[i]+b[half+i])
 // XOR-accumulated into d_out[0], d_out[1] (caller zeroes them first).
 hipError_t launch_roundeval_product2(hipStream_t s, int n_cu, const void *a, const void *b, uint64_t half, f128 *d_out);

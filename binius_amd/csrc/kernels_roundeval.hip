@@ -320,7 +320,7 @@ hipError_t launch_compute_composite_generic(hipStream_t s, const void *const *d_
 
 // ---- finalize: value[v] = init ^ XOR_t coeff_t * S[slot_t]; rets gathered ---------------------
 // one block of 128 lanes; lane i contributes bit_i(S) ? coeff * 2^i : 0 (gf128.hpp mul_basis)
-__global__ __launch_bounds__(128) void k_finalize(fin_args a, const f128 *S, f128 *rets)
+__global__ __launch_bounds__(128) void k_finalize(fin_args a, f128 *S, f128 *rets, f128 *mail)
 {
 	__shared__ uint64_t red[2][2];
 	__shared__ f128 values[kFinMaxValues];
@@ -358,11 +358,26 @@ __global__ __launch_bounds__(128) void k_finalize(fin_args a, const f128 *S, f12
 	__syncthreads();
 	if (tid < a.n_ret)
 		rets[tid] = values[a.ret_ids[tid]];
+	// leave the accumulator slots zero for the next launch (no memset on the per-round path)
+	if (tid < a.n_slots)
+		S[tid] = f128_zero();
+	if (a.seq) {
+		// zero-copy return: values, then the sequence word, into fine-grained host memory
+		if (tid < a.n_ret) {
+			const f128 v = values[a.ret_ids[tid]];
+			__hip_atomic_store(&mail[tid].lo, v.lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			__hip_atomic_store(&mail[tid].hi, v.hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		}
+		__threadfence_system();
+		__syncthreads();
+		if (tid == 0)
+			__hip_atomic_store(&mail[64].lo, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+	}
 }
 
-hipError_t launch_finalize(hipStream_t s, const fin_args &args, const f128 *d_S, f128 *d_rets)
+hipError_t launch_finalize(hipStream_t s, const fin_args &args, f128 *d_S, f128 *d_rets, f128 *d_mail)
 {
-	hipLaunchKernelGGL(k_finalize, dim3(1), dim3(128), 0, s, args, d_S, d_rets);
+	hipLaunchKernelGGL(k_finalize, dim3(1), dim3(128), 0, s, args, d_S, d_rets, d_mail);
 	return hipGetLastError();
 }
 

@@ -69,6 +69,35 @@ __global__ __launch_bounds__(256) void k_extrapolate_line(uint4 *__restrict__ x0
 	}
 }
 
+// the same over `count` (evals_0, evals_1) pairs of equal length in one launch: blockIdx.y picks the
+// pair.  This is what an executor `map` scope over the multilinears of a fold becomes
+// (v3/bivariate_product.rs:217-228) -- one launch per round instead of one per multilinear.
+template <int U>
+__global__ __launch_bounds__(256) void k_extrapolate_line_batch(fold_batch fb, uint64_t n, f128 z)
+{
+	__shared__ ctable_smem tab;
+	ctable_build(tab, z);
+	uint4 *__restrict__ x0 = (uint4 *)fb.x0[blockIdx.y];
+	const uint4 *__restrict__ x1 = (const uint4 *)fb.x1[blockIdx.y];
+	const uint64_t stride = (uint64_t)gridDim.x * 256;
+	uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+	for (; i + (U - 1) * stride < n; i += U * stride) {
+		uint4 a[U], b[U];
+#pragma unroll
+		for (int u = 0; u < U; u++) {
+			a[u] = x0[i + u * stride];
+			b[u] = x1[i + u * stride];
+		}
+#pragma unroll
+		for (int u = 0; u < U; u++)
+			x0[i + u * stride] = xor4(a[u], ctable_mul(tab, xor4(a[u], b[u])));
+	}
+	for (; i < n; i += stride) {
+		uint4 a = x0[i], b = x1[i];
+		x0[i] = xor4(a, ctable_mul(tab, xor4(a, b)));
+	}
+}
+
 // one tensor_expand pass: p = x[h]*r ; x[h] -= p ; x[half+h] = p
 // (crates/compute/src/layer.rs:269-296; "y = prod" as in crates/math/src/tensor_prod_eq_ind.rs:35-77)
 __global__ __launch_bounds__(256) void k_tensor_expand_pass(uint4 *__restrict__ x, uint64_t half, f128 r)
@@ -118,6 +147,21 @@ hipError_t launch_extrapolate_line(hipStream_t s, int n_cu, void *evals_0, const
 	} else {
 		unsigned g = grid_for(n, 256, n_cu, 8);
 		hipLaunchKernelGGL(k_extrapolate_line<1>, dim3(g), dim3(256), 0, s, (uint4 *)evals_0, (const uint4 *)evals_1, n, z);
+	}
+	return hipGetLastError();
+}
+
+hipError_t launch_extrapolate_line_batch(hipStream_t s, int n_cu, const fold_batch &b, uint32_t count, uint64_t n, f128 z)
+{
+	if (n == 0 || count == 0) return hipSuccess;
+	if (n >= (1u << 16)) {
+		unsigned g = grid_for(n, 256 * 2, n_cu, 8);
+		g = (g + count - 1) / count;
+		if (g < 1) g = 1;
+		hipLaunchKernelGGL(k_extrapolate_line_batch<2>, dim3(g, count), dim3(256), 0, s, b, n, z);
+	} else {
+		unsigned g = grid_for(n, 256, n_cu, 8);
+		hipLaunchKernelGGL(k_extrapolate_line_batch<1>, dim3(g, count), dim3(256), 0, s, b, n, z);
 	}
 	return hipGetLastError();
 }

@@ -44,6 +44,11 @@ class ShardedRoundReducer:
         host = self.gathered.cpu().numpy()
         return self._fold_xor(host, 2, self.world)
 
+    def gather_local(self):
+        """Combine the partial (y_1, y_inf) a kernel just left in `self.local` (same stream)."""
+        self.dist.all_gather_into_tensor(self.gathered, self.local)
+        return self._fold_xor(self.gathered.cpu().numpy(), 2, self.world)
+
     def xor_scalars(self, scalars):
         """XOR-combine one field element per rank (e.g. the claimed sum)."""
         out = []

@@ -1,0 +1,138 @@
+// binius_amd/host/host_capi.cpp -> libbinius_amd_host.so
+//
+// The compiled form of the C++ host mirror (compute_layer.hpp / sumcheck.hpp): a complete
+// BivariateSumcheckProver run behind one C call, so the benchmark times the prover loop the way a
+// compiled (Rust) host would drive the HAL -- per round: one accumulate_kernels, two scalar
+// multiplications, one extrapolate_line per multilinear -- without interpreter overhead between
+// HAL calls.  Links only against the C ABI of include/binius_amd.h.
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "sumcheck.hpp"
+
+using namespace binius_amd;
+
+namespace {
+thread_local std::string g_err;
+}
+
+extern "C" {
+
+const char *bnh_last_error(void) { return g_err.c_str(); }
+
+// Combine hook for the sharded prover: called once per round with the device pointer holding this
+// rank's partial (y_1, y_inf) (2 field elements); must return the XOR over all ranks in `evals`.
+typedef int (*bnh_round_reduce_fn)(void *user, const void *d_partial, bn_f128 *evals);
+
+// One full prove: execute -> fold for n_vars rounds, then finish.
+//   d_multilins[m]      device pointers, 2^n_vars elements each (never modified: PreFold)
+//   d_scratch           device memory for the folded multilinears, >= m * 2^(n_vars-1) elements
+//   comp_indices        2 per composition (IndexComposition<BivariateProduct, 2>)
+//   challenges[n_vars]  stand-in for the Fiat-Shamir transcript
+//   round_coeffs_out    3 per round ; final_evals_out m
+//   reduce              NULL on a single GPU
+int bnh_bivariate_sumcheck_prove(bn_ctx *ctx, uint32_t n_vars, uint32_t m, const void *const *d_multilins, void *d_scratch,
+                                 uint64_t scratch_elems, uint32_t n_comps, const uint32_t *comp_indices, const bn_f128 *sums,
+                                 const bn_f128 *batch_coeff, const bn_f128 *challenges, bn_f128 *round_coeffs_out,
+                                 bn_f128 *final_evals_out, bnh_round_reduce_fn reduce, void *reduce_user, void *d_partial)
+{
+	try {
+		ComputeLayer hal(ctx);
+		DeviceBumpAllocator dev_alloc(FSliceMut{d_scratch, (size_t)scratch_elems});
+		std::vector<B128> host_mem(m + 4);
+		HostBumpAllocator host_alloc(HostSliceMut{host_mem.data(), host_mem.size()});
+		std::vector<FSlice> mls;
+		for (uint32_t j = 0; j < m; j++) mls.push_back(FSlice{d_multilins[j], (size_t)1 << n_vars});
+		std::vector<IndexCompositionBivariate> comps;
+		std::vector<B128> sv;
+		for (uint32_t c = 0; c < n_comps; c++) {
+			comps.push_back(IndexCompositionBivariate{m, {comp_indices[2 * c], comp_indices[2 * c + 1]}});
+			sv.emplace_back(sums[c].lo, sums[c].hi);
+		}
+		const B128 bc(batch_coeff->lo, batch_coeff->hi);
+		if (!reduce) {
+			BivariateSumcheckProver prover(hal, dev_alloc, host_alloc, n_vars, comps, sv, mls);
+			for (uint32_t r = 0; r < n_vars; r++) {
+				std::vector<B128> rc = prover.execute(bc);
+				for (size_t i = 0; i < 3 && i < rc.size(); i++) round_coeffs_out[3 * r + i] = rc[i].raw();
+				prover.fold(B128(challenges[r].lo, challenges[r].hi));
+			}
+			std::vector<B128> fin = prover.finish();
+			for (uint32_t j = 0; j < m; j++) final_evals_out[j] = fin[j].raw();
+			return 0;
+		}
+		// sharded variant: same state machine, round evals combined across ranks by `reduce`
+		std::vector<ExprEval> evaluators;
+		for (const auto &c : comps) evaluators.push_back(hal.compile_expr(c.expression()));
+		std::vector<FSliceMut> cur;
+		for (const auto &ml : mls) cur.push_back(FSliceMut{const_cast<void *>(ml.ptr), ml.len_});
+		bool pre_fold = true;
+		B128 running = evaluate_univariate(sv, bc);
+		const std::vector<B128> coeffs = powers(bc, n_comps);
+		for (uint32_t r = 0; r < n_vars; r++) {
+			const size_t rem = n_vars - r, split = rem - 1;
+			std::vector<KernelMemMap> maps;
+			for (auto &ml : cur) {
+				auto h = ComputeMemory::split_half(ComputeMemory::as_const(ml));
+				maps.push_back(KernelMemMap::chunked(h.first, 0));
+				maps.push_back(KernelMemMap::chunked(h.second, 0));
+				maps.push_back(KernelMemMap::local(split));
+			}
+			hal.execute([&](ComputeLayerExecutor &exec) {
+				exec.accumulate_kernels_to_device(
+				    [&](KernelExecutor &ke, size_t log_chunks, std::vector<KernelBuffer> &b) {
+					    const size_t lcs = split - log_chunks;
+					    KernelValue a1 = ke.decl_value(B128::ZERO());
+					    std::vector<KSlice> rows;
+					    for (uint32_t i = 0; i < m; i++) rows.push_back(b[3 * i + 1].to_ref());
+					    SlicesBatch<KSlice> e1(rows, (size_t)1 << lcs);
+					    for (uint32_t c = 0; c < n_comps; c++) ke.sum_composition_evals(e1, evaluators[c], coeffs[c], a1);
+					    for (uint32_t i = 0; i < m; i++) ke.add(lcs, b[3 * i].to_ref(), b[3 * i + 1].to_ref(), b[3 * i + 2].as_mut());
+					    KernelValue ai = ke.decl_value(B128::ZERO());
+					    rows.clear();
+					    for (uint32_t i = 0; i < m; i++) rows.push_back(b[3 * i + 2].to_ref());
+					    SlicesBatch<KSlice> ei(rows, (size_t)1 << lcs);
+					    for (uint32_t c = 0; c < n_comps; c++) ke.sum_composition_evals(ei, evaluators[c], coeffs[c], ai);
+					    return std::vector<KernelValue>{a1, ai};
+				    },
+				    maps, d_partial);
+				return std::vector<B128>{};
+			});
+			bn_f128 ev[2];
+			if (reduce(reduce_user, d_partial, ev)) throw Error(Error::CoreLibError, "round reduce callback failed");
+			std::vector<B128> rc = calculate_round_coeffs_from_evals(running, {B128(ev[0].lo, ev[0].hi), B128(ev[1].lo, ev[1].hi)});
+			for (size_t i = 0; i < 3; i++) round_coeffs_out[3 * r + i] = rc[i].raw();
+			const B128 z(challenges[r].lo, challenges[r].hi);
+			running = evaluate_univariate(rc, z);
+			for (auto &ml : cur) {
+				auto h = ComputeMemory::split_half_mut(ml);
+				FSliceMut e0 = h.first;
+				if (pre_fold) {
+					e0 = dev_alloc.alloc(h.first.len_);
+					hal.copy_d2d(ComputeMemory::as_const(h.first), e0);
+				}
+				hal.execute([&](ComputeLayerExecutor &exec) {
+					exec.extrapolate_line(e0, ComputeMemory::as_const(h.second), z);
+					return std::vector<B128>{};
+				});
+				ml = e0;
+			}
+			pre_fold = false;
+		}
+		for (uint32_t j = 0; j < m; j++) {
+			B128 v;
+			hal.copy_d2h(ComputeMemory::as_const(cur[j]), &v, 1);
+			final_evals_out[j] = v.raw();
+		}
+		return 0;
+	} catch (const Error &e) {
+		g_err = e.what();
+		return (int)e.kind();
+	} catch (const std::exception &e) {
+		g_err = e.what();
+		return BN_ERR_CORE_LIB;
+	}
+}
+
+} // extern "C"

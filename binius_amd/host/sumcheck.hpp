@@ -1,0 +1,229 @@
+// binius_amd/host/sumcheck.hpp -- C++ mirror of the reference's callers of the HAL on the measured
+// path, generic over nothing but the ComputeLayer of compute_layer.hpp:
+//
+//   ops::eq_ind_partial_eval       crates/compute/src/ops.rs:26-50
+//   calculate_round_evals          crates/core/src/protocols/sumcheck/v3/bivariate_product.rs:303-408
+//   (with eq_ind)                  crates/core/src/protocols/sumcheck/v3/bivariate_mlecheck.rs:391-520
+//   round coeffs from evals        v3/bivariate_product.rs:410-424
+//   BivariateSumcheckProver        v3/bivariate_product.rs:27-254  (execute / fold / finish)
+//   evaluate_univariate            crates/math/src/univariate.rs:264-270
+//
+// Protocol bookkeeping only; every hypercube-sized operation is a HAL call.
+#pragma once
+
+#include <stdexcept>
+#include <vector>
+
+#include "compute_layer.hpp"
+
+namespace binius_amd {
+
+inline B128 evaluate_univariate(const std::vector<B128> &coeffs, B128 x)
+{
+	B128 e = B128::ZERO();
+	for (size_t i = coeffs.size(); i-- > 0;) e = e * x + coeffs[i];
+	return e;
+}
+
+inline std::vector<B128> powers(B128 x, size_t n)
+{
+	std::vector<B128> out;
+	B128 p = B128::ONE();
+	for (size_t i = 0; i < n; i++) {
+		out.push_back(p);
+		p = p * x;
+	}
+	return out;
+}
+
+// IndexComposition<BivariateProduct, 2> {indices}: expression = var(i0) * var(i1)
+// (core/src/composition/product_composition.rs:30-32, index.rs:50-55)
+struct IndexCompositionBivariate {
+	size_t n_vars;
+	size_t indices[2];
+	ArithCircuit expression() const { return (ArithCircuit::var(0) * ArithCircuit::var(1)).remap_vars({indices[0], indices[1]}); }
+};
+
+namespace ops {
+// eq_ind_partial_eval (ops.rs:26-50)
+inline FSliceMut eq_ind_partial_eval(ComputeLayer &hal, DeviceBumpAllocator &dev_alloc, const std::vector<B128> &point)
+{
+	const size_t n_vars = point.size();
+	FSliceMut out = dev_alloc.alloc((size_t)1 << n_vars);
+	{
+		FSliceMut dev_val = ComputeMemory::slice_power_of_two_mut(out, 1);
+		hal.fill(dev_val, B128::ONE());
+	}
+	hal.execute([&](ComputeLayerExecutor &exec) {
+		exec.tensor_expand(0, point, out);
+		return std::vector<B128>{};
+	});
+	return out;
+}
+} // namespace ops
+
+// calculate_round_evals: returns {y_1, y_inf}.  eq_ind (optional) is appended as the last
+// composition variable, as the MLE-check prover does.
+inline std::vector<B128> calculate_round_evals(ComputeLayer &hal, size_t n_vars, B128 batch_coeff, const std::vector<FSlice> &multilins,
+                                               const std::vector<ExprEval> &prod_evaluators, const FSlice *eq_ind = nullptr)
+{
+	const size_t split_n_vars = n_vars - 1;
+	std::vector<KernelMemMap> kernel_mappings;
+	for (const FSlice &ml : multilins) {
+		auto halves = ComputeMemory::split_half(ml);
+		kernel_mappings.push_back(KernelMemMap::chunked(halves.first, 0));
+		kernel_mappings.push_back(KernelMemMap::chunked(halves.second, 0));
+		kernel_mappings.push_back(KernelMemMap::local(split_n_vars)); // evaluations at the extra point
+	}
+	if (eq_ind) kernel_mappings.push_back(KernelMemMap::chunked(*eq_ind, 0));
+	const std::vector<B128> batch_coeffs = powers(batch_coeff, prod_evaluators.size());
+	const size_t m = multilins.size();
+
+	return hal.execute([&](ComputeLayerExecutor &exec) {
+		return exec.accumulate_kernels(
+		    [&](KernelExecutor &local_exec, size_t log_chunks, std::vector<KernelBuffer> &buffers) {
+			    const size_t log_chunk_size = split_n_vars - log_chunks;
+			    // composite evaluations at ONE
+			    KernelValue acc_1 = local_exec.decl_value(B128::ZERO());
+			    {
+				    std::vector<KSlice> rows;
+				    for (size_t i = 0; i < m; i++) rows.push_back(buffers[i * 3 + 1].to_ref());
+				    if (eq_ind) rows.push_back(buffers.back().to_ref());
+				    SlicesBatch<KSlice> eval_1s(rows, (size_t)1 << log_chunk_size);
+				    for (size_t c = 0; c < prod_evaluators.size(); c++)
+					    local_exec.sum_composition_evals(eval_1s, prod_evaluators[c], batch_coeffs[c], acc_1);
+			    }
+			    // extrapolate to the point at infinity: evals_inf = evals_0 + evals_1
+			    for (size_t i = 0; i < m; i++)
+				    local_exec.add(log_chunk_size, buffers[3 * i].to_ref(), buffers[3 * i + 1].to_ref(), buffers[3 * i + 2].as_mut());
+			    KernelValue acc_inf = local_exec.decl_value(B128::ZERO());
+			    {
+				    std::vector<KSlice> rows;
+				    for (size_t i = 0; i < m; i++) rows.push_back(buffers[i * 3 + 2].to_ref());
+				    if (eq_ind) rows.push_back(buffers.back().to_ref());
+				    SlicesBatch<KSlice> eval_infs(rows, (size_t)1 << log_chunk_size);
+				    for (size_t c = 0; c < prod_evaluators.size(); c++)
+					    local_exec.sum_composition_evals(eval_infs, prod_evaluators[c], batch_coeffs[c], acc_inf);
+			    }
+			    return std::vector<KernelValue>{acc_1, acc_inf};
+		    },
+		    kernel_mappings);
+	});
+}
+
+// RoundCoeffs c0, c1, c2 from (sum, y_1, y_inf) (v3/bivariate_product.rs:410-424)
+inline std::vector<B128> calculate_round_coeffs_from_evals(B128 sum, const std::vector<B128> &evals)
+{
+	const B128 y_1 = evals[0], y_inf = evals[1];
+	const B128 y_0 = sum - y_1;
+	const B128 c_0 = y_0, c_2 = y_inf;
+	const B128 c_1 = y_1 - c_0 - c_2;
+	return {c_0, c_1, c_2};
+}
+
+class SumcheckError : public std::logic_error {
+public:
+	using std::logic_error::logic_error;
+};
+
+// BivariateSumcheckProver (v3/bivariate_product.rs:27-254); evaluation order High-to-Low.
+class BivariateSumcheckProver {
+public:
+	BivariateSumcheckProver(ComputeLayer &hal, DeviceBumpAllocator &dev_alloc, HostBumpAllocator &host_alloc, size_t n_vars,
+	                        const std::vector<IndexCompositionBivariate> &compositions, const std::vector<B128> &sums,
+	                        const std::vector<FSlice> &multilins)
+	    : hal_(hal), dev_alloc_(dev_alloc), host_alloc_(host_alloc), n_vars_initial_(n_vars), n_vars_remaining_(n_vars)
+	{
+		for (const auto &ml : multilins)
+			if (ml.len() != (size_t)1 << n_vars) throw SumcheckError("NumberOfVariablesMismatch");
+		for (const auto &ml : multilins) multilins_.push_back(Multilin{true, FSliceMut{const_cast<void *>(ml.ptr), ml.len_}});
+		for (const auto &c : compositions) evaluators_.push_back(hal.compile_expr(c.expression()));
+		state_ = InitialSums;
+		sums_or_coeffs_ = sums;
+	}
+	static size_t required_host_memory(size_t n_multilinears) { return n_multilinears; }
+	static size_t required_device_memory(size_t n_multilinears, size_t n_vars) { return n_multilinears * ((size_t)1 << (n_vars - 1)); }
+	size_t n_vars() const { return n_vars_initial_; }
+
+	std::vector<B128> execute(B128 batch_coeff)
+	{
+		std::vector<FSlice> mls;
+		for (const auto &m : multilins_) mls.push_back(FSlice{m.evals.ptr, m.evals.len_});
+		const std::vector<B128> round_evals = calculate_round_evals(hal_, n_vars_remaining_, batch_coeff, mls, evaluators_);
+		B128 batched_sum;
+		switch (state_) {
+		case Coeffs: throw SumcheckError("ExpectedFold");
+		case InitialSums: batched_sum = evaluate_univariate(sums_or_coeffs_, batch_coeff); break;
+		default: batched_sum = batched_sum_; break;
+		}
+		std::vector<B128> round_coeffs = calculate_round_coeffs_from_evals(batched_sum, round_evals);
+		state_ = Coeffs;
+		sums_or_coeffs_ = round_coeffs;
+		if (evaluators_.empty()) return {};
+		return round_coeffs;
+	}
+
+	void fold(B128 challenge)
+	{
+		if (n_vars_remaining_ == 0) throw SumcheckError("ExpectedFinish");
+		if (state_ != Coeffs) throw SumcheckError("ExpectedExecution");
+		batched_sum_ = evaluate_univariate(sums_or_coeffs_, challenge);
+		state_ = BatchedSum;
+		struct Args {
+			FSliceMut evals_0;
+			FSlice evals_1;
+		};
+		std::vector<Args> prepared;
+		for (auto &m : multilins_) {
+			if (m.pre_fold) {
+				auto halves = ComputeMemory::split_half(FSlice{m.evals.ptr, m.evals.len_});
+				// allocate a new buffer for the folded evaluations and copy in evals_0
+				FSliceMut folded = dev_alloc_.alloc((size_t)1 << (n_vars_remaining_ - 1));
+				hal_.copy_d2d(halves.first, folded);
+				prepared.push_back(Args{folded, halves.second});
+			} else {
+				auto halves = ComputeMemory::split_half_mut(m.evals);
+				prepared.push_back(Args{halves.first, ComputeMemory::to_const(halves.second)});
+			}
+		}
+		hal_.execute([&](ComputeLayerExecutor &exec) {
+			auto folded = exec.map(prepared.begin(), prepared.end(), [&](ComputeLayerExecutor &e, Args &a) {
+				e.extrapolate_line(a.evals_0, a.evals_1, challenge);
+				return Multilin{false, a.evals_0};
+			});
+			multilins_ = folded;
+			return std::vector<B128>{};
+		});
+		n_vars_remaining_ -= 1;
+	}
+
+	std::vector<B128> finish()
+	{
+		if (state_ == Coeffs) throw SumcheckError("ExpectedFold");
+		if (n_vars_remaining_ != 0) throw SumcheckError("ExpectedExecution");
+		HostSliceMut buffer = host_alloc_.alloc(multilins_.size());
+		for (size_t i = 0; i < multilins_.size(); i++)
+			hal_.copy_d2h(FSlice{multilins_[i].evals.ptr, multilins_[i].evals.len_}, &buffer[i], 1);
+		return std::vector<B128>(buffer.ptr, buffer.ptr + multilins_.size());
+	}
+
+	struct Multilin {
+		bool pre_fold;
+		FSliceMut evals;
+	};
+	const std::vector<Multilin> &multilins() const { return multilins_; }
+
+private:
+	enum State { Coeffs, InitialSums, BatchedSum };
+	ComputeLayer &hal_;
+	DeviceBumpAllocator &dev_alloc_;
+	HostBumpAllocator &host_alloc_;
+	size_t n_vars_initial_, n_vars_remaining_;
+	std::vector<Multilin> multilins_;
+	std::vector<ExprEval> evaluators_;
+	State state_;
+	std::vector<B128> sums_or_coeffs_;
+	B128 batched_sum_;
+};
+
+} // namespace binius_amd

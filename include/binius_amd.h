@@ -85,6 +85,11 @@ int bn_expr_n_vars(const bn_expr *expr, uint32_t *n_vars);
 /* extrapolate_line (layer.rs:421): evals_0[i] += (evals_1[i] - evals_0[i]) * z */
 int bn_extrapolate_line(bn_ctx *ctx, void *d_evals_0, uint64_t n0, const void *d_evals_1, uint64_t n1,
                         const bn_f128 *z);
+/* `count` extrapolate_line calls with the same z and length issued inside one executor `map` scope
+ * (ComputeLayerExecutor::map, layer.rs:126; the fold of all multilinears of a round,
+ * v3/bivariate_product.rs:217-228) as a single launch.  count <= 8 per call. */
+int bn_extrapolate_line_batch(bn_ctx *ctx, void *const *d_evals_0, const void *const *d_evals_1, uint32_t count, uint64_t n,
+                              const bn_f128 *z);
 /* tensor_expand (layer.rs:291): data[..2^(log_n+k)] = data[..2^log_n] (x) (1-r_0,r_0) (x) ... */
 int bn_tensor_expand(bn_ctx *ctx, void *d_data, uint64_t data_len, uint32_t log_n, const bn_f128 *h_coords,
                      uint32_t k);
