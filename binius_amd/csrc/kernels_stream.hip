@@ -38,10 +38,33 @@ __global__ __launch_bounds__(256) void k_add(uint4 *dst, const uint4 *s1, const 
 		dst[i] = xor4(s1[i], s2[i]);
 }
 
+// streaming (non-temporal) 16-byte accesses for arrays far larger than the caches
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ uint4 ld16(const uint4 *p)
+{
+	if constexpr (NT) {
+		const v4u v = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(p));
+		return uint4{v.x, v.y, v.z, v.w};
+	} else {
+		return *p;
+	}
+}
+template <bool NT>
+__device__ __forceinline__ void st16(uint4 *p, uint4 r)
+{
+	if constexpr (NT) {
+		const v4u v = {r.x, r.y, r.z, r.w};
+		__builtin_nontemporal_store(v, reinterpret_cast<v4u *>(p));
+	} else {
+		*p = r;
+	}
+}
+
 // extrapolate_line: x0[i] += (x1[i] - x0[i]) * z          (crates/compute/src/layer.rs:421,
 // semantics of crates/compute/src/cpu/layer.rs:393-408).  Algorithmic traffic: read 32 B, write
 // 16 B per output element = 24 B per input element of the multilinear being folded.
-template <int U>
+template <int U, bool NT>
 __global__ __launch_bounds__(256) void k_extrapolate_line(uint4 *__restrict__ x0, const uint4 *__restrict__ x1, uint64_t n,
                                                           f128 z)
 {
@@ -54,13 +77,13 @@ __global__ __launch_bounds__(256) void k_extrapolate_line(uint4 *__restrict__ x0
 		uint4 a[U], b[U];
 #pragma unroll
 		for (int u = 0; u < U; u++) {
-			a[u] = x0[i + u * stride];
-			b[u] = x1[i + u * stride];
+			a[u] = ld16<NT>(&x0[i + u * stride]);
+			b[u] = ld16<NT>(&x1[i + u * stride]);
 		}
 #pragma unroll
 		for (int u = 0; u < U; u++) {
 			uint4 p = ctable_mul(tab, xor4(a[u], b[u]));
-			x0[i + u * stride] = xor4(a[u], p);
+			st16<NT>(&x0[i + u * stride], xor4(a[u], p));
 		}
 	}
 	for (; i < n; i += stride) {
@@ -72,7 +95,7 @@ __global__ __launch_bounds__(256) void k_extrapolate_line(uint4 *__restrict__ x0
 // the same over `count` (evals_0, evals_1) pairs of equal length in one launch: blockIdx.y picks the
 // pair.  This is what an executor `map` scope over the multilinears of a fold becomes
 // (v3/bivariate_product.rs:217-228) -- one launch per round instead of one per multilinear.
-template <int U>
+template <int U, bool NT>
 __global__ __launch_bounds__(256) void k_extrapolate_line_batch(fold_batch fb, uint64_t n, f128 z)
 {
 	__shared__ ctable_smem tab;
@@ -85,12 +108,12 @@ __global__ __launch_bounds__(256) void k_extrapolate_line_batch(fold_batch fb, u
 		uint4 a[U], b[U];
 #pragma unroll
 		for (int u = 0; u < U; u++) {
-			a[u] = x0[i + u * stride];
-			b[u] = x1[i + u * stride];
+			a[u] = ld16<NT>(&x0[i + u * stride]);
+			b[u] = ld16<NT>(&x1[i + u * stride]);
 		}
 #pragma unroll
 		for (int u = 0; u < U; u++)
-			x0[i + u * stride] = xor4(a[u], ctable_mul(tab, xor4(a[u], b[u])));
+			st16<NT>(&x0[i + u * stride], xor4(a[u], ctable_mul(tab, xor4(a[u], b[u]))));
 	}
 	for (; i < n; i += stride) {
 		uint4 a = x0[i], b = x1[i];
@@ -138,15 +161,24 @@ hipError_t launch_add(hipStream_t s, void *dst, const void *src1, const void *sr
 	return hipGetLastError();
 }
 
+// Launch geometry measured on MI355X (tools/fold_variants.hip, profiles/r01/fold_variants.txt):
+// for HBM-resident sizes 2 blocks per CU, 2 elements in flight per lane and non-temporal accesses
+// reach 5.8-5.9 TB/s; 8 blocks per CU only 4.6-4.8 TB/s.  Working sets that still fit the 256 MiB
+// Infinity Cache (the n <= 24 rounds) are faster with the cached form and more blocks
+// (70 us vs 87 us at r = 24), so the streaming form starts at 2^25 outputs (1.5 GiB of traffic).
 hipError_t launch_extrapolate_line(hipStream_t s, int n_cu, void *evals_0, const void *evals_1, uint64_t n, f128 z)
 {
 	if (n == 0) return hipSuccess;
-	if (n >= (1u << 16)) {
+	uint4 *x0 = (uint4 *)evals_0;
+	const uint4 *x1 = (const uint4 *)evals_1;
+	if (n >= (1u << 25)) {
+		hipLaunchKernelGGL((k_extrapolate_line<2, true>), dim3(2 * n_cu), dim3(256), 0, s, x0, x1, n, z);
+	} else if (n >= (1u << 16)) {
 		unsigned g = grid_for(n, 256 * 2, n_cu, 8);
-		hipLaunchKernelGGL(k_extrapolate_line<2>, dim3(g), dim3(256), 0, s, (uint4 *)evals_0, (const uint4 *)evals_1, n, z);
+		hipLaunchKernelGGL((k_extrapolate_line<2, false>), dim3(g), dim3(256), 0, s, x0, x1, n, z);
 	} else {
 		unsigned g = grid_for(n, 256, n_cu, 8);
-		hipLaunchKernelGGL(k_extrapolate_line<1>, dim3(g), dim3(256), 0, s, (uint4 *)evals_0, (const uint4 *)evals_1, n, z);
+		hipLaunchKernelGGL((k_extrapolate_line<1, false>), dim3(g), dim3(256), 0, s, x0, x1, n, z);
 	}
 	return hipGetLastError();
 }
@@ -154,14 +186,17 @@ hipError_t launch_extrapolate_line(hipStream_t s, int n_cu, void *evals_0, const
 hipError_t launch_extrapolate_line_batch(hipStream_t s, int n_cu, const fold_batch &b, uint32_t count, uint64_t n, f128 z)
 {
 	if (n == 0 || count == 0) return hipSuccess;
-	if (n >= (1u << 16)) {
+	if (n * count >= (1u << 25)) {
+		unsigned g = (2 * n_cu + count - 1) / count;
+		hipLaunchKernelGGL((k_extrapolate_line_batch<2, true>), dim3(g, count), dim3(256), 0, s, b, n, z);
+	} else if (n >= (1u << 16)) {
 		unsigned g = grid_for(n, 256 * 2, n_cu, 8);
 		g = (g + count - 1) / count;
 		if (g < 1) g = 1;
-		hipLaunchKernelGGL(k_extrapolate_line_batch<2>, dim3(g, count), dim3(256), 0, s, b, n, z);
+		hipLaunchKernelGGL((k_extrapolate_line_batch<2, false>), dim3(g, count), dim3(256), 0, s, b, n, z);
 	} else {
 		unsigned g = grid_for(n, 256, n_cu, 8);
-		hipLaunchKernelGGL(k_extrapolate_line_batch<1>, dim3(g, count), dim3(256), 0, s, b, n, z);
+		hipLaunchKernelGGL((k_extrapolate_line_batch<1, false>), dim3(g, count), dim3(256), 0, s, b, n, z);
 	}
 	return hipGetLastError();
 }
