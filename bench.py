@@ -53,10 +53,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if world > 1:
+    force_sharded = os.environ.get("BN_FORCE_SHARDED") == "1"  # exercise the RCCL path on one GPU
+    if world > 1 or force_sharded:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     else:
@@ -88,7 +90,7 @@ def main():
     stream = oracle.random_scalars(0xC4A1, n_vars + log_world + 1)
     batch_coeff, challenges = stream[0], stream[1:]
     F = binius_amd.HostField
-    reducer = ShardedRoundReducer(hal, dist, world) if world > 1 else None
+    reducer = ShardedRoundReducer(hal, dist, world) if dist is not None else None
 
     # The prover loop runs in the compiled C++ host mirror (binius_amd/host/sumcheck.hpp behind
     # libbinius_amd_host.so): per round one accumulate_kernels, two scalar multiplications and one
@@ -97,16 +99,15 @@ def main():
     from binius_amd._host import SumcheckPlan
 
     scratch = alloc.alloc(m * (n // 2))
-    reduce_cb = None
-    d_partial = 0
+    d_partial, d_gathered, rccl = 0, 0, None
     if reducer is not None:
-        d_partial = reducer.local.data_ptr()
+        # the per-round collective is issued from the compiled host loop: ncclAllGather of the 32-byte
+        # partial on the context's stream, communicator bootstrapped over the torch process group
+        from binius_amd._host import RcclComm
 
-        def reduce_cb(_user, _d_partial, evals):
-            vals = reducer.gather_local()
-            for k in range(2):
-                evals[k] = binius_amd._ffi.to_f128(vals[k])
-            return 0
+        rccl = RcclComm(dist, rank, world)
+        d_partial = reducer.local.data_ptr()
+        d_gathered = reducer.gathered.data_ptr()
 
     # the claimed sum (not timed): inner product on the device, combined across ranks
     claim = hal.inner_product(d_in[0], 7, d_in[1])
@@ -118,14 +119,36 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    plan = SumcheckPlan(hal, n_vars, d_in, scratch, [(0, 1)], [claim], batch_coeff, challenges[:n_vars], reduce_cb, d_partial)
-    for _ in range(args.warmup):
+    plan = SumcheckPlan(hal, n_vars, d_in, scratch, [(0, 1)], [claim], batch_coeff, challenges[:n_vars], None, d_partial,
+                        rccl.handle if rccl else None, world, d_gathered)
+    tail = None
+    if reducer is not None and log_world > 0:
+        # residual instance after the local rounds: m multilinears of `world` elements (index = rank)
+        d_res = [alloc.alloc(world) for _ in range(m)]
+        res_scratch = alloc.alloc(m * max(1, world // 2))
+
+    def one_step():
         plan.run()
+        if reducer is None or log_world == 0:
+            return plan.round_coeffs, plan.final_evals
+        # last log2(G) rounds: one all_gather of the m local finals, then a tiny local sumcheck
+        per_rank = reducer.all_gather_scalars(plan.final_evals())
+        running = claim
+        for r, (c0, c1, c2) in enumerate(plan.round_coeffs()):
+            running = F.mul(F.mul(c2, challenges[r]) ^ c1, challenges[r]) ^ c0
+        for j in range(m):
+            hal.copy_h2d(binius_amd._ffi_ints_to_arr([per_rank[g][j] for g in range(world)]), d_res[j])
+        tp = SumcheckPlan(hal, log_world, d_res, res_scratch, [(0, 1)], [running], batch_coeff, challenges[n_vars : n_vars + log_world])
+        tp.run()
+        return (lambda: plan.round_coeffs() + tp.round_coeffs()), tp.final_evals
+
+    for _ in range(args.warmup):
+        one_step()
     barrier()
     hal.prof_begin()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        plan.run()
+        get_coeffs, get_finals = one_step()
     barrier()
     t1 = time.perf_counter()
     prof = hal.prof_end()
@@ -136,15 +159,15 @@ def main():
         elapsed = float(t.item())
 
     # correctness of what was timed (N = 1: the sumcheck verifier's final check, on the device values)
+    # the sumcheck verifier on what was timed (all ranks hold the same transcript):
+    # P_r(0) + P_r(1) == running sum every round, product of the final evaluations == last sum
     ok = True
-    if world == 1:
-        # sumcheck verifier: P_r(0) + P_r(1) == running sum every round, final product == last sum
-        running = claim
-        for r, (c0, c1, c2) in enumerate(plan.round_coeffs()):
-            ok = ok and (c0 ^ (c0 ^ c1 ^ c2)) == running
-            running = F.mul(F.mul(c2, challenges[r]) ^ c1, challenges[r]) ^ c0
-        fa, fb = plan.final_evals()
-        ok = ok and F.mul(fa, fb) == running
+    running = claim
+    for r, (c0, c1, c2) in enumerate(get_coeffs()):
+        ok = ok and (c0 ^ (c0 ^ c1 ^ c2)) == running
+        running = F.mul(F.mul(c2, challenges[r]) ^ c1, challenges[r]) ^ c0
+    fa, fb = get_finals()
+    ok = ok and F.mul(fa, fb) == running
 
     total_elems = m * n * world
     value = total_elems * args.steps / elapsed
@@ -205,7 +228,7 @@ def main():
             "n_vars_local": n_vars,
             "n_vars_global": n_vars + log_world,
             "multilinears": m,
-            "sharding": "low index bits (last-bound variables), one 32-byte RCCL all_gather per round" if world > 1 else "none",
+            "sharding": "low index bits (last-bound variables), one 32-byte RCCL all_gather per round" if dist is not None else "none",
         },
         "bit_exact_check": bool(ok),
         "roofline": roofline,
@@ -213,7 +236,7 @@ def main():
     }
 
     # ---- CPU baseline: the oracle's multi-threaded port of the same loop, bounded sample, rank 0 only
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and dist is None and not args.no_cpu_baseline:
         cores = os.cpu_count() or 1
         cn = args.cpu_n_vars or 18
         while True:
@@ -236,6 +259,8 @@ def main():
 
     if rank == 0:
         print(json.dumps(out))
+    if rccl is not None:
+        rccl.destroy()
     hal.close()
     if dist is not None:
         dist.destroy_process_group()

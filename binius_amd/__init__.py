@@ -20,3 +20,14 @@ from ._ffi import (  # noqa: F401
     log_chunks_range,
     ntt_s_evals,
 )
+
+
+def _ffi_ints_to_arr(vals):
+    """list of Python ints -> numpy (n, 2) uint64 array in BinaryField128b memory layout."""
+    import numpy as np
+
+    a = np.zeros((len(vals), 2), dtype=np.uint64)
+    for i, v in enumerate(vals):
+        a[i, 0] = v & ((1 << 64) - 1)
+        a[i, 1] = v >> 64
+    return a

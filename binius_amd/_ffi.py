@@ -100,6 +100,7 @@ def lib():
         "bn_arena_base": [vp, C.POINTER(vp), C.POINTER(u64)],
         "bn_ctx_set_stream": [vp, vp],
         "bn_sync": [vp],
+        "bn_ctx_get_stream": [vp, C.POINTER(vp)],
         "bn_copy_h2d": [vp, vp, u64, vp, u64],
         "bn_copy_d2h": [vp, vp, u64, vp, u64],
         "bn_copy_d2d": [vp, vp, u64, vp, u64],
@@ -140,7 +141,7 @@ def lib():
 
 
 ABI_SYMBOLS = [
-    "bn_last_error", "bn_version", "bn_ctx_create", "bn_ctx_destroy", "bn_arena_base", "bn_ctx_set_stream", "bn_sync",
+    "bn_last_error", "bn_version", "bn_ctx_create", "bn_ctx_destroy", "bn_arena_base", "bn_ctx_set_stream", "bn_sync", "bn_ctx_get_stream",
     "bn_copy_h2d", "bn_copy_d2h", "bn_copy_d2d", "bn_fill", "bn_expr_compile", "bn_expr_free", "bn_expr_n_vars",
     "bn_extrapolate_line", "bn_extrapolate_line_batch", "bn_tensor_expand", "bn_inner_product", "bn_fold_left", "bn_fold_right", "bn_fri_fold",
     "bn_compute_composite", "bn_pairwise_product_reduce", "bn_log_chunks_range", "bn_pick_log_chunks",

@@ -25,8 +25,12 @@ def host_lib():
         L.bnh_bivariate_sumcheck_prove.argtypes = [
             C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p), C.c_void_p, C.c_uint64, C.c_uint32,
             C.POINTER(C.c_uint32), C.POINTER(F128), C.POINTER(F128), C.POINTER(F128), C.POINTER(F128), C.POINTER(F128),
-            REDUCE_FN, C.c_void_p, C.c_void_p,
+            REDUCE_FN, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
         ]
+        L.bnh_rccl_open.argtypes = [C.c_char_p]
+        L.bnh_rccl_unique_id.argtypes = [C.c_void_p]
+        L.bnh_rccl_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.bnh_rccl_destroy.argtypes = [C.c_void_p]
         _lib = L
     return _lib
 
@@ -34,7 +38,8 @@ def host_lib():
 class SumcheckPlan:
     """Pre-marshalled arguments of one prove so repeated runs have no per-call Python work."""
 
-    def __init__(self, hal, n_vars, multilins, scratch, comps, sums, batch_coeff, challenges, reduce=None, d_partial=0):
+    def __init__(self, hal, n_vars, multilins, scratch, comps, sums, batch_coeff, challenges, reduce=None, d_partial=0,
+                 rccl_comm=None, world=1, d_gathered=0):
         self.hal = hal
         self.n_vars = n_vars
         self.m = len(multilins)
@@ -50,11 +55,13 @@ class SumcheckPlan:
         self.final = (F128 * self.m)()
         self.reduce = REDUCE_FN(reduce) if reduce is not None else C.cast(None, REDUCE_FN)
         self.d_partial = d_partial
+        self.rccl_comm, self.world, self.d_gathered = rccl_comm, world, d_gathered
 
     def run(self):
         rc = host_lib().bnh_bivariate_sumcheck_prove(
             self.hal._h, self.n_vars, self.m, self.ptrs, self.scratch.ptr, self.scratch.len, self.n_comps, self.comps,
             self.sums, C.byref(self.bc), self.ch, self.coeffs, self.final, self.reduce, None, self.d_partial,
+            self.rccl_comm, self.world, self.d_gathered,
         )
         if rc != 0:
             raise BnError(rc, host_lib().bnh_last_error().decode())
@@ -64,3 +71,36 @@ class SumcheckPlan:
 
     def final_evals(self):
         return [from_f128(self.final[j]) for j in range(self.m)]
+
+
+class RcclComm:
+    """An RCCL communicator owned by the C++ host library (one per process / GPU), bootstrapped over
+    an existing torch.distributed group: rank 0 creates the unique id, everyone joins."""
+
+    def __init__(self, dist, rank, world):
+        import torch
+
+        L = host_lib()
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        if not os.path.exists(path):
+            path = "librccl.so"
+        rc = L.bnh_rccl_open(path.encode())
+        if rc != 0:
+            raise BnError(rc, L.bnh_last_error().decode())
+        uid = C.create_string_buffer(128)
+        if rank == 0:
+            rc = L.bnh_rccl_unique_id(uid)
+            if rc != 0:
+                raise BnError(rc, L.bnh_last_error().decode())
+        box = [bytes(uid.raw)]
+        dist.broadcast_object_list(box, src=0)
+        uid = C.create_string_buffer(box[0], 128)
+        self.handle = C.c_void_p()
+        rc = L.bnh_rccl_init(uid, world, rank, C.byref(self.handle))
+        if rc != 0:
+            raise BnError(rc, L.bnh_last_error().decode())
+
+    def destroy(self):
+        if self.handle:
+            host_lib().bnh_rccl_destroy(self.handle)
+            self.handle = None

@@ -203,6 +203,13 @@ int bn_ctx_set_stream(bn_ctx *ctx, void *hip_stream)
 	return BN_OK;
 }
 
+int bn_ctx_get_stream(bn_ctx *ctx, void **hip_stream)
+{
+	BN_REQUIRE(ctx && hip_stream, "null argument");
+	*hip_stream = (void *)ctx->stream;
+	return BN_OK;
+}
+
 int bn_sync(bn_ctx *ctx)
 {
 	BN_REQUIRE(ctx, "null ctx");

@@ -5,6 +5,8 @@
 // compiled (Rust) host would drive the HAL -- per round: one accumulate_kernels, two scalar
 // multiplications, one extrapolate_line per multilinear -- without interpreter overhead between
 // HAL calls.  Links only against the C ABI of include/binius_amd.h.
+#include <dlfcn.h>
+
 #include <cstring>
 #include <string>
 #include <vector>
@@ -15,11 +17,71 @@ using namespace binius_amd;
 
 namespace {
 thread_local std::string g_err;
-}
+
+// ---- RCCL, bound at run time from the librccl.so the process already uses (torch's) -----------
+struct rccl_unique_id {
+	char internal[128];
+};
+typedef int (*fn_get_unique_id)(rccl_unique_id *);
+typedef int (*fn_comm_init_rank)(void **comm, int nranks, rccl_unique_id id, int rank);
+typedef int (*fn_all_gather)(const void *send, void *recv, size_t count, int dtype, void *comm, void *stream);
+typedef int (*fn_comm_destroy)(void *comm);
+typedef const char *(*fn_get_error_string)(int);
+struct rccl_api {
+	void *lib = nullptr;
+	fn_get_unique_id get_unique_id = nullptr;
+	fn_comm_init_rank comm_init_rank = nullptr;
+	fn_all_gather all_gather = nullptr;
+	fn_comm_destroy comm_destroy = nullptr;
+	fn_get_error_string err = nullptr;
+} g_rccl;
+constexpr int kNcclUint8 = 1; // ncclDataType_t
+} // namespace
 
 extern "C" {
 
 const char *bnh_last_error(void) { return g_err.c_str(); }
+
+// ---- RCCL communicator for the sharded prover (one process per GPU) ----------------------------
+int bnh_rccl_open(const char *librccl_path)
+{
+	if (g_rccl.lib) return 0;
+	void *h = dlopen(librccl_path, RTLD_NOW | RTLD_GLOBAL);
+	if (!h) {
+		g_err = std::string("dlopen librccl failed: ") + dlerror();
+		return BN_ERR_CORE_LIB;
+	}
+	g_rccl.lib = h;
+	g_rccl.get_unique_id = (fn_get_unique_id)dlsym(h, "ncclGetUniqueId");
+	g_rccl.comm_init_rank = (fn_comm_init_rank)dlsym(h, "ncclCommInitRank");
+	g_rccl.all_gather = (fn_all_gather)dlsym(h, "ncclAllGather");
+	g_rccl.comm_destroy = (fn_comm_destroy)dlsym(h, "ncclCommDestroy");
+	g_rccl.err = (fn_get_error_string)dlsym(h, "ncclGetErrorString");
+	if (!g_rccl.get_unique_id || !g_rccl.comm_init_rank || !g_rccl.all_gather || !g_rccl.comm_destroy) {
+		g_err = "librccl does not export the expected nccl* symbols";
+		return BN_ERR_CORE_LIB;
+	}
+	return 0;
+}
+static int rccl_check(int rc, const char *what)
+{
+	if (rc == 0) return 0;
+	g_err = std::string(what) + ": " + (g_rccl.err ? g_rccl.err(rc) : "rccl error");
+	return BN_ERR_DEVICE;
+}
+int bnh_rccl_unique_id(void *out128)
+{
+	if (!g_rccl.lib) return (g_err = "bnh_rccl_open was not called", BN_ERR_CORE_LIB);
+	return rccl_check(g_rccl.get_unique_id((rccl_unique_id *)out128), "ncclGetUniqueId");
+}
+int bnh_rccl_init(const void *id128, int world, int rank, void **comm_out)
+{
+	if (!g_rccl.lib) return (g_err = "bnh_rccl_open was not called", BN_ERR_CORE_LIB);
+	rccl_unique_id id;
+	std::memcpy(&id, id128, sizeof(id));
+	return rccl_check(g_rccl.comm_init_rank(comm_out, world, id, rank), "ncclCommInitRank");
+}
+int bnh_rccl_destroy(void *comm) { return comm && g_rccl.lib ? rccl_check(g_rccl.comm_destroy(comm), "ncclCommDestroy") : 0; }
 
 // Combine hook for the sharded prover: called once per round with the device pointer holding this
 // rank's partial (y_1, y_inf) (2 field elements); must return the XOR over all ranks in `evals`.
@@ -35,7 +97,8 @@ typedef int (*bnh_round_reduce_fn)(void *user, const void *d_partial, bn_f128 *e
 int bnh_bivariate_sumcheck_prove(bn_ctx *ctx, uint32_t n_vars, uint32_t m, const void *const *d_multilins, void *d_scratch,
                                  uint64_t scratch_elems, uint32_t n_comps, const uint32_t *comp_indices, const bn_f128 *sums,
                                  const bn_f128 *batch_coeff, const bn_f128 *challenges, bn_f128 *round_coeffs_out,
-                                 bn_f128 *final_evals_out, bnh_round_reduce_fn reduce, void *reduce_user, void *d_partial)
+                                 bn_f128 *final_evals_out, bnh_round_reduce_fn reduce, void *reduce_user, void *d_partial,
+                                 void *rccl_comm, int world, void *d_gathered)
 {
 	try {
 		ComputeLayer hal(ctx);
@@ -51,7 +114,7 @@ int bnh_bivariate_sumcheck_prove(bn_ctx *ctx, uint32_t n_vars, uint32_t m, const
 			sv.emplace_back(sums[c].lo, sums[c].hi);
 		}
 		const B128 bc(batch_coeff->lo, batch_coeff->hi);
-		if (!reduce) {
+		if (!reduce && !rccl_comm) {
 			BivariateSumcheckProver prover(hal, dev_alloc, host_alloc, n_vars, comps, sv, mls);
 			for (uint32_t r = 0; r < n_vars; r++) {
 				std::vector<B128> rc = prover.execute(bc);
@@ -100,7 +163,26 @@ int bnh_bivariate_sumcheck_prove(bn_ctx *ctx, uint32_t n_vars, uint32_t m, const
 				return std::vector<B128>{};
 			});
 			bn_f128 ev[2];
-			if (reduce(reduce_user, d_partial, ev)) throw Error(Error::CoreLibError, "round reduce callback failed");
+			if (rccl_comm) {
+				// ONE RCCL collective per round: all_gather of this rank's 32-byte partial on the
+				// context's stream (stream-ordered after the kernels), then XOR of the G partials
+				void *stream = nullptr;
+				check(bn_ctx_get_stream(ctx, &stream));
+				if (g_rccl.all_gather(d_partial, d_gathered, 32, kNcclUint8, rccl_comm, stream) != 0)
+					throw Error(Error::DeviceError, "ncclAllGather failed");
+				std::vector<bn_f128> g((size_t)2 * world);
+				check(bn_copy_d2h(ctx, d_gathered, g.size(), g.data(), g.size()));
+				ev[0] = bn_f128{0, 0};
+				ev[1] = bn_f128{0, 0};
+				for (int w = 0; w < world; w++) {
+					ev[0].lo ^= g[2 * w].lo;
+					ev[0].hi ^= g[2 * w].hi;
+					ev[1].lo ^= g[2 * w + 1].lo;
+					ev[1].hi ^= g[2 * w + 1].hi;
+				}
+			} else if (reduce(reduce_user, d_partial, ev)) {
+				throw Error(Error::CoreLibError, "round reduce callback failed");
+			}
 			std::vector<B128> rc = calculate_round_coeffs_from_evals(running, {B128(ev[0].lo, ev[0].hi), B128(ev[1].lo, ev[1].hi)});
 			for (size_t i = 0; i < 3; i++) round_coeffs_out[3 * r + i] = rc[i].raw();
 			const B128 z(challenges[r].lo, challenges[r].hi);

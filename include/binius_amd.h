@@ -62,6 +62,8 @@ int bn_arena_base(bn_ctx *ctx, void **d_base, uint64_t *elems);
 /* run on an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = own stream */
 int bn_ctx_set_stream(bn_ctx *ctx, void *hip_stream);
 int bn_sync(bn_ctx *ctx);
+/* the hipStream_t the context enqueues on (so a caller can put an RCCL collective in the same order) */
+int bn_ctx_get_stream(bn_ctx *ctx, void **hip_stream);
 
 /* ---- ComputeLayer (layer.rs:36-87) ---- */
 int bn_copy_h2d(bn_ctx *ctx, const bn_f128 *h_src, uint64_t src_len, void *d_dst, uint64_t dst_len);
