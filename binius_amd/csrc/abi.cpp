@@ -432,8 +432,18 @@ int bn_inner_product(bn_ctx *ctx, const void *d_a, uint64_t a_len, uint32_t towe
 	BN_REQUIRE(ctx && h_out, "null argument");
 	BN_REQUIRE(tower_level <= 7 && (a_len << (7 - tower_level)) == b_len, "invalid input: inner_product lengths");
 	BN_REQUIRE(valid_tower_level(tower_level), "unsupported value of tower_level");
-	ctx->s_clean = false; // slot 0 of the accumulator area is used as this op's accumulator
-	BN_HIP(hipMemsetAsync(ctx->d_result, 0, sizeof(f128), ctx->stream));
+	ctx->s_clean = false; // slots 0..1 of the accumulator area are used as this op's accumulators
+	BN_HIP(hipMemsetAsync(ctx->d_result, 0, 2 * sizeof(f128), ctx->stream));
+	if (tower_level == 7 && b_len >= 2 && (b_len & 1) == 0) {
+		// F x F: a plain sum of products -> the bit-sliced product-sum kernel (two half-range streams)
+		BN_HIP(bn::launch_roundeval9_split(ctx->stream, ctx->n_cu, d_a, d_b, b_len / 2, b_len / 2, ctx->d_result));
+		bn_f128 two[2];
+		int rc = read_result(ctx, 2, two);
+		if (rc) return rc;
+		h_out->lo = two[0].lo ^ two[1].lo;
+		h_out->hi = two[0].hi ^ two[1].hi;
+		return BN_OK;
+	}
 	BN_HIP(bn::launch_inner_product(ctx->stream, ctx->n_cu, d_a, tower_level, d_b, b_len, ctx->d_result));
 	return read_result(ctx, 1, h_out);
 }

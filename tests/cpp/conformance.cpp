@@ -1,0 +1,499 @@
+// tests/cpp/conformance.cpp -- C++ ports of the reference's backend-conformance tests
+// (generic functions in crates/compute_test_utils/src/layer.rs, instantiated per backend in
+// crates/compute/tests/layer.rs) against the C++ host mirror binius_amd/host/compute_layer.hpp.
+// Expected values come from the oracle (oracle/*.c, linked in here as the checker only).
+// Run by tests/test_gpu_cpp_conformance.py on the GPU box; exit code 0 = all passed.
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "../../binius_amd/host/sumcheck.hpp"
+extern "C" {
+#include "../../oracle/layer_ref.h"
+#include "../../oracle/ntt_ref.h"
+#include "../../oracle/sumcheck_ref.h"
+}
+
+using namespace binius_amd;
+
+static int g_fail = 0;
+#define CHECK(cond)                                                                     \
+	do {                                                                                \
+		if (!(cond)) {                                                                  \
+			std::printf("    CHECK failed: %s  (%s:%d)\n", #cond, __FILE__, __LINE__); \
+			g_fail++;                                                                   \
+			return;                                                                     \
+		}                                                                               \
+	} while (0)
+
+static std::vector<B128> random_vec(uint64_t seed, size_t n)
+{
+	std::vector<B128> v(n);
+	ref_splitmix_fill(seed, reinterpret_cast<uint64_t *>(v.data()), 2 * n);
+	return v;
+}
+static const ref_b128 *R(const std::vector<B128> &v) { return reinterpret_cast<const ref_b128 *>(v.data()); }
+static ref_b128 *R(std::vector<B128> &v) { return reinterpret_cast<ref_b128 *>(v.data()); }
+static ref_b128 r1(B128 x) { return ref_b128{x.lo, x.hi}; }
+static B128 b1(ref_b128 x) { return B128(x.lo, x.hi); }
+static FSlice C(const FSliceMut &m) { return ComputeMemory::as_const(m); }
+
+struct Env {
+	ComputeHolder holder{1 << 16, 1 << 20};
+};
+
+// layer.rs:792-825
+static void test_copy_host_device(Env &e)
+{
+	ComputeData d = e.holder.to_data();
+	auto h1 = random_vec(1, 128);
+	std::vector<B128> h2(128);
+	FSliceMut d1 = d.dev_alloc.alloc(128), d2 = d.dev_alloc.alloc(128);
+	d.hal->copy_h2d(h1, d1);
+	d.hal->copy_d2d(C(d1), d2);
+	d.hal->copy_d2h(C(d2), h2);
+	CHECK(h1 == h2);
+	bool threw = false;
+	try {
+		FSliceMut small = d.dev_alloc.alloc(8);
+		d.hal->copy_h2d(h1, small);
+	} catch (const Error &err) {
+		threw = err.kind() == Error::InputValidation;
+	}
+	CHECK(threw);
+}
+
+// alloc.rs:123-158
+static void test_bump_allocator(Env &e)
+{
+	ComputeData d = e.holder.to_data();
+	FSliceMut buf = d.dev_alloc.alloc(256);
+	DeviceBumpAllocator bump(buf);
+	CHECK(bump.alloc(100).len() == 100);
+	CHECK(bump.alloc(100).len() == 100);
+	bool oom = false;
+	try {
+		bump.alloc(100);
+	} catch (const Error &err) {
+		oom = err.kind() == Error::Alloc;
+	}
+	CHECK(oom);
+	CHECK(bump.capacity() == 56);
+	DeviceBumpAllocator sub = bump.subscope_allocator();
+	CHECK(sub.alloc(56).len() == 56);
+}
+
+// layer.rs:827-848
+static void test_log_chunks_range(Env &)
+{
+	std::vector<KernelMemMap> maps = {KernelMemMap::chunked(FSlice{(void *)0x1000, 256}, 4),
+	                                  KernelMemMap::chunked_mut(FSliceMut{(void *)0x9000, 256}, 6), KernelMemMap::local(8)};
+	size_t s = 99, en = 99;
+	CHECK(KernelMemMap::log_chunks_range(maps, s, en));
+	CHECK(s == 0 && en == 2);
+}
+
+// compute_test_utils/src/layer.rs:22-72
+static void test_tensor_expand(Env &e)
+{
+	ComputeData d = e.holder.to_data();
+	const size_t n_vars = 8, log_n = 2;
+	std::vector<B128> buf(1 << n_vars);
+	auto head = random_vec(20, 1 << log_n);
+	for (size_t i = 0; i < head.size(); i++) buf[i] = head[i];
+	auto coords = random_vec(21, n_vars - log_n);
+	FSliceMut dev = d.dev_alloc.alloc(buf.size());
+	d.hal->copy_h2d(buf, dev);
+	d.hal->execute([&](ComputeLayerExecutor &exec) {
+		exec.tensor_expand(log_n, coords, dev);
+		return std::vector<B128>{};
+	});
+	std::vector<B128> got(buf.size());
+	d.hal->copy_d2h(C(dev), got);
+	ref_tensor_expand(R(buf), buf.size(), log_n, R(coords), coords.size(), 1);
+	CHECK(got == buf);
+}
+
+// layer.rs:74-125 (a at the B16 level) and every other level
+static void test_inner_product(Env &e)
+{
+	ComputeData d = e.holder.to_data();
+	for (size_t level : {0u, 3u, 4u, 5u, 6u, 7u}) {
+		const size_t n_b = 1 << 8, n_a = n_b >> (7 - level);
+		auto a = random_vec(40 + level, n_a), b = random_vec(50, n_b);
+		FSliceMut da = d.dev_alloc.alloc(n_a), db = d.dev_alloc.alloc(n_b);
+		d.hal->copy_h2d(a, da);
+		d.hal->copy_h2d(b, db);
+		auto res = d.hal->execute([&](ComputeLayerExecutor &exec) { return std::vector<B128>{exec.inner_product(SubfieldSlice(C(da), level), C(db))}; });
+		ref_b128 want;
+		CHECK(ref_inner_product(R(a), n_a, (int)level, R(b), n_b, &want) == 0);
+		CHECK(res[0] == b1(want));
+	}
+}
+
+// layer.rs:127-233: eq_ind_partial_eval + inner products == MLE evaluation, through `join`
+static void test_multilinear_evaluations(Env &e)
+{
+	ComputeData d = e.holder.to_data();
+	const size_t n_vars = 8;
+	auto point = random_vec(30, n_vars);
+	auto m1 = random_vec(31, (1 << n_vars) >> (7 - 4)), m2 = random_vec(32, (1 << n_vars) >> (7 - 5));
+	FSliceMut d1 = d.dev_alloc.alloc(m1.size()), d2 = d.dev_alloc.alloc(m2.size());
+	d.hal->copy_h2d(m1, d1);
+	d.hal->copy_h2d(m2, d2);
+	FSliceMut eq = ops::eq_ind_partial_eval(*d.hal, d.dev_alloc, point);
+	std::vector<B128> eq_h(1 << n_vars), exp(1 << n_vars);
+	d.hal->copy_d2h(C(eq), eq_h);
+	exp[0] = B128::ONE();
+	ref_tensor_expand(R(exp), exp.size(), 0, R(point), n_vars, 1);
+	CHECK(eq_h == exp);
+	auto res = d.hal->execute([&](ComputeLayerExecutor &exec) {
+		auto pr = exec.join([&](ComputeLayerExecutor &x) { return x.inner_product(SubfieldSlice(C(d1), 4), C(eq)); },
+		                    [&](ComputeLayerExecutor &x) { return x.inner_product(SubfieldSlice(C(d2), 5), C(eq)); });
+		return std::vector<B128>{pr.first, pr.second};
+	});
+	ref_b128 w1, w2;
+	ref_inner_product(R(m1), m1.size(), 4, R(exp), exp.size(), &w1);
+	ref_inner_product(R(m2), m2.size(), 5, R(exp), exp.size(), &w2);
+	CHECK(res[0] == b1(w1) && res[1] == b1(w2));
+}
+
+// layer.rs:329-410
+static void test_inner_product_using_kernel_accumulator(Env &e)
+{
+	ComputeData d = e.holder.to_data();
+	const size_t log_len = 8, n = 1 << log_len;
+	auto a = random_vec(94, n), b = random_vec(95, n);
+	FSliceMut da = d.dev_alloc.alloc(n), db = d.dev_alloc.alloc(n);
+	d.hal->copy_h2d(a, da);
+	d.hal->copy_h2d(b, db);
+	ExprEval eval = d.hal->compile_expr(ArithCircuit::var(0) * ArithCircuit::var(1));
+	auto res = d.hal->execute([&](ComputeLayerExecutor &exec) {
+		return exec.accumulate_kernels(
+		    [&](KernelExecutor &ke, size_t log_chunks, std::vector<KernelBuffer> &bufs) {
+			    const size_t log_chunk = log_len - log_chunks;
+			    KernelValue acc = ke.decl_value(B128::ZERO());
+			    SlicesBatch<KSlice> rows({bufs[0].to_ref(), bufs[1].to_ref()}, (size_t)1 << log_chunk);
+			    ke.sum_composition_evals(rows, eval, B128::ONE(), acc);
+			    return std::vector<KernelValue>{acc};
+		    },
+		    {KernelMemMap::chunked(C(da), 3), KernelMemMap::chunked(C(db), 3)});
+	});
+	ref_b128 want;
+	ref_inner_product(R(a), n, 7, R(b), n, &want);
+	CHECK(res.size() == 1 && res[0] == b1(want));
+}
+
+// layer.rs:412-501
+static void test_kernel_add(Env &e)
+{
+	ComputeData d = e.holder.to_data();
+	const size_t log_len = 10, n = 1 << log_len;
+	auto a = random_vec(92, n), b = random_vec(93, n);
+	FSliceMut da = d.dev_alloc.alloc(n), db = d.dev_alloc.alloc(n);
+	d.hal->copy_h2d(a, da);
+	d.hal->copy_h2d(b, db);
+	ExprEval eval = d.hal->compile_expr(ArithCircuit::var(0));
+	auto res = d.hal->execute([&](ComputeLayerExecutor &exec) {
+		return exec.accumulate_kernels(
+		    [&](KernelExecutor &ke, size_t log_chunks, std::vector<KernelBuffer> &bufs) {
+			    const size_t log_chunk = log_len - log_chunks;
+			    ke.add(log_chunk, bufs[0].to_ref(), bufs[1].to_ref(), bufs[2].as_mut());
+			    KernelValue acc = ke.decl_value(B128::ZERO());
+			    SlicesBatch<KSlice> rows({bufs[2].to_ref()}, (size_t)1 << log_chunk);
+			    ke.sum_composition_evals(rows, eval, B128::ONE(), acc);
+			    return std::vector<KernelValue>{acc};
+		    },
+		    {KernelMemMap::chunked(C(da), 3), KernelMemMap::chunked(C(db), 3), KernelMemMap::local(log_len)});
+	});
+	B128 want;
+	for (size_t i = 0; i < n; i++) want += a[i] + b[i];
+	CHECK(res[0] == want);
+}
+
+// layer.rs:503-570
+static void test_fri_fold(Env &e)
+{
+	for (size_t log_batch : {0u, 4u}) {
+		ComputeData d = e.holder.to_data();
+		const size_t log_len = 10, n_fold = 2, tw_level = 4; // FSub = B16 as in the reference test
+		AdditiveNTT ntt(*d.hal, tw_level, log_len);
+		auto data = random_vec(110, (size_t)1 << (log_len + log_batch));
+		auto challenges = random_vec(111, log_batch + n_fold);
+		const size_t out_len = (size_t)1 << (log_len - n_fold);
+		FSliceMut din = d.dev_alloc.alloc(data.size()), dout = d.dev_alloc.alloc(out_len);
+		d.hal->copy_h2d(data, din);
+		d.hal->execute([&](ComputeLayerExecutor &exec) {
+			exec.fri_fold(ntt, log_len, log_batch, challenges, C(din), dout);
+			return std::vector<B128>{};
+		});
+		std::vector<B128> got(out_len), want(out_len);
+		d.hal->copy_d2h(C(dout), got);
+		std::vector<uint64_t> s(REF_NTT_MAX_DIM * REF_NTT_MAX_DIM);
+		CHECK(ref_ntt_s_evals((int)tw_level, (int)log_len, s.data()) == 0);
+		for (size_t i = 0; i < s.size(); i++) CHECK(s[i] == ntt.s_evals()[i]);
+		CHECK(ref_fold_interleaved(s.data(), (int)tw_level, (int)log_len, (int)log_len, (int)log_batch, R(challenges), challenges.size(),
+		                           R(data), data.size(), R(want), out_len) == 0);
+		CHECK(got == want);
+	}
+}
+
+// layer.rs:572-724
+static void test_left_right_fold(Env &e)
+{
+	ComputeData d = e.holder.to_data();
+	const size_t level = 4, log_evals = 4, log_q = 1; // evals 2^4 B16 elements inside B128s, query 2^1
+	auto mat = random_vec(60, std::max<size_t>(1, ((size_t)1 << log_evals) >> (7 - level)));
+	auto vec = random_vec(61, 1 << log_q);
+	const size_t out_len = (size_t)1 << (log_evals - log_q);
+	FSliceMut dm = d.dev_alloc.alloc(mat.size()), dv = d.dev_alloc.alloc(vec.size()), dl = d.dev_alloc.alloc(out_len), dr = d.dev_alloc.alloc(out_len);
+	d.hal->copy_h2d(mat, dm);
+	d.hal->copy_h2d(vec, dv);
+	d.hal->execute([&](ComputeLayerExecutor &exec) {
+		exec.fold_left(SubfieldSlice(C(dm), level), C(dv), dl);
+		exec.fold_right(SubfieldSlice(C(dm), level), C(dv), dr);
+		return std::vector<B128>{};
+	});
+	std::vector<B128> gl(out_len), gr(out_len), wl(out_len), wr(out_len);
+	d.hal->copy_d2h(C(dl), gl);
+	d.hal->copy_d2h(C(dr), gr);
+	CHECK(ref_fold_left(R(mat), mat.size(), (int)level, R(vec), vec.size(), R(wl), out_len) == 0);
+	CHECK(ref_fold_right(R(mat), mat.size(), (int)level, R(vec), vec.size(), R(wr), out_len) == 0);
+	CHECK(gl == wl && gr == wr);
+}
+
+// layer.rs:726-771
+static void test_extrapolate_line(Env &e)
+{
+	ComputeData d = e.holder.to_data();
+	const size_t n = 1 << 10;
+	auto e0 = random_vec(10, n), e1 = random_vec(11, n);
+	B128 z = random_vec(12, 1)[0];
+	FSliceMut d0 = d.dev_alloc.alloc(n), d1 = d.dev_alloc.alloc(n);
+	d.hal->copy_h2d(e0, d0);
+	d.hal->copy_h2d(e1, d1);
+	d.hal->execute([&](ComputeLayerExecutor &exec) {
+		exec.extrapolate_line(d0, C(d1), z);
+		return std::vector<B128>{};
+	});
+	std::vector<B128> got(n);
+	d.hal->copy_d2h(C(d0), got);
+	ref_extrapolate_line(R(e0), R(e1), n, n, r1(z));
+	CHECK(got == e0);
+	bool threw = false;
+	try {
+		FSliceMut half = ComputeMemory::slice_mut(d0, 0, n / 2);
+		d.hal->execute([&](ComputeLayerExecutor &exec) {
+			exec.extrapolate_line(half, C(d1), z);
+			return std::vector<B128>{};
+		});
+	} catch (const Error &err) {
+		threw = err.kind() == Error::InputValidation;
+	}
+	CHECK(threw);
+}
+
+// layer.rs:773-826
+static void test_compute_composite(Env &e)
+{
+	ComputeData d = e.holder.to_data();
+	const size_t n = 1 << 10;
+	auto a = random_vec(70, n), b = random_vec(71, n);
+	FSliceMut da = d.dev_alloc.alloc(n), db = d.dev_alloc.alloc(n), dout = d.dev_alloc.alloc(n);
+	d.hal->copy_h2d(a, da);
+	d.hal->copy_h2d(b, db);
+	ExprEval eval = d.hal->compile_expr(ArithCircuit::var(0) * ArithCircuit::var(1));
+	d.hal->execute([&](ComputeLayerExecutor &exec) {
+		exec.compute_composite(SlicesBatch<FSlice>({C(da), C(db)}, n), dout, eval);
+		return std::vector<B128>{};
+	});
+	std::vector<B128> got(n), want(n);
+	d.hal->copy_d2h(C(dout), got);
+	ref_b128_mul_vec(R(a), R(b), R(want), n);
+	CHECK(got == want);
+}
+
+// layer.rs:828-907
+static void test_map_kernels(Env &e)
+{
+	ComputeData d = e.holder.to_data();
+	const size_t log_len = 10, n = 1 << log_len;
+	auto a = random_vec(90, n), b = random_vec(91, n);
+	for (auto &x : b) x = B128(x.lo & 1, 0); // b in {0, 1} as in the reference test
+	FSliceMut da = d.dev_alloc.alloc(n), db = d.dev_alloc.alloc(n);
+	d.hal->copy_h2d(a, da);
+	d.hal->copy_h2d(b, db);
+	d.hal->execute([&](ComputeLayerExecutor &exec) {
+		exec.map_kernels(
+		    [&](KernelExecutor &ke, size_t log_chunks, std::vector<KernelBuffer> &bufs) {
+			    ke.add_assign(log_len - log_chunks, bufs[1].to_ref(), bufs[0].as_mut());
+		    },
+		    {KernelMemMap::chunked_mut(da, 0), KernelMemMap::chunked(C(db), 0)});
+		return std::vector<B128>{};
+	});
+	std::vector<B128> got(n);
+	d.hal->copy_d2h(C(da), got);
+	for (size_t i = 0; i < n; i++) CHECK(got[i] == a[i] + b[i]);
+}
+
+// layer.rs:909-960
+static void test_pairwise_product_reduce(Env &e)
+{
+	for (size_t log_n : {1u, 8u}) {
+		ComputeData d = e.holder.to_data();
+		const size_t n = (size_t)1 << log_n;
+		auto x = random_vec(80, n);
+		FSliceMut dx = d.dev_alloc.alloc(n);
+		d.hal->copy_h2d(x, dx);
+		std::vector<FSliceMut> outs;
+		for (size_t r = 0; r < log_n; r++) outs.push_back(d.dev_alloc.alloc(n >> (r + 1)));
+		d.hal->execute([&](ComputeLayerExecutor &exec) {
+			exec.pairwise_product_reduce(C(dx), outs);
+			return std::vector<B128>{};
+		});
+		std::vector<B128> cur = x;
+		for (size_t r = 0; r < log_n; r++) {
+			std::vector<B128> next(cur.size() / 2), got(cur.size() / 2);
+			for (size_t i = 0; i < next.size(); i++) next[i] = b1(ref_b128_mul(r1(cur[2 * i]), r1(cur[2 * i + 1])));
+			d.hal->copy_d2h(C(outs[r]), got);
+			CHECK(got == next);
+			cur = next;
+		}
+	}
+}
+
+// compute_test_utils/src/bivariate_sumcheck.rs:44-262 (transcript replaced by a challenge stream)
+static void test_bivariate_sumcheck_prove_verify(Env &e)
+{
+	const size_t n_vars = 8, m = 8, n_comps = 8;
+	ComputeData d = e.holder.to_data();
+	std::vector<std::vector<B128>> mls;
+	std::vector<FSlice> dev;
+	for (size_t j = 0; j < m; j++) {
+		mls.push_back(random_vec(0xB1A50000 + j, (size_t)1 << n_vars));
+		FSliceMut s = d.dev_alloc.alloc(mls[j].size());
+		d.hal->copy_h2d(mls[j], s);
+		dev.push_back(C(s));
+	}
+	std::vector<IndexCompositionBivariate> comps;
+	std::vector<uint32_t> flat;
+	std::vector<B128> sums;
+	for (size_t c = 0; c < n_comps; c++) {
+		size_t i = (c * 5 + 1) % m, j = (c * 3 + 2) % m;
+		comps.push_back(IndexCompositionBivariate{m, {i, j}});
+		flat.push_back((uint32_t)i);
+		flat.push_back((uint32_t)j);
+		ref_b128 s;
+		ref_inner_product(R(mls[i]), mls[i].size(), 7, R(mls[j]), mls[j].size(), &s);
+		sums.push_back(b1(s));
+	}
+	auto stream = random_vec(0xC4A1, n_vars + 1);
+	B128 batch_coeff = stream[0];
+	std::vector<B128> challenges(stream.begin() + 1, stream.end());
+	BivariateSumcheckProver prover(*d.hal, d.dev_alloc, d.host_alloc, n_vars, comps, sums, dev);
+	std::vector<B128> got_coeffs;
+	B128 running = evaluate_univariate(sums, batch_coeff);
+	for (size_t r = 0; r < n_vars; r++) {
+		auto rc = prover.execute(batch_coeff);
+		CHECK(rc.size() == 3);
+		CHECK(rc[0] + (rc[0] + rc[1] + rc[2]) == running); // verifier: P(0) + P(1) == sum
+		running = evaluate_univariate(rc, challenges[r]);
+		got_coeffs.insert(got_coeffs.end(), rc.begin(), rc.end());
+		prover.fold(challenges[r]);
+	}
+	auto finals = prover.finish();
+	// oracle prover on copies
+	std::vector<std::vector<B128>> copies = mls;
+	std::vector<ref_b128 *> ptrs;
+	for (auto &c : copies) ptrs.push_back(R(c));
+	std::vector<B128> want_coeffs(3 * n_vars), want_final(m);
+	CHECK(ref_bivariate_sumcheck_prove(ptrs.data(), m, (unsigned)n_vars, flat.data(), n_comps, R(sums), r1(batch_coeff), R(challenges),
+	                                   R(want_coeffs), R(want_final), 1) == 0);
+	CHECK(got_coeffs == want_coeffs);
+	CHECK(finals == want_final);
+	// final evals == MLE at the reversed challenges (bivariate_sumcheck.rs:257-261)
+	std::vector<B128> point(challenges.rbegin(), challenges.rend());
+	for (size_t j = 0; j < m; j++) CHECK(finals[j] == b1(ref_mle_evaluate(R(mls[j]), (unsigned)n_vars, R(point))));
+	// state machine errors
+	bool threw = false;
+	try {
+		prover.fold(challenges[0]);
+	} catch (const SumcheckError &) {
+		threw = true;
+	}
+	CHECK(threw);
+}
+
+// crates/ntt/src/tests/ntt_tests.rs: forward == scalar reference, inverse round trip
+static void test_ntt(Env &e)
+{
+	ComputeData d = e.holder.to_data();
+	const size_t log_n = 12;
+	AdditiveNTT ntt(*d.hal, 5, log_n);
+	std::vector<uint32_t> data((size_t)1 << log_n), want, got(data.size());
+	std::vector<uint64_t> w(data.size());
+	ref_splitmix_fill(0x0177, w.data(), w.size());
+	for (size_t i = 0; i < data.size(); i++) data[i] = (uint32_t)w[i];
+	want = data;
+	FSliceMut dev = d.dev_alloc.alloc(data.size() / 4);
+	bn_ctx *ctx = d.hal->raw_ctx();
+	check(bn_copy_h2d(ctx, reinterpret_cast<const bn_f128 *>(data.data()), data.size() / 4, dev.ptr, dev.len()));
+	ntt.forward_transform(dev.ptr, 5, NTTShape{0, log_n, 0}, 0, 0, 0);
+	check(bn_copy_d2h(ctx, dev.ptr, dev.len(), reinterpret_cast<bn_f128 *>(got.data()), got.size() / 4));
+	std::vector<uint64_t> s(REF_NTT_MAX_DIM * REF_NTT_MAX_DIM);
+	ref_ntt_s_evals(5, (int)log_n, s.data());
+	CHECK(ref_ntt_forward(want.data(), 5, 5, s.data(), (int)log_n, 0, (int)log_n, 0, 0, 0, 0) == 0);
+	CHECK(got == want);
+	ntt.inverse_transform(dev.ptr, 5, NTTShape{0, log_n, 0}, 0, 0, 0);
+	check(bn_copy_d2h(ctx, dev.ptr, dev.len(), reinterpret_cast<bn_f128 *>(got.data()), got.size() / 4));
+	CHECK(got == data);
+}
+
+int main()
+{
+	struct T {
+		const char *name;
+		std::function<void(Env &)> fn;
+	};
+	std::vector<T> tests = {
+	    {"test_copy_host_device", test_copy_host_device},
+	    {"test_bump_allocator", test_bump_allocator},
+	    {"test_log_chunks_range", test_log_chunks_range},
+	    {"test_generic_single_tensor_expand", test_tensor_expand},
+	    {"test_generic_single_inner_product", test_inner_product},
+	    {"test_generic_multiple_multilinear_evaluations", test_multilinear_evaluations},
+	    {"test_generic_single_inner_product_using_kernel_accumulator", test_inner_product_using_kernel_accumulator},
+	    {"test_generic_kernel_add", test_kernel_add},
+	    {"test_generic_fri_fold", test_fri_fold},
+	    {"test_generic_single_left_right_fold", test_left_right_fold},
+	    {"test_extrapolate_line", test_extrapolate_line},
+	    {"test_generic_compute_composite", test_compute_composite},
+	    {"test_map_kernels", test_map_kernels},
+	    {"test_generic_pairwise_product_reduce", test_pairwise_product_reduce},
+	    {"generic_test_bivariate_sumcheck_prove_verify", test_bivariate_sumcheck_prove_verify},
+	    {"test_additive_ntt", test_ntt},
+	};
+	int failed = 0;
+	try {
+		Env env;
+		for (auto &t : tests) {
+			const int before = g_fail;
+			try {
+				t.fn(env);
+			} catch (const std::exception &ex) {
+				std::printf("    exception: %s\n", ex.what());
+				g_fail++;
+			}
+			const bool ok = g_fail == before;
+			std::printf("%s %s\n", ok ? "PASS" : "FAIL", t.name);
+			if (!ok) failed++;
+		}
+	} catch (const std::exception &ex) {
+		std::printf("FATAL: %s\n", ex.what());
+		return 2;
+	}
+	std::printf("%d/%zu conformance tests passed\n", (int)tests.size() - failed, tests.size());
+	return failed ? 1 : 0;
+}
