@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -140,6 +141,8 @@ int bn_ctx_create(int device, uint64_t arena_elems, bn_ctx **out)
 	BN_HIP(hipHostGetDevicePointer((void **)&ctx->d_mail, ctx->h_mail, 0));
 	BN_HIP(hipMemset(ctx->d_result, 0, sizeof(f128) * bn::kResultSlots));
 	ctx->s_clean = true;
+	BN_HIP(hipMalloc((void **)&ctx->d_mul8, 65536));
+	BN_HIP(bn::launch_build_mul8(ctx->stream, ctx->d_mul8));
 	if (arena_elems) {
 		hipError_t e = hipMalloc(&ctx->arena, arena_elems * sizeof(f128));
 		if (e != hipSuccess) {
@@ -162,6 +165,7 @@ int bn_ctx_destroy(bn_ctx *ctx)
 	if (ctx->arena) hipFree(ctx->arena);
 	if (ctx->scratch) hipFree(ctx->scratch);
 	if (ctx->d_result) hipFree(ctx->d_result);
+	if (ctx->d_mul8) hipFree(ctx->d_mul8);
 	if (ctx->h_result) hipHostFree(ctx->h_result);
 	if (ctx->h_mail) hipHostFree(ctx->h_mail);
 	if (ctx->ev0) hipEventDestroy(ctx->ev0);
@@ -977,6 +981,12 @@ static int ntt_common(bn_ctx *ctx, bool inverse, void *d_data, uint32_t elem_lev
 	int rc = upload_s_evals(ctx, h_s_evals, &d_s, 0, nullptr);
 	if (rc) return rc;
 	prof_scope ps(ctx, BN_PROF_NTT);
+	if (!getenv("BN_NTT_PER_LAYER")) {
+		hipError_t te = bn::launch_ntt_tiled(ctx->stream, ctx->n_cu, inverse, d_data, elem_level, tw_level, ctx->d_mul8, d_s, log_domain,
+		                                     log_x, log_y, log_z, coset, coset_bits, skip_rounds);
+		if (te == hipSuccess) return BN_OK;
+		if (te != hipErrorNotSupported) return bn::hip_fail(te, "launch_ntt_tiled");
+	}
 	BN_HIP(bn::launch_ntt(ctx->stream, inverse, d_data, elem_level, tw_level, d_s, log_domain, log_x, log_y, log_z, coset,
 	                      coset_bits, skip_rounds));
 	return BN_OK;

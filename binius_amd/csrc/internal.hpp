@@ -37,6 +37,7 @@ struct bn_ctx {
 	bn::f128 *d_mail = nullptr;        // device view of the same memory
 	uint64_t mail_seq = 0;
 	bool s_clean = false;              // accumulator slots d_result[0..64) known to be zero
+	uint8_t *d_mul8 = nullptr;         // 64 KiB GF(2^8) product table (tiled NTT)
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	int n_cu = 256;
 	// per-class kernel timing (bn_prof_begin / bn_prof_end)
@@ -135,5 +136,11 @@ hipError_t launch_fri_fold(hipStream_t s, const uint64_t *d_s_evals, uint32_t tw
 hipError_t launch_ntt(hipStream_t s, bool inverse, void *data, uint32_t elem_level, uint32_t tw_level,
                       const uint64_t *d_s_evals, uint32_t log_domain, uint32_t log_x, uint32_t log_y, uint32_t log_z,
                       uint64_t coset, uint32_t coset_bits, uint32_t skip_rounds);
+
+// ---- kernels_ntt_tiled.hip
+hipError_t launch_build_mul8(hipStream_t s, uint8_t *d_tab);
+hipError_t launch_ntt_tiled(hipStream_t s, int n_cu, bool inverse, void *data, uint32_t elem_level, uint32_t tw_level,
+                            const uint8_t *d_mul8, const uint64_t *d_s_evals, uint32_t log_domain, uint32_t log_x, uint32_t log_y,
+                            uint32_t log_z, uint64_t coset, uint32_t coset_bits, uint32_t skip_rounds);
 
 } // namespace bn
