@@ -141,6 +141,8 @@ int bn_ctx_create(int device, uint64_t arena_elems, bn_ctx **out)
 	BN_HIP(hipHostGetDevicePointer((void **)&ctx->d_mail, ctx->h_mail, 0));
 	BN_HIP(hipMemset(ctx->d_result, 0, sizeof(f128) * bn::kResultSlots));
 	ctx->s_clean = true;
+	BN_HIP(hipMalloc((void **)&ctx->d_ticket, sizeof(unsigned)));
+	BN_HIP(hipMemset(ctx->d_ticket, 0, sizeof(unsigned)));
 	BN_HIP(hipMalloc((void **)&ctx->d_mul8, 65536));
 	BN_HIP(bn::launch_build_mul8(ctx->stream, ctx->d_mul8));
 	if (arena_elems) {
@@ -166,6 +168,7 @@ int bn_ctx_destroy(bn_ctx *ctx)
 	if (ctx->scratch) hipFree(ctx->scratch);
 	if (ctx->d_result) hipFree(ctx->d_result);
 	if (ctx->d_mul8) hipFree(ctx->d_mul8);
+	if (ctx->d_ticket) hipFree(ctx->d_ticket);
 	if (ctx->h_result) hipHostFree(ctx->h_result);
 	if (ctx->h_mail) hipHostFree(ctx->h_mail);
 	if (ctx->ev0) hipEventDestroy(ctx->ev0);
@@ -712,6 +715,8 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 	std::vector<f128> h_values(n_values ? n_values : 1, bn::f128_zero());
 	std::vector<bn::fin_term> terms;
 	uint32_t n_slots = 0;
+	bool finalized_in_kernel = false;
+	uint64_t fused_seq = 0;
 	f128 *d_S = ctx->d_result;         // [0,64)
 	f128 *d_rets = ctx->d_result + 96;  // [96,128)
 	if (!ctx->s_clean)
@@ -825,17 +830,49 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 						}
 						if (ok) {
 							BN_REQUIRE(n_slots + 2 <= 64, "too many sum_composition_evals in one kernel");
-							{
-								prof_scope ps(ctx, BN_PROF_ROUND_EVAL);
-								BN_HIP(bn::launch_roundeval_product(s, ctx->n_cu, hi, lo, k, row_len, d_S + slot));
-							}
-							terms.push_back(bn::fin_term{op.value, slot, f128{op.scalar.lo, op.scalar.hi}});
+							const bn_kop &pop2 = ops[partner];
+							BN_REQUIRE(pop2.value < n_values, "sum_composition_evals: accumulator was never declared");
 							// DECLs between the two ops
 							for (uint32_t o2 = o + 1; o2 < (uint32_t)partner; o2++)
 								if (ops[o2].kind == BN_KOP_DECL_VALUE)
 									h_values[ops[o2].value] = f128{ops[o2].scalar.lo, ops[o2].scalar.hi};
-							BN_REQUIRE(pop.value < n_values, "sum_composition_evals: accumulator was never declared");
-							terms.push_back(bn::fin_term{pop.value, slot + 1, f128{pop.scalar.lo, pop.scalar.hi}});
+							terms.push_back(bn::fin_term{op.value, slot, f128{op.scalar.lo, op.scalar.hi}});
+							terms.push_back(bn::fin_term{pop2.value, slot + 1, f128{pop2.scalar.lo, pop2.scalar.hi}});
+							// If this pair is the whole kernel (the calculate_round_evals shape), the finalize
+							// step rides in the same launch: the last workgroup folds and publishes the values.
+							bool in_kernel = false;
+							if ((uint32_t)partner + 1 == n_ops && n_slots == 0 && n_ret > 0 && n_ret <= (uint32_t)bn::kFinMaxRets &&
+							    n_values <= (uint32_t)bn::kFinMaxValues) {
+								bn::fin_fuse fz{};
+								fz.args.n_terms = 2;
+								fz.args.n_values = n_values;
+								fz.args.n_ret = n_ret;
+								fz.args.n_slots = 2;
+								fz.args.seq = h_out ? ++ctx->mail_seq : 0;
+								fz.args.terms[0] = terms[terms.size() - 2];
+								fz.args.terms[1] = terms[terms.size() - 1];
+								for (uint32_t v = 0; v < n_values; v++) fz.args.init[v] = h_values[v];
+								for (uint32_t r = 0; r < n_ret; r++) fz.args.ret_ids[r] = ret_values[r];
+								fz.S = d_S;
+								fz.rets = d_out ? (f128 *)d_out : d_rets;
+								fz.mail = ctx->d_mail;
+								fz.counter = ctx->d_ticket;
+								prof_scope ps(ctx, BN_PROF_ROUND_EVAL);
+								hipError_t fe = bn::launch_roundeval_product(s, ctx->n_cu, hi, lo, k, row_len, d_S + slot, &fz);
+								if (fe == hipSuccess) {
+									in_kernel = true;
+									finalized_in_kernel = true;
+									fused_seq = fz.args.seq;
+								} else if (fe != hipErrorNotSupported) {
+									return bn::hip_fail(fe, "launch_roundeval_product (fused finalize)");
+								} else if (h_out) {
+									--ctx->mail_seq;
+								}
+							}
+							if (!in_kernel) {
+								prof_scope ps(ctx, BN_PROF_ROUND_EVAL);
+								BN_HIP(bn::launch_roundeval_product(s, ctx->n_cu, hi, lo, k, row_len, d_S + slot, nullptr));
+							}
 							n_slots += 2;
 							o = (uint32_t)partner; // consumed
 							fused = true;
@@ -866,7 +903,7 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 							hi[j] = fv[j].p;
 							lo[j] = fv[j].q; // nullptr => same at both
 						}
-						BN_HIP(bn::launch_roundeval_product(s, ctx->n_cu, hi, lo, k, row_len, d_S + slot));
+						BN_HIP(bn::launch_roundeval_product(s, ctx->n_cu, hi, lo, k, row_len, d_S + slot, nullptr));
 						terms.push_back(bn::fin_term{op.value, slot + 1, f128{op.scalar.lo, op.scalar.hi}});
 					}
 					n_slots += 2;
@@ -912,9 +949,10 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 	for (uint32_t v = 0; v < n_values; v++) fa.init[v] = h_values[v];
 	for (uint32_t r = 0; r < n_ret; r++) fa.ret_ids[r] = ret_values[r];
 	fa.n_slots = n_slots;
-	fa.seq = h_out ? ++ctx->mail_seq : 0;
+	fa.seq = finalized_in_kernel ? fused_seq : (h_out ? ++ctx->mail_seq : 0);
 	f128 *rets = d_out ? (f128 *)d_out : d_rets;
-	BN_HIP(bn::launch_finalize(s, fa, d_S, rets, ctx->d_mail));
+	if (!finalized_in_kernel)
+		BN_HIP(bn::launch_finalize(s, fa, d_S, rets, ctx->d_mail));
 	ctx->s_clean = true; // stream-ordered: the next launch on this stream sees zeroed slots
 	if (h_out) {
 		// spin on the sequence word the kernel publishes after the values (fine-grained host memory)

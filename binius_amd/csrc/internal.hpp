@@ -38,6 +38,7 @@ struct bn_ctx {
 	uint64_t mail_seq = 0;
 	bool s_clean = false;              // accumulator slots d_result[0..64) known to be zero
 	uint8_t *d_mul8 = nullptr;         // 64 KiB GF(2^8) product table (tiled NTT)
+	unsigned *d_ticket = nullptr;      // device-scope ticket counter for the fused finalize
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	int n_cu = 256;
 	// per-class kernel timing (bn_prof_begin / bn_prof_end)
@@ -88,8 +89,9 @@ struct fin_term {
 // fused round evaluation of a product composition: for factor j, hi[j] are the evaluations at 1;
 // lo[j] != null means the evaluation at infinity is lo[j]+hi[j], lo[j] == null means the factor is
 // the same at both points (e.g. the eq-indicator).  d_out[0] ^= S_1, d_out[1] ^= S_inf (unscaled).
+struct fin_fuse; // defined below: finalize work for the last workgroup of the round-eval kernel
 hipError_t launch_roundeval_product(hipStream_t s, int n_cu, const void *const *hi, const void *const *lo, uint32_t k,
-                                    uint64_t n, f128 *d_out);
+                                    uint64_t n, f128 *d_out, const fin_fuse *fuse);
 constexpr int kFinMaxTerms = 32, kFinMaxValues = 8, kFinMaxRets = 8;
 // passed BY VALUE as a kernel argument: no host->device staging copy on the per-round path
 struct fin_args {
@@ -101,6 +103,14 @@ struct fin_args {
 };
 // values[v] = init[v] ^ XOR_t coeff_t * S[slot_t], then rets[i] = values[ret_ids[i]]
 hipError_t launch_finalize(hipStream_t s, const fin_args &args, f128 *d_S, f128 *d_rets, f128 *d_mail);
+// fused form: the last workgroup to finish (device-scope ticket counter) runs the finalize body
+struct fin_fuse {
+	fin_args args;
+	f128 *S;
+	f128 *rets;
+	f128 *mail;
+	unsigned *counter; // zero before the launch; the last workgroup resets it
+};
 // raw (unscaled) sums S1 = sum_i a[half+i]*b[half+i], Sinf = sum_i (a[i]+a[half+i])*(b[i]+b[half+i])
 // XOR-accumulated into d_out[0], d_out[1] (caller zeroes them first).
 hipError_t launch_roundeval_product2(hipStream_t s, int n_cu, const void *a, const void *b, uint64_t half, f128 *d_out);
@@ -113,7 +123,7 @@ hipError_t launch_sum_product(hipStream_t s, int n_cu, const void *const *rows, 
 
 // ---- kernels_roundeval9.hip (the hot bivariate-product kernel)
 hipError_t launch_roundeval9_pair(hipStream_t s, int n_cu, const void *a_hi, const void *a_lo, const void *b_hi,
-                                  const void *b_lo, uint64_t n, f128 *d_out);
+                                  const void *b_lo, uint64_t n, f128 *d_out, const fin_fuse *fuse);
 hipError_t launch_roundeval9_split(hipStream_t s, int n_cu, const void *a, const void *b, uint64_t n, uint64_t split_off,
                                    f128 *d_out);
 

@@ -20,6 +20,7 @@
 
 #include "bitslice.hpp"
 #include "ctable.hpp"
+#include "finalize.hpp"
 #include "internal.hpp"
 
 namespace bn {
@@ -188,10 +189,11 @@ static unsigned prodsum_grid(uint64_t n, int n_cu)
 }
 
 hipError_t launch_roundeval_product(hipStream_t s, int n_cu, const void *const *hi, const void *const *lo, uint32_t k,
-                                    uint64_t n, f128 *d_out)
+                                    uint64_t n, f128 *d_out, const fin_fuse *fuse)
 {
 	if (k == 2 && lo[0] && lo[1])
-		return launch_roundeval9_pair(s, n_cu, hi[0], lo[0], hi[1], lo[1], n, d_out);
+		return launch_roundeval9_pair(s, n_cu, hi[0], lo[0], hi[1], lo[1], n, d_out, fuse);
+	if (fuse) return hipErrorNotSupported; // caller falls back to the stand-alone finalize kernel
 	bs_job job{};
 	job.k = k;
 	job.n = n;
@@ -209,7 +211,7 @@ hipError_t launch_roundeval_product2(hipStream_t s, int n_cu, const void *a, con
 {
 	const void *hi[2] = {(const char *)a + half * 16, (const char *)b + half * 16};
 	const void *lo[2] = {a, b};
-	return launch_roundeval_product(s, n_cu, hi, lo, 2, half, d_out);
+	return launch_roundeval_product(s, n_cu, hi, lo, 2, half, d_out, nullptr);
 }
 
 // d_out[0] ^= sum_i prod_j rows[j][i]   (d_out[1] is used as a second partial; caller XORs both)
@@ -319,60 +321,9 @@ hipError_t launch_compute_composite_generic(hipStream_t s, const void *const *d_
 }
 
 // ---- finalize: value[v] = init ^ XOR_t coeff_t * S[slot_t]; rets gathered ---------------------
-// one block of 128 lanes; lane i contributes bit_i(S) ? coeff * 2^i : 0 (gf128.hpp mul_basis)
 __global__ __launch_bounds__(128) void k_finalize(fin_args a, f128 *S, f128 *rets, f128 *mail)
 {
-	__shared__ uint64_t red[2][2];
-	__shared__ f128 values[kFinMaxValues];
-	const unsigned tid = threadIdx.x;
-	if (tid < a.n_values)
-		values[tid] = a.init[tid];
-	__syncthreads();
-	for (uint32_t t = 0; t < a.n_terms; t++) {
-		const fin_term tm = a.terms[t];
-		const f128 s = S[tm.slot];
-		f128 c = f128_zero();
-		if (tm.coeff.lo == 1 && tm.coeff.hi == 0) {
-			// batch coefficient alpha^0 = 1 (the only one on the measured single-claim path)
-			if (tid == 0) c = s;
-		} else {
-			const uint64_t word = tid < 64 ? s.lo : s.hi;
-			if ((word >> (tid & 63)) & 1)
-				c = mul_basis(tm.coeff, tid);
-		}
-		uint32_t w[4] = {(uint32_t)c.lo, (uint32_t)(c.lo >> 32), (uint32_t)c.hi, (uint32_t)(c.hi >> 32)};
-#pragma unroll
-		for (int q = 0; q < 4; q++)
-			w[q] = wave_xor(w[q]);
-		__syncthreads();
-		if ((tid & 63) == 0) {
-			red[tid >> 6][0] = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
-			red[tid >> 6][1] = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
-		}
-		__syncthreads();
-		if (tid == 0) {
-			values[tm.value].lo ^= red[0][0] ^ red[1][0];
-			values[tm.value].hi ^= red[0][1] ^ red[1][1];
-		}
-	}
-	__syncthreads();
-	if (tid < a.n_ret)
-		rets[tid] = values[a.ret_ids[tid]];
-	// leave the accumulator slots zero for the next launch (no memset on the per-round path)
-	if (tid < a.n_slots)
-		S[tid] = f128_zero();
-	if (a.seq) {
-		// zero-copy return: values, then the sequence word, into fine-grained host memory
-		if (tid < a.n_ret) {
-			const f128 v = values[a.ret_ids[tid]];
-			__hip_atomic_store(&mail[tid].lo, v.lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-			__hip_atomic_store(&mail[tid].hi, v.hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-		}
-		__threadfence_system();
-		__syncthreads();
-		if (tid == 0)
-			__hip_atomic_store(&mail[64].lo, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-	}
+	finalize_body(a, S, rets, mail);
 }
 
 hipError_t launch_finalize(hipStream_t s, const fin_args &args, f128 *d_S, f128 *d_rets, f128 *d_mail)

@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 
 #include "bitslice.hpp"
+#include "finalize.hpp"
 #include "internal.hpp"
 
 namespace bn {
@@ -65,7 +66,7 @@ __device__ __forceinline__ f128 combine64(uint64_t Z0, uint64_t Z2, uint64_t Z1p
 template <bool SPLIT, int WAVES, bool PREFETCH>
 __global__ __launch_bounds__(256, WAVES) void k_roundeval9(const uint32_t *__restrict__ a_hi, const uint32_t *__restrict__ a_lo,
                                                       const uint32_t *__restrict__ b_hi, const uint32_t *__restrict__ b_lo,
-                                                      uint64_t n, f128 *out)
+                                                      uint64_t n, f128 *out, fin_fuse fz)
 {
 	__shared__ uint4 tile[4][kWaveQ];
 	__shared__ uint32_t red[4][2][9][8];
@@ -239,6 +240,28 @@ __global__ __launch_bounds__(256, WAVES) void k_roundeval9(const uint32_t *__res
 		if (v)
 			atomicXor(reinterpret_cast<unsigned long long *>(out) + threadIdx.x, (unsigned long long)v);
 	}
+	if (fz.counter) {
+		// fused finalize: release our partial, take a ticket; the last workgroup folds the sums into
+		// the kernel's values and publishes them (same body as k_finalize)
+		// No release/acquire FENCES here (an agent-scope release writes back the whole L2: several
+		// microseconds per workgroup, measured +14 us per launch): every shared word is touched only by
+		// device-scope atomics, which are performed at the coherence point.  Each XOR-ing lane drains
+		// its own atomic (vmcnt(0)), the barrier orders the lanes, then one lane takes the ticket.
+		__shared__ unsigned is_last;
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			const unsigned t = atomicAdd(fz.counter, 1u);
+			is_last = (t == gridDim.x - 1) ? 1u : 0u;
+		}
+		__syncthreads();
+		if (is_last) {
+			// S is read with agent-scope atomic loads inside finalize_body (they bypass the L1)
+			finalize_body(fz.args, fz.S, fz.rets, fz.mail);
+			if (threadIdx.x == 0)
+				__hip_atomic_store(fz.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+	}
 }
 
 static unsigned grid9(uint64_t n, int n_cu, int waves)
@@ -252,21 +275,24 @@ static unsigned grid9(uint64_t n, int n_cu, int waves)
 
 template <bool SPLIT>
 static hipError_t launch9(hipStream_t s, int n_cu, const void *a_hi, const void *a_lo, const void *b_hi, const void *b_lo,
-                          uint64_t n, f128 *d_out)
+                          uint64_t n, f128 *d_out, const fin_fuse *fuse)
 {
+	fin_fuse fz{};
+	if (fuse) fz = *fuse;
+	if (n == 0 && fuse) return hipErrorNotSupported; // nothing to launch: the caller finalizes separately
 	if (n == 0) return hipSuccess;
 	const uint32_t *p0 = (const uint32_t *)a_hi, *p1 = (const uint32_t *)a_lo, *p2 = (const uint32_t *)b_hi, *p3 = (const uint32_t *)b_lo;
 	// 2 waves per SIMD with register prefetch measured fastest on MI355X (3 waves/SIMD spills to
 	// scratch: 0.36-0.70 ms vs 0.235 ms at n = 24; no prefetch: 0.277 ms) -- profiles/r01/.
-	hipLaunchKernelGGL((k_roundeval9<SPLIT, 2, true>), dim3(grid9(n, n_cu, 2)), dim3(256), 0, s, p0, p1, p2, p3, n, d_out);
+	hipLaunchKernelGGL((k_roundeval9<SPLIT, 2, true>), dim3(grid9(n, n_cu, 2)), dim3(256), 0, s, p0, p1, p2, p3, n, d_out, fz);
 	return hipGetLastError();
 }
 
 // d_out[0] ^= sum_i a_hi[i]*b_hi[i] ; d_out[1] ^= sum_i (a_lo[i]^a_hi[i])*(b_lo[i]^b_hi[i])
 hipError_t launch_roundeval9_pair(hipStream_t s, int n_cu, const void *a_hi, const void *a_lo, const void *b_hi,
-                                  const void *b_lo, uint64_t n, f128 *d_out)
+                                  const void *b_lo, uint64_t n, f128 *d_out, const fin_fuse *fuse)
 {
-	return launch9<false>(s, n_cu, a_hi, a_lo, b_hi, b_lo, n, d_out);
+	return launch9<false>(s, n_cu, a_hi, a_lo, b_hi, b_lo, n, d_out, fuse);
 }
 
 // d_out[0] ^= sum_{i<n} a[i]*b[i] ; d_out[1] ^= sum_{i<n} a[i+split]*b[i+split]
@@ -274,7 +300,7 @@ hipError_t launch_roundeval9_split(hipStream_t s, int n_cu, const void *a, const
                                    f128 *d_out)
 {
 	const char *a2 = (const char *)a + split_off * 16, *b2 = (const char *)b + split_off * 16;
-	return launch9<true>(s, n_cu, a, a2, b, b2, n, d_out);
+	return launch9<true>(s, n_cu, a, a2, b, b2, n, d_out, nullptr);
 }
 
 } // namespace bn
