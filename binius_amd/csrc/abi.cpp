@@ -544,8 +544,8 @@ int bn_compute_composite(bn_ctx *ctx, const void *const *d_rows, uint32_t n_rows
 	BN_REQUIRE(expr->n_vars == n_rows || (expr->n_vars <= n_rows), "composition not match with input");
 	BN_REQUIRE(expr->steps.size() <= 64, "circuit too large for this backend (max 64 steps)");
 	if (expr->shape == bn_expr::PRODUCT && expr->product_vars.size() == 2) {
-		BN_HIP(bn::launch_mul_elementwise(ctx->stream, ctx->n_cu, d_rows[expr->product_vars[0]], d_rows[expr->product_vars[1]],
-		                                  d_out, row_len, 1, 1, 0));
+		BN_HIP(bn::launch_mul9(ctx->stream, ctx->n_cu, d_rows[expr->product_vars[0]], 1, d_rows[expr->product_vars[1]], 1, 0, d_out,
+		                       row_len));
 		return BN_OK;
 	}
 	const void **d_ptrs = nullptr;
@@ -568,7 +568,7 @@ int bn_pairwise_product_reduce(bn_ctx *ctx, const void *d_in, uint64_t n, void *
 		BN_REQUIRE(round_lens[r] == ((uint64_t)1 << (log_n - r - 1)), "round_outputs[i].len() has the wrong size");
 	const void *src = d_in;
 	for (uint32_t r = 0; r < n_rounds; r++) {
-		BN_HIP(bn::launch_mul_elementwise(ctx->stream, ctx->n_cu, src, src, d_round_outs[r], round_lens[r], 2, 2, 1));
+		BN_HIP(bn::launch_mul9(ctx->stream, ctx->n_cu, src, 2, src, 2, 1, d_round_outs[r], round_lens[r]));
 		src = d_round_outs[r];
 	}
 	return BN_OK;

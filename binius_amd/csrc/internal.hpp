@@ -147,6 +147,10 @@ hipError_t launch_ntt(hipStream_t s, bool inverse, void *data, uint32_t elem_lev
                       const uint64_t *d_s_evals, uint32_t log_domain, uint32_t log_x, uint32_t log_y, uint32_t log_z,
                       uint64_t coset, uint32_t coset_bits, uint32_t skip_rounds);
 
+// ---- kernels_mul9.hip: out[i] = a[i*a_stride] * b[b_off + i*b_stride], bit-sliced
+hipError_t launch_mul9(hipStream_t s, int n_cu, const void *a, uint64_t a_stride, const void *b, uint64_t b_stride, uint64_t b_off,
+                       void *out, uint64_t n);
+
 // ---- kernels_ntt_tiled.hip
 hipError_t launch_build_mul8(hipStream_t s, uint8_t *d_tab);
 hipError_t launch_ntt_tiled(hipStream_t s, int n_cu, bool inverse, void *data, uint32_t elem_level, uint32_t tw_level,

@@ -1,0 +1,236 @@
+// binius_amd/csrc/kernels_mul9.hip -- element-wise GF(2^128) products, bit-sliced:
+//   out[i] = a[i * a_stride] * b[b_off + i * b_stride]
+// used by compute_composite for product compositions (crates/compute/src/layer.rs:459),
+// pairwise_product_reduce (layer.rs:505: a = in, strides 2, b_off 1) and as the first step of the
+// MLE-check round evaluation (b * eq, then the bivariate kernel).
+//
+// Same wave mapping as kernels_roundeval9.hip -- 7 groups of 9 lanes, each lane owning one of the 9
+// GF(2^32) limb-combination products of two Karatsuba levels -- but here the products are needed per
+// element, so after the multiplication the 9 partial products are exchanged through LDS, four lanes
+// per group rebuild the four 32-bit limbs of the result in the bit-sliced domain
+//     R0 = p0+p1+p3+p4                         R1 = p0+..+p5 + α(p1+p4)
+//     R2 = p0+p1+p5+p6+p7 + α(p4)              R3 = p0+p1+p2+p5+p6+p7+p8 + α(p1+p3+p5+p7) + α²(p4)
+// (α = multiplication by X_4 on 32 planes: pure XOR; derived from
+// pairwise_recursive_arithmetic.rs:18-28 applied at levels 6 and 7), transpose them back
+// (the 32x32 bit transpose is an involution) and store one word column each.
+// A register carries 32 elements (no [1|inf] packing); a wave-batch is 7 x 32 = 224 elements.
+#include <hip/hip_runtime.h>
+
+#include "bitslice.hpp"
+#include "internal.hpp"
+
+namespace bn {
+
+namespace {
+constexpr int kG = 7;            // groups per wave
+constexpr int kElems = 32;       // elements per group per batch
+constexpr int kWB = kG * kElems; // 224 elements per wave-batch
+constexpr int kQ = 9;            // uint4 per block (32 planes + pad)
+constexpr int kBlocks = 9 * kG;  // 63 partial-product blocks (>= 8*kG limb blocks)
+constexpr int kZero = kBlocks;   // zero block
+constexpr int kWaveQ4 = (kBlocks + 1) * kQ;
+} // namespace
+
+// Occupancy: with the rebuild phase the kernel needs > 256 registers at its peak; at 2 waves per SIMD
+// the compiler spills ~1 KiB per lane to scratch and a batch takes 55 us (measured), at 1 wave per
+// SIMD the spills go to AGPRs (v_accvgpr moves) and nothing touches memory.
+// STRIDE (in elements, the same for a and b) is a template parameter so that row addresses are one
+// base pointer plus immediates; a run-time stride makes the compiler keep 32 64-bit offsets alive
+// (spilled to scratch: measured 1.3 KiB per lane).
+template <int STRIDE>
+__global__ __launch_bounds__(256, 1) void k_mul9(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b,
+                                                uint32_t *__restrict__ out, uint64_t n)
+{
+	__shared__ uint4 tile[4][kWaveQ4];
+	const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const unsigned g = lane / 9, c = lane - g * 9;
+	const bool live = lane < 63;
+	const bool loader = live && c < 8;
+	const bool builder = live && c < 4;
+	uint4 *wt = tile[wave];
+	if (lane < kQ)
+		wt[kZero * kQ + lane] = uint4{0, 0, 0, 0};
+
+	const unsigned w = c & 3;
+	const uint32_t *src = ((c & 4) ? b : a) + w;
+	constexpr uint64_t stride_w = (uint64_t)STRIDE << 2; // in 32-bit words
+	unsigned mask;
+	switch (c) {
+	case 0: mask = 1; break;
+	case 1: mask = 2; break;
+	case 2: mask = 3; break;
+	case 3: mask = 4; break;
+	case 4: mask = 8; break;
+	case 5: mask = 12; break;
+	case 6: mask = 5; break;
+	case 7: mask = 10; break;
+	default: mask = 15; break;
+	}
+	if (!live) mask = 0;
+	unsigned off_a[4], off_b[4];
+#pragma unroll
+	for (int s = 0; s < 4; s++) {
+		const bool use = (mask >> s) & 1;
+		off_a[s] = (use ? (unsigned)(s * kG + g) : (unsigned)kZero) * kQ;
+		off_b[s] = (use ? (unsigned)((4 + s) * kG + g) : (unsigned)kZero) * kQ;
+	}
+	const unsigned gg = live ? g : 0;
+	const unsigned off_w = (loader ? (c * kG + gg) : 0u) * kQ;
+	const unsigned off_pp = (live ? (c * kG + g) : (unsigned)kZero) * kQ; // where this lane publishes its partial product
+	// partial products a builder needs: X (plain), Y (through alpha), W (through alpha^2); bit k = p_k
+	unsigned setX = 0, setY = 0, setW = 0;
+	if (builder) {
+		switch (c) {
+		case 0: setX = 0x01B; break;                              // p0 p1 p3 p4
+		case 1: setX = 0x03F; setY = 0x012; break;                // p0..p5 ; alpha(p1 p4)
+		case 2: setX = 0x0E3; setY = 0x010; break;                // p0 p1 p5 p6 p7 ; alpha(p4)
+		default: setX = 0x1E7; setY = 0x0AA; setW = 0x010; break; // p0 p1 p2 p5 p6 p7 p8 ; alpha(p1 p3 p5 p7) ; alpha^2(p4)
+		}
+	}
+	// The slot offsets of the rebuild phase are recomputed per batch from (setX, setY, setW, g) behind
+	// an opaque copy of g: hoisted out of the loop they are 15 more live registers across the
+	// multiplication and push the kernel into scratch (measured: 55 us per batch instead of ~5).
+	const uint64_t n_batches = (n + kWB - 1) / kWB;
+	const uint64_t wave_global = (uint64_t)blockIdx.x * 4 + wave;
+	const uint64_t n_waves = (uint64_t)gridDim.x * 4;
+
+	for (uint64_t bt = wave_global; bt < n_batches; bt += n_waves) {
+		const uint64_t base = bt * kWB + gg; // element of row j: base + 7*j
+		uint32_t r[32];
+		if ((bt + 1) * kWB <= n) {
+			const uint32_t *p = src + base * stride_w;
+#pragma unroll
+			for (int j = 0; j < 32; j++)
+				r[j] = p[(uint64_t)j * 7 * stride_w];
+		} else {
+			// ragged last batch: 8 rows at a time so only a few guarded addresses are live at once
+#pragma unroll
+			for (int j0 = 0; j0 < 32; j0 += 8) {
+#pragma unroll
+				for (int j = j0; j < j0 + 8; j++) {
+					const uint64_t e = base + 7 * (uint64_t)j;
+					const bool ok = e < n;
+					const uint32_t v = src[ok ? e * stride_w : 0];
+					r[j] = ok ? v : 0u;
+				}
+				__builtin_amdgcn_sched_barrier(0);
+			}
+		}
+		transpose32(r);
+		if (loader) {
+#pragma unroll
+			for (int q = 0; q < 8; q++)
+				wt[off_w + q] = uint4{r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]};
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		uint32_t A[32], B[32];
+#pragma unroll
+		for (int q = 0; q < 8; q++) {
+			const uint4 x0 = wt[off_a[0] + q], x1 = wt[off_a[1] + q], x2 = wt[off_a[2] + q], x3 = wt[off_a[3] + q];
+			const uint4 y0 = wt[off_b[0] + q], y1 = wt[off_b[1] + q], y2 = wt[off_b[2] + q], y3 = wt[off_b[3] + q];
+			A[4 * q] = xor3(x0.x, x1.x, x2.x) ^ x3.x;
+			A[4 * q + 1] = xor3(x0.y, x1.y, x2.y) ^ x3.y;
+			A[4 * q + 2] = xor3(x0.z, x1.z, x2.z) ^ x3.z;
+			A[4 * q + 3] = xor3(x0.w, x1.w, x2.w) ^ x3.w;
+			B[4 * q] = xor3(y0.x, y1.x, y2.x) ^ y3.x;
+			B[4 * q + 1] = xor3(y0.y, y1.y, y2.y) ^ y3.y;
+			B[4 * q + 2] = xor3(y0.z, y1.z, y2.z) ^ y3.z;
+			B[4 * q + 3] = xor3(y0.w, y1.w, y2.w) ^ y3.w;
+			if (q & 1)
+				__builtin_amdgcn_sched_barrier(0);
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		uint32_t P[32];
+		bs_mul<5>(A, B, P);
+		// publish the partial product (the limb tile is dead now: same LDS region)
+#pragma unroll
+		for (int q = 0; q < 8; q++)
+			wt[off_pp + q] = uint4{P[4 * q], P[4 * q + 1], P[4 * q + 2], P[4 * q + 3]};
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		// rebuild result limb c (lanes c < 4): R = X ^ alpha(Y ^ alpha(W)).  The LDS offsets are derived
+		// from an opaque copy of g that is re-laundered against the previous quad's result: without that
+		// chain the compiler hoists all ~100 ds_read_b128 of this phase to the top and spills their
+		// results to scratch (measured: 55 us per batch).
+		{
+			unsigned gl = g;
+			asm volatile("" : "+v"(gl));
+			constexpr int ycand[5] = {1, 3, 4, 5, 7};
+			uint32_t t0[32], t1[32];
+#pragma unroll
+			for (int q = 0; q < 8; q++) {
+				const unsigned offW = (setW ? (unsigned)(4 * kG) + gl : (unsigned)kZero) * kQ;
+				const uint4 ww = wt[offW + q];
+				t0[4 * q] = ww.x; t0[4 * q + 1] = ww.y; t0[4 * q + 2] = ww.z; t0[4 * q + 3] = ww.w;
+			}
+			bs_mul_alpha<5>(t0, t1); // t1 = alpha(W)
+			asm volatile("" : "+v"(gl) : "v"(t1[31]));
+#pragma unroll
+			for (int q = 0; q < 8; q++) {
+				uint4 y{0, 0, 0, 0};
+#pragma unroll
+				for (int s = 0; s < 5; s++) {
+					const unsigned off = (((setY >> ycand[s]) & 1) ? (unsigned)(ycand[s] * kG) + gl : (unsigned)kZero) * kQ;
+					const uint4 t = wt[off + q];
+					y.x ^= t.x; y.y ^= t.y; y.z ^= t.z; y.w ^= t.w;
+				}
+				t1[4 * q] ^= y.x; t1[4 * q + 1] ^= y.y; t1[4 * q + 2] ^= y.z; t1[4 * q + 3] ^= y.w; // Y + alpha(W)
+				if (q & 1) asm volatile("" : "+v"(gl) : "v"(t1[4 * q]));
+			}
+			bs_mul_alpha<5>(t1, t0); // t0 = alpha(Y) + alpha^2(W)
+			asm volatile("" : "+v"(gl) : "v"(t0[31]));
+#pragma unroll
+			for (int q = 0; q < 8; q++) {
+				uint4 x{0, 0, 0, 0};
+#pragma unroll
+				for (int k = 0; k < 9; k++) {
+					const unsigned off = (((setX >> k) & 1) ? (unsigned)(k * kG) + gl : (unsigned)kZero) * kQ;
+					const uint4 t = wt[off + q];
+					x.x ^= t.x; x.y ^= t.y; x.z ^= t.z; x.w ^= t.w;
+				}
+				r[4 * q] = t0[4 * q] ^ x.x; r[4 * q + 1] = t0[4 * q + 1] ^ x.y; r[4 * q + 2] = t0[4 * q + 2] ^ x.z; r[4 * q + 3] = t0[4 * q + 3] ^ x.w;
+				asm volatile("" : "+v"(gl) : "v"(r[4 * q]));
+			}
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		transpose32(r); // planes -> word c of 32 elements
+		if (builder) {
+			uint32_t *dst = out + c + (base << 2); // builder lanes: c == word index
+			if ((bt + 1) * kWB <= n) {
+#pragma unroll
+				for (int j = 0; j < 32; j++)
+					dst[28 * j] = r[j];
+			} else {
+#pragma unroll
+				for (int j = 0; j < 32; j++)
+					if (base + 7 * (uint64_t)j < n)
+						dst[28 * j] = r[j];
+			}
+		}
+	}
+}
+
+hipError_t launch_mul9(hipStream_t s, int n_cu, const void *a, uint64_t a_stride, const void *b, uint64_t b_stride, uint64_t b_off,
+                       void *out, uint64_t n)
+{
+	if (n == 0) return hipSuccess;
+	const uint64_t n_batches = (n + kWB - 1) / kWB;
+	uint64_t blocks = (n_batches + 3) / 4;
+	const uint64_t cap = (uint64_t)n_cu; // one workgroup per CU: the kernel is built for 1 wave per SIMD (AGPR spill space instead of scratch)
+	if (blocks > cap) blocks = cap;
+	const uint32_t *pb = (const uint32_t *)b + b_off * 4;
+	if (a_stride == 1 && b_stride == 1)
+		hipLaunchKernelGGL(k_mul9<1>, dim3((unsigned)blocks), dim3(256), 0, s, (const uint32_t *)a, pb, (uint32_t *)out, n);
+	else if (a_stride == 2 && b_stride == 2)
+		hipLaunchKernelGGL(k_mul9<2>, dim3((unsigned)blocks), dim3(256), 0, s, (const uint32_t *)a, pb, (uint32_t *)out, n);
+	else
+		return hipErrorInvalidValue;
+	return hipGetLastError();
+}
+
+} // namespace bn
