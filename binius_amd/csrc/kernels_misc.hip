@@ -91,6 +91,81 @@ __global__ __launch_bounds__(256) void k_fold(const uint64_t *mat, const uint4 *
 	}
 }
 
+// fold_left / fold_right with nibble tables of the vector entries (IOTA in {3,4,5}).
+// out[i] = sum_j vec[j] * m_ij with m_ij in T_IOTA: vec[j] is constant for the whole launch, so
+// vec[j] * m = XOR_p T_j[p][nibble_p(m)], T_j[p][e] = vec[j] * (e << 4p), p < 2^IOTA/4.  A chunk of
+// J = 256/P vectors' tables (64 KiB) lives in LDS; lookups are conflict-free for the same reason as
+// in ctable.hpp (one 16-entry table = one bank row, all lanes use the same (j, p)).
+template <int IOTA, bool LEFT, int R>
+__global__ __launch_bounds__(256) void k_fold_tab(const uint64_t *mat, const uint4 *vec, uint64_t vec_len, uint4 *out, uint64_t out_len)
+{
+	constexpr int P = (1 << IOTA) / 4;  // nibbles per subfield element
+	constexpr int J = 256 / P;          // vectors per LDS chunk (J * P * 256 B = 64 KiB)
+	constexpr int NB = 1 << IOTA;       // basis products per vector
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem_fold[];
+	uint4 *T = reinterpret_cast<uint4 *>(smem_fold);                 // [J][P][16]
+	uint4 *basis = reinterpret_cast<uint4 *>(smem_fold + 65536);     // [J][NB]
+	const unsigned tid = threadIdx.x;
+	const uint64_t tile0 = (uint64_t)blockIdx.x * 256 * R;
+	uint4 acc[R];
+#pragma unroll
+	for (int r = 0; r < R; r++) acc[r] = uint4{0, 0, 0, 0};
+	for (uint64_t j0 = 0; j0 < vec_len; j0 += J) {
+		const uint64_t jn = (vec_len - j0) < (uint64_t)J ? (vec_len - j0) : (uint64_t)J;
+		__syncthreads();
+		for (unsigned q = tid; q < jn * NB; q += 256) {
+			const unsigned jj = q / NB, b = q % NB;
+			basis[q] = to_u4(mul_basis(to_f128(vec[j0 + jj]), b));
+		}
+		__syncthreads();
+		for (unsigned q = tid; q < jn * P * 16; q += 256) {
+			const unsigned e = q & 15, p = (q >> 4) % P, jj = q / (16 * P);
+			const uint4 *bp = basis + jj * NB + 4 * p;
+			uint4 v{0, 0, 0, 0};
+			if (e & 1) v = xor4(v, bp[0]);
+			if (e & 2) v = xor4(v, bp[1]);
+			if (e & 4) v = xor4(v, bp[2]);
+			if (e & 8) v = xor4(v, bp[3]);
+			T[q] = v;
+		}
+		__syncthreads();
+#pragma unroll
+		for (int r = 0; r < R; r++) {
+			const uint64_t i = tile0 + (uint64_t)r * 256 + tid;
+			if (i >= out_len) continue;
+			for (uint64_t jj = 0; jj < jn; jj++) {
+				const uint64_t idx = LEFT ? ((j0 + jj) * out_len + i) : (i * vec_len + j0 + jj);
+				const uint32_t m = (uint32_t)subfield_limb<IOTA>(mat, idx);
+				const char *tb = reinterpret_cast<const char *>(T + jj * P * 16);
+#pragma unroll
+				for (int p = 0; p < P; p++) {
+					const uint32_t off = ((m >> (4 * p)) & 15u) << 4;
+					acc[r] = xor4(acc[r], *reinterpret_cast<const uint4 *>(tb + p * 256 + off));
+				}
+			}
+		}
+	}
+#pragma unroll
+	for (int r = 0; r < R; r++) {
+		const uint64_t i = tile0 + (uint64_t)r * 256 + tid;
+		if (i < out_len) out[i] = acc[r];
+	}
+}
+
+template <int IOTA, bool LEFT>
+static hipError_t run_fold_tab(hipStream_t s, const void *mat, const void *vec, uint64_t vec_len, void *out, uint64_t out_len)
+{
+	constexpr int R = 4;
+	constexpr int NB = 1 << IOTA, P = NB / 4, J = 256 / P;
+	const size_t lds = 65536 + (size_t)J * NB * 16;
+	const uint64_t blocks = (out_len + 256 * R - 1) / (256 * R);
+	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fold_tab<IOTA, LEFT, R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+	if (e != hipSuccess) return e;
+	hipLaunchKernelGGL((k_fold_tab<IOTA, LEFT, R>), dim3((unsigned)blocks), dim3(256), lds, s, (const uint64_t *)mat, (const uint4 *)vec, vec_len,
+	                   (uint4 *)out, out_len);
+	return hipGetLastError();
+}
+
 template <template <int> class Launcher, typename... Args>
 static hipError_t dispatch_level(uint32_t level, Args... args)
 {
@@ -146,6 +221,11 @@ hipError_t launch_fold_left(hipStream_t s, int n_cu, const void *mat, uint32_t t
                             uint64_t vec_len, void *out, uint64_t out_len)
 {
 	if (out_len == 0) return hipSuccess;
+	if (out_len >= 1024) {
+		if (tower_level == 3) return run_fold_tab<3, true>(s, mat, vec, vec_len, out, out_len);
+		if (tower_level == 4) return run_fold_tab<4, true>(s, mat, vec, vec_len, out, out_len);
+		if (tower_level == 5) return run_fold_tab<5, true>(s, mat, vec, vec_len, out, out_len);
+	}
 	uint64_t want = (out_len + 255) / 256;
 	unsigned g = (unsigned)(want < (uint64_t)n_cu * 8 ? want : (uint64_t)n_cu * 8);
 	return dispatch_level<foldl_launcher>(tower_level, s, g, mat, vec, vec_len, out, out_len);
@@ -155,6 +235,11 @@ hipError_t launch_fold_right(hipStream_t s, int n_cu, const void *mat, uint32_t 
                              uint64_t vec_len, void *out, uint64_t out_len)
 {
 	if (out_len == 0) return hipSuccess;
+	if (out_len >= 1024) {
+		if (tower_level == 3) return run_fold_tab<3, false>(s, mat, vec, vec_len, out, out_len);
+		if (tower_level == 4) return run_fold_tab<4, false>(s, mat, vec, vec_len, out, out_len);
+		if (tower_level == 5) return run_fold_tab<5, false>(s, mat, vec, vec_len, out, out_len);
+	}
 	uint64_t want = (out_len + 255) / 256;
 	unsigned g = (unsigned)(want < (uint64_t)n_cu * 8 ? want : (uint64_t)n_cu * 8);
 	return dispatch_level<foldr_launcher>(tower_level, s, g, mat, vec, vec_len, out, out_len);

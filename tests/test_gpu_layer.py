@@ -233,6 +233,27 @@ def test_fold_left_right(hal, oracle, level, log_q, left):
     assert np.array_equal(hal.copy_d2h(do), exp)
 
 
+@pytest.mark.parametrize("level,log_q", [(3, 2), (4, 5), (5, 6), (5, 1)])
+@pytest.mark.parametrize("left", [True, False])
+def test_fold_left_right_table_path(hal, oracle, level, log_q, left):
+    """Larger outputs take the LDS nibble-table kernel (out_len >= 1024, levels 3..5)."""
+    alloc = hal.dev_alloc()
+    log_evals = 13 + log_q - 2
+    mat = rnd(oracle, 160 + level, (1 << log_evals) >> (7 - level))
+    vec = rnd(oracle, 161, 1 << log_q)
+    out_len = 1 << (log_evals - log_q)
+    assert out_len >= 1024
+    dm, dv, do = upload(hal, alloc, mat), upload(hal, alloc, vec), alloc.alloc(out_len)
+    exp = oracle.arr(out_len)
+    if left:
+        hal.fold_left(dm, level, dv, do)
+        assert oracle.fold_left(mat, level, vec, exp) == 0
+    else:
+        hal.fold_right(dm, level, dv, do)
+        assert oracle.fold_right(mat, level, vec, exp) == 0
+    assert np.array_equal(hal.copy_d2h(do), exp)
+
+
 def test_fold_validation(hal):
     import binius_amd
 
