@@ -174,16 +174,30 @@ def main():
     ms_per_step = elapsed * 1e3 / args.steps
 
     # ---- roofline of the dominant kernel, from hipEvent pairs recorded around every launch in the timed region
-    # algorithmic bytes: round-eval at r remaining vars reads 16*m*2^r;
-    # one fold launch at r reads 16*2^r and writes 8*2^r = 24*2^r.
-    re_bytes = sum(16 * m * (1 << r) for r in range(1, n_vars + 1)) * args.steps
-    fold_bytes = sum(24 * (1 << r) for r in range(1, n_vars + 1)) * m * args.steps
+    # Algorithmic bytes, per launch at r remaining variables:
+    #   round evaluation alone  reads 16*m*2^r                                  (round 0 only)
+    #   fold + next evaluation  reads 16*m*2^r, writes 8*m*2^r = 24*m*2^r       (rounds 0..n-2, one fused kernel;
+    #                           the evaluation consumes the folded values on chip -- no bytes of its own)
+    #   fold alone              24*m*2^r                                        (the last fold, r = 1)
+    # The ABI decides per launch which kernel runs; the launch counts per class say what actually ran.
     re_ms, re_cnt = prof["round_eval"]
     fo_ms, fo_cnt = prof["fold"]
+    fe_ms, fe_cnt = prof["fold_eval"]
+    fused = fe_cnt > 0
+    if fused:
+        re_bytes = 16 * m * (1 << n_vars) * args.steps
+        fe_bytes = sum(24 * m * (1 << r) for r in range(2, n_vars + 1)) * args.steps
+        fold_bytes = 24 * m * 2 * args.steps
+    else:
+        re_bytes = sum(16 * m * (1 << r) for r in range(1, n_vars + 1)) * args.steps
+        fe_bytes = 0
+        fold_bytes = sum(24 * (1 << r) for r in range(1, n_vars + 1)) * m * args.steps
     kernels = {
         "k_roundeval9(round_eval)": (re_bytes, re_ms, re_cnt),
         "k_extrapolate_line(fold)": (fold_bytes, fo_ms, fo_cnt),
     }
+    if fused:
+        kernels["k_foldeval9(fold+round_eval)"] = (fe_bytes, fe_ms, fe_cnt)
     dom = max(kernels, key=lambda k: kernels[k][1])
     b, ms, cnt = kernels[dom]
     achieved = b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0

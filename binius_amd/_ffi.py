@@ -409,14 +409,14 @@ class Context:
         _check(lib().bn_timer_end_ms(self._h, C.byref(ms)))
         return ms.value
 
-    PROF_CLASSES = ("round_eval", "fold", "tensor_expand", "ntt", "other")
+    PROF_CLASSES = ("round_eval", "fold", "tensor_expand", "ntt", "other", "fold_eval")
 
     def prof_begin(self):
         _check(lib().bn_prof_begin(self._h))
 
     def prof_end(self):
-        ms = (C.c_double * 5)()
-        cnt = (C.c_uint64 * 5)()
+        ms = (C.c_double * len(self.PROF_CLASSES))()
+        cnt = (C.c_uint64 * len(self.PROF_CLASSES))()
         _check(lib().bn_prof_end(self._h, ms, cnt))
         return {k: (ms[i], int(cnt[i])) for i, k in enumerate(self.PROF_CLASSES)}
 
@@ -452,6 +452,18 @@ class Context:
     def extrapolate_line(self, evals_0, evals_1, z):
         zz = to_f128(z)
         _check(lib().bn_extrapolate_line(self._h, evals_0.ptr, evals_0.len, evals_1.ptr, evals_1.len, C.byref(zz)))
+
+    def extrapolate_line_batch(self, evals_0, evals_1, z):
+        """The `map` scope of a fold (v3/bivariate_product.rs:217-228): the same z applied to several
+        (evals_0, evals_1) pairs of equal length."""
+        n = evals_0[0].len if evals_0 else 0
+        for a, b in zip(evals_0, evals_1):
+            if a.len != n or b.len != n:
+                raise BnError(BN_ERR_INPUT_VALIDATION, "input validation: extrapolate_line batch slices differ in length")
+        p0 = (C.c_void_p * len(evals_0))(*[a.ptr for a in evals_0])
+        p1 = (C.c_void_p * len(evals_1))(*[b.ptr for b in evals_1])
+        zz = to_f128(z)
+        _check(lib().bn_extrapolate_line_batch(self._h, p0, p1, len(evals_0), n, C.byref(zz)))
 
     def tensor_expand(self, log_n, coordinates, data):
         c = _f128_array(list(coordinates))

@@ -96,6 +96,41 @@ struct prof_scope {
 			return bn::fail(BN_ERR_INPUT_VALIDATION, std::string("input validation: ") + (msg)); \
 	} while (0)
 
+// Launch a deferred extrapolate_line batch (see bn_extrapolate_line_batch).  Every entry point
+// that can observe device memory or the stream calls this first, so the deferral is invisible.
+static int flush_copies(bn_ctx *ctx)
+{
+	for (const auto &c : ctx->pend_copies)
+		BN_HIP(hipMemcpyAsync(c.dst, c.src, c.n * sizeof(f128), hipMemcpyDeviceToDevice, ctx->stream));
+	ctx->pend_copies.clear();
+	return BN_OK;
+}
+
+static int flush_pending(bn_ctx *ctx)
+{
+	if (!ctx->pend_copies.empty()) {
+		int rc = flush_copies(ctx);
+		if (rc) return rc;
+	}
+	if (!ctx->pend.active) return BN_OK;
+	ctx->pend.active = false;
+	bn::fold_batch fb{};
+	for (uint32_t i = 0; i < ctx->pend.count; i++) {
+		fb.x0[i] = ctx->pend.x0[i];
+		fb.x1[i] = ctx->pend.x1[i];
+		if (ctx->pend.src0[i] != ctx->pend.x0[i]) // absorbed copy: materialise it, then fold in place
+			BN_HIP(hipMemcpyAsync(ctx->pend.x0[i], ctx->pend.src0[i], ctx->pend.n * sizeof(f128), hipMemcpyDeviceToDevice, ctx->stream));
+	}
+	prof_scope ps(ctx, BN_PROF_FOLD);
+	BN_HIP(bn::launch_extrapolate_line_batch(ctx->stream, ctx->n_cu, fb, ctx->pend.count, ctx->pend.n, ctx->pend.z));
+	return BN_OK;
+}
+#define BN_FLUSH(ctx)                    \
+	do {                                 \
+		int rc_ = flush_pending(ctx);    \
+		if (rc_) return rc_;             \
+	} while (0)
+
 static bool is_pow2(uint64_t n) { return n && !(n & (n - 1)); }
 static uint32_t ilog2(uint64_t n)
 {
@@ -153,6 +188,7 @@ int bn_ctx_create(int device, uint64_t arena_elems, bn_ctx **out)
 		}
 		ctx->arena_elems = arena_elems;
 	}
+	ctx->lazy_fold = getenv("BN_NO_LAZY_FOLD") == nullptr;
 	*out = ctx;
 	return BN_OK;
 }
@@ -186,6 +222,7 @@ int bn_ctx_destroy(bn_ctx *ctx)
 int bn_arena_base(bn_ctx *ctx, void **d_base, uint64_t *elems)
 {
 	BN_REQUIRE(ctx && d_base && elems, "null argument");
+	BN_FLUSH(ctx);
 	*d_base = ctx->arena;
 	*elems = ctx->arena_elems;
 	return BN_OK;
@@ -194,6 +231,7 @@ int bn_arena_base(bn_ctx *ctx, void **d_base, uint64_t *elems)
 int bn_ctx_set_stream(bn_ctx *ctx, void *hip_stream)
 {
 	BN_REQUIRE(ctx, "null ctx");
+	BN_FLUSH(ctx);
 	BN_HIP(hipSetDevice(ctx->device));
 	BN_HIP(hipStreamSynchronize(ctx->stream));
 	if (hip_stream == nullptr) {
@@ -213,6 +251,7 @@ int bn_ctx_set_stream(bn_ctx *ctx, void *hip_stream)
 int bn_ctx_get_stream(bn_ctx *ctx, void **hip_stream)
 {
 	BN_REQUIRE(ctx && hip_stream, "null argument");
+	BN_FLUSH(ctx);
 	*hip_stream = (void *)ctx->stream;
 	return BN_OK;
 }
@@ -220,6 +259,7 @@ int bn_ctx_get_stream(bn_ctx *ctx, void **hip_stream)
 int bn_sync(bn_ctx *ctx)
 {
 	BN_REQUIRE(ctx, "null ctx");
+	BN_FLUSH(ctx);
 	BN_HIP(hipStreamSynchronize(ctx->stream));
 	return BN_OK;
 }
@@ -227,6 +267,7 @@ int bn_sync(bn_ctx *ctx)
 int bn_prof_begin(bn_ctx *ctx)
 {
 	BN_REQUIRE(ctx, "null ctx");
+	BN_FLUSH(ctx);
 	for (auto &r : ctx->prof) {
 		ctx->ev_pool.push_back(r.a);
 		ctx->ev_pool.push_back(r.b);
@@ -239,6 +280,7 @@ int bn_prof_begin(bn_ctx *ctx)
 int bn_prof_end(bn_ctx *ctx, double *ms_by_class, uint64_t *launches_by_class)
 {
 	BN_REQUIRE(ctx && ms_by_class && launches_by_class, "null argument");
+	BN_FLUSH(ctx);
 	ctx->prof_on = false;
 	BN_HIP(hipStreamSynchronize(ctx->stream));
 	for (int i = 0; i < BN_PROF_N; i++) {
@@ -260,6 +302,7 @@ int bn_prof_end(bn_ctx *ctx, double *ms_by_class, uint64_t *launches_by_class)
 int bn_timer_begin(bn_ctx *ctx)
 {
 	BN_REQUIRE(ctx, "null ctx");
+	BN_FLUSH(ctx);
 	BN_HIP(hipEventRecord(ctx->ev0, ctx->stream));
 	return BN_OK;
 }
@@ -267,6 +310,7 @@ int bn_timer_begin(bn_ctx *ctx)
 int bn_timer_end_ms(bn_ctx *ctx, float *ms)
 {
 	BN_REQUIRE(ctx && ms, "null argument");
+	BN_FLUSH(ctx);
 	BN_HIP(hipEventRecord(ctx->ev1, ctx->stream));
 	BN_HIP(hipEventSynchronize(ctx->ev1));
 	BN_HIP(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
@@ -277,6 +321,7 @@ int bn_timer_end_ms(bn_ctx *ctx, float *ms)
 int bn_copy_h2d(bn_ctx *ctx, const bn_f128 *h_src, uint64_t src_len, void *d_dst, uint64_t dst_len)
 {
 	BN_REQUIRE(ctx, "null ctx");
+	BN_FLUSH(ctx);
 	BN_REQUIRE(src_len == dst_len, "precondition: src and dst buffers must have the same length");
 	if (src_len == 0) return BN_OK;
 	BN_HIP(hipMemcpyAsync(d_dst, h_src, src_len * sizeof(f128), hipMemcpyHostToDevice, ctx->stream));
@@ -288,6 +333,7 @@ int bn_copy_h2d(bn_ctx *ctx, const bn_f128 *h_src, uint64_t src_len, void *d_dst
 int bn_copy_d2h(bn_ctx *ctx, const void *d_src, uint64_t src_len, bn_f128 *h_dst, uint64_t dst_len)
 {
 	BN_REQUIRE(ctx, "null ctx");
+	BN_FLUSH(ctx);
 	BN_REQUIRE(src_len == dst_len, "precondition: src and dst buffers must have the same length");
 	if (src_len == 0) return BN_OK;
 	BN_HIP(hipMemcpyAsync(h_dst, d_src, src_len * sizeof(f128), hipMemcpyDeviceToHost, ctx->stream));
@@ -300,6 +346,12 @@ int bn_copy_d2d(bn_ctx *ctx, const void *d_src, uint64_t src_len, void *d_dst, u
 	BN_REQUIRE(ctx, "null ctx");
 	BN_REQUIRE(src_len == dst_len, "precondition: src and dst buffers must have the same length");
 	if (src_len == 0) return BN_OK;
+	if (ctx->lazy_fold && !ctx->pend.active && ctx->pend_copies.size() < 8) {
+		// deferred: a fold into d_dst may absorb it (see bn_ctx::pending_copy)
+		ctx->pend_copies.push_back({d_src, d_dst, src_len});
+		return BN_OK;
+	}
+	BN_FLUSH(ctx);
 	BN_HIP(hipMemcpyAsync(d_dst, d_src, src_len * sizeof(f128), hipMemcpyDeviceToDevice, ctx->stream));
 	return BN_OK;
 }
@@ -307,6 +359,7 @@ int bn_copy_d2d(bn_ctx *ctx, const void *d_src, uint64_t src_len, void *d_dst, u
 int bn_fill(bn_ctx *ctx, void *d_dst, uint64_t n, const bn_f128 *value)
 {
 	BN_REQUIRE(ctx && value, "null argument");
+	BN_FLUSH(ctx);
 	BN_HIP(bn::launch_fill(ctx->stream, d_dst, n, to_f(value)));
 	return BN_OK;
 }
@@ -393,6 +446,7 @@ int bn_expr_n_vars(const bn_expr *expr, uint32_t *n_vars)
 int bn_extrapolate_line(bn_ctx *ctx, void *d_evals_0, uint64_t n0, const void *d_evals_1, uint64_t n1, const bn_f128 *z)
 {
 	BN_REQUIRE(ctx && z, "null argument");
+	BN_FLUSH(ctx);
 	BN_REQUIRE(n0 == n1, "evals_0 and evals_1 must be the same length");
 	prof_scope ps(ctx, BN_PROF_FOLD);
 	BN_HIP(bn::launch_extrapolate_line(ctx->stream, ctx->n_cu, d_evals_0, d_evals_1, n0, to_f(z)));
@@ -405,19 +459,45 @@ int bn_extrapolate_line_batch(bn_ctx *ctx, void *const *d_evals_0, const void *c
 	BN_REQUIRE(ctx && z && d_evals_0 && d_evals_1, "null argument");
 	BN_REQUIRE(count <= (uint32_t)bn::kFoldBatchMax, "too many slices in one extrapolate_line batch");
 	if (count == 0) return BN_OK;
-	bn::fold_batch fb{};
-	for (uint32_t i = 0; i < count; i++) {
-		fb.x0[i] = d_evals_0[i];
-		fb.x1[i] = d_evals_1[i];
+	// deferred copies whose destination is one of the evals_0 are absorbed (every one of them must
+	// be, otherwise they all run now, in issue order)
+	const void *src0[bn::kFoldBatchMax];
+	for (uint32_t i = 0; i < count; i++) src0[i] = d_evals_0[i];
+	if (!ctx->pend_copies.empty() && !ctx->pend.active) {
+		size_t absorbed = 0;
+		for (const auto &c : ctx->pend_copies)
+			for (uint32_t i = 0; i < count; i++)
+				if (c.dst == d_evals_0[i] && c.n == n && src0[i] == d_evals_0[i]) {
+					src0[i] = c.src;
+					absorbed++;
+					break;
+				}
+		if (absorbed == ctx->pend_copies.size()) {
+			ctx->pend_copies.clear();
+		} else {
+			for (uint32_t i = 0; i < count; i++) src0[i] = d_evals_0[i];
+		}
 	}
-	prof_scope ps(ctx, BN_PROF_FOLD);
-	BN_HIP(bn::launch_extrapolate_line_batch(ctx->stream, ctx->n_cu, fb, count, n, to_f(z)));
+	BN_FLUSH(ctx);
+	// Deferred: the next API call launches it -- or, if that call is the round evaluation of exactly
+	// these arrays, both run as one kernel (kernels_foldeval9.hip).
+	ctx->pend.active = true;
+	ctx->pend.count = count;
+	ctx->pend.n = n;
+	ctx->pend.z = to_f(z);
+	for (uint32_t i = 0; i < count; i++) {
+		ctx->pend.x0[i] = d_evals_0[i];
+		ctx->pend.x1[i] = d_evals_1[i];
+		ctx->pend.src0[i] = src0[i];
+	}
+	if (!ctx->lazy_fold) BN_FLUSH(ctx);
 	return BN_OK;
 }
 
 int bn_tensor_expand(bn_ctx *ctx, void *d_data, uint64_t data_len, uint32_t log_n, const bn_f128 *h_coords, uint32_t k)
 {
 	BN_REQUIRE(ctx, "null ctx");
+	BN_FLUSH(ctx);
 	BN_REQUIRE(log_n + k < 64 && data_len == ((uint64_t)1 << (log_n + k)), "invalid data length");
 	prof_scope ps(ctx, BN_PROF_TENSOR_EXPAND);
 	for (uint32_t i = 0; i < k; i++)
@@ -437,6 +517,7 @@ int bn_inner_product(bn_ctx *ctx, const void *d_a, uint64_t a_len, uint32_t towe
                      bn_f128 *h_out)
 {
 	BN_REQUIRE(ctx && h_out, "null argument");
+	BN_FLUSH(ctx);
 	BN_REQUIRE(tower_level <= 7 && (a_len << (7 - tower_level)) == b_len, "invalid input: inner_product lengths");
 	BN_REQUIRE(valid_tower_level(tower_level), "unsupported value of tower_level");
 	ctx->s_clean = false; // slots 0..1 of the accumulator area are used as this op's accumulators
@@ -459,6 +540,7 @@ static int fold_common(bn_ctx *ctx, bool left, const void *d_mat, uint64_t mat_l
                        uint64_t vec_len, void *d_out, uint64_t out_len)
 {
 	BN_REQUIRE(ctx, "null ctx");
+	BN_FLUSH(ctx);
 	BN_REQUIRE(tower_level <= 7, "invalid evals: tower_level > 7");
 	BN_REQUIRE(valid_tower_level(tower_level), "unsupported value of tower_level");
 	BN_REQUIRE(is_pow2(mat_len) && is_pow2(vec_len), "lengths must be powers of two");
@@ -503,6 +585,7 @@ int bn_fri_fold(bn_ctx *ctx, const uint64_t *h_s_evals, uint32_t tw_level, uint3
                 void *d_out, uint64_t out_len)
 {
 	BN_REQUIRE(ctx && h_s_evals, "null argument");
+	BN_FLUSH(ctx);
 	BN_REQUIRE(log_len + log_batch_size < 64 && in_len == ((uint64_t)1 << (log_len + log_batch_size)), "invalid data_in length");
 	BN_REQUIRE(n_challenges >= log_batch_size, "invalid challenges length");
 	BN_REQUIRE(n_challenges <= log_batch_size + log_len, "challenges length too big");
@@ -540,6 +623,7 @@ int bn_compute_composite(bn_ctx *ctx, const void *const *d_rows, uint32_t n_rows
                          uint64_t out_len, const bn_expr *expr)
 {
 	BN_REQUIRE(ctx && expr, "null argument");
+	BN_FLUSH(ctx);
 	BN_REQUIRE(row_len == out_len, "inputs and output must be the same length");
 	BN_REQUIRE(expr->n_vars == n_rows || (expr->n_vars <= n_rows), "composition not match with input");
 	BN_REQUIRE(expr->steps.size() <= 64, "circuit too large for this backend (max 64 steps)");
@@ -560,6 +644,7 @@ int bn_pairwise_product_reduce(bn_ctx *ctx, const void *d_in, uint64_t n, void *
                                uint32_t n_rounds)
 {
 	BN_REQUIRE(ctx, "null ctx");
+	BN_FLUSH(ctx);
 	BN_REQUIRE(is_pow2(n), "input length must be a power of 2");
 	BN_REQUIRE(n >= 2, "input length must be greater than or equal to 2 in order to perform at least one reduction");
 	const uint32_t log_n = ilog2(n);
@@ -630,6 +715,27 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 	BN_REQUIRE(log_chunks == 0, "this backend records kernels with log_chunks = bn_pick_log_chunks() = 0");
 	BN_REQUIRE(n_ret <= 64, "too many returned values");
 	hipStream_t s = ctx->stream;
+
+	// A deferred fold survives into this launch only if the kernel has the calculate_round_evals
+	// shape (two bivariate-product sums, Local "lo + hi" operands, nothing written to memory); the
+	// launch site below then checks that it reads exactly the folded arrays.
+	if (!ctx->pend.active) BN_FLUSH(ctx); // (deferred copies)
+	if (ctx->pend.active) {
+		uint32_t n_sum = 0;
+		bool pure = n_ret > 0 && ctx->pend.count == 2;
+		for (uint32_t o = 0; o < n_ops && pure; o++) {
+			const bn_kop &op = ops[o];
+			if (op.kind == BN_KOP_SUM_COMPOSITION) {
+				n_sum++;
+				if (!op.expr || op.expr->shape != bn_expr::PRODUCT || op.expr->product_vars.size() != 2) pure = false;
+			} else if (op.kind == BN_KOP_ADD) {
+				if (op.dst.buf >= n_maps || maps[op.dst.buf].kind != BN_MAP_LOCAL) pure = false;
+			} else if (op.kind != BN_KOP_DECL_VALUE) {
+				pure = false;
+			}
+		}
+		if (!pure || n_sum != 2) BN_FLUSH(ctx);
+	}
 
 	// Local buffers are virtual until something forces them into memory.
 	struct local_state {
@@ -857,8 +963,37 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 								fz.rets = d_out ? (f128 *)d_out : d_rets;
 								fz.mail = ctx->d_mail;
 								fz.counter = ctx->d_ticket;
-								prof_scope ps(ctx, BN_PROF_ROUND_EVAL);
-								hipError_t fe = bn::launch_roundeval_product(s, ctx->n_cu, hi, lo, k, row_len, d_S + slot, &fz);
+								hipError_t fe = hipErrorNotSupported;
+								if (ctx->pend.active) {
+									// fold + evaluate in one pass: this launch reads the halves of exactly the two
+									// arrays the deferred fold writes (evals_1 directly behind evals_0, in place)
+									const bn_ctx::pending_fold &pf = ctx->pend;
+									auto reads_folded = [&](uint32_t j, uint32_t i) {
+										return lo[j] == pf.x0[i] && (const char *)hi[j] == (const char *)lo[j] + row_len * sizeof(f128);
+									};
+									int perm = -1;
+									if (k == 2 && pf.n == 2 * row_len && pf.x0[0] != pf.x0[1] && lo[0] && lo[1]) {
+										if (reads_folded(0, 0) && reads_folded(1, 1)) perm = 0;
+										else if (reads_folded(0, 1) && reads_folded(1, 0)) perm = 1;
+									}
+									if (perm >= 0) {
+										bn::foldeval_args fa{};
+										for (uint32_t j = 0; j < 2; j++) {
+											const uint32_t i = perm ? 1 - j : j;
+											fa.x0[j] = pf.src0[i];
+											fa.x1[j] = pf.x1[i];
+											fa.out[j] = pf.x0[i];
+										}
+										prof_scope ps(ctx, BN_PROF_FOLD_EVAL);
+										fe = bn::launch_foldeval9(s, ctx->n_cu, fa, 2 * pf.n, pf.z, d_S + slot, &fz);
+										if (fe == hipSuccess) ctx->pend.active = false;
+									}
+									if (ctx->pend.active) BN_FLUSH(ctx);
+								}
+								if (fe == hipErrorNotSupported) {
+									prof_scope ps(ctx, BN_PROF_ROUND_EVAL);
+									fe = bn::launch_roundeval_product(s, ctx->n_cu, hi, lo, k, row_len, d_S + slot, &fz);
+								}
 								if (fe == hipSuccess) {
 									in_kernel = true;
 									finalized_in_kernel = true;
@@ -870,6 +1005,7 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 								}
 							}
 							if (!in_kernel) {
+								BN_FLUSH(ctx);
 								prof_scope ps(ctx, BN_PROF_ROUND_EVAL);
 								BN_HIP(bn::launch_roundeval_product(s, ctx->n_cu, hi, lo, k, row_len, d_S + slot, nullptr));
 							}
@@ -892,6 +1028,7 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 					if (any_zero || row_len == 0) {
 						// a factor is identically zero: contributes nothing
 					} else if (!any_virtual) {
+						BN_FLUSH(ctx);
 						const void *rows[4];
 						for (uint32_t j = 0; j < k; j++) rows[j] = fv[j].p;
 						BN_HIP(bn::launch_sum_product(s, ctx->n_cu, rows, k, row_len, d_S + slot));
@@ -899,6 +1036,7 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 						terms.push_back(bn::fin_term{op.value, slot + 1, f128{op.scalar.lo, op.scalar.hi}});
 					} else {
 						// "infinity" job alone: low group = p, high group = p ^ q; only the high sum is wanted
+						BN_FLUSH(ctx);
 						for (uint32_t j = 0; j < k; j++) {
 							hi[j] = fv[j].p;
 							lo[j] = fv[j].q; // nullptr => same at both
@@ -933,6 +1071,7 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 		}
 	}
 
+	BN_FLUSH(ctx); // (a launch that ended up reading nothing)
 	if (n_ret == 0)
 		return BN_OK;
 
@@ -1007,6 +1146,7 @@ static int ntt_common(bn_ctx *ctx, bool inverse, void *d_data, uint32_t elem_lev
                       uint64_t coset, uint32_t coset_bits, uint32_t skip_rounds)
 {
 	BN_REQUIRE(ctx && h_s_evals, "null argument");
+	BN_FLUSH(ctx);
 	BN_REQUIRE(elem_level >= 3 && elem_level <= 7, "unsupported element field");
 	BN_REQUIRE(tw_level >= 3 && tw_level <= 6 && tw_level <= elem_level, "unsupported twiddle field");
 	BN_REQUIRE(log_domain >= 1 && log_domain <= BN_NTT_MAX_DIM && log_domain <= (1u << tw_level), "bad NTT domain");

@@ -49,6 +49,27 @@ struct bn_ctx {
 	};
 	std::vector<prof_rec> prof;
 	std::vector<hipEvent_t> ev_pool;
+	// deferred extrapolate_line batch (abi.cpp): launched by the next API call, or folded into the
+	// next round-evaluation launch when that launch reads exactly the folded arrays
+	struct pending_fold {
+		bool active = false;
+		uint32_t count = 0;
+		uint64_t n = 0;
+		bn::f128 z{0, 0};
+		void *x0[8] = {};        // evals_0: written in place ...
+		const void *x1[8] = {};
+		const void *src0[8] = {}; // ... and read from here (== x0 unless a deferred copy_d2d fed it)
+	} pend;
+	// deferred copy_d2d (the "allocate a new buffer for the folded evaluations and copy in evals_0"
+	// of the first fold, v3/bivariate_product.rs:196-206): absorbed by the fold that overwrites its
+	// destination, which then reads evals_0 from the copy's source
+	struct pending_copy {
+		const void *src;
+		void *dst;
+		uint64_t n;
+	};
+	std::vector<pending_copy> pend_copies;
+	bool lazy_fold = true; // BN_NO_LAZY_FOLD=1 turns the deferral off
 };
 
 namespace bn {
@@ -124,6 +145,14 @@ hipError_t launch_sum_product(hipStream_t s, int n_cu, const void *const *rows, 
 // ---- kernels_roundeval9.hip (the hot bivariate-product kernel)
 hipError_t launch_roundeval9_pair(hipStream_t s, int n_cu, const void *a_hi, const void *a_lo, const void *b_hi,
                                   const void *b_lo, uint64_t n, f128 *d_out, const fin_fuse *fuse);
+// fold + next round evaluation in one pass (kernels_foldeval9.hip): per array, where the two halves
+// are read and where the folded half is written
+struct foldeval_args {
+	const void *x0[2];
+	const void *x1[2];
+	void *out[2];
+};
+hipError_t launch_foldeval9(hipStream_t s, int n_cu, const foldeval_args &fa, uint64_t n_in, f128 z, f128 *d_out, const fin_fuse *fuse);
 hipError_t launch_roundeval9_split(hipStream_t s, int n_cu, const void *a, const void *b, uint64_t n, uint64_t split_off,
                                    f128 *d_out);
 

@@ -20,45 +20,11 @@
 // a wave's DS operations execute in order), each lane XORs together the limbs of its combination.
 #include <hip/hip_runtime.h>
 
-#include "bitslice.hpp"
-#include "finalize.hpp"
-#include "internal.hpp"
+#include "re9.hpp"
 
 namespace bn {
 
-namespace {
-
-constexpr int kGroups = 7;          // 9-lane groups per wave
-constexpr int kPts = 16;            // hypercube points per group per batch
-constexpr int kBatch = kGroups * kPts; // 112 points per wave-batch
-constexpr int kBlkQ = 9;            // LDS uint4 per (limb, group) block: 32 planes + 16 B pad (bank spread)
-constexpr int kZeroBlk = 8 * kGroups; // block of zeros for unused combination slots
-constexpr int kWaveQ = (kZeroBlk + 1) * kBlkQ;
-
-__device__ __forceinline__ uint32_t wave_xor_u32(uint32_t v)
-{
-#pragma unroll
-	for (int m = 32; m >= 1; m >>= 1)
-		v ^= __shfl_xor(v, m, 64);
-	return v;
-}
-
-// (z0, z2, z1') of a Karatsuba level -> the product, for 32-bit pieces: T_6 element from T_5 parts
-// lo = z0 + z2 ; hi = z1' + z0 + z2 + z2 * X_4      (pairwise_recursive_arithmetic.rs:18-28)
-__device__ __forceinline__ uint64_t combine32(uint32_t z0, uint32_t z2, uint32_t z1p)
-{
-	const uint32_t lo = z0 ^ z2;
-	const uint32_t hi = z1p ^ lo ^ (uint32_t)mulx64<4>((uint64_t)z2);
-	return (uint64_t)lo | ((uint64_t)hi << 32);
-}
-
-__device__ __forceinline__ f128 combine64(uint64_t Z0, uint64_t Z2, uint64_t Z1p)
-{
-	const uint64_t lo = Z0 ^ Z2;
-	return f128{lo, Z1p ^ lo ^ mulx64<5>(Z2)};
-}
-
-} // namespace
+using namespace re9;
 
 // SPLIT == false: rows 16..31 come from the lo arrays and planes become [hi | lo^hi]
 // SPLIT == true : rows 16..31 come from the same arrays at +split_off and planes stay [x | y]
@@ -69,8 +35,6 @@ __global__ __launch_bounds__(256, WAVES) void k_roundeval9(const uint32_t *__res
                                                       uint64_t n, f128 *out, fin_fuse fz)
 {
 	__shared__ uint4 tile[4][kWaveQ];
-	__shared__ uint32_t red[4][2][9][8];
-	__shared__ uint64_t wsum[4][4];
 
 	const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const unsigned g = lane / 9, c = lane - g * 9;
@@ -204,64 +168,7 @@ __global__ __launch_bounds__(256, WAVES) void k_roundeval9(const uint32_t *__res
 			acc[p] ^= P[p];
 	}
 
-	// ---- collapse: per lane two GF(2^32) partial sums (low half -> S_1 / first stream, high -> S_inf)
-	uint32_t s_lo = 0, s_hi = 0;
-#pragma unroll
-	for (int p = 0; p < 32; p++) {
-		s_lo |= (__popc(acc[p] & 0xFFFFu) & 1u) << p;
-		s_hi |= (__popc(acc[p] >> 16) & 1u) << p;
-	}
-	if (live) {
-		red[wave][0][c][g] = s_lo;
-		red[wave][1][c][g] = s_hi;
-	}
-	__syncthreads();
-	if (lane < 2) {
-		// lane q of every wave recombines stream q of that wave
-		uint32_t pc[9];
-#pragma unroll
-		for (int cc = 0; cc < 9; cc++) {
-			uint32_t v = 0;
-#pragma unroll
-			for (int gg = 0; gg < kGroups; gg++)
-				v ^= red[wave][lane][cc][gg];
-			pc[cc] = v;
-		}
-		const uint64_t Z0 = combine32(pc[0], pc[1], pc[2]);
-		const uint64_t Z2 = combine32(pc[3], pc[4], pc[5]);
-		const uint64_t Z1p = combine32(pc[6], pc[7], pc[8]);
-		const f128 S = combine64(Z0, Z2, Z1p);
-		wsum[wave][2 * lane] = S.lo;
-		wsum[wave][2 * lane + 1] = S.hi;
-	}
-	__syncthreads();
-	if (threadIdx.x < 4) {
-		const uint64_t v = wsum[0][threadIdx.x] ^ wsum[1][threadIdx.x] ^ wsum[2][threadIdx.x] ^ wsum[3][threadIdx.x];
-		if (v)
-			atomicXor(reinterpret_cast<unsigned long long *>(out) + threadIdx.x, (unsigned long long)v);
-	}
-	if (fz.counter) {
-		// fused finalize: release our partial, take a ticket; the last workgroup folds the sums into
-		// the kernel's values and publishes them (same body as k_finalize)
-		// No release/acquire FENCES here (an agent-scope release writes back the whole L2: several
-		// microseconds per workgroup, measured +14 us per launch): every shared word is touched only by
-		// device-scope atomics, which are performed at the coherence point.  Each XOR-ing lane drains
-		// its own atomic (vmcnt(0)), the barrier orders the lanes, then one lane takes the ticket.
-		__shared__ unsigned is_last;
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-		__syncthreads();
-		if (threadIdx.x == 0) {
-			const unsigned t = atomicAdd(fz.counter, 1u);
-			is_last = (t == gridDim.x - 1) ? 1u : 0u;
-		}
-		__syncthreads();
-		if (is_last) {
-			// S is read with agent-scope atomic loads inside finalize_body (they bypass the L1)
-			finalize_body(fz.args, fz.S, fz.rets, fz.mail);
-			if (threadIdx.x == 0)
-				__hip_atomic_store(fz.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		}
-	}
+	re9::tail(acc, live, c, g, wave, lane, out, fz);
 }
 
 static unsigned grid9(uint64_t n, int n_cu, int waves)

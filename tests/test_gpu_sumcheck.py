@@ -191,3 +191,65 @@ def test_compiled_host_prover_matches_oracle(hal, oracle, n_vars, m, comps):
     assert plan.final_evals() == want_final
     plan.run()  # re-runnable: inputs are PreFold (never modified)
     assert plan.round_coeffs() == want_coeffs
+
+
+@pytest.mark.parametrize("n_vars", list(range(2, 13)) + [15, 18, 20])
+@pytest.mark.parametrize("out_of_place", [False, True])
+def test_fold_then_round_evals_fused(hal, oracle, n_vars, out_of_place):
+    """A fold batch followed by the round evaluation of the folded arrays runs as ONE kernel
+    (kernels_foldeval9.hip, the ABI defers the fold).  Both the round evaluations and the folded
+    arrays left in memory must equal fold-then-evaluate on the oracle.  out_of_place: the first
+    fold of the prover (copy evals_0 into a fresh buffer, then fold that) -- the copy is absorbed."""
+    from binius_amd.sumcheck import bivariate_product_expr, calculate_round_evals
+
+    alloc = hal.dev_alloc()
+    n = 1 << n_vars
+    mls = [oracle.random_b128(0xF01D0000 + j, n) for j in range(2)]
+    z = oracle.random_scalars(0xF01D, 1)[0]
+    d = [upload(hal, alloc, x) for x in mls]
+    halves = [x.split_half() for x in d]
+    if out_of_place:
+        dst = [alloc.alloc(n // 2) for _ in range(2)]
+        for (lo, _), t in zip(halves, dst):
+            hal.copy_d2d(lo, t)
+    else:
+        dst = [lo for lo, _ in halves]
+    hal.extrapolate_line_batch(dst, [hi for _, hi in halves], z)
+    expr = bivariate_product_expr(hal, 0, 1)
+    got = calculate_round_evals(hal, n_vars - 1, [1], dst, [expr])
+    folded = []
+    for x in mls:
+        f = x[: n // 2].copy()
+        assert oracle.extrapolate_line(f, x[n // 2 :].copy(), z) == 0
+        folded.append(f)
+    rc, want = oracle.round_evals(folded, n_vars - 1, [(0, 1)], 1)
+    assert rc == 0 and got == want
+    for t, f in zip(dst, folded):
+        assert np.array_equal(hal.copy_d2h(t), f)
+    if out_of_place:  # the sources are untouched
+        for x, dd in zip(mls, d):
+            assert np.array_equal(hal.copy_d2h(dd), x)
+
+
+def test_deferred_fold_is_invisible(hal, oracle):
+    """The deferral must not be observable: any API call after the fold batch sees folded data."""
+    alloc = hal.dev_alloc()
+    n = 1 << 10
+    mls = [oracle.random_b128(0xF01E0000 + j, n) for j in range(3)]
+    z = oracle.random_scalars(0xF01E, 1)[0]
+    d = [upload(hal, alloc, x) for x in mls]
+    halves = [x.split_half() for x in d]
+    hal.extrapolate_line_batch([lo for lo, _ in halves], [hi for _, hi in halves], z)
+    for x, (lo, _) in zip(mls, halves):
+        f = x[: n // 2].copy()
+        oracle.extrapolate_line(f, x[n // 2 :].copy(), z)
+        assert np.array_equal(hal.copy_d2h(lo), f)
+    # a deferred fold followed by an unrelated kernel launch (different arrays) still happens first
+    d2 = [upload(hal, alloc, x) for x in mls[:2]]
+    h2 = [x.split_half() for x in d2]
+    hal.extrapolate_line_batch([lo for lo, _ in h2], [hi for _, hi in h2], z)
+    got = hal.inner_product(h2[0][0], 7, h2[1][0])
+    fa, fb = mls[0][: n // 2].copy(), mls[1][: n // 2].copy()
+    oracle.extrapolate_line(fa, mls[0][n // 2 :].copy(), z)
+    oracle.extrapolate_line(fb, mls[1][n // 2 :].copy(), z)
+    assert got == oracle.inner_product(fa, 7, fb)[1]
