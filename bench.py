@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--n-vars", type=int, default=24, help="local variables per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prof", action="store_true", help="diagnostic: no per-launch hipEvents in the timed region (no roofline block)")
     ap.add_argument("--cpu-n-vars", type=int, default=0, help="size of the CPU baseline sample (0 = auto)")
     args = ap.parse_args()
 
@@ -144,15 +145,29 @@ def main():
 
     for _ in range(args.warmup):
         one_step()
+    # ---- timed region: exactly K steps, barrier + synchronize on both sides
     barrier()
-    hal.prof_begin()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         get_coeffs, get_finals = one_step()
     barrier()
     t1 = time.perf_counter()
-    prof = hal.prof_end()
     elapsed = t1 - t0
+    # ---- the same K steps once more with a hipEvent pair around every kernel launch (bn_prof_*), for
+    # the roofline block.  The events cost about 5 us per launch on the stream (measured: 1.30 -> 1.41 ms
+    # per step), which is instrumentation, not the workload -- so they stay out of `value`; the
+    # instrumented pass's own wall time is reported next to it as ms_per_step_instrumented.
+    prof = {k: (0.0, 0) for k in hal.PROF_CLASSES}
+    elapsed_prof = None
+    if not args.no_prof:
+        barrier()
+        hal.prof_begin()
+        t2 = time.perf_counter()
+        for _ in range(args.steps):
+            one_step()
+        barrier()
+        elapsed_prof = time.perf_counter() - t2
+        prof = hal.prof_end()
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -183,14 +198,19 @@ def main():
     re_ms, re_cnt = prof["round_eval"]
     fo_ms, fo_cnt = prof["fold"]
     fe_ms, fe_cnt = prof["fold_eval"]
+    tl_ms, tl_cnt = prof["tail"]
     fused = fe_cnt > 0
     if fused:
+        # the f largest fold+eval rounds are k_foldeval9 launches; the remaining small ones (if any) run
+        # inside one resident k_foldeval_tail launch per step (its time includes the host round trips)
+        f = fe_cnt // args.steps
         re_bytes = 16 * m * (1 << n_vars) * args.steps
-        fe_bytes = sum(24 * m * (1 << r) for r in range(2, n_vars + 1)) * args.steps
+        fe_bytes = sum(24 * m * (1 << r) for r in range(n_vars - f + 1, n_vars + 1)) * args.steps
+        tl_bytes = sum(24 * m * (1 << r) for r in range(2, n_vars - f + 1)) * args.steps
         fold_bytes = 24 * m * 2 * args.steps
     else:
         re_bytes = sum(16 * m * (1 << r) for r in range(1, n_vars + 1)) * args.steps
-        fe_bytes = 0
+        fe_bytes = tl_bytes = 0
         fold_bytes = sum(24 * (1 << r) for r in range(1, n_vars + 1)) * m * args.steps
     kernels = {
         "k_roundeval9(round_eval)": (re_bytes, re_ms, re_cnt),
@@ -198,6 +218,8 @@ def main():
     }
     if fused:
         kernels["k_foldeval9(fold+round_eval)"] = (fe_bytes, fe_ms, fe_cnt)
+    if tl_cnt:
+        kernels["k_foldeval_tail(resident, rounds <= 2^12)"] = (tl_bytes, tl_ms, tl_cnt)
     dom = max(kernels, key=lambda k: kernels[k][1])
     b, ms, cnt = kernels[dom]
     achieved = b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
@@ -231,6 +253,7 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
+        "ms_per_step_instrumented": (elapsed_prof * 1e3 / args.steps) if elapsed_prof else None,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,

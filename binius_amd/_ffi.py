@@ -127,6 +127,7 @@ def lib():
         "bn_scalar_invert": [PF, PF],
         "bn_prof_begin": [vp],
         "bn_prof_end": [vp, C.POINTER(C.c_double), C.POINTER(u64)],
+        "bn_xor_reduce": [vp, vp, u32, u32, PF],
         "bn_timer_begin": [vp],
         "bn_timer_end_ms": [vp, C.POINTER(C.c_float)],
     }
@@ -146,7 +147,7 @@ ABI_SYMBOLS = [
     "bn_extrapolate_line", "bn_extrapolate_line_batch", "bn_tensor_expand", "bn_inner_product", "bn_fold_left", "bn_fold_right", "bn_fri_fold",
     "bn_compute_composite", "bn_pairwise_product_reduce", "bn_log_chunks_range", "bn_pick_log_chunks",
     "bn_kernel_launch", "bn_ntt_forward", "bn_ntt_inverse", "bn_ntt_s_evals", "bn_scalar_mul", "bn_scalar_invert",
-    "bn_timer_begin", "bn_timer_end_ms", "bn_prof_begin", "bn_prof_end",
+    "bn_timer_begin", "bn_timer_end_ms", "bn_prof_begin", "bn_prof_end", "bn_xor_reduce",
 ]
 
 
@@ -409,7 +410,7 @@ class Context:
         _check(lib().bn_timer_end_ms(self._h, C.byref(ms)))
         return ms.value
 
-    PROF_CLASSES = ("round_eval", "fold", "tensor_expand", "ntt", "other", "fold_eval")
+    PROF_CLASSES = ("round_eval", "fold", "tensor_expand", "ntt", "other", "fold_eval", "tail")
 
     def prof_begin(self):
         _check(lib().bn_prof_begin(self._h))

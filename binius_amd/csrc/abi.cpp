@@ -74,7 +74,7 @@ struct prof_scope {
 				e = c->ev_pool.back();
 				c->ev_pool.pop_back();
 			} else {
-				hipEventCreate(&e);
+				hipEventCreateWithFlags(&e, hipEventDisableSystemFence);
 			}
 			return e;
 		};
@@ -98,6 +98,41 @@ struct prof_scope {
 
 // Launch a deferred extrapolate_line batch (see bn_extrapolate_line_batch).  Every entry point
 // that can observe device memory or the stream calls this first, so the deferral is invisible.
+// ---- resident tail kernel: host side of the protocol (device side: kernels_foldeval9.hip)
+// command block in the pinned mailbox page: h_mail[80].lo = command word, h_mail[81] = z,
+// h_mail[82].lo = status (the id of the last tail kernel that exited)
+static volatile uint64_t *tail_cmd(bn_ctx *ctx) { return &ctx->h_mail[80].lo; }
+static volatile uint64_t *tail_status(bn_ctx *ctx) { return &ctx->h_mail[82].lo; }
+
+// Stop the resident kernel (if any) and wait until it has left the device.
+static int tail_cancel(bn_ctx *ctx)
+{
+	if (!ctx->tail.active) return BN_OK;
+	ctx->tail.active = false;
+	__atomic_store_n(tail_cmd(ctx), (ctx->tail.id << 20) | 0xFFFFFull, __ATOMIC_RELEASE);
+	BN_HIP(hipStreamSynchronize(ctx->stream));
+	return BN_OK;
+}
+
+static std::vector<unsigned char> recipe_bytes(const bn::fin_args &a)
+{
+	bn::fin_args r;
+	std::memset(&r, 0, sizeof(r));
+	r.n_terms = a.n_terms;
+	r.n_values = a.n_values;
+	r.n_ret = a.n_ret;
+	r.n_slots = a.n_slots;
+	for (uint32_t t = 0; t < a.n_terms; t++) {
+		r.terms[t].value = a.terms[t].value;
+		r.terms[t].slot = a.terms[t].slot;
+		r.terms[t].coeff = a.terms[t].coeff;
+	}
+	for (uint32_t v = 0; v < a.n_values; v++) r.init[v] = a.init[v];
+	for (uint32_t i = 0; i < a.n_ret; i++) r.ret_ids[i] = a.ret_ids[i];
+	const unsigned char *p = reinterpret_cast<const unsigned char *>(&r);
+	return std::vector<unsigned char>(p, p + sizeof(r));
+}
+
 static int flush_copies(bn_ctx *ctx)
 {
 	for (const auto &c : ctx->pend_copies)
@@ -106,8 +141,12 @@ static int flush_copies(bn_ctx *ctx)
 	return BN_OK;
 }
 
-static int flush_pending(bn_ctx *ctx)
+static int flush_pending(bn_ctx *ctx, bool keep_tail = false)
 {
+	if (ctx->tail.active && !keep_tail) {
+		int rc = tail_cancel(ctx);
+		if (rc) return rc;
+	}
 	if (!ctx->pend_copies.empty()) {
 		int rc = flush_copies(ctx);
 		if (rc) return rc;
@@ -189,6 +228,11 @@ int bn_ctx_create(int device, uint64_t arena_elems, bn_ctx **out)
 		ctx->arena_elems = arena_elems;
 	}
 	ctx->lazy_fold = getenv("BN_NO_LAZY_FOLD") == nullptr;
+	if (const char *t = getenv("BN_TAIL_MAX_LOG2")) {
+		const int l = atoi(t);
+		ctx->tail_max_n_in = (l >= 3 && l <= 12) ? (1ull << l) : 0; // one workgroup: at most 2^12 elements per array
+	}
+	if (!ctx->lazy_fold) ctx->tail_max_n_in = 0;
 	*out = ctx;
 	return BN_OK;
 }
@@ -478,7 +522,19 @@ int bn_extrapolate_line_batch(bn_ctx *ctx, void *const *d_evals_0, const void *c
 			for (uint32_t i = 0; i < count; i++) src0[i] = d_evals_0[i];
 		}
 	}
-	BN_FLUSH(ctx);
+	{
+		// a resident tail kernel survives this call only if the batch is the fold it is parked for
+		bool keep_tail = false;
+		if (ctx->tail.active && count == 2 && 2 * n == ctx->tail.n_in_next) {
+			auto continues = [&](uint32_t i, uint32_t j) {
+				return d_evals_0[i] == ctx->tail.out[j] && src0[i] == d_evals_0[i] &&
+				       (const char *)d_evals_1[i] == (const char *)d_evals_0[i] + n * sizeof(f128);
+			};
+			keep_tail = (continues(0, 0) && continues(1, 1)) || (continues(0, 1) && continues(1, 0));
+		}
+		int rc_ = flush_pending(ctx, keep_tail);
+		if (rc_) return rc_;
+	}
 	// Deferred: the next API call launches it -- or, if that call is the round evaluation of exactly
 	// these arrays, both run as one kernel (kernels_foldeval9.hip).
 	ctx->pend.active = true;
@@ -719,7 +775,7 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 	// A deferred fold survives into this launch only if the kernel has the calculate_round_evals
 	// shape (two bivariate-product sums, Local "lo + hi" operands, nothing written to memory); the
 	// launch site below then checks that it reads exactly the folded arrays.
-	if (!ctx->pend.active) BN_FLUSH(ctx); // (deferred copies)
+	if (!ctx->pend.active) BN_FLUSH(ctx); // (deferred copies; a parked tail kernel without a fold to run)
 	if (ctx->pend.active) {
 		uint32_t n_sum = 0;
 		bool pure = n_ret > 0 && ctx->pend.count == 2;
@@ -984,9 +1040,75 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 											fa.x1[j] = pf.x1[i];
 											fa.out[j] = pf.x0[i];
 										}
-										prof_scope ps(ctx, BN_PROF_FOLD_EVAL);
-										fe = bn::launch_foldeval9(s, ctx->n_cu, fa, 2 * pf.n, pf.z, d_S + slot, &fz);
-										if (fe == hipSuccess) ctx->pend.active = false;
+										const uint64_t n_in = 2 * pf.n;
+										// (a) a resident tail kernel is parked for exactly this round: hand it z
+										if (ctx->tail.active) {
+											bn_ctx::tail_state &tl = ctx->tail;
+											const bool same = h_out && !d_out && n_in == tl.n_in_next && fa.x0[0] == fa.out[0] && fa.x0[1] == fa.out[1] &&
+											                  ((fa.out[0] == tl.out[0] && fa.out[1] == tl.out[1]) || (fa.out[0] == tl.out[1] && fa.out[1] == tl.out[0])) &&
+											                  fz.args.seq == tl.seq0 + tl.round + 1 && recipe_bytes(fz.args) == tl.recipe &&
+											                  __atomic_load_n(tail_status(ctx), __ATOMIC_ACQUIRE) != tl.id;
+											if (same) {
+												tl.round++;
+												ctx->h_mail[81].lo = pf.z.lo;
+												ctx->h_mail[81].hi = pf.z.hi;
+												__atomic_store_n(tail_cmd(ctx), (tl.id << 20) | tl.round, __ATOMIC_RELEASE);
+												volatile uint64_t *seqw = &ctx->h_mail[64].lo;
+												bool got = false;
+												for (;;) {
+													if (__atomic_load_n(seqw, __ATOMIC_ACQUIRE) == fz.args.seq) { got = true; break; }
+													if (__atomic_load_n(tail_status(ctx), __ATOMIC_ACQUIRE) == tl.id) {
+														// the kernel left (bounded spin ran out) -- did it answer first?
+														got = __atomic_load_n(seqw, __ATOMIC_ACQUIRE) == fz.args.seq;
+														break;
+													}
+												}
+												if (got) {
+													for (uint32_t r = 0; r < n_ret; r++) {
+														h_out[r].lo = __atomic_load_n(&ctx->h_mail[r].lo, __ATOMIC_RELAXED);
+														h_out[r].hi = __atomic_load_n(&ctx->h_mail[r].hi, __ATOMIC_RELAXED);
+													}
+													ctx->pend.active = false;
+													tl.n_in_next = n_in >> 1;
+													if (n_in <= 4) tl.active = false; // it has just run its last round and exits
+													ctx->s_clean = true;
+													return BN_OK;
+												}
+												tl.active = false; // gone without doing this round: run it the normal way
+												BN_HIP(hipStreamSynchronize(s));
+											} else {
+												rc = tail_cancel(ctx);
+												if (rc) return rc;
+											}
+										}
+										// (b) small arrays: start a resident tail kernel with this round
+										if (fe == hipErrorNotSupported && h_out && !d_out && ctx->tail_max_n_in && n_in <= ctx->tail_max_n_in && n_in >= 8) {
+											bn_ctx::tail_state &tl = ctx->tail;
+											const uint64_t id = ++ctx->tail_counter;
+											prof_scope ps(ctx, BN_PROF_TAIL);
+											fe = bn::launch_foldeval_tail(s, fa, n_in, pf.z, d_S + slot, fz, (const uint64_t *)&ctx->d_mail[80].lo,
+											                              (uint64_t *)&ctx->d_mail[82].lo, id);
+											if (fe == hipSuccess) {
+												tl.active = true;
+												tl.id = id;
+												tl.round = 0;
+												tl.n_in_next = n_in >> 1;
+												tl.out[0] = fa.out[0];
+												tl.out[1] = fa.out[1];
+												tl.seq0 = fz.args.seq;
+												tl.recipe = recipe_bytes(fz.args);
+												ctx->pend.active = false;
+											}
+										}
+										// (c) one fused kernel for this round
+										if (fe == hipErrorNotSupported) {
+											prof_scope ps(ctx, BN_PROF_FOLD_EVAL);
+											fe = bn::launch_foldeval9(s, ctx->n_cu, fa, n_in, pf.z, d_S + slot, &fz);
+											if (fe == hipSuccess) ctx->pend.active = false;
+										}
+									} else if (ctx->tail.active) {
+										rc = tail_cancel(ctx);
+										if (rc) return rc;
 									}
 									if (ctx->pend.active) BN_FLUSH(ctx);
 								}
@@ -1071,7 +1193,8 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 		}
 	}
 
-	BN_FLUSH(ctx); // (a launch that ended up reading nothing)
+	rc = flush_pending(ctx, /*keep_tail=*/true); // (a launch that ended up reading nothing)
+	if (rc) return rc;
 	if (n_ret == 0)
 		return BN_OK;
 
@@ -1111,6 +1234,33 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 			h_out[r].lo = __atomic_load_n(&ctx->h_mail[r].lo, __ATOMIC_RELAXED);
 			h_out[r].hi = __atomic_load_n(&ctx->h_mail[r].hi, __ATOMIC_RELAXED);
 		}
+	}
+	return BN_OK;
+}
+
+// XOR of n_groups device vectors of group_len (<= 64) elements, returned to the host through the
+// zero-copy mailbox.  Not part of the reference interface: it is the combine step behind the
+// per-round all_gather of the sharded prover (binius_amd/host/host_capi.cpp).
+int bn_xor_reduce(bn_ctx *ctx, const void *d_vals, uint32_t n_groups, uint32_t group_len, bn_f128 *h_out)
+{
+	BN_REQUIRE(ctx && d_vals && h_out, "null argument");
+	BN_FLUSH(ctx);
+	BN_REQUIRE(group_len >= 1 && group_len <= 64 && n_groups >= 1, "xor_reduce: group_len must be in 1..64");
+	const uint64_t seq = ++ctx->mail_seq;
+	BN_HIP(bn::launch_xor_publish(ctx->stream, (const f128 *)d_vals, n_groups, group_len, ctx->d_result + 96, ctx->d_mail, seq));
+	volatile uint64_t *seqw = &ctx->h_mail[64].lo;
+	uint64_t spins = 0;
+	while (__atomic_load_n(seqw, __ATOMIC_ACQUIRE) != seq) {
+		if (++spins > (1ull << 22)) {
+			BN_HIP(hipStreamSynchronize(ctx->stream));
+			if (__atomic_load_n(seqw, __ATOMIC_ACQUIRE) != seq)
+				return bn::fail(BN_ERR_DEVICE, "device error: result mailbox was not published");
+			break;
+		}
+	}
+	for (uint32_t r = 0; r < group_len; r++) {
+		h_out[r].lo = __atomic_load_n(&ctx->h_mail[r].lo, __ATOMIC_RELAXED);
+		h_out[r].hi = __atomic_load_n(&ctx->h_mail[r].hi, __ATOMIC_RELAXED);
 	}
 	return BN_OK;
 }

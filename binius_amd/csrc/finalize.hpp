@@ -24,7 +24,7 @@ __device__ __forceinline__ uint32_t fin_wave_xor(uint32_t v)
 // Must be called by EVERY thread of a workgroup with >= 128 threads (it contains barriers); the
 // first 128 threads do the work.  S is read with agent-scope atomic loads so the fused caller sees
 // the other workgroups' atomicXor results.
-__device__ __forceinline__ void finalize_body(const fin_args &a, f128 *S, f128 *rets, f128 *mail)
+__device__ __forceinline__ void finalize_body(const fin_args &a, f128 *S, f128 *rets, f128 *mail, uint64_t seq)
 {
 	__shared__ uint64_t fin_red[2][2];
 	__shared__ f128 fin_values[kFinMaxValues];
@@ -72,7 +72,7 @@ __device__ __forceinline__ void finalize_body(const fin_args &a, f128 *S, f128 *
 		__hip_atomic_store(&S[tid].lo, (uint64_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		__hip_atomic_store(&S[tid].hi, (uint64_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	}
-	if (a.seq) {
+	if (seq) {
 		// zero-copy return: values, then the sequence word, into fine-grained host memory
 		if (tid < a.n_ret) {
 			const f128 v = fin_values[a.ret_ids[tid]];
@@ -82,7 +82,7 @@ __device__ __forceinline__ void finalize_body(const fin_args &a, f128 *S, f128 *
 		__threadfence_system();
 		__syncthreads();
 		if (tid == 0)
-			__hip_atomic_store(&mail[64].lo, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+			__hip_atomic_store(&mail[64].lo, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 	}
 }
 

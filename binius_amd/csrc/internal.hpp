@@ -70,6 +70,18 @@ struct bn_ctx {
 	};
 	std::vector<pending_copy> pend_copies;
 	bool lazy_fold = true; // BN_NO_LAZY_FOLD=1 turns the deferral off
+	// resident tail kernel (kernels_foldeval9.hip k_foldeval_tail, protocol in abi.cpp)
+	struct tail_state {
+		bool active = false;
+		uint64_t id = 0;          // launch counter; commands are (id << 20) | round
+		uint64_t round = 0;       // rounds already executed after the first
+		uint64_t n_in_next = 0;   // size of the next round's (pre-fold) arrays
+		void *out[2] = {nullptr, nullptr};
+		uint64_t seq0 = 0;        // mailbox sequence of the first round
+		std::vector<unsigned char> recipe; // bytes of the fin_args the kernel was launched with (seq zeroed)
+	} tail;
+	uint64_t tail_counter = 0;
+	uint64_t tail_max_n_in = 0; // BN_TAIL_MAX_LOG2=3..12 enables the resident tail (off by default: see DESIGN.md)
 };
 
 namespace bn {
@@ -124,6 +136,8 @@ struct fin_args {
 };
 // values[v] = init[v] ^ XOR_t coeff_t * S[slot_t], then rets[i] = values[ret_ids[i]]
 hipError_t launch_finalize(hipStream_t s, const fin_args &args, f128 *d_S, f128 *d_rets, f128 *d_mail);
+hipError_t launch_xor_publish(hipStream_t s, const f128 *d_vals, uint32_t n_groups, uint32_t group_len, f128 *d_rets, f128 *d_mail,
+                              uint64_t seq);
 // fused form: the last workgroup to finish (device-scope ticket counter) runs the finalize body
 struct fin_fuse {
 	fin_args args;
@@ -153,6 +167,8 @@ struct foldeval_args {
 	void *out[2];
 };
 hipError_t launch_foldeval9(hipStream_t s, int n_cu, const foldeval_args &fa, uint64_t n_in, f128 z, f128 *d_out, const fin_fuse *fuse);
+hipError_t launch_foldeval_tail(hipStream_t s, const foldeval_args &fa, uint64_t n_in, f128 z, f128 *d_out, const fin_fuse &fz,
+                                const uint64_t *d_cmd, uint64_t *d_status, uint64_t tail_id);
 hipError_t launch_roundeval9_split(hipStream_t s, int n_cu, const void *a, const void *b, uint64_t n, uint64_t split_off,
                                    f128 *d_out);
 

@@ -42,19 +42,16 @@ static_assert(2 * kArrQ <= kZeroBlk * kBlkQ, "staging must not touch the tile's 
 // wave-uniform, so the addresses are one scalar base per quadrant + (lane*16 + immediate): no
 // per-lane address registers survive into the multiply (the kernel sits at the 256-VGPR limit of
 // two waves per SIMD).
-template <int WAVES>
-__global__ __launch_bounds__(256, WAVES) void k_foldeval9(foldeval_args fa, uint64_t n_in, f128 z, f128 *out, fin_fuse fz)
+// One round for one wave: folds and evaluates batches wave_global, wave_global + n_waves, ... and
+// leaves the wave's 32 accumulator planes in acc.  wt = this wave's LDS tile (kWaveQ uint4).
+template <bool PREFETCH = true>
+__device__ __forceinline__ void foldeval_wave(const foldeval_args &fa, uint64_t n_in, const ctable_smem &tab, uint4 *wt,
+                                              uint64_t wave_global, uint64_t n_waves, uint32_t (&acc)[32])
 {
-	__shared__ uint4 tile[4][kWaveQ];
-	__shared__ ctable_smem tab;
-	ctable_build(tab, z);
-
 	const unsigned lane = threadIdx.x & 63;
-	const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const unsigned g = lane / 9, c = lane - g * 9;
 	const bool live = lane < 63;
 	const bool loader = live && c < 8;
-	uint4 *wt = tile[wave];
 	const uint32_t *wtw = reinterpret_cast<const uint32_t *>(wt);
 	// zero block (read by combination slots a lane does not use)
 	if (lane < kBlkQ)
@@ -76,14 +73,11 @@ __global__ __launch_bounds__(256, WAVES) void k_foldeval9(foldeval_args fa, uint
 	const unsigned st_lo = (((c >> 2) & 1) * kArrQ + g_ld) * 4 + (c & 3); // lo' rows (first 112)
 	const unsigned st_hi = st_lo + kBatch * 4;                            // hi' rows
 
-	uint32_t acc[32];
 #pragma unroll
 	for (int p = 0; p < 32; p++)
 		acc[p] = 0;
 
 	const uint64_t n_batches = (n + kBatch - 1) / kBatch;
-	const uint64_t wave_global = (uint64_t)blockIdx.x * 4 + wave;
-	const uint64_t n_waves = (uint64_t)gridDim.x * 4;
 
 	uint4 x0[kSlots], x1[kSlots];
 	// quadrant base of slot t for batch point p0 (wave-uniform)
@@ -108,12 +102,15 @@ __global__ __launch_bounds__(256, WAVES) void k_foldeval9(foldeval_args fa, uint
 	using c0 = std::integral_constant<int, 0>;
 	using cP = std::integral_constant<int, kPre>;
 	using cN = std::integral_constant<int, kSlots>;
-	if (wave_global < n_batches)
+	if (PREFETCH && wave_global < n_batches)
 		load_raw(wave_global, c0{}, cP{});
 	for (uint64_t b = wave_global; b < n_batches; b += n_waves) {
 		const uint64_t p0 = b * kBatch;
 		const uint64_t left = n - p0;
-		load_raw(b, cP{}, cN{});
+		if (PREFETCH)
+			load_raw(b, cP{}, cN{});
+		else
+			load_raw(b, c0{}, cN{}); // resident tail: a wave sees one or two batches, nothing to overlap
 		// ---- fold: f = x0 + z * (x0 + x1); back to HBM (next round's input) and into the staging tile
 #pragma unroll
 		for (int t = 0; t < kSlots; t++) {
@@ -138,7 +135,7 @@ __global__ __launch_bounds__(256, WAVES) void k_foldeval9(foldeval_args fa, uint
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		__builtin_amdgcn_wave_barrier();
 		// next batch's raw elements fly while this batch is transposed and multiplied
-		if (b + n_waves < n_batches)
+		if (PREFETCH && b + n_waves < n_batches)
 			load_raw(b + n_waves, c0{}, cP{});
 #pragma unroll
 		for (int j = 0; j < 16; j++)
@@ -177,7 +174,90 @@ __global__ __launch_bounds__(256, WAVES) void k_foldeval9(foldeval_args fa, uint
 			acc[p] ^= P[p];
 	}
 
-	re9::tail(acc, live, c, g, wave, lane, out, fz);
+}
+
+template <int WAVES>
+__global__ __launch_bounds__(256, WAVES) void k_foldeval9(foldeval_args fa, uint64_t n_in, f128 z, f128 *out, fin_fuse fz)
+{
+	__shared__ uint4 tile[4][kWaveQ];
+	__shared__ ctable_smem tab;
+	ctable_build(tab, z);
+	const unsigned lane = threadIdx.x & 63;
+	const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const unsigned g = lane / 9, c = lane - g * 9;
+	uint32_t acc[32];
+	foldeval_wave(fa, n_in, tab, tile[wave], (uint64_t)blockIdx.x * 4 + wave, (uint64_t)gridDim.x * 4, acc);
+	re9::tail<4>(acc, lane < 63, c, g, wave, lane, out, fz, fz.args.seq);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Resident tail.  Once the arrays are small a round costs ~17 us of kernel latency plus ~11 us of
+// launch + completion round trip, for microseconds of arithmetic.  k_foldeval_tail runs the round
+// it is launched for and then STAYS on the device: one workgroup of 8 waves, parked on a command
+// word in fine-grained pinned host memory.  The host side of the next rounds (abi.cpp, "tail")
+// checks that the next fold + evaluation request is the one this kernel will execute (same arrays,
+// half the size, same finalize recipe), then just writes (z, command) and waits for the result
+// mailbox -- a 1.8 us ping-pong instead of a launch (tools/launch_latency.hip).  Anything else
+// cancels the kernel; so does a bounded spin (a host that went away cannot hang the GPU).
+//
+// All rounds after the first fold in place on fa.out.  Within one workgroup the folded values of
+// round k are ordered before the loads of round k+1 by the workgroup barrier.
+constexpr int kTailWaves = 8;
+__global__ __launch_bounds__(64 * kTailWaves) void k_foldeval_tail(foldeval_args fa, uint64_t n_in, f128 z, f128 *out, fin_fuse fz,
+                                                                  const uint64_t *cmd, uint64_t *status, uint64_t tail_id)
+{
+	extern __shared__ __attribute__((aligned(16))) uint4 tail_tile[]; // [kTailWaves][kWaveQ]
+	__shared__ ctable_smem tab;
+	__shared__ uint64_t next_z[2];
+	__shared__ unsigned go;
+	const unsigned lane = threadIdx.x & 63;
+	const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const unsigned g = lane / 9, c = lane - g * 9;
+	uint64_t round = 0;
+	foldeval_args cur = fa;
+	for (;;) {
+		ctable_build(tab, z);
+		uint32_t acc[32];
+		foldeval_wave<false>(cur, n_in, tab, tail_tile + wave * kWaveQ, wave, kTailWaves, acc);
+		re9::tail<kTailWaves>(acc, lane < 63, c, g, wave, lane, out, fz, fz.args.seq + round); // single workgroup: it is the "last" one
+		if (n_in <= 4) break; // the fold to one element has no evaluation behind it
+		// ---- park: wait for (tail_id, round + 1) or a cancel
+		round++;
+		if (threadIdx.x == 0) {
+			unsigned ok = 0;
+			for (uint32_t spins = 0; spins < (1u << 21); spins++) {
+				const uint64_t w = __hip_atomic_load(cmd, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+				if (w == ((tail_id << 20) | round)) {
+					next_z[0] = __hip_atomic_load(cmd + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+					next_z[1] = __hip_atomic_load(cmd + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+					ok = 1;
+					break;
+				}
+				if (w == ((tail_id << 20) | 0xFFFFFu)) break; // cancelled
+				__builtin_amdgcn_s_sleep(2);
+			}
+			go = ok;
+		}
+		__syncthreads();
+		if (!__builtin_amdgcn_readfirstlane(go)) break; // (readfirstlane: keeps the loop state wave-uniform = in SGPRs)
+		{
+			const volatile uint32_t *zw = reinterpret_cast<const volatile uint32_t *>(next_z);
+			const uint32_t z0 = __builtin_amdgcn_readfirstlane(zw[0]), z1 = __builtin_amdgcn_readfirstlane(zw[1]);
+			const uint32_t z2 = __builtin_amdgcn_readfirstlane(zw[2]), z3 = __builtin_amdgcn_readfirstlane(zw[3]);
+			z = f128{(uint64_t)z0 | ((uint64_t)z1 << 32), (uint64_t)z2 | ((uint64_t)z3 << 32)};
+		}
+		// next round: in place on the folded halves
+		n_in >>= 1;
+		cur.x0[0] = fa.out[0];
+		cur.x0[1] = fa.out[1];
+		cur.x1[0] = (const uint4 *)fa.out[0] + (n_in >> 1);
+		cur.x1[1] = (const uint4 *)fa.out[1] + (n_in >> 1);
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) {
+		__threadfence_system();
+		__hip_atomic_store(status, tail_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+	}
 }
 
 // For both arrays j: out_j[i] = x0_j[i] + z * (x1_j[i] - x0_j[i]), i < n_in/2 (out_j may be x0_j), and
@@ -193,6 +273,21 @@ hipError_t launch_foldeval9(hipStream_t s, int n_cu, const foldeval_args &fa, ui
 	const uint64_t cap = (uint64_t)n_cu * 2;
 	if (blocks > cap) blocks = cap;
 	hipLaunchKernelGGL((k_foldeval9<2>), dim3((unsigned)blocks), dim3(256), 0, s, fa, n_in, z, d_out, fz);
+	return hipGetLastError();
+}
+
+hipError_t launch_foldeval_tail(hipStream_t s, const foldeval_args &fa, uint64_t n_in, f128 z, f128 *d_out, const fin_fuse &fz,
+                                const uint64_t *d_cmd, uint64_t *d_status, uint64_t tail_id)
+{
+	if (n_in < 8 || (n_in & 3) || !fz.counter || !fz.args.seq) return hipErrorNotSupported;
+	const size_t lds = (size_t)kTailWaves * kWaveQ * sizeof(uint4);
+	static bool attr_set = false;
+	if (!attr_set) {
+		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_foldeval_tail), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		if (e != hipSuccess) return e;
+		attr_set = true;
+	}
+	hipLaunchKernelGGL(k_foldeval_tail, dim3(1), dim3(64 * kTailWaves), lds, s, fa, n_in, z, d_out, fz, d_cmd, d_status, tail_id);
 	return hipGetLastError();
 }
 

@@ -323,12 +323,39 @@ hipError_t launch_compute_composite_generic(hipStream_t s, const void *const *d_
 // ---- finalize: value[v] = init ^ XOR_t coeff_t * S[slot_t]; rets gathered ---------------------
 __global__ __launch_bounds__(128) void k_finalize(fin_args a, f128 *S, f128 *rets, f128 *mail)
 {
-	finalize_body(a, S, rets, mail);
+	finalize_body(a, S, rets, mail, a.seq);
 }
 
 hipError_t launch_finalize(hipStream_t s, const fin_args &args, f128 *d_S, f128 *d_rets, f128 *d_mail)
 {
 	hipLaunchKernelGGL(k_finalize, dim3(1), dim3(128), 0, s, args, d_S, d_rets, d_mail);
+	return hipGetLastError();
+}
+
+// out[i] = XOR_g vals[g * group_len + i], straight into the host mailbox (the combine step of the
+// sharded prover after the per-round all_gather; RCCL has no XOR reduction)
+__global__ __launch_bounds__(64) void k_xor_publish(const f128 *vals, uint32_t n_groups, uint32_t group_len, f128 *rets, f128 *mail,
+                                                    uint64_t seq)
+{
+	const unsigned i = threadIdx.x;
+	if (i < group_len) {
+		f128 v = f128_zero();
+		for (uint32_t g = 0; g < n_groups; g++)
+			v ^= vals[(size_t)g * group_len + i];
+		rets[i] = v;
+		__hip_atomic_store(&mail[i].lo, v.lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		__hip_atomic_store(&mail[i].hi, v.hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+	}
+	__threadfence_system();
+	__syncthreads();
+	if (i == 0)
+		__hip_atomic_store(&mail[64].lo, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+hipError_t launch_xor_publish(hipStream_t s, const f128 *d_vals, uint32_t n_groups, uint32_t group_len, f128 *d_rets, f128 *d_mail,
+                              uint64_t seq)
+{
+	hipLaunchKernelGGL(k_xor_publish, dim3(1), dim3(64), 0, s, d_vals, n_groups, group_len, d_rets, d_mail, seq);
 	return hipGetLastError();
 }
 

@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256, WAVES) void k_roundeval9(const uint32_t *__res
 			acc[p] ^= P[p];
 	}
 
-	re9::tail(acc, live, c, g, wave, lane, out, fz);
+	re9::tail(acc, live, c, g, wave, lane, out, fz, fz.args.seq);
 }
 
 static unsigned grid9(uint64_t n, int n_cu, int waves)

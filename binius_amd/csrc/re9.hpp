@@ -60,12 +60,13 @@ __device__ __forceinline__ unsigned combo_mask(unsigned c)
 // Workgroup tail: every lane holds 32 accumulator planes (low 16 bits: first stream, high 16 bits:
 // second stream).  Collapses them, recombines the 9 limb products of every wave into field elements,
 // XORs the two sums into out[0], out[1] and, if asked, runs the fused finalize in the last workgroup.
-// Must be called by all 256 threads.
+// Must be called by all NW*64 threads of the workgroup.
+template <int NW = 4>
 __device__ __forceinline__ void tail(const uint32_t (&acc)[32], bool live, unsigned c, unsigned g, unsigned wave, unsigned lane,
-                                     f128 *out, const fin_fuse &fz)
+                                     f128 *out, const fin_fuse &fz, uint64_t seq)
 {
-	__shared__ uint32_t red[4][2][9][8];
-	__shared__ uint64_t wsum[4][4];
+	__shared__ uint32_t red[NW][2][9][8];
+	__shared__ uint64_t wsum[NW][4];
 	// ---- collapse: per lane two GF(2^32) partial sums (low half -> S_1 / first stream, high -> S_inf)
 	uint32_t s_lo = 0, s_hi = 0;
 #pragma unroll
@@ -98,7 +99,10 @@ __device__ __forceinline__ void tail(const uint32_t (&acc)[32], bool live, unsig
 	}
 	__syncthreads();
 	if (threadIdx.x < 4) {
-		const uint64_t v = wsum[0][threadIdx.x] ^ wsum[1][threadIdx.x] ^ wsum[2][threadIdx.x] ^ wsum[3][threadIdx.x];
+		uint64_t v = 0;
+#pragma unroll
+		for (int ww = 0; ww < NW; ww++)
+			v ^= wsum[ww][threadIdx.x];
 		if (v)
 			atomicXor(reinterpret_cast<unsigned long long *>(out) + threadIdx.x, (unsigned long long)v);
 	}
@@ -119,7 +123,7 @@ __device__ __forceinline__ void tail(const uint32_t (&acc)[32], bool live, unsig
 		__syncthreads();
 		if (is_last) {
 			// S is read with agent-scope atomic loads inside finalize_body (they bypass the L1)
-			finalize_body(fz.args, fz.S, fz.rets, fz.mail);
+			finalize_body(fz.args, fz.S, fz.rets, fz.mail, seq);
 			if (threadIdx.x == 0)
 				__hip_atomic_store(fz.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}

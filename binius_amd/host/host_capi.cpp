@@ -170,16 +170,8 @@ int bnh_bivariate_sumcheck_prove(bn_ctx *ctx, uint32_t n_vars, uint32_t m, const
 				check(bn_ctx_get_stream(ctx, &stream));
 				if (g_rccl.all_gather(d_partial, d_gathered, 32, kNcclUint8, rccl_comm, stream) != 0)
 					throw Error(Error::DeviceError, "ncclAllGather failed");
-				std::vector<bn_f128> g((size_t)2 * world);
-				check(bn_copy_d2h(ctx, d_gathered, g.size(), g.data(), g.size()));
-				ev[0] = bn_f128{0, 0};
-				ev[1] = bn_f128{0, 0};
-				for (int w = 0; w < world; w++) {
-					ev[0].lo ^= g[2 * w].lo;
-					ev[0].hi ^= g[2 * w].hi;
-					ev[1].lo ^= g[2 * w + 1].lo;
-					ev[1].hi ^= g[2 * w + 1].hi;
-				}
+				// XOR of the G partials on the device, result through the zero-copy mailbox
+				check(bn_xor_reduce(ctx, d_gathered, (uint32_t)world, 2, ev));
 			} else if (reduce(reduce_user, d_partial, ev)) {
 				throw Error(Error::CoreLibError, "round reduce callback failed");
 			}
@@ -187,6 +179,11 @@ int bnh_bivariate_sumcheck_prove(bn_ctx *ctx, uint32_t n_vars, uint32_t m, const
 			for (size_t i = 0; i < 3; i++) round_coeffs_out[3 * r + i] = rc[i].raw();
 			const B128 z(challenges[r].lo, challenges[r].hi);
 			running = evaluate_univariate(rc, z);
+			struct FoldArgs {
+				FSliceMut evals_0;
+				FSlice evals_1;
+			};
+			std::vector<FoldArgs> prepared;
 			for (auto &ml : cur) {
 				auto h = ComputeMemory::split_half_mut(ml);
 				FSliceMut e0 = h.first;
@@ -194,12 +191,18 @@ int bnh_bivariate_sumcheck_prove(bn_ctx *ctx, uint32_t n_vars, uint32_t m, const
 					e0 = dev_alloc.alloc(h.first.len_);
 					hal.copy_d2d(ComputeMemory::as_const(h.first), e0);
 				}
-				hal.execute([&](ComputeLayerExecutor &exec) {
-					exec.extrapolate_line(e0, ComputeMemory::as_const(h.second), z);
-					return std::vector<B128>{};
-				});
+				prepared.push_back(FoldArgs{e0, ComputeMemory::as_const(h.second)});
 				ml = e0;
 			}
+			// one `map` scope over the multilinears (v3/bivariate_product.rs:217-228): one fold batch,
+			// which the ABI runs together with the next round's evaluation
+			hal.execute([&](ComputeLayerExecutor &exec) {
+				exec.map(prepared.begin(), prepared.end(), [&](ComputeLayerExecutor &e, FoldArgs &a) {
+					e.extrapolate_line(a.evals_0, a.evals_1, z);
+					return 0;
+				});
+				return std::vector<B128>{};
+			});
 			pre_fold = false;
 		}
 		for (uint32_t j = 0; j < m; j++) {

@@ -180,10 +180,15 @@ int bn_scalar_invert(const bn_f128 *a, bn_f128 *out);
  * the context's stream.  Not part of the reference interface. */
 int bn_timer_begin(bn_ctx *ctx);
 int bn_timer_end_ms(bn_ctx *ctx, float *ms);
+/* out[i] = XOR over g < n_groups of d_vals[g * group_len + i], i < group_len <= 64, returned to the
+ * host.  Not part of the reference interface: the combine step behind the per-round all_gather of
+ * the multi-GPU prover (RCCL has no XOR reduction). */
+int bn_xor_reduce(bn_ctx *ctx, const void *d_vals, uint32_t n_groups, uint32_t group_len, bn_f128 *h_out);
+
 /* Per-kernel-class timing without perturbing the stream: while profiling is on, every launch of a
  * hot kernel is bracketed by two hipEvents recorded on the context's stream (no synchronisation);
  * bn_prof_end synchronises once and sums the elapsed times per class. */
-enum { BN_PROF_ROUND_EVAL = 0, BN_PROF_FOLD = 1, BN_PROF_TENSOR_EXPAND = 2, BN_PROF_NTT = 3, BN_PROF_OTHER = 4, BN_PROF_FOLD_EVAL = 5, BN_PROF_N = 6 };
+enum { BN_PROF_ROUND_EVAL = 0, BN_PROF_FOLD = 1, BN_PROF_TENSOR_EXPAND = 2, BN_PROF_NTT = 3, BN_PROF_OTHER = 4, BN_PROF_FOLD_EVAL = 5, BN_PROF_TAIL = 6, BN_PROF_N = 7 };
 int bn_prof_begin(bn_ctx *ctx);
 int bn_prof_end(bn_ctx *ctx, double *ms_by_class /*[BN_PROF_N]*/, uint64_t *launches_by_class /*[BN_PROF_N]*/);
 

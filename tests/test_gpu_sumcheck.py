@@ -253,3 +253,85 @@ def test_deferred_fold_is_invisible(hal, oracle):
     oracle.extrapolate_line(fa, mls[0][n // 2 :].copy(), z)
     oracle.extrapolate_line(fb, mls[1][n // 2 :].copy(), z)
     assert got == oracle.inner_product(fa, 7, fb)[1]
+
+
+def _rounds_with_oracle(hal, oracle, n_vars, disturb=None, seed=0x7A110000):
+    """Drive evaluate -> fold -> evaluate ... through the Python mirror (fold as one batch, the shape
+    the ABI fuses and, for small arrays, hands to the resident tail kernel) and check every round's
+    (y_1, y_inf) and the final folded values against the oracle.  disturb(round) may poke the
+    context between rounds."""
+    from binius_amd.sumcheck import bivariate_product_expr, calculate_round_evals
+
+    alloc = hal.dev_alloc()
+    mls = [oracle.random_b128(seed + j, 1 << n_vars) for j in range(2)]
+    zs = oracle.random_scalars(seed ^ 0x55, n_vars)
+    d = [upload(hal, alloc, x) for x in mls]
+    expr = bivariate_product_expr(hal, 0, 1)
+    cur = [x.copy() for x in mls]
+    for r in range(n_vars):
+        nv = n_vars - r
+        got = calculate_round_evals(hal, nv, [1], d, [expr])
+        rc, want = oracle.round_evals(cur, nv, [(0, 1)], 1)
+        assert rc == 0 and got == want, f"round {r}"
+        if disturb is not None:
+            disturb(r, d)
+        halves = [x.split_half() for x in d]
+        hal.extrapolate_line_batch([lo for lo, _ in halves], [hi for _, hi in halves], zs[r])
+        nxt = []
+        for x in cur:
+            f = x[: len(x) // 2].copy()
+            assert oracle.extrapolate_line(f, x[len(x) // 2 :].copy(), zs[r]) == 0
+            nxt.append(f)
+        cur = nxt
+        d = [lo for lo, _ in halves]
+    for dd, x in zip(d, cur):
+        assert np.array_equal(hal.copy_d2h(dd), x)
+
+
+@pytest.fixture()
+def hal_tail(monkeypatch):
+    """A context with the resident tail kernel switched on (BN_TAIL_MAX_LOG2, off by default)."""
+    import binius_amd
+
+    monkeypatch.setenv("BN_TAIL_MAX_LOG2", "12")
+    ctx = binius_amd.Context(0, 1 << 17)
+    yield ctx
+    ctx.close()
+
+
+@pytest.mark.parametrize("n_vars", [3, 4, 7, 12, 13, 15])
+def test_rounds_through_resident_tail(hal_tail, oracle, n_vars):
+    """Rounds with <= 2^12 elements per array run inside ONE resident kernel that is fed the
+    challenges through pinned host memory (kernels_foldeval9.hip k_foldeval_tail)."""
+    _rounds_with_oracle(hal_tail, oracle, n_vars)
+
+
+@pytest.mark.parametrize("n_vars", [3, 6, 13, 16])
+def test_rounds_without_resident_tail(hal, oracle, n_vars):
+    _rounds_with_oracle(hal, oracle, n_vars)
+
+
+def test_resident_tail_is_cancelled_by_other_calls(hal_tail, oracle):
+    hal = hal_tail
+    """Any other API call while the tail kernel is parked cancels it; the rounds continue on the
+    ordinary kernels (and a new tail may start) with identical results."""
+    def disturb(r, d):
+        if r in (3, 4, 8):
+            hal.copy_d2h(d[0].slice(0, 1))
+        if r == 6:
+            hal.sync()
+
+    _rounds_with_oracle(hal, oracle, 12, disturb)
+
+
+def test_resident_tail_times_out_safely(hal_tail, oracle):
+    hal = hal_tail
+    """A host that stops talking cannot hang the GPU: the parked kernel leaves after a bounded spin
+    and the next round falls back to an ordinary launch."""
+    import time
+
+    def disturb(r, d):
+        if r == 5:
+            time.sleep(8.0)
+
+    _rounds_with_oracle(hal, oracle, 9, disturb)
