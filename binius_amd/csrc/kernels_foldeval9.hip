@@ -42,6 +42,89 @@ static_assert(2 * kArrQ <= kZeroBlk * kBlkQ, "staging must not touch the tile's 
 // wave-uniform, so the addresses are one scalar base per quadrant + (lane*16 + immediate): no
 // per-lane address registers survive into the multiply (the kernel sits at the 256-VGPR limit of
 // two waves per SIMD).
+// per-lane constants of the evaluation stage
+struct eval_layout {
+	unsigned off_a[4], off_b[4]; // LDS offsets (uint4) of the a- and b-limb blocks this lane combines
+	unsigned off_w;              // where a loader lane publishes its transposed limb
+	unsigned st_lo, st_hi;       // staging word offsets of this loader's column (lo' rows, hi' rows)
+	bool loader;
+};
+
+__device__ __forceinline__ eval_layout make_eval_layout(unsigned lane)
+{
+	const unsigned g = lane / 9, c = lane - g * 9;
+	const bool live = lane < 63;
+	eval_layout lay;
+	lay.loader = live && c < 8;
+	const unsigned mask = live ? combo_mask(c) : 0u;
+#pragma unroll
+	for (int s = 0; s < 4; s++) {
+		const bool use = (mask >> s) & 1;
+		lay.off_a[s] = (use ? (unsigned)(s * kGroups + g) : (unsigned)kZeroBlk) * kBlkQ;
+		lay.off_b[s] = (use ? (unsigned)((4 + s) * kGroups + g) : (unsigned)kZeroBlk) * kBlkQ;
+	}
+	lay.off_w = (lay.loader ? (c * kGroups + g) : 0u) * kBlkQ;
+	// staging word offsets of this loader's column: array c>>2, word c&3, rows 7*j + g
+	const unsigned g_ld = live ? g : 0;
+	lay.st_lo = (((c >> 2) & 1) * kArrQ + g_ld) * 4 + (c & 3); // lo' rows (first 112)
+	lay.st_hi = lay.st_lo + kBatch * 4;                        // hi' rows
+	return lay;
+}
+
+// Evaluation stage of one batch: the folded elements are staged in the wave's tile wt (array-major,
+// lo' rows then hi' rows); accumulates this lane's limb-combination product into acc.
+// after_read() runs once the rows are in registers (the staging area is dead from then on).
+template <class F>
+__device__ __forceinline__ void eval_staged(uint4 *wt, const eval_layout &lay, uint32_t (&acc)[32], F &&after_read)
+{
+	const uint32_t *wtw = reinterpret_cast<const uint32_t *>(wt);
+	// ---- lay.loader lanes pick their word column: rows 0..15 = hi', rows 16..31 = lo'
+	uint32_t r[32];
+#pragma unroll
+	for (int j = 0; j < 16; j++) {
+		r[j] = wtw[lay.st_hi + 28 * j];
+		r[16 + j] = wtw[lay.st_lo + 28 * j];
+	}
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	after_read();
+#pragma unroll
+	for (int j = 0; j < 16; j++)
+		r[16 + j] ^= r[j];
+	transpose32(r);
+	if (lay.loader) {
+#pragma unroll
+		for (int q = 0; q < 8; q++)
+			wt[lay.off_w + q] = uint4{r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]};
+	}
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+	uint32_t A[32], B[32];
+#pragma unroll
+	for (int q = 0; q < 8; q++) {
+		const uint4 a0 = wt[lay.off_a[0] + q], a1 = wt[lay.off_a[1] + q], a2 = wt[lay.off_a[2] + q], a3 = wt[lay.off_a[3] + q];
+		const uint4 y0 = wt[lay.off_b[0] + q], y1 = wt[lay.off_b[1] + q], y2 = wt[lay.off_b[2] + q], y3 = wt[lay.off_b[3] + q];
+		A[4 * q] = xor3(a0.x, a1.x, a2.x) ^ a3.x;
+		A[4 * q + 1] = xor3(a0.y, a1.y, a2.y) ^ a3.y;
+		A[4 * q + 2] = xor3(a0.z, a1.z, a2.z) ^ a3.z;
+		A[4 * q + 3] = xor3(a0.w, a1.w, a2.w) ^ a3.w;
+		B[4 * q] = xor3(y0.x, y1.x, y2.x) ^ y3.x;
+		B[4 * q + 1] = xor3(y0.y, y1.y, y2.y) ^ y3.y;
+		B[4 * q + 2] = xor3(y0.z, y1.z, y2.z) ^ y3.z;
+		B[4 * q + 3] = xor3(y0.w, y1.w, y2.w) ^ y3.w;
+		if (q & 1)
+			__builtin_amdgcn_sched_barrier(0);
+	}
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	uint32_t P[32];
+	bs_mul<5>(A, B, P);
+#pragma unroll
+	for (int p = 0; p < 32; p++)
+		acc[p] ^= P[p];
+}
+
 // One round for one wave: folds and evaluates batches wave_global, wave_global + n_waves, ... and
 // leaves the wave's 32 accumulator planes in acc.  wt = this wave's LDS tile (kWaveQ uint4).
 template <bool PREFETCH = true>
@@ -49,29 +132,12 @@ __device__ __forceinline__ void foldeval_wave(const foldeval_args &fa, uint64_t 
                                               uint64_t wave_global, uint64_t n_waves, uint32_t (&acc)[32])
 {
 	const unsigned lane = threadIdx.x & 63;
-	const unsigned g = lane / 9, c = lane - g * 9;
-	const bool live = lane < 63;
-	const bool loader = live && c < 8;
-	const uint32_t *wtw = reinterpret_cast<const uint32_t *>(wt);
+	const eval_layout lay = make_eval_layout(lane);
 	// zero block (read by combination slots a lane does not use)
 	if (lane < kBlkQ)
 		wt[kZeroBlk * kBlkQ + lane] = uint4{0, 0, 0, 0};
 
 	const uint64_t n = n_in >> 2;     // evaluation points of the next round
-
-	unsigned mask = live ? combo_mask(c) : 0u;
-	unsigned off_a[4], off_b[4];
-#pragma unroll
-	for (int s = 0; s < 4; s++) {
-		const bool use = (mask >> s) & 1;
-		off_a[s] = (use ? (unsigned)(s * kGroups + g) : (unsigned)kZeroBlk) * kBlkQ;
-		off_b[s] = (use ? (unsigned)((4 + s) * kGroups + g) : (unsigned)kZeroBlk) * kBlkQ;
-	}
-	const unsigned off_w = (loader ? (c * kGroups + g) : 0u) * kBlkQ;
-	// staging word offsets of this loader's column: array c>>2, word c&3, rows 7*j + g
-	const unsigned g_ld = live ? g : 0;
-	const unsigned st_lo = (((c >> 2) & 1) * kArrQ + g_ld) * 4 + (c & 3); // lo' rows (first 112)
-	const unsigned st_hi = st_lo + kBatch * 4;                            // hi' rows
 
 #pragma unroll
 	for (int p = 0; p < 32; p++)
@@ -125,53 +191,11 @@ __device__ __forceinline__ void foldeval_wave(const foldeval_args &fa, uint64_t 
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		__builtin_amdgcn_wave_barrier();
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-		// ---- loader lanes pick their word column: rows 0..15 = hi', rows 16..31 = lo'
-		uint32_t r[32];
-#pragma unroll
-		for (int j = 0; j < 16; j++) {
-			r[j] = wtw[st_hi + 28 * j];
-			r[16 + j] = wtw[st_lo + 28 * j];
-		}
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-		__builtin_amdgcn_wave_barrier();
-		// next batch's raw elements fly while this batch is transposed and multiplied
-		if (PREFETCH && b + n_waves < n_batches)
-			load_raw(b + n_waves, c0{}, cP{});
-#pragma unroll
-		for (int j = 0; j < 16; j++)
-			r[16 + j] ^= r[j];
-		transpose32(r);
-		if (loader) {
-#pragma unroll
-			for (int q = 0; q < 8; q++)
-				wt[off_w + q] = uint4{r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]};
-		}
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-		__builtin_amdgcn_wave_barrier();
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-		uint32_t A[32], B[32];
-#pragma unroll
-		for (int q = 0; q < 8; q++) {
-			const uint4 a0 = wt[off_a[0] + q], a1 = wt[off_a[1] + q], a2 = wt[off_a[2] + q], a3 = wt[off_a[3] + q];
-			const uint4 y0 = wt[off_b[0] + q], y1 = wt[off_b[1] + q], y2 = wt[off_b[2] + q], y3 = wt[off_b[3] + q];
-			A[4 * q] = xor3(a0.x, a1.x, a2.x) ^ a3.x;
-			A[4 * q + 1] = xor3(a0.y, a1.y, a2.y) ^ a3.y;
-			A[4 * q + 2] = xor3(a0.z, a1.z, a2.z) ^ a3.z;
-			A[4 * q + 3] = xor3(a0.w, a1.w, a2.w) ^ a3.w;
-			B[4 * q] = xor3(y0.x, y1.x, y2.x) ^ y3.x;
-			B[4 * q + 1] = xor3(y0.y, y1.y, y2.y) ^ y3.y;
-			B[4 * q + 2] = xor3(y0.z, y1.z, y2.z) ^ y3.z;
-			B[4 * q + 3] = xor3(y0.w, y1.w, y2.w) ^ y3.w;
-			if (q & 1)
-				__builtin_amdgcn_sched_barrier(0);
-		}
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-		__builtin_amdgcn_wave_barrier();
-		uint32_t P[32];
-		bs_mul<5>(A, B, P);
-#pragma unroll
-		for (int p = 0; p < 32; p++)
-			acc[p] ^= P[p];
+		eval_staged(wt, lay, acc, [&]() {
+			// next batch's raw elements fly while this batch is transposed and multiplied
+			if (PREFETCH && b + n_waves < n_batches)
+				load_raw(b + n_waves, c0{}, cP{});
+		});
 	}
 
 }
@@ -187,6 +211,64 @@ __global__ __launch_bounds__(256, WAVES) void k_foldeval9(foldeval_args fa, uint
 	const unsigned g = lane / 9, c = lane - g * 9;
 	uint32_t acc[32];
 	foldeval_wave(fa, n_in, tab, tile[wave], (uint64_t)blockIdx.x * 4 + wave, (uint64_t)gridDim.x * 4, acc);
+	re9::tail<4>(acc, lane < 63, c, g, wave, lane, out, fz, fz.args.seq);
+}
+
+// Latency-shaped variant for small rounds (every batch gets its own workgroup: n_batches <= 2 per CU).
+// A lone wave issues one VALU instruction per ~4.7 cycles, so the 8 serial constant multiplications
+// of a batch (1600 instructions) cost 3 us on one wave; here the four waves of the workgroup fold one
+// quadrant each (2 slots), with the loads in flight while the nibble tables are built, and wave 0
+// evaluates the batch.
+__global__ __launch_bounds__(256, 2) void k_foldeval9_small(foldeval_args fa, uint64_t n_in, f128 z, f128 *out, fin_fuse fz)
+{
+	__shared__ uint4 tile[kWaveQ];
+	__shared__ ctable_smem tab;
+	const unsigned lane = threadIdx.x & 63;
+	const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const unsigned g = lane / 9, c = lane - g * 9;
+	const uint64_t n = n_in >> 2;
+	const uint64_t p0 = (uint64_t)blockIdx.x * kBatch;
+	const uint64_t left = n - p0;
+	// this wave's quadrant: array wave>>1, half wave&1; two slots: points lane, lane + 64
+	const uint64_t qo = ((wave & 1) ? n : 0) + p0;
+	const uint4 *q0 = (const uint4 *)fa.x0[wave >> 1] + qo, *q1 = (const uint4 *)fa.x1[wave >> 1] + qo;
+	uint4 *qd = (uint4 *)fa.out[wave >> 1] + qo;
+	uint4 x0[2], x1[2];
+#pragma unroll
+	for (int sub = 0; sub < 2; sub++) {
+		const unsigned pt = lane + 64 * sub;
+		uint4 v0{0, 0, 0, 0}, v1{0, 0, 0, 0};
+		if (pt < kBatch && pt < left) {
+			v0 = q0[pt];
+			v1 = q1[pt];
+		}
+		x0[sub] = v0;
+		x1[sub] = v1;
+	}
+	ctable_build(tab, z); // the loads above are in flight meanwhile
+	if (threadIdx.x < kBlkQ)
+		tile[kZeroBlk * kBlkQ + threadIdx.x] = uint4{0, 0, 0, 0};
+#pragma unroll
+	for (int sub = 0; sub < 2; sub++) {
+		const unsigned pt = lane + 64 * sub;
+		if (sub == 1 && left <= 64) break; // (uniform) nothing in the second slot
+		const uint4 f = xor4(x0[sub], ctable_mul(tab, xor4(x0[sub], x1[sub])));
+		if (pt < kBatch) {
+			if (pt < left) qd[pt] = f;
+			tile[(wave >> 1) * kArrQ + (wave & 1) * kBatch + pt] = f;
+		}
+	}
+	if (left <= 64 && lane < kBatch - 64) // second slot skipped: its staging rows must still read as zero
+		tile[(wave >> 1) * kArrQ + (wave & 1) * kBatch + 64 + lane] = uint4{0, 0, 0, 0};
+	__syncthreads();
+	uint32_t acc[32];
+#pragma unroll
+	for (int p = 0; p < 32; p++)
+		acc[p] = 0;
+	if (wave == 0) {
+		const eval_layout lay = make_eval_layout(lane);
+		eval_staged(tile, lay, acc, []() {});
+	}
 	re9::tail<4>(acc, lane < 63, c, g, wave, lane, out, fz, fz.args.seq);
 }
 
@@ -271,6 +353,11 @@ hipError_t launch_foldeval9(hipStream_t s, int n_cu, const foldeval_args &fa, ui
 	const uint64_t n_batches = (n + kBatch - 1) / kBatch;
 	uint64_t blocks = (n_batches + 3) / 4;
 	const uint64_t cap = (uint64_t)n_cu * 2;
+	if (n_batches <= cap) {
+		// small round: one workgroup per batch, the four waves share the fold (latency, not throughput)
+		hipLaunchKernelGGL(k_foldeval9_small, dim3((unsigned)n_batches), dim3(256), 0, s, fa, n_in, z, d_out, fz);
+		return hipGetLastError();
+	}
 	if (blocks > cap) blocks = cap;
 	hipLaunchKernelGGL((k_foldeval9<2>), dim3((unsigned)blocks), dim3(256), 0, s, fa, n_in, z, d_out, fz);
 	return hipGetLastError();

@@ -98,6 +98,20 @@ __device__ __forceinline__ void tail(const uint32_t (&acc)[32], bool live, unsig
 		wsum[wave][2 * lane + 1] = S.hi;
 	}
 	__syncthreads();
+	if (fz.counter && gridDim.x == 1 && out == fz.S) {
+		// single workgroup: the sums never leave the chip -- finalize straight from LDS
+		__shared__ f128 s_loc[2];
+		if (threadIdx.x < 4) {
+			uint64_t v = 0;
+#pragma unroll
+			for (int ww = 0; ww < NW; ww++)
+				v ^= wsum[ww][threadIdx.x];
+			reinterpret_cast<uint64_t *>(s_loc)[threadIdx.x] = v;
+		}
+		__syncthreads();
+		finalize_body(fz.args, fz.S, fz.rets, fz.mail, seq, s_loc);
+		return;
+	}
 	if (threadIdx.x < 4) {
 		uint64_t v = 0;
 #pragma unroll
