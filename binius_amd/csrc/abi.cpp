@@ -141,7 +141,7 @@ static int flush_copies(bn_ctx *ctx)
 	return BN_OK;
 }
 
-static int flush_pending(bn_ctx *ctx, bool keep_tail = false)
+static int flush_pending(bn_ctx *ctx, bool keep_tail = false, bool publish_tiny = false)
 {
 	if (ctx->tail.active && !keep_tail) {
 		int rc = tail_cancel(ctx);
@@ -153,6 +153,19 @@ static int flush_pending(bn_ctx *ctx, bool keep_tail = false)
 	}
 	if (!ctx->pend.active) return BN_OK;
 	ctx->pend.active = false;
+	if (publish_tiny && (uint64_t)ctx->pend.count * ctx->pend.n <= 64) {
+		// the caller is a host read: fold and mirror the (few) results into the mailbox in one launch
+		const uint64_t seq = ++ctx->mail_seq;
+		prof_scope ps(ctx, BN_PROF_FOLD);
+		BN_HIP(bn::launch_fold_publish(ctx->stream, ctx->pend.x0, ctx->pend.src0, ctx->pend.x1, ctx->pend.count, (uint32_t)ctx->pend.n,
+		                               ctx->pend.z, ctx->d_mail, seq));
+		ctx->mirror.valid = true;
+		ctx->mirror.seq = seq;
+		ctx->mirror.count = ctx->pend.count;
+		ctx->mirror.n = (uint32_t)ctx->pend.n;
+		for (uint32_t i = 0; i < ctx->pend.count; i++) ctx->mirror.ptr[i] = ctx->pend.x0[i];
+		return BN_OK;
+	}
 	bn::fold_batch fb{};
 	for (uint32_t i = 0; i < ctx->pend.count; i++) {
 		fb.x0[i] = ctx->pend.x0[i];
@@ -167,6 +180,7 @@ static int flush_pending(bn_ctx *ctx, bool keep_tail = false)
 #define BN_FLUSH(ctx)                    \
 	do {                                 \
 		int rc_ = flush_pending(ctx);    \
+		(ctx)->mirror.valid = false;     \
 		if (rc_) return rc_;             \
 	} while (0)
 
@@ -377,9 +391,37 @@ int bn_copy_h2d(bn_ctx *ctx, const bn_f128 *h_src, uint64_t src_len, void *d_dst
 int bn_copy_d2h(bn_ctx *ctx, const void *d_src, uint64_t src_len, bn_f128 *h_dst, uint64_t dst_len)
 {
 	BN_REQUIRE(ctx, "null ctx");
-	BN_FLUSH(ctx);
+	{
+		// a read does not invalidate the host mirror of a tiny fold -- and may create it
+		int rc_ = flush_pending(ctx, false, /*publish_tiny=*/ctx->lazy_fold);
+		if (rc_) return rc_;
+	}
 	BN_REQUIRE(src_len == dst_len, "precondition: src and dst buffers must have the same length");
 	if (src_len == 0) return BN_OK;
+	if (ctx->mirror.valid) {
+		for (uint32_t i = 0; i < ctx->mirror.count; i++) {
+			const char *base = (const char *)ctx->mirror.ptr[i];
+			const char *p = (const char *)d_src;
+			if (p >= base && p + src_len * sizeof(f128) <= base + (size_t)ctx->mirror.n * sizeof(f128)) {
+				volatile uint64_t *seqw = &ctx->h_mail[64].lo;
+				uint64_t spins = 0;
+				while (__atomic_load_n(seqw, __ATOMIC_ACQUIRE) != ctx->mirror.seq) {
+					if (++spins > (1ull << 22)) {
+						BN_HIP(hipStreamSynchronize(ctx->stream));
+						if (__atomic_load_n(seqw, __ATOMIC_ACQUIRE) != ctx->mirror.seq)
+							return bn::fail(BN_ERR_DEVICE, "device error: result mailbox was not published");
+						break;
+					}
+				}
+				const size_t off = (size_t)i * ctx->mirror.n + (size_t)(p - base) / sizeof(f128);
+				for (uint64_t e = 0; e < src_len; e++) {
+					h_dst[e].lo = __atomic_load_n(&ctx->h_mail[off + e].lo, __ATOMIC_RELAXED);
+					h_dst[e].hi = __atomic_load_n(&ctx->h_mail[off + e].hi, __ATOMIC_RELAXED);
+				}
+				return BN_OK;
+			}
+		}
+	}
 	BN_HIP(hipMemcpyAsync(h_dst, d_src, src_len * sizeof(f128), hipMemcpyDeviceToHost, ctx->stream));
 	BN_HIP(hipStreamSynchronize(ctx->stream));
 	return BN_OK;
@@ -390,6 +432,7 @@ int bn_copy_d2d(bn_ctx *ctx, const void *d_src, uint64_t src_len, void *d_dst, u
 	BN_REQUIRE(ctx, "null ctx");
 	BN_REQUIRE(src_len == dst_len, "precondition: src and dst buffers must have the same length");
 	if (src_len == 0) return BN_OK;
+	ctx->mirror.valid = false;
 	if (ctx->lazy_fold && !ctx->pend.active && ctx->pend_copies.size() < 8) {
 		// deferred: a fold into d_dst may absorb it (see bn_ctx::pending_copy)
 		ctx->pend_copies.push_back({d_src, d_dst, src_len});
@@ -458,16 +501,19 @@ int bn_expr_compile(bn_ctx *ctx, const bn_step *steps, uint64_t n_steps, bn_expr
 		e->shape = bn_expr::PRODUCT;
 		e->product_vars = prod[n_steps - 1];
 	}
-	if (n_steps) {
-		hipError_t err = hipMalloc((void **)&e->d_steps, n_steps * sizeof(bn_step));
-		if (err == hipSuccess)
-			err = hipMemcpy(e->d_steps, steps, n_steps * sizeof(bn_step), hipMemcpyHostToDevice);
-		if (err != hipSuccess) {
-			delete e;
-			return bn::hip_fail(err, "bn_expr_compile");
-		}
-	}
+	// the device copy of the steps is only needed by the generic interpreter kernels: uploaded on
+	// first use (ensure_d_steps), so compiling a product composition touches no device memory
 	*out = e;
+	return BN_OK;
+}
+
+static int ensure_d_steps(const bn_expr *e)
+{
+	if (e->d_steps || e->steps.empty()) return BN_OK;
+	const size_t bytes = e->steps.size() * sizeof(bn_step);
+	hipError_t err = hipMalloc((void **)&e->d_steps, bytes);
+	if (err == hipSuccess) err = hipMemcpy(e->d_steps, e->steps.data(), bytes, hipMemcpyHostToDevice);
+	if (err != hipSuccess) return bn::hip_fail(err, "bn_expr upload");
 	return BN_OK;
 }
 
@@ -503,6 +549,7 @@ int bn_extrapolate_line_batch(bn_ctx *ctx, void *const *d_evals_0, const void *c
 	BN_REQUIRE(ctx && z && d_evals_0 && d_evals_1, "null argument");
 	BN_REQUIRE(count <= (uint32_t)bn::kFoldBatchMax, "too many slices in one extrapolate_line batch");
 	if (count == 0) return BN_OK;
+	ctx->mirror.valid = false;
 	// deferred copies whose destination is one of the evals_0 are absorbed (every one of them must
 	// be, otherwise they all run now, in issue order)
 	const void *src0[bn::kFoldBatchMax];
@@ -690,6 +737,8 @@ int bn_compute_composite(bn_ctx *ctx, const void *const *d_rows, uint32_t n_rows
 	}
 	const void **d_ptrs = nullptr;
 	int rc = upload_ptrs(ctx, d_rows, n_rows, &d_ptrs);
+	if (rc) return rc;
+	rc = ensure_d_steps(expr);
 	if (rc) return rc;
 	BN_HIP(bn::launch_compute_composite_generic(ctx->stream, d_ptrs, n_rows, row_len, d_out, expr->d_steps,
 	                                            (uint32_t)expr->steps.size()));
@@ -1178,6 +1227,8 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 				}
 				const void **d_ptrs = nullptr;
 				rc = upload_ptrs(ctx, rows.data(), op.n_rows, &d_ptrs);
+				if (rc) return rc;
+				rc = ensure_d_steps(op.expr);
 				if (rc) return rc;
 				BN_HIP(bn::launch_sum_composition_generic(s, ctx->n_cu, d_ptrs, op.n_rows, row_len, op.expr->d_steps,
 				                                          (uint32_t)op.expr->steps.size(), d_S + slot));

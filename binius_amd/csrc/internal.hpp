@@ -16,7 +16,7 @@ struct bn_expr {
 	// classification for the specialised kernels
 	enum Shape { GENERIC = 0, PRODUCT = 1 } shape = GENERIC;
 	std::vector<uint32_t> product_vars; // PRODUCT: var indices multiplied together (in order)
-	bn_step *d_steps = nullptr;         // device copy for the interpreter kernels
+	mutable bn_step *d_steps = nullptr; // device copy for the interpreter kernels (uploaded on first use)
 	int device = 0;
 };
 
@@ -69,6 +69,14 @@ struct bn_ctx {
 		uint64_t n;
 	};
 	std::vector<pending_copy> pend_copies;
+	// host mirror of tiny folded arrays (k_fold_publish): valid until the next call that may write
+	// device memory; mailbox slot = off + i for element i of [ptr, ptr + n)
+	struct mirror_state {
+		bool valid = false;
+		uint64_t seq = 0;
+		uint32_t count = 0, n = 0;
+		const void *ptr[8] = {};
+	} mirror;
 	bool lazy_fold = true; // BN_NO_LAZY_FOLD=1 turns the deferral off
 	// resident tail kernel (kernels_foldeval9.hip k_foldeval_tail, protocol in abi.cpp)
 	struct tail_state {
@@ -111,6 +119,8 @@ struct fold_batch {
 	const void *x1[kFoldBatchMax];
 };
 hipError_t launch_extrapolate_line_batch(hipStream_t s, int n_cu, const fold_batch &b, uint32_t count, uint64_t n, f128 z);
+hipError_t launch_fold_publish(hipStream_t s, void *const *x0, const void *const *src0, const void *const *x1, uint32_t count, uint32_t n,
+                               f128 z, f128 *d_mail, uint64_t seq);
 hipError_t launch_tensor_expand_pass(hipStream_t s, int n_cu, void *data, uint64_t half, f128 r);
 
 // ---- kernels_roundeval.hip

@@ -201,6 +201,47 @@ hipError_t launch_extrapolate_line_batch(hipStream_t s, int n_cu, const fold_bat
 	return hipGetLastError();
 }
 
+// A tiny fold batch (count * n <= 64 elements) whose results the host is about to read: fold in
+// place and mirror every folded element into the pinned host mailbox (mail[arr * n + i]), then the
+// sequence word.  The host-side copy_d2h calls that follow are served from the mailbox.
+struct fold_publish_args {
+	void *x0[kFoldBatchMax];
+	const void *src0[kFoldBatchMax];
+	const void *x1[kFoldBatchMax];
+};
+__global__ __launch_bounds__(256) void k_fold_publish(fold_publish_args fb, uint32_t count, uint32_t n, f128 z, f128 *mail, uint64_t seq)
+{
+	__shared__ ctable_smem tab;
+	ctable_build(tab, z);
+	const unsigned i = threadIdx.x;
+	if (i < count * n) {
+		const unsigned arr = i / n, j = i - arr * n;
+		const uint4 a = ((const uint4 *)fb.src0[arr])[j], b = ((const uint4 *)fb.x1[arr])[j];
+		const uint4 f = xor4(a, ctable_mul(tab, xor4(a, b)));
+		((uint4 *)fb.x0[arr])[j] = f;
+		const f128 v = to_f128(f);
+		__hip_atomic_store(&mail[i].lo, v.lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		__hip_atomic_store(&mail[i].hi, v.hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+	}
+	// count * n <= 64: all value stores were issued by wave 0, whose release drains them first
+	if (i == 0)
+		__hip_atomic_store(&mail[64].lo, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+hipError_t launch_fold_publish(hipStream_t s, void *const *x0, const void *const *src0, const void *const *x1, uint32_t count, uint32_t n,
+                               f128 z, f128 *d_mail, uint64_t seq)
+{
+	if (count == 0 || n == 0 || count > (uint32_t)kFoldBatchMax || (uint64_t)count * n > 64) return hipErrorNotSupported;
+	fold_publish_args fb{};
+	for (uint32_t i = 0; i < count; i++) {
+		fb.x0[i] = x0[i];
+		fb.src0[i] = src0[i];
+		fb.x1[i] = x1[i];
+	}
+	hipLaunchKernelGGL(k_fold_publish, dim3(1), dim3(256), 0, s, fb, count, n, z, d_mail, seq);
+	return hipGetLastError();
+}
+
 hipError_t launch_tensor_expand_pass(hipStream_t s, int n_cu, void *data, uint64_t half, f128 r)
 {
 	if (half == 0) return hipSuccess;

@@ -335,3 +335,31 @@ def test_resident_tail_times_out_safely(hal_tail, oracle):
             time.sleep(8.0)
 
     _rounds_with_oracle(hal, oracle, 9, disturb)
+
+
+def test_tiny_fold_results_are_mirrored_to_the_host(hal, oracle):
+    """finish(): the last fold leaves one element per multilinear and the prover reads them back one
+    by one; the ABI folds and mirrors them into the pinned mailbox in one launch.  Reads must see
+    fresh data also after further folds of the same arrays."""
+    alloc = hal.dev_alloc()
+    for n in (2, 4, 16, 64, 128):
+        mls = [oracle.random_b128(0x71000 + 17 * n + j, n) for j in range(3)]
+        d = [upload(hal, alloc, x) for x in mls]
+        cur = [x.copy() for x in mls]
+        zs = oracle.random_scalars(0x7100 + n, 8)
+        r = 0
+        while len(cur[0]) > 1:
+            halves = [x.split_half() for x in d]
+            hal.extrapolate_line_batch([lo for lo, _ in halves], [hi for _, hi in halves], zs[r])
+            nxt = []
+            for x in cur:
+                f = x[: len(x) // 2].copy()
+                oracle.extrapolate_line(f, x[len(x) // 2 :].copy(), zs[r])
+                nxt.append(f)
+            cur, d = nxt, [lo for lo, _ in halves]
+            # read back in pieces, twice (second read is served from the same mirror)
+            for _ in range(2):
+                for dd, x in zip(d, cur):
+                    assert np.array_equal(hal.copy_d2h(dd), x)
+                    assert np.array_equal(hal.copy_d2h(dd.slice(len(x) - 1, len(x))), x[-1:])
+            r += 1
