@@ -74,34 +74,45 @@ __device__ __forceinline__ uint32_t ct_xor3(uint32_t a, uint32_t b, uint32_t c) 
 // (its low nibbles become the high nibbles of the rotated word's bytes), eight SDWA byte-selects
 // that produce nibble*16 directly, and the 32 looked-up entries folded two at a time with the
 // three-input XOR (v_bitop3_b32).
+// The lookups are issued in groups of G (default 16 = two words) before anything consumes them: a
+// dependent read-xor chain would keep only 2-4 reads in flight and turn the multiplication into
+// 8-16 serialized LDS round trips (measured: the fused fold+eval kernel 222 -> see profiles/r01).
+template <int G = 16>
 __device__ __forceinline__ uint4 ctable_mul(const ctable_smem &s, uint4 x)
 {
+	static_assert(G == 8 || G == 16 || G == 32, "group = 1, 2 or 4 words of lookups in flight");
 	const char *base = reinterpret_cast<const char *>(s.T);
 	uint4 acc{0, 0, 0, 0};
 	const uint32_t w[4] = {x.x, x.y, x.z, x.w};
 	const uint32_t m = 0xF0u;
+	constexpr int WPG = G / 8; // words per group
 #pragma unroll
-	for (int wi = 0; wi < 4; wi++) {
-		const uint32_t hi = w[wi];
-		const uint32_t lo = __builtin_amdgcn_alignbit(hi, hi, 28); // rotl(w, 4)
-		uint32_t off[8];
-		off[0] = byte_and<0>(lo, m);
-		off[1] = byte_and<0>(hi, m);
-		off[2] = byte_and<1>(lo, m);
-		off[3] = byte_and<1>(hi, m);
-		off[4] = byte_and<2>(lo, m);
-		off[5] = byte_and<2>(hi, m);
-		off[6] = byte_and<3>(lo, m);
-		off[7] = byte_and<3>(hi, m);
+	for (int w0 = 0; w0 < 4; w0 += WPG) {
+		uint32_t off[G];
 #pragma unroll
-		for (int j = 0; j < 8; j += 2) {
-			// byte offset of entry: table (8*wi + j) * 256 + nibble * 16
-			const uint4 t0 = *reinterpret_cast<const uint4 *>(base + (8 * wi + j) * 256 + off[j]);
-			const uint4 t1 = *reinterpret_cast<const uint4 *>(base + (8 * wi + j + 1) * 256 + off[j + 1]);
-			acc.x = ct_xor3(acc.x, t0.x, t1.x);
-			acc.y = ct_xor3(acc.y, t0.y, t1.y);
-			acc.z = ct_xor3(acc.z, t0.z, t1.z);
-			acc.w = ct_xor3(acc.w, t0.w, t1.w);
+		for (int wq = 0; wq < WPG; wq++) {
+			const uint32_t hi = w[w0 + wq];
+			const uint32_t lo = __builtin_amdgcn_alignbit(hi, hi, 28); // rotl(w, 4)
+			off[8 * wq + 0] = byte_and<0>(lo, m);
+			off[8 * wq + 1] = byte_and<0>(hi, m);
+			off[8 * wq + 2] = byte_and<1>(lo, m);
+			off[8 * wq + 3] = byte_and<1>(hi, m);
+			off[8 * wq + 4] = byte_and<2>(lo, m);
+			off[8 * wq + 5] = byte_and<2>(hi, m);
+			off[8 * wq + 6] = byte_and<3>(lo, m);
+			off[8 * wq + 7] = byte_and<3>(hi, m);
+		}
+		uint4 t[G];
+#pragma unroll
+		for (int j = 0; j < G; j++) // byte offset of entry: table (8*word + nibble_index) * 256 + nibble * 16
+			t[j] = *reinterpret_cast<const uint4 *>(base + (8 * w0 + j) * 256 + off[j]);
+		__builtin_amdgcn_sched_barrier(0); // keep the G reads ahead of their consumers
+#pragma unroll
+		for (int j = 0; j < G; j += 2) {
+			acc.x = ct_xor3(acc.x, t[j].x, t[j + 1].x);
+			acc.y = ct_xor3(acc.y, t[j].y, t[j + 1].y);
+			acc.z = ct_xor3(acc.z, t[j].z, t[j + 1].z);
+			acc.w = ct_xor3(acc.w, t[j].w, t[j + 1].w);
 		}
 	}
 	return acc;

@@ -173,15 +173,16 @@ __device__ __forceinline__ void foldeval_wave(const foldeval_args &fa, uint64_t 
 	for (uint64_t b = wave_global; b < n_batches; b += n_waves) {
 		const uint64_t p0 = b * kBatch;
 		const uint64_t left = n - p0;
-		if (PREFETCH)
+		if (PREFETCH) {
 			load_raw(b, cP{}, cN{});
-		else
+		} else {
 			load_raw(b, c0{}, cN{}); // resident tail: a wave sees one or two batches, nothing to overlap
+		}
 		// ---- fold: f = x0 + z * (x0 + x1); back to HBM (next round's input) and into the staging tile
 #pragma unroll
 		for (int t = 0; t < kSlots; t++) {
 			const unsigned pt = lane + 64 * (t & 1);
-			const uint4 f = xor4(x0[t], ctable_mul(tab, xor4(x0[t], x1[t])));
+			const uint4 f = xor4(x0[t], ctable_mul<8>(tab, xor4(x0[t], x1[t])));
 			if (pt < kBatch) {
 				if (pt < left)
 					((uint4 *)fa.out[t >> 2] + qoff(t, p0))[pt] = f;
