@@ -177,6 +177,8 @@ static int flush_pending(bn_ctx *ctx, bool keep_tail = false, bool publish_tiny 
 	BN_HIP(bn::launch_extrapolate_line_batch(ctx->stream, ctx->n_cu, fb, ctx->pend.count, ctx->pend.n, ctx->pend.z));
 	return BN_OK;
 }
+// one call at a time per context (the trait allows the host to call from several threads: rayon join/map)
+#define BN_ENTER(ctx) std::lock_guard<std::recursive_mutex> bn_enter_lock_((ctx)->mu)
 #define BN_FLUSH(ctx)                    \
 	do {                                 \
 		int rc_ = flush_pending(ctx);    \
@@ -280,6 +282,7 @@ int bn_ctx_destroy(bn_ctx *ctx)
 int bn_arena_base(bn_ctx *ctx, void **d_base, uint64_t *elems)
 {
 	BN_REQUIRE(ctx && d_base && elems, "null argument");
+	BN_ENTER(ctx);
 	BN_FLUSH(ctx);
 	*d_base = ctx->arena;
 	*elems = ctx->arena_elems;
@@ -289,6 +292,7 @@ int bn_arena_base(bn_ctx *ctx, void **d_base, uint64_t *elems)
 int bn_ctx_set_stream(bn_ctx *ctx, void *hip_stream)
 {
 	BN_REQUIRE(ctx, "null ctx");
+	BN_ENTER(ctx);
 	BN_FLUSH(ctx);
 	BN_HIP(hipSetDevice(ctx->device));
 	BN_HIP(hipStreamSynchronize(ctx->stream));
@@ -309,6 +313,7 @@ int bn_ctx_set_stream(bn_ctx *ctx, void *hip_stream)
 int bn_ctx_get_stream(bn_ctx *ctx, void **hip_stream)
 {
 	BN_REQUIRE(ctx && hip_stream, "null argument");
+	BN_ENTER(ctx);
 	BN_FLUSH(ctx);
 	*hip_stream = (void *)ctx->stream;
 	return BN_OK;
@@ -317,6 +322,7 @@ int bn_ctx_get_stream(bn_ctx *ctx, void **hip_stream)
 int bn_sync(bn_ctx *ctx)
 {
 	BN_REQUIRE(ctx, "null ctx");
+	BN_ENTER(ctx);
 	BN_FLUSH(ctx);
 	BN_HIP(hipStreamSynchronize(ctx->stream));
 	return BN_OK;
@@ -325,6 +331,7 @@ int bn_sync(bn_ctx *ctx)
 int bn_prof_begin(bn_ctx *ctx)
 {
 	BN_REQUIRE(ctx, "null ctx");
+	BN_ENTER(ctx);
 	BN_FLUSH(ctx);
 	for (auto &r : ctx->prof) {
 		ctx->ev_pool.push_back(r.a);
@@ -338,6 +345,7 @@ int bn_prof_begin(bn_ctx *ctx)
 int bn_prof_end(bn_ctx *ctx, double *ms_by_class, uint64_t *launches_by_class)
 {
 	BN_REQUIRE(ctx && ms_by_class && launches_by_class, "null argument");
+	BN_ENTER(ctx);
 	BN_FLUSH(ctx);
 	ctx->prof_on = false;
 	BN_HIP(hipStreamSynchronize(ctx->stream));
@@ -360,6 +368,7 @@ int bn_prof_end(bn_ctx *ctx, double *ms_by_class, uint64_t *launches_by_class)
 int bn_timer_begin(bn_ctx *ctx)
 {
 	BN_REQUIRE(ctx, "null ctx");
+	BN_ENTER(ctx);
 	BN_FLUSH(ctx);
 	BN_HIP(hipEventRecord(ctx->ev0, ctx->stream));
 	return BN_OK;
@@ -368,6 +377,7 @@ int bn_timer_begin(bn_ctx *ctx)
 int bn_timer_end_ms(bn_ctx *ctx, float *ms)
 {
 	BN_REQUIRE(ctx && ms, "null argument");
+	BN_ENTER(ctx);
 	BN_FLUSH(ctx);
 	BN_HIP(hipEventRecord(ctx->ev1, ctx->stream));
 	BN_HIP(hipEventSynchronize(ctx->ev1));
@@ -379,6 +389,7 @@ int bn_timer_end_ms(bn_ctx *ctx, float *ms)
 int bn_copy_h2d(bn_ctx *ctx, const bn_f128 *h_src, uint64_t src_len, void *d_dst, uint64_t dst_len)
 {
 	BN_REQUIRE(ctx, "null ctx");
+	BN_ENTER(ctx);
 	BN_FLUSH(ctx);
 	BN_REQUIRE(src_len == dst_len, "precondition: src and dst buffers must have the same length");
 	if (src_len == 0) return BN_OK;
@@ -391,6 +402,7 @@ int bn_copy_h2d(bn_ctx *ctx, const bn_f128 *h_src, uint64_t src_len, void *d_dst
 int bn_copy_d2h(bn_ctx *ctx, const void *d_src, uint64_t src_len, bn_f128 *h_dst, uint64_t dst_len)
 {
 	BN_REQUIRE(ctx, "null ctx");
+	BN_ENTER(ctx);
 	{
 		// a read does not invalidate the host mirror of a tiny fold -- and may create it
 		int rc_ = flush_pending(ctx, false, /*publish_tiny=*/ctx->lazy_fold);
@@ -430,6 +442,7 @@ int bn_copy_d2h(bn_ctx *ctx, const void *d_src, uint64_t src_len, bn_f128 *h_dst
 int bn_copy_d2d(bn_ctx *ctx, const void *d_src, uint64_t src_len, void *d_dst, uint64_t dst_len)
 {
 	BN_REQUIRE(ctx, "null ctx");
+	BN_ENTER(ctx);
 	BN_REQUIRE(src_len == dst_len, "precondition: src and dst buffers must have the same length");
 	if (src_len == 0) return BN_OK;
 	ctx->mirror.valid = false;
@@ -446,6 +459,7 @@ int bn_copy_d2d(bn_ctx *ctx, const void *d_src, uint64_t src_len, void *d_dst, u
 int bn_fill(bn_ctx *ctx, void *d_dst, uint64_t n, const bn_f128 *value)
 {
 	BN_REQUIRE(ctx && value, "null argument");
+	BN_ENTER(ctx);
 	BN_FLUSH(ctx);
 	BN_HIP(bn::launch_fill(ctx->stream, d_dst, n, to_f(value)));
 	return BN_OK;
@@ -455,6 +469,7 @@ int bn_fill(bn_ctx *ctx, void *d_dst, uint64_t n, const bn_f128 *value)
 int bn_expr_compile(bn_ctx *ctx, const bn_step *steps, uint64_t n_steps, bn_expr **out)
 {
 	BN_REQUIRE(ctx && out, "null argument");
+	BN_ENTER(ctx);
 	BN_REQUIRE(n_steps == 0 || steps, "null steps");
 	bn_expr *e = new bn_expr();
 	e->device = ctx->device;
@@ -536,6 +551,7 @@ int bn_expr_n_vars(const bn_expr *expr, uint32_t *n_vars)
 int bn_extrapolate_line(bn_ctx *ctx, void *d_evals_0, uint64_t n0, const void *d_evals_1, uint64_t n1, const bn_f128 *z)
 {
 	BN_REQUIRE(ctx && z, "null argument");
+	BN_ENTER(ctx);
 	BN_FLUSH(ctx);
 	BN_REQUIRE(n0 == n1, "evals_0 and evals_1 must be the same length");
 	prof_scope ps(ctx, BN_PROF_FOLD);
@@ -547,6 +563,7 @@ int bn_extrapolate_line_batch(bn_ctx *ctx, void *const *d_evals_0, const void *c
                               const bn_f128 *z)
 {
 	BN_REQUIRE(ctx && z && d_evals_0 && d_evals_1, "null argument");
+	BN_ENTER(ctx);
 	BN_REQUIRE(count <= (uint32_t)bn::kFoldBatchMax, "too many slices in one extrapolate_line batch");
 	if (count == 0) return BN_OK;
 	ctx->mirror.valid = false;
@@ -600,6 +617,7 @@ int bn_extrapolate_line_batch(bn_ctx *ctx, void *const *d_evals_0, const void *c
 int bn_tensor_expand(bn_ctx *ctx, void *d_data, uint64_t data_len, uint32_t log_n, const bn_f128 *h_coords, uint32_t k)
 {
 	BN_REQUIRE(ctx, "null ctx");
+	BN_ENTER(ctx);
 	BN_FLUSH(ctx);
 	BN_REQUIRE(log_n + k < 64 && data_len == ((uint64_t)1 << (log_n + k)), "invalid data length");
 	prof_scope ps(ctx, BN_PROF_TENSOR_EXPAND);
@@ -620,6 +638,7 @@ int bn_inner_product(bn_ctx *ctx, const void *d_a, uint64_t a_len, uint32_t towe
                      bn_f128 *h_out)
 {
 	BN_REQUIRE(ctx && h_out, "null argument");
+	BN_ENTER(ctx);
 	BN_FLUSH(ctx);
 	BN_REQUIRE(tower_level <= 7 && (a_len << (7 - tower_level)) == b_len, "invalid input: inner_product lengths");
 	BN_REQUIRE(valid_tower_level(tower_level), "unsupported value of tower_level");
@@ -643,6 +662,7 @@ static int fold_common(bn_ctx *ctx, bool left, const void *d_mat, uint64_t mat_l
                        uint64_t vec_len, void *d_out, uint64_t out_len)
 {
 	BN_REQUIRE(ctx, "null ctx");
+	BN_ENTER(ctx);
 	BN_FLUSH(ctx);
 	BN_REQUIRE(tower_level <= 7, "invalid evals: tower_level > 7");
 	BN_REQUIRE(valid_tower_level(tower_level), "unsupported value of tower_level");
@@ -688,6 +708,7 @@ int bn_fri_fold(bn_ctx *ctx, const uint64_t *h_s_evals, uint32_t tw_level, uint3
                 void *d_out, uint64_t out_len)
 {
 	BN_REQUIRE(ctx && h_s_evals, "null argument");
+	BN_ENTER(ctx);
 	BN_FLUSH(ctx);
 	BN_REQUIRE(log_len + log_batch_size < 64 && in_len == ((uint64_t)1 << (log_len + log_batch_size)), "invalid data_in length");
 	BN_REQUIRE(n_challenges >= log_batch_size, "invalid challenges length");
@@ -726,6 +747,7 @@ int bn_compute_composite(bn_ctx *ctx, const void *const *d_rows, uint32_t n_rows
                          uint64_t out_len, const bn_expr *expr)
 {
 	BN_REQUIRE(ctx && expr, "null argument");
+	BN_ENTER(ctx);
 	BN_FLUSH(ctx);
 	BN_REQUIRE(row_len == out_len, "inputs and output must be the same length");
 	BN_REQUIRE(expr->n_vars == n_rows || (expr->n_vars <= n_rows), "composition not match with input");
@@ -749,6 +771,7 @@ int bn_pairwise_product_reduce(bn_ctx *ctx, const void *d_in, uint64_t n, void *
                                uint32_t n_rounds)
 {
 	BN_REQUIRE(ctx, "null ctx");
+	BN_ENTER(ctx);
 	BN_FLUSH(ctx);
 	BN_REQUIRE(is_pow2(n), "input length must be a power of 2");
 	BN_REQUIRE(n >= 2, "input length must be greater than or equal to 2 in order to perform at least one reduction");
@@ -814,6 +837,7 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
                      const uint32_t *ret_values, uint32_t n_ret, uint32_t log_chunks, bn_f128 *h_out, void *d_out)
 {
 	BN_REQUIRE(ctx && maps && n_maps > 0, "kernel launch needs at least one mapping");
+	BN_ENTER(ctx);
 	uint32_t lo_c, hi_c;
 	int rc = bn_log_chunks_range(maps, n_maps, &lo_c, &hi_c);
 	if (rc) return rc;
@@ -1295,6 +1319,7 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 int bn_xor_reduce(bn_ctx *ctx, const void *d_vals, uint32_t n_groups, uint32_t group_len, bn_f128 *h_out)
 {
 	BN_REQUIRE(ctx && d_vals && h_out, "null argument");
+	BN_ENTER(ctx);
 	BN_FLUSH(ctx);
 	BN_REQUIRE(group_len >= 1 && group_len <= 64 && n_groups >= 1, "xor_reduce: group_len must be in 1..64");
 	const uint64_t seq = ++ctx->mail_seq;
@@ -1347,6 +1372,7 @@ static int ntt_common(bn_ctx *ctx, bool inverse, void *d_data, uint32_t elem_lev
                       uint64_t coset, uint32_t coset_bits, uint32_t skip_rounds)
 {
 	BN_REQUIRE(ctx && h_s_evals, "null argument");
+	BN_ENTER(ctx);
 	BN_FLUSH(ctx);
 	BN_REQUIRE(elem_level >= 3 && elem_level <= 7, "unsupported element field");
 	BN_REQUIRE(tw_level >= 3 && tw_level <= 6 && tw_level <= elem_level, "unsupported twiddle field");

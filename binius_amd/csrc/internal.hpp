@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "../../include/binius_amd.h"
@@ -21,6 +22,7 @@ struct bn_expr {
 };
 
 struct bn_ctx {
+	std::recursive_mutex mu; // serialises the entry points of this context
 	int device = 0;
 	hipStream_t stream = nullptr;
 	bool own_stream = false;

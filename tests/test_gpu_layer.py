@@ -448,3 +448,37 @@ def test_fri_fold_validation(hal, oracle):
         hal.fri_fold(s, 5, 10, 4, 2, [1], alloc.alloc(1 << 6), alloc.alloc(1 << 4))  # too few challenges
     with pytest.raises(binius_amd.BnError):
         hal.fri_fold(s, 5, 10, 4, 0, [1, 2], alloc.alloc(1 << 4), alloc.alloc(1 << 3))  # bad out len
+
+
+def test_context_is_safe_to_call_from_several_threads(hal, oracle):
+    """The trait lets the host call a layer from several threads (rayon join/map); entry points of
+    one context are serialised by the library."""
+    import threading
+
+    alloc = hal.dev_alloc()
+    n = 1 << 12
+    jobs = []
+    for t in range(8):
+        e0, e1 = rnd(oracle, 900 + t, n), rnd(oracle, 950 + t, n)
+        z = oracle.random_scalars(970 + t, 1)[0]
+        jobs.append((upload(hal, alloc, e0), upload(hal, alloc, e1), e0, e1, z))
+    errs = []
+
+    def work(job):
+        d0, d1, e0, e1, z = job
+        try:
+            for _ in range(5):
+                hal.extrapolate_line(d0, d1, z)
+                exp = e0
+                oracle.extrapolate_line(exp, e1, z)
+                if not np.array_equal(hal.copy_d2h(d0), exp):
+                    errs.append("mismatch")
+        except Exception as ex:  # noqa: BLE001
+            errs.append(repr(ex))
+
+    ts = [threading.Thread(target=work, args=(j,)) for j in jobs]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs
