@@ -148,3 +148,121 @@ class BivariateSumcheckProver:
             h = self.hal.copy_d2h(ml)
             out.append(int(h[0, 0]) | (int(h[0, 1]) << 64))
         return out
+
+
+def bivariate_product_eq_expr(hal, i, j, m):
+    """IndexComposition<BivariateProduct, 2>::expression() * var(m) -- the eq indicator is the last
+    composition variable (v3/bivariate_mlecheck.rs:399-407)."""
+    return hal.compile_expr([("var", i), ("var", j), ("mul", 0, 1), ("var", m), ("mul", 2, 3)])
+
+
+class BivariateMLEcheckProver:
+    """BivariateMLEcheckProver (v3/bivariate_mlecheck.rs:27-372): eq-indicator sumcheck for bivariate
+    products, High-to-Low.  eq_ind_partial_evals is the tensor expansion of
+    eq_ind_challenges[0 .. n_vars-1) (2^(n_vars-1) elements)."""
+
+    def __init__(self, hal, dev_alloc, n_vars, multilins, composition_indices, sums, eq_ind_partial_evals, eq_ind_challenges,
+                 field=HostField):
+        for ml in multilins:
+            if ml.len != 1 << n_vars:
+                raise BnError(BN_ERR_INPUT_VALIDATION, "NumberOfVariablesMismatch")
+        if eq_ind_partial_evals.len != 1 << max(n_vars - 1, 0):
+            raise BnError(BN_ERR_INPUT_VALIDATION, "IncorrectEqIndPartialEvalsSize")
+        self.hal, self.dev_alloc, self.field = hal, dev_alloc, field
+        self.n_vars_initial = self.n_vars_remaining = n_vars
+        self.multilins = [("pre", ml) for ml in multilins]
+        m = len(multilins)
+        self.compositions = [bivariate_product_eq_expr(hal, i, j, m) for (i, j) in composition_indices]
+        self.state = ("initial_sums", list(sums))
+        self.eq_ind_prefix_eval = 1
+        self.eq_ind = ("pre", eq_ind_partial_evals)
+        self.eq_ind_challenges = list(eq_ind_challenges)
+
+    def _evaluate_univariate(self, coeffs, x):
+        e = 0
+        for c in reversed(coeffs):
+            e = self.field.mul(e, x) ^ c
+        return e
+
+    def execute(self, batch_coeff):
+        f = self.field
+        coeffs, p = [], 1
+        for _ in self.compositions:
+            coeffs.append(p)
+            p = f.mul(p, batch_coeff)
+        y_1, y_inf = calculate_round_evals(
+            self.hal, self.n_vars_remaining, coeffs, [ml for _, ml in self.multilins], self.compositions, eq_ind=self.eq_ind[1]
+        )
+        kind, val = self.state
+        if kind == "coeffs":
+            raise RuntimeError("ExpectedFold")
+        batched_sum = self._evaluate_univariate(val, batch_coeff) if kind == "initial_sums" else val
+        alpha = self.eq_ind_challenges[self.n_vars_remaining - 1]
+        # calculate_round_coeffs_from_evals (:375-389)
+        y_0 = f.mul(batched_sum ^ f.mul(y_1, alpha), f.invert(1 ^ alpha))
+        prime = [y_0, y_1 ^ y_0 ^ y_inf, y_inf]
+        self.state = ("coeffs", prime)
+        # v(X) = v'(X) * ((1 - alpha) + (2 alpha - 1) X) * prefix; 2 alpha = 0 in characteristic 2 (:303-313)
+        k0 = 1 ^ alpha
+        out = []
+        for d in range(4):
+            v = 0
+            if d < 3:
+                v ^= f.mul(prime[d], k0)
+            if d >= 1:
+                v ^= prime[d - 1]
+            out.append(f.mul(v, self.eq_ind_prefix_eval))
+        return out
+
+    def fold(self, challenge):
+        if self.n_vars_remaining == 0:
+            raise RuntimeError("ExpectedFinish")
+        kind, val = self.state
+        if kind != "coeffs":
+            raise RuntimeError("ExpectedExecution")
+        self.state = ("batched_sum", self._evaluate_univariate(val, challenge))
+        # eq(alpha, z) = alpha + z + 1 in characteristic 2 (field/src/util.rs:74-81)
+        alpha = self.eq_ind_challenges[self.n_vars_remaining - 1]
+        self.eq_ind_prefix_eval = self.field.mul(self.eq_ind_prefix_eval, alpha ^ challenge ^ 1)
+        # fold_multilinears (:145-193): one map scope = one fold batch
+        e0s, e1s = [], []
+        for kind, evals in self.multilins:
+            evals_0, evals_1 = evals.split_half()
+            if kind == "pre":
+                folded = self.dev_alloc.alloc(1 << (self.n_vars_remaining - 1))
+                self.hal.copy_d2d(evals_0, folded)
+                evals_0 = folded
+            e0s.append(evals_0)
+            e1s.append(evals_1)
+        self.hal.extrapolate_line_batch(e0s, e1s, challenge)
+        self.multilins = [("post", e) for e in e0s]
+        if self.n_vars_remaining - 1 != 0:
+            # fold_eq_ind (:195-254): map_kernels { add_assign(evals_1 -> evals_0) }
+            kind, evals = self.eq_ind
+            evals_0, evals_1 = evals.split_half()
+            if kind == "pre":
+                buf = self.dev_alloc.alloc(evals_0.len)
+                self.hal.copy_d2d(evals_0, buf)
+                evals_0 = buf
+            split_n_vars = self.n_vars_remaining - 2
+
+            def kernel(local_exec, log_chunks, buffers):
+                local_exec.add_assign(split_n_vars - log_chunks, buffers[1], buffers[0])
+
+            self.hal.map_kernels(kernel, [("chunked_mut", evals_0, 0), ("chunked", evals_1, 0)])
+            self.eq_ind = ("post", evals_0)
+        self.n_vars_remaining -= 1
+
+    def finish(self):
+        kind, _ = self.state
+        if kind == "coeffs":
+            raise RuntimeError("ExpectedFold")
+        if self.n_vars_remaining != 0:
+            raise RuntimeError("ExpectedExecution")
+        out = []
+        for _, ml in self.multilins:
+            h = self.hal.copy_d2h(ml)
+            out.append(int(h[0, 0]) | (int(h[0, 1]) << 64))
+        out.append(self.eq_ind_prefix_eval)
+        return out
+

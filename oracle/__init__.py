@@ -173,6 +173,14 @@ def lib():
             C.POINTER(C.POINTER(B128)), C.c_size_t, C.c_uint, C.POINTER(C.c_uint32), C.c_size_t,
             C.POINTER(B128), B128, C.POINTER(B128), C.POINTER(B128), C.POINTER(B128), C.c_int,
         ]
+        L.ref_round_evals_eq.argtypes = [
+            C.POINTER(C.POINTER(B128)), C.c_size_t, C.c_uint, C.POINTER(B128), C.POINTER(C.c_uint32), C.c_size_t, B128,
+            C.POINTER(B128),
+        ]
+        L.ref_bivariate_mlecheck_prove.argtypes = [
+            C.POINTER(C.POINTER(B128)), C.c_size_t, C.c_uint, C.POINTER(B128), C.POINTER(B128), C.POINTER(C.c_uint32),
+            C.c_size_t, C.POINTER(B128), B128, C.POINTER(B128), C.POINTER(B128), C.POINTER(B128),
+        ]
         L.ref_mle_evaluate.restype = B128
         L.ref_mle_evaluate.argtypes = [C.POINTER(B128), C.c_uint, C.POINTER(B128)]
         L.ref_evaluate_univariate.restype = B128
@@ -452,6 +460,35 @@ def bivariate_sumcheck_prove(multilins, n_vars, comps, sums, batch_coeff, challe
     assert rc == 0
     co = arr_to_ints(rc_out)
     return [co[3 * r : 3 * r + 3] for r in range(n_vars)], arr_to_ints(fe)
+
+
+def round_evals_eq(multilins, n_vars, eq_ind, comps, batch_coeff):
+    """MLE-check round evaluations (v3/bivariate_mlecheck.rs:391-520): compositions a*b*eq_ind."""
+    ptrs = (C.POINTER(B128) * len(multilins))(*[_p(a) for a in multilins])
+    flat = [i for pair in comps for i in pair]
+    cc = (C.c_uint32 * max(1, len(flat)))(*flat)
+    out = arr(2)
+    rc = lib().ref_round_evals_eq(ptrs, len(multilins), n_vars, _p(eq_ind), cc, len(comps), to_b128(batch_coeff), _p(out))
+    return rc, arr_to_ints(out)
+
+
+def bivariate_mlecheck_prove(multilins, n_vars, eq_ind, eq_ind_challenges, comps, sums, batch_coeff, challenges):
+    """multilins and eq_ind (arrays) are folded in place.  Returns (round_coeffs[n_vars][4],
+    final_evals[m + 1]) -- the last final value is eq_ind_prefix_eval."""
+    ptrs = (C.POINTER(B128) * len(multilins))(*[_p(a) for a in multilins])
+    flat = [i for pair in comps for i in pair]
+    cc = (C.c_uint32 * max(1, len(flat)))(*flat)
+    s = ints_to_arr(list(sums)) if len(sums) else arr(1)
+    ch = ints_to_arr(list(challenges))
+    eqc = ints_to_arr(list(eq_ind_challenges))
+    rc_out = arr(4 * n_vars)
+    fe = arr(len(multilins) + 1)
+    rc = lib().ref_bivariate_mlecheck_prove(
+        ptrs, len(multilins), n_vars, _p(eq_ind), _p(eqc), cc, len(comps), _p(s), to_b128(batch_coeff), _p(ch), _p(rc_out), _p(fe)
+    )
+    assert rc == 0
+    co = arr_to_ints(rc_out)
+    return [co[4 * r : 4 * r + 4] for r in range(n_vars)], arr_to_ints(fe)
 
 
 def mle_evaluate(evals, n_vars, point):

@@ -199,3 +199,84 @@ int ref_bivariate_sumcheck_prove(ref_b128 *const *multilins, size_t m, unsigned 
 		final_evals_out[j] = multilins[j][0];
 	return 0;
 }
+
+/* ---- MLE-check prover (v3/bivariate_mlecheck.rs) ------------------------------------------- */
+
+/* calculate_round_evals (:391-520): compositions are  multilin_i * multilin_j * eq_ind  where the
+ * eq indicator chunk is the same for the evaluation at 1 and at infinity */
+int ref_round_evals_eq(const ref_b128 *const *multilins, size_t m, unsigned n_vars, const ref_b128 *eq_ind,
+                       const uint32_t *comps, size_t n_comps, ref_b128 batch_coeff, ref_b128 out[2])
+{
+	if (n_vars < 1) return 1;
+	const size_t half = (size_t)1 << (n_vars - 1);
+	ref_b128 acc1 = ref_b128_zero(), accinf = ref_b128_zero();
+	ref_b128 coeff = ref_b128_one();
+	for (size_t c = 0; c < n_comps; c++) {
+		const uint32_t i = comps[2 * c], j = comps[2 * c + 1];
+		if (i >= m || j >= m) return 1;
+		const ref_b128 *a = multilins[i], *b = multilins[j];
+		ref_b128 s1 = ref_b128_zero(), sinf = ref_b128_zero();
+		for (size_t k = 0; k < half; k++) {
+			ref_b128 p1 = ref_b128_mul(ref_b128_mul(a[half + k], b[half + k]), eq_ind[k]);
+			ref_b128 pinf = ref_b128_mul(ref_b128_mul(ref_b128_add(a[k], a[half + k]), ref_b128_add(b[k], b[half + k])), eq_ind[k]);
+			s1 = ref_b128_add(s1, p1);
+			sinf = ref_b128_add(sinf, pinf);
+		}
+		acc1 = ref_b128_add(acc1, ref_b128_mul(s1, coeff));     /* *accumulator += ret * batch_coeff (cpu/layer.rs:512) */
+		accinf = ref_b128_add(accinf, ref_b128_mul(sinf, coeff));
+		coeff = ref_b128_mul(coeff, batch_coeff);                /* powers(batch_coeff) */
+	}
+	out[0] = acc1;
+	out[1] = accinf;
+	return 0;
+}
+
+int ref_bivariate_mlecheck_prove(ref_b128 *const *multilins, size_t m, unsigned n_vars, ref_b128 *eq_ind,
+                                 const ref_b128 *eq_ind_challenges, const uint32_t *comps, size_t n_comps,
+                                 const ref_b128 *sums, ref_b128 batch_coeff, const ref_b128 *challenges,
+                                 ref_b128 *round_coeffs_out, ref_b128 *final_evals_out)
+{
+	const ref_b128 one = ref_b128_one();
+	ref_b128 batched_sum = ref_evaluate_univariate(sums, n_comps, batch_coeff); /* InitialSums (:291) */
+	ref_b128 prefix = one;                                                       /* eq_ind_prefix_eval */
+	for (unsigned round = 0; round < n_vars; round++) {
+		const unsigned rem = n_vars - round;
+		ref_b128 ev[2];
+		if (ref_round_evals_eq((const ref_b128 *const *)multilins, m, rem, eq_ind, comps, n_comps, batch_coeff, ev)) return 1;
+		const ref_b128 alpha = eq_ind_challenges[rem - 1];
+		/* calculate_round_coeffs_from_evals (:375-389): y_0 = (sum - y_1 alpha) / (1 - alpha) */
+		const ref_b128 y1 = ev[0], yinf = ev[1];
+		const ref_b128 y0 = ref_b128_mul(ref_b128_add(batched_sum, ref_b128_mul(y1, alpha)), ref_b128_invert(ref_b128_add(one, alpha)));
+		ref_b128 prime[3];
+		prime[0] = y0;
+		prime[2] = yinf;
+		prime[1] = ref_b128_add(ref_b128_add(y1, prime[0]), prime[2]);
+		/* v(X) = v'(X) * eq(X, alpha) * prefix, eq(X, alpha) = (1 - alpha) + (2 alpha - 1) X; in
+		 * characteristic 2: alpha.double() = 0, so the linear term is  -1 = 1   (:303-313) */
+		const ref_b128 k0 = ref_b128_add(one, alpha), k1 = one;
+		ref_b128 *rc = &round_coeffs_out[4 * round];
+		for (int d = 0; d < 4; d++) {
+			ref_b128 v = ref_b128_zero();
+			if (d < 3) v = ref_b128_add(v, ref_b128_mul(prime[d], k0));
+			if (d >= 1) v = ref_b128_add(v, ref_b128_mul(prime[d - 1], k1));
+			rc[d] = ref_b128_mul(v, prefix);
+		}
+		/* fold (:320-346): the stored state is the PRIME polynomial (last_coeffs_or_sums = Coeffs(prime)) */
+		const ref_b128 z = challenges[round];
+		batched_sum = ref_evaluate_univariate(prime, 3, z);
+		prefix = ref_b128_mul(prefix, ref_b128_add(ref_b128_add(alpha, z), one)); /* eq(alpha, z) = alpha + z + 1 */
+		for (size_t j = 0; j < m; j++)
+			ref_fold_high(multilins[j], rem, z, 1);
+		if (rem - 1 != 0) {
+			/* fold_eq_ind (:195-254): evals_0[i] += evals_1[i] over the halves of the 2^(rem-1) table */
+			const size_t h = (size_t)1 << (rem - 2);
+			for (size_t i = 0; i < h; i++)
+				eq_ind[i] = ref_b128_add(eq_ind[i], eq_ind[h + i]);
+		}
+	}
+	for (size_t j = 0; j < m; j++)
+		final_evals_out[j] = multilins[j][0];
+	final_evals_out[m] = prefix;
+	return 0;
+}
+

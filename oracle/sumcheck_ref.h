@@ -38,6 +38,24 @@ int ref_bivariate_sumcheck_prove(ref_b128 *const *multilins, size_t m, unsigned 
                                  const ref_b128 *challenges, ref_b128 *round_coeffs_out,
                                  ref_b128 *final_evals_out, int threads);
 
+/* MLE-check (eq-indicator sumcheck) prover for bivariate products,
+ * crates/core/src/protocols/sumcheck/v3/bivariate_mlecheck.rs:
+ *   calculate_round_evals with the eq indicator as last composition variable   :391-520
+ *   calculate_round_coeffs_from_evals (y_0 from the sum, alpha)               :375-389
+ *   execute: prime polynomial -> round polynomial, times eq_ind_prefix_eval   :273-318
+ *   fold: prefix eval *= eq(alpha_r, challenge), multilinears folded, eq indicator halved by
+ *   add_assign of its halves                                                   :120-123,145-254,320-346
+ *   finish: final evaluations + eq_ind_prefix_eval                             :348-372
+ * multilins (2^n_vars each) and eq_ind (2^(n_vars-1), the tensor expansion of
+ * eq_ind_challenges[0..n_vars-1)) are MODIFIED.  round_coeffs_out[4*n_vars] (degree-3 round
+ * polynomials c0..c3), final_evals_out[m+1] (last = eq_ind_prefix_eval). */
+int ref_round_evals_eq(const ref_b128 *const *multilins, size_t m, unsigned n_vars, const ref_b128 *eq_ind,
+                       const uint32_t *comps, size_t n_comps, ref_b128 batch_coeff, ref_b128 out[2]);
+int ref_bivariate_mlecheck_prove(ref_b128 *const *multilins, size_t m, unsigned n_vars, ref_b128 *eq_ind,
+                                 const ref_b128 *eq_ind_challenges, const uint32_t *comps, size_t n_comps,
+                                 const ref_b128 *sums, ref_b128 batch_coeff, const ref_b128 *challenges,
+                                 ref_b128 *round_coeffs_out, ref_b128 *final_evals_out);
+
 /* Evaluate the multilinear extension of evals (2^n_vars) at point (low variable first) --
  * crates/math/src/multilinear_extension.rs:163 via tensor expansion + inner product. */
 ref_b128 ref_mle_evaluate(const ref_b128 *evals, unsigned n_vars, const ref_b128 *point);

@@ -363,3 +363,38 @@ def test_tiny_fold_results_are_mirrored_to_the_host(hal, oracle):
                     assert np.array_equal(hal.copy_d2h(dd), x)
                     assert np.array_equal(hal.copy_d2h(dd.slice(len(x) - 1, len(x))), x[-1:])
             r += 1
+
+
+@pytest.mark.parametrize("n_vars,m,comps", [(1, 2, [(0, 1)]), (2, 2, [(0, 1)]), (8, 8, [(0, 1), (2, 5), (7, 7), (3, 4)]), (13, 3, [(0, 1), (2, 0)])])
+def test_bivariate_mlecheck_prove(hal, oracle, n_vars, m, comps):
+    """generic_test_bivariate_mlecheck_prove_verify (compute_test_utils bivariate_sumcheck.rs:313-458):
+    the MLE-check prover over the HIP backend -- round polynomials (degree 3) and final values
+    bit-exact against the oracle's restatement of v3/bivariate_mlecheck.rs."""
+    from binius_amd.sumcheck import BivariateMLEcheckProver, eq_ind_partial_eval
+
+    alloc = hal.dev_alloc()
+    mls = [oracle.random_b128(0x3C3C00 + j, 1 << n_vars) for j in range(m)]
+    eq_ch = oracle.random_scalars(0x3C3C00 ^ 0xE9, n_vars)
+    full = oracle.arr(1 << n_vars)
+    full[0] = (1, 0)
+    oracle.tensor_expand(full, 0, eq_ch)
+    sums = []
+    for i, j in comps:
+        p = oracle.mul_vec(oracle.mul_vec(mls[i], mls[j]), full)
+        sums.append(int(np.bitwise_xor.reduce(p[:, 0])) | (int(np.bitwise_xor.reduce(p[:, 1])) << 64))
+    d = [upload(hal, alloc, x) for x in mls]
+    eq_dev = eq_ind_partial_eval(hal, alloc, eq_ch[: n_vars - 1])
+    eq_host = hal.copy_d2h(eq_dev)
+    stream = oracle.random_scalars(0xC4A2, n_vars + 1)
+    bc, ch = stream[0], stream[1:]
+    prover = BivariateMLEcheckProver(hal, alloc, n_vars, d, comps, sums, eq_dev, eq_ch)
+    got = []
+    for r in range(n_vars):
+        got.append(prover.execute(bc))
+        prover.fold(ch[r])
+    finals = prover.finish()
+    want_coeffs, want_finals = oracle.bivariate_mlecheck_prove([x.copy() for x in mls], n_vars, eq_host.copy(), eq_ch, comps, sums, bc, ch)
+    assert got == want_coeffs
+    assert finals == want_finals
+    for j in range(m):  # PreFold inputs are never modified
+        assert np.array_equal(hal.copy_d2h(d[j]), mls[j])

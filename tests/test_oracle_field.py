@@ -6,6 +6,7 @@ import json
 import os
 import random
 
+import numpy as np
 import pytest
 
 KATS = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "field_kats.json")))
@@ -180,3 +181,51 @@ def test_small_levels_consistent(oracle):
                 assert oracle.gf_mul(a, oracle.gf_invert(a, lvl), lvl) == 1
             # mul_alpha_k == multiplication by X_{k-1} = 1 << 2^(k-1)
             assert oracle.gf_mul_alpha(a, lvl) == oracle.gf_mul(a, 1 << (bits // 2), lvl)
+
+
+def _mlecheck_instance(oracle, n_vars, m, comps, seed):
+    mls = [oracle.random_b128(seed + j, 1 << n_vars) for j in range(m)]
+    eq_ch = oracle.random_scalars(seed ^ 0xE9, n_vars)
+    # eq indicator over all n variables (claims) and over the first n-1 (the prover's table)
+    full = oracle.arr(1 << n_vars)
+    full[0] = (1, 0)
+    oracle.tensor_expand(full, 0, eq_ch)
+    sums = []
+    for i, j in comps:
+        p = oracle.mul_vec(oracle.mul_vec(mls[i], mls[j]), full)
+        sums.append(int(np.bitwise_xor.reduce(p[:, 0])) | (int(np.bitwise_xor.reduce(p[:, 1])) << 64))
+    eq = oracle.arr(1 << max(n_vars - 1, 0))
+    eq[0] = (1, 0)
+    oracle.tensor_expand(eq, 0, eq_ch[: max(n_vars - 1, 0)])
+    return mls, eq_ch, eq, sums
+
+
+@pytest.mark.parametrize("n_vars,m,comps", [(1, 2, [(0, 1)]), (4, 2, [(0, 1)]), (8, 4, [(0, 1), (2, 3), (1, 1)])])
+def test_oracle_mlecheck_prover_verifies(oracle, n_vars, m, comps):
+    """The oracle's restatement of BivariateMLEcheckProver (v3/bivariate_mlecheck.rs) passes the
+    checks the reference's own test applies (compute_test_utils bivariate_sumcheck.rs:313-458):
+    every round polynomial sums to the running claim, and the final values are the MLE evaluations
+    at the (reversed) challenges with prod * eq == last claim."""
+    mls, eq_ch, eq, sums = _mlecheck_instance(oracle, n_vars, m, comps, 0x3C3C00)
+    stream = oracle.random_scalars(0xC4A2, n_vars + 1)
+    bc, ch = stream[0], stream[1:]
+    coeffs, finals = oracle.bivariate_mlecheck_prove([x.copy() for x in mls], n_vars, eq.copy(), eq_ch, comps, sums, bc, ch)
+    running = oracle.evaluate_univariate(sums, bc)
+    for r, c in enumerate(coeffs):
+        p0, p1 = c[0], c[0] ^ c[1] ^ c[2] ^ c[3]
+        assert p0 ^ p1 == running, f"round {r}"
+        running = oracle.evaluate_univariate(c, ch[r])
+    point = list(reversed(ch))  # High-to-Low binding
+    for x, f in zip(mls, finals[:m]):
+        assert oracle.mle_evaluate(x, n_vars, point) == f
+    # eq_ind_prefix_eval = eq(eq_ch, point) = prod (a_i + z_i + 1)
+    want_eq = 1
+    for a, z in zip(eq_ch, point):
+        want_eq = oracle.mul(want_eq, a ^ z ^ 1)
+    assert finals[m] == want_eq
+    comp = 0
+    p = 1
+    for i, j in comps:
+        comp ^= oracle.mul(p, oracle.mul(finals[i], finals[j]))
+        p = oracle.mul(p, bc)
+    assert oracle.mul(comp, finals[m]) == running
