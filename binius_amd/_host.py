@@ -27,6 +27,11 @@ def host_lib():
             C.POINTER(C.c_uint32), C.POINTER(F128), C.POINTER(F128), C.POINTER(F128), C.POINTER(F128), C.POINTER(F128),
             REDUCE_FN, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
         ]
+        L.bnh_bivariate_mlecheck_prove.restype = C.c_int
+        L.bnh_bivariate_mlecheck_prove.argtypes = [
+            C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p), C.c_void_p, C.POINTER(F128), C.c_void_p, C.c_uint64,
+            C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(F128), C.POINTER(F128), C.POINTER(F128), C.POINTER(F128), C.POINTER(F128),
+        ]
         L.bnh_rccl_open.argtypes = [C.c_char_p]
         L.bnh_rccl_unique_id.argtypes = [C.c_void_p]
         L.bnh_rccl_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
@@ -71,6 +76,38 @@ class SumcheckPlan:
 
     def final_evals(self):
         return [from_f128(self.final[j]) for j in range(self.m)]
+
+
+class MlecheckPlan:
+    """One BivariateMLEcheckProver run of the compiled host mirror (bnh_bivariate_mlecheck_prove)."""
+
+    def __init__(self, hal, n_vars, multilins, eq_ind, eq_ind_challenges, scratch, comps, sums, batch_coeff, challenges):
+        self.hal, self.n_vars, self.m = hal, n_vars, len(multilins)
+        self.ptrs = (C.c_void_p * self.m)(*[s.ptr for s in multilins])
+        self.eq_ind, self.scratch = eq_ind, scratch
+        self.eqc = _f128_array(list(eq_ind_challenges))
+        flat = [i for pair in comps for i in pair]
+        self.n_comps = len(comps)
+        self.comps = (C.c_uint32 * max(1, len(flat)))(*flat)
+        self.sums = _f128_array(list(sums))
+        self.bc = to_f128(batch_coeff)
+        self.ch = _f128_array(list(challenges))
+        self.coeffs = (F128 * (4 * n_vars))()
+        self.final = (F128 * (self.m + 1))()
+
+    def run(self):
+        rc = host_lib().bnh_bivariate_mlecheck_prove(
+            self.hal._h, self.n_vars, self.m, self.ptrs, self.eq_ind.ptr, self.eqc, self.scratch.ptr, self.scratch.len,
+            self.n_comps, self.comps, self.sums, C.byref(self.bc), self.ch, self.coeffs, self.final,
+        )
+        if rc != 0:
+            raise BnError(rc, host_lib().bnh_last_error().decode())
+
+    def round_coeffs(self):
+        return [[from_f128(self.coeffs[4 * r + i]) for i in range(4)] for r in range(self.n_vars)]
+
+    def final_evals(self):
+        return [from_f128(self.final[j]) for j in range(self.m + 1)]
 
 
 class RcclComm:

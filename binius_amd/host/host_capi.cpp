@@ -220,4 +220,47 @@ int bnh_bivariate_sumcheck_prove(bn_ctx *ctx, uint32_t n_vars, uint32_t m, const
 	}
 }
 
+// One complete BivariateMLEcheckProver run (v3/bivariate_mlecheck.rs) behind a C call.
+//   d_eq_ind             2^(n_vars-1) elements: tensor expansion of eq_ind_challenges[0 .. n_vars-1)
+//   round_coeffs_out     [4 * n_vars] (degree-3 round polynomials)
+//   final_evals_out      [m + 1]      (the last one is eq_ind_prefix_eval)
+int bnh_bivariate_mlecheck_prove(bn_ctx *ctx, uint32_t n_vars, uint32_t m, const void *const *d_multilins, const void *d_eq_ind,
+                                 const bn_f128 *eq_ind_challenges, void *d_scratch, uint64_t scratch_elems, uint32_t n_comps,
+                                 const uint32_t *comp_indices, const bn_f128 *sums, const bn_f128 *batch_coeff,
+                                 const bn_f128 *challenges, bn_f128 *round_coeffs_out, bn_f128 *final_evals_out)
+{
+	try {
+		ComputeLayer hal(ctx);
+		DeviceBumpAllocator dev_alloc(FSliceMut{d_scratch, (size_t)scratch_elems});
+		std::vector<B128> host_mem(m + 4);
+		HostBumpAllocator host_alloc(HostSliceMut{host_mem.data(), host_mem.size()});
+		std::vector<FSlice> mls;
+		for (uint32_t j = 0; j < m; j++) mls.push_back(FSlice{d_multilins[j], (size_t)1 << n_vars});
+		std::vector<IndexCompositionBivariate> comps;
+		std::vector<B128> sv, eqc;
+		for (uint32_t c = 0; c < n_comps; c++) {
+			comps.push_back(IndexCompositionBivariate{m, {comp_indices[2 * c], comp_indices[2 * c + 1]}});
+			sv.emplace_back(sums[c].lo, sums[c].hi);
+		}
+		for (uint32_t i = 0; i < n_vars; i++) eqc.emplace_back(eq_ind_challenges[i].lo, eq_ind_challenges[i].hi);
+		const B128 bc(batch_coeff->lo, batch_coeff->hi);
+		BivariateMLEcheckProver prover(hal, dev_alloc, host_alloc, n_vars, comps, sv, mls,
+		                               FSlice{d_eq_ind, (size_t)1 << (n_vars ? n_vars - 1 : 0)}, eqc);
+		for (uint32_t r = 0; r < n_vars; r++) {
+			std::vector<B128> rc = prover.execute(bc);
+			for (size_t i = 0; i < 4 && i < rc.size(); i++) round_coeffs_out[4 * r + i] = rc[i].raw();
+			prover.fold(B128(challenges[r].lo, challenges[r].hi));
+		}
+		std::vector<B128> fin = prover.finish();
+		for (uint32_t j = 0; j <= m; j++) final_evals_out[j] = fin[j].raw();
+		return 0;
+	} catch (const Error &e) {
+		g_err = e.what();
+		return (int)e.kind();
+	} catch (const std::exception &e) {
+		g_err = e.what();
+		return BN_ERR_CORE_LIB;
+	}
+}
+
 } // extern "C"

@@ -6,6 +6,7 @@
 //   (with eq_ind)                  crates/core/src/protocols/sumcheck/v3/bivariate_mlecheck.rs:391-520
 //   round coeffs from evals        v3/bivariate_product.rs:410-424
 //   BivariateSumcheckProver        v3/bivariate_product.rs:27-254  (execute / fold / finish)
+//   BivariateMLEcheckProver        v3/bivariate_mlecheck.rs:27-389  (execute / fold / finish, fold_eq_ind)
 //   evaluate_univariate            crates/math/src/univariate.rs:264-270
 //
 // Protocol bookkeeping only; every hypercube-sized operation is a HAL call.
@@ -224,6 +225,174 @@ private:
 	State state_;
 	std::vector<B128> sums_or_coeffs_;
 	B128 batched_sum_;
+};
+
+// eq(x, y): the 2-variate multilinear indicating x == y (field/src/util.rs:72-81); characteristic 2
+inline B128 eq(B128 x, B128 y) { return x + y + B128::ONE(); }
+
+// BivariateMLEcheckProver (v3/bivariate_mlecheck.rs:27-372): the eq-indicator sumcheck for bivariate
+// products.  eq_ind_partial_evals = tensor expansion of eq_ind_challenges[0 .. n_vars-1).
+class BivariateMLEcheckProver {
+public:
+	BivariateMLEcheckProver(ComputeLayer &hal, DeviceBumpAllocator &dev_alloc, HostBumpAllocator &host_alloc, size_t n_vars,
+	                        const std::vector<IndexCompositionBivariate> &compositions, const std::vector<B128> &sums,
+	                        const std::vector<FSlice> &multilins, FSlice eq_ind_partial_evals, std::vector<B128> eq_ind_challenges)
+	    : hal_(hal), dev_alloc_(dev_alloc), host_alloc_(host_alloc), n_vars_initial_(n_vars), n_vars_remaining_(n_vars),
+	      eq_ind_challenges_(std::move(eq_ind_challenges))
+	{
+		for (const auto &ml : multilins)
+			if (ml.len() != (size_t)1 << n_vars) throw SumcheckError("NumberOfVariablesMismatch");
+		// only one value of the expanded indicator is used per 1-variable subcube (:97-101)
+		if (eq_ind_partial_evals.len() != (size_t)1 << (n_vars ? n_vars - 1 : 0)) throw SumcheckError("IncorrectEqIndPartialEvalsSize");
+		for (const auto &ml : multilins) multilins_.push_back(Multilin{true, FSliceMut{const_cast<void *>(ml.ptr), ml.len_}});
+		const size_t m = multilins.size();
+		for (const auto &c : compositions) {
+			ArithCircuit prod_expr = c.expression();
+			prod_expr *= ArithCircuit::var(m); // add eq_ind (:399-407)
+			evaluators_.push_back(hal.compile_expr(prod_expr));
+		}
+		state_ = InitialSums;
+		sums_or_coeffs_ = sums;
+		eq_ind_ = Multilin{true, FSliceMut{const_cast<void *>(eq_ind_partial_evals.ptr), eq_ind_partial_evals.len_}};
+	}
+	static size_t required_host_memory(size_t n_multilinears) { return n_multilinears + 1; }
+	static size_t required_device_memory(size_t n_multilinears, size_t n_vars, bool with_eq_ind_partial_evals)
+	{
+		return (n_multilinears + (with_eq_ind_partial_evals ? 0 : 1)) * ((size_t)1 << (n_vars - 1));
+	}
+	size_t n_vars() const { return n_vars_initial_; }
+
+	// round polynomial of degree 3 (:273-318)
+	std::vector<B128> execute(B128 batch_coeff)
+	{
+		std::vector<FSlice> mls;
+		for (const auto &m : multilins_) mls.push_back(FSlice{m.evals.ptr, m.evals.len_});
+		const FSlice eq{eq_ind_.evals.ptr, eq_ind_.evals.len_};
+		const std::vector<B128> round_evals = calculate_round_evals(hal_, n_vars_remaining_, batch_coeff, mls, evaluators_, &eq);
+		B128 batched_sum;
+		switch (state_) {
+		case Coeffs: throw SumcheckError("ExpectedFold");
+		case InitialSums: batched_sum = evaluate_univariate(sums_or_coeffs_, batch_coeff); break;
+		default: batched_sum = batched_sum_; break;
+		}
+		const B128 alpha = eq_ind_challenges_[n_vars_remaining_ - 1];
+		// calculate_round_coeffs_from_evals (:375-389)
+		const B128 y_1 = round_evals[0], y_inf = round_evals[1];
+		const B128 y_0 = (batched_sum - y_1 * alpha) * (B128::ONE() - alpha).invert_or_zero();
+		const B128 c_0 = y_0, c_2 = y_inf, c_1 = y_1 - c_0 - c_2;
+		const std::vector<B128> prime{c_0, c_1, c_2};
+		state_ = Coeffs;
+		sums_or_coeffs_ = prime;
+		// v' -> v: eq(X, alpha) = (1 - alpha) + (2 alpha - 1) X   (:303-313)
+		const B128 k0 = B128::ONE() - alpha, k1 = alpha.dbl() - B128::ONE();
+		std::vector<B128> coeffs(4, B128::ZERO());
+		for (size_t d = 0; d < 3; d++) {
+			coeffs[d] = coeffs[d] + prime[d] * k0;
+			coeffs[d + 1] = coeffs[d + 1] + prime[d] * k1;
+		}
+		for (auto &c : coeffs) c = c * eq_ind_prefix_eval_;
+		return coeffs;
+	}
+
+	void fold(B128 challenge)
+	{
+		if (n_vars_remaining_ == 0) throw SumcheckError("ExpectedFinish");
+		if (state_ != Coeffs) throw SumcheckError("ExpectedExecution");
+		batched_sum_ = evaluate_univariate(sums_or_coeffs_, challenge);
+		state_ = BatchedSum;
+		eq_ind_prefix_eval_ = eq_ind_prefix_eval_ * eq(eq_ind_challenges_[n_vars_remaining_ - 1], challenge); // (:120-123)
+		fold_multilinears(challenge);
+		if (n_vars_remaining_ - 1 != 0) fold_eq_ind();
+		n_vars_remaining_ -= 1;
+	}
+
+	// final evaluations followed by eq_ind_prefix_eval (:348-372)
+	std::vector<B128> finish()
+	{
+		if (state_ == Coeffs) throw SumcheckError("ExpectedFold");
+		if (n_vars_remaining_ != 0) throw SumcheckError("ExpectedExecution");
+		HostSliceMut buffer = host_alloc_.alloc(multilins_.size());
+		for (size_t i = 0; i < multilins_.size(); i++)
+			hal_.copy_d2h(FSlice{multilins_[i].evals.ptr, multilins_[i].evals.len_}, &buffer[i], 1);
+		std::vector<B128> res(buffer.ptr, buffer.ptr + multilins_.size());
+		res.push_back(eq_ind_prefix_eval_);
+		return res;
+	}
+
+private:
+	struct Multilin {
+		bool pre_fold;
+		FSliceMut evals;
+	};
+	struct FoldArgs {
+		FSliceMut evals_0;
+		FSlice evals_1;
+	};
+
+	void fold_multilinears(B128 challenge) // (:145-193)
+	{
+		std::vector<FoldArgs> prepared;
+		for (auto &m : multilins_) {
+			if (m.pre_fold) {
+				auto halves = ComputeMemory::split_half(FSlice{m.evals.ptr, m.evals.len_});
+				FSliceMut folded = dev_alloc_.alloc((size_t)1 << (n_vars_remaining_ - 1));
+				hal_.copy_d2d(halves.first, folded);
+				prepared.push_back(FoldArgs{folded, halves.second});
+			} else {
+				auto halves = ComputeMemory::split_half_mut(m.evals);
+				prepared.push_back(FoldArgs{halves.first, ComputeMemory::to_const(halves.second)});
+			}
+		}
+		hal_.execute([&](ComputeLayerExecutor &exec) {
+			multilins_ = exec.map(prepared.begin(), prepared.end(), [&](ComputeLayerExecutor &e, FoldArgs &a) {
+				e.extrapolate_line(a.evals_0, a.evals_1, challenge);
+				return Multilin{false, a.evals_0};
+			});
+			return std::vector<B128>{};
+		});
+	}
+
+	void fold_eq_ind() // (:195-254): map_kernels { add_assign(evals_1 -> evals_0) }
+	{
+		const size_t split_n_vars = n_vars_remaining_ - 2;
+		FSliceMut evals_0;
+		FSlice evals_1;
+		if (eq_ind_.pre_fold) {
+			auto halves = ComputeMemory::split_half(FSlice{eq_ind_.evals.ptr, eq_ind_.evals.len_});
+			evals_0 = dev_alloc_.alloc(halves.first.len());
+			hal_.copy_d2d(halves.first, evals_0);
+			evals_1 = halves.second;
+		} else {
+			auto halves = ComputeMemory::split_half_mut(eq_ind_.evals);
+			evals_0 = halves.first;
+			evals_1 = ComputeMemory::to_const(halves.second);
+		}
+		std::vector<KernelMemMap> kernel_mappings{KernelMemMap::chunked_mut(evals_0, 0), KernelMemMap::chunked(evals_1, 0)};
+		hal_.execute([&](ComputeLayerExecutor &exec) {
+			exec.map_kernels(
+			    [&](KernelExecutor &local_exec, size_t log_chunks, std::vector<KernelBuffer> &buffers) {
+				    const size_t log_chunk_size = split_n_vars - log_chunks;
+				    local_exec.add_assign(log_chunk_size, buffers[1].to_ref(), buffers[0].as_mut());
+			    },
+			    kernel_mappings);
+			return std::vector<B128>{};
+		});
+		eq_ind_ = Multilin{false, evals_0};
+	}
+
+	enum State { Coeffs, InitialSums, BatchedSum };
+	ComputeLayer &hal_;
+	DeviceBumpAllocator &dev_alloc_;
+	HostBumpAllocator &host_alloc_;
+	size_t n_vars_initial_, n_vars_remaining_;
+	std::vector<Multilin> multilins_;
+	std::vector<ExprEval> evaluators_;
+	State state_;
+	std::vector<B128> sums_or_coeffs_;
+	B128 batched_sum_;
+	B128 eq_ind_prefix_eval_ = B128::ONE();
+	Multilin eq_ind_{};
+	std::vector<B128> eq_ind_challenges_;
 };
 
 } // namespace binius_amd

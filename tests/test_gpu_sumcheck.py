@@ -398,3 +398,34 @@ def test_bivariate_mlecheck_prove(hal, oracle, n_vars, m, comps):
     assert finals == want_finals
     for j in range(m):  # PreFold inputs are never modified
         assert np.array_equal(hal.copy_d2h(d[j]), mls[j])
+
+
+@pytest.mark.parametrize("n_vars,m,comps", [(1, 2, [(0, 1)]), (9, 2, [(0, 1)]), (12, 4, [(0, 1), (2, 3), (1, 1)])])
+def test_compiled_mlecheck_prover_matches_oracle(hal, oracle, n_vars, m, comps):
+    """The C++ BivariateMLEcheckProver mirror (binius_amd/host/sumcheck.hpp) over the C ABI."""
+    from binius_amd._host import MlecheckPlan
+    from binius_amd.sumcheck import eq_ind_partial_eval
+
+    alloc = hal.dev_alloc()
+    mls = [oracle.random_b128(0x3C3C00 + j, 1 << n_vars) for j in range(m)]
+    eq_ch = oracle.random_scalars(0x3C3C00 ^ 0xE9, n_vars)
+    full = oracle.arr(1 << n_vars)
+    full[0] = (1, 0)
+    oracle.tensor_expand(full, 0, eq_ch)
+    sums = []
+    for i, j in comps:
+        p = oracle.mul_vec(oracle.mul_vec(mls[i], mls[j]), full)
+        sums.append(int(np.bitwise_xor.reduce(p[:, 0])) | (int(np.bitwise_xor.reduce(p[:, 1])) << 64))
+    d = [upload(hal, alloc, x) for x in mls]
+    eq_dev = eq_ind_partial_eval(hal, alloc, eq_ch[: n_vars - 1])
+    eq_host = hal.copy_d2h(eq_dev)
+    scratch = alloc.alloc(max(1, (m + 1) * (1 << n_vars) // 2))
+    stream = oracle.random_scalars(0xC4A2, n_vars + 1)
+    bc, ch = stream[0], stream[1:]
+    plan = MlecheckPlan(hal, n_vars, d, eq_dev, eq_ch, scratch, comps, sums, bc, ch)
+    plan.run()
+    want_coeffs, want_finals = oracle.bivariate_mlecheck_prove([x.copy() for x in mls], n_vars, eq_host.copy(), eq_ch, comps, sums, bc, ch)
+    assert plan.round_coeffs() == want_coeffs
+    assert plan.final_evals() == want_finals
+    plan.run()  # inputs (PreFold) are never modified: re-runnable
+    assert plan.round_coeffs() == want_coeffs
