@@ -621,8 +621,9 @@ int bn_tensor_expand(bn_ctx *ctx, void *d_data, uint64_t data_len, uint32_t log_
 	BN_FLUSH(ctx);
 	BN_REQUIRE(log_n + k < 64 && data_len == ((uint64_t)1 << (log_n + k)), "invalid data length");
 	prof_scope ps(ctx, BN_PROF_TENSOR_EXPAND);
-	for (uint32_t i = 0; i < k; i++)
-		BN_HIP(bn::launch_tensor_expand_pass(ctx->stream, ctx->n_cu, d_data, (uint64_t)1 << (log_n + i), to_f(&h_coords[i])));
+	std::vector<f128> coords(k);
+	for (uint32_t i = 0; i < k; i++) coords[i] = to_f(&h_coords[i]);
+	BN_HIP(bn::launch_tensor_expand(ctx->stream, ctx->n_cu, d_data, log_n, coords.data(), k));
 	return BN_OK;
 }
 

@@ -32,6 +32,26 @@ __device__ __forceinline__ f128 to_f128(uint4 v)
 }
 __device__ __forceinline__ uint4 xor4(uint4 a, uint4 b) { return uint4{a.x ^ b.x, a.y ^ b.y, a.z ^ b.z, a.w ^ b.w}; }
 
+// Group form: `nthreads` (>= 128) consecutive threads, numbered ltid, build table s for z; every
+// thread of the workgroup must call it (it contains workgroup barriers), threads outside any group
+// pass ltid >= nthreads.  Several groups can build different tables at the same time.
+__device__ __forceinline__ void ctable_build_group(ctable_smem &s, f128 z, unsigned ltid, unsigned nthreads)
+{
+	if (ltid < 128)
+		s.basis[ltid] = to_u4(mul_basis(z, ltid));
+	__syncthreads();
+	for (unsigned e = ltid; e < 512; e += nthreads) {
+		const unsigned p4 = (e >> 4) << 2;
+		uint4 v{0, 0, 0, 0};
+		if (e & 1) v = xor4(v, s.basis[p4]);
+		if (e & 2) v = xor4(v, s.basis[p4 + 1]);
+		if (e & 4) v = xor4(v, s.basis[p4 + 2]);
+		if (e & 8) v = xor4(v, s.basis[p4 + 3]);
+		s.T[e] = v;
+	}
+	__syncthreads();
+}
+
 // Requires blockDim.x >= 128.  Ends with __syncthreads().
 __device__ __forceinline__ void ctable_build(ctable_smem &s, f128 z)
 {

@@ -124,6 +124,7 @@ hipError_t launch_extrapolate_line_batch(hipStream_t s, int n_cu, const fold_bat
 hipError_t launch_fold_publish(hipStream_t s, void *const *x0, const void *const *src0, const void *const *x1, uint32_t count, uint32_t n,
                                f128 z, f128 *d_mail, uint64_t seq);
 hipError_t launch_tensor_expand_pass(hipStream_t s, int n_cu, void *data, uint64_t half, f128 r);
+hipError_t launch_tensor_expand(hipStream_t s, int n_cu, void *data, uint32_t log_n, const f128 *coords, uint32_t k);
 
 // ---- kernels_roundeval.hip
 struct fin_term {

@@ -242,6 +242,118 @@ hipError_t launch_fold_publish(hipStream_t s, void *const *x0, const void *const
 	return hipGetLastError();
 }
 
+// ---- tensor_expand, fused ---------------------------------------------------------------------
+// (1) head: while the expansion fits in LDS (<= 2^12 elements) ALL passes run inside one workgroup.
+struct expand_coords {
+	f128 r[16];
+};
+constexpr int kHeadLog = 12;
+// Up to four coordinates per step: the four quarters of the workgroup build one nibble table each at
+// the same time (the table build, not the arithmetic, dominates these tiny passes); the passes
+// themselves stay one multiplication per thread, a barrier apart.
+__global__ __launch_bounds__(1024) void k_tensor_expand_head(uint4 *__restrict__ x, uint32_t log_n, uint32_t n_pass, expand_coords rc)
+{
+	extern __shared__ __attribute__((aligned(16))) uint4 head_buf[]; // 2^(log_n + n_pass) elements
+	__shared__ ctable_smem tabs[4];
+	const unsigned tid = threadIdx.x, grp = tid >> 8, ltid = tid & 255;
+	for (unsigned h = tid; h < (1u << log_n); h += 1024)
+		head_buf[h] = x[h];
+	for (uint32_t i = 0; i < n_pass; i += 4) {
+		const uint32_t P = (n_pass - i) < 4 ? (n_pass - i) : 4;
+		// (the first barrier inside also orders the previous pass's / the load's LDS writes)
+		ctable_build_group(tabs[grp], rc.r[(i + grp) & 15], grp < P ? ltid : 256u, 256u);
+		for (uint32_t q = 0; q < P; q++) {
+			const unsigned half = 1u << (log_n + i + q);
+			for (unsigned h = tid; h < half; h += 1024) {
+				const uint4 v = head_buf[h];
+				const uint4 p = ctable_mul(tabs[q], v);
+				head_buf[h] = xor4(v, p);
+				head_buf[half + h] = p;
+			}
+			__syncthreads();
+		}
+	}
+	for (unsigned h = tid; h < (1u << (log_n + n_pass)); h += 1024)
+		x[h] = head_buf[h];
+}
+
+// (2) body: P consecutive passes in one streaming kernel.  Input element h (< half) ends up in 2^P
+// places: after pass q the value w splits into w - w*r_q (same place) and w*r_q (place + half * 2^q).
+// Reads 16 B, writes 2^P * 16 B per input element instead of (2^P - 1) reads + 2 (2^P - 1) writes.
+template <int P>
+struct expand_tabs {
+	ctable_smem t[P];
+};
+template <int P>
+__global__ __launch_bounds__(256) void k_tensor_expand_multi(uint4 *__restrict__ x, uint64_t half, expand_coords rc)
+{
+	__shared__ expand_tabs<P> tabs;
+#pragma unroll
+	for (int q = 0; q < P; q++)
+		ctable_build(tabs.t[q], rc.r[q]);
+	const uint64_t stride = (uint64_t)gridDim.x * 256;
+	for (uint64_t h = (uint64_t)blockIdx.x * 256 + threadIdx.x; h < half; h += stride) {
+		uint4 w[1 << P];
+		w[0] = x[h];
+#pragma unroll
+		for (int q = 0; q < P; q++) {
+#pragma unroll
+			for (int e = 0; e < (1 << q); e++) {
+				const uint4 p = ctable_mul(tabs.t[q], w[e]);
+				w[e] = xor4(w[e], p);
+				w[e + (1 << q)] = p;
+			}
+		}
+#pragma unroll
+		for (int e = 0; e < (1 << P); e++)
+			x[h + (uint64_t)e * half] = w[e];
+	}
+}
+
+// all k passes of a tensor_expand (layer.rs:269-296)
+hipError_t launch_tensor_expand(hipStream_t s, int n_cu, void *data, uint32_t log_n, const f128 *coords, uint32_t k)
+{
+	uint32_t i = 0;
+	if (log_n < (uint32_t)kHeadLog && k > 0) {
+		uint32_t n_pass = (uint32_t)kHeadLog - log_n;
+		if (n_pass > k) n_pass = k;
+		if (n_pass > 16) n_pass = 16;
+		expand_coords rc{};
+		for (uint32_t q = 0; q < n_pass; q++) rc.r[q] = coords[q];
+		const size_t lds = ((size_t)16 << (log_n + n_pass));
+		static bool attr_set = false;
+		if (!attr_set) {
+			hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tensor_expand_head), hipFuncAttributeMaxDynamicSharedMemorySize,
+			                                   (int)((size_t)16 << kHeadLog));
+			if (e != hipSuccess) return e;
+			attr_set = true;
+		}
+		hipLaunchKernelGGL(k_tensor_expand_head, dim3(1), dim3(1024), lds, s, (uint4 *)data, log_n, n_pass, rc);
+		hipError_t e = hipGetLastError();
+		if (e != hipSuccess) return e;
+		i = n_pass;
+	}
+	while (i < k) {
+		const uint32_t left = k - i;
+		// groups of 3 from here; a remainder of 1 or 2 goes first so the largest passes are 3-fused
+		const uint32_t P = (left % 3) ? (left % 3) : 3;
+		const uint64_t half = (uint64_t)1 << (log_n + i);
+		expand_coords rc{};
+		for (uint32_t q = 0; q < P; q++) rc.r[q] = coords[i + q];
+		const unsigned g = grid_for(half, 256, n_cu, P == 3 ? 4 : 8);
+		if (P == 1)
+			hipLaunchKernelGGL((k_tensor_expand_multi<1>), dim3(g), dim3(256), 0, s, (uint4 *)data, half, rc);
+		else if (P == 2)
+			hipLaunchKernelGGL((k_tensor_expand_multi<2>), dim3(g), dim3(256), 0, s, (uint4 *)data, half, rc);
+		else
+			hipLaunchKernelGGL((k_tensor_expand_multi<3>), dim3(g), dim3(256), 0, s, (uint4 *)data, half, rc);
+		hipError_t e = hipGetLastError();
+		if (e != hipSuccess) return e;
+		i += P;
+	}
+	return hipSuccess;
+}
+
 hipError_t launch_tensor_expand_pass(hipStream_t s, int n_cu, void *data, uint64_t half, f128 r)
 {
 	if (half == 0) return hipSuccess;

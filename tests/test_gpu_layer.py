@@ -129,7 +129,7 @@ def test_extrapolate_line_length_mismatch(hal, oracle):
 
 
 # ---- test_generic_single_tensor_expand (layer.rs:22-72) + eq_ind_partial_eval (ops.rs:26-50)
-@pytest.mark.parametrize("log_n,k", [(2, 6), (0, 8), (0, 1), (3, 0), (0, 14)])
+@pytest.mark.parametrize("log_n,k", [(2, 6), (0, 8), (0, 1), (3, 0), (0, 14), (0, 15), (5, 13), (13, 4), (12, 1), (11, 2), (0, 20), (3, 16)])
 def test_tensor_expand(hal, oracle, log_n, k):
     alloc = hal.dev_alloc()
     n = 1 << (log_n + k)
