@@ -54,7 +54,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    force_sharded = os.environ.get("BN_FORCE_SHARDED") == "1"  # exercise the RCCL path on one GPU
+    force_sharded = os.environ.get("BN_FORCE_SHARDED") == "1"  # exercise the multi-GPU code path on one GPU
+    # per-round exchange of the ranks' 32-byte partials: "shm" (host shared memory; all ranks on one
+    # node, the measured configuration) or "rccl" (one ncclAllGather per round on the device)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    exchange = os.environ.get("BN_EXCHANGE", "shm" if local_world == int(os.environ.get("WORLD_SIZE", "1")) else "rccl")
     if world > 1 or force_sharded:
         import torch.distributed as dist
 
@@ -100,8 +104,15 @@ def main():
     from binius_amd._host import SumcheckPlan
 
     scratch = alloc.alloc(m * (n // 2))
-    d_partial, d_gathered, rccl = 0, 0, None
-    if reducer is not None:
+    d_partial, d_gathered, rccl, shm = 0, 0, None, None
+    if reducer is not None and exchange == "shm":
+        # the round loop runs exactly as on one GPU (fused kernels, result mailbox); the ranks' partials
+        # meet in a shared-memory segment (binius_amd/host/host_capi.cpp bnh_shm_*)
+        from binius_amd._host import ShmExchange
+
+        shm = ShmExchange(dist, rank, world)
+        comm = shm
+    elif reducer is not None:
         # the per-round collective is issued from the compiled host loop: ncclAllGather of the 32-byte
         # partial on the context's stream, communicator bootstrapped over the torch process group
         from binius_amd._host import RcclComm
@@ -109,11 +120,12 @@ def main():
         rccl = RcclComm(dist, rank, world)
         d_partial = reducer.local.data_ptr()
         d_gathered = reducer.gathered.data_ptr()
+        comm = reducer
 
     # the claimed sum (not timed): inner product on the device, combined across ranks
     claim = hal.inner_product(d_in[0], 7, d_in[1])
     if reducer is not None:
-        claim = reducer.xor_scalars([claim])[0]
+        claim = comm.xor_scalars([claim])[0]
 
     def barrier():
         if dist is not None:
@@ -121,7 +133,7 @@ def main():
         torch.cuda.synchronize()
 
     plan = SumcheckPlan(hal, n_vars, d_in, scratch, [(0, 1)], [claim], batch_coeff, challenges[:n_vars], None, d_partial,
-                        rccl.handle if rccl else None, world, d_gathered)
+                        rccl.handle if rccl else None, world, d_gathered, shm.handle if shm else None)
     tail = None
     if reducer is not None and log_world > 0:
         # residual instance after the local rounds: m multilinears of `world` elements (index = rank)
@@ -133,7 +145,7 @@ def main():
         if reducer is None or log_world == 0:
             return plan.round_coeffs, plan.final_evals
         # last log2(G) rounds: one all_gather of the m local finals, then a tiny local sumcheck
-        per_rank = reducer.all_gather_scalars(plan.final_evals())
+        per_rank = comm.all_gather_scalars(plan.final_evals())
         running = claim
         for r, (c0, c1, c2) in enumerate(plan.round_coeffs()):
             running = F.mul(F.mul(c2, challenges[r]) ^ c1, challenges[r]) ^ c0
@@ -265,7 +277,8 @@ def main():
             "n_vars_local": n_vars,
             "n_vars_global": n_vars + log_world,
             "multilinears": m,
-            "sharding": "low index bits (last-bound variables), one 32-byte RCCL all_gather per round" if dist is not None else "none",
+            "sharding": ("low index bits (last-bound variables), one 32-byte exchange per round: "
+                         + ("host shared memory" if exchange == "shm" else "RCCL all_gather")) if dist is not None else "none",
         },
         "bit_exact_check": bool(ok),
         "roofline": roofline,
@@ -298,6 +311,8 @@ def main():
         print(json.dumps(out))
     if rccl is not None:
         rccl.destroy()
+    if shm is not None:
+        shm.close()
     hal.close()
     if dist is not None:
         dist.destroy_process_group()

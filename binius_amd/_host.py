@@ -25,8 +25,11 @@ def host_lib():
         L.bnh_bivariate_sumcheck_prove.argtypes = [
             C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p), C.c_void_p, C.c_uint64, C.c_uint32,
             C.POINTER(C.c_uint32), C.POINTER(F128), C.POINTER(F128), C.POINTER(F128), C.POINTER(F128), C.POINTER(F128),
-            REDUCE_FN, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+            REDUCE_FN, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
         ]
+        L.bnh_shm_open.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.bnh_shm_close.argtypes = [C.c_void_p]
+        L.bnh_shm_allgather.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(C.c_uint64)]
         L.bnh_bivariate_mlecheck_prove.restype = C.c_int
         L.bnh_bivariate_mlecheck_prove.argtypes = [
             C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p), C.c_void_p, C.POINTER(F128), C.c_void_p, C.c_uint64,
@@ -44,7 +47,7 @@ class SumcheckPlan:
     """Pre-marshalled arguments of one prove so repeated runs have no per-call Python work."""
 
     def __init__(self, hal, n_vars, multilins, scratch, comps, sums, batch_coeff, challenges, reduce=None, d_partial=0,
-                 rccl_comm=None, world=1, d_gathered=0):
+                 rccl_comm=None, world=1, d_gathered=0, shm=None):
         self.hal = hal
         self.n_vars = n_vars
         self.m = len(multilins)
@@ -61,12 +64,13 @@ class SumcheckPlan:
         self.reduce = REDUCE_FN(reduce) if reduce is not None else C.cast(None, REDUCE_FN)
         self.d_partial = d_partial
         self.rccl_comm, self.world, self.d_gathered = rccl_comm, world, d_gathered
+        self.shm = shm
 
     def run(self):
         rc = host_lib().bnh_bivariate_sumcheck_prove(
             self.hal._h, self.n_vars, self.m, self.ptrs, self.scratch.ptr, self.scratch.len, self.n_comps, self.comps,
             self.sums, C.byref(self.bc), self.ch, self.coeffs, self.final, self.reduce, None, self.d_partial,
-            self.rccl_comm, self.world, self.d_gathered,
+            self.rccl_comm, self.world, self.d_gathered, self.shm,
         )
         if rc != 0:
             raise BnError(rc, host_lib().bnh_last_error().decode())
@@ -108,6 +112,65 @@ class MlecheckPlan:
 
     def final_evals(self):
         return [from_f128(self.final[j]) for j in range(self.m + 1)]
+
+
+class ShmExchange:
+    """Intra-node exchange of a few 64-bit words per round through POSIX shared memory (host_capi.cpp
+    bnh_shm_*): rank 0 creates the segment, the name travels over the torch.distributed group."""
+
+    def __init__(self, dist, rank, world):
+        import uuid
+
+        L = host_lib()
+        box = ["/bn_amd_%s" % uuid.uuid4().hex[:16] if rank == 0 else None]
+        if dist is not None:
+            dist.broadcast_object_list(box, src=0)
+        self.name = box[0]
+        self.world, self.rank = world, rank
+        self.handle = C.c_void_p()
+        if rank == 0:
+            self._open(L, 1)
+        if dist is not None:
+            dist.barrier()  # the segment exists (and is zeroed) before anyone else maps it
+        if rank != 0:
+            self._open(L, 0)
+        if dist is not None:
+            dist.barrier()
+
+    def _open(self, L, create):
+        rc = L.bnh_shm_open(self.name.encode(), self.world, self.rank, create, C.byref(self.handle))
+        if rc != 0:
+            raise BnError(rc, L.bnh_last_error().decode())
+
+    def allgather_words(self, words):
+        """words: list of < 8 ints (64-bit).  Returns [rank][i]."""
+        n = len(words)
+        src = (C.c_uint64 * n)(*words)
+        dst = (C.c_uint64 * (n * self.world))()
+        rc = host_lib().bnh_shm_allgather(self.handle, src, n, dst)
+        if rc != 0:
+            raise BnError(rc, host_lib().bnh_last_error().decode())
+        return [[int(dst[w * n + i]) for i in range(n)] for w in range(self.world)]
+
+    def all_gather_scalars(self, vals):
+        """128-bit scalars (<= 3): returns [rank][i] like TorchComm.all_gather_scalars."""
+        words = []
+        for v in vals:
+            words += [v & ((1 << 64) - 1), v >> 64]
+        per = self.allgather_words(words)
+        return [[r[2 * i] | (r[2 * i + 1] << 64) for i in range(len(vals))] for r in per]
+
+    def xor_scalars(self, vals):
+        out = [0] * len(vals)
+        for r in self.all_gather_scalars(vals):
+            for i, v in enumerate(r):
+                out[i] ^= v
+        return out
+
+    def close(self):
+        if self.handle:
+            host_lib().bnh_shm_close(self.handle)
+            self.handle = C.c_void_p()
 
 
 class RcclComm:

@@ -6,6 +6,14 @@
 // multiplications, one extrapolate_line per multilinear -- without interpreter overhead between
 // HAL calls.  Links only against the C ABI of include/binius_amd.h.
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <cerrno>
+#include <cstring>
+#include <thread>
 
 #include <cstring>
 #include <string>
@@ -85,6 +93,87 @@ int bnh_rccl_destroy(void *comm) { return comm && g_rccl.lib ? rccl_check(g_rccl
 
 // Combine hook for the sharded prover: called once per round with the device pointer holding this
 // rank's partial (y_1, y_inf) (2 field elements); must return the XOR over all ranks in `evals`.
+// ---- intra-node exchange of a few scalars per round through POSIX shared memory ---------------
+// The sharded prover needs, every round, the XOR of one 32-byte partial per rank.  All ranks of the
+// measured configuration sit on one node, so the cheapest exchange is the host's cache-coherent
+// memory: every rank publishes (payload, round) in its own cache line pair and spins on the others'
+// (~1 us per round, no launch, no device round trip) -- the device side of a round is then exactly
+// the single-GPU one (fused kernel + result mailbox).  The RCCL all_gather path above stays for
+// ranks that do not share a node.  Two slots per rank suffice: a rank can only get one round ahead
+// (it needs everybody's round r+1 value, published after they have read round r).
+struct shm_slot {
+	alignas(64) std::atomic<uint64_t> seq;
+	uint64_t v[7];
+};
+struct bnh_shm {
+	shm_slot *base = nullptr; // [world][2]
+	int world = 0, rank = 0;
+	uint64_t round = 0;
+	size_t bytes = 0;
+	std::string name;
+	bool owner = false;
+};
+
+int bnh_shm_open(const char *name, int world, int rank, int create, void **out)
+{
+	if (!name || !out || world < 1 || rank < 0 || rank >= world) return (g_err = "bnh_shm_open: bad arguments", BN_ERR_INPUT_VALIDATION);
+	const size_t bytes = sizeof(shm_slot) * 2 * (size_t)world;
+	int fd = create ? shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600) : shm_open(name, O_RDWR, 0600);
+	if (fd < 0) return (g_err = std::string("shm_open failed: ") + strerror(errno), BN_ERR_CORE_LIB);
+	if (create && ftruncate(fd, (off_t)bytes) != 0) {
+		close(fd);
+		shm_unlink(name);
+		return (g_err = std::string("ftruncate failed: ") + strerror(errno), BN_ERR_CORE_LIB);
+	}
+	void *p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+	close(fd);
+	if (p == MAP_FAILED) return (g_err = std::string("mmap failed: ") + strerror(errno), BN_ERR_CORE_LIB);
+	if (create) std::memset(p, 0, bytes); // seq = 0 everywhere; rounds start at 1
+	bnh_shm *h = new bnh_shm;
+	h->base = (shm_slot *)p;
+	h->world = world;
+	h->rank = rank;
+	h->bytes = bytes;
+	h->name = name;
+	h->owner = create != 0;
+	*out = h;
+	return 0;
+}
+
+int bnh_shm_close(void *hv)
+{
+	bnh_shm *h = (bnh_shm *)hv;
+	if (!h) return 0;
+	munmap(h->base, h->bytes);
+	if (h->owner) shm_unlink(h->name.c_str());
+	delete h;
+	return 0;
+}
+
+// every rank contributes n_words (<= 7) 64-bit words; out[world * n_words] = all of them, rank-major
+int bnh_shm_allgather(void *hv, const uint64_t *in, uint32_t n_words, uint64_t *out)
+{
+	bnh_shm *h = (bnh_shm *)hv;
+	if (!h || !in || !out || n_words > 7) return (g_err = "bnh_shm_allgather: bad arguments", BN_ERR_INPUT_VALIDATION);
+	const uint64_t r = ++h->round;
+	shm_slot &mine = h->base[2 * h->rank + (r & 1)];
+	for (uint32_t i = 0; i < n_words; i++) mine.v[i] = in[i];
+	mine.seq.store(r, std::memory_order_release);
+	for (int w = 0; w < h->world; w++) {
+		shm_slot &s = h->base[2 * w + (r & 1)];
+		uint64_t spins = 0;
+		while (s.seq.load(std::memory_order_acquire) != r) {
+			if (++spins > (1ull << 22)) {
+				// slow path: yield, and give up after ~20 s (a rank died)
+				std::this_thread::yield();
+				if (spins > (1ull << 22) + 20000000ull) return (g_err = "shm exchange timed out waiting for a rank", BN_ERR_DEVICE);
+			}
+		}
+		for (uint32_t i = 0; i < n_words; i++) out[(size_t)w * n_words + i] = s.v[i];
+	}
+	return 0;
+}
+
 typedef int (*bnh_round_reduce_fn)(void *user, const void *d_partial, bn_f128 *evals);
 
 // One full prove: execute -> fold for n_vars rounds, then finish.
@@ -98,7 +187,7 @@ int bnh_bivariate_sumcheck_prove(bn_ctx *ctx, uint32_t n_vars, uint32_t m, const
                                  uint64_t scratch_elems, uint32_t n_comps, const uint32_t *comp_indices, const bn_f128 *sums,
                                  const bn_f128 *batch_coeff, const bn_f128 *challenges, bn_f128 *round_coeffs_out,
                                  bn_f128 *final_evals_out, bnh_round_reduce_fn reduce, void *reduce_user, void *d_partial,
-                                 void *rccl_comm, int world, void *d_gathered)
+                                 void *rccl_comm, int world, void *d_gathered, void *shm)
 {
 	try {
 		ComputeLayer hal(ctx);
@@ -114,7 +203,7 @@ int bnh_bivariate_sumcheck_prove(bn_ctx *ctx, uint32_t n_vars, uint32_t m, const
 			sv.emplace_back(sums[c].lo, sums[c].hi);
 		}
 		const B128 bc(batch_coeff->lo, batch_coeff->hi);
-		if (!reduce && !rccl_comm) {
+		if (!reduce && !rccl_comm && !shm) {
 			BivariateSumcheckProver prover(hal, dev_alloc, host_alloc, n_vars, comps, sv, mls);
 			for (uint32_t r = 0; r < n_vars; r++) {
 				std::vector<B128> rc = prover.execute(bc);
@@ -142,38 +231,57 @@ int bnh_bivariate_sumcheck_prove(bn_ctx *ctx, uint32_t n_vars, uint32_t m, const
 				maps.push_back(KernelMemMap::chunked(h.second, 0));
 				maps.push_back(KernelMemMap::local(split));
 			}
-			hal.execute([&](ComputeLayerExecutor &exec) {
-				exec.accumulate_kernels_to_device(
-				    [&](KernelExecutor &ke, size_t log_chunks, std::vector<KernelBuffer> &b) {
-					    const size_t lcs = split - log_chunks;
-					    KernelValue a1 = ke.decl_value(B128::ZERO());
-					    std::vector<KSlice> rows;
-					    for (uint32_t i = 0; i < m; i++) rows.push_back(b[3 * i + 1].to_ref());
-					    SlicesBatch<KSlice> e1(rows, (size_t)1 << lcs);
-					    for (uint32_t c = 0; c < n_comps; c++) ke.sum_composition_evals(e1, evaluators[c], coeffs[c], a1);
-					    for (uint32_t i = 0; i < m; i++) ke.add(lcs, b[3 * i].to_ref(), b[3 * i + 1].to_ref(), b[3 * i + 2].as_mut());
-					    KernelValue ai = ke.decl_value(B128::ZERO());
-					    rows.clear();
-					    for (uint32_t i = 0; i < m; i++) rows.push_back(b[3 * i + 2].to_ref());
-					    SlicesBatch<KSlice> ei(rows, (size_t)1 << lcs);
-					    for (uint32_t c = 0; c < n_comps; c++) ke.sum_composition_evals(ei, evaluators[c], coeffs[c], ai);
-					    return std::vector<KernelValue>{a1, ai};
-				    },
-				    maps, d_partial);
-				return std::vector<B128>{};
-			});
 			bn_f128 ev[2];
-			if (rccl_comm) {
-				// ONE RCCL collective per round: all_gather of this rank's 32-byte partial on the
-				// context's stream (stream-ordered after the kernels), then XOR of the G partials
-				void *stream = nullptr;
-				check(bn_ctx_get_stream(ctx, &stream));
-				if (g_rccl.all_gather(d_partial, d_gathered, 32, kNcclUint8, rccl_comm, stream) != 0)
-					throw Error(Error::DeviceError, "ncclAllGather failed");
-				// XOR of the G partials on the device, result through the zero-copy mailbox
-				check(bn_xor_reduce(ctx, d_gathered, (uint32_t)world, 2, ev));
-			} else if (reduce(reduce_user, d_partial, ev)) {
-				throw Error(Error::CoreLibError, "round reduce callback failed");
+			if (shm) {
+				// device side identical to the single-GPU round (result through the mailbox); the
+				// partials of the ranks are combined in host shared memory
+				std::vector<FSlice> cmls;
+				for (auto &ml : cur) cmls.push_back(ComputeMemory::as_const(ml));
+				const std::vector<B128> part = calculate_round_evals(hal, rem, bc, cmls, evaluators);
+				const uint64_t mine[4] = {part[0].raw().lo, part[0].raw().hi, part[1].raw().lo, part[1].raw().hi};
+				std::vector<uint64_t> all((size_t)4 * world);
+				if (bnh_shm_allgather(shm, mine, 4, all.data())) throw Error(Error::DeviceError, g_err);
+				ev[0] = bn_f128{0, 0};
+				ev[1] = bn_f128{0, 0};
+				for (int w = 0; w < world; w++) {
+					ev[0].lo ^= all[4 * w + 0];
+					ev[0].hi ^= all[4 * w + 1];
+					ev[1].lo ^= all[4 * w + 2];
+					ev[1].hi ^= all[4 * w + 3];
+				}
+			} else {
+				hal.execute([&](ComputeLayerExecutor &exec) {
+					exec.accumulate_kernels_to_device(
+					    [&](KernelExecutor &ke, size_t log_chunks, std::vector<KernelBuffer> &b) {
+						    const size_t lcs = split - log_chunks;
+						    KernelValue a1 = ke.decl_value(B128::ZERO());
+						    std::vector<KSlice> rows;
+						    for (uint32_t i = 0; i < m; i++) rows.push_back(b[3 * i + 1].to_ref());
+						    SlicesBatch<KSlice> e1(rows, (size_t)1 << lcs);
+						    for (uint32_t c = 0; c < n_comps; c++) ke.sum_composition_evals(e1, evaluators[c], coeffs[c], a1);
+						    for (uint32_t i = 0; i < m; i++) ke.add(lcs, b[3 * i].to_ref(), b[3 * i + 1].to_ref(), b[3 * i + 2].as_mut());
+						    KernelValue ai = ke.decl_value(B128::ZERO());
+						    rows.clear();
+						    for (uint32_t i = 0; i < m; i++) rows.push_back(b[3 * i + 2].to_ref());
+						    SlicesBatch<KSlice> ei(rows, (size_t)1 << lcs);
+						    for (uint32_t c = 0; c < n_comps; c++) ke.sum_composition_evals(ei, evaluators[c], coeffs[c], ai);
+						    return std::vector<KernelValue>{a1, ai};
+					    },
+					    maps, d_partial);
+					return std::vector<B128>{};
+				});
+				if (rccl_comm) {
+					// ONE RCCL collective per round: all_gather of this rank's 32-byte partial on the
+					// context's stream (stream-ordered after the kernels), then XOR of the G partials
+					void *stream = nullptr;
+					check(bn_ctx_get_stream(ctx, &stream));
+					if (g_rccl.all_gather(d_partial, d_gathered, 32, kNcclUint8, rccl_comm, stream) != 0)
+						throw Error(Error::DeviceError, "ncclAllGather failed");
+					// XOR of the G partials on the device, result through the zero-copy mailbox
+					check(bn_xor_reduce(ctx, d_gathered, (uint32_t)world, 2, ev));
+				} else if (reduce(reduce_user, d_partial, ev)) {
+					throw Error(Error::CoreLibError, "round reduce callback failed");
+				}
 			}
 			std::vector<B128> rc = calculate_round_coeffs_from_evals(running, {B128(ev[0].lo, ev[0].hi), B128(ev[1].lo, ev[1].hi)});
 			for (size_t i = 0; i < 3; i++) round_coeffs_out[3 * r + i] = rc[i].raw();

@@ -57,7 +57,7 @@ class OracleField:
         return self.o.mul(a, b)
 
 
-def _worker(rank, world, port, n_global, q):
+def _worker(rank, world, port, n_global, q, use_shm=False):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -77,9 +77,13 @@ def _worker(rank, world, port, n_global, q):
         stream = oracle.random_scalars(0xC4A1, n_global + 1)
         batch_coeff, challenges = stream[0], stream[1:]
         sums = [oracle.inner_product(full[i], 7, full[j])[1] for i, j in comps]
-        prover = ShardedBivariateSumcheck(
-            TorchComm(dist, world), OracleCompute(oracle, local, comps, batch_coeff), OracleField(oracle), n_local, world, len(comps)
-        )
+        if use_shm:
+            from binius_amd._host import ShmExchange
+
+            comm = ShmExchange(dist, rank, world)  # the exchange bench.py uses on a single node
+        else:
+            comm = TorchComm(dist, world)
+        prover = ShardedBivariateSumcheck(comm, OracleCompute(oracle, local, comps, batch_coeff), OracleField(oracle), n_local, world, len(comps))
         coeffs, finals = prover.prove(sums, batch_coeff, challenges)
         want_coeffs, want_finals = oracle.bivariate_sumcheck_prove([x.copy() for x in full], n_global, comps, sums, batch_coeff, challenges)
         ok = coeffs == want_coeffs and finals == want_finals
@@ -96,8 +100,8 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,n_global", [(2, 9), (4, 10)])
-def test_sharded_sumcheck_gloo(world, n_global):
+@pytest.mark.parametrize("world,n_global,use_shm", [(2, 9, False), (4, 10, False), (2, 9, True), (4, 8, True)])
+def test_sharded_sumcheck_gloo(world, n_global, use_shm):
     import torch.multiprocessing as mp
 
     import oracle
@@ -106,7 +110,7 @@ def test_sharded_sumcheck_gloo(world, n_global):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_global, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_global, q, use_shm)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -135,3 +139,55 @@ def test_shard_layout_keeps_pairs_local():
                 assert gi + size // 2 == idx[li + half_local]
             size //= 2
         assert local_n == N // world
+
+
+def _shm_worker(rank, world, port, q):
+    import os
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from binius_amd._host import ShmExchange
+
+        ex = ShmExchange(dist, rank, world)
+        ok = True
+        acc = 0
+        for r in range(2000):  # many rounds: exercises the two-slot reuse
+            mine = [(rank + 1) * 0x9E3779B97F4A7C15 * (r + 1) & ((1 << 128) - 1), (r << 64) | rank]
+            got = ex.all_gather_scalars(mine)
+            for w in range(world):
+                want = [(w + 1) * 0x9E3779B97F4A7C15 * (r + 1) & ((1 << 128) - 1), (r << 64) | w]
+                ok = ok and got[w] == want
+            acc ^= ex.xor_scalars([rank + r])[0]
+        ex.close()
+        q.put((rank, ok, acc))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_shared_memory_exchange(world):
+    """The intra-node exchange used by the sharded prover (bnh_shm_*): every rank sees every rank's
+    words, round after round, with two slots per rank."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_shm_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in ps:
+        p.join(timeout=60)
+    assert all(ok for _, ok, _ in res)
+    want = 0
+    for r in range(2000):
+        x = 0
+        for w in range(world):
+            x ^= w + r
+        want ^= x
+    assert all(acc == want for _, _, acc in res)
