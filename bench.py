@@ -64,8 +64,16 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        # diagnostics for a 1-GPU box: BN_ALL_ON_GPU0=1 BN_PG_BACKEND=gloo runs several ranks on one device
+        # (RCCL refuses that; the shared-memory exchange does not need it)
+        if os.environ.get("BN_ALL_ON_GPU0") == "1":
+            local_rank = 0
+        backend = os.environ.get("BN_PG_BACKEND", "nccl")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(local_rank)
 
@@ -103,7 +111,7 @@ def main():
     # interpreter time between HAL calls.
     from binius_amd._host import SumcheckPlan
 
-    scratch = alloc.alloc(m * (n // 2))
+    scratch = alloc.alloc(m * (n // 2) + 64)  # folded copies (+ the residual rounds' folded copies)
     d_partial, d_gathered, rccl, shm = 0, 0, None, None
     if reducer is not None and exchange == "shm":
         # the round loop runs exactly as on one GPU (fused kernels, result mailbox); the ranks' partials
@@ -132,17 +140,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    plan = SumcheckPlan(hal, n_vars, d_in, scratch, [(0, 1)], [claim], batch_coeff, challenges[:n_vars], None, d_partial,
-                        rccl.handle if rccl else None, world, d_gathered, shm.handle if shm else None)
+    # shared-memory exchange: the residual log2(G) rounds run inside the same compiled call
+    in_call_tail = shm is not None and log_world > 0
+    plan = SumcheckPlan(hal, n_vars, d_in, scratch, [(0, 1)], [claim], batch_coeff,
+                        challenges[: n_vars + (log_world if in_call_tail else 0)], None, d_partial,
+                        rccl.handle if rccl else None, world, d_gathered, shm.handle if shm else None, tail_rounds=in_call_tail)
     tail = None
-    if reducer is not None and log_world > 0:
+    if reducer is not None and log_world > 0 and not in_call_tail:
         # residual instance after the local rounds: m multilinears of `world` elements (index = rank)
         d_res = [alloc.alloc(world) for _ in range(m)]
         res_scratch = alloc.alloc(m * max(1, world // 2))
 
     def one_step():
         plan.run()
-        if reducer is None or log_world == 0:
+        if reducer is None or log_world == 0 or in_call_tail:
             return plan.round_coeffs, plan.final_evals
         # last log2(G) rounds: one all_gather of the m local finals, then a tiny local sumcheck
         per_rank = comm.all_gather_scalars(plan.final_evals())
@@ -181,7 +192,7 @@ def main():
         elapsed_prof = time.perf_counter() - t2
         prof = hal.prof_end()
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

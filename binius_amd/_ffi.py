@@ -128,6 +128,7 @@ def lib():
         "bn_prof_begin": [vp],
         "bn_prof_end": [vp, C.POINTER(C.c_double), C.POINTER(u64)],
         "bn_xor_reduce": [vp, vp, u32, u32, PF],
+        "bn_host_scratch": [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)],
         "bn_timer_begin": [vp],
         "bn_timer_end_ms": [vp, C.POINTER(C.c_float)],
     }
@@ -147,7 +148,7 @@ ABI_SYMBOLS = [
     "bn_extrapolate_line", "bn_extrapolate_line_batch", "bn_tensor_expand", "bn_inner_product", "bn_fold_left", "bn_fold_right", "bn_fri_fold",
     "bn_compute_composite", "bn_pairwise_product_reduce", "bn_log_chunks_range", "bn_pick_log_chunks",
     "bn_kernel_launch", "bn_ntt_forward", "bn_ntt_inverse", "bn_ntt_s_evals", "bn_scalar_mul", "bn_scalar_invert",
-    "bn_timer_begin", "bn_timer_end_ms", "bn_prof_begin", "bn_prof_end", "bn_xor_reduce",
+    "bn_timer_begin", "bn_timer_end_ms", "bn_prof_begin", "bn_prof_end", "bn_xor_reduce", "bn_host_scratch",
 ]
 
 

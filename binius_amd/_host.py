@@ -25,7 +25,7 @@ def host_lib():
         L.bnh_bivariate_sumcheck_prove.argtypes = [
             C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p), C.c_void_p, C.c_uint64, C.c_uint32,
             C.POINTER(C.c_uint32), C.POINTER(F128), C.POINTER(F128), C.POINTER(F128), C.POINTER(F128), C.POINTER(F128),
-            REDUCE_FN, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+            REDUCE_FN, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
         ]
         L.bnh_shm_open.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
         L.bnh_shm_close.argtypes = [C.c_void_p]
@@ -47,7 +47,9 @@ class SumcheckPlan:
     """Pre-marshalled arguments of one prove so repeated runs have no per-call Python work."""
 
     def __init__(self, hal, n_vars, multilins, scratch, comps, sums, batch_coeff, challenges, reduce=None, d_partial=0,
-                 rccl_comm=None, world=1, d_gathered=0, shm=None):
+                 rccl_comm=None, world=1, d_gathered=0, shm=None, tail_rounds=False):
+        """tail_rounds (shm exchange only): `challenges` holds n_vars + log2(world) values and the run
+        also does the residual rounds; round_coeffs() then has n_vars + log2(world) entries."""
         self.hal = hal
         self.n_vars = n_vars
         self.m = len(multilins)
@@ -59,7 +61,10 @@ class SumcheckPlan:
         self.sums = _f128_array(list(sums))
         self.bc = to_f128(batch_coeff)
         self.ch = _f128_array(list(challenges))
-        self.coeffs = (F128 * (3 * n_vars))()
+        self.tail_rounds = bool(tail_rounds and shm is not None and world > 1)
+        self.n_rounds = n_vars + ((world.bit_length() - 1) if self.tail_rounds else 0)
+        assert len(challenges) >= self.n_rounds
+        self.coeffs = (F128 * (3 * self.n_rounds))()
         self.final = (F128 * self.m)()
         self.reduce = REDUCE_FN(reduce) if reduce is not None else C.cast(None, REDUCE_FN)
         self.d_partial = d_partial
@@ -70,13 +75,13 @@ class SumcheckPlan:
         rc = host_lib().bnh_bivariate_sumcheck_prove(
             self.hal._h, self.n_vars, self.m, self.ptrs, self.scratch.ptr, self.scratch.len, self.n_comps, self.comps,
             self.sums, C.byref(self.bc), self.ch, self.coeffs, self.final, self.reduce, None, self.d_partial,
-            self.rccl_comm, self.world, self.d_gathered, self.shm,
+            self.rccl_comm, self.world, self.d_gathered, self.shm, 1 if self.tail_rounds else 0,
         )
         if rc != 0:
             raise BnError(rc, host_lib().bnh_last_error().decode())
 
     def round_coeffs(self):
-        return [[from_f128(self.coeffs[3 * r + i]) for i in range(3)] for r in range(self.n_vars)]
+        return [[from_f128(self.coeffs[3 * r + i]) for i in range(3)] for r in range(self.n_rounds)]
 
     def final_evals(self):
         return [from_f128(self.final[j]) for j in range(self.m)]

@@ -1314,6 +1314,20 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 	return BN_OK;
 }
 
+// A small region of fine-grained pinned host memory that the device can read directly (32
+// elements): inputs of a few elements can be handed to kernels without an upload.  Not part of the
+// reference interface (used for the residual instance of the sharded prover).
+int bn_host_scratch(bn_ctx *ctx, void **h_ptr, void **d_ptr, uint64_t *elems)
+{
+	BN_REQUIRE(ctx && h_ptr && d_ptr && elems, "null argument");
+	BN_ENTER(ctx);
+	BN_FLUSH(ctx);
+	*h_ptr = ctx->h_mail + 96;
+	*d_ptr = ctx->d_mail + 96;
+	*elems = 32;
+	return BN_OK;
+}
+
 // XOR of n_groups device vectors of group_len (<= 64) elements, returned to the host through the
 // zero-copy mailbox.  Not part of the reference interface: it is the combine step behind the
 // per-round all_gather of the sharded prover (binius_amd/host/host_capi.cpp).

@@ -187,7 +187,7 @@ int bnh_bivariate_sumcheck_prove(bn_ctx *ctx, uint32_t n_vars, uint32_t m, const
                                  uint64_t scratch_elems, uint32_t n_comps, const uint32_t *comp_indices, const bn_f128 *sums,
                                  const bn_f128 *batch_coeff, const bn_f128 *challenges, bn_f128 *round_coeffs_out,
                                  bn_f128 *final_evals_out, bnh_round_reduce_fn reduce, void *reduce_user, void *d_partial,
-                                 void *rccl_comm, int world, void *d_gathered, void *shm)
+                                 void *rccl_comm, int world, void *d_gathered, void *shm, int tail_rounds)
 {
 	try {
 		ComputeLayer hal(ctx);
@@ -222,8 +222,11 @@ int bnh_bivariate_sumcheck_prove(bn_ctx *ctx, uint32_t n_vars, uint32_t m, const
 		bool pre_fold = true;
 		B128 running = evaluate_univariate(sv, bc);
 		const std::vector<B128> coeffs = powers(bc, n_comps);
-		for (uint32_t r = 0; r < n_vars; r++) {
-			const size_t rem = n_vars - r, split = rem - 1;
+		// `n_rounds` rounds on the arrays in `cur` (2^n_rounds elements each); exchange: combine the
+		// ranks' partial round evaluations (local rounds) or not (residual rounds, identical everywhere)
+		auto do_rounds = [&](uint32_t n_rounds, bool exchange, const bn_f128 *ch, bn_f128 *coeffs_out) {
+		for (uint32_t r = 0; r < n_rounds; r++) {
+			const size_t rem = n_rounds - r, split = rem - 1;
 			std::vector<KernelMemMap> maps;
 			for (auto &ml : cur) {
 				auto h = ComputeMemory::split_half(ComputeMemory::as_const(ml));
@@ -232,7 +235,7 @@ int bnh_bivariate_sumcheck_prove(bn_ctx *ctx, uint32_t n_vars, uint32_t m, const
 				maps.push_back(KernelMemMap::local(split));
 			}
 			bn_f128 ev[2];
-			if (shm) {
+			if (shm || !exchange) {
 				// device side identical to the single-GPU round (result through the mailbox); the
 				// partials of the ranks are combined in host shared memory
 				std::vector<FSlice> cmls;
@@ -240,10 +243,15 @@ int bnh_bivariate_sumcheck_prove(bn_ctx *ctx, uint32_t n_vars, uint32_t m, const
 				const std::vector<B128> part = calculate_round_evals(hal, rem, bc, cmls, evaluators);
 				const uint64_t mine[4] = {part[0].raw().lo, part[0].raw().hi, part[1].raw().lo, part[1].raw().hi};
 				std::vector<uint64_t> all((size_t)4 * world);
-				if (bnh_shm_allgather(shm, mine, 4, all.data())) throw Error(Error::DeviceError, g_err);
+				const int n_src = exchange ? world : 1;
+				if (exchange) {
+					if (bnh_shm_allgather(shm, mine, 4, all.data())) throw Error(Error::DeviceError, g_err);
+				} else {
+					for (int i = 0; i < 4; i++) all[i] = mine[i];
+				}
 				ev[0] = bn_f128{0, 0};
 				ev[1] = bn_f128{0, 0};
-				for (int w = 0; w < world; w++) {
+				for (int w = 0; w < n_src; w++) {
 					ev[0].lo ^= all[4 * w + 0];
 					ev[0].hi ^= all[4 * w + 1];
 					ev[1].lo ^= all[4 * w + 2];
@@ -284,8 +292,8 @@ int bnh_bivariate_sumcheck_prove(bn_ctx *ctx, uint32_t n_vars, uint32_t m, const
 				}
 			}
 			std::vector<B128> rc = calculate_round_coeffs_from_evals(running, {B128(ev[0].lo, ev[0].hi), B128(ev[1].lo, ev[1].hi)});
-			for (size_t i = 0; i < 3; i++) round_coeffs_out[3 * r + i] = rc[i].raw();
-			const B128 z(challenges[r].lo, challenges[r].hi);
+			for (size_t i = 0; i < 3; i++) coeffs_out[3 * r + i] = rc[i].raw();
+			const B128 z(ch[r].lo, ch[r].hi);
 			running = evaluate_univariate(rc, z);
 			struct FoldArgs {
 				FSliceMut evals_0;
@@ -312,6 +320,38 @@ int bnh_bivariate_sumcheck_prove(bn_ctx *ctx, uint32_t n_vars, uint32_t m, const
 				return std::vector<B128>{};
 			});
 			pre_fold = false;
+		}
+		};
+		do_rounds(n_vars, true, challenges, round_coeffs_out);
+		uint32_t log_world = 0;
+		while ((1 << (log_world + 1)) <= world) log_world++;
+		if (shm && tail_rounds && log_world > 0) {
+			// ---- residual rounds: every rank is down to one element per multilinear.  One exchange of
+			// the m local finals rebuilds the m residual multilinears of `world` elements (index = rank)
+			// in pinned, device-visible host memory (no upload); the last log2(world) rounds run on them.
+			std::vector<B128> fin(m);
+			for (uint32_t j = 0; j < m; j++) hal.copy_d2h(ComputeMemory::as_const(cur[j]), &fin[j], 1);
+			void *h_scr = nullptr, *d_scr = nullptr;
+			uint64_t scr_elems = 0;
+			check(bn_host_scratch(ctx, &h_scr, &d_scr, &scr_elems));
+			if ((uint64_t)m * world > scr_elems) throw Error(Error::InputValidation, "residual instance does not fit the pinned scratch");
+			bn_f128 *res = (bn_f128 *)h_scr;
+			for (uint32_t j0 = 0; j0 < m; j0 += 3) {
+				const uint32_t nj = (m - j0) < 3 ? (m - j0) : 3;
+				uint64_t mine[6];
+				for (uint32_t j = 0; j < nj; j++) {
+					mine[2 * j] = fin[j0 + j].raw().lo;
+					mine[2 * j + 1] = fin[j0 + j].raw().hi;
+				}
+				std::vector<uint64_t> all((size_t)2 * nj * world);
+				if (bnh_shm_allgather(shm, mine, 2 * nj, all.data())) throw Error(Error::DeviceError, g_err);
+				for (int w = 0; w < world; w++)
+					for (uint32_t j = 0; j < nj; j++) res[(size_t)(j0 + j) * world + w] = bn_f128{all[(size_t)w * 2 * nj + 2 * j], all[(size_t)w * 2 * nj + 2 * j + 1]};
+			}
+			std::atomic_thread_fence(std::memory_order_seq_cst);
+			for (uint32_t j = 0; j < m; j++) cur[j] = FSliceMut{(char *)d_scr + (size_t)j * world * sizeof(bn_f128), (size_t)world};
+			pre_fold = true; // the pinned inputs are read-only: fold into device scratch
+			do_rounds(log_world, false, challenges + n_vars, round_coeffs_out + 3 * n_vars);
 		}
 		for (uint32_t j = 0; j < m; j++) {
 			B128 v;

@@ -180,6 +180,10 @@ int bn_scalar_invert(const bn_f128 *a, bn_f128 *out);
  * the context's stream.  Not part of the reference interface. */
 int bn_timer_begin(bn_ctx *ctx);
 int bn_timer_end_ms(bn_ctx *ctx, float *ms);
+/* 32 elements of fine-grained pinned host memory, readable by kernels through *d_ptr: a handful of
+ * elements can be handed to the device without an upload.  Not part of the reference interface. */
+int bn_host_scratch(bn_ctx *ctx, void **h_ptr, void **d_ptr, uint64_t *elems);
+
 /* out[i] = XOR over g < n_groups of d_vals[g * group_len + i], i < group_len <= 64, returned to the
  * host.  Not part of the reference interface: the combine step behind the per-round all_gather of
  * the multi-GPU prover (RCCL has no XOR reduction). */

@@ -1,0 +1,49 @@
+"""The N > 1 path of bench.py on a one-GPU box: two (and four) ranks share cuda:0, process group over
+gloo, per-round exchange through host shared memory, residual rounds inside the compiled call.
+RCCL refuses several ranks on one device, so its path is covered by BN_FORCE_SHARDED=1 (world = 1)
+below; everything else of the multi-GPU flow is exactly what the driver launches on 2/4/8 GPUs."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(cmd, env):
+    e = dict(os.environ)
+    e.update(env)
+    out = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and lines, out.stdout[-2000:] + out.stderr[-2000:]
+    return json.loads(lines[-1])
+
+
+@pytest.mark.parametrize("n_ranks", [2, 4])
+def test_bench_two_and_four_ranks_on_one_gpu(n_ranks):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), "bench.py", "--gpus", str(n_ranks), "--steps", "2", "--warmup", "1", "--n-vars", "15",
+           "--no-cpu-baseline"]
+    r = _run(cmd, {"BN_ALL_ON_GPU0": "1", "BN_PG_BACKEND": "gloo", "BN_EXCHANGE": "shm"})
+    assert r["n_gpus"] == n_ranks and r["bit_exact_check"] is True
+    assert r["config"]["n_vars_global"] == 15 + n_ranks.bit_length() - 1
+    assert r["scaling"] == "weak"
+
+
+@pytest.mark.parametrize("exchange", ["shm", "rccl"])
+def test_bench_sharded_code_path_world1(exchange):
+    r = _run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--n-vars", "15", "--no-cpu-baseline"],
+             {"BN_FORCE_SHARDED": "1", "BN_EXCHANGE": exchange})
+    assert r["bit_exact_check"] is True and r["n_gpus"] == 1
