@@ -1,0 +1,250 @@
+// binius_amd/csrc/kernels_ntt_bs.hip -- bit-sliced additive NTT for BinaryField32b data with
+// BinaryField32b twiddles (forward, one transform of 2^L elements: BASELINE config "2^24 coeffs over
+// BinaryField32b"; semantics of crates/ntt/src/tests/reference.rs:68-112).
+//
+// A butterfly is (u, v) -> (u + v*t, v + u + v*t) with a VARIABLE twiddle t per block, i.e. one
+// variable x variable GF(2^32) product per butterfly.  Word-level that is ~15 table lookups + ~60
+// VALU; bit-sliced (bitslice.hpp) it is ~1040 VALU per THIRTY-TWO products.
+//
+// Slicing.  Index p = c * S + i with c = the top 5 index bits, S = 2^(L-5).  The plane set of i is 32
+// registers W[j] whose bit c is bit j of element (c, i): 32 elements that are 2^(L-5) apart.
+//   * The 5 top layers (distance >= S) pair bit positions INSIDE the registers; their twiddles do not
+//     depend on i, so their plane patterns are launch constants (ttop).
+//   * A lower layer l pairs plane sets i and i + 2^l.  The twiddle of bit position c is
+//     tw(l, (c*S + i) >> (l+1)) -- and the twiddle is GF(2)-linear in its index
+//     (OnTheFlyTwiddleAccess: XOR of basis values, crates/ntt/src/twiddle.rs:141-168), so its planes
+//     are  pat[l][j] ^ broadcast(bit j of tw(l, i >> (l+1)) ^ coset term)  with pat a launch constant.
+//
+// Passes (HBM: 2 x 64 MiB each):  head = convert to plane sets + the 5 top layers;  then the lower
+// layers <= 6 at a time on a 512-set tile in LDS;  tail = convert back.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <vector>
+
+#include "bitslice.hpp"
+#include "internal.hpp"
+
+namespace bn {
+
+namespace {
+
+struct ntt_bs_tables {
+	uint32_t ttop[5][32];  // [b][j]: twiddle planes of the top layer with in-register distance 2^b
+	uint32_t pat[32][32];  // [l][j]: c-dependent part of the twiddle planes of lower layer l
+	uint32_t rows[32][32]; // [l][bit]: basis value of bit `bit` of the block index i >> (l+1)
+	uint32_t tconst[32];   // [l]: coset contribution (uniform)
+};
+
+constexpr int kSetQ = 9;     // LDS uint4 per plane set: 8 + 1 pad (bank spread)
+constexpr int kTileLog = 9;  // plane sets per tile = 512
+
+__device__ __forceinline__ void butterfly_planes(uint32_t (&U)[32], uint32_t (&V)[32], const uint32_t (&T)[32])
+{
+	uint32_t M[32];
+	bs_mul<5>(V, T, M);
+#pragma unroll
+	for (int j = 0; j < 32; j++) {
+		U[j] ^= M[j]; // u += v * t
+		V[j] ^= U[j]; // v += u
+	}
+}
+
+// ---- head: standard layout -> plane sets, then the five in-register layers (distance 16, 8, .., 1)
+__global__ __launch_bounds__(256) void k_ntt_bs_head(const uint32_t *__restrict__ data, uint4 *__restrict__ bs, uint64_t S,
+                                                     const ntt_bs_tables *__restrict__ tb)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+	if (i >= S) return;
+	uint32_t W[32];
+#pragma unroll
+	for (int c = 0; c < 32; c++)
+		W[c] = data[(uint64_t)c * S + i];
+	transpose32(W);
+#pragma unroll
+	for (int b = 4; b >= 0; b--) {
+		constexpr uint32_t masks[5] = {0x55555555u, 0x33333333u, 0x0F0F0F0Fu, 0x00FF00FFu, 0x0000FFFFu};
+		const uint32_t mk = masks[b];
+		const int sh = 1 << b;
+		uint32_t U[32], V[32], T[32];
+#pragma unroll
+		for (int j = 0; j < 32; j++) {
+			U[j] = W[j] & mk;
+			V[j] = (W[j] >> sh) & mk;
+			T[j] = tb->ttop[b][j];
+		}
+		butterfly_planes(U, V, T);
+#pragma unroll
+		for (int j = 0; j < 32; j++)
+			W[j] = U[j] | (V[j] << sh);
+	}
+	uint4 *dst = bs + i * 8;
+#pragma unroll
+	for (int k = 0; k < 8; k++)
+		dst[k] = uint4{W[4 * k], W[4 * k + 1], W[4 * k + 2], W[4 * k + 3]};
+}
+
+// ---- tail: plane sets -> standard layout
+__global__ __launch_bounds__(256) void k_ntt_bs_tail(const uint4 *__restrict__ bs, uint32_t *__restrict__ data, uint64_t S)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+	if (i >= S) return;
+	uint32_t W[32];
+	const uint4 *src = bs + i * 8;
+#pragma unroll
+	for (int k = 0; k < 8; k++) {
+		const uint4 v = src[k];
+		W[4 * k] = v.x;
+		W[4 * k + 1] = v.y;
+		W[4 * k + 2] = v.z;
+		W[4 * k + 3] = v.w;
+	}
+	transpose32(W); // (an involution)
+#pragma unroll
+	for (int c = 0; c < 32; c++)
+		data[(uint64_t)c * S + i] = W[c];
+}
+
+// ---- R lower layers l_lo + R - 1 .. l_lo on a tile of 512 plane sets held in LDS.
+// Tile-local set number s (9 bits) <-> index bits: run A = bits [0, n_lo), run B = bits
+// [l_lo, l_lo + 9 - n_lo) with n_lo = min(9 - R, l_lo); the butterfly bit of layer l_lo + t is local
+// bit n_lo + t.  The other index bits enumerate the tiles.
+__global__ __launch_bounds__(256, 2) void k_ntt_bs_pass(uint4 *__restrict__ bs, uint32_t l_lo, uint32_t R, uint32_t n_lo,
+                                                        const ntt_bs_tables *__restrict__ tb)
+{
+	extern __shared__ __attribute__((aligned(16))) uint4 tile[]; // [512][kSetQ]
+	const unsigned tid = threadIdx.x;
+	const uint32_t gap = l_lo - n_lo; // tile bits between the two local runs
+	const uint64_t b = blockIdx.x;
+	const uint64_t i_tile = ((b & (((uint64_t)1 << gap) - 1)) << n_lo) | ((b >> gap) << (l_lo + kTileLog - n_lo));
+	auto index_of = [&](unsigned s) -> uint64_t { return i_tile | (s & ((1u << n_lo) - 1)) | ((uint64_t)(s >> n_lo) << l_lo); };
+	// load: 512 sets x 8 chunks of 16 B
+#pragma unroll 4
+	for (unsigned k = 0; k < 16; k++) {
+		const unsigned idx = tid + 256 * k, s = idx >> 3, ch = idx & 7;
+		tile[s * kSetQ + ch] = bs[index_of(s) * 8 + ch];
+	}
+	__syncthreads();
+	for (int t = (int)R - 1; t >= 0; t--) {
+		const uint32_t l = l_lo + (uint32_t)t;
+		const unsigned pos = n_lo + (unsigned)t;
+		// butterfly tid: u set = tid with a zero inserted at bit `pos`
+		const unsigned s_u = ((tid >> pos) << (pos + 1)) | (tid & ((1u << pos) - 1));
+		const unsigned s_v = s_u | (1u << pos);
+		uint32_t U[32], V[32], T[32];
+#pragma unroll
+		for (int k = 0; k < 8; k++) {
+			const uint4 a = tile[s_u * kSetQ + k], c = tile[s_v * kSetQ + k];
+			U[4 * k] = a.x;
+			U[4 * k + 1] = a.y;
+			U[4 * k + 2] = a.z;
+			U[4 * k + 3] = a.w;
+			V[4 * k] = c.x;
+			V[4 * k + 1] = c.y;
+			V[4 * k + 2] = c.z;
+			V[4 * k + 3] = c.w;
+		}
+		// twiddle of bit position c: pat (c part) ^ tbase (i part + coset part), all XOR-linear
+		uint64_t q = index_of(s_u) >> (l + 1);
+		uint32_t tbase = tb->tconst[l];
+		for (unsigned bit = 0; q; bit++, q >>= 1)
+			if (q & 1) tbase ^= tb->rows[l][bit];
+#pragma unroll
+		for (int j = 0; j < 32; j++)
+			T[j] = tb->pat[l][j] ^ (uint32_t)__builtin_amdgcn_sbfe((int)tbase, j, 1);
+		butterfly_planes(U, V, T);
+#pragma unroll
+		for (int k = 0; k < 8; k++) {
+			tile[s_u * kSetQ + k] = uint4{U[4 * k], U[4 * k + 1], U[4 * k + 2], U[4 * k + 3]};
+			tile[s_v * kSetQ + k] = uint4{V[4 * k], V[4 * k + 1], V[4 * k + 2], V[4 * k + 3]};
+		}
+		__syncthreads();
+	}
+#pragma unroll 4
+	for (unsigned k = 0; k < 16; k++) {
+		const unsigned idx = tid + 256 * k, s = idx >> 3, ch = idx & 7;
+		bs[index_of(s) * 8 + ch] = tile[s * kSetQ + ch];
+	}
+}
+
+// OnTheFlyTwiddleAccess::get (twiddle.rs:141-168): XOR of the layer's basis values over the index bits
+uint32_t host_twiddle(const uint64_t *s_evals, uint32_t log_domain, uint32_t layer, uint64_t index)
+{
+	const uint64_t *row = s_evals + (size_t)layer * BN_NTT_MAX_DIM;
+	const int n_bits = (int)log_domain - 1 - (int)layer;
+	uint64_t t = 0;
+	for (int b = 0; b < n_bits; b++)
+		if ((index >> b) & 1) t ^= row[b];
+	return (uint32_t)t;
+}
+
+} // namespace
+
+// Forward NTT of ONE array of 2^log_y BinaryField32b elements (log_x = log_z = 0, skip_rounds = 0).
+// d_scratch: 2^log_y * 4 bytes for the plane sets + sizeof(ntt_bs_tables), 16-byte aligned.
+// Returns hipErrorNotSupported for shapes this path does not cover (the caller falls back).
+size_t ntt_bs_scratch_bytes(uint32_t log_y) { return ((size_t)4 << log_y) + sizeof(ntt_bs_tables) + 256; }
+
+hipError_t launch_ntt_bs_forward(hipStream_t s, void *data, const uint64_t *h_s_evals, uint32_t log_domain, uint32_t log_y,
+                                 uint64_t coset, uint32_t coset_bits, void *d_scratch)
+{
+	const uint32_t L = log_y;
+	if (L < 5 + kTileLog || L > 31) return hipErrorNotSupported;
+	const uint32_t NB = L - 5;           // lower layers
+	const uint64_t S = (uint64_t)1 << NB; // plane sets
+	const uint32_t base = log_domain - (log_y + coset_bits);
+	// ---- launch constants
+	static thread_local ntt_bs_tables tb;
+	std::memset(&tb, 0, sizeof(tb));
+	for (uint32_t b = 0; b < 5; b++) {
+		const uint32_t l = NB + b;
+		for (uint32_t c = 0; c < 32; c++) {
+			if ((c >> b) & 1) continue; // u positions only
+			const uint32_t tw = host_twiddle(h_s_evals, log_domain, base + l, (coset << (L - 1 - l)) | (c >> (b + 1)));
+			for (uint32_t j = 0; j < 32; j++)
+				if ((tw >> j) & 1) tb.ttop[b][j] |= 1u << c;
+		}
+	}
+	for (uint32_t l = 0; l < NB; l++) {
+		// (c*S + i) >> (l+1) = (c << (NB - l - 1)) + (i >> (l+1)): no carries, the twiddle splits
+		for (uint32_t c = 0; c < 32; c++) {
+			const uint32_t tw = host_twiddle(h_s_evals, log_domain, base + l, (uint64_t)c << (NB - l - 1));
+			for (uint32_t j = 0; j < 32; j++)
+				if ((tw >> j) & 1) tb.pat[l][j] |= 1u << c;
+		}
+		for (uint32_t bit = 0; bit < NB - l - 1 && bit < 32; bit++)
+			tb.rows[l][bit] = host_twiddle(h_s_evals, log_domain, base + l, (uint64_t)1 << bit);
+		tb.tconst[l] = host_twiddle(h_s_evals, log_domain, base + l, coset << (L - 1 - l));
+	}
+	uint4 *bs = (uint4 *)d_scratch;
+	ntt_bs_tables *d_tb = (ntt_bs_tables *)((char *)d_scratch + (((size_t)4 << L) + 255) / 256 * 256);
+	hipError_t e = hipMemcpyAsync(d_tb, &tb, sizeof(tb), hipMemcpyHostToDevice, s);
+	if (e != hipSuccess) return e;
+	e = hipStreamSynchronize(s); // tb is reused by the next call
+	if (e != hipSuccess) return e;
+
+	const unsigned blocks = (unsigned)((S + 255) / 256);
+	hipLaunchKernelGGL(k_ntt_bs_head, dim3(blocks), dim3(256), 0, s, (const uint32_t *)data, bs, S, d_tb);
+	const size_t lds = (size_t)(1 << kTileLog) * kSetQ * sizeof(uint4);
+	static bool attr_set = false;
+	if (!attr_set) {
+		e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ntt_bs_pass), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		if (e != hipSuccess) return e;
+		attr_set = true;
+	}
+	// lower layers from NB-1 down to 0, at most 6 per pass
+	uint32_t hi = NB; // layers [0, hi) remain
+	while (hi > 0) {
+		const uint32_t n_pass = (hi + 5) / 6;
+		const uint32_t R = (hi + n_pass - 1) / n_pass; // even split
+		const uint32_t l_lo = hi - R;
+		const uint32_t Q = kTileLog - R;
+		const uint32_t n_lo = Q < l_lo ? Q : l_lo;
+		hipLaunchKernelGGL(k_ntt_bs_pass, dim3((unsigned)(S >> kTileLog)), dim3(256), lds, s, bs, l_lo, R, n_lo, d_tb);
+		hi = l_lo;
+	}
+	hipLaunchKernelGGL(k_ntt_bs_tail, dim3(blocks), dim3(256), 0, s, bs, (uint32_t *)data, S);
+	return hipGetLastError();
+}
+
+} // namespace bn

@@ -31,6 +31,13 @@ def make_data(oracle, seed, n, elem_level):
     [
         (5, 5, 12, 0, 12, 0, 0, 0, 0),
         (5, 5, 14, 0, 10, 0, 5, 3, 0),
+        # large single B32 transforms: the bit-sliced path (kernels_ntt_bs.hip), every pass split
+        (5, 5, 14, 0, 14, 0, 0, 0, 0),
+        (5, 5, 15, 0, 15, 0, 0, 0, 0),
+        (5, 5, 19, 0, 16, 0, 5, 3, 0),
+        (5, 5, 17, 0, 17, 0, 0, 0, 0),
+        (5, 5, 20, 0, 19, 0, 1, 1, 0),
+        (5, 5, 20, 0, 20, 0, 0, 0, 0),
         (5, 5, 12, 2, 8, 1, 1, 2, 0),
         (5, 5, 12, 0, 10, 0, 0, 0, 3),
         (7, 5, 12, 0, 10, 0, 0, 1, 0),
