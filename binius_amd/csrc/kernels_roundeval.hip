@@ -193,6 +193,19 @@ hipError_t launch_roundeval_product(hipStream_t s, int n_cu, const void *const *
 {
 	if (k == 2 && lo[0] && lo[1])
 		return launch_roundeval9_pair(s, n_cu, hi[0], lo[0], hi[1], lo[1], n, d_out, fuse);
+	if (k == 3) {
+		// a * b * eq (MLE-check): exactly one factor is the same at both evaluation points
+		int same = -1, n_same = 0;
+		for (int j = 0; j < 3; j++)
+			if (!lo[j]) {
+				same = j;
+				n_same++;
+			}
+		if (n_same == 1) {
+			const int x = (same + 1) % 3, y = (same + 2) % 3;
+			return launch_roundeval9_eq(s, n_cu, hi[x], lo[x], hi[y], lo[y], hi[same], n, d_out, fuse);
+		}
+	}
 	if (fuse) return hipErrorNotSupported; // caller falls back to the stand-alone finalize kernel
 	bs_job job{};
 	job.k = k;
