@@ -1,6 +1,8 @@
-// binius_amd/csrc/kernels_ntt_bs.hip -- bit-sliced additive NTT for BinaryField32b data with
-// BinaryField32b twiddles (forward, one transform of 2^L elements: BASELINE config "2^24 coeffs over
-// BinaryField32b"; semantics of crates/ntt/src/tests/reference.rs:68-112).
+// binius_amd/csrc/kernels_ntt_bs.hip -- bit-sliced additive NTT with BinaryField32b twiddles (forward;
+// BASELINE config "2^24 coeffs over BinaryField32b"; semantics of crates/ntt/src/tests/reference.rs
+// :68-112 with the batching of :170-204).  Data of a larger field (B64, B128) is 2 or 4 interleaved
+// B32 columns -- a B32 scalar acts limb-wise -- so every shape is a batch of B32 transforms: word
+// address of element p of batch (z, x) = ((z << log_y | p) << lx) | x, lx = log_x + (elem_level - 5).
 //
 // A butterfly is (u, v) -> (u + v*t, v + u + v*t) with a VARIABLE twiddle t per block, i.e. one
 // variable x variable GF(2^32) product per butterfly.  Word-level that is ~15 table lookups + ~60
@@ -51,15 +53,19 @@ __device__ __forceinline__ void butterfly_planes(uint32_t (&U)[32], uint32_t (&V
 }
 
 // ---- head: standard layout -> plane sets, then the five in-register layers (distance 16, 8, .., 1)
-__global__ __launch_bounds__(256) void k_ntt_bs_head(const uint32_t *__restrict__ data, uint4 *__restrict__ bs, uint64_t S,
-                                                     const ntt_bs_tables *__restrict__ tb)
+// batch beta = blockIdx.y: x = beta & (2^lx - 1), z = beta >> lx
+__global__ __launch_bounds__(256) void k_ntt_bs_head(const uint32_t *__restrict__ data, uint4 *__restrict__ bs, uint64_t S, uint32_t lx,
+                                                     uint32_t log_y, const ntt_bs_tables *__restrict__ tb)
 {
 	const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
 	if (i >= S) return;
+	const uint64_t beta = blockIdx.y;
+	data += ((beta >> lx) << (log_y + lx)) + (beta & (((uint64_t)1 << lx) - 1));
+	bs += beta * S * 8;
 	uint32_t W[32];
 #pragma unroll
 	for (int c = 0; c < 32; c++)
-		W[c] = data[(uint64_t)c * S + i];
+		W[c] = data[((uint64_t)c * S + i) << lx];
 	transpose32(W);
 #pragma unroll
 	for (int b = 4; b >= 0; b--) {
@@ -85,10 +91,14 @@ __global__ __launch_bounds__(256) void k_ntt_bs_head(const uint32_t *__restrict_
 }
 
 // ---- tail: plane sets -> standard layout
-__global__ __launch_bounds__(256) void k_ntt_bs_tail(const uint4 *__restrict__ bs, uint32_t *__restrict__ data, uint64_t S)
+__global__ __launch_bounds__(256) void k_ntt_bs_tail(const uint4 *__restrict__ bs, uint32_t *__restrict__ data, uint64_t S, uint32_t lx,
+                                                     uint32_t log_y)
 {
 	const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
 	if (i >= S) return;
+	const uint64_t beta = blockIdx.y;
+	data += ((beta >> lx) << (log_y + lx)) + (beta & (((uint64_t)1 << lx) - 1));
+	bs += beta * S * 8;
 	uint32_t W[32];
 	const uint4 *src = bs + i * 8;
 #pragma unroll
@@ -102,18 +112,19 @@ __global__ __launch_bounds__(256) void k_ntt_bs_tail(const uint4 *__restrict__ b
 	transpose32(W); // (an involution)
 #pragma unroll
 	for (int c = 0; c < 32; c++)
-		data[(uint64_t)c * S + i] = W[c];
+		data[((uint64_t)c * S + i) << lx] = W[c];
 }
 
 // ---- R lower layers l_lo + R - 1 .. l_lo on a tile of 512 plane sets held in LDS.
 // Tile-local set number s (9 bits) <-> index bits: run A = bits [0, n_lo), run B = bits
 // [l_lo, l_lo + 9 - n_lo) with n_lo = min(9 - R, l_lo); the butterfly bit of layer l_lo + t is local
 // bit n_lo + t.  The other index bits enumerate the tiles.
-__global__ __launch_bounds__(256, 2) void k_ntt_bs_pass(uint4 *__restrict__ bs, uint32_t l_lo, uint32_t R, uint32_t n_lo,
+__global__ __launch_bounds__(256, 2) void k_ntt_bs_pass(uint4 *__restrict__ bs, uint64_t S, uint32_t l_lo, uint32_t R, uint32_t n_lo,
                                                         const ntt_bs_tables *__restrict__ tb)
 {
 	extern __shared__ __attribute__((aligned(16))) uint4 tile[]; // [512][kSetQ]
 	const unsigned tid = threadIdx.x;
+	bs += (uint64_t)blockIdx.y * S * 8; // batch
 	const uint32_t gap = l_lo - n_lo; // tile bits between the two local runs
 	const uint64_t b = blockIdx.x;
 	const uint64_t i_tile = ((b & (((uint64_t)1 << gap) - 1)) << n_lo) | ((b >> gap) << (l_lo + kTileLog - n_lo));
@@ -180,18 +191,19 @@ uint32_t host_twiddle(const uint64_t *s_evals, uint32_t log_domain, uint32_t lay
 
 } // namespace
 
-// Forward NTT of ONE array of 2^log_y BinaryField32b elements (log_x = log_z = 0, skip_rounds = 0).
-// d_scratch: 2^log_y * 4 bytes for the plane sets + sizeof(ntt_bs_tables), 16-byte aligned.
+// Forward NTT of 2^(lx + log_z) interleaved B32 transforms of 2^log_y elements each (skip_rounds = 0).
+// d_scratch: ntt_bs_scratch_bytes() bytes, 256-byte aligned.
 // Returns hipErrorNotSupported for shapes this path does not cover (the caller falls back).
-size_t ntt_bs_scratch_bytes(uint32_t log_y) { return ((size_t)4 << log_y) + sizeof(ntt_bs_tables) + 256; }
+size_t ntt_bs_scratch_bytes(uint32_t log_words) { return ((size_t)4 << log_words) + sizeof(ntt_bs_tables) + 256; }
 
-hipError_t launch_ntt_bs_forward(hipStream_t s, void *data, const uint64_t *h_s_evals, uint32_t log_domain, uint32_t log_y,
-                                 uint64_t coset, uint32_t coset_bits, void *d_scratch)
+hipError_t launch_ntt_bs_forward(hipStream_t s, void *data, const uint64_t *h_s_evals, uint32_t log_domain, uint32_t lx, uint32_t log_y,
+                                 uint32_t log_z, uint64_t coset, uint32_t coset_bits, void *d_scratch)
 {
 	const uint32_t L = log_y;
-	if (L < 5 + kTileLog || L > 31) return hipErrorNotSupported;
+	if (L < 5 + kTileLog || L > 31 || lx + log_z > 12) return hipErrorNotSupported;
+	const unsigned n_batch = 1u << (lx + log_z);
 	const uint32_t NB = L - 5;           // lower layers
-	const uint64_t S = (uint64_t)1 << NB; // plane sets
+	const uint64_t S = (uint64_t)1 << NB; // plane sets per transform
 	const uint32_t base = log_domain - (log_y + coset_bits);
 	// ---- launch constants
 	static thread_local ntt_bs_tables tb;
@@ -217,14 +229,14 @@ hipError_t launch_ntt_bs_forward(hipStream_t s, void *data, const uint64_t *h_s_
 		tb.tconst[l] = host_twiddle(h_s_evals, log_domain, base + l, coset << (L - 1 - l));
 	}
 	uint4 *bs = (uint4 *)d_scratch;
-	ntt_bs_tables *d_tb = (ntt_bs_tables *)((char *)d_scratch + (((size_t)4 << L) + 255) / 256 * 256);
+	ntt_bs_tables *d_tb = (ntt_bs_tables *)((char *)d_scratch + (((size_t)4 << (L + lx + log_z)) + 255) / 256 * 256);
 	hipError_t e = hipMemcpyAsync(d_tb, &tb, sizeof(tb), hipMemcpyHostToDevice, s);
 	if (e != hipSuccess) return e;
 	e = hipStreamSynchronize(s); // tb is reused by the next call
 	if (e != hipSuccess) return e;
 
 	const unsigned blocks = (unsigned)((S + 255) / 256);
-	hipLaunchKernelGGL(k_ntt_bs_head, dim3(blocks), dim3(256), 0, s, (const uint32_t *)data, bs, S, d_tb);
+	hipLaunchKernelGGL(k_ntt_bs_head, dim3(blocks, n_batch), dim3(256), 0, s, (const uint32_t *)data, bs, S, lx, log_y, d_tb);
 	const size_t lds = (size_t)(1 << kTileLog) * kSetQ * sizeof(uint4);
 	static bool attr_set = false;
 	if (!attr_set) {
@@ -240,10 +252,10 @@ hipError_t launch_ntt_bs_forward(hipStream_t s, void *data, const uint64_t *h_s_
 		const uint32_t l_lo = hi - R;
 		const uint32_t Q = kTileLog - R;
 		const uint32_t n_lo = Q < l_lo ? Q : l_lo;
-		hipLaunchKernelGGL(k_ntt_bs_pass, dim3((unsigned)(S >> kTileLog)), dim3(256), lds, s, bs, l_lo, R, n_lo, d_tb);
+		hipLaunchKernelGGL(k_ntt_bs_pass, dim3((unsigned)(S >> kTileLog), n_batch), dim3(256), lds, s, bs, S, l_lo, R, n_lo, d_tb);
 		hi = l_lo;
 	}
-	hipLaunchKernelGGL(k_ntt_bs_tail, dim3(blocks), dim3(256), 0, s, bs, (uint32_t *)data, S);
+	hipLaunchKernelGGL(k_ntt_bs_tail, dim3(blocks, n_batch), dim3(256), 0, s, bs, (uint32_t *)data, S, lx, log_y);
 	return hipGetLastError();
 }
 

@@ -38,6 +38,11 @@ def make_data(oracle, seed, n, elem_level):
         (5, 5, 17, 0, 17, 0, 0, 0, 0),
         (5, 5, 20, 0, 19, 0, 1, 1, 0),
         (5, 5, 20, 0, 20, 0, 0, 0, 0),
+        # the same path for batches and for B64 / B128 data (interleaved B32 columns)
+        (5, 5, 16, 2, 14, 1, 1, 1, 0),
+        (6, 5, 15, 0, 15, 0, 0, 0, 0),
+        (7, 5, 16, 0, 15, 0, 1, 1, 0),
+        (7, 5, 14, 1, 14, 1, 0, 0, 0),
         (5, 5, 12, 2, 8, 1, 1, 2, 0),
         (5, 5, 12, 0, 10, 0, 0, 0, 3),
         (7, 5, 12, 0, 10, 0, 0, 1, 0),
