@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstring>
+#include <utility>
 #include <vector>
 
 #include "bitslice.hpp"
@@ -41,19 +42,51 @@ struct ntt_bs_tables {
 constexpr int kSetQ = 9;     // LDS uint4 per plane set: 8 + 1 pad (bank spread)
 constexpr int kTileLog = 9;  // plane sets per tile = 512
 
+// forward: u += v*t; v += u        inverse: v += u; u += v*t   (reference.rs:96-104 / :143-151)
+template <bool INV>
 __device__ __forceinline__ void butterfly_planes(uint32_t (&U)[32], uint32_t (&V)[32], const uint32_t (&T)[32])
 {
 	uint32_t M[32];
+	if (INV) {
+#pragma unroll
+		for (int j = 0; j < 32; j++)
+			V[j] ^= U[j];
+	}
 	bs_mul<5>(V, T, M);
 #pragma unroll
 	for (int j = 0; j < 32; j++) {
-		U[j] ^= M[j]; // u += v * t
-		V[j] ^= U[j]; // v += u
+		U[j] ^= M[j];
+		if (!INV) V[j] ^= U[j];
 	}
 }
 
-// ---- head: standard layout -> plane sets, then the five in-register layers (distance 16, 8, .., 1)
+// the five in-register layers of a plane set (distance 2^b in the bit positions)
+template <bool INV>
+__device__ __forceinline__ void top_layers(uint32_t (&W)[32], const uint32_t (*ttop)[32])
+{
+#pragma unroll
+	for (int bb = 0; bb < 5; bb++) {
+		const int b = INV ? bb : 4 - bb;
+		constexpr uint32_t masks[5] = {0x55555555u, 0x33333333u, 0x0F0F0F0Fu, 0x00FF00FFu, 0x0000FFFFu};
+		const uint32_t mk = masks[b];
+		const int sh = 1 << b;
+		uint32_t U[32], V[32], T[32];
+#pragma unroll
+		for (int j = 0; j < 32; j++) {
+			U[j] = W[j] & mk;
+			V[j] = (W[j] >> sh) & mk;
+			T[j] = ttop[b][j];
+		}
+		butterfly_planes<INV>(U, V, T);
+#pragma unroll
+		for (int j = 0; j < 32; j++)
+			W[j] = U[j] | (V[j] << sh);
+	}
+}
+
+// ---- head: standard layout -> plane sets; forward: then the five in-register layers (16, 8, .., 1)
 // batch beta = blockIdx.y: x = beta & (2^lx - 1), z = beta >> lx
+template <bool INV>
 __global__ __launch_bounds__(256) void k_ntt_bs_head(const uint32_t *__restrict__ data, uint4 *__restrict__ bs, uint64_t S, uint32_t lx,
                                                      uint32_t log_y, const ntt_bs_tables *__restrict__ tb)
 {
@@ -67,32 +100,17 @@ __global__ __launch_bounds__(256) void k_ntt_bs_head(const uint32_t *__restrict_
 	for (int c = 0; c < 32; c++)
 		W[c] = data[((uint64_t)c * S + i) << lx];
 	transpose32(W);
-#pragma unroll
-	for (int b = 4; b >= 0; b--) {
-		constexpr uint32_t masks[5] = {0x55555555u, 0x33333333u, 0x0F0F0F0Fu, 0x00FF00FFu, 0x0000FFFFu};
-		const uint32_t mk = masks[b];
-		const int sh = 1 << b;
-		uint32_t U[32], V[32], T[32];
-#pragma unroll
-		for (int j = 0; j < 32; j++) {
-			U[j] = W[j] & mk;
-			V[j] = (W[j] >> sh) & mk;
-			T[j] = tb->ttop[b][j];
-		}
-		butterfly_planes(U, V, T);
-#pragma unroll
-		for (int j = 0; j < 32; j++)
-			W[j] = U[j] | (V[j] << sh);
-	}
+	if (!INV) top_layers<false>(W, tb->ttop);
 	uint4 *dst = bs + i * 8;
 #pragma unroll
 	for (int k = 0; k < 8; k++)
 		dst[k] = uint4{W[4 * k], W[4 * k + 1], W[4 * k + 2], W[4 * k + 3]};
 }
 
-// ---- tail: plane sets -> standard layout
+// ---- tail: (inverse: the five in-register layers 1, 2, .., 16, then) plane sets -> standard layout
+template <bool INV>
 __global__ __launch_bounds__(256) void k_ntt_bs_tail(const uint4 *__restrict__ bs, uint32_t *__restrict__ data, uint64_t S, uint32_t lx,
-                                                     uint32_t log_y)
+                                                     uint32_t log_y, const ntt_bs_tables *__restrict__ tb)
 {
 	const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
 	if (i >= S) return;
@@ -109,6 +127,7 @@ __global__ __launch_bounds__(256) void k_ntt_bs_tail(const uint4 *__restrict__ b
 		W[4 * k + 2] = v.z;
 		W[4 * k + 3] = v.w;
 	}
+	if (INV) top_layers<true>(W, tb->ttop);
 	transpose32(W); // (an involution)
 #pragma unroll
 	for (int c = 0; c < 32; c++)
@@ -119,6 +138,7 @@ __global__ __launch_bounds__(256) void k_ntt_bs_tail(const uint4 *__restrict__ b
 // Tile-local set number s (9 bits) <-> index bits: run A = bits [0, n_lo), run B = bits
 // [l_lo, l_lo + 9 - n_lo) with n_lo = min(9 - R, l_lo); the butterfly bit of layer l_lo + t is local
 // bit n_lo + t.  The other index bits enumerate the tiles.
+template <bool INV>
 __global__ __launch_bounds__(256, 2) void k_ntt_bs_pass(uint4 *__restrict__ bs, uint64_t S, uint32_t l_lo, uint32_t R, uint32_t n_lo,
                                                         const ntt_bs_tables *__restrict__ tb)
 {
@@ -136,7 +156,8 @@ __global__ __launch_bounds__(256, 2) void k_ntt_bs_pass(uint4 *__restrict__ bs, 
 		tile[s * kSetQ + ch] = bs[index_of(s) * 8 + ch];
 	}
 	__syncthreads();
-	for (int t = (int)R - 1; t >= 0; t--) {
+	for (int tt = 0; tt < (int)R; tt++) {
+		const int t = INV ? tt : (int)R - 1 - tt; // forward: high layer first
 		const uint32_t l = l_lo + (uint32_t)t;
 		const unsigned pos = n_lo + (unsigned)t;
 		// butterfly tid: u set = tid with a zero inserted at bit `pos`
@@ -163,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void k_ntt_bs_pass(uint4 *__restrict__ bs, 
 #pragma unroll
 		for (int j = 0; j < 32; j++)
 			T[j] = tb->pat[l][j] ^ (uint32_t)__builtin_amdgcn_sbfe((int)tbase, j, 1);
-		butterfly_planes(U, V, T);
+		butterfly_planes<INV>(U, V, T);
 #pragma unroll
 		for (int k = 0; k < 8; k++) {
 			tile[s_u * kSetQ + k] = uint4{U[4 * k], U[4 * k + 1], U[4 * k + 2], U[4 * k + 3]};
@@ -191,13 +212,14 @@ uint32_t host_twiddle(const uint64_t *s_evals, uint32_t log_domain, uint32_t lay
 
 } // namespace
 
-// Forward NTT of 2^(lx + log_z) interleaved B32 transforms of 2^log_y elements each (skip_rounds = 0).
+// Forward / inverse NTT of 2^(lx + log_z) interleaved B32 transforms of 2^log_y elements each (skip_rounds = 0).
 // d_scratch: ntt_bs_scratch_bytes() bytes, 256-byte aligned.
 // Returns hipErrorNotSupported for shapes this path does not cover (the caller falls back).
 size_t ntt_bs_scratch_bytes(uint32_t log_words) { return ((size_t)4 << log_words) + sizeof(ntt_bs_tables) + 256; }
 
-hipError_t launch_ntt_bs_forward(hipStream_t s, void *data, const uint64_t *h_s_evals, uint32_t log_domain, uint32_t lx, uint32_t log_y,
-                                 uint32_t log_z, uint64_t coset, uint32_t coset_bits, void *d_scratch)
+template <bool INV>
+static hipError_t run_ntt_bs(hipStream_t s, void *data, const uint64_t *h_s_evals, uint32_t log_domain, uint32_t lx, uint32_t log_y,
+                             uint32_t log_z, uint64_t coset, uint32_t coset_bits, void *d_scratch)
 {
 	const uint32_t L = log_y;
 	if (L < 5 + kTileLog || L > 31 || lx + log_z > 12) return hipErrorNotSupported;
@@ -236,27 +258,37 @@ hipError_t launch_ntt_bs_forward(hipStream_t s, void *data, const uint64_t *h_s_
 	if (e != hipSuccess) return e;
 
 	const unsigned blocks = (unsigned)((S + 255) / 256);
-	hipLaunchKernelGGL(k_ntt_bs_head, dim3(blocks, n_batch), dim3(256), 0, s, (const uint32_t *)data, bs, S, lx, log_y, d_tb);
+	hipLaunchKernelGGL(k_ntt_bs_head<INV>, dim3(blocks, n_batch), dim3(256), 0, s, (const uint32_t *)data, bs, S, lx, log_y, d_tb);
 	const size_t lds = (size_t)(1 << kTileLog) * kSetQ * sizeof(uint4);
 	static bool attr_set = false;
 	if (!attr_set) {
-		e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ntt_bs_pass), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ntt_bs_pass<INV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 		if (e != hipSuccess) return e;
 		attr_set = true;
 	}
-	// lower layers from NB-1 down to 0, at most 6 per pass
-	uint32_t hi = NB; // layers [0, hi) remain
-	while (hi > 0) {
+	// lower layers, at most 6 per pass: forward from NB-1 down to 0, inverse from 0 up to NB-1
+	std::vector<std::pair<uint32_t, uint32_t>> plan; // (l_lo, R), highest layers first
+	for (uint32_t hi = NB; hi > 0;) {
 		const uint32_t n_pass = (hi + 5) / 6;
 		const uint32_t R = (hi + n_pass - 1) / n_pass; // even split
-		const uint32_t l_lo = hi - R;
-		const uint32_t Q = kTileLog - R;
-		const uint32_t n_lo = Q < l_lo ? Q : l_lo;
-		hipLaunchKernelGGL(k_ntt_bs_pass, dim3((unsigned)(S >> kTileLog), n_batch), dim3(256), lds, s, bs, S, l_lo, R, n_lo, d_tb);
-		hi = l_lo;
+		plan.push_back({hi - R, R});
+		hi -= R;
 	}
-	hipLaunchKernelGGL(k_ntt_bs_tail, dim3(blocks, n_batch), dim3(256), 0, s, bs, (uint32_t *)data, S, lx, log_y);
+	for (size_t k = 0; k < plan.size(); k++) {
+		const auto &pr = INV ? plan[plan.size() - 1 - k] : plan[k];
+		const uint32_t l_lo = pr.first, R = pr.second, Q = kTileLog - R;
+		const uint32_t n_lo = Q < l_lo ? Q : l_lo;
+		hipLaunchKernelGGL(k_ntt_bs_pass<INV>, dim3((unsigned)(S >> kTileLog), n_batch), dim3(256), lds, s, bs, S, l_lo, R, n_lo, d_tb);
+	}
+	hipLaunchKernelGGL(k_ntt_bs_tail<INV>, dim3(blocks, n_batch), dim3(256), 0, s, bs, (uint32_t *)data, S, lx, log_y, d_tb);
 	return hipGetLastError();
+}
+
+hipError_t launch_ntt_bs(hipStream_t s, bool inverse, void *data, const uint64_t *h_s_evals, uint32_t log_domain, uint32_t lx,
+                         uint32_t log_y, uint32_t log_z, uint64_t coset, uint32_t coset_bits, void *d_scratch)
+{
+	return inverse ? run_ntt_bs<true>(s, data, h_s_evals, log_domain, lx, log_y, log_z, coset, coset_bits, d_scratch)
+	               : run_ntt_bs<false>(s, data, h_s_evals, log_domain, lx, log_y, log_z, coset, coset_bits, d_scratch);
 }
 
 } // namespace bn
