@@ -176,11 +176,23 @@ __global__ __launch_bounds__(256, 2) void k_ntt_bs_pass(uint4 *__restrict__ bs, 
 			V[4 * k + 2] = c.z;
 			V[4 * k + 3] = c.w;
 		}
-		// twiddle of bit position c: pat (c part) ^ tbase (i part + coset part), all XOR-linear
-		uint64_t q = index_of(s_u) >> (l + 1);
+		// twiddle of bit position c: pat (c part) ^ tbase (i part + coset part), all XOR-linear.  The
+		// index bits of this set split into the tile's (wave-uniform: scalar loop) and the <= 9 local
+		// ones (one conditional XOR each, basis values through scalar loads) -- no divergent loop.
 		uint32_t tbase = tb->tconst[l];
-		for (unsigned bit = 0; q; bit++, q >>= 1)
-			if (q & 1) tbase ^= tb->rows[l][bit];
+		{
+			uint64_t qt = i_tile >> (l + 1);
+			for (unsigned bit = 0; qt; bit++, qt >>= 1)
+				if (qt & 1) tbase ^= tb->rows[l][bit];
+#pragma unroll
+			for (unsigned k = 0; k < (unsigned)kTileLog; k++) {
+				const unsigned gp = k < n_lo ? k : l_lo + k - n_lo; // index bit of local bit k
+				if (gp > l) {
+					const uint32_t rv = tb->rows[l][gp - (l + 1)];
+					tbase ^= ((s_u >> k) & 1) ? rv : 0u;
+				}
+			}
+		}
 #pragma unroll
 		for (int j = 0; j < 32; j++)
 			T[j] = tb->pat[l][j] ^ (uint32_t)__builtin_amdgcn_sbfe((int)tbase, j, 1);
