@@ -115,12 +115,24 @@ def main():
     d_partial, d_gathered, rccl, shm = 0, 0, None, None
     if reducer is not None and exchange == "shm":
         # the round loop runs exactly as on one GPU (fused kernels, result mailbox); the ranks' partials
-        # meet in a shared-memory segment (binius_amd/host/host_capi.cpp bnh_shm_*)
+        # meet in a shared-memory segment (binius_amd/host/host_capi.cpp bnh_shm_*).  If the segment
+        # cannot be set up on any rank, every rank falls back to the RCCL transport.
         from binius_amd._host import ShmExchange
 
-        shm = ShmExchange(dist, rank, world)
+        try:
+            shm = ShmExchange(dist, rank, world)
+            ok = 1
+        except Exception as ex:  # noqa: BLE001
+            print("[bench] rank %d: shared-memory exchange unavailable (%s)" % (rank, ex), file=sys.stderr)
+            shm, ok = None, 0
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            if shm is not None:
+                shm.close()
+            shm, exchange = None, "rccl"
         comm = shm
-    elif reducer is not None:
+    if reducer is not None and exchange != "shm":
         # the per-round collective is issued from the compiled host loop: ncclAllGather of the 32-byte
         # partial on the context's stream, communicator bootstrapped over the torch process group
         from binius_amd._host import RcclComm
