@@ -123,7 +123,6 @@ struct fold_batch {
 hipError_t launch_extrapolate_line_batch(hipStream_t s, int n_cu, const fold_batch &b, uint32_t count, uint64_t n, f128 z);
 hipError_t launch_fold_publish(hipStream_t s, void *const *x0, const void *const *src0, const void *const *x1, uint32_t count, uint32_t n,
                                f128 z, f128 *d_mail, uint64_t seq);
-hipError_t launch_tensor_expand_pass(hipStream_t s, int n_cu, void *data, uint64_t half, f128 r);
 hipError_t launch_tensor_expand(hipStream_t s, int n_cu, void *data, uint32_t log_n, const f128 *coords, uint32_t k);
 
 // ---- kernels_roundeval.hip
@@ -159,9 +158,6 @@ struct fin_fuse {
 	f128 *mail;
 	unsigned *counter; // zero before the launch; the last workgroup resets it
 };
-// raw (unscaled) sums S1 = sum_i a[half+i]*b[half+i], Sinf = sum_i (a[i]+a[half+i])*(b[i]+b[half+i])
-// XOR-accumulated into d_out[0], d_out[1] (caller zeroes them first).
-hipError_t launch_roundeval_product2(hipStream_t s, int n_cu, const void *a, const void *b, uint64_t half, f128 *d_out);
 // generic: sum_i C(rows[0][i], ..) over a circuit, XOR-accumulated into d_out[0]
 hipError_t launch_sum_composition_generic(hipStream_t s, int n_cu, const void *const *d_rows_dev, uint32_t n_rows,
                                           uint64_t row_len, const bn_step *d_steps, uint32_t n_steps, f128 *d_out);
@@ -196,8 +192,6 @@ hipError_t launch_fold_right(hipStream_t s, int n_cu, const void *mat, uint32_t 
                              uint64_t vec_len, void *out, uint64_t out_len);
 hipError_t launch_compute_composite_generic(hipStream_t s, const void *const *d_rows_dev, uint32_t n_rows,
                                             uint64_t row_len, void *out, const bn_step *d_steps, uint32_t n_steps);
-hipError_t launch_mul_elementwise(hipStream_t s, int n_cu, const void *a, const void *b, void *out, uint64_t n,
-                                  uint64_t a_stride, uint64_t b_stride, uint64_t b_off);
 hipError_t launch_fri_fold(hipStream_t s, const uint64_t *d_s_evals, uint32_t tw_level, uint32_t log_domain,
                            uint32_t log_len, uint32_t log_batch, const f128 *h_challenges, uint32_t n_challenges,
                            const void *in, void *out, uint64_t out_len, void *scratch);

@@ -245,25 +245,6 @@ hipError_t launch_fold_right(hipStream_t s, int n_cu, const void *mat, uint32_t 
 	return dispatch_level<foldr_launcher>(tower_level, s, g, mat, vec, vec_len, out, out_len);
 }
 
-// out[i] = a[i*a_stride] * b[b_off + i*b_stride]   (pairwise_product_reduce: a = in, strides 2, b_off 1)
-__global__ __launch_bounds__(256) void k_mul_elementwise(const uint4 *a, const uint4 *b, uint4 *out, uint64_t n,
-                                                         uint64_t a_stride, uint64_t b_stride, uint64_t b_off)
-{
-	for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256)
-		out[i] = to_u4(mul_slow(to_f128(a[i * a_stride]), to_f128(b[b_off + i * b_stride])));
-}
-
-hipError_t launch_mul_elementwise(hipStream_t s, int n_cu, const void *a, const void *b, void *out, uint64_t n,
-                                  uint64_t a_stride, uint64_t b_stride, uint64_t b_off)
-{
-	if (n == 0) return hipSuccess;
-	uint64_t want = (n + 255) / 256;
-	unsigned g = (unsigned)(want < (uint64_t)n_cu * 8 ? want : (uint64_t)n_cu * 8);
-	hipLaunchKernelGGL(k_mul_elementwise, dim3(g), dim3(256), 0, s, (const uint4 *)a, (const uint4 *)b, (uint4 *)out, n,
-	                   a_stride, b_stride, b_off);
-	return hipGetLastError();
-}
-
 // ---- fri_fold as halving passes ---------------------------------------------------------------
 // Reference semantics: crates/compute/src/cpu/layer.rs:345-388.  Per output chunk the reference
 // folds 2^b interleaved symbols with the b interleave challenges, then for every fold challenge

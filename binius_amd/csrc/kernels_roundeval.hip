@@ -220,13 +220,6 @@ hipError_t launch_roundeval_product(hipStream_t s, int n_cu, const void *const *
 	return hipGetLastError();
 }
 
-hipError_t launch_roundeval_product2(hipStream_t s, int n_cu, const void *a, const void *b, uint64_t half, f128 *d_out)
-{
-	const void *hi[2] = {(const char *)a + half * 16, (const char *)b + half * 16};
-	const void *lo[2] = {a, b};
-	return launch_roundeval_product(s, n_cu, hi, lo, 2, half, d_out, nullptr);
-}
-
 // d_out[0] ^= sum_i prod_j rows[j][i]   (d_out[1] is used as a second partial; caller XORs both)
 hipError_t launch_sum_product(hipStream_t s, int n_cu, const void *const *rows, uint32_t n_rows, uint64_t row_len,
                               f128 *d_out)

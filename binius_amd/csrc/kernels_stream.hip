@@ -1,5 +1,5 @@
 // binius_amd/csrc/kernels_stream.hip -- HBM-streaming kernels: fill, add / add_assign,
-// extrapolate_line (the sumcheck fold) and one tensor_expand pass.
+// extrapolate_line (the sumcheck fold) and tensor_expand.
 //
 // All of them are bound by HBM bandwidth: 128-bit coalesced loads/stores (one uint4 per lane =
 // 1 KiB per wave instruction), grid-stride loops sized to keep >= 8 waves per SIMD in flight, and
@@ -118,21 +118,6 @@ __global__ __launch_bounds__(256) void k_extrapolate_line_batch(fold_batch fb, u
 	for (; i < n; i += stride) {
 		uint4 a = x0[i], b = x1[i];
 		x0[i] = xor4(a, ctable_mul(tab, xor4(a, b)));
-	}
-}
-
-// one tensor_expand pass: p = x[h]*r ; x[h] -= p ; x[half+h] = p
-// (crates/compute/src/layer.rs:269-296; "y = prod" as in crates/math/src/tensor_prod_eq_ind.rs:35-77)
-__global__ __launch_bounds__(256) void k_tensor_expand_pass(uint4 *__restrict__ x, uint64_t half, f128 r)
-{
-	__shared__ ctable_smem tab;
-	ctable_build(tab, r);
-	const uint64_t stride = (uint64_t)gridDim.x * 256;
-	for (uint64_t h = (uint64_t)blockIdx.x * 256 + threadIdx.x; h < half; h += stride) {
-		uint4 v = x[h];
-		uint4 p = ctable_mul(tab, v);
-		x[h] = xor4(v, p);
-		x[half + h] = p;
 	}
 }
 
@@ -352,14 +337,6 @@ hipError_t launch_tensor_expand(hipStream_t s, int n_cu, void *data, uint32_t lo
 		i += P;
 	}
 	return hipSuccess;
-}
-
-hipError_t launch_tensor_expand_pass(hipStream_t s, int n_cu, void *data, uint64_t half, f128 r)
-{
-	if (half == 0) return hipSuccess;
-	unsigned g = grid_for(half, 256, n_cu, 8);
-	hipLaunchKernelGGL(k_tensor_expand_pass, dim3(g), dim3(256), 0, s, (uint4 *)data, half, r);
-	return hipGetLastError();
 }
 
 } // namespace bn
