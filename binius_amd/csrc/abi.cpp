@@ -580,7 +580,18 @@ int bn_extrapolate_line_batch(bn_ctx *ctx, void *const *d_evals_0, const void *c
 					absorbed++;
 					break;
 				}
-		if (absorbed == ctx->pend_copies.size()) {
+		// an absorbed copy is read while the fold writes: its source must not overlap any array the
+		// batch writes (e.g. a copy chain s -> d1 -> d2 followed by a fold of both)
+		bool clash = false;
+		auto overlaps = [&](const void *p, const void *q) {
+			const char *a = (const char *)p, *b = (const char *)q;
+			return a < b + n * sizeof(f128) && b < a + n * sizeof(f128);
+		};
+		for (uint32_t i = 0; i < count && !clash; i++)
+			if (src0[i] != d_evals_0[i])
+				for (uint32_t j = 0; j < count; j++)
+					if (overlaps(src0[i], d_evals_0[j])) clash = true;
+		if (absorbed == ctx->pend_copies.size() && !clash) {
 			ctx->pend_copies.clear();
 		} else {
 			for (uint32_t i = 0; i < count; i++) src0[i] = d_evals_0[i];
