@@ -638,11 +638,24 @@ int bn_tensor_expand(bn_ctx *ctx, void *d_data, uint64_t data_len, uint32_t log_
 	return BN_OK;
 }
 
-static int read_result(bn_ctx *ctx, uint32_t n, bn_f128 *h_out)
+// XOR of n_groups partial results in d_result[0 .. n_groups) -> host, through the zero-copy mailbox
+// (one tiny kernel instead of a device-to-host copy plus a stream synchronisation)
+static int publish_result(bn_ctx *ctx, uint32_t n_groups, bn_f128 *h_out)
 {
-	BN_HIP(hipMemcpyAsync(ctx->h_result, ctx->d_result, n * sizeof(f128), hipMemcpyDeviceToHost, ctx->stream));
-	BN_HIP(hipStreamSynchronize(ctx->stream));
-	std::memcpy(h_out, ctx->h_result, n * sizeof(f128));
+	const uint64_t seq = ++ctx->mail_seq;
+	BN_HIP(bn::launch_xor_publish(ctx->stream, ctx->d_result, n_groups, 1, ctx->d_result + 96, ctx->d_mail, seq));
+	volatile uint64_t *seqw = &ctx->h_mail[64].lo;
+	uint64_t spins = 0;
+	while (__atomic_load_n(seqw, __ATOMIC_ACQUIRE) != seq) {
+		if (++spins > (1ull << 22)) {
+			BN_HIP(hipStreamSynchronize(ctx->stream));
+			if (__atomic_load_n(seqw, __ATOMIC_ACQUIRE) != seq)
+				return bn::fail(BN_ERR_DEVICE, "device error: result mailbox was not published");
+			break;
+		}
+	}
+	h_out->lo = __atomic_load_n(&ctx->h_mail[0].lo, __ATOMIC_RELAXED);
+	h_out->hi = __atomic_load_n(&ctx->h_mail[0].hi, __ATOMIC_RELAXED);
 	return BN_OK;
 }
 
@@ -659,15 +672,15 @@ int bn_inner_product(bn_ctx *ctx, const void *d_a, uint64_t a_len, uint32_t towe
 	if (tower_level == 7 && b_len >= 2 && (b_len & 1) == 0) {
 		// F x F: a plain sum of products -> the bit-sliced product-sum kernel (two half-range streams)
 		BN_HIP(bn::launch_roundeval9_split(ctx->stream, ctx->n_cu, d_a, d_b, b_len / 2, b_len / 2, ctx->d_result));
-		bn_f128 two[2];
-		int rc = read_result(ctx, 2, two);
-		if (rc) return rc;
-		h_out->lo = two[0].lo ^ two[1].lo;
-		h_out->hi = two[0].hi ^ two[1].hi;
-		return BN_OK;
+		return publish_result(ctx, 2, h_out);
+	}
+	if (tower_level == 5 && b_len >= 8192 && b_len % 512 == 0) {
+		// B32 x F: four independent bit-sliced GF(2^32) inner products (kernels_ip32.hip)
+		BN_HIP(bn::launch_ip32(ctx->stream, ctx->n_cu, d_a, d_b, b_len, ctx->d_result));
+		return publish_result(ctx, 1, h_out);
 	}
 	BN_HIP(bn::launch_inner_product(ctx->stream, ctx->n_cu, d_a, tower_level, d_b, b_len, ctx->d_result));
-	return read_result(ctx, 1, h_out);
+	return publish_result(ctx, 1, h_out);
 }
 
 static int fold_common(bn_ctx *ctx, bool left, const void *d_mat, uint64_t mat_len, uint32_t tower_level, const void *d_vec,
