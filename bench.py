@@ -86,7 +86,7 @@ def main():
     assert 1 << log_world == world, "number of GPUs must be a power of two"
 
     # ---- inputs: resident in HBM before the timed region
-    import oracle  # input generation (SplitMix64) and the cpu_baseline leg only
+    from binius_amd import synthetic  # SplitMix64 input streams (numpy)
 
     hal = binius_amd.Context(local_rank, m * n + m * (n // 2) + 4096)
     hal.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -95,12 +95,12 @@ def main():
     for j in range(m):
         # rank g holds the elements with global index = g mod world; as a stream that is simply an
         # independent uniform array per (multilinear, rank)
-        host = oracle.random_b128(0xB1A50000 + j + 0x100 * rank, n)
+        host = synthetic.random_b128(0xB1A50000 + j + 0x100 * rank, n)
         s = alloc.alloc(n)
         hal.copy_h2d(host, s)
         d_in.append(s)
         del host
-    stream = oracle.random_scalars(0xC4A1, n_vars + log_world + 1)
+    stream = synthetic.random_scalars(0xC4A1, n_vars + log_world + 1)
     batch_coeff, challenges = stream[0], stream[1:]
     F = binius_amd.HostField
     reducer = ShardedRoundReducer(hal, dist, world) if dist is not None else None
@@ -310,6 +310,8 @@ def main():
 
     # ---- CPU baseline: the oracle's multi-threaded port of the same loop, bounded sample, rank 0 only
     if rank == 0 and world == 1 and dist is None and not args.no_cpu_baseline:
+        import oracle  # the CPU port being timed (the only use of oracle/ in this file)
+
         cores = os.cpu_count() or 1
         cn = args.cpu_n_vars or 18
         while True:

@@ -4,6 +4,7 @@ include/binius_amd.h declares, host-only entry points work, and a missing GPU fa
 import os
 import re
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -98,3 +99,27 @@ def test_product_code_never_imports_the_oracle():
                 txt = open(os.path.join(dirpath, fn)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt, fn
                 assert "oracle/" not in txt and "_ref.h" not in txt, fn
+
+
+def test_oracle_is_only_the_checker():
+    """Outside tests/, the oracle may be used by __graft_entry__.smoke() (as the checker) and by the
+    cpu_baseline leg of bench.py -- nowhere else (tools included)."""
+    import re
+
+    for fn in os.listdir(os.path.join(ROOT, "tools")):
+        if fn.endswith(".py"):
+            txt = open(os.path.join(ROOT, "tools", fn)).read()
+            assert not re.search(r"^\s*(import|from)\s+.*\boracle\b", txt, re.M), fn
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    imports = [m.start() for m in re.finditer(r"^\s*import oracle\b", bench, re.M)]
+    assert len(imports) == 1
+    assert bench.index("# ---- CPU baseline") < imports[0], "bench.py imports the oracle outside its cpu_baseline leg"
+    entry = open(os.path.join(ROOT, "__graft_entry__.py")).read()
+    assert entry.index("def smoke") < entry.index("import oracle")
+
+
+def test_synthetic_streams_match_the_oracle_generator(oracle):
+    from binius_amd import synthetic
+
+    assert np.array_equal(oracle.random_b128(123, 1000), synthetic.random_b128(123, 1000))
+    assert oracle.random_scalars(77, 9) == synthetic.random_scalars(77, 9)

@@ -4,7 +4,8 @@ algorithmic-bytes roofline fraction (SURVEY.md section 8d figures).  Output: one
 import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-import binius_amd, oracle
+import binius_amd
+from binius_amd import synthetic
 from binius_amd.sumcheck import bivariate_product_expr, round_eval_kernel
 
 ap = argparse.ArgumentParser()
@@ -16,9 +17,9 @@ hal = binius_amd.Context(0, 5 * n + (1 << 16))
 alloc = hal.dev_alloc()
 A, B, Cc, D = (alloc.alloc(n) for _ in range(4))
 for j, s in enumerate((A, B)):
-    hal.copy_h2d(oracle.random_b128(0xB1A50000 + j, n), s)
+    hal.copy_h2d(synthetic.random_b128(0xB1A50000 + j, n), s)
 hal.copy_d2d(A, Cc); hal.copy_d2d(B, D)
-z = oracle.random_scalars(0xC4A1, 1)[0]
+z = synthetic.random_scalars(0xC4A1, 1)[0]
 
 def timed(name, fn, alg_bytes, setup=None, note=""):
     ts = []
@@ -34,7 +35,7 @@ timed("extrapolate_line (fold), 2^%d outputs" % (a.log_n - 1), lambda: hal.extra
 expr = bivariate_product_expr(hal, 0, 1)
 k, maps = round_eval_kernel(a.log_n, [1], [A, B], [expr]); ops, rets, lc = hal.record(k, maps)
 timed("accumulate_kernels round-eval a*b, m=2, 2^%d" % a.log_n, lambda: hal.kernel_launch(maps, ops, rets, lc), 16 * 2 * n)
-pt = oracle.random_scalars(7, a.log_n - 1)
+pt = synthetic.random_scalars(7, a.log_n - 1)
 def te_setup(): hal.fill(Cc.slice(0, 1), 1)
 timed("tensor_expand 0 -> %d vars" % (a.log_n - 1), lambda: hal.tensor_expand(0, pt, Cc.slice(0, half)), 3 * 16 * half, te_setup)
 e3 = hal.compile_expr([("var", 0), ("var", 1), ("mul", 0, 1), ("var", 2), ("mul", 2, 3)])
@@ -46,13 +47,13 @@ timed("inner_product B1 x F, 2^%d" % a.log_n, lambda: hal.inner_product(A.slice(
 def am(ke, lc_, b): ke.add_assign(a.log_n - 1 - lc_, b[1].to_ref(), b[0])
 mm = [("chunked_mut", Cc.slice(0, half), 0), ("chunked", Cc.slice(half, n), 0)]
 timed("map_kernels add_assign, 2^%d" % (a.log_n - 1), lambda: hal.map_kernels(am, mm), 48 * half)
-vec = alloc.alloc(64); hal.copy_h2d(oracle.random_b128(9, 64), vec)
+vec = alloc.alloc(64); hal.copy_h2d(synthetic.random_b128(9, 64), vec)
 out = alloc.alloc(n // 64 * 4)
 timed("fold_right B32 matrix 2^%d x vec 2^6" % (a.log_n + 2 - 6), lambda: hal.fold_right(A, 5, vec, out), 16 * n + 16 * (n // 16))
 timed("fold_left  B32 matrix, vec 2^6", lambda: hal.fold_left(A, 5, vec, out), 16 * n + 16 * (n // 16))
 s5 = binius_amd.ntt_s_evals(5, 28)
 lb = 4
-ch = oracle.random_scalars(11, lb + 3)
+ch = synthetic.random_scalars(11, lb + 3)
 fo = alloc.alloc(n >> (lb + 3))
 timed("fri_fold log_len=%d log_batch=4, 3 fold rounds" % (a.log_n - lb), lambda: hal.fri_fold(s5, 5, 28, a.log_n - lb, lb, ch, A, fo), 16 * n + 16 * (n >> 7))
 small = 1 << 20

@@ -16,7 +16,7 @@ def main():
     ap.add_argument("--min-r", type=int, default=1)
     args = ap.parse_args()
     import binius_amd
-    import oracle
+    from binius_amd import synthetic
     from binius_amd.sumcheck import bivariate_product_expr, round_eval_kernel
 
     n = 1 << args.n_vars
@@ -25,11 +25,11 @@ def main():
     d = []
     for j in range(2):
         s = alloc.alloc(n)
-        hal.copy_h2d(oracle.random_b128(0xB1A50000 + j, n), s)
+        hal.copy_h2d(synthetic.random_b128(0xB1A50000 + j, n), s)
         d.append(s)
     scratch = [alloc.alloc(n // 2) for _ in range(2)]
     expr = bivariate_product_expr(hal, 0, 1)
-    z = oracle.random_scalars(0xC4A1, 1)[0]
+    z = synthetic.random_scalars(0xC4A1, 1)[0]
     rows = []
     for r in range(args.n_vars, args.min_r - 1, -1):
         N = 1 << r

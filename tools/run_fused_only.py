@@ -4,7 +4,8 @@
 one (copy evals_0 into a fresh buffer, fold that), so the inputs are never modified."""
 import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import binius_amd, oracle
+import binius_amd
+from binius_amd import synthetic
 from binius_amd.sumcheck import bivariate_product_expr, calculate_round_evals
 
 ap = argparse.ArgumentParser()
@@ -16,7 +17,7 @@ hal = binius_amd.Context(0, 3 * n + 4096)
 alloc = hal.dev_alloc()
 d = []
 for j in range(2):
-    s = alloc.alloc(n); hal.copy_h2d(oracle.random_b128(0xB1A50000 + j, n), s); d.append(s)
+    s = alloc.alloc(n); hal.copy_h2d(synthetic.random_b128(0xB1A50000 + j, n), s); d.append(s)
 dst = [alloc.alloc(n // 2) for _ in range(2)]
 expr = bivariate_product_expr(hal, 0, 1)
 halves = [x.split_half() for x in d]

@@ -2,7 +2,8 @@
 """Runs only the r = n round-eval (and optionally fold) kernels a few times -- a target for rocprofv3."""
 import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import binius_amd, oracle
+import binius_amd
+from binius_amd import synthetic
 from binius_amd.sumcheck import bivariate_product_expr, round_eval_kernel
 
 ap = argparse.ArgumentParser()
@@ -15,7 +16,7 @@ hal = binius_amd.Context(0, 3 * n + 4096)
 alloc = hal.dev_alloc()
 d = []
 for j in range(2):
-    s = alloc.alloc(n); hal.copy_h2d(oracle.random_b128(0xB1A50000 + j, n), s); d.append(s)
+    s = alloc.alloc(n); hal.copy_h2d(synthetic.random_b128(0xB1A50000 + j, n), s); d.append(s)
 f = alloc.alloc(n // 2)
 expr = bivariate_product_expr(hal, 0, 1)
 kernel, maps = round_eval_kernel(a.n_vars, [1], d, [expr])

@@ -6,7 +6,7 @@ import time
 
 sys.path.insert(0, ".")
 import binius_amd  # noqa: E402
-import oracle  # noqa: E402  (inputs only)
+from binius_amd import synthetic
 from binius_amd._host import SumcheckPlan  # noqa: E402
 
 
@@ -14,14 +14,14 @@ def main():
     hal = binius_amd.Context(0, 1 << 16)
     for n_vars in (4, 8, 12):
         alloc = hal.dev_alloc()
-        mls = [oracle.random_b128(0xB1A50000 + j, 1 << n_vars) for j in range(2)]
+        mls = [synthetic.random_b128(0xB1A50000 + j, 1 << n_vars) for j in range(2)]
         d = []
         for x in mls:
             s = alloc.alloc(1 << n_vars)
             hal.copy_h2d(x, s)
             d.append(s)
         scratch = alloc.alloc(1 << n_vars)
-        stream = oracle.random_scalars(0xC4A1, n_vars + 1)
+        stream = synthetic.random_scalars(0xC4A1, n_vars + 1)
         plan = SumcheckPlan(hal, n_vars, d, scratch, [(0, 1)], [0], stream[0], stream[1:])
         for _ in range(20):
             plan.run()
