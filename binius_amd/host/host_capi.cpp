@@ -19,6 +19,7 @@
 #include <string>
 #include <vector>
 
+#include "../../include/binius_amd_host.h"
 #include "sumcheck.hpp"
 
 using namespace binius_amd;
@@ -174,7 +175,6 @@ int bnh_shm_allgather(void *hv, const uint64_t *in, uint32_t n_words, uint64_t *
 	return 0;
 }
 
-typedef int (*bnh_round_reduce_fn)(void *user, const void *d_partial, bn_f128 *evals);
 
 // One full prove: execute -> fold for n_vars rounds, then finish.
 //   d_multilins[m]      device pointers, 2^n_vars elements each (never modified: PreFold)

@@ -1,0 +1,76 @@
+/*
+ * include/binius_amd_host.h -- C entry points of libbinius_amd_host.so, the COMPILED HOST MIRROR.
+ *
+ * This is NOT the drop-in boundary (that is include/binius_amd.h, which the reference's Rust host
+ * binds directly).  The reference's callers of the HAL are Rust generics over ComputeLayer; with no
+ * Rust toolchain in the build image they are mirrored in C++ (binius_amd/host/compute_layer.hpp,
+ * sumcheck.hpp) and driven through these few calls, so that tests and bench.py run the prover loops
+ * at compiled-host speed over the same C ABI:
+ *
+ *   bnh_bivariate_sumcheck_prove   BivariateSumcheckProver  execute/fold/finish loop
+ *                                  crates/core/src/protocols/sumcheck/v3/bivariate_product.rs:27-254
+ *                                  (+ the multi-GPU variants of DESIGN.md section 6)
+ *   bnh_bivariate_mlecheck_prove   BivariateMLEcheckProver   v3/bivariate_mlecheck.rs:27-372
+ *   bnh_shm_*                      intra-node exchange of the per-round partials (host shared memory)
+ *   bnh_rccl_*                     the same exchange through one ncclAllGather per round (librccl is
+ *                                  bound at run time from the process's own copy)
+ *
+ * All functions return 0 on success or a BN_ERR_* code; bnh_last_error() describes the last failure
+ * of the calling thread's library instance.
+ */
+#ifndef BINIUS_AMD_HOST_H
+#define BINIUS_AMD_HOST_H
+
+#include "binius_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char *bnh_last_error(void);
+
+/* combine callback of the generic sharded variant: XOR the rank partials left in d_partial (2
+ * elements: y_1, y_inf) across ranks into evals[2]; 0 on success */
+typedef int (*bnh_round_reduce_fn)(void *user, const void *d_partial, bn_f128 *evals);
+
+/* One complete prove.  d_multilins[m]: 2^n_vars elements each, never modified; d_scratch: device
+ * memory for the folded copies (m * 2^(n_vars-1) elements, + 64 with tail_rounds); comp_indices:
+ * n_comps pairs; sums[n_comps]; challenges[n_vars (+ log2 world with tail_rounds)];
+ * round_coeffs_out[3 * rounds]; final_evals_out[m].
+ * Single GPU: reduce = NULL, rccl_comm = NULL, shm = NULL.
+ * Sharded (rank holds the elements with index = rank mod world): exactly one of
+ *   shm        handle from bnh_shm_open: partials combined in host shared memory; with tail_rounds != 0
+ *              the residual log2(world) rounds run in the same call
+ *   rccl_comm  communicator from bnh_rccl_init, d_partial (2 elements) and d_gathered (2 * world
+ *              elements) device buffers: one ncclAllGather per round on the context's stream
+ *   reduce     caller-supplied combine of d_partial */
+int bnh_bivariate_sumcheck_prove(bn_ctx *ctx, uint32_t n_vars, uint32_t m, const void *const *d_multilins, void *d_scratch,
+                                 uint64_t scratch_elems, uint32_t n_comps, const uint32_t *comp_indices, const bn_f128 *sums,
+                                 const bn_f128 *batch_coeff, const bn_f128 *challenges, bn_f128 *round_coeffs_out,
+                                 bn_f128 *final_evals_out, bnh_round_reduce_fn reduce, void *reduce_user, void *d_partial,
+                                 void *rccl_comm, int world, void *d_gathered, void *shm, int tail_rounds);
+
+/* d_eq_ind: 2^(n_vars-1) elements = tensor expansion of eq_ind_challenges[0 .. n_vars-1);
+ * round_coeffs_out[4 * n_vars] (degree-3 round polynomials); final_evals_out[m + 1] (the last one is
+ * eq_ind_prefix_eval); d_scratch: (m + 1) * 2^(n_vars-1) elements */
+int bnh_bivariate_mlecheck_prove(bn_ctx *ctx, uint32_t n_vars, uint32_t m, const void *const *d_multilins, const void *d_eq_ind,
+                                 const bn_f128 *eq_ind_challenges, void *d_scratch, uint64_t scratch_elems, uint32_t n_comps,
+                                 const uint32_t *comp_indices, const bn_f128 *sums, const bn_f128 *batch_coeff,
+                                 const bn_f128 *challenges, bn_f128 *round_coeffs_out, bn_f128 *final_evals_out);
+
+/* shared-memory exchange: rank 0 creates the segment `name` ("/..."), the others open it afterwards */
+int bnh_shm_open(const char *name, int world, int rank, int create, void **handle_out);
+int bnh_shm_close(void *handle);
+/* every rank contributes n_words (<= 7) 64-bit words; out[world * n_words], rank-major */
+int bnh_shm_allgather(void *handle, const uint64_t *in, uint32_t n_words, uint64_t *out);
+
+/* RCCL, bound with dlopen from `librccl_path` (the librccl.so the process already uses) */
+int bnh_rccl_open(const char *librccl_path);
+int bnh_rccl_unique_id(void *out128);
+int bnh_rccl_init(const void *id128, int world, int rank, void **comm_out);
+int bnh_rccl_destroy(void *comm);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -123,3 +123,15 @@ def test_synthetic_streams_match_the_oracle_generator(oracle):
 
     assert np.array_equal(oracle.random_b128(123, 1000), synthetic.random_b128(123, 1000))
     assert oracle.random_scalars(77, 9) == synthetic.random_scalars(77, 9)
+
+
+def test_host_library_exports_every_declared_symbol(ffi):
+    import ctypes
+
+    hdr = open(os.path.join(ROOT, "include", "binius_amd_host.h")).read()
+    syms = sorted(set(re.findall(r"\b(bnh_[a-z0-9_]+)\s*\(", hdr)) - {"bnh_round_reduce_fn"})
+    assert len(syms) >= 10
+    ffi.lib()
+    L = ctypes.CDLL(os.path.join(ROOT, "binius_amd", "libbinius_amd_host.so"))
+    for s in syms:
+        assert hasattr(L, s), "libbinius_amd_host.so does not export %s" % s
