@@ -482,3 +482,27 @@ def test_context_is_safe_to_call_from_several_threads(hal, oracle):
     for t in ts:
         t.join()
     assert not errs
+
+
+@pytest.mark.parametrize("log_n", [1, 4, 9, 13])
+def test_product_circuit_layers(hal, oracle, log_n):
+    """ProductCircuitLayers::compute (core/src/protocols/prodcheck/prove.rs:24-77): every layer is the
+    element-wise product of the halves of the layer below; the top is the product of all values."""
+    from binius_amd.prodcheck import ProductCircuitLayers
+
+    alloc = hal.dev_alloc()
+    evals = rnd(oracle, 0x9C0D + log_n, 1 << log_n)
+    d = upload(hal, alloc, evals)
+    pcl = ProductCircuitLayers.compute(d, hal, alloc)
+    layers = pcl.layers()
+    assert len(layers) == log_n and [l.len for l in layers] == [1 << (i + 1) for i in range(log_n)]
+    cur = evals
+    want = []
+    for _ in range(log_n):
+        want.append(cur)
+        half = cur.shape[0] // 2
+        cur = oracle.mul_vec(cur[:half].copy(), cur[half:].copy())
+    want.reverse()
+    for got, w in zip(layers, want):
+        assert np.array_equal(hal.copy_d2h(got), w)
+    assert pcl.product == to_int(cur)
