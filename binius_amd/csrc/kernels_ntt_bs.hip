@@ -278,10 +278,10 @@ static hipError_t run_ntt_bs(hipStream_t s, void *data, const uint64_t *h_s_eval
 		if (e != hipSuccess) return e;
 		attr_set = true;
 	}
-	// lower layers, at most 6 per pass: forward from NB-1 down to 0, inverse from 0 up to NB-1
+	// lower layers, at most 7 per pass: forward from NB-1 down to 0, inverse from 0 up to NB-1
 	std::vector<std::pair<uint32_t, uint32_t>> plan; // (l_lo, R), highest layers first
 	for (uint32_t hi = NB; hi > 0;) {
-		const uint32_t n_pass = (hi + 5) / 6;
+		const uint32_t n_pass = (hi + 6) / 7;
 		const uint32_t R = (hi + n_pass - 1) / n_pass; // even split
 		plan.push_back({hi - R, R});
 		hi -= R;
