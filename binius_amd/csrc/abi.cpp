@@ -1421,14 +1421,15 @@ static int ntt_common(bn_ctx *ctx, bool inverse, void *d_data, uint32_t elem_lev
 	BN_REQUIRE(skip_rounds <= log_y, "skip_rounds larger than log_y");
 	BN_REQUIRE(log_x + log_y + log_z < 48, "transform too large");
 	if (log_y == 0 || skip_rounds == log_y) return BN_OK;
-	if (elem_level >= 5 && tw_level == 5 && skip_rounds == 0 && log_y >= 14 && !getenv("BN_NTT_NO_BITSLICE")) {
+	if (elem_level >= 5 && tw_level == 5 && log_y >= 14 && !getenv("BN_NTT_NO_BITSLICE")) {
 		// large transforms with B32 twiddles: bit-sliced butterflies (kernels_ntt_bs.hip); B64 / B128
 		// data and log_x / log_z batches are interleaved B32 transforms
 		const uint32_t lx = log_x + (elem_level - 5);
 		void *scr = bn::ctx_scratch(ctx, bn::ntt_bs_scratch_bytes(log_y + lx + log_z));
 		if (!scr) return bn::fail(BN_ERR_ALLOC, "allocation error: allocator is out of memory (NTT scratch)");
 		prof_scope ps(ctx, BN_PROF_NTT);
-		hipError_t be = bn::launch_ntt_bs(ctx->stream, inverse, d_data, h_s_evals, log_domain, lx, log_y, log_z, coset, coset_bits, scr);
+		hipError_t be = bn::launch_ntt_bs(ctx->stream, inverse, d_data, h_s_evals, log_domain, lx, log_y, log_z, coset, coset_bits,
+		                                  skip_rounds, scr);
 		if (be == hipSuccess) return BN_OK;
 		if (be != hipErrorNotSupported) return bn::hip_fail(be, "launch_ntt_bs");
 	}

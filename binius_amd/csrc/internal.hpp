@@ -214,6 +214,6 @@ hipError_t launch_ntt_tiled(hipStream_t s, int n_cu, bool inverse, void *data, u
 hipError_t launch_ip32(hipStream_t s, int n_cu, const void *a_sub, const void *b, uint64_t n, f128 *d_out);
 size_t ntt_bs_scratch_bytes(uint32_t log_words);
 hipError_t launch_ntt_bs(hipStream_t s, bool inverse, void *data, const uint64_t *h_s_evals, uint32_t log_domain, uint32_t lx,
-                         uint32_t log_y, uint32_t log_z, uint64_t coset, uint32_t coset_bits, void *d_scratch);
+                         uint32_t log_y, uint32_t log_z, uint64_t coset, uint32_t coset_bits, uint32_t skip_rounds, void *d_scratch);
 
 } // namespace bn

@@ -61,12 +61,14 @@ __device__ __forceinline__ void butterfly_planes(uint32_t (&U)[32], uint32_t (&V
 }
 
 // the five in-register layers of a plane set (distance 2^b in the bit positions)
+// (skip_rounds drops the highest layers: only b < n_top are applied)
 template <bool INV>
-__device__ __forceinline__ void top_layers(uint32_t (&W)[32], const uint32_t (*ttop)[32])
+__device__ __forceinline__ void top_layers(uint32_t (&W)[32], const uint32_t (*ttop)[32], uint32_t n_top)
 {
 #pragma unroll
 	for (int bb = 0; bb < 5; bb++) {
 		const int b = INV ? bb : 4 - bb;
+		if ((uint32_t)b >= n_top) continue;
 		constexpr uint32_t masks[5] = {0x55555555u, 0x33333333u, 0x0F0F0F0Fu, 0x00FF00FFu, 0x0000FFFFu};
 		const uint32_t mk = masks[b];
 		const int sh = 1 << b;
@@ -88,7 +90,7 @@ __device__ __forceinline__ void top_layers(uint32_t (&W)[32], const uint32_t (*t
 // batch beta = blockIdx.y: x = beta & (2^lx - 1), z = beta >> lx
 template <bool INV>
 __global__ __launch_bounds__(256) void k_ntt_bs_head(const uint32_t *__restrict__ data, uint4 *__restrict__ bs, uint64_t S, uint32_t lx,
-                                                     uint32_t log_y, const ntt_bs_tables *__restrict__ tb)
+                                                     uint32_t log_y, const ntt_bs_tables *__restrict__ tb, uint32_t n_top)
 {
 	const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
 	if (i >= S) return;
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(256) void k_ntt_bs_head(const uint32_t *__restrict_
 	for (int c = 0; c < 32; c++)
 		W[c] = data[((uint64_t)c * S + i) << lx];
 	transpose32(W);
-	if (!INV) top_layers<false>(W, tb->ttop);
+	if (!INV) top_layers<false>(W, tb->ttop, n_top);
 	uint4 *dst = bs + i * 8;
 #pragma unroll
 	for (int k = 0; k < 8; k++)
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(256) void k_ntt_bs_head(const uint32_t *__restrict_
 // ---- tail: (inverse: the five in-register layers 1, 2, .., 16, then) plane sets -> standard layout
 template <bool INV>
 __global__ __launch_bounds__(256) void k_ntt_bs_tail(const uint4 *__restrict__ bs, uint32_t *__restrict__ data, uint64_t S, uint32_t lx,
-                                                     uint32_t log_y, const ntt_bs_tables *__restrict__ tb)
+                                                     uint32_t log_y, const ntt_bs_tables *__restrict__ tb, uint32_t n_top)
 {
 	const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
 	if (i >= S) return;
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(256) void k_ntt_bs_tail(const uint4 *__restrict__ b
 		W[4 * k + 2] = v.z;
 		W[4 * k + 3] = v.w;
 	}
-	if (INV) top_layers<true>(W, tb->ttop);
+	if (INV) top_layers<true>(W, tb->ttop, n_top);
 	transpose32(W); // (an involution)
 #pragma unroll
 	for (int c = 0; c < 32; c++)
@@ -224,14 +226,14 @@ uint32_t host_twiddle(const uint64_t *s_evals, uint32_t log_domain, uint32_t lay
 
 } // namespace
 
-// Forward / inverse NTT of 2^(lx + log_z) interleaved B32 transforms of 2^log_y elements each (skip_rounds = 0).
+// Forward / inverse NTT of 2^(lx + log_z) interleaved B32 transforms of 2^log_y elements each; skip_rounds drops the highest layers.
 // d_scratch: ntt_bs_scratch_bytes() bytes, 256-byte aligned.
 // Returns hipErrorNotSupported for shapes this path does not cover (the caller falls back).
 size_t ntt_bs_scratch_bytes(uint32_t log_words) { return ((size_t)4 << log_words) + sizeof(ntt_bs_tables) + 256; }
 
 template <bool INV>
 static hipError_t run_ntt_bs(hipStream_t s, void *data, const uint64_t *h_s_evals, uint32_t log_domain, uint32_t lx, uint32_t log_y,
-                             uint32_t log_z, uint64_t coset, uint32_t coset_bits, void *d_scratch)
+                             uint32_t log_z, uint64_t coset, uint32_t coset_bits, uint32_t skip_rounds, void *d_scratch)
 {
 	const uint32_t L = log_y;
 	if (L < 5 + kTileLog || L > 31 || lx + log_z > 12) return hipErrorNotSupported;
@@ -270,7 +272,11 @@ static hipError_t run_ntt_bs(hipStream_t s, void *data, const uint64_t *h_s_eval
 	if (e != hipSuccess) return e;
 
 	const unsigned blocks = (unsigned)((S + 255) / 256);
-	hipLaunchKernelGGL(k_ntt_bs_head<INV>, dim3(blocks, n_batch), dim3(256), 0, s, (const uint32_t *)data, bs, S, lx, log_y, d_tb);
+	// layers log_y - skip_rounds - 1 .. 0 are applied (reference.rs:88): of the five in-register layers
+	// the lowest n_top, of the NB lower layers the lowest n_low
+	const uint32_t n_top = skip_rounds >= 5 ? 0 : 5 - skip_rounds;
+	const uint32_t n_low = skip_rounds > 5 ? NB - (skip_rounds - 5) : NB;
+	hipLaunchKernelGGL(k_ntt_bs_head<INV>, dim3(blocks, n_batch), dim3(256), 0, s, (const uint32_t *)data, bs, S, lx, log_y, d_tb, n_top);
 	const size_t lds = (size_t)(1 << kTileLog) * kSetQ * sizeof(uint4);
 	static bool attr_set = false;
 	if (!attr_set) {
@@ -280,7 +286,7 @@ static hipError_t run_ntt_bs(hipStream_t s, void *data, const uint64_t *h_s_eval
 	}
 	// lower layers, at most 7 per pass: forward from NB-1 down to 0, inverse from 0 up to NB-1
 	std::vector<std::pair<uint32_t, uint32_t>> plan; // (l_lo, R), highest layers first
-	for (uint32_t hi = NB; hi > 0;) {
+	for (uint32_t hi = n_low; hi > 0;) {
 		const uint32_t n_pass = (hi + 6) / 7;
 		const uint32_t R = (hi + n_pass - 1) / n_pass; // even split
 		plan.push_back({hi - R, R});
@@ -292,15 +298,15 @@ static hipError_t run_ntt_bs(hipStream_t s, void *data, const uint64_t *h_s_eval
 		const uint32_t n_lo = Q < l_lo ? Q : l_lo;
 		hipLaunchKernelGGL(k_ntt_bs_pass<INV>, dim3((unsigned)(S >> kTileLog), n_batch), dim3(256), lds, s, bs, S, l_lo, R, n_lo, d_tb);
 	}
-	hipLaunchKernelGGL(k_ntt_bs_tail<INV>, dim3(blocks, n_batch), dim3(256), 0, s, bs, (uint32_t *)data, S, lx, log_y, d_tb);
+	hipLaunchKernelGGL(k_ntt_bs_tail<INV>, dim3(blocks, n_batch), dim3(256), 0, s, bs, (uint32_t *)data, S, lx, log_y, d_tb, n_top);
 	return hipGetLastError();
 }
 
 hipError_t launch_ntt_bs(hipStream_t s, bool inverse, void *data, const uint64_t *h_s_evals, uint32_t log_domain, uint32_t lx,
-                         uint32_t log_y, uint32_t log_z, uint64_t coset, uint32_t coset_bits, void *d_scratch)
+                         uint32_t log_y, uint32_t log_z, uint64_t coset, uint32_t coset_bits, uint32_t skip_rounds, void *d_scratch)
 {
-	return inverse ? run_ntt_bs<true>(s, data, h_s_evals, log_domain, lx, log_y, log_z, coset, coset_bits, d_scratch)
-	               : run_ntt_bs<false>(s, data, h_s_evals, log_domain, lx, log_y, log_z, coset, coset_bits, d_scratch);
+	return inverse ? run_ntt_bs<true>(s, data, h_s_evals, log_domain, lx, log_y, log_z, coset, coset_bits, skip_rounds, d_scratch)
+	               : run_ntt_bs<false>(s, data, h_s_evals, log_domain, lx, log_y, log_z, coset, coset_bits, skip_rounds, d_scratch);
 }
 
 } // namespace bn

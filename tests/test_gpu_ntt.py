@@ -43,6 +43,11 @@ def make_data(oracle, seed, n, elem_level):
         (6, 5, 15, 0, 15, 0, 0, 0, 0),
         (7, 5, 16, 0, 15, 0, 1, 1, 0),
         (7, 5, 14, 1, 14, 1, 0, 0, 0),
+        # skip_rounds (the RS-encoding shape): fewer in-register layers / fewer lower layers
+        (5, 5, 16, 0, 16, 0, 0, 0, 2),
+        (5, 5, 16, 0, 15, 0, 1, 1, 7),
+        (7, 5, 15, 1, 14, 0, 0, 0, 1),
+        (5, 5, 14, 0, 14, 0, 0, 0, 5),
         (5, 5, 12, 2, 8, 1, 1, 2, 0),
         (5, 5, 12, 0, 10, 0, 0, 0, 3),
         (7, 5, 12, 0, 10, 0, 0, 1, 0),
