@@ -437,6 +437,26 @@ def test_fri_fold(hal, oracle, log_batch, tw_level):
     assert np.array_equal(got, exp1)
 
 
+@pytest.mark.parametrize("log_len,log_batch,n_fold,tw_level", [(14, 2, 1, 5), (13, 4, 3, 5), (15, 1, 4, 4), (12, 4, 2, 5), (16, 0, 3, 5), (14, 3, 4, 5)])
+def test_fri_fold_larger_shapes(hal, oracle, log_len, log_batch, n_fold, tw_level):
+    """More arities and sizes (the reference's own test uses log_len 10 with 2 fold rounds)."""
+    import binius_amd
+
+    alloc = hal.dev_alloc()
+    log_domain = log_len + 1
+    s_ref = oracle.ntt_s_evals(tw_level, log_domain)
+    s_dev = binius_amd.ntt_s_evals(tw_level, log_domain)
+    data = rnd(oracle, 112 + log_len, 1 << (log_len + log_batch))
+    challenges = oracle.random_scalars(113 + n_fold, log_batch + n_fold)
+    out_len = 1 << (log_len - n_fold)
+    din, dout = upload(hal, alloc, data), alloc.alloc(out_len)
+    hal.fri_fold(s_dev, tw_level, log_domain, log_len, log_batch, challenges, din, dout)
+    exp = oracle.arr(out_len)
+    assert oracle.fri_fold(s_ref, tw_level, log_domain, log_len, log_batch, challenges, data, exp) == 0
+    assert np.array_equal(hal.copy_d2h(dout), exp)
+    assert np.array_equal(hal.copy_d2h(din), data)  # the input is read-only
+
+
 def test_fri_fold_validation(hal, oracle):
     import binius_amd
 
