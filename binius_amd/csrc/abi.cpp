@@ -260,6 +260,11 @@ int bn_ctx_destroy(bn_ctx *ctx)
 	hipSetDevice(ctx->device);
 	if (ctx->stream)
 		hipStreamSynchronize(ctx->stream);
+	if (ctx->ntt_cache) {
+		bn::ntt_bs_cache *nc = (bn::ntt_bs_cache *)ctx->ntt_cache;
+		if (nc->d_tables) hipFree(nc->d_tables);
+		delete nc;
+	}
 	if (ctx->arena) hipFree(ctx->arena);
 	if (ctx->scratch) hipFree(ctx->scratch);
 	if (ctx->d_result) hipFree(ctx->d_result);
@@ -1427,9 +1432,17 @@ static int ntt_common(bn_ctx *ctx, bool inverse, void *d_data, uint32_t elem_lev
 		const uint32_t lx = log_x + (elem_level - 5);
 		void *scr = bn::ctx_scratch(ctx, bn::ntt_bs_scratch_bytes(log_y + lx + log_z));
 		if (!scr) return bn::fail(BN_ERR_ALLOC, "allocation error: allocator is out of memory (NTT scratch)");
+		if (!ctx->ntt_cache) {
+			bn::ntt_bs_cache *nc = new bn::ntt_bs_cache;
+			if (hipMalloc(&nc->d_tables, bn::ntt_bs_tables_bytes()) != hipSuccess) {
+				delete nc;
+				return bn::fail(BN_ERR_ALLOC, "allocation error: allocator is out of memory (NTT tables)");
+			}
+			ctx->ntt_cache = nc;
+		}
 		prof_scope ps(ctx, BN_PROF_NTT);
 		hipError_t be = bn::launch_ntt_bs(ctx->stream, inverse, d_data, h_s_evals, log_domain, lx, log_y, log_z, coset, coset_bits,
-		                                  skip_rounds, scr);
+		                                  skip_rounds, scr, (bn::ntt_bs_cache *)ctx->ntt_cache);
 		if (be == hipSuccess) return BN_OK;
 		if (be != hipErrorNotSupported) return bn::hip_fail(be, "launch_ntt_bs");
 	}

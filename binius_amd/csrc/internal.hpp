@@ -79,6 +79,7 @@ struct bn_ctx {
 		uint32_t count = 0, n = 0;
 		const void *ptr[8] = {};
 	} mirror;
+	void *ntt_cache = nullptr; // bn::ntt_bs_cache (allocated on first use)
 	bool lazy_fold = true; // BN_NO_LAZY_FOLD=1 turns the deferral off
 	// resident tail kernel (kernels_foldeval9.hip k_foldeval_tail, protocol in abi.cpp)
 	struct tail_state {
@@ -212,8 +213,16 @@ hipError_t launch_ntt_tiled(hipStream_t s, int n_cu, bool inverse, void *data, u
                             uint32_t log_z, uint64_t coset, uint32_t coset_bits, uint32_t skip_rounds);
 
 hipError_t launch_ip32(hipStream_t s, int n_cu, const void *a_sub, const void *b, uint64_t n, f128 *d_out);
+// device copy of the bit-sliced NTT's launch constants, kept across calls (kernels_ntt_bs.hip)
+struct ntt_bs_cache {
+	void *d_tables = nullptr;
+	bool valid = false;
+	uint64_t key = 0;
+};
+size_t ntt_bs_tables_bytes();
 size_t ntt_bs_scratch_bytes(uint32_t log_words);
 hipError_t launch_ntt_bs(hipStream_t s, bool inverse, void *data, const uint64_t *h_s_evals, uint32_t log_domain, uint32_t lx,
-                         uint32_t log_y, uint32_t log_z, uint64_t coset, uint32_t coset_bits, uint32_t skip_rounds, void *d_scratch);
+                         uint32_t log_y, uint32_t log_z, uint64_t coset, uint32_t coset_bits, uint32_t skip_rounds, void *d_scratch,
+                         ntt_bs_cache *cache);
 
 } // namespace bn

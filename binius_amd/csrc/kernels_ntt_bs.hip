@@ -229,11 +229,11 @@ uint32_t host_twiddle(const uint64_t *s_evals, uint32_t log_domain, uint32_t lay
 // Forward / inverse NTT of 2^(lx + log_z) interleaved B32 transforms of 2^log_y elements each; skip_rounds drops the highest layers.
 // d_scratch: ntt_bs_scratch_bytes() bytes, 256-byte aligned.
 // Returns hipErrorNotSupported for shapes this path does not cover (the caller falls back).
-size_t ntt_bs_scratch_bytes(uint32_t log_words) { return ((size_t)4 << log_words) + sizeof(ntt_bs_tables) + 256; }
+size_t ntt_bs_scratch_bytes(uint32_t log_words) { return ((size_t)4 << log_words) + 256; }
 
 template <bool INV>
 static hipError_t run_ntt_bs(hipStream_t s, void *data, const uint64_t *h_s_evals, uint32_t log_domain, uint32_t lx, uint32_t log_y,
-                             uint32_t log_z, uint64_t coset, uint32_t coset_bits, uint32_t skip_rounds, void *d_scratch)
+                             uint32_t log_z, uint64_t coset, uint32_t coset_bits, uint32_t skip_rounds, void *d_scratch, ntt_bs_cache *cache)
 {
 	const uint32_t L = log_y;
 	if (L < 5 + kTileLog || L > 31 || lx + log_z > 12) return hipErrorNotSupported;
@@ -241,7 +241,24 @@ static hipError_t run_ntt_bs(hipStream_t s, void *data, const uint64_t *h_s_eval
 	const uint32_t NB = L - 5;           // lower layers
 	const uint64_t S = (uint64_t)1 << NB; // plane sets per transform
 	const uint32_t base = log_domain - (log_y + coset_bits);
-	// ---- launch constants
+	// ---- launch constants: rebuilt and uploaded only when the domain / coset / size changed since the
+	// previous call of this context (a prover transforms many columns over the same domain)
+	uint64_t key = 0xcbf29ce484222325ull; // FNV-1a over everything the tables depend on
+	auto mix = [&](uint64_t v) {
+		for (int k = 0; k < 8; k++) {
+			key ^= (v >> (8 * k)) & 0xFF;
+			key *= 0x100000001b3ull;
+		}
+	};
+	mix(L);
+	mix(log_domain);
+	mix(coset);
+	mix(coset_bits);
+	for (uint32_t l = 0; l < L; l++)
+		for (uint32_t b = 0; b + 1 + base + l < log_domain; b++) mix(h_s_evals[(size_t)(base + l) * BN_NTT_MAX_DIM + b]);
+	ntt_bs_tables *d_tb = (ntt_bs_tables *)cache->d_tables;
+	hipError_t e = hipSuccess;
+	if (!cache->valid || cache->key != key) {
 	static thread_local ntt_bs_tables tb;
 	std::memset(&tb, 0, sizeof(tb));
 	for (uint32_t b = 0; b < 5; b++) {
@@ -264,12 +281,14 @@ static hipError_t run_ntt_bs(hipStream_t s, void *data, const uint64_t *h_s_eval
 			tb.rows[l][bit] = host_twiddle(h_s_evals, log_domain, base + l, (uint64_t)1 << bit);
 		tb.tconst[l] = host_twiddle(h_s_evals, log_domain, base + l, coset << (L - 1 - l));
 	}
+	e = hipMemcpyAsync(d_tb, &tb, sizeof(tb), hipMemcpyHostToDevice, s);
+	if (e != hipSuccess) return e;
+	e = hipStreamSynchronize(s); // tb is reused by the next rebuild
+	if (e != hipSuccess) return e;
+	cache->valid = true;
+	cache->key = key;
+	}
 	uint4 *bs = (uint4 *)d_scratch;
-	ntt_bs_tables *d_tb = (ntt_bs_tables *)((char *)d_scratch + (((size_t)4 << (L + lx + log_z)) + 255) / 256 * 256);
-	hipError_t e = hipMemcpyAsync(d_tb, &tb, sizeof(tb), hipMemcpyHostToDevice, s);
-	if (e != hipSuccess) return e;
-	e = hipStreamSynchronize(s); // tb is reused by the next call
-	if (e != hipSuccess) return e;
 
 	const unsigned blocks = (unsigned)((S + 255) / 256);
 	// layers log_y - skip_rounds - 1 .. 0 are applied (reference.rs:88): of the five in-register layers
@@ -303,10 +322,13 @@ static hipError_t run_ntt_bs(hipStream_t s, void *data, const uint64_t *h_s_eval
 }
 
 hipError_t launch_ntt_bs(hipStream_t s, bool inverse, void *data, const uint64_t *h_s_evals, uint32_t log_domain, uint32_t lx,
-                         uint32_t log_y, uint32_t log_z, uint64_t coset, uint32_t coset_bits, uint32_t skip_rounds, void *d_scratch)
+                         uint32_t log_y, uint32_t log_z, uint64_t coset, uint32_t coset_bits, uint32_t skip_rounds, void *d_scratch,
+                         ntt_bs_cache *cache)
 {
-	return inverse ? run_ntt_bs<true>(s, data, h_s_evals, log_domain, lx, log_y, log_z, coset, coset_bits, skip_rounds, d_scratch)
-	               : run_ntt_bs<false>(s, data, h_s_evals, log_domain, lx, log_y, log_z, coset, coset_bits, skip_rounds, d_scratch);
+	return inverse ? run_ntt_bs<true>(s, data, h_s_evals, log_domain, lx, log_y, log_z, coset, coset_bits, skip_rounds, d_scratch, cache)
+	               : run_ntt_bs<false>(s, data, h_s_evals, log_domain, lx, log_y, log_z, coset, coset_bits, skip_rounds, d_scratch, cache);
 }
+
+size_t ntt_bs_tables_bytes() { return sizeof(ntt_bs_tables); }
 
 } // namespace bn
