@@ -140,22 +140,48 @@ __global__ __launch_bounds__(256) void k_ntt_bs_tail(const uint4 *__restrict__ b
 // Tile-local set number s (9 bits) <-> index bits: run A = bits [0, n_lo), run B = bits
 // [l_lo, l_lo + 9 - n_lo) with n_lo = min(9 - R, l_lo); the butterfly bit of layer l_lo + t is local
 // bit n_lo + t.  The other index bits enumerate the tiles.
-template <bool INV>
+// CONV (only with l_lo == 0, i.e. a tile of 512 CONSECUTIVE sets): the conversion between the
+// standard layout and the plane sets rides in this pass -- forward: the last pass stores elements
+// (no tail kernel), inverse: the first pass loads elements (no head kernel); `data`, lx, log_y as in
+// the head / tail kernels.
+template <bool INV, bool CONV>
 __global__ __launch_bounds__(256, 2) void k_ntt_bs_pass(uint4 *__restrict__ bs, uint64_t S, uint32_t l_lo, uint32_t R, uint32_t n_lo,
-                                                        const ntt_bs_tables *__restrict__ tb)
+                                                        const ntt_bs_tables *__restrict__ tb, uint32_t *__restrict__ data, uint32_t lx,
+                                                        uint32_t log_y)
 {
 	extern __shared__ __attribute__((aligned(16))) uint4 tile[]; // [512][kSetQ]
 	const unsigned tid = threadIdx.x;
 	bs += (uint64_t)blockIdx.y * S * 8; // batch
+	if (CONV) {
+		const uint64_t beta = blockIdx.y;
+		data += ((beta >> lx) << (log_y + lx)) + (beta & (((uint64_t)1 << lx) - 1));
+	}
 	const uint32_t gap = l_lo - n_lo; // tile bits between the two local runs
 	const uint64_t b = blockIdx.x;
 	const uint64_t i_tile = ((b & (((uint64_t)1 << gap) - 1)) << n_lo) | ((b >> gap) << (l_lo + kTileLog - n_lo));
 	auto index_of = [&](unsigned s) -> uint64_t { return i_tile | (s & ((1u << n_lo) - 1)) | ((uint64_t)(s >> n_lo) << l_lo); };
-	// load: 512 sets x 8 chunks of 16 B
+	if (CONV && INV) {
+		// elements -> plane sets, two sets per thread (consecutive i across the lanes: coalesced words)
+#pragma unroll 1
+		for (unsigned h = 0; h < 2; h++) {
+			const unsigned sset = tid + 256 * h;
+			const uint64_t i = index_of(sset);
+			uint32_t W[32];
+#pragma unroll
+			for (int c = 0; c < 32; c++)
+				W[c] = data[((uint64_t)c * S + i) << lx];
+			transpose32(W);
+#pragma unroll
+			for (int k = 0; k < 8; k++)
+				tile[sset * kSetQ + k] = uint4{W[4 * k], W[4 * k + 1], W[4 * k + 2], W[4 * k + 3]};
+		}
+	} else {
+		// load: 512 sets x 8 chunks of 16 B
 #pragma unroll 4
-	for (unsigned k = 0; k < 16; k++) {
-		const unsigned idx = tid + 256 * k, s = idx >> 3, ch = idx & 7;
-		tile[s * kSetQ + ch] = bs[index_of(s) * 8 + ch];
+		for (unsigned k = 0; k < 16; k++) {
+			const unsigned idx = tid + 256 * k, s = idx >> 3, ch = idx & 7;
+			tile[s * kSetQ + ch] = bs[index_of(s) * 8 + ch];
+		}
 	}
 	__syncthreads();
 	for (int tt = 0; tt < (int)R; tt++) {
@@ -205,6 +231,28 @@ __global__ __launch_bounds__(256, 2) void k_ntt_bs_pass(uint4 *__restrict__ bs, 
 			tile[s_v * kSetQ + k] = uint4{V[4 * k], V[4 * k + 1], V[4 * k + 2], V[4 * k + 3]};
 		}
 		__syncthreads();
+	}
+	if (CONV && !INV) {
+		// plane sets -> elements
+#pragma unroll 1
+		for (unsigned h = 0; h < 2; h++) {
+			const unsigned sset = tid + 256 * h;
+			const uint64_t i = index_of(sset);
+			uint32_t W[32];
+#pragma unroll
+			for (int k = 0; k < 8; k++) {
+				const uint4 v = tile[sset * kSetQ + k];
+				W[4 * k] = v.x;
+				W[4 * k + 1] = v.y;
+				W[4 * k + 2] = v.z;
+				W[4 * k + 3] = v.w;
+			}
+			transpose32(W);
+#pragma unroll
+			for (int c = 0; c < 32; c++)
+				data[((uint64_t)c * S + i) << lx] = W[c];
+		}
+		return;
 	}
 #pragma unroll 4
 	for (unsigned k = 0; k < 16; k++) {
@@ -295,11 +343,12 @@ static hipError_t run_ntt_bs(hipStream_t s, void *data, const uint64_t *h_s_eval
 	// the lowest n_top, of the NB lower layers the lowest n_low
 	const uint32_t n_top = skip_rounds >= 5 ? 0 : 5 - skip_rounds;
 	const uint32_t n_low = skip_rounds > 5 ? NB - (skip_rounds - 5) : NB;
-	hipLaunchKernelGGL(k_ntt_bs_head<INV>, dim3(blocks, n_batch), dim3(256), 0, s, (const uint32_t *)data, bs, S, lx, log_y, d_tb, n_top);
 	const size_t lds = (size_t)(1 << kTileLog) * kSetQ * sizeof(uint4);
 	static bool attr_set = false;
 	if (!attr_set) {
-		e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ntt_bs_pass<INV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ntt_bs_pass<INV, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		if (e == hipSuccess)
+			e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ntt_bs_pass<INV, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 		if (e != hipSuccess) return e;
 		attr_set = true;
 	}
@@ -311,13 +360,23 @@ static hipError_t run_ntt_bs(hipStream_t s, void *data, const uint64_t *h_s_eval
 		plan.push_back({hi - R, R});
 		hi -= R;
 	}
+	// the pass over layers R-1..0 works on consecutive sets and converts the layout itself: forward it
+	// is the last kernel (no tail), inverse the first (no head)
+	const bool merged = !plan.empty();
+	if (!(INV && merged))
+		hipLaunchKernelGGL(k_ntt_bs_head<INV>, dim3(blocks, n_batch), dim3(256), 0, s, (const uint32_t *)data, bs, S, lx, log_y, d_tb, n_top);
 	for (size_t k = 0; k < plan.size(); k++) {
 		const auto &pr = INV ? plan[plan.size() - 1 - k] : plan[k];
 		const uint32_t l_lo = pr.first, R = pr.second, Q = kTileLog - R;
 		const uint32_t n_lo = Q < l_lo ? Q : l_lo;
-		hipLaunchKernelGGL(k_ntt_bs_pass<INV>, dim3((unsigned)(S >> kTileLog), n_batch), dim3(256), lds, s, bs, S, l_lo, R, n_lo, d_tb);
+		const dim3 grid((unsigned)(S >> kTileLog), n_batch);
+		if (l_lo == 0)
+			hipLaunchKernelGGL((k_ntt_bs_pass<INV, true>), grid, dim3(256), lds, s, bs, S, l_lo, R, n_lo, d_tb, (uint32_t *)data, lx, log_y);
+		else
+			hipLaunchKernelGGL((k_ntt_bs_pass<INV, false>), grid, dim3(256), lds, s, bs, S, l_lo, R, n_lo, d_tb, (uint32_t *)data, lx, log_y);
 	}
-	hipLaunchKernelGGL(k_ntt_bs_tail<INV>, dim3(blocks, n_batch), dim3(256), 0, s, bs, (uint32_t *)data, S, lx, log_y, d_tb, n_top);
+	if (INV || !merged)
+		hipLaunchKernelGGL(k_ntt_bs_tail<INV>, dim3(blocks, n_batch), dim3(256), 0, s, bs, (uint32_t *)data, S, lx, log_y, d_tb, n_top);
 	return hipGetLastError();
 }
 
