@@ -10,8 +10,9 @@
 //
 // Slicing.  Index p = c * S + i with c = the top 5 index bits, S = 2^(L-5).  The plane set of i is 32
 // registers W[j] whose bit c is bit j of element (c, i): 32 elements that are 2^(L-5) apart.
-//   * The 5 top layers (distance >= S) pair bit positions INSIDE the registers; their twiddles do not
-//     depend on i, so their plane patterns are launch constants (ttop).
+//   * The 5 top layers (distance >= S) pair elements INSIDE a plane set; their 31 twiddles do not
+//     depend on i.  They run word-level on the 32 words of the set, before the transpose, through
+//     per-twiddle nibble tables in LDS (bit-sliced they would compute on half-empty bit positions).
 //   * A lower layer l pairs plane sets i and i + 2^l.  The twiddle of bit position c is
 //     tw(l, (c*S + i) >> (l+1)) -- and the twiddle is GF(2)-linear in its index
 //     (OnTheFlyTwiddleAccess: XOR of basis values, crates/ntt/src/twiddle.rs:141-168), so its planes
@@ -33,7 +34,10 @@ namespace bn {
 namespace {
 
 struct ntt_bs_tables {
-	uint32_t ttop[5][32];  // [b][j]: twiddle planes of the top layer with in-register distance 2^b
+	// top layers: 31 launch-constant twiddles (layer b = distance 2^b among the 32 words of a set has
+	// 2^(4-b) of them, slot (16 >> b) - 1 + blk... see top_slot); per twiddle 8 nibble tables of 16
+	// products  tw * (e << 4p)  -- 16 KiB, staged in LDS by the head / tail kernels
+	uint32_t ttab[31][8][16];
 	uint32_t pat[32][32];  // [l][j]: c-dependent part of the twiddle planes of lower layer l
 	uint32_t rows[32][32]; // [l][bit]: basis value of bit `bit` of the block index i >> (l+1)
 	uint32_t tconst[32];   // [l]: coset contribution (uniform)
@@ -60,30 +64,56 @@ __device__ __forceinline__ void butterfly_planes(uint32_t (&U)[32], uint32_t (&V
 	}
 }
 
-// the five in-register layers of a plane set (distance 2^b in the bit positions)
-// (skip_rounds drops the highest layers: only b < n_top are applied)
+// slot of the twiddle of block `blk` of top layer b (b = 4: 1 block, ..., b = 0: 16 blocks)
+__host__ __device__ constexpr int top_slot(int b, int blk) { return (16 >> b) - 1 + blk; }
+
+// v * tw through the twiddle's nibble tables (LDS): 8 lookups, all lanes of a wave use the same
+// twiddle, so a lookup touches one 64-byte table row (conflict-free)
+__device__ __forceinline__ uint32_t top_mul(const uint32_t *tab /*[8][16]*/, uint32_t v)
+{
+	uint32_t r = 0;
+#pragma unroll
+	for (int p = 0; p < 8; p++)
+		r ^= tab[16 * p + ((v >> (4 * p)) & 15u)];
+	return r;
+}
+
+// The five top layers act among the 32 words W[c] = element (c, i) of one plane set BEFORE it is
+// transposed (forward) / after it is transposed back (inverse): butterflies (c, c + 2^b) with the
+// launch-constant twiddle of block c >> (b+1).  Word-level with nibble tables this is ~30 VALU per
+// butterfly; bit-sliced inside the registers it would run on half-empty bit positions (~78).
+// skip_rounds drops the highest layers: only b < n_top are applied.
 template <bool INV>
-__device__ __forceinline__ void top_layers(uint32_t (&W)[32], const uint32_t (*ttop)[32], uint32_t n_top)
+__device__ __forceinline__ void top_layers(uint32_t (&W)[32], const uint32_t *ttab_lds, uint32_t n_top)
 {
 #pragma unroll
 	for (int bb = 0; bb < 5; bb++) {
 		const int b = INV ? bb : 4 - bb;
 		if ((uint32_t)b >= n_top) continue;
-		constexpr uint32_t masks[5] = {0x55555555u, 0x33333333u, 0x0F0F0F0Fu, 0x00FF00FFu, 0x0000FFFFu};
-		const uint32_t mk = masks[b];
-		const int sh = 1 << b;
-		uint32_t U[32], V[32], T[32];
 #pragma unroll
-		for (int j = 0; j < 32; j++) {
-			U[j] = W[j] & mk;
-			V[j] = (W[j] >> sh) & mk;
-			T[j] = ttop[b][j];
+		for (int c = 0; c < 32; c++) {
+			if ((c >> b) & 1) continue;
+			const uint32_t *tab = ttab_lds + top_slot(b, c >> (b + 1)) * 128;
+			uint32_t u = W[c], v = W[c + (1 << b)];
+			if (INV) {
+				v ^= u;
+				u ^= top_mul(tab, v);
+			} else {
+				u ^= top_mul(tab, v);
+				v ^= u;
+			}
+			W[c] = u;
+			W[c + (1 << b)] = v;
 		}
-		butterfly_planes<INV>(U, V, T);
-#pragma unroll
-		for (int j = 0; j < 32; j++)
-			W[j] = U[j] | (V[j] << sh);
 	}
+}
+
+__device__ __forceinline__ void stage_top_tables(uint32_t *lds, const ntt_bs_tables *tb)
+{
+	const uint32_t *src = &tb->ttab[0][0][0];
+	for (unsigned q = threadIdx.x; q < 31 * 128; q += blockDim.x)
+		lds[q] = src[q];
+	__syncthreads();
 }
 
 // ---- head: standard layout -> plane sets; forward: then the five in-register layers (16, 8, .., 1)
@@ -92,6 +122,8 @@ template <bool INV>
 __global__ __launch_bounds__(256) void k_ntt_bs_head(const uint32_t *__restrict__ data, uint4 *__restrict__ bs, uint64_t S, uint32_t lx,
                                                      uint32_t log_y, const ntt_bs_tables *__restrict__ tb, uint32_t n_top)
 {
+	__shared__ uint32_t ttab_lds[31 * 128];
+	if (!INV) stage_top_tables(ttab_lds, tb);
 	const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
 	if (i >= S) return;
 	const uint64_t beta = blockIdx.y;
@@ -101,8 +133,8 @@ __global__ __launch_bounds__(256) void k_ntt_bs_head(const uint32_t *__restrict_
 #pragma unroll
 	for (int c = 0; c < 32; c++)
 		W[c] = data[((uint64_t)c * S + i) << lx];
+	if (!INV) top_layers<false>(W, ttab_lds, n_top);
 	transpose32(W);
-	if (!INV) top_layers<false>(W, tb->ttop, n_top);
 	uint4 *dst = bs + i * 8;
 #pragma unroll
 	for (int k = 0; k < 8; k++)
@@ -114,6 +146,8 @@ template <bool INV>
 __global__ __launch_bounds__(256) void k_ntt_bs_tail(const uint4 *__restrict__ bs, uint32_t *__restrict__ data, uint64_t S, uint32_t lx,
                                                      uint32_t log_y, const ntt_bs_tables *__restrict__ tb, uint32_t n_top)
 {
+	__shared__ uint32_t ttab_lds[31 * 128];
+	if (INV) stage_top_tables(ttab_lds, tb);
 	const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
 	if (i >= S) return;
 	const uint64_t beta = blockIdx.y;
@@ -129,8 +163,8 @@ __global__ __launch_bounds__(256) void k_ntt_bs_tail(const uint4 *__restrict__ b
 		W[4 * k + 2] = v.z;
 		W[4 * k + 3] = v.w;
 	}
-	if (INV) top_layers<true>(W, tb->ttop, n_top);
 	transpose32(W); // (an involution)
+	if (INV) top_layers<true>(W, ttab_lds, n_top);
 #pragma unroll
 	for (int c = 0; c < 32; c++)
 		data[((uint64_t)c * S + i) << lx] = W[c];
@@ -311,11 +345,11 @@ static hipError_t run_ntt_bs(hipStream_t s, void *data, const uint64_t *h_s_eval
 	std::memset(&tb, 0, sizeof(tb));
 	for (uint32_t b = 0; b < 5; b++) {
 		const uint32_t l = NB + b;
-		for (uint32_t c = 0; c < 32; c++) {
-			if ((c >> b) & 1) continue; // u positions only
-			const uint32_t tw = host_twiddle(h_s_evals, log_domain, base + l, (coset << (L - 1 - l)) | (c >> (b + 1)));
-			for (uint32_t j = 0; j < 32; j++)
-				if ((tw >> j) & 1) tb.ttop[b][j] |= 1u << c;
+		for (uint32_t blk = 0; blk < (16u >> b); blk++) {
+			const uint32_t tw = host_twiddle(h_s_evals, log_domain, base + l, (coset << (L - 1 - l)) | blk);
+			for (uint32_t p = 0; p < 8; p++)
+				for (uint32_t e = 0; e < 16; e++)
+					tb.ttab[top_slot((int)b, (int)blk)][p][e] = (uint32_t)mul_slow(f128{tw, 0}, f128{(uint64_t)e << (4 * p), 0}).lo;
 		}
 	}
 	for (uint32_t l = 0; l < NB; l++) {
