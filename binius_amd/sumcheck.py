@@ -126,15 +126,18 @@ class BivariateSumcheckProver:
         if kind != "coeffs":
             raise RuntimeError("ExpectedExecution")
         self.state = ("batched_sum", self._evaluate_univariate(val, challenge))
-        new = []
+        # exec.map over the multilinears (v3/bivariate_product.rs:217-228): one fold batch
+        e0s, e1s = [], []
         for kind, evals in self.multilins:
             evals_0, evals_1 = evals.split_half()
             if kind == "pre":
                 folded = self.dev_alloc.alloc(1 << (self.n_vars_remaining - 1))
                 self.hal.copy_d2d(evals_0, folded)
                 evals_0 = folded
-            self.hal.extrapolate_line(evals_0, evals_1, challenge)
-            new.append(("post", evals_0))
+            e0s.append(evals_0)
+            e1s.append(evals_1)
+        self.hal.extrapolate_line_batch(e0s, e1s, challenge)
+        new = [("post", e) for e in e0s]
         self.multilins = new
         self.n_vars_remaining -= 1
 
