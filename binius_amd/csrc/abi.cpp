@@ -984,8 +984,13 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 	uint64_t fused_seq = 0;
 	f128 *d_S = ctx->d_result;         // [0,64)
 	f128 *d_rets = ctx->d_result + 96;  // [96,128)
-	if (!ctx->s_clean)
+	bool has_sum = false;
+	for (uint32_t o = 0; o < n_ops; o++) has_sum |= ops[o].kind == BN_KOP_SUM_COMPOSITION;
+	if (!ctx->s_clean && has_sum) {
 		BN_HIP(hipMemsetAsync(d_S, 0, 64 * sizeof(f128), s));
+		ctx->s_clean = true;
+	}
+	const bool was_clean_or_zeroed = ctx->s_clean;
 	ctx->s_clean = false; // until the finalize kernel of THIS call has re-zeroed the slots it used
 
 	for (uint32_t o = 0; o < n_ops; o++) {
@@ -1300,8 +1305,10 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 
 	rc = flush_pending(ctx, /*keep_tail=*/true); // (a launch that ended up reading nothing)
 	if (rc) return rc;
-	if (n_ret == 0)
+	if (n_ret == 0) {
+		if (n_slots == 0) ctx->s_clean = was_clean_or_zeroed; // no accumulator was touched by this launch
 		return BN_OK;
+	}
 
 	// finalize on device: values = init ^ sum coeff*S ; rets gathered into d_rets (and d_out).
 	// Everything the kernel needs travels as a by-value kernel argument (no staging copies).
@@ -1398,12 +1405,8 @@ int bn_scalar_mul(const bn_f128 *a, const bn_f128 *b, bn_f128 *out)
 int bn_scalar_invert(const bn_f128 *a, bn_f128 *out)
 {
 	BN_REQUIRE(a && out, "null argument");
-	// a^(2^128 - 2) = prod_{i=1}^{127} a^(2^i); invert_or_zero semantics (0 -> 0)
-	f128 sq = to_f(a), r = bn::f128_one();
-	for (int i = 1; i < 128; i++) {
-		sq = bn::mul_slow(sq, sq);
-		r = bn::mul_slow(r, sq);
-	}
+	// invert_or_zero semantics (0 -> 0); tower descent, ~1 us on the host
+	f128 r = bn::invert_tower(to_f(a));
 	if (a->lo == 0 && a->hi == 0) r = bn::f128_zero();
 	out->lo = r.lo;
 	out->hi = r.hi;

@@ -50,8 +50,12 @@ def test_host_scalar_field_matches_oracle(ffi, oracle):
     for _ in range(200):
         a, b = rng.getrandbits(128), rng.getrandbits(128)
         assert ffi.HostField.mul(a, b) == oracle.mul(a, b)
-    for a in (1, 2, rng.getrandbits(128)):
-        assert ffi.HostField.mul(a, ffi.HostField.invert(a)) == 1
+    cases = [1, 2, 3, 0xFF, 1 << 64, (1 << 64) - 1, (1 << 128) - 1] + [1 << i for i in range(0, 128, 7)]
+    cases += [rng.getrandbits(w) | 1 for w in (2, 4, 8, 16, 32, 64, 128) for _ in range(20)]
+    for a in cases:
+        inv = ffi.HostField.invert(a)
+        assert ffi.HostField.mul(a, inv) == 1
+        assert inv == oracle.invert(a)
     assert ffi.HostField.invert(0) == 0
 
 
