@@ -129,6 +129,9 @@ def lib():
         "bn_prof_end": [vp, C.POINTER(C.c_double), C.POINTER(u64)],
         "bn_xor_reduce": [vp, vp, u32, u32, PF],
         "bn_host_scratch": [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)],
+        "bn_merkle_build": [vp, vp, u64, u64, vp],
+        "bn_groestl256_leaves": [vp, vp, u64, u64, vp],
+        "bn_groestl256_compress_layer": [vp, vp, u64, vp],
         "bn_timer_begin": [vp],
         "bn_timer_end_ms": [vp, C.POINTER(C.c_float)],
     }
@@ -149,6 +152,7 @@ ABI_SYMBOLS = [
     "bn_compute_composite", "bn_pairwise_product_reduce", "bn_log_chunks_range", "bn_pick_log_chunks",
     "bn_kernel_launch", "bn_ntt_forward", "bn_ntt_inverse", "bn_ntt_s_evals", "bn_scalar_mul", "bn_scalar_invert",
     "bn_timer_begin", "bn_timer_end_ms", "bn_prof_begin", "bn_prof_end", "bn_xor_reduce", "bn_host_scratch",
+    "bn_merkle_build", "bn_groestl256_leaves", "bn_groestl256_compress_layer",
 ]
 
 
@@ -490,6 +494,23 @@ class Context:
                 ch, len(challenges), data_in.ptr, data_in.len, data_out.ptr, data_out.len,
             )
         )
+
+    # ---- Merkle commitment with Groestl-256 (include/binius_amd.h; digests are 2 arena elements each)
+    def merkle_build(self, elems, batch_size, nodes):
+        """nodes: DevSlice of 2 * (2 * n_leaves - 1) elements receiving the flattened tree."""
+        if batch_size and elems.len % batch_size == 0 and nodes.len != 2 * (2 * (elems.len // batch_size) - 1):
+            raise BnError(BN_ERR_INPUT_VALIDATION, "input validation: merkle_build: nodes must hold 2 * n_leaves - 1 digests")
+        _check(lib().bn_merkle_build(self._h, elems.ptr, elems.len, batch_size, nodes.ptr))
+
+    def groestl256_leaves(self, elems, batch_size, digests):
+        if batch_size and elems.len % batch_size == 0 and digests.len != 2 * (elems.len // batch_size):
+            raise BnError(BN_ERR_INPUT_VALIDATION, "input validation: groestl256_leaves: digests must hold one digest per batch")
+        _check(lib().bn_groestl256_leaves(self._h, elems.ptr, elems.len, batch_size, digests.ptr))
+
+    def groestl256_compress_layer(self, prev, nxt):
+        if prev.len != 2 * nxt.len:
+            raise BnError(BN_ERR_INPUT_VALIDATION, "input validation: compress_layer: the next layer is half the previous one")
+        _check(lib().bn_groestl256_compress_layer(self._h, prev.ptr, nxt.len // 2, nxt.ptr))
 
     def compute_composite(self, inputs, output, composition):
         rows = (C.c_void_p * max(1, len(inputs)))(*[r.ptr for r in inputs])

@@ -1392,6 +1392,39 @@ int bn_xor_reduce(bn_ctx *ctx, const void *d_vals, uint32_t n_groups, uint32_t g
 	return BN_OK;
 }
 
+// ---------------------------------------------------------------------------------- Merkle / Groestl
+int bn_groestl256_leaves(bn_ctx *ctx, const void *d_elems, uint64_t n_elems, uint64_t batch_size, void *d_digests)
+{
+	BN_REQUIRE(ctx && d_elems && d_digests, "null argument");
+	BN_ENTER(ctx);
+	BN_FLUSH(ctx);
+	BN_REQUIRE(batch_size != 0 && n_elems % batch_size == 0, "IncorrectBatchSize");
+	BN_HIP(bn::launch_groestl_leaves(ctx->stream, ctx->n_cu, d_elems, batch_size, n_elems / batch_size, d_digests));
+	return BN_OK;
+}
+
+int bn_groestl256_compress_layer(bn_ctx *ctx, const void *d_prev, uint64_t n_out, void *d_next)
+{
+	BN_REQUIRE(ctx && d_prev && d_next, "null argument");
+	BN_ENTER(ctx);
+	BN_FLUSH(ctx);
+	BN_HIP(bn::launch_groestl_layer(ctx->stream, ctx->n_cu, d_prev, n_out, d_next));
+	return BN_OK;
+}
+
+int bn_merkle_build(bn_ctx *ctx, const void *d_elems, uint64_t n_elems, uint64_t batch_size, void *d_nodes)
+{
+	BN_REQUIRE(ctx && d_elems && d_nodes, "null argument");
+	BN_ENTER(ctx);
+	BN_FLUSH(ctx);
+	BN_REQUIRE(batch_size != 0 && n_elems % batch_size == 0, "IncorrectBatchSize");
+	const uint64_t n_leaves = n_elems / batch_size;
+	BN_REQUIRE(n_leaves != 0 && (n_leaves & (n_leaves - 1)) == 0, "PowerOfTwoLengthRequired");
+	BN_HIP(bn::launch_groestl_leaves(ctx->stream, ctx->n_cu, d_elems, batch_size, n_leaves, d_nodes));
+	BN_HIP(bn::launch_merkle_layers(ctx->stream, ctx->n_cu, d_nodes, n_leaves));
+	return BN_OK;
+}
+
 // ---------------------------------------------------------------------------------- host scalars
 int bn_scalar_mul(const bn_f128 *a, const bn_f128 *b, bn_f128 *out)
 {

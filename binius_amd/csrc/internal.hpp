@@ -225,4 +225,10 @@ hipError_t launch_ntt_bs(hipStream_t s, bool inverse, void *data, const uint64_t
                          uint32_t log_y, uint32_t log_z, uint64_t coset, uint32_t coset_bits, uint32_t skip_rounds, void *d_scratch,
                          ntt_bs_cache *cache);
 
+
+// ---- kernels_groestl.hip: Groestl-256 leaves, 2-to-1 compression layers, the flattened Merkle tree
+hipError_t launch_groestl_leaves(hipStream_t s, int n_cu, const void *elems, uint64_t batch, uint64_t n_leaves, void *digests);
+hipError_t launch_groestl_layer(hipStream_t s, int n_cu, const void *prev, uint64_t n_out, void *next);
+hipError_t launch_merkle_layers(hipStream_t s, int n_cu, void *nodes, uint64_t n_leaves);
+
 } // namespace bn

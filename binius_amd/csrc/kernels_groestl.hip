@@ -1,0 +1,385 @@
+// binius_amd/csrc/kernels_groestl.hip -- Groestl-256 leaf hashing, the Groestl 2-to-1 compression and
+// the binary Merkle tree of the reference's vector commitment, on device.
+//
+// What it replaces: BinaryMerkleTreeProver::commit (crates/core/src/merkle_tree/prover.rs:47-62) ->
+// binary_merkle_tree::build (binary_merkle_tree.rs:27-101) with H = Groestl256
+// (crates/hash/src/groestl/digest.rs:30-87) and C = Groestl256ByteCompression (compression.rs:21-36),
+// which the FRI prover calls on every folded codeword after copying it to the host
+// (crates/core/src/protocols/fri/prove.rs:395-420).  With the tree built on device only the
+// 64 B-per-leaf node array crosses PCIe for the commitment, not the codeword.
+//
+// Shape.  One lane = one hash instance: its state is the 8 x 8 byte matrix as eight little-endian
+// 64-bit columns (16 VGPRs); a round is AddRoundConstant on the columns, then SubBytes + ShiftBytes +
+// MixBytes as 64 lookups of the fused column table T0[b] = S(b) * (02 02 03 04 05 03 05 07)^T
+// (the other seven row tables are byte rotations of T0: v_alignbyte).  Byte work, no GEMM shape; the
+// bound is LDS lookups + VALU issue, far under the HBM roofline (~150 lane-ops per message byte).
+//
+// LDS.  T0 is 2 KiB; it is replicated 32 times (64 KiB), copy c = lane & 31 at byte offset
+// b * 256 + c * 8, so that every half-wave ds_read_b64 touches 32 distinct bank pairs whatever the
+// data is: no bank conflicts (a single shared copy serialises ~3.5x on random bytes).  The lookup
+// address {0, 0, byte, lane offset} is one v_perm_b32.
+#include <hip/hip_runtime.h>
+
+#include "internal.hpp"
+
+namespace bn {
+
+namespace {
+
+// ---- the column table, generated at compile time from the definitions (specification 3.4.3, 3.4.5)
+struct groestl_t0 {
+	uint64_t v[256];
+};
+
+constexpr uint8_t gr_xtime(uint8_t x) { return (uint8_t)((x << 1) ^ ((x & 0x80) ? 0x1B : 0)); }
+constexpr uint8_t gr_rotl8(uint8_t x, int s) { return (uint8_t)((x << s) | (x >> (8 - s))); }
+
+constexpr groestl_t0 make_groestl_t0()
+{
+	uint8_t sbox[256] = {};
+	uint8_t p = 1, q = 1;
+	do { // p runs over the multiplicative group of GF(2^8) (times 3), q = 1 / p
+		p = (uint8_t)(p ^ (p << 1) ^ ((p & 0x80) ? 0x1B : 0));
+		q = (uint8_t)(q ^ (q << 1));
+		q = (uint8_t)(q ^ (q << 2));
+		q = (uint8_t)(q ^ (q << 4));
+		if (q & 0x80) q = (uint8_t)(q ^ 0x09);
+		sbox[p] = (uint8_t)(q ^ gr_rotl8(q, 1) ^ gr_rotl8(q, 2) ^ gr_rotl8(q, 3) ^ gr_rotl8(q, 4) ^ 0x63);
+	} while (p != 1);
+	sbox[0] = 0x63;
+	// byte r of T0[b] = circ[(0 - r) mod 8] * S(b): what a byte in row 0 of a column adds to row r
+	const int circ[8] = {2, 2, 3, 4, 5, 3, 5, 7};
+	groestl_t0 t{};
+	for (int b = 0; b < 256; b++) {
+		const uint8_t s1 = sbox[b], s2 = gr_xtime(s1), s4 = gr_xtime(s2);
+		uint64_t w = 0;
+		for (int r = 0; r < 8; r++) {
+			const int m = circ[(8 - r) & 7];
+			const uint8_t e = (uint8_t)(((m & 1) ? s1 : 0) ^ ((m & 2) ? s2 : 0) ^ ((m & 4) ? s4 : 0));
+			w |= (uint64_t)e << (8 * r);
+		}
+		t.v[b] = w;
+	}
+	return t;
+}
+
+__constant__ groestl_t0 kGroestlT0 = make_groestl_t0();
+
+constexpr int kCopies = 32;
+constexpr unsigned kTableBytes = 256 * kCopies * 8; // 64 KiB
+
+__device__ __forceinline__ void stage_table(uint2 *tab)
+{
+	for (unsigned i = threadIdx.x; i < 256u * kCopies; i += blockDim.x) {
+		const uint64_t w = kGroestlT0.v[i >> 5];
+		tab[i] = uint2{(uint32_t)w, (uint32_t)(w >> 32)};
+	}
+	__syncthreads();
+}
+
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
+
+// the state: column c = (lo[c], hi[c]), row r of the column = byte r of the 64-bit value
+struct gstate {
+	uint32_t lo[8], hi[8];
+};
+
+// table value of byte K (0..7) of column `col`, rotated up by K bytes, XORed into (alo, ahi) pairs
+template <int K>
+__device__ __forceinline__ uint2 lookup(const char *tab_lane, uint32_t lo, uint32_t hi, uint32_t lane_off)
+{
+	// address = byte << 8 | lane_off: bytes {lane_off.b0, word.bK, 0, 0}
+	const uint32_t word = K < 4 ? lo : hi;
+	constexpr uint32_t sel = 0x0C0C0000u | ((4u + (K & 3)) << 8) | 0u;
+	const uint32_t addr = __builtin_amdgcn_perm(word, lane_off, sel);
+	return *reinterpret_cast<const uint2 *>(tab_lane + addr);
+}
+
+// ROTL64(t, 8K) XORed later: returns the rotated pair
+template <int K>
+__device__ __forceinline__ uint2 rot_bytes(uint2 t)
+{
+	if constexpr (K == 0) return t;
+	else if constexpr (K == 4) return uint2{t.y, t.x};
+	else if constexpr (K < 4)
+		return uint2{__builtin_amdgcn_alignbyte(t.x, t.y, 4 - K), __builtin_amdgcn_alignbyte(t.y, t.x, 4 - K)};
+	else
+		return uint2{__builtin_amdgcn_alignbyte(t.y, t.x, 8 - K), __builtin_amdgcn_alignbyte(t.x, t.y, 8 - K)};
+}
+
+template <bool Q>
+struct shifts;
+template <>
+struct shifts<false> {
+	static constexpr int s[8] = {0, 1, 2, 3, 4, 5, 6, 7};
+};
+template <>
+struct shifts<true> {
+	static constexpr int s[8] = {1, 3, 5, 7, 0, 2, 4, 6};
+};
+
+// one output column: XOR_k T_k[row k of column (C + sigma_k) mod 8]
+template <bool Q, int C>
+__device__ __forceinline__ void column(const gstate &in, gstate &out, const char *tab, uint32_t lane_off)
+{
+	using S = shifts<Q>;
+	const uint2 t0 = rot_bytes<0>(lookup<0>(tab, in.lo[(C + S::s[0]) & 7], in.hi[(C + S::s[0]) & 7], lane_off));
+	const uint2 t1 = rot_bytes<1>(lookup<1>(tab, in.lo[(C + S::s[1]) & 7], in.hi[(C + S::s[1]) & 7], lane_off));
+	const uint2 t2 = rot_bytes<2>(lookup<2>(tab, in.lo[(C + S::s[2]) & 7], in.hi[(C + S::s[2]) & 7], lane_off));
+	const uint2 t3 = rot_bytes<3>(lookup<3>(tab, in.lo[(C + S::s[3]) & 7], in.hi[(C + S::s[3]) & 7], lane_off));
+	const uint2 t4 = rot_bytes<4>(lookup<4>(tab, in.lo[(C + S::s[4]) & 7], in.hi[(C + S::s[4]) & 7], lane_off));
+	const uint2 t5 = rot_bytes<5>(lookup<5>(tab, in.lo[(C + S::s[5]) & 7], in.hi[(C + S::s[5]) & 7], lane_off));
+	const uint2 t6 = rot_bytes<6>(lookup<6>(tab, in.lo[(C + S::s[6]) & 7], in.hi[(C + S::s[6]) & 7], lane_off));
+	const uint2 t7 = rot_bytes<7>(lookup<7>(tab, in.lo[(C + S::s[7]) & 7], in.hi[(C + S::s[7]) & 7], lane_off));
+	out.lo[C] = xor3(xor3(t0.x, t1.x, t2.x), xor3(t3.x, t4.x, t5.x), t6.x ^ t7.x);
+	out.hi[C] = xor3(xor3(t0.y, t1.y, t2.y), xor3(t3.y, t4.y, t5.y), t6.y ^ t7.y);
+}
+
+template <bool Q>
+__device__ __forceinline__ void round_fn(gstate &s, uint32_t rnd, const char *tab, uint32_t lane_off)
+{
+	// AddRoundConstant (3.4.2): P: row 0 of column c ^= (c << 4) ^ round;
+	// Q: everything ^= 0xFF, row 7 of column c additionally ^= (c << 4) ^ round
+#pragma unroll
+	for (int c = 0; c < 8; c++) {
+		if constexpr (!Q) {
+			s.lo[c] ^= (uint32_t)(c << 4) ^ rnd;
+		} else {
+			s.lo[c] = ~s.lo[c];
+			s.hi[c] = ~s.hi[c] ^ (((uint32_t)(c << 4) ^ rnd) << 24);
+		}
+	}
+	gstate n;
+	column<Q, 0>(s, n, tab, lane_off);
+	column<Q, 1>(s, n, tab, lane_off);
+	column<Q, 2>(s, n, tab, lane_off);
+	column<Q, 3>(s, n, tab, lane_off);
+	column<Q, 4>(s, n, tab, lane_off);
+	column<Q, 5>(s, n, tab, lane_off);
+	column<Q, 6>(s, n, tab, lane_off);
+	column<Q, 7>(s, n, tab, lane_off);
+	s = n;
+}
+
+// P alone (output transformation, 2-to-1 compression)
+__device__ __forceinline__ void perm_p(gstate &s, const char *tab, uint32_t lane_off)
+{
+#pragma unroll 1
+	for (uint32_t r = 0; r < 10; r++) round_fn<false>(s, r, tab, lane_off);
+}
+
+// h <- P(h ^ m) ^ Q(m) ^ h (crates/hash/src/groestl/mod.rs:26-34); the two permutations advance together:
+// two independent dependency chains per lane
+__device__ __forceinline__ void compress(gstate &h, const gstate &m, const char *tab, uint32_t lane_off)
+{
+	gstate p, q;
+#pragma unroll
+	for (int c = 0; c < 8; c++) {
+		p.lo[c] = h.lo[c] ^ m.lo[c];
+		p.hi[c] = h.hi[c] ^ m.hi[c];
+		q.lo[c] = m.lo[c];
+		q.hi[c] = m.hi[c];
+	}
+#pragma unroll 1
+	for (uint32_t r = 0; r < 10; r++) {
+		round_fn<false>(p, r, tab, lane_off);
+		round_fn<true>(q, r, tab, lane_off);
+	}
+#pragma unroll
+	for (int c = 0; c < 8; c++) {
+		h.lo[c] ^= p.lo[c] ^ q.lo[c];
+		h.hi[c] ^= p.hi[c] ^ q.hi[c];
+	}
+}
+
+// Omega(x) = the last 32 bytes of P(x) ^ x = columns 4..7
+__device__ __forceinline__ void output_transform(const gstate &x, uint4 &d0, uint4 &d1, const char *tab, uint32_t lane_off)
+{
+	gstate p = x;
+	perm_p(p, tab, lane_off);
+	d0 = uint4{p.lo[4] ^ x.lo[4], p.hi[4] ^ x.hi[4], p.lo[5] ^ x.lo[5], p.hi[5] ^ x.hi[5]};
+	d1 = uint4{p.lo[6] ^ x.lo[6], p.hi[6] ^ x.hi[6], p.lo[7] ^ x.lo[7], p.hi[7] ^ x.hi[7]};
+}
+
+__device__ __forceinline__ void set_cols(gstate &m, int c0, uint4 v)
+{
+	m.lo[c0] = v.x;
+	m.hi[c0] = v.y;
+	m.lo[c0 + 1] = v.z;
+	m.hi[c0 + 1] = v.w;
+}
+
+constexpr int kThreads = 512;
+
+// digest[leaf] = Groestl-256(elems[leaf * batch .. (leaf + 1) * batch) as 16 * batch bytes)
+// (binary_merkle_tree.rs:175-211 hash_interleaved; digest.rs:62-87 padding: 16 * batch mod 64 is at
+// most 48 < 56, so there is always exactly one padding block and the block count is full + 1)
+__global__ __launch_bounds__(kThreads) void k_groestl_leaves(const uint4 *__restrict__ elems, uint64_t batch, uint64_t n_leaves,
+                                                             uint4 *__restrict__ digests)
+{
+	extern __shared__ __align__(16) unsigned char smem[];
+	stage_table(reinterpret_cast<uint2 *>(smem));
+	const char *tab = reinterpret_cast<const char *>(smem);
+	const uint32_t lane_off = (threadIdx.x & (kCopies - 1)) * 8;
+	const uint64_t n_full = batch >> 2; // 64-byte blocks
+	const uint32_t rem = (uint32_t)(batch & 3);
+	uint32_t cnt = (uint32_t)(n_full + 1); // (a leaf of 2^38 bytes does not exist: 32 bits are enough)
+	cnt = __builtin_bswap32(cnt);
+	for (uint64_t leaf = (uint64_t)blockIdx.x * kThreads + threadIdx.x; leaf < n_leaves; leaf += (uint64_t)gridDim.x * kThreads) {
+		const uint4 *src = elems + leaf * batch;
+		gstate h;
+#pragma unroll
+		for (int c = 0; c < 8; c++) h.lo[c] = h.hi[c] = 0;
+		h.hi[7] = 0x00010000u; // byte 62 = 0x01: the output length 256 as a big-endian 64-bit integer in column 7
+		for (uint64_t b = 0; b < n_full; b++) {
+			gstate m;
+			set_cols(m, 0, src[4 * b]);
+			set_cols(m, 2, src[4 * b + 1]);
+			set_cols(m, 4, src[4 * b + 2]);
+			set_cols(m, 6, src[4 * b + 3]);
+			compress(h, m, tab, lane_off);
+		}
+		{
+			gstate m;
+#pragma unroll
+			for (int c = 0; c < 8; c++) m.lo[c] = m.hi[c] = 0;
+			const uint4 *tail = src + 4 * n_full;
+			if (rem > 0) set_cols(m, 0, tail[0]);
+			if (rem > 1) set_cols(m, 2, tail[1]);
+			if (rem > 2) set_cols(m, 4, tail[2]);
+			// 0x80 right after the message: byte 16 * rem = row 0 of column 2 * rem
+			if (rem == 0) m.lo[0] = 0x80;
+			if (rem == 1) m.lo[2] = 0x80;
+			if (rem == 2) m.lo[4] = 0x80;
+			if (rem == 3) m.lo[6] = 0x80;
+			m.hi[7] = cnt; // the block count, big-endian, in the last 8 bytes
+			compress(h, m, tab, lane_off);
+		}
+		uint4 d0, d1;
+		output_transform(h, d0, d1, tab, lane_off);
+		digests[2 * leaf] = d0;
+		digests[2 * leaf + 1] = d1;
+	}
+}
+
+// next[i] = last 32 bytes of P(x) ^ x, x = prev[2i] || prev[2i+1]  (compression.rs:21-36,
+// binary_merkle_tree.rs:158-168 compress_layer)
+__global__ __launch_bounds__(kThreads) void k_groestl_layer(const uint4 *__restrict__ prev, uint64_t n_out, uint4 *__restrict__ next)
+{
+	extern __shared__ __align__(16) unsigned char smem[];
+	stage_table(reinterpret_cast<uint2 *>(smem));
+	const char *tab = reinterpret_cast<const char *>(smem);
+	const uint32_t lane_off = (threadIdx.x & (kCopies - 1)) * 8;
+	for (uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x; i < n_out; i += (uint64_t)gridDim.x * kThreads) {
+		gstate x;
+		set_cols(x, 0, prev[4 * i]);
+		set_cols(x, 2, prev[4 * i + 1]);
+		set_cols(x, 4, prev[4 * i + 2]);
+		set_cols(x, 6, prev[4 * i + 3]);
+		uint4 d0, d1;
+		output_transform(x, d0, d1, tab, lane_off);
+		next[2 * i] = d0;
+		next[2 * i + 1] = d1;
+	}
+}
+
+// The top of the tree in one workgroup: layer of n_in <= 2 * kThreads digests at `layer`, every
+// following layer written right behind it (the flattened order of binary_merkle_tree.rs:22-25), down
+// to the root.  The levels are exchanged through LDS.
+__global__ __launch_bounds__(kThreads) void k_groestl_top(uint4 *__restrict__ layer, uint32_t n_in)
+{
+	extern __shared__ __align__(16) unsigned char smem[];
+	stage_table(reinterpret_cast<uint2 *>(smem));
+	const char *tab = reinterpret_cast<const char *>(smem);
+	uint4 *xch = reinterpret_cast<uint4 *>(smem + kTableBytes); // 2 * kThreads digests = 32 KiB
+	const uint32_t lane_off = (threadIdx.x & (kCopies - 1)) * 8;
+	for (uint32_t i = threadIdx.x; i < 2 * n_in; i += kThreads) xch[i] = layer[i];
+	__syncthreads();
+	uint4 *out = layer + 2 * (uint64_t)n_in;
+	for (uint32_t n = n_in >> 1; n >= 1; n >>= 1) {
+		const bool act = threadIdx.x < n;
+		gstate x;
+		const uint32_t i = act ? threadIdx.x : 0;
+		set_cols(x, 0, xch[4 * i]);
+		set_cols(x, 2, xch[4 * i + 1]);
+		set_cols(x, 4, xch[4 * i + 2]);
+		set_cols(x, 6, xch[4 * i + 3]);
+		uint4 d0, d1;
+		output_transform(x, d0, d1, tab, lane_off);
+		__syncthreads(); // everybody has read its children
+		if (act) {
+			xch[2 * i] = d0;
+			xch[2 * i + 1] = d1;
+			out[2 * i] = d0;
+			out[2 * i + 1] = d1;
+		}
+		__syncthreads();
+		out += 2 * (uint64_t)n;
+	}
+}
+
+} // namespace
+
+static hipError_t set_lds_limits()
+{
+	static hipError_t once = [] {
+		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_groestl_leaves), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTableBytes);
+		if (e != hipSuccess) return e;
+		e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_groestl_layer), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTableBytes);
+		if (e != hipSuccess) return e;
+		return hipFuncSetAttribute(reinterpret_cast<const void *>(k_groestl_top), hipFuncAttributeMaxDynamicSharedMemorySize,
+		                           (int)(kTableBytes + 2 * kThreads * 32));
+	}();
+	return once;
+}
+
+static unsigned grid_for(uint64_t n, int n_cu)
+{
+	uint64_t blocks = (n + kThreads - 1) / kThreads;
+	const uint64_t cap = (uint64_t)n_cu * 2; // two 64 KiB tables per CU
+	if (blocks > cap) blocks = cap;
+	return (unsigned)(blocks ? blocks : 1);
+}
+
+hipError_t launch_groestl_leaves(hipStream_t s, int n_cu, const void *elems, uint64_t batch, uint64_t n_leaves, void *digests)
+{
+	if (n_leaves == 0) return hipSuccess;
+	hipError_t e = set_lds_limits();
+	if (e != hipSuccess) return e;
+	hipLaunchKernelGGL(k_groestl_leaves, dim3(grid_for(n_leaves, n_cu)), dim3(kThreads), kTableBytes, s, (const uint4 *)elems, batch, n_leaves,
+	                   (uint4 *)digests);
+	return hipGetLastError();
+}
+
+hipError_t launch_groestl_layer(hipStream_t s, int n_cu, const void *prev, uint64_t n_out, void *next)
+{
+	if (n_out == 0) return hipSuccess;
+	hipError_t e = set_lds_limits();
+	if (e != hipSuccess) return e;
+	hipLaunchKernelGGL(k_groestl_layer, dim3(grid_for(n_out, n_cu)), dim3(kThreads), kTableBytes, s, (const uint4 *)prev, n_out, (uint4 *)next);
+	return hipGetLastError();
+}
+
+// nodes: the flattened tree (leaf digests already at the front).  Large layers one launch each, the
+// last <= 2 * kThreads-wide layers in one workgroup.
+hipError_t launch_merkle_layers(hipStream_t s, int n_cu, void *nodes, uint64_t n_leaves)
+{
+	hipError_t e = set_lds_limits();
+	if (e != hipSuccess) return e;
+	char *layer = (char *)nodes;
+	uint64_t n = n_leaves;
+	while (n > 2 * (uint64_t)kThreads) {
+		char *next = layer + 32 * n;
+		e = launch_groestl_layer(s, n_cu, layer, n >> 1, next);
+		if (e != hipSuccess) return e;
+		layer = next;
+		n >>= 1;
+	}
+	if (n >= 2) {
+		hipLaunchKernelGGL(k_groestl_top, dim3(1), dim3(kThreads), kTableBytes + 2 * kThreads * 32, s, (uint4 *)layer, (uint32_t)n);
+		return hipGetLastError();
+	}
+	return hipSuccess;
+}
+
+} // namespace bn

@@ -189,6 +189,24 @@ int bn_host_scratch(bn_ctx *ctx, void **h_ptr, void **d_ptr, uint64_t *elems);
  * the multi-GPU prover (RCCL has no XOR reduction). */
 int bn_xor_reduce(bn_ctx *ctx, const void *d_vals, uint32_t n_groups, uint32_t group_len, bn_f128 *h_out);
 
+/* ---- Merkle commitment of a BinaryField128b vector with Groestl-256.
+ * BinaryMerkleTreeProver::commit (crates/core/src/merkle_tree/prover.rs:47-62) =
+ * binary_merkle_tree::build (binary_merkle_tree.rs:27-101) with H = Groestl256
+ * (crates/hash/src/groestl/digest.rs:30-87) and C = Groestl256ByteCompression
+ * (crates/hash/src/groestl/compression.rs:21-36), which the FRI prover runs on the host copy of every
+ * folded codeword (crates/core/src/protocols/fri/prove.rs:395-420).
+ * Leaf i = Groestl-256 of the canonical serialization (16 little-endian bytes per element,
+ * crates/utils/src/serialization.rs:94-104) of elements [i * batch_size, (i + 1) * batch_size).
+ * d_nodes receives the flattened tree, (2 * n_leaves - 1) digests of 32 bytes = 2 * (2 * n_leaves - 1)
+ * arena elements, leaves first, root last (binary_merkle_tree.rs:22-25).  No synchronisation.
+ * Errors as the reference: n_elems % batch_size != 0 -> "IncorrectBatchSize", leaf count not a power
+ * of two -> "PowerOfTwoLengthRequired" (both BN_ERR_INPUT_VALIDATION). */
+int bn_merkle_build(bn_ctx *ctx, const void *d_elems, uint64_t n_elems, uint64_t batch_size, void *d_nodes);
+/* hash_interleaved alone (binary_merkle_tree.rs:175-211): d_digests[i] = Groestl-256(batch i), 32 B each. */
+int bn_groestl256_leaves(bn_ctx *ctx, const void *d_elems, uint64_t n_elems, uint64_t batch_size, void *d_digests);
+/* compress_layer alone (binary_merkle_tree.rs:158-168): d_next[i] = C(d_prev[2i], d_prev[2i+1]), i < n_out. */
+int bn_groestl256_compress_layer(bn_ctx *ctx, const void *d_prev, uint64_t n_out, void *d_next);
+
 /* Per-kernel-class timing without perturbing the stream: while profiling is on, every launch of a
  * hot kernel is bracketed by two hipEvents recorded on the context's stream (no synchronisation);
  * bn_prof_end synchronises once and sums the elapsed times per class. */

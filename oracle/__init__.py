@@ -183,6 +183,11 @@ def lib():
         ]
         L.ref_mle_evaluate.restype = B128
         L.ref_mle_evaluate.argtypes = [C.POINTER(B128), C.c_uint, C.POINTER(B128)]
+        U8P = C.POINTER(C.c_uint8)
+        L.ref_groestl256.argtypes = [C.c_char_p, C.c_size_t, U8P]
+        L.ref_groestl256_compress2.argtypes = [C.c_char_p, C.c_char_p, U8P]
+        L.ref_merkle_build.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
+        L.ref_merkle_root_from_branch.argtypes = [C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint32, U8P]
         L.ref_evaluate_univariate.restype = B128
         L.ref_evaluate_univariate.argtypes = [C.POINTER(B128), C.c_size_t, B128]
         _lib = L
@@ -499,3 +504,34 @@ def mle_evaluate(evals, n_vars, point):
 def evaluate_univariate(coeffs, x):
     c = ints_to_arr(list(coeffs))
     return from_b128(lib().ref_evaluate_univariate(_p(c), len(coeffs), to_b128(x)))
+
+
+# ---- Groestl-256 and the binary Merkle tree (oracle/merkle_ref.h)
+def groestl256(msg):
+    out = (C.c_uint8 * 32)()
+    lib().ref_groestl256(bytes(msg), len(msg), out)
+    return bytes(out)
+
+
+def groestl256_compress2(left, right):
+    assert len(left) == 32 and len(right) == 32
+    out = (C.c_uint8 * 32)()
+    lib().ref_groestl256_compress2(bytes(left), bytes(right), out)
+    return bytes(out)
+
+
+def merkle_build(elems, batch_size):
+    """elems: (n, 2) uint64 array of BinaryField128b.  Returns (rc, nodes) with nodes a
+    (2 * n_leaves - 1, 32) uint8 array: layers flattened leaves first, root last."""
+    elems = np.ascontiguousarray(elems, dtype=np.uint64)
+    n = elems.shape[0]
+    n_leaves = n // batch_size if batch_size else 0
+    nodes = np.zeros((max(2 * n_leaves - 1, 1), 32), dtype=np.uint8)
+    rc = lib().ref_merkle_build(elems.ctypes.data, n, batch_size, nodes.ctypes.data)
+    return rc, nodes
+
+
+def merkle_root_from_branch(leaf_digest, index, branch):
+    out = (C.c_uint8 * 32)()
+    lib().ref_merkle_root_from_branch(bytes(leaf_digest), index, b"".join(bytes(b) for b in branch), len(branch), out)
+    return bytes(out)
