@@ -9,9 +9,11 @@
 #include <string>
 #include <vector>
 
+#include "../../binius_amd/host/merkle.hpp"
 #include "../../binius_amd/host/sumcheck.hpp"
 extern "C" {
 #include "../../oracle/layer_ref.h"
+#include "../../oracle/merkle_ref.h"
 #include "../../oracle/ntt_ref.h"
 #include "../../oracle/sumcheck_ref.h"
 }
@@ -451,6 +453,51 @@ static void test_ntt(Env &e)
 	CHECK(got == data);
 }
 
+// crates/core/src/merkle_tree/tests.rs:13-45, 47-88, 90-102: commit, open every index at every layer,
+// verify with the oracle's restatement of verify_opening / verify_layer / verify_vector
+static void test_binary_merkle_vcs(Env &e)
+{
+	ComputeData d = e.holder.to_data();
+	const size_t batch = 4, log_len = 5, n = batch << log_len;
+	auto data = random_vec(0x3E7, n);
+	FSliceMut dd = d.dev_alloc.alloc(n);
+	d.hal->copy_h2d(data, dd);
+	BinaryMerkleTreeProver prover(*d.hal);
+	auto [commitment, tree] = prover.commit(C(dd), batch, d.dev_alloc);
+	CHECK(commitment.depth == log_len);
+	CHECK(commitment.root == tree.root());
+	// verify_vector: the whole tree recomputed by the oracle
+	std::vector<Digest> want(2 * ((size_t)1 << log_len) - 1);
+	CHECK(ref_merkle_build(reinterpret_cast<const uint8_t *>(data.data()), n, batch, want[0].data()) == 0);
+	CHECK(want == tree.inner_nodes);
+	for (size_t layer_depth = 0; layer_depth <= log_len; layer_depth++) {
+		auto [layer, layer_len] = prover.layer(tree, layer_depth);
+		CHECK(layer_len == (size_t)1 << layer_depth);
+		for (size_t index = 0; index < (size_t)1 << log_len; index++) {
+			auto branch = prover.prove_opening(tree, layer_depth, index);
+			CHECK(branch.size() == log_len - layer_depth);
+			Digest leaf, top;
+			ref_groestl256(reinterpret_cast<const uint8_t *>(data.data() + index * batch), 16 * batch, leaf.data());
+			ref_merkle_root_from_branch(leaf.data(), index, branch.empty() ? nullptr : branch[0].data(), (uint32_t)branch.size(), top.data());
+			CHECK(top == layer[index >> (log_len - layer_depth)]);
+		}
+	}
+	bool threw = false;
+	try {
+		prover.commit(ComputeMemory::slice(C(dd), 0, 24), 5, d.dev_alloc);
+	} catch (const Error &ex) {
+		threw = ex.kind() == Error::InputValidation && std::string(ex.what()).find("IncorrectBatchSize") != std::string::npos;
+	}
+	CHECK(threw);
+	threw = false;
+	try {
+		prover.commit(ComputeMemory::slice(C(dd), 0, 24), 8, d.dev_alloc);
+	} catch (const Error &ex) {
+		threw = std::string(ex.what()).find("PowerOfTwoLengthRequired") != std::string::npos;
+	}
+	CHECK(threw);
+}
+
 int main()
 {
 	struct T {
@@ -474,6 +521,7 @@ int main()
 	    {"test_generic_pairwise_product_reduce", test_pairwise_product_reduce},
 	    {"generic_test_bivariate_sumcheck_prove_verify", test_bivariate_sumcheck_prove_verify},
 	    {"test_additive_ntt", test_ntt},
+	    {"test_binary_merkle_vcs_commit_prove_open_correctly", test_binary_merkle_vcs},
 	};
 	int failed = 0;
 	try {
