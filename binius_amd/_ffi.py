@@ -132,6 +132,7 @@ def lib():
         "bn_merkle_build": [vp, vp, u64, u64, vp],
         "bn_groestl256_leaves": [vp, vp, u64, u64, vp],
         "bn_groestl256_compress_layer": [vp, vp, u64, vp],
+        "bn_gather_d2h": [vp, vp, C.POINTER(u64), u64, u64, vp],
         "bn_timer_begin": [vp],
         "bn_timer_end_ms": [vp, C.POINTER(C.c_float)],
     }
@@ -152,7 +153,7 @@ ABI_SYMBOLS = [
     "bn_compute_composite", "bn_pairwise_product_reduce", "bn_log_chunks_range", "bn_pick_log_chunks",
     "bn_kernel_launch", "bn_ntt_forward", "bn_ntt_inverse", "bn_ntt_s_evals", "bn_scalar_mul", "bn_scalar_invert",
     "bn_timer_begin", "bn_timer_end_ms", "bn_prof_begin", "bn_prof_end", "bn_xor_reduce", "bn_host_scratch",
-    "bn_merkle_build", "bn_groestl256_leaves", "bn_groestl256_compress_layer",
+    "bn_merkle_build", "bn_groestl256_leaves", "bn_groestl256_compress_layer", "bn_gather_d2h",
 ]
 
 
@@ -511,6 +512,15 @@ class Context:
         if prev.len != 2 * nxt.len:
             raise BnError(BN_ERR_INPUT_VALIDATION, "input validation: compress_layer: the next layer is half the previous one")
         _check(lib().bn_groestl256_compress_layer(self._h, prev.ptr, nxt.len // 2, nxt.ptr))
+
+    def gather_d2h(self, src, offsets, item_elems):
+        """(len(offsets), item_elems, 2) uint64 array: src[offsets[i] : offsets[i] + item_elems] for every i."""
+        offs = np.ascontiguousarray(offsets, dtype=np.uint64)
+        if len(offs) and int(offs.max()) + item_elems > src.len:
+            raise BnError(BN_ERR_INPUT_VALIDATION, "input validation: gather: item out of range")
+        out = np.zeros((len(offs), item_elems, 2), dtype=np.uint64)
+        _check(lib().bn_gather_d2h(self._h, src.ptr, offs.ctypes.data_as(C.POINTER(C.c_uint64)), len(offs), item_elems, out.ctypes.data))
+        return out
 
     def compute_composite(self, inputs, output, composition):
         rows = (C.c_void_p * max(1, len(inputs)))(*[r.ptr for r in inputs])

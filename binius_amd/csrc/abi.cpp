@@ -272,6 +272,7 @@ int bn_ctx_destroy(bn_ctx *ctx)
 	if (ctx->d_ticket) hipFree(ctx->d_ticket);
 	if (ctx->h_result) hipHostFree(ctx->h_result);
 	if (ctx->h_mail) hipHostFree(ctx->h_mail);
+	if (ctx->h_gather) hipHostFree(ctx->h_gather);
 	if (ctx->ev0) hipEventDestroy(ctx->ev0);
 	if (ctx->ev1) hipEventDestroy(ctx->ev1);
 	for (auto &r : ctx->prof) {
@@ -1422,6 +1423,36 @@ int bn_merkle_build(bn_ctx *ctx, const void *d_elems, uint64_t n_elems, uint64_t
 	BN_REQUIRE(n_leaves != 0 && (n_leaves & (n_leaves - 1)) == 0, "PowerOfTwoLengthRequired");
 	BN_HIP(bn::launch_groestl_leaves(ctx->stream, ctx->n_cu, d_elems, batch_size, n_leaves, d_nodes));
 	BN_HIP(bn::launch_merkle_layers(ctx->stream, ctx->n_cu, d_nodes, n_leaves));
+	return BN_OK;
+}
+
+// Openings: h_out[i * item_elems .. +item_elems) = d_src[h_offsets[i] .. +item_elems).  One kernel reads the
+// offsets from and writes the items to pinned host memory; one synchronisation.
+int bn_gather_d2h(bn_ctx *ctx, const void *d_src, const uint64_t *h_offsets, uint64_t n_items, uint64_t item_elems, bn_f128 *h_out)
+{
+	BN_REQUIRE(ctx && d_src && (n_items == 0 || (h_offsets && h_out)), "null argument");
+	BN_ENTER(ctx);
+	BN_FLUSH(ctx);
+	if (n_items == 0 || item_elems == 0) return BN_OK;
+	BN_REQUIRE(n_items <= (1ull << 24) && item_elems <= (1ull << 24) && n_items * item_elems <= (1ull << 26), "gather: too many elements for one call");
+	const size_t off_bytes = ((size_t)n_items * 8 + 15) & ~(size_t)15;
+	const size_t need = off_bytes + (size_t)n_items * item_elems * sizeof(f128);
+	if (need > ctx->gather_bytes) {
+		BN_HIP(hipStreamSynchronize(ctx->stream));
+		if (ctx->h_gather) hipHostFree(ctx->h_gather);
+		ctx->h_gather = nullptr;
+		ctx->gather_bytes = 0;
+		size_t cap = 1 << 16;
+		while (cap < need) cap <<= 1;
+		if (hipHostMalloc(&ctx->h_gather, cap, hipHostMallocMapped) != hipSuccess)
+			return bn::fail(BN_ERR_ALLOC, "allocation error: allocator is out of memory (pinned gather buffer)");
+		BN_HIP(hipHostGetDevicePointer(&ctx->d_gather, ctx->h_gather, 0));
+		ctx->gather_bytes = cap;
+	}
+	std::memcpy(ctx->h_gather, h_offsets, (size_t)n_items * 8);
+	BN_HIP(bn::launch_gather(ctx->stream, d_src, (const uint64_t *)ctx->d_gather, n_items, item_elems, (char *)ctx->d_gather + off_bytes));
+	BN_HIP(hipStreamSynchronize(ctx->stream));
+	std::memcpy(h_out, (const char *)ctx->h_gather + off_bytes, (size_t)n_items * item_elems * sizeof(f128));
 	return BN_OK;
 }
 

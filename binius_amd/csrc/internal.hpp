@@ -80,6 +80,9 @@ struct bn_ctx {
 		const void *ptr[8] = {};
 	} mirror;
 	void *ntt_cache = nullptr; // bn::ntt_bs_cache (allocated on first use)
+	// pinned, device-mapped staging of bn_gather_d2h: offsets in, gathered items out (grown on demand)
+	void *h_gather = nullptr, *d_gather = nullptr;
+	size_t gather_bytes = 0;
 	bool lazy_fold = true; // BN_NO_LAZY_FOLD=1 turns the deferral off
 	// resident tail kernel (kernels_foldeval9.hip k_foldeval_tail, protocol in abi.cpp)
 	struct tail_state {
@@ -229,6 +232,7 @@ hipError_t launch_ntt_bs(hipStream_t s, bool inverse, void *data, const uint64_t
 // ---- kernels_groestl.hip: Groestl-256 leaves, 2-to-1 compression layers, the flattened Merkle tree
 hipError_t launch_groestl_leaves(hipStream_t s, int n_cu, const void *elems, uint64_t batch, uint64_t n_leaves, void *digests);
 hipError_t launch_groestl_layer(hipStream_t s, int n_cu, const void *prev, uint64_t n_out, void *next);
+hipError_t launch_gather(hipStream_t s, const void *src, const uint64_t *offsets, uint64_t n_items, uint64_t item_elems, void *out);
 hipError_t launch_merkle_layers(hipStream_t s, int n_cu, void *nodes, uint64_t n_leaves);
 
 } // namespace bn

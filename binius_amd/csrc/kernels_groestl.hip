@@ -360,6 +360,28 @@ hipError_t launch_groestl_layer(hipStream_t s, int n_cu, const void *prev, uint6
 	return hipGetLastError();
 }
 
+// out[i * item_elems + e] = src[offsets[i] + e]: the openings of a committed vector (branch digests,
+// cosets).  offsets and out live in pinned host memory mapped into the device (zero-copy both ways).
+__global__ void k_gather(const uint4 *__restrict__ src, const uint64_t *__restrict__ offsets, uint64_t n_items, uint64_t item_elems,
+                         uint4 *__restrict__ out)
+{
+	const uint64_t total = n_items * item_elems;
+	for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) {
+		const uint64_t item = t / item_elems, e = t - item * item_elems;
+		out[t] = src[offsets[item] + e];
+	}
+}
+
+hipError_t launch_gather(hipStream_t s, const void *src, const uint64_t *offsets, uint64_t n_items, uint64_t item_elems, void *out)
+{
+	const uint64_t total = n_items * item_elems;
+	if (total == 0) return hipSuccess;
+	uint64_t blocks = (total + 255) / 256;
+	if (blocks > 1024) blocks = 1024;
+	hipLaunchKernelGGL(k_gather, dim3((unsigned)blocks), dim3(256), 0, s, (const uint4 *)src, offsets, n_items, item_elems, (uint4 *)out);
+	return hipGetLastError();
+}
+
 // nodes: the flattened tree (leaf digests already at the front).  Large layers one launch each, the
 // last <= 2 * kThreads-wide layers in one workgroup.
 hipError_t launch_merkle_layers(hipStream_t s, int n_cu, void *nodes, uint64_t n_leaves)

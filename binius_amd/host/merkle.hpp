@@ -5,8 +5,8 @@
 //   BinaryMerkleTree{log_len, inner_nodes}, root / layer / branch   binary_merkle_tree.rs:20-25, 103-141
 //   BinaryMerkleTreeProver::commit / layer / prove_opening           prover.rs:19-106
 // The caller of the reference (FRIFolder::execute_fold_round, fri/prove.rs:395-420) copies the folded
-// codeword to the host and hashes it there; with this class the codeword stays on the device and only
-// the 32-byte nodes come back.
+// codeword to the host and hashes it there; with this class the codeword and the tree stay on the
+// device and only roots, layers and branches come back.
 #pragma once
 #include <array>
 #include <cstring>
@@ -28,29 +28,50 @@ struct Commitment { // merkle_tree_vcs.rs: Commitment{root, depth}
 	size_t depth;
 };
 
+// The node array lives on the device; root / layer / branch read back what they return
+// (bn_gather_d2h), inner_nodes() the whole array.
 class BinaryMerkleTree {
 public:
 	size_t log_len = 0;
-	std::vector<Digest> inner_nodes; // flattened layers, leaves first, root last
+	FSlice nodes{};          // 2 * (2^(log_len+1) - 1) elements: flattened layers, leaves first, root last
+	ComputeLayer *hal = nullptr;
 
-	Digest root() const { return inner_nodes.back(); }
+	size_t n_nodes() const { return ((size_t)2 << log_len) - 1; }
+	std::vector<Digest> inner_nodes() const
+	{
+		std::vector<Digest> out(n_nodes());
+		hal->copy_d2h(nodes, reinterpret_cast<B128 *>(out.data()), nodes.len());
+		return out;
+	}
+	Digest root() const { return gather({n_nodes() - 1})[0]; }
 	// binary_merkle_tree.rs:109-116
-	std::pair<const Digest *, size_t> layer(size_t layer_depth) const
+	std::vector<Digest> layer(size_t layer_depth) const
 	{
 		if (layer_depth > log_len) throw MerkleError("IncorrectLayerDepth");
-		const size_t start = inner_nodes.size() + 1 - ((size_t)1 << (layer_depth + 1));
-		return {inner_nodes.data() + start, (size_t)1 << layer_depth};
+		const size_t start = n_nodes() + 1 - ((size_t)1 << (layer_depth + 1)), n = (size_t)1 << layer_depth;
+		std::vector<Digest> out(n);
+		hal->copy_d2h(ComputeMemory::slice(nodes, 2 * start, 2 * (start + n)), reinterpret_cast<B128 *>(out.data()), 2 * n);
+		return out;
 	}
 	// binary_merkle_tree.rs:121-141
 	std::vector<Digest> branch(size_t index, size_t layer_depth) const
 	{
 		if (index >= ((size_t)1 << log_len) || layer_depth > log_len)
 			throw MerkleError("IndexOutOfRange { max: " + std::to_string(((size_t)1 << log_len) - 1) + " }");
-		std::vector<Digest> out;
-		for (size_t j = 0; j < log_len - layer_depth; j++) {
-			const size_t node_index = ((((size_t)1 << j) - 1) << (log_len + 1 - j)) | ((index >> j) ^ 1);
-			out.push_back(inner_nodes[node_index]);
-		}
+		std::vector<size_t> ids;
+		for (size_t j = 0; j < log_len - layer_depth; j++)
+			ids.push_back(((((size_t)1 << j) - 1) << (log_len + 1 - j)) | ((index >> j) ^ 1));
+		return gather(ids);
+	}
+
+private:
+	std::vector<Digest> gather(const std::vector<size_t> &node_ids) const
+	{
+		std::vector<uint64_t> offs;
+		for (size_t id : node_ids) offs.push_back(2 * (uint64_t)id);
+		std::vector<Digest> out(node_ids.size());
+		static_assert(sizeof(Digest) == 2 * sizeof(B128), "a digest is two field elements wide");
+		check(bn_gather_d2h(hal->raw_ctx(), nodes.ptr, offs.data(), offs.size(), 2, reinterpret_cast<bn_f128 *>(out.data())));
 		return out;
 	}
 };
@@ -72,12 +93,11 @@ public:
 		check(bn_merkle_build(hal_.raw_ctx(), data.ptr, data.len(), batch_size, nodes.ptr));
 		BinaryMerkleTree tree;
 		while (((size_t)1 << tree.log_len) < n_leaves) tree.log_len++;
-		tree.inner_nodes.resize(2 * n_leaves - 1);
-		static_assert(sizeof(Digest) == 2 * sizeof(B128), "a digest is two field elements wide");
-		hal_.copy_d2h(ComputeMemory::as_const(nodes), reinterpret_cast<B128 *>(tree.inner_nodes.data()), nodes.len());
-		return {Commitment{tree.root(), tree.log_len}, std::move(tree)};
+		tree.nodes = ComputeMemory::as_const(nodes);
+		tree.hal = &hal_;
+		return {Commitment{tree.root(), tree.log_len}, tree};
 	}
-	std::pair<const Digest *, size_t> layer(const BinaryMerkleTree &committed, size_t depth) const { return committed.layer(depth); }
+	std::vector<Digest> layer(const BinaryMerkleTree &committed, size_t depth) const { return committed.layer(depth); }
 	// prover.rs:73-83: the branch that is written to the transcript
 	std::vector<Digest> prove_opening(const BinaryMerkleTree &committed, size_t layer_depth, size_t index) const
 	{

@@ -4,8 +4,9 @@ the device (bn_merkle_build).
 Mirrors crates/core/src/merkle_tree/prover.rs:19-106 (BinaryMerkleTreeProver: commit / layer /
 prove_opening) and binary_merkle_tree.rs:103-141 (BinaryMerkleTree: root / layer / branch) with
 H = Groestl256 and C = Groestl256ByteCompression -- the instantiation every prover entry point of the
-reference uses (e.g. crates/core/src/constraint_system/prove.rs, examples).  The committed data stays
-on the device; only the 32-byte nodes come back.
+reference uses (e.g. crates/core/src/constraint_system/prove.rs, examples).  The committed data and
+the node array stay on the device; the root, a layer or a branch is read back when asked for
+(bn_gather_d2h).
 """
 import numpy as np
 
@@ -17,28 +18,50 @@ class MerkleError(BnError):
 
 
 class BinaryMerkleTree:
-    """binary_merkle_tree.rs:20-25: log_len + inner_nodes (flattened layers, root last)."""
+    """binary_merkle_tree.rs:20-25: log_len + inner_nodes (flattened layers, root last) -- with the node
+    array resident on the device: root / layer / branch read back only what they return."""
 
-    def __init__(self, log_len, inner_nodes):
+    def __init__(self, hal, log_len, nodes):
+        self.hal = hal
         self.log_len = log_len
-        self.inner_nodes = inner_nodes  # (2^(log_len+1) - 1, 32) uint8
+        self.nodes = nodes  # device slice of 2 * (2^(log_len+1) - 1) elements
+        self._n_nodes = (2 << log_len) - 1
+
+    @staticmethod
+    def _digests(a):
+        return np.ascontiguousarray(a).view(np.uint8).reshape(-1, 32)
+
+    @property
+    def inner_nodes(self):
+        """The whole flattened tree on the host ((2^(log_len+1) - 1, 32) uint8): tests and small trees."""
+        return self._digests(self.hal.copy_d2h(self.nodes))
 
     def root(self):
-        return bytes(self.inner_nodes[-1])
+        return bytes(self._digests(self.hal.gather_d2h(self.nodes, [2 * (self._n_nodes - 1)], 2))[0])
 
     def layer(self, layer_depth):
         if layer_depth > self.log_len:
             raise MerkleError(BN_ERR_INPUT_VALIDATION, "IncorrectLayerDepth")
-        start = len(self.inner_nodes) + 1 - (1 << (layer_depth + 1))
-        return self.inner_nodes[start : start + (1 << layer_depth)]
+        start = self._n_nodes + 1 - (1 << (layer_depth + 1))
+        return self._digests(self.hal.copy_d2h(self.nodes.slice(2 * start, 2 * (start + (1 << layer_depth)))))
 
-    def branch(self, index, layer_depth):
+    def _branch_nodes(self, index, layer_depth):
         if index >= (1 << self.log_len) or layer_depth > self.log_len:
             raise MerkleError(BN_ERR_INPUT_VALIDATION, "IndexOutOfRange { max: %d }" % ((1 << self.log_len) - 1))
-        out = []
-        for j in range(self.log_len - layer_depth):
-            node_index = (((1 << j) - 1) << (self.log_len + 1 - j)) | ((index >> j) ^ 1)
-            out.append(bytes(self.inner_nodes[node_index]))
+        return [(((1 << j) - 1) << (self.log_len + 1 - j)) | ((index >> j) ^ 1) for j in range(self.log_len - layer_depth)]
+
+    def branch(self, index, layer_depth):
+        return self.branches([index], layer_depth)[0]
+
+    def branches(self, indices, layer_depth):
+        """Merkle branches of several leaves with one device gather."""
+        node_ids = [self._branch_nodes(i, layer_depth) for i in indices]
+        flat = [2 * n for ids in node_ids for n in ids]
+        got = self._digests(self.hal.gather_d2h(self.nodes, flat, 2)) if flat else np.zeros((0, 32), np.uint8)
+        out, k = [], 0
+        for ids in node_ids:
+            out.append([bytes(got[k + j]) for j in range(len(ids))])
+            k += len(ids)
         return out
 
 
@@ -60,8 +83,7 @@ class BinaryMerkleTreeProver:
         log_len = n_leaves.bit_length() - 1
         nodes = self.dev_alloc.alloc(2 * (2 * n_leaves - 1))
         self.hal.merkle_build(data, batch_size, nodes)
-        host = self.hal.copy_d2h(nodes)
-        tree = BinaryMerkleTree(log_len, np.ascontiguousarray(host).view(np.uint8).reshape(-1, 32))
+        tree = BinaryMerkleTree(self.hal, log_len, nodes)
         return (tree.root(), tree.log_len), tree
 
     def layer(self, committed, depth):

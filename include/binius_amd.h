@@ -207,6 +207,13 @@ int bn_groestl256_leaves(bn_ctx *ctx, const void *d_elems, uint64_t n_elems, uin
 /* compress_layer alone (binary_merkle_tree.rs:158-168): d_next[i] = C(d_prev[2i], d_prev[2i+1]), i < n_out. */
 int bn_groestl256_compress_layer(bn_ctx *ctx, const void *d_prev, uint64_t n_out, void *d_next);
 
+/* Openings of a committed vector: h_out[i * item_elems + e] = d_src[h_offsets[i] + e] (offsets and
+ * lengths in 16-byte elements), e < item_elems, i < n_items, in one kernel and one synchronisation.
+ * Not part of the reference interface: the reference reads branches and cosets out of host copies
+ * (binary_merkle_tree.rs:121-141, fri/prove.rs:631-661); here the tree and the codewords stay on the
+ * device and only what a query opens is read back. */
+int bn_gather_d2h(bn_ctx *ctx, const void *d_src, const uint64_t *h_offsets, uint64_t n_items, uint64_t item_elems, bn_f128 *h_out);
+
 /* Per-kernel-class timing without perturbing the stream: while profiling is on, every launch of a
  * hot kernel is bracketed by two hipEvents recorded on the context's stream (no synchronisation);
  * bn_prof_end synchronises once and sums the elapsed times per class. */

@@ -469,10 +469,10 @@ static void test_binary_merkle_vcs(Env &e)
 	// verify_vector: the whole tree recomputed by the oracle
 	std::vector<Digest> want(2 * ((size_t)1 << log_len) - 1);
 	CHECK(ref_merkle_build(reinterpret_cast<const uint8_t *>(data.data()), n, batch, want[0].data()) == 0);
-	CHECK(want == tree.inner_nodes);
+	CHECK(want == tree.inner_nodes());
 	for (size_t layer_depth = 0; layer_depth <= log_len; layer_depth++) {
-		auto [layer, layer_len] = prover.layer(tree, layer_depth);
-		CHECK(layer_len == (size_t)1 << layer_depth);
+		auto layer = prover.layer(tree, layer_depth);
+		CHECK(layer.size() == (size_t)1 << layer_depth);
 		for (size_t index = 0; index < (size_t)1 << log_len; index++) {
 			auto branch = prover.prove_opening(tree, layer_depth, index);
 			CHECK(branch.size() == log_len - layer_depth);
