@@ -22,6 +22,7 @@
 // layers <= 6 at a time on a 512-set tile in LDS;  tail = convert back.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <utility>
 #include <vector>
@@ -117,17 +118,20 @@ __device__ __forceinline__ void stage_top_tables(uint32_t *lds, const ntt_bs_tab
 }
 
 // ---- head: standard layout -> plane sets; forward: then the five in-register layers (16, 8, .., 1)
-// batch beta = blockIdx.y: x = beta & (2^lx - 1), z = beta >> lx
+// batch beta = z * 2^lx + x with z = blockIdx.y
 template <bool INV>
 __global__ __launch_bounds__(256) void k_ntt_bs_head(const uint32_t *__restrict__ data, uint4 *__restrict__ bs, uint64_t S, uint32_t lx,
                                                      uint32_t log_y, const ntt_bs_tables *__restrict__ tb, uint32_t n_top)
 {
 	__shared__ uint32_t ttab_lds[31 * 128];
 	if (!INV) stage_top_tables(ttab_lds, tb);
-	const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+	// the interleaved transforms x are the fastest index over the lanes: the 2^lx words of one (c, i)
+	// are contiguous in memory, so the loads coalesce whatever lx is
+	const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+	const uint64_t i = g >> lx, x = g & (((uint64_t)1 << lx) - 1);
 	if (i >= S) return;
-	const uint64_t beta = blockIdx.y;
-	data += ((beta >> lx) << (log_y + lx)) + (beta & (((uint64_t)1 << lx) - 1));
+	const uint64_t beta = ((uint64_t)blockIdx.y << lx) | x;
+	data += ((uint64_t)blockIdx.y << (log_y + lx)) + x;
 	bs += beta * S * 8;
 	uint32_t W[32];
 #pragma unroll
@@ -148,10 +152,11 @@ __global__ __launch_bounds__(256) void k_ntt_bs_tail(const uint4 *__restrict__ b
 {
 	__shared__ uint32_t ttab_lds[31 * 128];
 	if (INV) stage_top_tables(ttab_lds, tb);
-	const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+	const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x; // x fastest, as in the head
+	const uint64_t i = g >> lx, x = g & (((uint64_t)1 << lx) - 1);
 	if (i >= S) return;
-	const uint64_t beta = blockIdx.y;
-	data += ((beta >> lx) << (log_y + lx)) + (beta & (((uint64_t)1 << lx) - 1));
+	const uint64_t beta = ((uint64_t)blockIdx.y << lx) | x;
+	data += ((uint64_t)blockIdx.y << (log_y + lx)) + x;
 	bs += beta * S * 8;
 	uint32_t W[32];
 	const uint4 *src = bs + i * 8;
@@ -372,7 +377,6 @@ static hipError_t run_ntt_bs(hipStream_t s, void *data, const uint64_t *h_s_eval
 	}
 	uint4 *bs = (uint4 *)d_scratch;
 
-	const unsigned blocks = (unsigned)((S + 255) / 256);
 	// layers log_y - skip_rounds - 1 .. 0 are applied (reference.rs:88): of the five in-register layers
 	// the lowest n_top, of the NB lower layers the lowest n_low
 	const uint32_t n_top = skip_rounds >= 5 ? 0 : 5 - skip_rounds;
@@ -396,21 +400,28 @@ static hipError_t run_ntt_bs(hipStream_t s, void *data, const uint64_t *h_s_eval
 	}
 	// the pass over layers R-1..0 works on consecutive sets and converts the layout itself: forward it
 	// is the last kernel (no tail), inverse the first (no head)
-	const bool merged = !plan.empty();
+	// -- unless the transforms are interleaved (lx > kMergeMaxLx): the merged conversion walks one transform,
+	// i.e. words 2^lx apart, and every 4-byte access costs a whole sector; head and tail put x across the lanes
+	static const uint32_t merge_max_lx = [] {
+		const char *v = getenv("BN_NTT_MERGE_MAX_LX");
+		return v ? (uint32_t)atoi(v) : 1u;
+	}();
+	const bool merged = !plan.empty() && lx <= merge_max_lx;
+	const dim3 ht_grid((unsigned)(((S << lx) + 255) / 256), 1u << log_z);
 	if (!(INV && merged))
-		hipLaunchKernelGGL(k_ntt_bs_head<INV>, dim3(blocks, n_batch), dim3(256), 0, s, (const uint32_t *)data, bs, S, lx, log_y, d_tb, n_top);
+		hipLaunchKernelGGL(k_ntt_bs_head<INV>, ht_grid, dim3(256), 0, s, (const uint32_t *)data, bs, S, lx, log_y, d_tb, n_top);
 	for (size_t k = 0; k < plan.size(); k++) {
 		const auto &pr = INV ? plan[plan.size() - 1 - k] : plan[k];
 		const uint32_t l_lo = pr.first, R = pr.second, Q = kTileLog - R;
 		const uint32_t n_lo = Q < l_lo ? Q : l_lo;
 		const dim3 grid((unsigned)(S >> kTileLog), n_batch);
-		if (l_lo == 0)
+		if (l_lo == 0 && merged)
 			hipLaunchKernelGGL((k_ntt_bs_pass<INV, true>), grid, dim3(256), lds, s, bs, S, l_lo, R, n_lo, d_tb, (uint32_t *)data, lx, log_y);
 		else
 			hipLaunchKernelGGL((k_ntt_bs_pass<INV, false>), grid, dim3(256), lds, s, bs, S, l_lo, R, n_lo, d_tb, (uint32_t *)data, lx, log_y);
 	}
 	if (INV || !merged)
-		hipLaunchKernelGGL(k_ntt_bs_tail<INV>, dim3(blocks, n_batch), dim3(256), 0, s, bs, (uint32_t *)data, S, lx, log_y, d_tb, n_top);
+		hipLaunchKernelGGL(k_ntt_bs_tail<INV>, ht_grid, dim3(256), 0, s, bs, (uint32_t *)data, S, lx, log_y, d_tb, n_top);
 	return hipGetLastError();
 }
 
