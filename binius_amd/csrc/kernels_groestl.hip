@@ -20,6 +20,8 @@
 // address {0, 0, byte, lane offset} is one v_perm_b32.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "internal.hpp"
 
 namespace bn {
@@ -283,38 +285,153 @@ __global__ __launch_bounds__(kThreads) void k_groestl_layer(const uint4 *__restr
 	}
 }
 
-// The top of the tree in one workgroup: layer of n_in <= 2 * kThreads digests at `layer`, every
-// following layer written right behind it (the flattened order of binary_merkle_tree.rs:22-25), down
-// to the root.  The levels are exchanged through LDS.
-__global__ __launch_bounds__(kThreads) void k_groestl_top(uint4 *__restrict__ layer, uint32_t n_in)
+// ---- the top of the tree in one workgroup, eight lanes per hash.
+// The upper levels are a chain of dependent permutations with little parallelism: what counts is the
+// latency of one P, not throughput.  One lane per hash spends ~13 us per level (64 dependent lookups and
+// ~250 VALU per round in ONE wave); here the eight columns of a state sit in eight lanes, a round is
+// 8 lookups + ~36 VALU per lane, and the ShiftBytes traffic between columns is DPP: two hashes share a
+// 16-lane row, hash j = lane & 1, column c = (lane & 15) >> 1, so "the column sigma_k = k further on"
+// is row_ror by 16 - 2k.  Levels are exchanged through two LDS buffers; every level is also written to
+// its place behind `layer` (the flattened order of binary_merkle_tree.rs:22-25).
+template <int SIGMA>
+__device__ __forceinline__ uint32_t from_column_plus(uint32_t v)
+{
+	if constexpr (SIGMA == 0) return v;
+	else return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x120 + (16 - 2 * SIGMA), 0xF, 0xF, false); // row_ror:16-2*sigma
+}
+
+template <bool Q, int K>
+__device__ __forceinline__ uint2 lane_lookup(const char *tab, uint32_t lo, uint32_t hi, uint32_t lane_off)
+{
+	const uint32_t w = from_column_plus<shifts<Q>::s[K]>(K < 4 ? lo : hi);
+	return rot_bytes<K>(lookup<K>(tab, w, w, lane_off));
+}
+
+// one round of P or Q on a state spread over eight lanes: (lo, hi) = this lane's column c
+template <bool Q>
+__device__ __forceinline__ void round_lanes(uint32_t &lo, uint32_t &hi, uint32_t c, uint32_t r, const char *tab, uint32_t lane_off)
+{
+	if constexpr (!Q) {
+		lo ^= (c << 4) ^ r;
+	} else {
+		lo = ~lo;
+		hi = ~hi ^ (((c << 4) ^ r) << 24);
+	}
+	const uint2 t0 = lane_lookup<Q, 0>(tab, lo, hi, lane_off), t1 = lane_lookup<Q, 1>(tab, lo, hi, lane_off);
+	const uint2 t2 = lane_lookup<Q, 2>(tab, lo, hi, lane_off), t3 = lane_lookup<Q, 3>(tab, lo, hi, lane_off);
+	const uint2 t4 = lane_lookup<Q, 4>(tab, lo, hi, lane_off), t5 = lane_lookup<Q, 5>(tab, lo, hi, lane_off);
+	const uint2 t6 = lane_lookup<Q, 6>(tab, lo, hi, lane_off), t7 = lane_lookup<Q, 7>(tab, lo, hi, lane_off);
+	lo = xor3(xor3(t0.x, t1.x, t2.x), xor3(t3.x, t4.x, t5.x), t6.x ^ t7.x);
+	hi = xor3(xor3(t0.y, t1.y, t2.y), xor3(t3.y, t4.y, t5.y), t6.y ^ t7.y);
+}
+
+__device__ __forceinline__ void perm_p_lanes(uint32_t &lo, uint32_t &hi, uint32_t c, const char *tab, uint32_t lane_off)
+{
+#pragma unroll 1
+	for (uint32_t r = 0; r < 10; r++) round_lanes<false>(lo, hi, c, r, tab, lane_off);
+}
+
+// h <- P(h ^ m) ^ Q(m) ^ h on eight lanes
+__device__ __forceinline__ void compress_lanes(uint2 &h, uint2 m, uint32_t c, const char *tab, uint32_t lane_off)
+{
+	uint32_t plo = h.x ^ m.x, phi = h.y ^ m.y, qlo = m.x, qhi = m.y;
+#pragma unroll 1
+	for (uint32_t r = 0; r < 10; r++) {
+		round_lanes<false>(plo, phi, c, r, tab, lane_off);
+		round_lanes<true>(qlo, qhi, c, r, tab, lane_off);
+	}
+	h.x ^= plo ^ qlo;
+	h.y ^= phi ^ qhi;
+}
+
+constexpr int kLaneThreads = 256; // 32 hashes per workgroup
+
+// Latency form of k_groestl_leaves for small leaf counts (eight lanes per leaf): the same digests.
+__global__ __launch_bounds__(kLaneThreads) void k_groestl_leaves_lanes(const uint2 *__restrict__ elems, uint64_t batch, uint64_t n_leaves,
+                                                                       uint2 *__restrict__ digests)
 {
 	extern __shared__ __align__(16) unsigned char smem[];
 	stage_table(reinterpret_cast<uint2 *>(smem));
 	const char *tab = reinterpret_cast<const char *>(smem);
-	uint4 *xch = reinterpret_cast<uint4 *>(smem + kTableBytes); // 2 * kThreads digests = 32 KiB
 	const uint32_t lane_off = (threadIdx.x & (kCopies - 1)) * 8;
-	for (uint32_t i = threadIdx.x; i < 2 * n_in; i += kThreads) xch[i] = layer[i];
+	const uint32_t l16 = threadIdx.x & 15, c = l16 >> 1;
+	const uint64_t leaf_raw = (uint64_t)blockIdx.x * (kLaneThreads / 8) + (threadIdx.x >> 4) * 2 + (l16 & 1);
+	const bool act = leaf_raw < n_leaves;
+	const uint64_t leaf = act ? leaf_raw : 0; // (idle slots recompute leaf 0: every lane of a row stays in step for the DPP)
+	const uint64_t n_full = batch >> 2;
+	const uint32_t rem = (uint32_t)(batch & 3);
+	const uint2 *src = elems + leaf * batch * 2 + c; // column c of block b at src[8 * b]
+	uint2 h{0, c == 7 ? 0x00010000u : 0u};
+	for (uint64_t b = 0; b < n_full; b++) compress_lanes(h, src[8 * b], c, tab, lane_off);
+	{
+		uint2 m{0, 0};
+		if (c < 2 * rem) m = src[8 * n_full];
+		if (c == 2 * rem) m.x = 0x80;
+		if (c == 7) m.y = __builtin_bswap32((uint32_t)(n_full + 1));
+		compress_lanes(h, m, c, tab, lane_off);
+	}
+	uint32_t lo = h.x, hi = h.y;
+	perm_p_lanes(lo, hi, c, tab, lane_off);
+	if (act && c >= 4) digests[4 * leaf + (c - 4)] = uint2{lo ^ h.x, hi ^ h.y};
+}
+
+// Latency form of k_groestl_layer.
+__global__ __launch_bounds__(kLaneThreads) void k_groestl_layer_lanes(const uint2 *__restrict__ prev, uint64_t n_out, uint2 *__restrict__ next)
+{
+	extern __shared__ __align__(16) unsigned char smem[];
+	stage_table(reinterpret_cast<uint2 *>(smem));
+	const char *tab = reinterpret_cast<const char *>(smem);
+	const uint32_t lane_off = (threadIdx.x & (kCopies - 1)) * 8;
+	const uint32_t l16 = threadIdx.x & 15, c = l16 >> 1;
+	const uint64_t i_raw = (uint64_t)blockIdx.x * (kLaneThreads / 8) + (threadIdx.x >> 4) * 2 + (l16 & 1);
+	const bool act = i_raw < n_out;
+	const uint64_t i = act ? i_raw : 0;
+	const uint2 x = prev[8 * i + c];
+	uint32_t lo = x.x, hi = x.y;
+	perm_p_lanes(lo, hi, c, tab, lane_off);
+	if (act && c >= 4) next[4 * i + (c - 4)] = uint2{lo ^ x.x, hi ^ x.y};
+}
+
+constexpr int kTopThreads = 1024;
+constexpr int kTopMaxIn = 1024; // digests of the widest layer it takes
+
+__global__ __launch_bounds__(kTopThreads) void k_groestl_top(uint4 *__restrict__ layer, uint32_t n_in)
+{
+	extern __shared__ __align__(16) unsigned char smem[];
+	stage_table(reinterpret_cast<uint2 *>(smem));
+	const char *tab = reinterpret_cast<const char *>(smem);
+	uint2 *buf_a = reinterpret_cast<uint2 *>(smem + kTableBytes); // kTopMaxIn digests = 32 KiB
+	uint2 *buf_b = buf_a + 4 * kTopMaxIn;                          // kTopMaxIn / 2 digests = 16 KiB
+	const uint32_t lane_off = (threadIdx.x & (kCopies - 1)) * 8;
+	{
+		uint4 *a4 = reinterpret_cast<uint4 *>(buf_a);
+		for (uint32_t i = threadIdx.x; i < 2 * n_in; i += kTopThreads) a4[i] = layer[i];
+	}
 	__syncthreads();
-	uint4 *out = layer + 2 * (uint64_t)n_in;
+	const uint32_t l16 = threadIdx.x & 15, c = l16 >> 1;
+	const uint32_t slot = (threadIdx.x >> 4) * 2 + (l16 & 1); // hash slot of this lane: kTopThreads / 8 per pass
+	uint2 *out = reinterpret_cast<uint2 *>(layer + 2 * (uint64_t)n_in);
+	uint2 *src = buf_a, *dst = buf_b;
 	for (uint32_t n = n_in >> 1; n >= 1; n >>= 1) {
-		const bool act = threadIdx.x < n;
-		gstate x;
-		const uint32_t i = act ? threadIdx.x : 0;
-		set_cols(x, 0, xch[4 * i]);
-		set_cols(x, 2, xch[4 * i + 1]);
-		set_cols(x, 4, xch[4 * i + 2]);
-		set_cols(x, 6, xch[4 * i + 3]);
-		uint4 d0, d1;
-		output_transform(x, d0, d1, tab, lane_off);
-		__syncthreads(); // everybody has read its children
-		if (act) {
-			xch[2 * i] = d0;
-			xch[2 * i + 1] = d1;
-			out[2 * i] = d0;
-			out[2 * i + 1] = d1;
+		for (uint32_t base = 0; base < n; base += kTopThreads / 8) {
+			if (base + (threadIdx.x >> 4) * 2 >= n) break; // (wave-uniform: a wave is four rows = 8 slots)
+			const uint32_t p = base + slot;
+			const bool act = p < n;
+			const uint32_t pc = act ? p : 0;
+			const uint2 x = src[8 * pc + c]; // column c of child(2p) || child(2p + 1)
+			uint32_t lo = x.x, hi = x.y;
+			perm_p_lanes(lo, hi, c, tab, lane_off);
+			if (act && c >= 4) { // Omega: columns 4..7 of P(x) ^ x
+				const uint2 d{lo ^ x.x, hi ^ x.y};
+				dst[4 * p + (c - 4)] = d;
+				out[4 * p + (c - 4)] = d;
+			}
 		}
 		__syncthreads();
-		out += 2 * (uint64_t)n;
+		out += 4 * (uint64_t)n;
+		uint2 *t = src;
+		src = dst;
+		dst = t;
 	}
 }
 
@@ -327,10 +444,24 @@ static hipError_t set_lds_limits()
 		if (e != hipSuccess) return e;
 		e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_groestl_layer), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTableBytes);
 		if (e != hipSuccess) return e;
+		e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_groestl_leaves_lanes), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTableBytes);
+		if (e != hipSuccess) return e;
+		e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_groestl_layer_lanes), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTableBytes);
+		if (e != hipSuccess) return e;
 		return hipFuncSetAttribute(reinterpret_cast<const void *>(k_groestl_top), hipFuncAttributeMaxDynamicSharedMemorySize,
-		                           (int)(kTableBytes + 2 * kThreads * 32));
+		                           (int)(kTableBytes + 48 * kTopMaxIn));
 	}();
 	return once;
+}
+
+// up to this many hashes a launch uses the eight-lanes-per-hash kernels (BN_GROESTL_LANES_MAX overrides)
+static uint64_t lanes_max()
+{
+	static const uint64_t v = [] {
+		const char *e = getenv("BN_GROESTL_LANES_MAX");
+		return e ? (uint64_t)strtoull(e, nullptr, 10) : (uint64_t)1 << 16;
+	}();
+	return v;
 }
 
 static unsigned grid_for(uint64_t n, int n_cu)
@@ -346,6 +477,11 @@ hipError_t launch_groestl_leaves(hipStream_t s, int n_cu, const void *elems, uin
 	if (n_leaves == 0) return hipSuccess;
 	hipError_t e = set_lds_limits();
 	if (e != hipSuccess) return e;
+	if (n_leaves <= lanes_max()) { // latency form: eight lanes per hash, ~7x shorter dependency chain
+		const unsigned blocks = (unsigned)((n_leaves + kLaneThreads / 8 - 1) / (kLaneThreads / 8));
+		hipLaunchKernelGGL(k_groestl_leaves_lanes, dim3(blocks), dim3(kLaneThreads), kTableBytes, s, (const uint2 *)elems, batch, n_leaves, (uint2 *)digests);
+		return hipGetLastError();
+	}
 	hipLaunchKernelGGL(k_groestl_leaves, dim3(grid_for(n_leaves, n_cu)), dim3(kThreads), kTableBytes, s, (const uint4 *)elems, batch, n_leaves,
 	                   (uint4 *)digests);
 	return hipGetLastError();
@@ -356,6 +492,11 @@ hipError_t launch_groestl_layer(hipStream_t s, int n_cu, const void *prev, uint6
 	if (n_out == 0) return hipSuccess;
 	hipError_t e = set_lds_limits();
 	if (e != hipSuccess) return e;
+	if (n_out <= lanes_max()) {
+		const unsigned blocks = (unsigned)((n_out + kLaneThreads / 8 - 1) / (kLaneThreads / 8));
+		hipLaunchKernelGGL(k_groestl_layer_lanes, dim3(blocks), dim3(kLaneThreads), kTableBytes, s, (const uint2 *)prev, n_out, (uint2 *)next);
+		return hipGetLastError();
+	}
 	hipLaunchKernelGGL(k_groestl_layer, dim3(grid_for(n_out, n_cu)), dim3(kThreads), kTableBytes, s, (const uint4 *)prev, n_out, (uint4 *)next);
 	return hipGetLastError();
 }
@@ -383,14 +524,14 @@ hipError_t launch_gather(hipStream_t s, const void *src, const uint64_t *offsets
 }
 
 // nodes: the flattened tree (leaf digests already at the front).  Large layers one launch each, the
-// last <= 2 * kThreads-wide layers in one workgroup.
+// last <= kTopMaxIn-wide layers in one workgroup.
 hipError_t launch_merkle_layers(hipStream_t s, int n_cu, void *nodes, uint64_t n_leaves)
 {
 	hipError_t e = set_lds_limits();
 	if (e != hipSuccess) return e;
 	char *layer = (char *)nodes;
 	uint64_t n = n_leaves;
-	while (n > 2 * (uint64_t)kThreads) {
+	while (n > (uint64_t)kTopMaxIn) {
 		char *next = layer + 32 * n;
 		e = launch_groestl_layer(s, n_cu, layer, n >> 1, next);
 		if (e != hipSuccess) return e;
@@ -398,7 +539,7 @@ hipError_t launch_merkle_layers(hipStream_t s, int n_cu, void *nodes, uint64_t n
 		n >>= 1;
 	}
 	if (n >= 2) {
-		hipLaunchKernelGGL(k_groestl_top, dim3(1), dim3(kThreads), kTableBytes + 2 * kThreads * 32, s, (uint4 *)layer, (uint32_t)n);
+		hipLaunchKernelGGL(k_groestl_top, dim3(1), dim3(kTopThreads), kTableBytes + 48 * kTopMaxIn, s, (uint4 *)layer, (uint32_t)n);
 		return hipGetLastError();
 	}
 	return hipSuccess;
