@@ -3,7 +3,7 @@
 codeword, per batch size (= FRI coset size, crates/core/src/protocols/fri/prove.rs:400-407), with the
 leaf-hash and layer kernels also timed alone.  One JSON line per case; inputs from binius_amd.synthetic.
 Groestl is compute-bound: the rate to look at is message bytes hashed per second, not the HBM roofline
-(DESIGN.md section 4.9)."""
+(DESIGN.md section 4.8)."""
 import argparse, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import binius_amd
