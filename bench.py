@@ -233,26 +233,33 @@ def main():
     re_ms, re_cnt = prof["round_eval"]
     fo_ms, fo_cnt = prof["fold"]
     fe_ms, fe_cnt = prof["fold_eval"]
+    fs_ms, fs_cnt = prof["fold_eval_small"]
     tl_ms, tl_cnt = prof["tail"]
-    fused = fe_cnt > 0
+    fused = fe_cnt + fs_cnt > 0
     if fused:
-        # the f largest fold+eval rounds are k_foldeval9 launches; the remaining small ones (if any) run
-        # inside one resident k_foldeval_tail launch per step (its time includes the host round trips)
+        # rocprof lists two kernel symbols for the fused launches and so does this block: the f largest
+        # rounds are k_foldeval9<2> launches, the next g k_foldeval9_small ones (one workgroup per batch:
+        # latency-shaped); what remains (if anything) runs inside one resident k_foldeval_tail launch per
+        # step (its time includes the host round trips)
         f = fe_cnt // args.steps
+        g = fs_cnt // args.steps
         re_bytes = 16 * m * (1 << n_vars) * args.steps
         fe_bytes = sum(24 * m * (1 << r) for r in range(n_vars - f + 1, n_vars + 1)) * args.steps
-        tl_bytes = sum(24 * m * (1 << r) for r in range(2, n_vars - f + 1)) * args.steps
+        fs_bytes = sum(24 * m * (1 << r) for r in range(n_vars - f - g + 1, n_vars - f + 1)) * args.steps
+        tl_bytes = sum(24 * m * (1 << r) for r in range(2, n_vars - f - g + 1)) * args.steps
         fold_bytes = 24 * m * 2 * args.steps
     else:
         re_bytes = sum(16 * m * (1 << r) for r in range(1, n_vars + 1)) * args.steps
-        fe_bytes = tl_bytes = 0
+        fe_bytes = fs_bytes = tl_bytes = 0
         fold_bytes = sum(24 * (1 << r) for r in range(1, n_vars + 1)) * m * args.steps
     kernels = {
         "k_roundeval9(round_eval)": (re_bytes, re_ms, re_cnt),
         "k_extrapolate_line(fold)": (fold_bytes, fo_ms, fo_cnt),
     }
-    if fused:
+    if fe_cnt:
         kernels["k_foldeval9(fold+round_eval)"] = (fe_bytes, fe_ms, fe_cnt)
+    if fs_cnt:
+        kernels["k_foldeval9_small(fold+round_eval, <= 2 batches per CU)"] = (fs_bytes, fs_ms, fs_cnt)
     if tl_cnt:
         kernels["k_foldeval_tail(resident, rounds <= 2^12)"] = (tl_bytes, tl_ms, tl_cnt)
     dom = max(kernels, key=lambda k: kernels[k][1])

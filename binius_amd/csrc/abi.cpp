@@ -1211,7 +1211,7 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 										}
 										// (c) one fused kernel for this round
 										if (fe == hipErrorNotSupported) {
-											prof_scope ps(ctx, BN_PROF_FOLD_EVAL);
+											prof_scope ps(ctx, bn::foldeval9_is_small(ctx->n_cu, n_in) ? BN_PROF_FOLD_EVAL_SMALL : BN_PROF_FOLD_EVAL);
 											fe = bn::launch_foldeval9(s, ctx->n_cu, fa, n_in, pf.z, d_S + slot, &fz);
 											if (fe == hipSuccess) ctx->pend.active = false;
 										}

@@ -179,6 +179,7 @@ struct foldeval_args {
 	const void *x1[2];
 	void *out[2];
 };
+bool foldeval9_is_small(int n_cu, uint64_t n_in);
 hipError_t launch_foldeval9(hipStream_t s, int n_cu, const foldeval_args &fa, uint64_t n_in, f128 z, f128 *d_out, const fin_fuse *fuse);
 hipError_t launch_foldeval_tail(hipStream_t s, const foldeval_args &fa, uint64_t n_in, f128 z, f128 *d_out, const fin_fuse &fz,
                                 const uint64_t *d_cmd, uint64_t *d_status, uint64_t tail_id);

@@ -343,6 +343,13 @@ __global__ __launch_bounds__(64 * kTailWaves) void k_foldeval_tail(foldeval_args
 	}
 }
 
+// which of the two kernels launch_foldeval9 picks for this size (abi.cpp labels the launch with it)
+bool foldeval9_is_small(int n_cu, uint64_t n_in)
+{
+	const uint64_t n = n_in >> 2;
+	return (n + kBatch - 1) / kBatch <= (uint64_t)n_cu * 2;
+}
+
 // For both arrays j: out_j[i] = x0_j[i] + z * (x1_j[i] - x0_j[i]), i < n_in/2 (out_j may be x0_j), and
 // accumulate the next round's (S_1, S_inf) of out_0 * out_1 into d_out[0], d_out[1].  n_in >= 4.
 hipError_t launch_foldeval9(hipStream_t s, int n_cu, const foldeval_args &fa, uint64_t n_in, f128 z, f128 *d_out, const fin_fuse *fuse)
@@ -354,7 +361,7 @@ hipError_t launch_foldeval9(hipStream_t s, int n_cu, const foldeval_args &fa, ui
 	const uint64_t n_batches = (n + kBatch - 1) / kBatch;
 	uint64_t blocks = (n_batches + 3) / 4;
 	const uint64_t cap = (uint64_t)n_cu * 2;
-	if (n_batches <= cap) {
+	if (foldeval9_is_small(n_cu, n_in)) {
 		// small round: one workgroup per batch, the four waves share the fold (latency, not throughput)
 		hipLaunchKernelGGL(k_foldeval9_small, dim3((unsigned)n_batches), dim3(256), 0, s, fa, n_in, z, d_out, fz);
 		return hipGetLastError();

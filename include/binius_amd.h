@@ -217,7 +217,7 @@ int bn_gather_d2h(bn_ctx *ctx, const void *d_src, const uint64_t *h_offsets, uin
 /* Per-kernel-class timing without perturbing the stream: while profiling is on, every launch of a
  * hot kernel is bracketed by two hipEvents recorded on the context's stream (no synchronisation);
  * bn_prof_end synchronises once and sums the elapsed times per class. */
-enum { BN_PROF_ROUND_EVAL = 0, BN_PROF_FOLD = 1, BN_PROF_TENSOR_EXPAND = 2, BN_PROF_NTT = 3, BN_PROF_OTHER = 4, BN_PROF_FOLD_EVAL = 5, BN_PROF_TAIL = 6, BN_PROF_N = 7 };
+enum { BN_PROF_ROUND_EVAL = 0, BN_PROF_FOLD = 1, BN_PROF_TENSOR_EXPAND = 2, BN_PROF_NTT = 3, BN_PROF_OTHER = 4, BN_PROF_FOLD_EVAL = 5, BN_PROF_TAIL = 6, BN_PROF_FOLD_EVAL_SMALL = 7, BN_PROF_N = 8 };
 int bn_prof_begin(bn_ctx *ctx);
 int bn_prof_end(bn_ctx *ctx, double *ms_by_class /*[BN_PROF_N]*/, uint64_t *launches_by_class /*[BN_PROF_N]*/);
 
