@@ -86,18 +86,30 @@ struct gstate {
 	uint32_t lo[8], hi[8];
 };
 
-// table value of byte K (0..7) of column `col`, rotated up by K bytes, XORed into (alo, ahi) pairs
+// The table sits at LDS address 0 (these kernels have no static __shared__; checked at kernel entry),
+// so the lookup address IS the LDS address: reading through an integer-made LDS pointer keeps the
+// compiler from adding the (zero) dynamic-LDS base to every address -- one VALU less per lookup.
+typedef unsigned int gr_u2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const gr_u2 lds_cuint2;
+
+__device__ __forceinline__ void require_table_at_lds_zero(const void *smem)
+{
+	if ((uint32_t)(size_t)(__attribute__((address_space(3))) const void *)smem != 0u) __builtin_trap();
+}
+
+// table value of byte K (0..7) of the column word pair (lo, hi)
 template <int K>
-__device__ __forceinline__ uint2 lookup(const char *tab_lane, uint32_t lo, uint32_t hi, uint32_t lane_off)
+__device__ __forceinline__ uint2 lookup(const char *, uint32_t lo, uint32_t hi, uint32_t lane_off)
 {
 	// address = byte << 8 | lane_off: bytes {lane_off.b0, word.bK, 0, 0}
 	const uint32_t word = K < 4 ? lo : hi;
 	constexpr uint32_t sel = 0x0C0C0000u | ((4u + (K & 3)) << 8) | 0u;
 	const uint32_t addr = __builtin_amdgcn_perm(word, lane_off, sel);
-	return *reinterpret_cast<const uint2 *>(tab_lane + addr);
+	const gr_u2 v = *(lds_cuint2 *)(size_t)addr;
+	return uint2{v.x, v.y};
 }
 
-// ROTL64(t, 8K) XORed later: returns the rotated pair
+// ROTL64(t, 8K)
 template <int K>
 __device__ __forceinline__ uint2 rot_bytes(uint2 t)
 {
@@ -107,6 +119,16 @@ __device__ __forceinline__ uint2 rot_bytes(uint2 t)
 		return uint2{__builtin_amdgcn_alignbyte(t.x, t.y, 4 - K), __builtin_amdgcn_alignbyte(t.y, t.x, 4 - K)};
 	else
 		return uint2{__builtin_amdgcn_alignbyte(t.y, t.x, 8 - K), __builtin_amdgcn_alignbyte(t.x, t.y, 8 - K)};
+}
+
+// XOR_k ROTL64(t_k, 8k): rows k and k + 4 differ by a half swap, which is free, so they are paired
+// BEFORE the byte rotation -- three rotations per column instead of six
+__device__ __forceinline__ uint2 mix_rows(uint2 t0, uint2 t1, uint2 t2, uint2 t3, uint2 t4, uint2 t5, uint2 t6, uint2 t7)
+{
+	const uint2 r1 = rot_bytes<1>(uint2{t1.x ^ t5.y, t1.y ^ t5.x});
+	const uint2 r2 = rot_bytes<2>(uint2{t2.x ^ t6.y, t2.y ^ t6.x});
+	const uint2 r3 = rot_bytes<3>(uint2{t3.x ^ t7.y, t3.y ^ t7.x});
+	return uint2{xor3(xor3(t0.x, t4.y, r1.x), r2.x, r3.x), xor3(xor3(t0.y, t4.x, r1.y), r2.y, r3.y)};
 }
 
 template <bool Q>
@@ -125,16 +147,17 @@ template <bool Q, int C>
 __device__ __forceinline__ void column(const gstate &in, gstate &out, const char *tab, uint32_t lane_off)
 {
 	using S = shifts<Q>;
-	const uint2 t0 = rot_bytes<0>(lookup<0>(tab, in.lo[(C + S::s[0]) & 7], in.hi[(C + S::s[0]) & 7], lane_off));
-	const uint2 t1 = rot_bytes<1>(lookup<1>(tab, in.lo[(C + S::s[1]) & 7], in.hi[(C + S::s[1]) & 7], lane_off));
-	const uint2 t2 = rot_bytes<2>(lookup<2>(tab, in.lo[(C + S::s[2]) & 7], in.hi[(C + S::s[2]) & 7], lane_off));
-	const uint2 t3 = rot_bytes<3>(lookup<3>(tab, in.lo[(C + S::s[3]) & 7], in.hi[(C + S::s[3]) & 7], lane_off));
-	const uint2 t4 = rot_bytes<4>(lookup<4>(tab, in.lo[(C + S::s[4]) & 7], in.hi[(C + S::s[4]) & 7], lane_off));
-	const uint2 t5 = rot_bytes<5>(lookup<5>(tab, in.lo[(C + S::s[5]) & 7], in.hi[(C + S::s[5]) & 7], lane_off));
-	const uint2 t6 = rot_bytes<6>(lookup<6>(tab, in.lo[(C + S::s[6]) & 7], in.hi[(C + S::s[6]) & 7], lane_off));
-	const uint2 t7 = rot_bytes<7>(lookup<7>(tab, in.lo[(C + S::s[7]) & 7], in.hi[(C + S::s[7]) & 7], lane_off));
-	out.lo[C] = xor3(xor3(t0.x, t1.x, t2.x), xor3(t3.x, t4.x, t5.x), t6.x ^ t7.x);
-	out.hi[C] = xor3(xor3(t0.y, t1.y, t2.y), xor3(t3.y, t4.y, t5.y), t6.y ^ t7.y);
+	const uint2 t0 = lookup<0>(tab, in.lo[(C + S::s[0]) & 7], in.hi[(C + S::s[0]) & 7], lane_off);
+	const uint2 t1 = lookup<1>(tab, in.lo[(C + S::s[1]) & 7], in.hi[(C + S::s[1]) & 7], lane_off);
+	const uint2 t2 = lookup<2>(tab, in.lo[(C + S::s[2]) & 7], in.hi[(C + S::s[2]) & 7], lane_off);
+	const uint2 t3 = lookup<3>(tab, in.lo[(C + S::s[3]) & 7], in.hi[(C + S::s[3]) & 7], lane_off);
+	const uint2 t4 = lookup<4>(tab, in.lo[(C + S::s[4]) & 7], in.hi[(C + S::s[4]) & 7], lane_off);
+	const uint2 t5 = lookup<5>(tab, in.lo[(C + S::s[5]) & 7], in.hi[(C + S::s[5]) & 7], lane_off);
+	const uint2 t6 = lookup<6>(tab, in.lo[(C + S::s[6]) & 7], in.hi[(C + S::s[6]) & 7], lane_off);
+	const uint2 t7 = lookup<7>(tab, in.lo[(C + S::s[7]) & 7], in.hi[(C + S::s[7]) & 7], lane_off);
+	const uint2 o = mix_rows(t0, t1, t2, t3, t4, t5, t6, t7);
+	out.lo[C] = o.x;
+	out.hi[C] = o.y;
 }
 
 template <bool Q>
@@ -220,6 +243,7 @@ __global__ __launch_bounds__(kThreads) void k_groestl_leaves(const uint4 *__rest
                                                              uint4 *__restrict__ digests)
 {
 	extern __shared__ __align__(16) unsigned char smem[];
+	require_table_at_lds_zero(smem);
 	stage_table(reinterpret_cast<uint2 *>(smem));
 	const char *tab = reinterpret_cast<const char *>(smem);
 	const uint32_t lane_off = (threadIdx.x & (kCopies - 1)) * 8;
@@ -269,6 +293,7 @@ __global__ __launch_bounds__(kThreads) void k_groestl_leaves(const uint4 *__rest
 __global__ __launch_bounds__(kThreads) void k_groestl_layer(const uint4 *__restrict__ prev, uint64_t n_out, uint4 *__restrict__ next)
 {
 	extern __shared__ __align__(16) unsigned char smem[];
+	require_table_at_lds_zero(smem);
 	stage_table(reinterpret_cast<uint2 *>(smem));
 	const char *tab = reinterpret_cast<const char *>(smem);
 	const uint32_t lane_off = (threadIdx.x & (kCopies - 1)) * 8;
@@ -304,7 +329,7 @@ template <bool Q, int K>
 __device__ __forceinline__ uint2 lane_lookup(const char *tab, uint32_t lo, uint32_t hi, uint32_t lane_off)
 {
 	const uint32_t w = from_column_plus<shifts<Q>::s[K]>(K < 4 ? lo : hi);
-	return rot_bytes<K>(lookup<K>(tab, w, w, lane_off));
+	return lookup<K>(tab, w, w, lane_off);
 }
 
 // one round of P or Q on a state spread over eight lanes: (lo, hi) = this lane's column c
@@ -321,8 +346,9 @@ __device__ __forceinline__ void round_lanes(uint32_t &lo, uint32_t &hi, uint32_t
 	const uint2 t2 = lane_lookup<Q, 2>(tab, lo, hi, lane_off), t3 = lane_lookup<Q, 3>(tab, lo, hi, lane_off);
 	const uint2 t4 = lane_lookup<Q, 4>(tab, lo, hi, lane_off), t5 = lane_lookup<Q, 5>(tab, lo, hi, lane_off);
 	const uint2 t6 = lane_lookup<Q, 6>(tab, lo, hi, lane_off), t7 = lane_lookup<Q, 7>(tab, lo, hi, lane_off);
-	lo = xor3(xor3(t0.x, t1.x, t2.x), xor3(t3.x, t4.x, t5.x), t6.x ^ t7.x);
-	hi = xor3(xor3(t0.y, t1.y, t2.y), xor3(t3.y, t4.y, t5.y), t6.y ^ t7.y);
+	const uint2 o = mix_rows(t0, t1, t2, t3, t4, t5, t6, t7);
+	lo = o.x;
+	hi = o.y;
 }
 
 __device__ __forceinline__ void perm_p_lanes(uint32_t &lo, uint32_t &hi, uint32_t c, const char *tab, uint32_t lane_off)
@@ -351,6 +377,7 @@ __global__ __launch_bounds__(kLaneThreads) void k_groestl_leaves_lanes(const uin
                                                                        uint2 *__restrict__ digests)
 {
 	extern __shared__ __align__(16) unsigned char smem[];
+	require_table_at_lds_zero(smem);
 	stage_table(reinterpret_cast<uint2 *>(smem));
 	const char *tab = reinterpret_cast<const char *>(smem);
 	const uint32_t lane_off = (threadIdx.x & (kCopies - 1)) * 8;
@@ -379,6 +406,7 @@ __global__ __launch_bounds__(kLaneThreads) void k_groestl_leaves_lanes(const uin
 __global__ __launch_bounds__(kLaneThreads) void k_groestl_layer_lanes(const uint2 *__restrict__ prev, uint64_t n_out, uint2 *__restrict__ next)
 {
 	extern __shared__ __align__(16) unsigned char smem[];
+	require_table_at_lds_zero(smem);
 	stage_table(reinterpret_cast<uint2 *>(smem));
 	const char *tab = reinterpret_cast<const char *>(smem);
 	const uint32_t lane_off = (threadIdx.x & (kCopies - 1)) * 8;
@@ -398,6 +426,7 @@ constexpr int kTopMaxIn = 1024; // digests of the widest layer it takes
 __global__ __launch_bounds__(kTopThreads) void k_groestl_top(uint4 *__restrict__ layer, uint32_t n_in)
 {
 	extern __shared__ __align__(16) unsigned char smem[];
+	require_table_at_lds_zero(smem);
 	stage_table(reinterpret_cast<uint2 *>(smem));
 	const char *tab = reinterpret_cast<const char *>(smem);
 	uint2 *buf_a = reinterpret_cast<uint2 *>(smem + kTableBytes); // kTopMaxIn digests = 32 KiB
