@@ -9,6 +9,7 @@
 #include <string>
 #include <vector>
 
+#include "../../binius_amd/host/fri.hpp"
 #include "../../binius_amd/host/merkle.hpp"
 #include "../../binius_amd/host/sumcheck.hpp"
 extern "C" {
@@ -498,6 +499,102 @@ static void test_binary_merkle_vcs(Env &e)
 	CHECK(threw);
 }
 
+// crates/core/src/protocols/fri/tests.rs (test_commit_prove_verify_*): commit the interleaved message,
+// run every fold round, finalize, open queries -- against the composition of the oracle's NTT, fri_fold
+// and Merkle restatements, bit for bit
+static void test_fri_commit_fold_query(Env &e)
+{
+	struct Shape {
+		size_t log_dim, log_inv_rate, log_batch;
+		std::vector<size_t> arities;
+	};
+	for (const Shape &sh : {Shape{8, 2, 3, {3, 2, 1}}, Shape{8, 2, 0, {4, 3}}, Shape{6, 1, 2, {}}}) {
+		ComputeData d = e.holder.to_data();
+		FRIParams p(sh.log_dim, sh.log_inv_rate, sh.log_batch, sh.arities, 3);
+		AdditiveNTT ntt(*d.hal, 5, p.rs_log_len());
+		BinaryMerkleTreeProver merkle(*d.hal);
+		auto message = random_vec(0xF21 + sh.log_dim + sh.log_batch, (size_t)1 << (sh.log_dim + sh.log_batch));
+		FSliceMut dmsg = d.dev_alloc.alloc(message.size());
+		d.hal->copy_h2d(message, dmsg);
+		CommitOutput out = commit_interleaved(*d.hal, d.dev_alloc, p, ntt, merkle, C(dmsg));
+		// oracle: repeat, NTT, tree
+		std::vector<B128> code;
+		for (size_t j = 0; j < ((size_t)1 << sh.log_inv_rate); j++) code.insert(code.end(), message.begin(), message.end());
+		CHECK(ref_ntt_forward(code.data(), 5, 5, ntt.s_evals(), (int)p.rs_log_len(), (int)sh.log_batch + 2, (int)p.rs_log_len(), 0, 0, 0,
+		                      (int)sh.log_inv_rate) == 0);
+		std::vector<B128> got_code(code.size());
+		d.hal->copy_d2h(C(out.codeword), got_code);
+		CHECK(got_code == code);
+		const size_t coset0 = sh.arities.empty() ? sh.log_dim + sh.log_batch : sh.arities[0];
+		std::vector<Digest> want_nodes(2 * (code.size() >> coset0) - 1);
+		CHECK(ref_merkle_build(reinterpret_cast<const uint8_t *>(code.data()), code.size(), (uint64_t)1 << coset0, want_nodes[0].data()) == 0);
+		CHECK(out.committed.inner_nodes() == want_nodes);
+		CHECK(out.commitment == want_nodes.back());
+		// fold rounds
+		FRIFolder folder(*d.hal, p, ntt, merkle, C(out.codeword), out.committed);
+		auto challenges = random_vec(0xC4A + sh.log_dim, folder.n_rounds());
+		std::vector<std::vector<B128>> codes{code};
+		std::vector<B128> pending;
+		size_t cur_log_len = p.rs_log_len(), cur_log_batch = sh.log_batch, next_commit = sh.arities.empty() ? 0 : sh.arities[0], n_committed = 0;
+		for (size_t r = 1; r <= challenges.size(); r++) {
+			auto [has_root, root] = folder.execute_fold_round(d.dev_alloc, challenges[r - 1]);
+			pending.push_back(challenges[r - 1]);
+			if (r != next_commit) {
+				CHECK(!has_root);
+				continue;
+			}
+			const size_t new_log_len = cur_log_len - (pending.size() - cur_log_batch);
+			std::vector<B128> nxt((size_t)1 << new_log_len);
+			CHECK(ref_fri_fold(ntt.s_evals(), 5, (int)p.rs_log_len(), (int)cur_log_len, (int)cur_log_batch, R(pending), pending.size(),
+			                   R(codes.back()), codes.back().size(), R(nxt), nxt.size()) == 0);
+			n_committed++;
+			const size_t coset = (size_t)1 << (n_committed < sh.arities.size() ? sh.arities[n_committed] : p.n_final_challenges());
+			std::vector<Digest> nodes(2 * (nxt.size() / coset) - 1);
+			CHECK(ref_merkle_build(reinterpret_cast<const uint8_t *>(nxt.data()), nxt.size(), coset, nodes[0].data()) == 0);
+			CHECK(has_root && root == nodes.back());
+			CHECK(folder.round_committed().back().second.inner_nodes() == nodes);
+			codes.push_back(nxt);
+			cur_log_len = new_log_len;
+			cur_log_batch = 0;
+			pending.clear();
+			next_commit = n_committed < sh.arities.size() ? next_commit + sh.arities[n_committed] : 0;
+		}
+		CHECK(folder.round_committed().size() == sh.arities.size());
+		auto [terminate, qp] = folder.finalize();
+		CHECK(terminate == codes.back());
+		// queries: opened cosets == the oracle's codewords, branches lead to the advertised layers
+		auto layers = qp.vcs_optimal_layers();
+		auto depths = p.optimal_layer_depths();
+		for (size_t index : {(size_t)0, ((size_t)1 << p.index_bits()) - 1, (size_t)0x5A5 & (((size_t)1 << p.index_bits()) - 1)}) {
+			auto openings = qp.prove_query(index);
+			CHECK(openings.size() == sh.arities.size());
+			size_t idx = index;
+			for (size_t i = 0; i < openings.size(); i++) {
+				const size_t arity = sh.arities[i];
+				if (i > 0) idx >>= arity;
+				const auto &cw = codes[i];
+				CHECK(openings[i].values == std::vector<B128>(cw.begin() + (idx << arity), cw.begin() + ((idx + 1) << arity)));
+				size_t log_cw = 0;
+				while (((size_t)1 << log_cw) < cw.size()) log_cw++;
+				const size_t log_n_cosets = log_cw - arity;
+				CHECK(openings[i].branch.size() == log_n_cosets - depths[i]);
+				Digest leaf, top;
+				ref_groestl256(reinterpret_cast<const uint8_t *>(openings[i].values.data()), 16 * openings[i].values.size(), leaf.data());
+				ref_merkle_root_from_branch(leaf.data(), idx, openings[i].branch.empty() ? nullptr : openings[i].branch[0].data(),
+				                            (uint32_t)openings[i].branch.size(), top.data());
+				CHECK(top == layers[i][idx >> (log_n_cosets - depths[i])]);
+			}
+		}
+	}
+	bool threw = false;
+	try {
+		FRIParams bad(4, 1, 0, {2, 2}, 1);
+	} catch (const Error &ex) {
+		threw = std::string(ex.what()).find("InvalidFoldAritySequence") != std::string::npos;
+	}
+	CHECK(threw);
+}
+
 int main()
 {
 	struct T {
@@ -522,6 +619,7 @@ int main()
 	    {"generic_test_bivariate_sumcheck_prove_verify", test_bivariate_sumcheck_prove_verify},
 	    {"test_additive_ntt", test_ntt},
 	    {"test_binary_merkle_vcs_commit_prove_open_correctly", test_binary_merkle_vcs},
+	    {"test_fri_commit_fold_query_device_resident", test_fri_commit_fold_query},
 	};
 	int failed = 0;
 	try {
