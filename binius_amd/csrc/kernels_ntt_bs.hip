@@ -44,6 +44,8 @@ struct ntt_bs_tables {
 	uint32_t tconst[32];   // [l]: coset contribution (uniform)
 };
 
+typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) volatile u4v lds_vu4; // one LDS access = one 128-bit instruction
 constexpr int kSetQ = 9;     // LDS uint4 per plane set: 8 + 1 pad (bank spread)
 constexpr int kTileLog = 9;  // plane sets per tile = 512
 
@@ -189,6 +191,7 @@ __global__ __launch_bounds__(256, 2) void k_ntt_bs_pass(uint4 *__restrict__ bs, 
                                                         uint32_t log_y)
 {
 	extern __shared__ __attribute__((aligned(16))) uint4 tile[]; // [512][kSetQ]
+	lds_vu4 *tile3 = (lds_vu4 *)(__attribute__((address_space(3))) void *)tile;
 	const unsigned tid = threadIdx.x;
 	bs += (uint64_t)blockIdx.y * S * 8; // batch
 	if (CONV) {
@@ -233,7 +236,10 @@ __global__ __launch_bounds__(256, 2) void k_ntt_bs_pass(uint4 *__restrict__ bs, 
 		uint32_t U[32], V[32], T[32];
 #pragma unroll
 		for (int k = 0; k < 8; k++) {
-			const uint4 a = tile[s_u * kSetQ + k], c = tile[s_v * kSetQ + k];
+			// (volatile: keeps each access one ds_read_b128 / ds_write_b128 -- left alone the compiler re-splits
+			// them into ds_read2_b32 / ds_write2_b32, whose 32-bank mapping makes the 144-byte set stride a
+			// 4-way conflict: 74 % of this kernel's LDS cycles were conflict cycles)
+			const u4v a = tile3[s_u * kSetQ + k], c = tile3[s_v * kSetQ + k];
 			U[4 * k] = a.x;
 			U[4 * k + 1] = a.y;
 			U[4 * k + 2] = a.z;
@@ -266,8 +272,8 @@ __global__ __launch_bounds__(256, 2) void k_ntt_bs_pass(uint4 *__restrict__ bs, 
 		butterfly_planes<INV>(U, V, T);
 #pragma unroll
 		for (int k = 0; k < 8; k++) {
-			tile[s_u * kSetQ + k] = uint4{U[4 * k], U[4 * k + 1], U[4 * k + 2], U[4 * k + 3]};
-			tile[s_v * kSetQ + k] = uint4{V[4 * k], V[4 * k + 1], V[4 * k + 2], V[4 * k + 3]};
+			tile3[s_u * kSetQ + k] = u4v{U[4 * k], U[4 * k + 1], U[4 * k + 2], U[4 * k + 3]};
+			tile3[s_v * kSetQ + k] = u4v{V[4 * k], V[4 * k + 1], V[4 * k + 2], V[4 * k + 3]};
 		}
 		__syncthreads();
 	}
