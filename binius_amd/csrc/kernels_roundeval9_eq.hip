@@ -51,6 +51,11 @@ __global__ __launch_bounds__(256, 2) void k_roundeval9_eq(const uint32_t *__rest
 	const bool loader = live && c < 8;
 	const bool builder = live && c < 4;
 	uint4 *wt = tile[wave];
+	// stores go through a volatile 128-bit LDS pointer: otherwise some of the 8-chunk block stores are
+	// re-split into ds_write2_b32, whose 32-bank mapping conflicts 4-way on the 144-byte block stride
+	typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+	typedef __attribute__((address_space(3))) volatile u4v lds_vu4;
+	lds_vu4 *wv = (lds_vu4 *)(__attribute__((address_space(3))) void *)wt;
 	if (lane < kBlkQ)
 		wt[kZeroP * kBlkQ + lane] = uint4{0, 0, 0, 0};
 
@@ -154,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void k_roundeval9_eq(const uint32_t *__rest
 		if (loader) {
 #pragma unroll
 			for (int q = 0; q < 8; q++)
-				wt[off_w + q] = uint4{r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]};
+				wv[off_w + q] = u4v{r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]};
 		}
 		wave_sync();
 		// the eq rows of this batch fly during the first product
@@ -170,18 +175,18 @@ __global__ __launch_bounds__(256, 2) void k_roundeval9_eq(const uint32_t *__rest
 			// they write their values into the zero block only if those are zero -- so they skip instead.
 #pragma unroll
 			for (int q = 0; q < 8; q++)
-				wt[off_pp + q] = uint4{P[4 * q], P[4 * q + 1], P[4 * q + 2], P[4 * q + 3]};
+				wv[off_pp + q] = u4v{P[4 * q], P[4 * q + 1], P[4 * q + 2], P[4 * q + 3]};
 			bs_mul_alpha<5>(P, A); // A = alpha * P
 			if (atype >= 0 && live) {
 #pragma unroll
 				for (int q = 0; q < 8; q++)
-					wt[off_ap + q] = uint4{A[4 * q], A[4 * q + 1], A[4 * q + 2], A[4 * q + 3]};
+					wv[off_ap + q] = u4v{A[4 * q], A[4 * q + 1], A[4 * q + 2], A[4 * q + 3]};
 			}
 			bs_mul_alpha<5>(A, B); // B = alpha^2 * P
 			if (c == 4 && live) {
 #pragma unroll
 				for (int q = 0; q < 8; q++)
-					wt[off_aap + q] = uint4{B[4 * q], B[4 * q + 1], B[4 * q + 2], B[4 * q + 3]};
+					wv[off_aap + q] = u4v{B[4 * q], B[4 * q + 1], B[4 * q + 2], B[4 * q + 3]};
 			}
 		}
 		wave_sync();
