@@ -38,12 +38,13 @@ def test_random_call_sequences(monkeypatch, oracle, seed, tail):
             bufs = [alloc.alloc(n) for _ in range(n_bufs)]
             for b, h in zip(bufs, host):
                 hal.copy_h2d(h, b)
+            hal._nodes = alloc.alloc(4 * n)  # room for the Merkle tree of any live prefix
             ctxs.append((hal, bufs, bivariate_product_expr(hal, 0, 1)))
         zs = oracle.random_scalars(0xFA22 + seed, 64)
         cur = n  # current "live" length of the arrays (they shrink when folded)
         log = []
         for step in range(40):
-            op = rng.choice(["fold2", "fold_any", "copy", "eval", "read", "fill", "fold_copy_first", "chain"])
+            op = rng.choice(["fold2", "fold_any", "copy", "eval", "read", "fill", "fold_copy_first", "chain", "merkle", "gather"])
             a, b, c = [int(x) for x in rng.choice(n_bufs, 3, replace=False)]
             z = zs[step]
             outs = []
@@ -73,6 +74,14 @@ def test_random_call_sequences(monkeypatch, oracle, seed, tail):
                     outs.append(hal.copy_d2h(bufs[a].slice(0, min(cur, 4))).tolist())
                 elif op == "fill":
                     hal.fill(bufs[c].slice(0, cur), z)
+                elif op == "merkle":
+                    # the commitment entry points observe device memory: deferred folds / copies must land first
+                    batch = 2 if cur >= 4 else 1
+                    nodes = hal._nodes.slice(0, 2 * (2 * (cur // batch) - 1))
+                    hal.merkle_build(bufs[a].slice(0, cur), batch, nodes)
+                    outs.append(hal.copy_d2h(nodes.slice(nodes.len - 2, nodes.len)).tolist())
+                elif op == "gather":
+                    outs.append(hal.gather_d2h(bufs[b].slice(0, cur), [0, cur - 1, cur // 2], 1).tolist())
                 elif op == "fold_copy_first" and cur >= 2:
                     # first fold of a prover: copy evals_0 into fresh buffers, fold those
                     hal.copy_d2d(bufs[a].slice(0, half), bufs[c].slice(0, half))
