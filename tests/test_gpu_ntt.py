@@ -43,6 +43,10 @@ def make_data(oracle, seed, n, elem_level):
         (6, 5, 15, 0, 15, 0, 0, 0, 0),
         (7, 5, 16, 0, 15, 0, 1, 1, 0),
         (7, 5, 14, 1, 14, 1, 0, 0, 0),
+        # many interleaved transforms (lx >= 2: head and tail kernels with the column index across the lanes)
+        (5, 5, 15, 5, 15, 0, 0, 0, 0),
+        (7, 5, 15, 4, 14, 0, 1, 1, 1),
+        (5, 5, 14, 3, 14, 1, 0, 0, 2),
         # skip_rounds (the RS-encoding shape): fewer in-register layers / fewer lower layers
         (5, 5, 16, 0, 16, 0, 0, 0, 2),
         (5, 5, 16, 0, 15, 0, 1, 1, 7),
@@ -90,3 +94,53 @@ def test_ntt_validation(hal):
         hal.ntt_forward(d.ptr, 5, 5, s, 10, 0, 8, 0, coset=4, coset_bits=2)  # coset out of bounds
     with pytest.raises(binius_amd.BnError):
         hal.ntt_forward(d.ptr, 4, 5, s, 10, 0, 8, 0)  # twiddle field larger than element field
+
+
+def test_ntt_config3_full_size(oracle):
+    """BASELINE config 3: 2^24 BinaryField32b coefficients, shape {log_x 0, log_y 24, log_z 0}, coset 0.
+    A quarter-size transform is compared with the scalar oracle outright; at full size the checks are
+    size-independent: forward then inverse is the identity, the transform is GF(2)-linear, and (the
+    recursive structure of the novel-basis evaluation, additive_ntt.rs:23-56) the full transform with
+    skip_rounds = 2 equals four quarter-size transforms over the cosets 0..3 of the same domain."""
+    import binius_amd
+
+    hal = binius_amd.Context(0, (3 << 22) + (1 << 12))  # three buffers of 2^24 B32 = 2^22 elements each
+    try:
+        alloc = hal.dev_alloc()
+        L = 24
+        s = binius_amd.ntt_s_evals(5, L)
+        x = oracle.splitmix_words(0xC0F3, 1 << L).astype(np.uint32)
+        y = oracle.splitmix_words(0xC0F4, 1 << L).astype(np.uint32)
+        dx, dy, dz = (alloc.alloc(1 << (L - 2)) for _ in range(3))
+        # quarter size against the oracle
+        q = x[: 1 << (L - 2)].copy()
+        hal.copy_bytes_h2d(q, dx.ptr)
+        hal.ntt_forward(dx.ptr, 5, 5, s, L, 0, L - 2, 0, 1, 2, 0)
+        got_q = hal.copy_bytes_d2h(dx.ptr, np.zeros_like(q))
+        assert oracle.ntt_forward(q, 5, 5, s, L, 0, L - 2, 0, 1, 2, 0) == 0
+        assert np.array_equal(got_q, q)
+        # full size
+        hal.copy_bytes_h2d(x, dx.ptr)
+        hal.copy_bytes_h2d(y, dy.ptr)
+        hal.copy_bytes_h2d(x ^ y, dz.ptr)
+        for d in (dx, dy, dz):
+            hal.ntt_forward(d.ptr, 5, 5, s, L, 0, L, 0)
+        fx = hal.copy_bytes_d2h(dx.ptr, np.zeros_like(x))
+        fy = hal.copy_bytes_d2h(dy.ptr, np.zeros_like(x))
+        fz = hal.copy_bytes_d2h(dz.ptr, np.zeros_like(x))
+        assert np.array_equal(fx ^ fy, fz)
+        assert not np.array_equal(fx, x)
+        hal.ntt_inverse(dx.ptr, 5, 5, s, L, 0, L, 0)
+        assert np.array_equal(hal.copy_bytes_d2h(dx.ptr, np.zeros_like(x)), x)
+        # skip_rounds = 2 leaves four independent quarter-size transforms, quarter c over coset c
+        hal.copy_bytes_h2d(x, dy.ptr)
+        hal.ntt_forward(dy.ptr, 5, 5, s, L, 0, L, 0, 0, 0, 2)
+        skipped = hal.copy_bytes_d2h(dy.ptr, np.zeros_like(x))
+        quarter = 1 << (L - 2)
+        for c in range(4):
+            part = x[c * quarter : (c + 1) * quarter].copy()
+            hal.copy_bytes_h2d(part, dz.ptr)
+            hal.ntt_forward(dz.ptr, 5, 5, s, L, 0, L - 2, 0, c, 2, 0)
+            assert np.array_equal(hal.copy_bytes_d2h(dz.ptr, np.zeros_like(part)), skipped[c * quarter : (c + 1) * quarter]), c
+    finally:
+        hal.close()
