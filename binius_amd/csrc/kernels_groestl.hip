@@ -423,7 +423,11 @@ __global__ __launch_bounds__(kLaneThreads) void k_groestl_layer_lanes(const uint
 constexpr int kTopThreads = 1024;
 constexpr int kTopMaxIn = 1024; // digests of the widest layer it takes
 
-__global__ __launch_bounds__(kTopThreads) void k_groestl_top(uint4 *__restrict__ layer, uint32_t n_in)
+// Workgroup b takes the n_sub (<= kTopMaxIn) consecutive digests b * n_sub .. of a layer that is n_total
+// digests wide and walks `levels` (<= log2 n_sub) levels up; level j of the whole tree is
+// n_total >> j digests wide and starts right behind level j - 1 (the flattened order), workgroup b owns
+// its digests b * (n_sub >> j) ...  One workgroup with n_sub = n_total is the top of the tree.
+__global__ __launch_bounds__(kTopThreads) void k_groestl_top(uint4 *__restrict__ layer, uint64_t n_total, uint32_t n_sub, uint32_t levels)
 {
 	extern __shared__ __align__(16) unsigned char smem[];
 	require_table_at_lds_zero(smem);
@@ -434,16 +438,20 @@ __global__ __launch_bounds__(kTopThreads) void k_groestl_top(uint4 *__restrict__
 	const uint32_t lane_off = (threadIdx.x & (kCopies - 1)) * 8;
 	{
 		uint4 *a4 = reinterpret_cast<uint4 *>(buf_a);
-		for (uint32_t i = threadIdx.x; i < 2 * n_in; i += kTopThreads) a4[i] = layer[i];
+		const uint4 *in = layer + 2 * (uint64_t)blockIdx.x * n_sub;
+		for (uint32_t i = threadIdx.x; i < 2 * n_sub; i += kTopThreads) a4[i] = in[i];
 	}
 	__syncthreads();
 	const uint32_t l16 = threadIdx.x & 15, c = l16 >> 1;
 	const uint32_t slot = (threadIdx.x >> 4) * 2 + (l16 & 1); // hash slot of this lane: kTopThreads / 8 per pass
-	uint2 *out = reinterpret_cast<uint2 *>(layer + 2 * (uint64_t)n_in);
+	uint2 *level = reinterpret_cast<uint2 *>(layer + 2 * n_total); // level 1 of the whole layer
+	uint64_t width = n_total >> 1;
 	uint2 *src = buf_a, *dst = buf_b;
-	for (uint32_t n = n_in >> 1; n >= 1; n >>= 1) {
+	uint32_t n = n_sub >> 1;
+	for (uint32_t lv = 0; lv < levels; lv++, n >>= 1) {
+		uint2 *out = level + 4 * (uint64_t)blockIdx.x * n;
 		for (uint32_t base = 0; base < n; base += kTopThreads / 8) {
-			if (base + (threadIdx.x >> 4) * 2 >= n) break; // (wave-uniform: a wave is four rows = 8 slots)
+			if (base + (threadIdx.x >> 4) * 2 >= n) break; // (a 16-lane row leaves or stays as a whole)
 			const uint32_t p = base + slot;
 			const bool act = p < n;
 			const uint32_t pc = act ? p : 0;
@@ -457,7 +465,8 @@ __global__ __launch_bounds__(kTopThreads) void k_groestl_top(uint4 *__restrict__
 			}
 		}
 		__syncthreads();
-		out += 4 * (uint64_t)n;
+		level += 4 * width;
+		width >>= 1;
 		uint2 *t = src;
 		src = dst;
 		dst = t;
@@ -552,24 +561,39 @@ hipError_t launch_gather(hipStream_t s, const void *src, const uint64_t *offsets
 	return hipGetLastError();
 }
 
-// nodes: the flattened tree (leaf digests already at the front).  Large layers one launch each, the
-// last <= kTopMaxIn-wide layers in one workgroup.
+// nodes: the flattened tree (leaf digests already at the front).  Layers wider than 2^20 digests one
+// throughput launch each; below that, sub-trees of 1024 digests per workgroup (ten levels per launch:
+// 7 G compressions/s with one launch against ~5 G/s and ten launches of the per-layer kernels at
+// these widths), the last one being the top of the tree.
 hipError_t launch_merkle_layers(hipStream_t s, int n_cu, void *nodes, uint64_t n_leaves)
 {
 	hipError_t e = set_lds_limits();
 	if (e != hipSuccess) return e;
+	static const uint64_t subtree_max = [] {
+		const char *v = getenv("BN_GROESTL_SUBTREE_MAX_LOG2");
+		return (uint64_t)1 << (v ? atoi(v) : 20);
+	}();
 	char *layer = (char *)nodes;
 	uint64_t n = n_leaves;
-	while (n > (uint64_t)kTopMaxIn) {
+	while (n > subtree_max && n > (uint64_t)kTopMaxIn) {
 		char *next = layer + 32 * n;
 		e = launch_groestl_layer(s, n_cu, layer, n >> 1, next);
 		if (e != hipSuccess) return e;
 		layer = next;
 		n >>= 1;
 	}
-	if (n >= 2) {
-		hipLaunchKernelGGL(k_groestl_top, dim3(1), dim3(kTopThreads), kTableBytes + 48 * kTopMaxIn, s, (uint4 *)layer, (uint32_t)n);
-		return hipGetLastError();
+	while (n >= 2) {
+		const uint32_t n_sub = n < (uint64_t)kTopMaxIn ? (uint32_t)n : (uint32_t)kTopMaxIn;
+		uint32_t levels = 0;
+		while ((1u << levels) < n_sub) levels++;
+		hipLaunchKernelGGL(k_groestl_top, dim3((unsigned)(n / n_sub)), dim3(kTopThreads), kTableBytes + 48 * kTopMaxIn, s, (uint4 *)layer, n, n_sub,
+		                   levels);
+		e = hipGetLastError();
+		if (e != hipSuccess) return e;
+		for (uint32_t j = 0; j < levels; j++) {
+			layer += 32 * n;
+			n >>= 1;
+		}
 	}
 	return hipSuccess;
 }
