@@ -273,10 +273,23 @@ def main():
         "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4),
         "traffic": None,
+        "traffic_source": None,
         "launches": cnt,
         "avg_launch_ms": round(ms / cnt, 5) if cnt else None,
         "algorithmic_bytes_per_launch": b // cnt if cnt else None,
     }
+    # HBM traffic of the dominant kernel: PMC counters cannot be collected inside this process, so the
+    # value comes from the committed counters-only rocprofv3 passes OF THIS COMMAND on this workload
+    # (profiles/r01/bench_n24_pmc.json: FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, bytes per launch);
+    # null for any other workload or kernel
+    try:
+        pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "bench_n24_pmc.json")))
+        sym = {"k_foldeval9(fold+round_eval)": "k_foldeval9<2>", "k_roundeval9(round_eval)": "k_roundeval9"}.get(dom)
+        if sym and pmc["workload"] == {"n_vars": n_vars, "multilinears": m} and sym in pmc["kernels"]:
+            roofline["traffic"] = pmc["kernels"][sym]["traffic_bytes_per_launch"]
+            roofline["traffic_source"] = "profiles/r01/bench_n24_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; bytes per launch)"
+    except (OSError, KeyError, ValueError):
+        pass
     per_kernel = {
         k: {
             "GBps": round(v[0] / (v[1] * 1e-3) / 1e9, 2) if v[1] > 0 else None,
