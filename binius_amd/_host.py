@@ -35,6 +35,11 @@ def host_lib():
             C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p), C.c_void_p, C.POINTER(F128), C.c_void_p, C.c_uint64,
             C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(F128), C.POINTER(F128), C.POINTER(F128), C.POINTER(F128), C.POINTER(F128),
         ]
+        L.bnh_fri_commit_fold.restype = C.c_int
+        L.bnh_fri_commit_fold.argtypes = [
+            C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+            C.c_uint64, C.POINTER(F128), C.c_void_p, C.c_void_p, C.POINTER(C.c_double),
+        ]
         L.bnh_rccl_open.argtypes = [C.c_char_p]
         L.bnh_rccl_unique_id.argtypes = [C.c_void_p]
         L.bnh_rccl_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
@@ -117,6 +122,31 @@ class MlecheckPlan:
 
     def final_evals(self):
         return [from_f128(self.final[j]) for j in range(self.m + 1)]
+
+
+class FriPlan:
+    """FRI commit phase + every fold round + finalize through the compiled C++ mirror (bnh_fri_commit_fold,
+    binius_amd/host/fri.hpp).  `scratch` takes the codeword, the folded codewords and the Merkle trees."""
+
+    def __init__(self, hal, params, message, scratch, challenges):
+        import numpy as np
+
+        self.hal, self.p, self.message, self.scratch = hal, params, message, scratch
+        self.arities = (C.c_uint32 * max(1, len(params.fold_arities)))(*params.fold_arities)
+        self.ch = _f128_array(list(challenges))
+        self.roots = np.zeros((len(params.fold_arities) + 1, 32), dtype=np.uint8)
+        self.terminate = np.zeros((1 << (params.log_inv_rate + params.n_final_challenges()), 2), dtype=np.uint64)
+        self.phase_ms = (C.c_double * 2)()
+
+    def run(self):
+        p = self.p
+        rc = host_lib().bnh_fri_commit_fold(
+            self.hal._h, p.log_dim, p.log_inv_rate, p.log_batch_size, self.arities, len(p.fold_arities), p.n_test_queries,
+            self.message.ptr, self.scratch.ptr, self.scratch.len, self.ch, self.roots.ctypes.data, self.terminate.ctypes.data, self.phase_ms,
+        )
+        if rc != 0:
+            raise BnError(rc, host_lib().bnh_last_error().decode())
+        return self.phase_ms[0], self.phase_ms[1]
 
 
 class ShmExchange:

@@ -20,6 +20,10 @@
 #include <vector>
 
 #include "../../include/binius_amd_host.h"
+#include <chrono>
+#include <cstring>
+
+#include "fri.hpp"
 #include "sumcheck.hpp"
 
 using namespace binius_amd;
@@ -401,6 +405,55 @@ int bnh_bivariate_mlecheck_prove(bn_ctx *ctx, uint32_t n_vars, uint32_t m, const
 		}
 		std::vector<B128> fin = prover.finish();
 		for (uint32_t j = 0; j <= m; j++) final_evals_out[j] = fin[j].raw();
+		return 0;
+	} catch (const Error &e) {
+		g_err = e.what();
+		return (int)e.kind();
+	} catch (const std::exception &e) {
+		g_err = e.what();
+		return BN_ERR_CORE_LIB;
+	}
+}
+
+// FRI commit phase + all fold rounds + finalize through the C++ mirror (fri.hpp), everything on the device.
+//   d_message        2^(log_dim + log_batch_size) elements (the interleaved message)
+//   d_scratch        device memory for the codeword, the folded codewords and the Merkle trees:
+//                    2 * 2^(log_dim + log_batch_size + log_inv_rate) elements are always enough
+//   challenges       [log_dim + log_batch_size]
+//   roots_out        [(n_arities + 1) * 32 bytes]: the commitment, then one root per committed oracle
+//   terminate_out    [2^(log_inv_rate + n_final_challenges)] elements or NULL
+//   phase_ms_out     [2] wall-clock milliseconds of the commit phase and of the fold phase, or NULL
+int bnh_fri_commit_fold(bn_ctx *ctx, uint32_t log_dim, uint32_t log_inv_rate, uint32_t log_batch_size, const uint32_t *fold_arities,
+                        uint32_t n_arities, uint32_t n_test_queries, const void *d_message, void *d_scratch, uint64_t scratch_elems,
+                        const bn_f128 *challenges, uint8_t *roots_out, bn_f128 *terminate_out, double *phase_ms_out)
+{
+	try {
+		ComputeLayer hal(ctx);
+		DeviceBumpAllocator dev_alloc(FSliceMut{d_scratch, (size_t)scratch_elems});
+		FRIParams p(log_dim, log_inv_rate, log_batch_size, std::vector<size_t>(fold_arities, fold_arities + n_arities), n_test_queries);
+		AdditiveNTT ntt(hal, 5, p.rs_log_len());
+		BinaryMerkleTreeProver merkle(hal);
+		hal.sync();
+		const auto t0 = std::chrono::steady_clock::now();
+		CommitOutput out = commit_interleaved(hal, dev_alloc, p, ntt, merkle, FSlice{d_message, (size_t)1 << (log_dim + log_batch_size)});
+		hal.sync();
+		const auto t1 = std::chrono::steady_clock::now();
+		std::memcpy(roots_out, out.commitment.data(), 32);
+		FRIFolder folder(hal, p, ntt, merkle, ComputeMemory::as_const(out.codeword), out.committed);
+		size_t n_roots = 1;
+		for (size_t r = 0; r < folder.n_rounds(); r++) {
+			auto [has_root, root] = folder.execute_fold_round(dev_alloc, B128(challenges[r].lo, challenges[r].hi));
+			if (has_root) std::memcpy(roots_out + 32 * n_roots++, root.data(), 32);
+		}
+		auto fin = folder.finalize();
+		hal.sync();
+		const auto t2 = std::chrono::steady_clock::now();
+		if (terminate_out)
+			for (size_t i = 0; i < fin.first.size(); i++) terminate_out[i] = fin.first[i].raw();
+		if (phase_ms_out) {
+			phase_ms_out[0] = std::chrono::duration<double, std::milli>(t1 - t0).count();
+			phase_ms_out[1] = std::chrono::duration<double, std::milli>(t2 - t1).count();
+		}
 		return 0;
 	} catch (const Error &e) {
 		g_err = e.what();

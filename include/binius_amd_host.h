@@ -58,6 +58,17 @@ int bnh_bivariate_mlecheck_prove(bn_ctx *ctx, uint32_t n_vars, uint32_t m, const
                                  const uint32_t *comp_indices, const bn_f128 *sums, const bn_f128 *batch_coeff,
                                  const bn_f128 *challenges, bn_f128 *round_coeffs_out, bn_f128 *final_evals_out);
 
+/* FRI commit phase (commit_interleaved, crates/core/src/protocols/fri/prove.rs:88-198), every fold round
+ * (FRIFolder::execute_fold_round, :307-432) and finalize (:444-482) through the C++ mirror
+ * binius_amd/host/fri.hpp, codewords and Merkle trees resident on the device.
+ * d_message: 2^(log_dim + log_batch_size) elements; d_scratch: 2 * 2^(log_dim + log_batch_size + log_inv_rate) elements are always enough (codeword + folded codewords + trees)
+ * ; challenges[log_dim + log_batch_size]; roots_out[(n_arities + 1) * 32]: the commitment, then one
+ * root per committed oracle; terminate_out: 2^(log_inv_rate + n_final_challenges) elements or NULL;
+ * phase_ms_out[2]: wall-clock ms of the commit and of the fold phase, or NULL. */
+int bnh_fri_commit_fold(bn_ctx *ctx, uint32_t log_dim, uint32_t log_inv_rate, uint32_t log_batch_size, const uint32_t *fold_arities,
+                        uint32_t n_arities, uint32_t n_test_queries, const void *d_message, void *d_scratch, uint64_t scratch_elems,
+                        const bn_f128 *challenges, uint8_t *roots_out, bn_f128 *terminate_out, double *phase_ms_out);
+
 /* shared-memory exchange: rank 0 creates the segment `name` ("/..."), the others open it afterwards */
 int bnh_shm_open(const char *name, int world, int rank, int create, void **handle_out);
 int bnh_shm_close(void *handle);

@@ -125,3 +125,40 @@ def test_fri_params_and_errors(hal, oracle):
 
     with pytest.raises(fri.FriError, match="InvalidArgs"):
         fri.commit_interleaved(hal, alloc, p, ntt, BinaryMerkleTreeProver(hal, alloc), alloc.alloc(1 << 10))
+
+
+@pytest.mark.parametrize("log_dim,log_inv_rate,log_batch,arities", [(8, 2, 3, [3, 2, 1]), (10, 1, 4, [4, 4, 2]), (6, 1, 2, [])])
+def test_compiled_fri_matches_oracle(hal, oracle, log_dim, log_inv_rate, log_batch, arities):
+    """bnh_fri_commit_fold (the C++ mirror behind one C call): every root and the terminal codeword against
+    the oracle composition."""
+    from binius_amd import fri
+    from binius_amd._host import FriPlan
+
+    p = fri.FRIParams(log_dim, log_inv_rate, log_batch, arities, n_test_queries=3)
+    log_domain = p.rs_log_len()
+    s_ref = oracle.ntt_s_evals(5, log_domain)
+    alloc = hal.dev_alloc()
+    message = oracle.random_b128(0xF77 + log_dim, 1 << (log_dim + log_batch))
+    d_msg = alloc.alloc(message.shape[0])
+    hal.copy_h2d(message, d_msg)
+    scratch = alloc.alloc(2 << (log_dim + log_batch + log_inv_rate))
+    challenges = oracle.random_scalars(0xC4B + log_dim, p.n_fold_rounds())
+    plan = FriPlan(hal, p, d_msg, scratch, challenges)
+    plan.run()
+    code, nodes = oracle_commit(oracle, s_ref, log_domain, p, message)
+    want_roots = [bytes(nodes[-1])]
+    cur, cur_log_len, cur_log_batch, pos = code, p.rs_log_len(), p.log_batch_size, 0
+    for k, arity in enumerate(arities):
+        chs = challenges[pos : pos + arity]
+        pos += arity
+        new_log_len = cur_log_len - (len(chs) - cur_log_batch)
+        nxt = oracle.arr(1 << new_log_len)
+        assert oracle.fri_fold(s_ref, 5, log_domain, cur_log_len, cur_log_batch, chs, cur, nxt) == 0
+        coset = 1 << (arities[k + 1] if k + 1 < len(arities) else p.n_final_challenges())
+        rc, nd = oracle.merkle_build(nxt, coset)
+        assert rc == 0
+        want_roots.append(bytes(nd[-1]))
+        cur, cur_log_len, cur_log_batch = nxt, new_log_len, 0
+    assert [bytes(r) for r in plan.roots] == want_roots
+    if arities:
+        assert np.array_equal(plan.terminate, cur)

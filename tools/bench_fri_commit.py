@@ -44,9 +44,14 @@ def run_once():
     return (t1 - t0) * 1e3, (t2 - t1) * 1e3
 
 
+from binius_amd._host import FriPlan
+plan = FriPlan(hal, p, d_msg, base.subscope_allocator().alloc(3 * n_code), challenges)
+cs = [plan.run() for _ in range(a.reps + 1)][1:]
 ts = [run_once() for _ in range(a.reps + 1)][1:]
 commit_ms = min(t[0] for t in ts); fold_ms = min(t[1] for t in ts)
 shape = "log_dim %d, log_batch %d, log_inv_rate %d, arities %s" % (a.log_dim, a.log_batch, a.log_inv_rate, p.fold_arities)
 print(json.dumps({"op": "FRI commit phase (RS encode + Merkle tree, root read back), " + shape, "ms": round(commit_ms, 3),
                   "codeword_MiB": n_code * 16 >> 20, "codeword_GBps": round(16 * n_code / commit_ms / 1e6, 1)}))
+print(json.dumps({"op": "the same through the compiled C++ mirror (bnh_fri_commit_fold)", "commit_ms": round(min(c[0] for c in cs), 3),
+                  "fold_ms": round(min(c[1] for c in cs), 3)}))
 print(json.dumps({"op": "FRI fold phase (%d rounds, %d oracles committed), " % (p.n_fold_rounds(), p.n_oracles()) + shape, "ms": round(fold_ms, 3)}))
