@@ -1,5 +1,8 @@
+#!/usr/bin/env python3
+"""Timing of the bit-sliced additive NTT across element widths and interleavings (B32 / B64 / B128 data,
+batched columns, the Reed-Solomon encoding shape).  One JSON line per shape; inputs from binius_amd.synthetic."""
 import sys, os, json
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import binius_amd
 from binius_amd import synthetic
 hal = binius_amd.Context(0, (1 << 25) + (1 << 12))

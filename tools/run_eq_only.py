@@ -1,5 +1,8 @@
+#!/usr/bin/env python3
+"""Two launches of the MLE-check round evaluation (sum a*b*eq at the points 1 and infinity) at n = 24, for
+rocprofv3 --pmc / --kernel-trace runs on k_roundeval9_eq alone."""
 import sys, os
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import binius_amd
 from binius_amd import synthetic
 from binius_amd.sumcheck import round_eval_kernel
