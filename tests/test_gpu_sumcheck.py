@@ -429,3 +429,52 @@ def test_compiled_mlecheck_prover_matches_oracle(hal, oracle, n_vars, m, comps):
     assert plan.final_evals() == want_finals
     plan.run()  # inputs (PreFold) are never modified: re-runnable
     assert plan.round_coeffs() == want_coeffs
+
+
+def test_independent_provers_share_the_gpu(oracle):
+    """Several contexts driven from their own host threads (tools/bench_concurrent.py): every prover's
+    transcript is the oracle's, whatever the interleaving of their launches."""
+    import threading
+
+    import binius_amd
+    from binius_amd._host import SumcheckPlan
+
+    n_vars, m, provers = 14, 2, 4
+    stream = oracle.random_scalars(0xC4A1, n_vars + 1)
+    batch_coeff, challenges = stream[0], stream[1:]
+    ctxs, want = [], []
+    for p in range(provers):
+        mls = [oracle.random_b128(0x5EED00 + 16 * p + j, 1 << n_vars) for j in range(m)]
+        rc, claim = oracle.inner_product(mls[0], 7, mls[1])
+        assert rc == 0
+        hal = binius_amd.Context(0, 4 << n_vars)
+        alloc = hal.dev_alloc()
+        d = []
+        for x in mls:
+            s = alloc.alloc(x.shape[0])
+            hal.copy_h2d(x, s)
+            d.append(s)
+        plan = SumcheckPlan(hal, n_vars, d, alloc.alloc(m << (n_vars - 1)), [(0, 1)], [claim], batch_coeff, challenges)
+        ctxs.append((hal, plan))
+        want.append(oracle.bivariate_sumcheck_prove([x.copy() for x in mls], n_vars, [(0, 1)], [claim], batch_coeff, challenges))
+    go = threading.Barrier(provers)
+    errors = []
+
+    def work(i):
+        try:
+            go.wait()
+            for _ in range(5):
+                ctxs[i][1].run()
+                assert ctxs[i][1].round_coeffs() == want[i][0]
+                assert ctxs[i][1].final_evals() == want[i][1]
+        except Exception as e:  # noqa: BLE001 -- reported below
+            errors.append((i, repr(e)))
+
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(provers)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    for hal, _ in ctxs:
+        hal.close()
+    assert not errors, errors
