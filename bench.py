@@ -328,29 +328,64 @@ def main():
         "kernels": per_kernel,
     }
 
-    # ---- CPU baseline: the oracle's multi-threaded port of the same loop, bounded sample, rank 0 only
+    # ---- CPU baseline, rank 0 only: the same loop (round-eval + fold every round) on the host cores.
+    # Reported value = the OPTIMIZED port (oracle/fastcpu_ref.c: arithmetic in the isomorphic POLYVAL field with
+    # PCLMULQDQ, OpenMP over all cores -- BASELINE.md section 2's "best available host ISA"), on the full
+    # workload when that takes seconds; the scalar CpuLayer-style port is timed beside it on a bounded sample.
     if rank == 0 and world == 1 and dist is None and not args.no_cpu_baseline:
-        import oracle  # the CPU port being timed (the only use of oracle/ in this file)
+        import oracle  # the CPU ports being timed (the only use of oracle/ in this file)
 
-        cores = os.cpu_count() or 1
-        cn = args.cpu_n_vars or 18
+        # host cores this process may actually use: affinity mask, capped by the cgroup CPU quota (this pool's
+        # containers see 256 logical CPUs and are granted 16; 256 spinning OpenMP threads on a 16-CPU quota
+        # run 1000x slower than 16)
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        try:
+            quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            if quota != "max":
+                cores = max(1, min(cores, int(quota) // int(period)))
+        except (OSError, ValueError):
+            pass
+        # scalar port: bounded sample
+        cn = args.cpu_n_vars or 16
         while True:
             mls = [oracle.random_b128(0xB1A50000 + j, 1 << cn) for j in range(m)]
-            rc, cclaim = oracle.inner_product(mls[0], 7, mls[1])
             c0 = time.perf_counter()
-            oracle.bivariate_sumcheck_prove(mls, cn, [(0, 1)], [cclaim], batch_coeff, challenges[:cn], threads=cores)
+            oracle.bivariate_sumcheck_prove(mls, cn, [(0, 1)], [0], batch_coeff, challenges[:cn], threads=cores)
             dt = time.perf_counter() - c0
-            if args.cpu_n_vars or dt > 4.0 or cn >= 24:
+            if args.cpu_n_vars or dt > 2.0 or cn >= 22:
                 break
-            cn += 2 if dt < 1.0 else 1
-        out["cpu_baseline"] = {
-            "value": m * (1 << cn) / dt,
-            "unit": "elems/s",
-            "cores": cores,
-            "kind": "port",
-            "sample": "same sumcheck loop (round-eval + fold every round), m=2, n_vars=%d, oracle C port, %d threads, %.2f s"
-            % (cn, cores, dt),
-        }
+            cn += 2 if dt < 0.5 else 1
+        scalar = {"value": m * (1 << cn) / dt, "n_vars": cn, "seconds": round(dt, 2)}
+        # optimized port: the workload itself (bounded at 2^26 per multilinear)
+        fn = min(n_vars, 26)
+        best = None
+        for _ in range(3):
+            mls = [oracle.random_b128(0xB1A50000 + j, 1 << fn) for j in range(m)]
+            c0 = time.perf_counter()
+            res = oracle.fast_bivariate_sumcheck_prove(mls, fn, [(0, 1)], [0], batch_coeff, challenges[:fn], threads=cores)
+            fdt = time.perf_counter() - c0
+            if res is None:
+                break
+            best = fdt if best is None else min(best, fdt)
+        if best is not None:
+            out["cpu_baseline"] = {
+                "value": m * (1 << fn) / best,
+                "unit": "elems/s",
+                "cores": cores,
+                "kind": "port",
+                "sample": "same sumcheck loop (round-eval + fold every round), m=2, n_vars=%d, optimized C port "
+                "(POLYVAL-basis PCLMULQDQ arithmetic, OpenMP, basis conversion of the inputs included), %d threads, best of 3: %.3f s"
+                % (fn, cores, best),
+                "scalar_port": {"value": scalar["value"], "sample": "scalar tower-recursion C port, n_vars=%d, %d threads, %.2f s" % (cn, cores, scalar["seconds"])},
+            }
+        else:
+            out["cpu_baseline"] = {
+                "value": scalar["value"],
+                "unit": "elems/s",
+                "cores": cores,
+                "kind": "port",
+                "sample": "same sumcheck loop, m=2, n_vars=%d, scalar C port (host without PCLMULQDQ), %d threads, %.2f s" % (cn, cores, scalar["seconds"]),
+            }
 
     if rank == 0:
         print(json.dumps(out))

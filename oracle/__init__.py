@@ -188,6 +188,10 @@ def lib():
         L.ref_groestl256_compress2.argtypes = [C.c_char_p, C.c_char_p, U8P]
         L.ref_merkle_build.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
         L.ref_merkle_root_from_branch.argtypes = [C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint32, U8P]
+        L.ref_fast_bivariate_sumcheck_prove.argtypes = [
+            C.POINTER(C.POINTER(B128)), C.c_size_t, C.c_uint, C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(B128), B128,
+            C.POINTER(B128), C.POINTER(B128), C.POINTER(B128), C.POINTER(B128), C.POINTER(B128), C.c_int,
+        ]
         L.ref_evaluate_univariate.restype = B128
         L.ref_evaluate_univariate.argtypes = [C.POINTER(B128), C.c_size_t, B128]
         _lib = L
@@ -535,3 +539,40 @@ def merkle_root_from_branch(leaf_digest, index, branch):
     out = (C.c_uint8 * 32)()
     lib().ref_merkle_root_from_branch(bytes(leaf_digest), index, b"".join(bytes(b) for b in branch), len(branch), out)
     return bytes(out)
+
+
+# ---- optimized CPU version of the sumcheck loop (oracle/fastcpu_ref.c): the cpu_baseline of bench.py
+_POLYVAL = None
+
+
+def _polyval_tables():
+    """The reference's BINARY_TO_POLYVAL_TRANSFORMATION and its inverse (crates/field/src/polyval.rs:516-784),
+    from the committed golden data."""
+    global _POLYVAL
+    if _POLYVAL is None:
+        import json
+
+        kats = json.load(open(os.path.join(os.path.dirname(_HERE), "tests", "golden", "field_kats.json")))
+        _POLYVAL = (ints_to_arr([int(x, 16) for x in kats["binary_to_polyval"]]), ints_to_arr([int(x, 16) for x in kats["polyval_to_binary"]]))
+    return _POLYVAL
+
+
+def fast_bivariate_sumcheck_prove(multilins, n_vars, comps, sums, batch_coeff, challenges, threads=1):
+    """Same transcript as bivariate_sumcheck_prove, computed in the isomorphic POLYVAL field with PCLMULQDQ
+    and OpenMP.  multilins are overwritten.  Returns None when the host has no PCLMULQDQ."""
+    fwd, inv = _polyval_tables()
+    ptrs = (C.POINTER(B128) * len(multilins))(*[_p(a) for a in multilins])
+    flat = [i for pair in comps for i in pair]
+    cc = (C.c_uint32 * max(1, len(flat)))(*flat)
+    s = ints_to_arr(list(sums)) if len(sums) else arr(1)
+    ch = ints_to_arr(list(challenges))
+    rc_out = arr(3 * n_vars)
+    fe = arr(len(multilins))
+    rc = lib().ref_fast_bivariate_sumcheck_prove(
+        ptrs, len(multilins), n_vars, cc, len(comps), _p(s), to_b128(batch_coeff), _p(ch), _p(fwd), _p(inv), _p(rc_out), _p(fe), threads
+    )
+    if rc == 2:
+        return None
+    assert rc == 0
+    co = arr_to_ints(rc_out)
+    return [co[3 * r : 3 * r + 3] for r in range(n_vars)], arr_to_ints(fe)
