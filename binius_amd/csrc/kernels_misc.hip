@@ -8,6 +8,8 @@
 // over only 2^iota bits (gf128.hpp mul_walk<iota>), so small-field matrices cost almost nothing.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "ctable.hpp"
 #include "internal.hpp"
 
@@ -96,8 +98,10 @@ __global__ __launch_bounds__(256) void k_fold(const uint64_t *mat, const uint4 *
 // vec[j] * m = XOR_p T_j[p][nibble_p(m)], T_j[p][e] = vec[j] * (e << 4p), p < 2^IOTA/4.  A chunk of
 // J = 256/P vectors' tables (64 KiB) lives in LDS; lookups are conflict-free for the same reason as
 // in ctable.hpp (one 16-entry table = one bank row, all lanes use the same (j, p)).
-template <int IOTA, bool LEFT, int R>
-__global__ __launch_bounds__(256) void k_fold_tab(const uint64_t *mat, const uint4 *vec, uint64_t vec_len, uint4 *out, uint64_t out_len)
+// TH threads per workgroup: the 80 KiB of tables allow ONE workgroup per CU, so the workgroup itself has to
+// bring the waves (256 threads = one wave per SIMD ran this kernel at a quarter of its rate)
+template <int IOTA, bool LEFT, int R, int TH>
+__global__ __launch_bounds__(TH) void k_fold_tab(const uint64_t *mat, const uint4 *vec, uint64_t vec_len, uint4 *out, uint64_t out_len)
 {
 	constexpr int P = (1 << IOTA) / 4;  // nibbles per subfield element
 	constexpr int J = 256 / P;          // vectors per LDS chunk (J * P * 256 B = 64 KiB)
@@ -106,19 +110,19 @@ __global__ __launch_bounds__(256) void k_fold_tab(const uint64_t *mat, const uin
 	uint4 *T = reinterpret_cast<uint4 *>(smem_fold);                 // [J][P][16]
 	uint4 *basis = reinterpret_cast<uint4 *>(smem_fold + 65536);     // [J][NB]
 	const unsigned tid = threadIdx.x;
-	const uint64_t tile0 = (uint64_t)blockIdx.x * 256 * R;
+	const uint64_t tile0 = (uint64_t)blockIdx.x * TH * R;
 	uint4 acc[R];
 #pragma unroll
 	for (int r = 0; r < R; r++) acc[r] = uint4{0, 0, 0, 0};
 	for (uint64_t j0 = 0; j0 < vec_len; j0 += J) {
 		const uint64_t jn = (vec_len - j0) < (uint64_t)J ? (vec_len - j0) : (uint64_t)J;
 		__syncthreads();
-		for (unsigned q = tid; q < jn * NB; q += 256) {
+		for (unsigned q = tid; q < jn * NB; q += TH) {
 			const unsigned jj = q / NB, b = q % NB;
 			basis[q] = to_u4(mul_basis(to_f128(vec[j0 + jj]), b));
 		}
 		__syncthreads();
-		for (unsigned q = tid; q < jn * P * 16; q += 256) {
+		for (unsigned q = tid; q < jn * P * 16; q += TH) {
 			const unsigned e = q & 15, p = (q >> 4) % P, jj = q / (16 * P);
 			const uint4 *bp = basis + jj * NB + 4 * p;
 			uint4 v{0, 0, 0, 0};
@@ -131,23 +135,75 @@ __global__ __launch_bounds__(256) void k_fold_tab(const uint64_t *mat, const uin
 		__syncthreads();
 #pragma unroll
 		for (int r = 0; r < R; r++) {
-			const uint64_t i = tile0 + (uint64_t)r * 256 + tid;
+			const uint64_t i = tile0 + (uint64_t)r * TH + tid;
 			if (i >= out_len) continue;
-			for (uint64_t jj = 0; jj < jn; jj++) {
-				const uint64_t idx = LEFT ? ((j0 + jj) * out_len + i) : (i * vec_len + j0 + jj);
-				const uint32_t m = (uint32_t)subfield_limb<IOTA>(mat, idx);
-				const char *tb = reinterpret_cast<const char *>(T + jj * P * 16);
+			// the matrix entries of a group are loaded before any of them is used: a load -> 8 dependent
+			// lookups -> next load chain exposes the full memory latency once per entry at 2 waves per SIMD
+			constexpr int G = J < 32 ? J : 32;
+			for (uint64_t g0 = 0; g0 < jn; g0 += G) {
+				uint32_t mm[G];
+				constexpr int EB = (1 << IOTA) / 8;  // bytes per matrix entry
+				constexpr int NU4 = G * EB / 16;      // 16-byte words per full group of a row
+				if (!LEFT && NU4 >= 1 && vec_len % G == 0 && g0 + G <= jn) {
+					// fold_right, full group: the G entries are contiguous in the thread's own row -- wide loads in
+					// one burst (every 64-byte sector fetched once) instead of G strided narrow ones
+					const uint4 *row = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(mat) + (i * vec_len + j0 + g0) * EB);
+					uint32_t w[NU4 >= 1 ? 4 * NU4 : 4];
 #pragma unroll
-				for (int p = 0; p < P; p++) {
-					const uint32_t off = ((m >> (4 * p)) & 15u) << 4;
-					acc[r] = xor4(acc[r], *reinterpret_cast<const uint4 *>(tb + p * 256 + off));
+					for (int u = 0; u < NU4; u++) {
+						const uint4 v = row[u];
+						w[4 * u] = v.x;
+						w[4 * u + 1] = v.y;
+						w[4 * u + 2] = v.z;
+						w[4 * u + 3] = v.w;
+					}
+#pragma unroll
+					for (int k = 0; k < G; k++) {
+						constexpr int PER = 4 / EB; // entries per 32-bit word
+						mm[k] = IOTA == 5 ? w[k] : ((w[k / PER] >> ((k % PER) * 8 * EB)) & ((1u << (8 * EB)) - 1u));
+					}
+				} else {
+					// entry-sized loads (fold_left: consecutive lanes read consecutive entries of row j)
+					using entry_t = std::conditional_t<IOTA == 5, uint32_t, std::conditional_t<IOTA == 4, uint16_t, uint8_t>>;
+					const entry_t *ent = reinterpret_cast<const entry_t *>(mat);
+#pragma unroll
+					for (int k = 0; k < G; k++) {
+						const uint64_t jj = g0 + k;
+						const uint64_t idx = LEFT ? ((j0 + jj) * out_len + i) : (i * vec_len + j0 + jj);
+						mm[k] = jj < jn ? (uint32_t)ent[idx] : 0u;
+					}
+				}
+				// lookups in groups of 16, all issued before any is consumed (otherwise every ds_read_b128 is
+				// followed by its own s_waitcnt: one LDS round trip per lookup)
+				constexpr int KG = 16 / P > 0 ? 16 / P : 1; // entries per lookup group
+#pragma unroll
+				for (int k = 0; k < G; k += KG) {
+					if (g0 + k >= jn) break;
+					uint4 t[KG * P];
+#pragma unroll
+					for (int kk = 0; kk < KG; kk++) {
+						const bool on = g0 + k + kk < jn; // (beyond the chunk: entry 0 of table 0, masked below)
+						const char *tb = reinterpret_cast<const char *>(T + (on ? (g0 + k + kk) : 0) * P * 16);
+#pragma unroll
+						for (int p = 0; p < P; p++) {
+							const uint32_t off = ((mm[k + kk] >> (4 * p)) & 15u) << 4;
+							t[kk * P + p] = *reinterpret_cast<const uint4 *>(tb + p * 256 + off);
+						}
+					}
+					__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+					for (int kk = 0; kk < KG; kk++) {
+						if (g0 + k + kk >= jn) break; // (mm = 0 there anyway, but table 0's entry 0 is vec * 0 = 0 too)
+#pragma unroll
+						for (int p = 0; p < P; p++) acc[r] = xor4(acc[r], t[kk * P + p]);
+					}
 				}
 			}
 		}
 	}
 #pragma unroll
 	for (int r = 0; r < R; r++) {
-		const uint64_t i = tile0 + (uint64_t)r * 256 + tid;
+		const uint64_t i = tile0 + (uint64_t)r * TH + tid;
 		if (i < out_len) out[i] = acc[r];
 	}
 }
@@ -155,13 +211,13 @@ __global__ __launch_bounds__(256) void k_fold_tab(const uint64_t *mat, const uin
 template <int IOTA, bool LEFT>
 static hipError_t run_fold_tab(hipStream_t s, const void *mat, const void *vec, uint64_t vec_len, void *out, uint64_t out_len)
 {
-	constexpr int R = 4;
+	constexpr int R = 1, TH = 1024;
 	constexpr int NB = 1 << IOTA, P = NB / 4, J = 256 / P;
 	const size_t lds = 65536 + (size_t)J * NB * 16;
-	const uint64_t blocks = (out_len + 256 * R - 1) / (256 * R);
-	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fold_tab<IOTA, LEFT, R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+	const uint64_t blocks = (out_len + TH * R - 1) / (TH * R);
+	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fold_tab<IOTA, LEFT, R, TH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 	if (e != hipSuccess) return e;
-	hipLaunchKernelGGL((k_fold_tab<IOTA, LEFT, R>), dim3((unsigned)blocks), dim3(256), lds, s, (const uint64_t *)mat, (const uint4 *)vec, vec_len,
+	hipLaunchKernelGGL((k_fold_tab<IOTA, LEFT, R, TH>), dim3((unsigned)blocks), dim3(TH), lds, s, (const uint64_t *)mat, (const uint4 *)vec, vec_len,
 	                   (uint4 *)out, out_len);
 	return hipGetLastError();
 }
