@@ -290,6 +290,24 @@ def main():
             roofline["traffic_source"] = "profiles/r01/bench_n24_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; bytes per launch)"
     except (OSError, KeyError, ValueError):
         pass
+    # the streaming ceiling this box reaches: a device-to-device copy of one multilinear (read + write), next to
+    # the 8 TB/s spec the fractions above are quoted against (report both)
+    try:
+        cp_src, cp_dst = d_in[0], scratch.slice(0, min(scratch.len, d_in[0].len))
+        cp_n = cp_dst.len
+        best = None
+        for _ in range(4):
+            hal.sync()
+            hal.timer_begin()
+            hal.copy_d2d(cp_src.slice(0, cp_n), cp_dst)
+            ms_cp = hal.timer_end_ms()
+            best = ms_cp if best is None else min(best, ms_cp)
+        copy_gbs = 2 * 16 * cp_n / (best * 1e-3) / 1e9
+        roofline["measured_copy_GBps"] = round(copy_gbs, 1)
+        roofline["frac_of_measured_copy"] = round(achieved / copy_gbs, 4) if copy_gbs > 0 else None
+    except Exception as ex:  # noqa: BLE001 -- the ceiling is a side measurement
+        roofline["measured_copy_GBps"] = None
+        print("[bench] copy ceiling not measured: %r" % (ex,), file=sys.stderr)
     per_kernel = {
         k: {
             "GBps": round(v[0] / (v[1] * 1e-3) / 1e9, 2) if v[1] > 0 else None,
@@ -367,6 +385,14 @@ def main():
             if res is None:
                 break
             best = fdt if best is None else min(best, fdt)
+        single = None
+        if best is not None:
+            # one thread, the analogue of RAYON_NUM_THREADS=1 (scripts/run_benchmark.py:211), on 2^22 per multilinear
+            sn = min(n_vars, 22)
+            mls = [oracle.random_b128(0xB1A50000 + j, 1 << sn) for j in range(m)]
+            c0 = time.perf_counter()
+            oracle.fast_bivariate_sumcheck_prove(mls, sn, [(0, 1)], [0], batch_coeff, challenges[:sn], threads=1)
+            single = {"value": m * (1 << sn) / (time.perf_counter() - c0), "n_vars": sn}
         if best is not None:
             out["cpu_baseline"] = {
                 "value": m * (1 << fn) / best,
@@ -376,6 +402,7 @@ def main():
                 "sample": "same sumcheck loop (round-eval + fold every round), m=2, n_vars=%d, optimized C port "
                 "(POLYVAL-basis PCLMULQDQ arithmetic, OpenMP, basis conversion of the inputs included), %d threads, best of 3: %.3f s"
                 % (fn, cores, best),
+                "single_thread": single,
                 "scalar_port": {"value": scalar["value"], "sample": "scalar tower-recursion C port, n_vars=%d, %d threads, %.2f s" % (cn, cores, scalar["seconds"])},
             }
         else:
