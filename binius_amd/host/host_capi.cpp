@@ -168,8 +168,12 @@ int bnh_shm_allgather(void *hv, const uint64_t *in, uint32_t n_words, uint64_t *
 		shm_slot &s = h->base[2 * w + (r & 1)];
 		uint64_t spins = 0;
 		while (s.seq.load(std::memory_order_acquire) != r) {
-			if (++spins > (1ull << 22)) {
-				// slow path: yield, and give up after ~20 s (a rank died)
+			++spins;
+			// a rank that is late by more than ~0.1 ms is probably not running (more ranks than granted host
+			// CPUs): give the core away between looks instead of burning the quota
+			if (spins > (1ull << 14) && (spins & 1023) == 0) std::this_thread::yield();
+			if (spins > (1ull << 22)) {
+				// slow path: yield every time, and give up after ~20 s (a rank died)
 				std::this_thread::yield();
 				if (spins > (1ull << 22) + 20000000ull) return (g_err = "shm exchange timed out waiting for a rank", BN_ERR_DEVICE);
 			}
