@@ -9,6 +9,7 @@
 #include <string>
 #include <vector>
 
+#include "../../binius_amd/host/callers.hpp"
 #include "../../binius_amd/host/fri.hpp"
 #include "../../binius_amd/host/merkle.hpp"
 #include "../../binius_amd/host/sumcheck.hpp"
@@ -595,6 +596,58 @@ static void test_fri_commit_fold_query(Env &e)
 	CHECK(threw);
 }
 
+// crates/core/src/protocols/prodcheck/prove.rs:24-77 and crates/core/src/ring_switch/eq_ind.rs:123-141
+// (compute_test_utils/src/ring_switch.rs) against the oracle's element-wise product, tensor_expand, fold_right
+static void test_prodcheck_and_ring_switch_callers(Env &e)
+{
+	{
+		ComputeData d = e.holder.to_data();
+		const size_t log_n = 9;
+		auto evals = random_vec(0x9C0D, (size_t)1 << log_n);
+		FSliceMut dv = d.dev_alloc.alloc(evals.size());
+		d.hal->copy_h2d(evals, dv);
+		ProductCircuitLayers pcl = ProductCircuitLayers::compute(C(dv), *d.hal, d.dev_alloc);
+		CHECK(pcl.layers().size() == log_n);
+		std::vector<B128> cur = evals;
+		std::vector<std::vector<B128>> want;
+		for (size_t i = 0; i < log_n; i++) {
+			want.push_back(cur);
+			const size_t half = cur.size() / 2;
+			std::vector<B128> nxt(half);
+			ref_b128_mul_vec(R(cur), R(cur) + half, R(nxt), half);
+			cur = nxt;
+		}
+		for (size_t i = 0; i < log_n; i++) {
+			const auto &w = want[log_n - 1 - i];
+			CHECK(pcl.layers()[i].len() == w.size());
+			std::vector<B128> got(w.size());
+			d.hal->copy_d2h(pcl.layers()[i], got);
+			CHECK(got == w);
+		}
+		CHECK(pcl.product() == cur[0]);
+	}
+	for (size_t kappa : {(size_t)2, (size_t)4, (size_t)7}) {
+		ComputeData d = e.holder.to_data();
+		const size_t n_vars = 9;
+		auto z_vals = random_vec(0x515 + kappa, n_vars);
+		auto coeffs = random_vec(0x516 + kappa, (size_t)1 << kappa);
+		const B128 mixing = random_vec(0x517, 1)[0];
+		RingSwitchEqInd rs(z_vals, coeffs, mixing, kappa);
+		auto pre = rs.precompute_values(*d.hal, d.dev_alloc);
+		FSlice mle{};
+		d.hal->execute([&](ComputeLayerExecutor &exec) {
+			mle = rs.multilinear_extension(pre, exec);
+			return std::vector<B128>{};
+		});
+		std::vector<B128> got((size_t)1 << n_vars), ev((size_t)1 << n_vars), want((size_t)1 << n_vars);
+		d.hal->copy_d2h(mle, got);
+		ev[0] = mixing;
+		CHECK(ref_tensor_expand(R(ev), ev.size(), 0, R(z_vals), n_vars, 1) == 0);
+		CHECK(ref_fold_right(R(ev), ev.size(), (int)(7 - kappa), R(coeffs), coeffs.size(), R(want), want.size()) == 0);
+		CHECK(got == want);
+	}
+}
+
 int main()
 {
 	struct T {
@@ -620,6 +673,7 @@ int main()
 	    {"test_additive_ntt", test_ntt},
 	    {"test_binary_merkle_vcs_commit_prove_open_correctly", test_binary_merkle_vcs},
 	    {"test_fri_commit_fold_query_device_resident", test_fri_commit_fold_query},
+	    {"test_prodcheck_layers_and_ring_switch_eq_ind", test_prodcheck_and_ring_switch_callers},
 	};
 	int failed = 0;
 	try {
