@@ -677,7 +677,10 @@ int bn_inner_product(bn_ctx *ctx, const void *d_a, uint64_t a_len, uint32_t towe
 	BN_HIP(hipMemsetAsync(ctx->d_result, 0, 2 * sizeof(f128), ctx->stream));
 	if (tower_level == 7 && b_len >= 2 && (b_len & 1) == 0) {
 		// F x F: a plain sum of products -> the bit-sliced product-sum kernel (two half-range streams)
-		BN_HIP(bn::launch_roundeval9_split(ctx->stream, ctx->n_cu, d_a, d_b, b_len / 2, b_len / 2, ctx->d_result));
+		if (bn::mfma_applies(ctx->n_cu, b_len / 2))
+			BN_HIP(bn::launch_roundeval_mfma_split(ctx->stream, ctx->n_cu, d_a, d_b, b_len / 2, b_len / 2, ctx->d_result));
+		else
+			BN_HIP(bn::launch_roundeval9_split(ctx->stream, ctx->n_cu, d_a, d_b, b_len / 2, b_len / 2, ctx->d_result));
 		return publish_result(ctx, 2, h_out);
 	}
 	if (tower_level == 5 && b_len >= 8192 && b_len % 512 == 0) {
@@ -1211,8 +1214,10 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 										}
 										// (c) one fused kernel for this round
 										if (fe == hipErrorNotSupported) {
-											prof_scope ps(ctx, bn::foldeval9_is_small(ctx->n_cu, n_in) ? BN_PROF_FOLD_EVAL_SMALL : BN_PROF_FOLD_EVAL);
-											fe = bn::launch_foldeval9(s, ctx->n_cu, fa, n_in, pf.z, d_S + slot, &fz);
+											const bool mfma = bn::mfma_applies(ctx->n_cu, n_in >> 2);
+											prof_scope ps(ctx, !mfma && bn::foldeval9_is_small(ctx->n_cu, n_in) ? BN_PROF_FOLD_EVAL_SMALL : BN_PROF_FOLD_EVAL);
+											fe = mfma ? bn::launch_foldeval_mfma(s, ctx->n_cu, fa, n_in, pf.z, d_S + slot, &fz)
+											          : bn::launch_foldeval9(s, ctx->n_cu, fa, n_in, pf.z, d_S + slot, &fz);
 											if (fe == hipSuccess) ctx->pend.active = false;
 										}
 									} else if (ctx->tail.active) {

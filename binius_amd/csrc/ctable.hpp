@@ -138,4 +138,58 @@ __device__ __forceinline__ uint4 ctable_mul(const ctable_smem &s, uint4 x)
 	return acc;
 }
 
+// Same product with the lookup schedule pinned by compiler barriers: groups of G lookups, group g + 1
+// requested before group g is folded in, nothing else in flight.  ctable_mul leaves the placement of the
+// reads to the scheduler, which (when the surrounding kernel leaves it head-room) hoists all 32 reads of
+// an element -- and of the next elements -- to the front and spills hundreds of registers; the kernels
+// that also hold MFMA accumulators cannot afford that.
+template <int G = 4>
+__device__ __forceinline__ uint4 ctable_mul_pinned(const ctable_smem &s, uint4 x)
+{
+	static_assert(G == 4 || G == 8, "half a word or one word of lookups per group");
+	const char *base = reinterpret_cast<const char *>(s.T);
+	const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+	const uint32_t m = 0xF0u;
+	uint32_t off[32];
+#pragma unroll
+	for (int wq = 0; wq < 4; wq++) {
+		const uint32_t hi = w[wq];
+		const uint32_t lo = __builtin_amdgcn_alignbit(hi, hi, 28); // rotl(w, 4)
+		off[8 * wq + 0] = byte_and<0>(lo, m);
+		off[8 * wq + 1] = byte_and<0>(hi, m);
+		off[8 * wq + 2] = byte_and<1>(lo, m);
+		off[8 * wq + 3] = byte_and<1>(hi, m);
+		off[8 * wq + 4] = byte_and<2>(lo, m);
+		off[8 * wq + 5] = byte_and<2>(hi, m);
+		off[8 * wq + 6] = byte_and<3>(lo, m);
+		off[8 * wq + 7] = byte_and<3>(hi, m);
+	}
+	uint4 acc{0, 0, 0, 0};
+	uint4 cur[G], nxt[G];
+#pragma unroll
+	for (int j = 0; j < G; j++)
+		cur[j] = *reinterpret_cast<const uint4 *>(base + j * 256 + off[j]);
+#pragma unroll
+	for (int g0 = 0; g0 < 32; g0 += G) {
+		if (g0 + G < 32) {
+#pragma unroll
+			for (int j = 0; j < G; j++)
+				nxt[j] = *reinterpret_cast<const uint4 *>(base + (g0 + G + j) * 256 + off[g0 + G + j]);
+		}
+		asm volatile("" ::: "memory");
+#pragma unroll
+		for (int j = 0; j < G; j += 2) {
+			acc.x = ct_xor3(acc.x, cur[j].x, cur[j + 1].x);
+			acc.y = ct_xor3(acc.y, cur[j].y, cur[j + 1].y);
+			acc.z = ct_xor3(acc.z, cur[j].z, cur[j + 1].z);
+			acc.w = ct_xor3(acc.w, cur[j].w, cur[j + 1].w);
+		}
+		asm volatile("" : "+v"(acc.x), "+v"(acc.y), "+v"(acc.z), "+v"(acc.w)::"memory");
+#pragma unroll
+		for (int j = 0; j < G; j++)
+			cur[j] = nxt[j];
+	}
+	return acc;
+}
+
 } // namespace bn

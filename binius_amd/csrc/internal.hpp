@@ -188,6 +188,15 @@ hipError_t launch_roundeval9_eq(hipStream_t s, int n_cu, const void *a_hi, const
 hipError_t launch_roundeval9_split(hipStream_t s, int n_cu, const void *a, const void *b, uint64_t n, uint64_t split_off,
                                    f128 *d_out);
 
+// ---- kernels_roundeval_mfma.hip / kernels_foldeval_mfma.hip: the same three jobs with the products on the
+// matrix cores (gram.hpp).  mfma_applies(): enough points to fill the chip with 256-point tiles (the
+// 9-lane VALU kernels keep the small, latency-shaped rounds); BN_EVAL=valu forces the VALU kernels.
+bool mfma_applies(int n_cu, uint64_t n_points);
+hipError_t launch_roundeval_mfma_pair(hipStream_t s, int n_cu, const void *a_hi, const void *a_lo, const void *b_hi, const void *b_lo,
+                                      uint64_t n, f128 *d_out, const fin_fuse *fuse);
+hipError_t launch_roundeval_mfma_split(hipStream_t s, int n_cu, const void *a, const void *b, uint64_t n, uint64_t split_off, f128 *d_out);
+hipError_t launch_foldeval_mfma(hipStream_t s, int n_cu, const foldeval_args &fa, uint64_t n_in, f128 z, f128 *d_out, const fin_fuse *fuse);
+
 // ---- kernels_misc.hip
 hipError_t launch_inner_product(hipStream_t s, int n_cu, const void *a, uint32_t tower_level, const void *b,
                                 uint64_t b_len, f128 *d_out);

@@ -1,0 +1,140 @@
+// binius_amd/csrc/kernels_foldeval_mfma.hip -- fold of round r and round evaluation of round r+1 in ONE
+// pass over the data, the evaluation on the matrix cores (gram.hpp):
+//
+//   a'[i] = a[i] + z*(a[i + N/2] - a[i])        i < N/2        (extrapolate_line, layer.rs:421)
+//   S_1   = sum_{j < N/4} a'[j + N/4] * b'[j + N/4]
+//   S_inf = sum_{j < N/4} (a'[j] + a'[j + N/4]) * (b'[j] + b'[j + N/4])
+//                                                (v3/bivariate_product.rs:217-228 then :303-408)
+//
+// Same contract as kernels_foldeval9.hip (which keeps the small rounds): the ABI defers the fold and,
+// when the next kernel launch evaluates exactly the folded arrays, runs this kernel instead of two.
+// Algorithmic bytes: read 16*m*N + write 8*m*N = 24*m*N per launch.
+//
+// Workgroup = 4 waves, two workgroups per CU.  Per tile of 256 evaluation points a lane folds the four
+// elements of ONE point (array x half): 16-byte coalesced loads (prefetched one tile ahead), the
+// constant multiplication through the LDS nibble tables (ctable.hpp), a 16-byte coalesced store of the
+// folded element (it is the next round's input), and the quad byte transposes that turn the folded
+// registers into the point's Gram-tile words (stage_T) -- the folded values never take a second trip
+// through memory.  The Gram k-steps of the PREVIOUS tile are issued between the four constant
+// multiplications: matrix pipe and VALU/LDS work side by side; one workgroup barrier per tile.
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+#include "ctable.hpp"
+#include "gram.hpp"
+
+namespace bn {
+
+using namespace gram;
+
+__global__ __launch_bounds__(256, 2) void k_foldeval_mfma(foldeval_args fa, uint64_t n_in, f128 z, f128 *out, fin_fuse fz)
+{
+	__shared__ __attribute__((aligned(16))) uint32_t T[2][kTileW];
+	__shared__ ctable_smem tab;
+	const unsigned lane = threadIdx.x & 63;
+	const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const stage_role sr = make_stage_role(wave, lane);
+	const gram_role gr = make_gram_role(wave, lane);
+	const uint64_t n = n_in >> 2; // evaluation points of the next round
+	const uint64_t n_tiles = (n + kTP - 1) / kTP;
+
+	v16i acc[kAccTiles];
+	acc_zero(acc);
+
+	// quadrant k = 2 * array + half: element index half * n + point
+	uint4 x0[4], x1[4];
+	// (a lane past the end loads element 0 of the quadrant: its fold result is zeroed before use, so
+	// nothing depends on the loaded value until the constant multiplication consumes it)
+	auto load1 = [&](uint64_t t, int k) {
+		const uint64_t pt = t * kTP + threadIdx.x;
+		const uint64_t e = (k & 1 ? n : 0) + (pt < n ? pt : 0);
+		x0[k] = ((const uint4 *)fa.x0[k >> 1])[e];
+		x1[k] = ((const uint4 *)fa.x1[k >> 1])[e];
+	};
+	auto load = [&](uint64_t t) {
+#pragma unroll
+		for (int k = 0; k < 4; k++)
+			load1(t, k);
+	};
+	uint64_t t = blockIdx.x;
+	if (t < n_tiles) load(t);
+	ctable_build(tab, z); // the loads above are in flight meanwhile; ends with a barrier
+
+	// One iteration: fold tile tt (VALU + LDS lookups) with, when GRAM, the Gram k-steps of the previous
+	// tile (in Tp) between the four constant multiplications (matrix pipe); the folded registers go to HBM
+	// and, byte-transposed, into the Gram tile Tn.
+	auto iteration = [&](uint64_t tt, const uint32_t *Tp, uint32_t *Tn, auto with_gram) {
+		constexpr bool GRAM = decltype(with_gram)::value;
+		const uint64_t pt = tt * kTP + threadIdx.x;
+		const bool ok = pt < n;
+		// the last iteration re-requests its own tile (cache hits) instead of branching around the loads
+		const uint64_t tn = tt + gridDim.x < n_tiles ? tt + gridDim.x : tt;
+		gram_pipe gp;
+		uint4 f[4];
+		if (GRAM) gram_begin(Tp, gr, gp);
+		f[0] = xor4(x0[0], ctable_mul_pinned<4>(tab, xor4(x0[0], x1[0])));
+		load1(tn, 0); // this quadrant of the next tile flies from here on
+		if (GRAM) {
+			gram_step<0>(Tp, gr, gp, acc);
+			gram_step<1>(Tp, gr, gp, acc);
+		}
+		f[1] = xor4(x0[1], ctable_mul_pinned<4>(tab, xor4(x0[1], x1[1])));
+		load1(tn, 1); // this quadrant of the next tile flies from here on
+		if (GRAM) {
+			gram_step<2>(Tp, gr, gp, acc);
+			gram_step<3>(Tp, gr, gp, acc);
+		}
+		f[2] = xor4(x0[2], ctable_mul_pinned<4>(tab, xor4(x0[2], x1[2])));
+		load1(tn, 2); // this quadrant of the next tile flies from here on
+		if (GRAM) {
+			gram_step<4>(Tp, gr, gp, acc);
+			gram_step<5>(Tp, gr, gp, acc);
+		}
+		f[3] = xor4(x0[3], ctable_mul_pinned<4>(tab, xor4(x0[3], x1[3])));
+		load1(tn, 3); // this quadrant of the next tile flies from here on
+		if (GRAM) {
+			gram_step<6>(Tp, gr, gp, acc);
+			gram_step<7>(Tp, gr, gp, acc);
+		}
+		if (ok) {
+#pragma unroll
+			for (int k = 0; k < 4; k++)
+				((uint4 *)fa.out[k >> 1])[(k & 1 ? n : 0) + pt] = f[k];
+		} else {
+#pragma unroll
+			for (int k = 0; k < 4; k++)
+				f[k] = uint4{0, 0, 0, 0};
+		}
+		// quadrant 2 * array + half: half 1 is the evaluation at 1, half 0 its partner; points past the
+		// end carry zeros
+		stage_T<true>(Tn, sr, 0, f[1], f[0]);
+		stage_T<true>(Tn, sr, 1, f[3], f[2]);
+		__syncthreads();
+	};
+	if (t < n_tiles) {
+		unsigned buf = 0;
+		iteration(t, T[1], T[0], std::false_type{});
+		for (t += gridDim.x; t < n_tiles; t += gridDim.x) {
+			iteration(t, T[buf], T[buf ^ 1], std::true_type{});
+			buf ^= 1;
+		}
+		gram_tile(T[buf], gr, acc);
+	}
+	gram::tail(acc, wave, lane, out, fz, fz.args.seq);
+}
+
+// For both arrays j: out_j[i] = x0_j[i] + z * (x1_j[i] - x0_j[i]), i < n_in/2 (out_j may be x0_j), and
+// accumulate the next round's (S_1, S_inf) of out_0 * out_1 into d_out[0], d_out[1].  n_in >= 4.
+hipError_t launch_foldeval_mfma(hipStream_t s, int n_cu, const foldeval_args &fa, uint64_t n_in, f128 z, f128 *d_out, const fin_fuse *fuse)
+{
+	if (n_in < 4 || (n_in & 3)) return hipErrorNotSupported;
+	fin_fuse fz{};
+	if (fuse) fz = *fuse;
+	const uint64_t n_tiles = ((n_in >> 2) + kTP - 1) / kTP;
+	const uint64_t cap = (uint64_t)n_cu * 2;
+	hipLaunchKernelGGL(k_foldeval_mfma, dim3((unsigned)(n_tiles < cap ? n_tiles : cap)), dim3(256), 0, s, fa, n_in, z, d_out, fz);
+	return hipGetLastError();
+}
+
+} // namespace bn

@@ -191,8 +191,10 @@ static unsigned prodsum_grid(uint64_t n, int n_cu)
 hipError_t launch_roundeval_product(hipStream_t s, int n_cu, const void *const *hi, const void *const *lo, uint32_t k,
                                     uint64_t n, f128 *d_out, const fin_fuse *fuse)
 {
-	if (k == 2 && lo[0] && lo[1])
+	if (k == 2 && lo[0] && lo[1]) {
+		if (mfma_applies(n_cu, n)) return launch_roundeval_mfma_pair(s, n_cu, hi[0], lo[0], hi[1], lo[1], n, d_out, fuse);
 		return launch_roundeval9_pair(s, n_cu, hi[0], lo[0], hi[1], lo[1], n, d_out, fuse);
+	}
 	if (k == 3) {
 		// a * b * eq (MLE-check): exactly one factor is the same at both evaluation points
 		int same = -1, n_same = 0;
@@ -224,8 +226,10 @@ hipError_t launch_roundeval_product(hipStream_t s, int n_cu, const void *const *
 hipError_t launch_sum_product(hipStream_t s, int n_cu, const void *const *rows, uint32_t n_rows, uint64_t row_len,
                               f128 *d_out)
 {
-	if (n_rows == 2 && row_len >= 2 && (row_len & 1) == 0)
+	if (n_rows == 2 && row_len >= 2 && (row_len & 1) == 0) {
+		if (mfma_applies(n_cu, row_len / 2)) return launch_roundeval_mfma_split(s, n_cu, rows[0], rows[1], row_len / 2, row_len / 2, d_out);
 		return launch_roundeval9_split(s, n_cu, rows[0], rows[1], row_len / 2, row_len / 2, d_out);
+	}
 	bs_job job{};
 	job.k = n_rows;
 	if (row_len >= 2) {

@@ -1,0 +1,125 @@
+// binius_amd/csrc/kernels_roundeval_mfma.hip -- round evaluation of the bivariate product on the matrix
+// cores (gram.hpp):
+//   S_1 = sum_i a_hi[i]*b_hi[i],   S_inf = sum_i (a_lo[i]+a_hi[i])*(b_lo[i]+b_hi[i])
+// (crates/core/src/protocols/sumcheck/v3/bivariate_product.rs:303-408), one pass over the data; the
+// SPLIT form computes two plain sums of products (inner_product / sum-of-products compositions).
+//
+// Workgroup = 4 waves, two workgroups per CU (two waves per SIMD; the workgroups drift apart, so one
+// stages while the other multiplies).  Per tile of 256 points a lane loads the four elements of ONE point
+// (a_hi, a_lo, b_hi, b_lo: 16-byte coalesced loads, the next tile's elements fly while this tile is
+// multiplied), byte-transposes them across its quad into the LDS tile (stage_T), and after the barrier
+// its wave runs the Gram k-steps of its (product, column half).
+// Algorithmic bytes: 16*m*n per launch (m = 2 arrays, n points), read once.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+
+#include "gram.hpp"
+
+namespace bn {
+
+using namespace gram;
+
+template <bool SPLIT>
+__global__ __launch_bounds__(256, 2) void k_roundeval_mfma(const uint4 *__restrict__ a_hi, const uint4 *__restrict__ a_lo,
+                                                           const uint4 *__restrict__ b_hi, const uint4 *__restrict__ b_lo, uint64_t n,
+                                                           f128 *out, fin_fuse fz)
+{
+	__shared__ __attribute__((aligned(16))) uint32_t T[2][kTileW];
+	const unsigned lane = threadIdx.x & 63;
+	const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const stage_role sr = make_stage_role(wave, lane);
+	const gram_role gr = make_gram_role(wave, lane);
+
+	v16i acc[kAccTiles];
+	acc_zero(acc);
+
+	const uint64_t n_tiles = (n + kTP - 1) / kTP;
+	uint4 x[4]; // a_hi, a_lo, b_hi, b_lo of this lane's point
+	// a lane past the end loads element 0 and zeroes it when the tile is staged: nothing depends on a
+	// loaded value before then, so the loads stay in flight across the Gram k-steps
+	auto load = [&](uint64_t t) {
+		const uint64_t pt = t * kTP + threadIdx.x;
+		const uint64_t e = pt < n ? pt : 0;
+		x[0] = a_hi[e];
+		x[1] = a_lo[e];
+		x[2] = b_hi[e];
+		x[3] = b_lo[e];
+	};
+	auto stage = [&](uint64_t t, uint32_t *Tb) {
+		if (t * kTP + threadIdx.x >= n) {
+#pragma unroll
+			for (int k = 0; k < 4; k++)
+				x[k] = uint4{0, 0, 0, 0};
+		}
+		stage_T<!SPLIT>(Tb, sr, 0, x[0], x[1]);
+		stage_T<!SPLIT>(Tb, sr, 1, x[2], x[3]);
+	};
+
+	uint64_t t = blockIdx.x;
+	unsigned buf = 0;
+	if (t < n_tiles) {
+		load(t);
+		stage(t, T[0]);
+	}
+	__syncthreads();
+	for (; t < n_tiles; t += gridDim.x) {
+		const uint64_t tn = t + gridDim.x;
+		if (tn < n_tiles) load(tn);
+		gram_tile(T[buf], gr, acc);
+		if (tn < n_tiles) stage(tn, T[buf ^ 1]);
+		__syncthreads();
+		buf ^= 1;
+	}
+	gram::tail(acc, wave, lane, out, fz, fz.args.seq);
+}
+
+bool mfma_applies(int n_cu, uint64_t n_points)
+{
+	// BN_EVAL=valu: 9-lane VALU kernels only; BN_MFMA_MIN_TILES: tiles from which the matrix-core kernels run
+	static const int64_t min_tiles = [] {
+		const char *m = getenv("BN_EVAL");
+		if (m && m[0] == 'v') return (int64_t)-1;
+		const char *e = getenv("BN_MFMA_MIN_TILES");
+		return e ? (int64_t)atoll(e) : (int64_t)0;
+	}();
+	if (min_tiles < 0) return false;
+	const uint64_t n_tiles = (n_points + kTP - 1) / kTP;
+	return n_tiles >= (min_tiles ? (uint64_t)min_tiles : (uint64_t)n_cu * 2);
+}
+
+static unsigned grid_mfma(uint64_t n, int n_cu)
+{
+	const uint64_t n_tiles = (n + kTP - 1) / kTP;
+	const uint64_t cap = (uint64_t)n_cu * 2;
+	return (unsigned)(n_tiles < cap ? (n_tiles ? n_tiles : 1) : cap);
+}
+
+template <bool SPLIT>
+static hipError_t launch_mfma(hipStream_t s, int n_cu, const void *a_hi, const void *a_lo, const void *b_hi, const void *b_lo, uint64_t n,
+                              f128 *d_out, const fin_fuse *fuse)
+{
+	fin_fuse fz{};
+	if (fuse) fz = *fuse;
+	if (n == 0 && fuse) return hipErrorNotSupported; // nothing to launch: the caller finalizes separately
+	if (n == 0) return hipSuccess;
+	hipLaunchKernelGGL((k_roundeval_mfma<SPLIT>), dim3(grid_mfma(n, n_cu)), dim3(256), 0, s, (const uint4 *)a_hi, (const uint4 *)a_lo,
+	                   (const uint4 *)b_hi, (const uint4 *)b_lo, n, d_out, fz);
+	return hipGetLastError();
+}
+
+// d_out[0] ^= sum_i a_hi[i]*b_hi[i] ; d_out[1] ^= sum_i (a_lo[i]^a_hi[i])*(b_lo[i]^b_hi[i])
+hipError_t launch_roundeval_mfma_pair(hipStream_t s, int n_cu, const void *a_hi, const void *a_lo, const void *b_hi, const void *b_lo,
+                                      uint64_t n, f128 *d_out, const fin_fuse *fuse)
+{
+	return launch_mfma<false>(s, n_cu, a_hi, a_lo, b_hi, b_lo, n, d_out, fuse);
+}
+
+// d_out[0] ^= sum_{i<n} a[i]*b[i] ; d_out[1] ^= sum_{i<n} a[i+split]*b[i+split]
+hipError_t launch_roundeval_mfma_split(hipStream_t s, int n_cu, const void *a, const void *b, uint64_t n, uint64_t split_off, f128 *d_out)
+{
+	const char *a2 = (const char *)a + split_off * 16, *b2 = (const char *)b + split_off * 16;
+	return launch_mfma<true>(s, n_cu, a, a2, b, b2, n, d_out, nullptr);
+}
+
+} // namespace bn

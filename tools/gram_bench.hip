@@ -1,0 +1,131 @@
+// tools/gram_bench.hip -- stand-alone check + timing of the matrix-core round-evaluation kernels
+// (kernels_roundeval_mfma.hip) against a host bilinear-walk product.
+// Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -Ibinius_amd/csrc -Iinclude tools/gram_bench.hip -o tools/gram_bench
+#include "../binius_amd/csrc/kernels_roundeval_mfma.hip"
+#include "../binius_amd/csrc/kernels_foldeval_mfma.hip"
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+using namespace bn;
+
+static uint64_t sm64(uint64_t &s)
+{
+	uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+	z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+	return z ^ (z >> 31);
+}
+
+int main(int argc, char **argv)
+{
+	const int log_n = argc > 1 ? atoi(argv[1]) : 24;
+	const uint64_t n = 1ull << log_n;
+	std::vector<f128> h[4];
+	uint64_t seed = 1234;
+	f128 *d[4];
+	const uint64_t n_host = n < (1ull << 18) ? n : (1ull << 18);
+	for (int k = 0; k < 4; k++) {
+		h[k].resize(n_host);
+		for (uint64_t i = 0; i < n_host; i++) h[k][i] = f128{sm64(seed), sm64(seed)};
+		(void)hipMalloc(&d[k], n * 16);
+		for (uint64_t off = 0; off < n; off += n_host) // repeat the host block
+			(void)hipMemcpy(d[k] + off, h[k].data(), n_host * 16, hipMemcpyHostToDevice);
+	}
+	f128 *d_out;
+	(void)hipMalloc(&d_out, 32);
+	int bad = 0;
+	const bool prof = argc > 2; // profile mode: one launch of each kernel at full size, nothing else
+	for (uint64_t nc : {1ull, 5ull, 255ull, 256ull, 257ull, 1000ull, 4096ull, 70001ull, 1ull << 17}) {
+		if (nc > n_host || prof) continue;
+		(void)hipMemset(d_out, 0, 32);
+		hipError_t e = launch_roundeval_mfma_pair(0, 256, d[0], d[1], d[2], d[3], nc, d_out, nullptr);
+		f128 got[2];
+		(void)hipMemcpy(got, d_out, 32, hipMemcpyDeviceToHost);
+		f128 e1 = f128_zero(), ei = f128_zero();
+		for (uint64_t i = 0; i < nc; i++) {
+			e1 ^= mul_slow(h[0][i], h[2][i]);
+			ei ^= mul_slow(h[0][i] ^ h[1][i], h[2][i] ^ h[3][i]);
+		}
+		const bool ok = got[0] == e1 && got[1] == ei && e == hipSuccess;
+		bad += !ok;
+		printf("pair  n=%llu: %s\n", (unsigned long long)nc, ok ? "OK" : "MISMATCH");
+		// split: sums over [0,nc/2) and [nc/2, nc/2*2)
+		const uint64_t hn = nc / 2;
+		if (hn) {
+			(void)hipMemset(d_out, 0, 32);
+			e = launch_roundeval_mfma_split(0, 256, d[0], d[2], hn, hn, d_out);
+			(void)hipMemcpy(got, d_out, 32, hipMemcpyDeviceToHost);
+			f128 s0 = f128_zero(), s1 = f128_zero();
+			for (uint64_t i = 0; i < hn; i++) {
+				s0 ^= mul_slow(h[0][i], h[2][i]);
+				s1 ^= mul_slow(h[0][i + hn], h[2][i + hn]);
+			}
+			const bool ok2 = got[0] == s0 && got[1] == s1 && e == hipSuccess;
+			bad += !ok2;
+			printf("split n=%llu: %s\n", (unsigned long long)hn, ok2 ? "OK" : "MISMATCH");
+		}
+	}
+	hipEvent_t ea, eb;
+	(void)hipEventCreate(&ea);
+	(void)hipEventCreate(&eb);
+	for (int rep = 0; rep < (prof ? 1 : 4); rep++) {
+		(void)hipMemset(d_out, 0, 32);
+		(void)hipEventRecord(ea);
+		(void)launch_roundeval_mfma_pair(0, 256, d[0], d[1], d[2], d[3], n, d_out, nullptr);
+		(void)hipEventRecord(eb);
+		(void)hipEventSynchronize(eb);
+		float ms;
+		(void)hipEventElapsedTime(&ms, ea, eb);
+		printf("pair n=2^%d: %.3f ms  %.2f G points/s  %.2f TB/s algorithmic (64 B/point)\n", log_n, ms, n / ms * 1e-6, n * 64.0 / ms * 1e-9);
+	}
+	// ---- fused fold + evaluation: arrays a = d[0], b = d[2] of N elements, folded into d[1], d[3]
+	const f128 z{0x0123456789abcdefull, 0xfedcba9876543210ull};
+	for (uint64_t N : {1024ull, 4096ull + 8, 1ull << 16, 1ull << 18}) {
+		if (N > n_host || prof) continue;
+		foldeval_args fa;
+		fa.x0[0] = d[0]; fa.x1[0] = d[0] + N / 2; fa.out[0] = d[1];
+		fa.x0[1] = d[2]; fa.x1[1] = d[2] + N / 2; fa.out[1] = d[3];
+		(void)hipMemset(d_out, 0, 32);
+		hipError_t e = launch_foldeval_mfma(0, 256, fa, N, z, d_out, nullptr);
+		f128 got[2];
+		(void)hipMemcpy(got, d_out, 32, hipMemcpyDeviceToHost);
+		std::vector<f128> fa_h(N / 2), fb_h(N / 2), ga(N / 2), gb(N / 2);
+		for (uint64_t i = 0; i < N / 2; i++) {
+			fa_h[i] = h[0][i] ^ mul_slow(h[0][i] ^ h[0][i + N / 2], z);
+			fb_h[i] = h[2][i] ^ mul_slow(h[2][i] ^ h[2][i + N / 2], z);
+		}
+		(void)hipMemcpy(ga.data(), d[1], N / 2 * 16, hipMemcpyDeviceToHost);
+		(void)hipMemcpy(gb.data(), d[3], N / 2 * 16, hipMemcpyDeviceToHost);
+		f128 e1 = f128_zero(), ei = f128_zero();
+		const uint64_t q = N / 4;
+		for (uint64_t j = 0; j < q; j++) {
+			e1 ^= mul_slow(fa_h[j + q], fb_h[j + q]);
+			ei ^= mul_slow(fa_h[j] ^ fa_h[j + q], fb_h[j] ^ fb_h[j + q]);
+		}
+		bool same = true;
+		for (uint64_t i = 0; i < N / 2; i++) same = same && ga[i] == fa_h[i] && gb[i] == fb_h[i];
+		const bool ok = same && got[0] == e1 && got[1] == ei && e == hipSuccess;
+		bad += !ok;
+		printf("fused N=%llu: fold %s, sums %s\n", (unsigned long long)N, same ? "OK" : "MISMATCH", (got[0] == e1 && got[1] == ei) ? "OK" : "MISMATCH");
+	}
+	{
+		// timing: in place on a = d[0], b = d[2] (N = n elements each)
+		foldeval_args fa;
+		fa.x0[0] = d[0]; fa.x1[0] = d[0] + n / 2; fa.out[0] = d[0];
+		fa.x0[1] = d[2]; fa.x1[1] = d[2] + n / 2; fa.out[1] = d[2];
+		for (int rep = 0; rep < (prof ? 1 : 4); rep++) {
+			(void)hipMemset(d_out, 0, 32);
+			(void)hipEventRecord(ea);
+			(void)launch_foldeval_mfma(0, 256, fa, n, z, d_out, nullptr);
+			(void)hipEventRecord(eb);
+			(void)hipEventSynchronize(eb);
+			float ms;
+			(void)hipEventElapsedTime(&ms, ea, eb);
+			printf("fused N=2^%d: %.3f ms  %.2f TB/s algorithmic (48 B/element)\n", log_n, ms, n * 48.0 / ms * 1e-9);
+		}
+	}
+	printf("%s\n", bad ? "FAILED" : "ALL OK");
+	return bad != 0;
+}

@@ -1,0 +1,18 @@
+#!/bin/bash
+# counters-only rocprofv3 passes over tools/gram_bench (one launch per kernel at 2^LOG elements)
+LOG=${1:-24}
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/pmc_gram
+rm -rf $OUT; mkdir -p $OUT
+i=0
+for set in "SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVES GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_INSTS_SALU" \
+           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_ADDR_CONFLICT" \
+           "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" \
+           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA" \
+           "FETCH_SIZE" "WRITE_SIZE"; do
+  i=$((i+1))
+  rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -- $R/tools/gram_bench $LOG prof > $OUT/p$i.log 2>&1
+done
+python3 $R/tools/pmc_summary.py $OUT/summary.json $OUT/p1 $OUT/p2 $OUT/p3 $OUT/p4 $OUT/p5 $OUT/p6 > /dev/null
+cat $OUT/summary.json
