@@ -96,6 +96,18 @@ __device__ __forceinline__ void stage_T(uint32_t *T, const stage_role &sr, unsig
 	dst_mx[3 * kLimbW] = quad_btr(mx.w, sr);
 }
 
+// One limb of stage_T: piece (o, w) -- two T words.  Lets a caller spread the staging of a tile over the
+// Gram k-steps of the previous one.
+template <bool MIX, int W>
+__device__ __forceinline__ void stage_T_limb(uint32_t *T, const stage_role &sr, unsigned o, const uint4 &hi, const uint4 &lo)
+{
+	const uint32_t h = W == 0 ? hi.x : (W == 1 ? hi.y : (W == 2 ? hi.z : hi.w));
+	const uint32_t l = W == 0 ? lo.x : (W == 1 ? lo.y : (W == 2 ? lo.z : lo.w));
+	uint32_t *dst_hi = T + o * kSetW + sr.st_off + W * kLimbW;
+	dst_hi[0] = quad_btr(h, sr);
+	dst_hi[2 * kSetW] = quad_btr(MIX ? (h ^ l) : l, sr);
+}
+
 __device__ __forceinline__ v4i and4(v4i x, uint32_t m)
 {
 	return v4i{(int)((uint32_t)x.x & m), (int)((uint32_t)x.y & m), (int)((uint32_t)x.z & m), (int)((uint32_t)x.w & m)};
@@ -170,6 +182,11 @@ __device__ __forceinline__ void gram_step(const uint32_t *T, const gram_role &g,
 			un[w] = *reinterpret_cast<const v4i *>(U + w * kLimbW + (KS + 1) * kBlkW);
 		vn[0] = *reinterpret_cast<const v4i *>(V + (KS + 1) * kBlkW);
 		vn[1] = *reinterpret_cast<const v4i *>(V + 2 * kLimbW + (KS + 1) * kBlkW);
+		// keep the requests HERE, ahead of this k-step's MFMAs: left alone, the scheduler sinks them to
+		// their first use (or hoists the next k-step's operand preparation up to them) and the LDS latency
+		// of every k-step is exposed
+		asm volatile("" ::: "memory");
+		__builtin_amdgcn_sched_barrier(0);
 	}
 #ifndef GRAM_VARIANT
 #define GRAM_VARIANT 0
@@ -207,6 +224,7 @@ __device__ __forceinline__ void gram_step(const uint32_t *T, const gram_role &g,
 	}
 #endif
 	if (KS < 7) {
+		__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
 		for (int w = 0; w < 4; w++)
 			p.u[w] = un[w];

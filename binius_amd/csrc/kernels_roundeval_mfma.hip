@@ -25,7 +25,8 @@ __global__ __launch_bounds__(256, 2) void k_roundeval_mfma(const uint4 *__restri
                                                            const uint4 *__restrict__ b_hi, const uint4 *__restrict__ b_lo, uint64_t n,
                                                            f128 *out, fin_fuse fz)
 {
-	__shared__ __attribute__((aligned(16))) uint32_t T[2][kTileW];
+	constexpr int kTiles = 2; // tiles per iteration: 32 KiB of loads in flight per workgroup, one barrier per 512 points
+	__shared__ __attribute__((aligned(16))) uint32_t T[2][kTiles][kTileW];
 	const unsigned lane = threadIdx.x & 63;
 	const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const stage_role sr = make_stage_role(wave, lane);
@@ -34,41 +35,54 @@ __global__ __launch_bounds__(256, 2) void k_roundeval_mfma(const uint4 *__restri
 	v16i acc[kAccTiles];
 	acc_zero(acc);
 
-	const uint64_t n_tiles = (n + kTP - 1) / kTP;
-	uint4 x[4]; // a_hi, a_lo, b_hi, b_lo of this lane's point
-	// a lane past the end loads element 0 and zeroes it when the tile is staged: nothing depends on a
-	// loaded value before then, so the loads stay in flight across the Gram k-steps
-	auto load = [&](uint64_t t) {
-		const uint64_t pt = t * kTP + threadIdx.x;
-		const uint64_t e = pt < n ? pt : 0;
-		x[0] = a_hi[e];
-		x[1] = a_lo[e];
-		x[2] = b_hi[e];
-		x[3] = b_lo[e];
-	};
-	auto stage = [&](uint64_t t, uint32_t *Tb) {
-		if (t * kTP + threadIdx.x >= n) {
+	const uint64_t n_groups = (n + kTiles * kTP - 1) / (kTiles * kTP);
+	// a_hi, a_lo, b_hi, b_lo of this lane's point in each tile of the group.  One tile of 16 KiB in flight
+	// per workgroup covers only ~2.7 us of HBM latency at 3 TB/s -- what a loaded HBM takes to answer.
+	// (a lane past the end loads element 0 and zeroes it when the tile is staged: nothing depends on a
+	// loaded value before then, so the loads stay in flight across the Gram k-steps)
+	uint4 x[kTiles][4];
+	auto load = [&](uint64_t g) {
 #pragma unroll
-			for (int k = 0; k < 4; k++)
-				x[k] = uint4{0, 0, 0, 0};
+		for (int i = 0; i < kTiles; i++) {
+			const uint64_t pt = (g * kTiles + i) * kTP + threadIdx.x;
+			const uint64_t e = pt < n ? pt : 0;
+			x[i][0] = a_hi[e];
+			x[i][1] = a_lo[e];
+			x[i][2] = b_hi[e];
+			x[i][3] = b_lo[e];
 		}
-		stage_T<!SPLIT>(Tb, sr, 0, x[0], x[1]);
-		stage_T<!SPLIT>(Tb, sr, 1, x[2], x[3]);
+	};
+	auto stage = [&](uint64_t g, uint32_t (*Tb)[kTileW]) {
+#pragma unroll
+		for (int i = 0; i < kTiles; i++) {
+			if ((g * kTiles + i) * kTP + threadIdx.x >= n) {
+#pragma unroll
+				for (int k = 0; k < 4; k++)
+					x[i][k] = uint4{0, 0, 0, 0};
+			}
+			stage_T<!SPLIT>(Tb[i], sr, 0, x[i][0], x[i][1]);
+			stage_T<!SPLIT>(Tb[i], sr, 1, x[i][2], x[i][3]);
+		}
 	};
 
-	uint64_t t = blockIdx.x;
+	uint64_t g = blockIdx.x;
 	unsigned buf = 0;
-	if (t < n_tiles) {
-		load(t);
-		stage(t, T[0]);
+	if (g < n_groups) {
+		load(g);
+		stage(g, T[0]);
 	}
 	__syncthreads();
-	for (; t < n_tiles; t += gridDim.x) {
-		const uint64_t tn = t + gridDim.x;
-		if (tn < n_tiles) load(tn);
-		gram_tile(T[buf], gr, acc);
-		if (tn < n_tiles) stage(tn, T[buf ^ 1]);
-		__syncthreads();
+	for (; g < n_groups; g += gridDim.x) {
+		const uint64_t gn = g + gridDim.x;
+#ifndef GRAM_DBG
+#define GRAM_DBG 0
+#endif
+		if (!(GRAM_DBG & 1) && gn < n_groups) load(gn);
+#pragma unroll
+		for (int i = 0; i < kTiles; i++)
+			gram_tile(T[buf][i], gr, acc);
+		if (!(GRAM_DBG & 2) && gn < n_groups) stage(gn, T[buf ^ 1]);
+		if (!(GRAM_DBG & 4)) __syncthreads();
 		buf ^= 1;
 	}
 	gram::tail(acc, wave, lane, out, fz, fz.args.seq);
@@ -90,9 +104,9 @@ bool mfma_applies(int n_cu, uint64_t n_points)
 
 static unsigned grid_mfma(uint64_t n, int n_cu)
 {
-	const uint64_t n_tiles = (n + kTP - 1) / kTP;
+	const uint64_t n_groups = (n + 2 * kTP - 1) / (2 * kTP); // kTiles = 2 tiles per iteration
 	const uint64_t cap = (uint64_t)n_cu * 2;
-	return (unsigned)(n_tiles < cap ? (n_tiles ? n_tiles : 1) : cap);
+	return (unsigned)(n_groups < cap ? (n_groups ? n_groups : 1) : cap);
 }
 
 template <bool SPLIT>
