@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """bench.py -- GF(2^128) sumcheck (round-eval + fold) throughput on MI355X.
 
 Contract (one JSON line on rank 0):
@@ -9,19 +8,25 @@ Contract (one JSON line on rank 0):
 A "step" is ONE complete bivariate-product sumcheck over the resident multilinears: for every
 round, the round evaluation (accumulate_kernels -> y_1, y_inf), the host's three XORs / two scalar
 multiplications for the round polynomial and the next challenge, and the fold (extrapolate_line)
-of every multilinear.  Workload at N = 1: BASELINE.json configs[1] -- m = 2 multilinears of 2^24
-BinaryField128b elements (512 MiB), one product claim, 24 rounds.  Inputs are generated once
-(SplitMix64), uploaded before the timed region and never modified (the
-prover's first fold copies, like the reference's PreFold -> PostFold).  Challenges come from a
-fixed SplitMix64 stream instead of a Grøstl transcript (host-side protocol code, out of scope).
+of every multilinear.
 
-N > 1: hypercube sharded on the LAST-bound variables (low index bits under High-to-Low binding,
-SURVEY.md section 8e): rank g owns global indices = g mod N as one contiguous local array, every
-rank runs the same rounds on 2^24 local elements per multilinear (weak scaling: the global
-instance has n = 24 + log2 N variables) and the per-round partial (y_1, y_inf) pairs are combined
-with ONE RCCL all_gather of 32 bytes per round + local XOR (RCCL has no XOR reduction).
+Workload: the north-star instance -- m = 2 multilinears of 2^28 BinaryField128b elements (8 GiB), one
+product claim, 28 rounds (BASELINE.json: the configuration the target is quoted on; config 5 when
+N = 8).  The GLOBAL instance is fixed, so N > 1 is STRONG scaling: the hypercube is sharded on the
+LAST-bound variables (low index bits under High-to-Low binding), rank g owns the
+global indices = g mod N as one contiguous local array of 2^(28 - log2 N) elements per multilinear --
+a shard of the SAME SplitMix64 instance the single-GPU run proves (synthetic.random_b128_shard).
+Every round each rank evaluates its shard and the N partial (y_1, y_inf) pairs are combined with ONE
+device-side RCCL collective (ncclAllGather of 32 bytes on the context's stream + a one-workgroup XOR;
+RCCL has no XOR reduction); after the local rounds one ncclAllGather per multilinear rebuilds the
+N-element residual instance and the last log2 N rounds run on it.  The host-shared-memory exchange
+(BN_EXCHANGE=shm) is timed beside it and reported as `alt_exchange`.  `--n-vars 24` gives
+BASELINE.json configs[1].  Inputs are generated once, uploaded before the timed region and never
+modified (the prover's first fold copies, like the reference's PreFold -> PostFold).  Challenges
+come from a fixed SplitMix64 stream instead of a Groestl transcript (host-side protocol code, out of
+scope).
 
-value = (elements of all multilinears on all ranks) * K / wall seconds  [elems/s].
+value = (elements of all multilinears of the global instance) * K / wall seconds  [elems/s].
 """
 import argparse
 import json
@@ -34,16 +39,18 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+PMC_FILE = os.path.join("profiles", "r02", "bench_pmc.json")  # tools/pmc_bench.sh: FETCH_SIZE / WRITE_SIZE passes of this command
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n-vars", type=int, default=24, help="local variables per rank")
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n-vars", type=int, default=28, help="variables of the GLOBAL instance (28: north star; 24: BASELINE configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="diagnostic: no per-launch hipEvents in the timed region (no roofline block)")
+    ap.add_argument("--no-alt-exchange", action="store_true", help="do not time the shared-memory exchange beside the RCCL one")
     ap.add_argument("--cpu-n-vars", type=int, default=0, help="size of the CPU baseline sample (0 = auto)")
     args = ap.parse_args()
 
@@ -55,10 +62,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
     force_sharded = os.environ.get("BN_FORCE_SHARDED") == "1"  # exercise the multi-GPU code path on one GPU
-    # per-round exchange of the ranks' 32-byte partials: "shm" (host shared memory; all ranks on one
-    # node, the measured configuration) or "rccl" (one ncclAllGather per round on the device)
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
-    exchange = os.environ.get("BN_EXCHANGE", "shm" if local_world == int(os.environ.get("WORLD_SIZE", "1")) else "rccl")
     if world > 1 or force_sharded:
         import torch.distributed as dist
 
@@ -76,122 +80,113 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(local_rank)
+    # per-round exchange of the ranks' 32-byte partials: "rccl" (one ncclAllGather per round on the device,
+    # the default wherever RCCL runs) or "shm" (host shared memory; all ranks on one node)
+    rccl_possible = dist is not None and dist.get_backend() == "nccl"
+    exchange = os.environ.get("BN_EXCHANGE", "rccl" if rccl_possible else "shm")
 
     import binius_amd
-    from binius_amd.distributed import ShardedRoundReducer
+    from binius_amd import synthetic  # SplitMix64 input streams (numpy)
+    from binius_amd._host import RcclComm, ShmExchange, SumcheckPlan
 
-    n_vars, m = args.n_vars, 2
-    n = 1 << n_vars
+    m = 2
     log_world = world.bit_length() - 1
     assert 1 << log_world == world, "number of GPUs must be a power of two"
+    n_global = args.n_vars
+    n_vars = n_global - log_world  # local variables per rank
+    assert n_vars >= 2, "instance too small for this many ranks"
+    n = 1 << n_vars
 
-    # ---- inputs: resident in HBM before the timed region
-    from binius_amd import synthetic  # SplitMix64 input streams (numpy)
-
-    hal = binius_amd.Context(local_rank, m * n + m * (n // 2) + 4096)
-    hal.set_stream(torch.cuda.current_stream().cuda_stream)
+    # ---- inputs: resident in HBM before the timed region.  The context keeps its OWN stream (deferred
+    # folds are legal there, include/binius_amd.h "Stream contract"); RCCL collectives are enqueued on it by
+    # the compiled host loop after bn_ctx_get_stream.
+    hal = binius_amd.Context(local_rank, m * n + m * (n // 2) + 8 * world + 4096)
     alloc = hal.dev_alloc()
     d_in = []
+    chunk = 1 << 22
     for j in range(m):
-        # rank g holds the elements with global index = g mod world; as a stream that is simply an
-        # independent uniform array per (multilinear, rank)
-        host = synthetic.random_b128(0xB1A50000 + j + 0x100 * rank, n)
         s = alloc.alloc(n)
-        hal.copy_h2d(host, s)
+        for off in range(0, n, chunk):
+            c = min(chunk, n - off)
+            hal.copy_h2d(synthetic.random_b128_shard(0xB1A50000 + j, c, world, rank, start=off), s.slice(off, off + c))
         d_in.append(s)
-        del host
-    stream = synthetic.random_scalars(0xC4A1, n_vars + log_world + 1)
+    stream = synthetic.random_scalars(0xC4A1, n_global + 1)
     batch_coeff, challenges = stream[0], stream[1:]
     F = binius_amd.HostField
-    reducer = ShardedRoundReducer(hal, dist, world) if dist is not None else None
+    scratch = alloc.alloc(m * (n // 2) + 8 * world + 64)  # folded copies (+ the residual instance and its folded copies)
 
-    # The prover loop runs in the compiled C++ host mirror (binius_amd/host/sumcheck.hpp behind
-    # libbinius_amd_host.so): per round one accumulate_kernels, two scalar multiplications and one
-    # extrapolate_line per multilinear through the C ABI -- what a Rust host would do, without
-    # interpreter time between HAL calls.
-    from binius_amd._host import SumcheckPlan
+    shm, rccl, reducer = None, None, None
+    d_partial, d_gathered = 0, 0
+    if dist is not None:
+        from binius_amd.distributed import ShardedRoundReducer
 
-    scratch = alloc.alloc(m * (n // 2) + 64)  # folded copies (+ the residual rounds' folded copies)
-    d_partial, d_gathered, rccl, shm = 0, 0, None, None
-    if reducer is not None and exchange == "shm":
-        # the round loop runs exactly as on one GPU (fused kernels, result mailbox); the ranks' partials
-        # meet in a shared-memory segment (binius_amd/host/host_capi.cpp bnh_shm_*).  If the segment
-        # cannot be set up on any rank, every rank falls back to the RCCL transport.
-        from binius_amd._host import ShmExchange
-
-        try:
-            shm = ShmExchange(dist, rank, world)
-            ok = 1
-        except Exception as ex:  # noqa: BLE001
-            print("[bench] rank %d: shared-memory exchange unavailable (%s)" % (rank, ex), file=sys.stderr)
-            shm, ok = None, 0
-        flag = torch.tensor([ok], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:
-            if shm is not None:
-                shm.close()
-            shm, exchange = None, "rccl"
-        comm = shm
-    if reducer is not None and exchange != "shm":
-        # the per-round collective is issued from the compiled host loop: ncclAllGather of the 32-byte
-        # partial on the context's stream, communicator bootstrapped over the torch process group
-        from binius_amd._host import RcclComm
-
-        rccl = RcclComm(dist, rank, world)
-        d_partial = reducer.local.data_ptr()
-        d_gathered = reducer.gathered.data_ptr()
-        comm = reducer
+        reducer = ShardedRoundReducer(hal, dist, world)  # device buffers of the RCCL exchange + scalar all-gathers
+        # the shared-memory segment (alt exchange, or the primary one under BN_EXCHANGE=shm / gloo)
+        if local_world == world:
+            try:
+                shm = ShmExchange(dist, rank, world)
+                ok = 1
+            except Exception as ex:  # noqa: BLE001
+                print("[bench] rank %d: shared-memory exchange unavailable (%s)" % (rank, ex), file=sys.stderr)
+                shm, ok = None, 0
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                if shm is not None:
+                    shm.close()
+                shm = None
+        if exchange == "shm" and shm is None:
+            exchange = "rccl"
+        if rccl_possible:
+            # the per-round collective is issued from the compiled host loop: ncclAllGather of the 32-byte
+            # partial on the context's stream, communicator bootstrapped over the torch process group
+            rccl = RcclComm(dist, rank, world)
+            d_partial = reducer.local.data_ptr()
+            d_gathered = reducer.gathered.data_ptr()
+        elif exchange == "rccl":
+            raise SystemExit("BN_EXCHANGE=rccl needs the nccl process-group backend")
 
     # the claimed sum (not timed): inner product on the device, combined across ranks
     claim = hal.inner_product(d_in[0], 7, d_in[1])
-    if reducer is not None:
-        claim = comm.xor_scalars([claim])[0]
+    if dist is not None:
+        claim = (shm if shm is not None else reducer).xor_scalars([claim])[0]
 
     def barrier():
         if dist is not None:
             dist.barrier()
+        hal.sync()
         torch.cuda.synchronize()
 
-    # shared-memory exchange: the residual log2(G) rounds run inside the same compiled call
-    in_call_tail = shm is not None and log_world > 0
-    plan = SumcheckPlan(hal, n_vars, d_in, scratch, [(0, 1)], [claim], batch_coeff,
-                        challenges[: n_vars + (log_world if in_call_tail else 0)], None, d_partial,
-                        rccl.handle if rccl else None, world, d_gathered, shm.handle if shm else None, tail_rounds=in_call_tail)
-    tail = None
-    if reducer is not None and log_world > 0 and not in_call_tail:
-        # residual instance after the local rounds: m multilinears of `world` elements (index = rank)
-        d_res = [alloc.alloc(world) for _ in range(m)]
-        res_scratch = alloc.alloc(m * max(1, world // 2))
+    def make_plan(kind):
+        use_shm = kind == "shm"
+        return SumcheckPlan(hal, n_vars, d_in, scratch, [(0, 1)], [claim], batch_coeff, challenges[:n_global], None,
+                            0 if use_shm else d_partial, None if (use_shm or rccl is None) else rccl.handle, world,
+                            0 if use_shm else d_gathered, shm.handle if use_shm else None, tail_rounds=log_world > 0)
 
-    def one_step():
-        plan.run()
-        if reducer is None or log_world == 0 or in_call_tail:
-            return plan.round_coeffs, plan.final_evals
-        # last log2(G) rounds: one all_gather of the m local finals, then a tiny local sumcheck
-        per_rank = comm.all_gather_scalars(plan.final_evals())
-        running = claim
-        for r, (c0, c1, c2) in enumerate(plan.round_coeffs()):
-            running = F.mul(F.mul(c2, challenges[r]) ^ c1, challenges[r]) ^ c0
-        for j in range(m):
-            hal.copy_h2d(binius_amd._ffi_ints_to_arr([per_rank[g][j] for g in range(world)]), d_res[j])
-        tp = SumcheckPlan(hal, log_world, d_res, res_scratch, [(0, 1)], [running], batch_coeff, challenges[n_vars : n_vars + log_world])
-        tp.run()
-        return (lambda: plan.round_coeffs() + tp.round_coeffs()), tp.final_evals
+    plan = make_plan(exchange) if dist is not None else SumcheckPlan(hal, n_vars, d_in, scratch, [(0, 1)], [claim], batch_coeff, challenges[:n_global])
+
+    def timed(pl, steps):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            pl.run()
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
 
     for _ in range(args.warmup):
-        one_step()
-    # ---- timed region: exactly K steps, barrier + synchronize on both sides
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        get_coeffs, get_finals = one_step()
-    barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
+        plan.run()
+    # ---- timed region: exactly K steps, barrier + synchronize on both sides, MAX over ranks
+    elapsed = timed(plan, args.steps)
+    get_coeffs, get_finals = plan.round_coeffs, plan.final_evals
     # ---- the same K steps once more with a hipEvent pair around every kernel launch (bn_prof_*), for
-    # the roofline block.  The events cost about 5 us per launch on the stream (measured: 1.30 -> 1.41 ms
-    # per step), which is instrumentation, not the workload -- so they stay out of `value`; the
-    # instrumented pass's own wall time is reported next to it as ms_per_step_instrumented.
+    # the roofline block.  The events cost about 5 us per launch on the stream, which is instrumentation,
+    # not the workload -- so they stay out of `value`; the instrumented pass's own wall time is reported
+    # next to it as ms_per_step_instrumented.
     prof = {k: (0.0, 0) for k in hal.PROF_CLASSES}
     elapsed_prof = None
     if not args.no_prof:
@@ -199,14 +194,21 @@ def main():
         hal.prof_begin()
         t2 = time.perf_counter()
         for _ in range(args.steps):
-            one_step()
+            plan.run()
         barrier()
         elapsed_prof = time.perf_counter() - t2
         prof = hal.prof_end()
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # ---- the other transport, same steps (all ranks on one node): reported beside the default, never as `value`
+    alt = None
+    if dist is not None and not args.no_alt_exchange and world > 1:
+        other = "shm" if exchange == "rccl" else "rccl"
+        if (other == "shm" and shm is not None) or (other == "rccl" and rccl is not None):
+            plan_alt = make_plan(other)
+            plan_alt.run()
+            dt_alt = timed(plan_alt, args.steps)
+            same = plan_alt.round_coeffs() == get_coeffs() and plan_alt.final_evals() == get_finals()
+            alt = {"exchange": other, "ms_per_step": dt_alt * 1e3 / args.steps, "value": m * (1 << n_global) * args.steps / dt_alt,
+                   "same_transcript_as_default": bool(same)}
 
     # correctness of what was timed (N = 1: the sumcheck verifier's final check, on the device values)
     # the sumcheck verifier on what was timed (all ranks hold the same transcript):
@@ -219,7 +221,7 @@ def main():
     fa, fb = get_finals()
     ok = ok and F.mul(fa, fb) == running
 
-    total_elems = m * n * world
+    total_elems = m * (1 << n_global)
     value = total_elems * args.steps / elapsed
     ms_per_step = elapsed * 1e3 / args.steps
 
@@ -230,38 +232,55 @@ def main():
     #                           the evaluation consumes the folded values on chip -- no bytes of its own)
     #   fold alone              24*m*2^r                                        (the last fold, r = 1)
     # The ABI decides per launch which kernel runs; the launch counts per class say what actually ran.
-    re_ms, re_cnt = prof["round_eval"]
-    fo_ms, fo_cnt = prof["fold"]
-    fe_ms, fe_cnt = prof["fold_eval"]
-    fs_ms, fs_cnt = prof["fold_eval_small"]
-    tl_ms, tl_cnt = prof["tail"]
-    fused = fe_cnt + fs_cnt > 0
+    # Classes (include/binius_amd.h BN_PROF_*), as rocprof lists the kernel symbols:
+    #   round_eval_mfma  k_roundeval_mfma   round 0 on the matrix cores        fold_eval_mfma   k_foldeval_mfma  (>= 2 tiles of 256 points per CU)
+    #   round_eval       k_roundeval9       round 0, 9-lane VALU kernel        fold_eval        k_foldeval9<2>   (the next size down)
+    #   fold             k_extrapolate_line / k_fold_publish (last fold)       fold_eval_small  k_foldeval9_small (one workgroup per batch: latency-shaped)
+    #                                                                          tail             k_foldeval_tail  (resident; opt-in)
+    K = args.steps
+    counts = {c: prof[c][1] // K if K else 0 for c in prof}
+    # the fused launches of a step, largest round first: mfma, then k_foldeval9<2>, then small, then tail
+    order = ["fold_eval_mfma", "fold_eval", "fold_eval_small"]
+    r_hi = n_vars  # r of the next fused launch (pre-fold size 2^r)
+    fused_bytes = {}
+    for c in order:
+        f = counts.get(c, 0)
+        fused_bytes[c] = sum(24 * m * (1 << r) for r in range(r_hi - f + 1, r_hi + 1)) * K
+        r_hi -= f
+    fused = sum(counts.get(c, 0) for c in order) + counts.get("tail", 0) > 0
+    tl_bytes = sum(24 * m * (1 << r) for r in range(2, r_hi + 1)) * K if counts.get("tail", 0) else 0
+    n_re = counts.get("round_eval", 0) + counts.get("round_eval_mfma", 0)
     if fused:
-        # rocprof lists two kernel symbols for the fused launches and so does this block: the f largest
-        # rounds are k_foldeval9<2> launches, the next g k_foldeval9_small ones (one workgroup per batch:
-        # latency-shaped); what remains (if anything) runs inside one resident k_foldeval_tail launch per
-        # step (its time includes the host round trips)
-        f = fe_cnt // args.steps
-        g = fs_cnt // args.steps
-        re_bytes = 16 * m * (1 << n_vars) * args.steps
-        fe_bytes = sum(24 * m * (1 << r) for r in range(n_vars - f + 1, n_vars + 1)) * args.steps
-        fs_bytes = sum(24 * m * (1 << r) for r in range(n_vars - f - g + 1, n_vars - f + 1)) * args.steps
-        tl_bytes = sum(24 * m * (1 << r) for r in range(2, n_vars - f - g + 1)) * args.steps
-        fold_bytes = 24 * m * 2 * args.steps
+        re_bytes_each = 16 * m * (1 << n_vars)  # round 0 (and round 0 of the residual instance: negligible)
+        fold_bytes = 24 * m * 2 * K
     else:
-        re_bytes = sum(16 * m * (1 << r) for r in range(1, n_vars + 1)) * args.steps
-        fe_bytes = fs_bytes = tl_bytes = 0
-        fold_bytes = sum(24 * (1 << r) for r in range(1, n_vars + 1)) * m * args.steps
-    kernels = {
-        "k_roundeval9(round_eval)": (re_bytes, re_ms, re_cnt),
-        "k_extrapolate_line(fold)": (fold_bytes, fo_ms, fo_cnt),
+        re_bytes_each = None
+        fold_bytes = sum(24 * (1 << r) for r in range(1, n_vars + 1)) * m * K
+    label = {
+        "round_eval_mfma": "k_roundeval_mfma(round_eval)",
+        "round_eval": "k_roundeval9(round_eval)",
+        "fold": "k_extrapolate_line(fold)",
+        "fold_eval_mfma": "k_foldeval_mfma(fold+round_eval)",
+        "fold_eval": "k_foldeval9(fold+round_eval)",
+        "fold_eval_small": "k_foldeval9_small(fold+round_eval, <= 2 batches per CU)",
+        "tail": "k_foldeval_tail(resident, rounds <= 2^12)",
     }
-    if fe_cnt:
-        kernels["k_foldeval9(fold+round_eval)"] = (fe_bytes, fe_ms, fe_cnt)
-    if fs_cnt:
-        kernels["k_foldeval9_small(fold+round_eval, <= 2 batches per CU)"] = (fs_bytes, fs_ms, fs_cnt)
-    if tl_cnt:
-        kernels["k_foldeval_tail(resident, rounds <= 2^12)"] = (tl_bytes, tl_ms, tl_cnt)
+    kernels = {}
+    for c in ("round_eval_mfma", "round_eval"):
+        ms_c, cnt_c = prof[c]
+        if cnt_c:
+            if fused:
+                # the large launch of the class is round 0 of the local instance; residual-instance launches are bytes-free here
+                bytes_c = re_bytes_each * K if (c == "round_eval_mfma" or counts.get("round_eval_mfma", 0) == 0) else 0
+            else:
+                bytes_c = sum(16 * m * (1 << r) for r in range(1, n_vars + 1)) * K
+            kernels[label[c]] = (bytes_c, ms_c, cnt_c)
+    kernels[label["fold"]] = (fold_bytes, prof["fold"][0], prof["fold"][1])
+    for c in order:
+        if prof[c][1]:
+            kernels[label[c]] = (fused_bytes[c], prof[c][0], prof[c][1])
+    if prof["tail"][1]:
+        kernels[label["tail"]] = (tl_bytes, prof["tail"][0], prof["tail"][1])
     dom = max(kernels, key=lambda k: kernels[k][1])
     b, ms, cnt = kernels[dom]
     achieved = b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
@@ -279,15 +298,17 @@ def main():
         "algorithmic_bytes_per_launch": b // cnt if cnt else None,
     }
     # HBM traffic of the dominant kernel: PMC counters cannot be collected inside this process, so the
-    # value comes from the committed counters-only rocprofv3 passes OF THIS COMMAND on this workload
-    # (profiles/r01/bench_n24_pmc.json: FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, bytes per launch);
-    # null for any other workload or kernel
+    # value comes from the committed counters-only rocprofv3 passes OF THIS COMMAND (tools/pmc_bench.sh ->
+    # profiles/r02/bench_pmc.json: FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, average bytes per launch
+    # of the kernel symbol, with the commit of the build it was taken on); null for a workload it does not hold
     try:
-        pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "bench_n24_pmc.json")))
-        sym = {"k_foldeval9(fold+round_eval)": "k_foldeval9<2>", "k_roundeval9(round_eval)": "k_roundeval9"}.get(dom)
-        if sym and pmc["workload"] == {"n_vars": n_vars, "multilinears": m} and sym in pmc["kernels"]:
-            roofline["traffic"] = pmc["kernels"][sym]["traffic_bytes_per_launch"]
-            roofline["traffic_source"] = "profiles/r01/bench_n24_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; bytes per launch)"
+        pmc = json.load(open(os.path.join(ROOT, PMC_FILE)))
+        sym = dom.split("(")[0]
+        ent = pmc["workloads"].get("n_vars_local=%d,m=%d" % (n_vars, m), {}).get(sym)
+        if ent:
+            roofline["traffic"] = ent["traffic_bytes_per_launch"]
+            roofline["traffic_source"] = "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command at build %s; average bytes per launch of %s)" % (
+                PMC_FILE, pmc.get("build", "?"), sym)
     except (OSError, KeyError, ValueError):
         pass
     # the streaming ceiling this box reaches: a device-to-device copy of one multilinear (read + write), next to
@@ -328,19 +349,20 @@ def main():
         "ms_per_step": ms_per_step,
         "ms_per_step_instrumented": (elapsed_prof * 1e3 / args.steps) if elapsed_prof else None,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong",
         "vs_baseline": None,
         "dtype": "gf2^128 (u128 bitwise)",
         "data": "synthetic",
         "config": {
-            "workload": "2^%d-var GF(2^128) bivariate-product sumcheck: round-eval + fold every round, m=2 multilinears per GPU"
-            % n_vars,
+            "workload": "2^%d-var GF(2^128) bivariate-product sumcheck: round-eval + fold every round, m=2 multilinears, %s"
+            % (n_global, "1 GPU" if world == 1 else "sharded on the top-bound-last (low index) variables across %d GPUs" % world),
             "n_vars_local": n_vars,
-            "n_vars_global": n_vars + log_world,
+            "n_vars_global": n_global,
             "multilinears": m,
             "sharding": ("low index bits (last-bound variables), one 32-byte exchange per round: "
-                         + ("host shared memory" if exchange == "shm" else "RCCL all_gather")) if dist is not None else "none",
+                         + ("host shared memory" if exchange == "shm" else "RCCL all_gather on the context's stream + device XOR")) if dist is not None else "none",
         },
+        "alt_exchange": alt,
         "bit_exact_check": bool(ok),
         "roofline": roofline,
         "kernels": per_kernel,
@@ -378,7 +400,7 @@ def main():
         fn = min(n_vars, 26)
         best = None
         for _ in range(3):
-            mls = [oracle.random_b128(0xB1A50000 + j, 1 << fn) for j in range(m)]
+            mls = [oracle.random_b128(0xB1A50000 + j, 1 << fn) for j in range(m)]  # (the port folds in place)
             c0 = time.perf_counter()
             res = oracle.fast_bivariate_sumcheck_prove(mls, fn, [(0, 1)], [0], batch_coeff, challenges[:fn], threads=cores)
             fdt = time.perf_counter() - c0

@@ -416,7 +416,7 @@ class Context:
         _check(lib().bn_timer_end_ms(self._h, C.byref(ms)))
         return ms.value
 
-    PROF_CLASSES = ("round_eval", "fold", "tensor_expand", "ntt", "other", "fold_eval", "tail", "fold_eval_small")
+    PROF_CLASSES = ("round_eval", "fold", "tensor_expand", "ntt", "other", "fold_eval", "tail", "fold_eval_small", "fold_eval_mfma", "round_eval_mfma")
 
     def prof_begin(self):
         _check(lib().bn_prof_begin(self._h))

@@ -53,7 +53,7 @@ class SumcheckPlan:
 
     def __init__(self, hal, n_vars, multilins, scratch, comps, sums, batch_coeff, challenges, reduce=None, d_partial=0,
                  rccl_comm=None, world=1, d_gathered=0, shm=None, tail_rounds=False):
-        """tail_rounds (shm exchange only): `challenges` holds n_vars + log2(world) values and the run
+        """tail_rounds (shm or RCCL exchange): `challenges` holds n_vars + log2(world) values and the run
         also does the residual rounds; round_coeffs() then has n_vars + log2(world) entries."""
         self.hal = hal
         self.n_vars = n_vars
@@ -66,7 +66,7 @@ class SumcheckPlan:
         self.sums = _f128_array(list(sums))
         self.bc = to_f128(batch_coeff)
         self.ch = _f128_array(list(challenges))
-        self.tail_rounds = bool(tail_rounds and shm is not None and world > 1)
+        self.tail_rounds = bool(tail_rounds and (shm is not None or rccl_comm is not None) and world > 1)
         self.n_rounds = n_vars + ((world.bit_length() - 1) if self.tail_rounds else 0)
         assert len(challenges) >= self.n_rounds
         self.coeffs = (F128 * (3 * self.n_rounds))()

@@ -178,7 +178,14 @@ static int flush_pending(bn_ctx *ctx, bool keep_tail = false, bool publish_tiny 
 	return BN_OK;
 }
 // one call at a time per context (the trait allows the host to call from several threads: rayon join/map)
-#define BN_ENTER(ctx) std::lock_guard<std::recursive_mutex> bn_enter_lock_((ctx)->mu)
+// Every entry point also makes the context's device current on the calling thread: scratch buffers, NTT
+// tables and pinned staging are allocated lazily inside calls, and a worker thread (or a process that
+// drives several GPUs) would otherwise put them on whatever device that thread last used.
+struct bn_enter_guard {
+	std::lock_guard<std::recursive_mutex> lock;
+	explicit bn_enter_guard(bn_ctx *c) : lock(c->mu) { (void)hipSetDevice(c->device); }
+};
+#define BN_ENTER(ctx) bn_enter_guard bn_enter_lock_(ctx)
 #define BN_FLUSH(ctx)                    \
 	do {                                 \
 		int rc_ = flush_pending(ctx);    \
@@ -306,6 +313,7 @@ int bn_ctx_set_stream(bn_ctx *ctx, void *hip_stream)
 		if (!ctx->own_stream) {
 			BN_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
 			ctx->own_stream = true;
+			ctx->lazy_fold = getenv("BN_NO_LAZY_FOLD") == nullptr;
 		}
 		return BN_OK;
 	}
@@ -313,6 +321,12 @@ int bn_ctx_set_stream(bn_ctx *ctx, void *hip_stream)
 		hipStreamDestroy(ctx->stream);
 	ctx->stream = (hipStream_t)hip_stream;
 	ctx->own_stream = false;
+	// On a stream the caller also enqueues on, deferred folds/copies would be visible: work the caller
+	// puts on the stream right after bn_extrapolate_line would run BEFORE the fold.  Deferral is
+	// therefore off on caller-supplied streams unless the caller opts in (BN_LAZY_ON_SHARED_STREAM=1)
+	// and promises to call bn_ctx_get_stream / bn_sync (both flush) before touching the stream itself.
+	ctx->lazy_fold = getenv("BN_NO_LAZY_FOLD") == nullptr && getenv("BN_LAZY_ON_SHARED_STREAM") != nullptr;
+	if (!ctx->lazy_fold) ctx->tail_max_n_in = 0;
 	return BN_OK;
 }
 
@@ -1167,12 +1181,19 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 												__atomic_store_n(tail_cmd(ctx), (tl.id << 20) | tl.round, __ATOMIC_RELEASE);
 												volatile uint64_t *seqw = &ctx->h_mail[64].lo;
 												bool got = false;
-												for (;;) {
+												for (uint64_t spins = 0;; spins++) {
 													if (__atomic_load_n(seqw, __ATOMIC_ACQUIRE) == fz.args.seq) { got = true; break; }
 													if (__atomic_load_n(tail_status(ctx), __ATOMIC_ACQUIRE) == tl.id) {
 														// the kernel left (bounded spin ran out) -- did it answer first?
 														got = __atomic_load_n(seqw, __ATOMIC_ACQUIRE) == fz.args.seq;
 														break;
+													}
+													if (spins > (1ull << 26)) {
+														// neither word moves: the kernel faulted or the device hangs.  Same fallback as
+														// the other mailbox waits: let the stream report it.
+														tl.active = false;
+														BN_HIP(hipStreamSynchronize(s));
+														return bn::fail(BN_ERR_DEVICE, "device error: resident tail kernel stopped answering");
 													}
 												}
 												if (got) {
@@ -1215,7 +1236,7 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 										// (c) one fused kernel for this round
 										if (fe == hipErrorNotSupported) {
 											const bool mfma = bn::mfma_applies(ctx->n_cu, n_in >> 2);
-											prof_scope ps(ctx, !mfma && bn::foldeval9_is_small(ctx->n_cu, n_in) ? BN_PROF_FOLD_EVAL_SMALL : BN_PROF_FOLD_EVAL);
+											prof_scope ps(ctx, mfma ? BN_PROF_FOLD_EVAL_MFMA : (bn::foldeval9_is_small(ctx->n_cu, n_in) ? BN_PROF_FOLD_EVAL_SMALL : BN_PROF_FOLD_EVAL));
 											fe = mfma ? bn::launch_foldeval_mfma(s, ctx->n_cu, fa, n_in, pf.z, d_S + slot, &fz)
 											          : bn::launch_foldeval9(s, ctx->n_cu, fa, n_in, pf.z, d_S + slot, &fz);
 											if (fe == hipSuccess) ctx->pend.active = false;
@@ -1227,7 +1248,7 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 									if (ctx->pend.active) BN_FLUSH(ctx);
 								}
 								if (fe == hipErrorNotSupported) {
-									prof_scope ps(ctx, BN_PROF_ROUND_EVAL);
+									prof_scope ps(ctx, k == 2 && bn::mfma_applies(ctx->n_cu, row_len) ? BN_PROF_ROUND_EVAL_MFMA : BN_PROF_ROUND_EVAL);
 									fe = bn::launch_roundeval_product(s, ctx->n_cu, hi, lo, k, row_len, d_S + slot, &fz);
 								}
 								if (fe == hipSuccess) {

@@ -232,8 +232,8 @@ hipError_t launch_sum_product(hipStream_t s, int n_cu, const void *const *rows, 
 	}
 	bs_job job{};
 	job.k = n_rows;
-	if (row_len >= 2) {
-		job.n = row_len / 2; // row_len is a power of two in every caller; odd tails are handled by the caller
+	if (row_len >= 2 && (row_len & 1) == 0) {
+		job.n = row_len / 2; // two half-range streams, both halves of every register busy
 		job.split_off = row_len / 2;
 		for (uint32_t j = 0; j < n_rows; j++) {
 			job.v[j].p = (const uint4 *)rows[j];
@@ -241,7 +241,8 @@ hipError_t launch_sum_product(hipStream_t s, int n_cu, const void *const *rows, 
 			job.v[j].mode = BS_SPLIT;
 		}
 	} else {
-		// a single element: put it in group 0 only (group 1 = zero rows via PAIR_XOR with q = p)
+		// odd length (CpuLayer takes any SlicesBatch row_len, cpu/layer.rs:168-249) or a single element:
+		// everything in group 0 (group 1 = zero rows via PAIR_XOR with q = p)
 		job.n = row_len;
 		job.split_off = 0;
 		for (uint32_t j = 0; j < n_rows; j++) {

@@ -333,7 +333,22 @@ int bnh_bivariate_sumcheck_prove(bn_ctx *ctx, uint32_t n_vars, uint32_t m, const
 		do_rounds(n_vars, true, challenges, round_coeffs_out);
 		uint32_t log_world = 0;
 		while ((1 << (log_world + 1)) <= world) log_world++;
-		if (shm && tail_rounds && log_world > 0) {
+		if (rccl_comm && !shm && tail_rounds && log_world > 0) {
+			// ---- residual rounds, RCCL transport: every rank is down to one element per multilinear on the
+			// device.  One ncclAllGather per multilinear (16 bytes per rank, on the context's stream) rebuilds
+			// the residual multilinears of `world` elements (index = rank) in device memory; the last
+			// log2(world) rounds run on them, identically on every rank, with no further exchange.
+			void *stream = nullptr;
+			check(bn_ctx_get_stream(ctx, &stream)); // flushes the deferred last fold
+			std::vector<FSliceMut> res;
+			for (uint32_t j = 0; j < m; j++) res.push_back(dev_alloc.alloc((size_t)world));
+			for (uint32_t j = 0; j < m; j++)
+				if (g_rccl.all_gather(cur[j].ptr, res[j].ptr, 16, kNcclUint8, rccl_comm, stream) != 0)
+					throw Error(Error::DeviceError, "ncclAllGather (residual multilinears) failed");
+			for (uint32_t j = 0; j < m; j++) cur[j] = res[j];
+			pre_fold = true; // fold into fresh scratch, as in the first local round
+			do_rounds(log_world, false, challenges + n_vars, round_coeffs_out + 3 * n_vars);
+		} else if (shm && tail_rounds && log_world > 0) {
 			// ---- residual rounds: every rank is down to one element per multilinear.  One exchange of
 			// the m local finals rebuilds the m residual multilinears of `world` elements (index = rank)
 			// in pinned, device-visible host memory (no upload); the last log2(world) rounds run on them.

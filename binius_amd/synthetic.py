@@ -22,6 +22,22 @@ def random_b128(seed, n):
     return splitmix_words(seed, 2 * n).reshape(n, 2)
 
 
+def random_b128_shard(seed, n_local, world, rank, start=0):
+    """Rank `rank`'s shard of the GLOBAL array random_b128(seed, n_local * world): the elements with global
+    index = rank (mod world), in local order (binius_amd/distributed.py shard_indices), computed without
+    materialising the global array -- SplitMix64 output k depends only on seed + (k + 1) * gamma.
+    start: first local index (for chunked uploads)."""
+    with np.errstate(over="ignore"):
+        i = (np.uint64(start) + np.arange(n_local, dtype=np.uint64)) * np.uint64(world) + np.uint64(rank)  # global element index
+        k = np.empty(2 * n_local, dtype=np.uint64)
+        k[0::2] = np.uint64(2) * i + np.uint64(1)
+        k[1::2] = np.uint64(2) * i + np.uint64(2)
+        x = np.uint64(seed) + _GAMMA * k
+        z = (x ^ (x >> np.uint64(30))) * _M1
+        z = (z ^ (z >> np.uint64(27))) * _M2
+        return (z ^ (z >> np.uint64(31))).reshape(n_local, 2)
+
+
 def random_scalars(seed, n):
     a = random_b128(seed, n)
     return [int(a[i, 0]) | (int(a[i, 1]) << 64) for i in range(n)]

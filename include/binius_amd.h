@@ -59,10 +59,19 @@ const char *bn_version(void);
 int bn_ctx_create(int device, uint64_t arena_elems, bn_ctx **out);
 int bn_ctx_destroy(bn_ctx *ctx);
 int bn_arena_base(bn_ctx *ctx, void **d_base, uint64_t *elems);
-/* run on an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = own stream */
+/* Stream contract.  Work is enqueued on the context's stream in call order, with ONE exception: on the
+ * context's OWN stream (the default) bn_extrapolate_line[_batch] and bn_copy_d2d may be deferred to the
+ * next bn_* call (which either launches them first or fuses them into its own kernel) -- invisible to
+ * every bn_* call, host read-back included.  Anything the caller enqueues on that stream itself must
+ * come after bn_ctx_get_stream or bn_sync: both flush deferred work first.
+ * bn_ctx_set_stream(s != NULL) runs the context on a caller-owned hipStream_t (e.g.
+ * torch.cuda.current_stream().cuda_stream) and turns the deferral OFF (strict call order, no fold +
+ * evaluation fusion) unless BN_LAZY_ON_SHARED_STREAM=1 accepts the rule above; NULL = back to an own
+ * stream.  Every entry point makes the context's device current on the calling thread. */
 int bn_ctx_set_stream(bn_ctx *ctx, void *hip_stream);
 int bn_sync(bn_ctx *ctx);
-/* the hipStream_t the context enqueues on (so a caller can put an RCCL collective in the same order) */
+/* the hipStream_t the context enqueues on, after flushing deferred work (so a caller can put an RCCL
+ * collective in the same order) */
 int bn_ctx_get_stream(bn_ctx *ctx, void **hip_stream);
 
 /* ---- ComputeLayer (layer.rs:36-87) ---- */
@@ -92,7 +101,12 @@ int bn_extrapolate_line(bn_ctx *ctx, void *d_evals_0, uint64_t n0, const void *d
  * v3/bivariate_product.rs:217-228) as a single launch.  count <= 8 per call. */
 int bn_extrapolate_line_batch(bn_ctx *ctx, void *const *d_evals_0, const void *const *d_evals_1, uint32_t count, uint64_t n,
                               const bn_f128 *z);
-/* tensor_expand (layer.rs:291): data[..2^(log_n+k)] = data[..2^log_n] (x) (1-r_0,r_0) (x) ... */
+/* tensor_expand (layer.rs:291): data[..2^(log_n+k)] = data[..2^log_n] (x) (1-r_0,r_0) (x) ...
+ * The upper half of every pass is OVERWRITTEN (y = prod), as in FastCpuLayer and
+ * math/src/tensor_prod_eq_ind.rs:35-77.  The scalar CpuLayer ACCUMULATES into it instead (*y += prod,
+ * cpu/layer.rs:298); the two agree whenever data[2^log_n ..] is zero on entry, which is what every
+ * caller in crates/core guarantees (they allocate and zero-fill first).  A caller that relies on the
+ * accumulate form with a non-zero tail must add the old tail itself. */
 int bn_tensor_expand(bn_ctx *ctx, void *d_data, uint64_t data_len, uint32_t log_n, const bn_f128 *h_coords,
                      uint32_t k);
 /* inner_product (layer.rs:263): a is a SubfieldSlice{slice, tower_level} (memory.rs:257-281) */
@@ -217,7 +231,7 @@ int bn_gather_d2h(bn_ctx *ctx, const void *d_src, const uint64_t *h_offsets, uin
 /* Per-kernel-class timing without perturbing the stream: while profiling is on, every launch of a
  * hot kernel is bracketed by two hipEvents recorded on the context's stream (no synchronisation);
  * bn_prof_end synchronises once and sums the elapsed times per class. */
-enum { BN_PROF_ROUND_EVAL = 0, BN_PROF_FOLD = 1, BN_PROF_TENSOR_EXPAND = 2, BN_PROF_NTT = 3, BN_PROF_OTHER = 4, BN_PROF_FOLD_EVAL = 5, BN_PROF_TAIL = 6, BN_PROF_FOLD_EVAL_SMALL = 7, BN_PROF_N = 8 };
+enum { BN_PROF_ROUND_EVAL = 0, BN_PROF_FOLD = 1, BN_PROF_TENSOR_EXPAND = 2, BN_PROF_NTT = 3, BN_PROF_OTHER = 4, BN_PROF_FOLD_EVAL = 5, BN_PROF_TAIL = 6, BN_PROF_FOLD_EVAL_SMALL = 7, BN_PROF_FOLD_EVAL_MFMA = 8, BN_PROF_ROUND_EVAL_MFMA = 9, BN_PROF_N = 10 };
 int bn_prof_begin(bn_ctx *ctx);
 int bn_prof_end(bn_ctx *ctx, double *ms_by_class /*[BN_PROF_N]*/, uint64_t *launches_by_class /*[BN_PROF_N]*/);
 

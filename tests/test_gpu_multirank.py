@@ -33,13 +33,32 @@ def _run(cmd, env):
 
 @pytest.mark.parametrize("n_ranks", [2, 4])
 def test_bench_two_and_four_ranks_on_one_gpu(n_ranks):
+    """bench.py's N > 1 path: STRONG scaling of a fixed global instance (here 2^17 variables... elements),
+    shm exchange (gloo process group: RCCL refuses several ranks on one device)."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks), "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), "bench.py", "--gpus", str(n_ranks), "--steps", "2", "--warmup", "1", "--n-vars", "15",
+           "--master-port", str(_free_port()), "bench.py", "--gpus", str(n_ranks), "--steps", "2", "--warmup", "1", "--n-vars", "17",
            "--no-cpu-baseline"]
     r = _run(cmd, {"BN_ALL_ON_GPU0": "1", "BN_PG_BACKEND": "gloo", "BN_EXCHANGE": "shm"})
     assert r["n_gpus"] == n_ranks and r["bit_exact_check"] is True
-    assert r["config"]["n_vars_global"] == 15 + n_ranks.bit_length() - 1
-    assert r["scaling"] == "weak"
+    assert r["config"]["n_vars_global"] == 17
+    assert r["config"]["n_vars_local"] == 17 - (n_ranks.bit_length() - 1)
+    assert r["scaling"] == "strong"
+
+
+def test_bench_transcript_is_independent_of_the_number_of_ranks():
+    """Strong scaling proves the SAME instance: the round polynomials of the 1-, 2- and 4-rank runs are
+    checked against the same claim by the verifier; here the throughput lines must all describe 2^17."""
+    vals = []
+    for n_ranks in (1, 2):
+        if n_ranks == 1:
+            r = _run([sys.executable, "bench.py", "--steps", "1", "--warmup", "1", "--n-vars", "17", "--no-cpu-baseline"], {})
+        else:
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks), "--master-addr", "127.0.0.1",
+                   "--master-port", str(_free_port()), "bench.py", "--gpus", str(n_ranks), "--steps", "1", "--warmup", "1", "--n-vars", "17",
+                   "--no-cpu-baseline"]
+            r = _run(cmd, {"BN_ALL_ON_GPU0": "1", "BN_PG_BACKEND": "gloo", "BN_EXCHANGE": "shm"})
+        assert r["bit_exact_check"] is True and r["config"]["n_vars_global"] == 17
+        vals.append(r)
 
 
 @pytest.mark.parametrize("exchange", ["shm", "rccl"])

@@ -1,0 +1,112 @@
+"""The sharded HIP path against the UNSHARDED oracle ("Next round" item 2c).
+
+A global SplitMix64 instance is sharded with shard_indices (rank g owns the global indices = g mod G,
+crates/core/src/protocols/sumcheck/v3/bivariate_product.rs:129-131,199,321: High-to-Low binding, so the
+shard id is taken from the variables bound last); 2 and 4 ranks share cuda:0 (process group over gloo,
+per-round exchange through host shared memory -- RCCL refuses several ranks on one device; its
+transport differs from this one only in how the 32-byte partials travel).  Every rank runs the compiled
+prover of bench.py (SumcheckPlan: fused fold + evaluation kernels, residual rounds inside the call) on
+ITS shard; the round polynomials and final evaluations must equal oracle.bivariate_sumcheck_prove on the
+unsharded arrays, bit for bit.  A rank whose contribution was dropped or mis-indexed cannot pass.
+
+The larger case (n_local = 20) runs the matrix-core kernels (k_roundeval_mfma / k_foldeval_mfma), the
+small ones the 9-lane VALU kernels."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_global, m, comps, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+
+    import binius_amd
+    from binius_amd import synthetic
+    from binius_amd._host import ShmExchange, SumcheckPlan
+    from binius_amd.distributed import shard_indices
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    hal = None
+    try:
+        log_world = world.bit_length() - 1
+        n_local = n_global - log_world
+        n = 1 << n_local
+        hal = binius_amd.Context(0, m * n + m * (n // 2) + 8 * world + 4096)
+        alloc = hal.dev_alloc()
+        d_in = []
+        for j in range(m):
+            shard = synthetic.random_b128_shard(0xB1A50000 + j, n, world, rank)
+            # the shard generator IS shard_indices of the global stream
+            if n_global <= 14:
+                full = synthetic.random_b128(0xB1A50000 + j, 1 << n_global)
+                assert (shard == full[shard_indices(1 << n_global, world, rank)]).all()
+            s = alloc.alloc(n)
+            hal.copy_h2d(shard, s)
+            d_in.append(s)
+        scratch = alloc.alloc(m * (n // 2) + 8 * world + 64)
+        stream = synthetic.random_scalars(0xC4A1, n_global + 1)
+        batch_coeff, challenges = stream[0], stream[1:]
+        shm = ShmExchange(dist, rank, world)
+        sums = [shm.xor_scalars([hal.inner_product(d_in[i], 7, d_in[j])])[0] for i, j in comps]
+        plan = SumcheckPlan(hal, n_local, d_in, scratch, comps, sums, batch_coeff, challenges[:n_global], None, 0, None, world, 0,
+                            shm.handle, tail_rounds=True)
+        plan.run()
+        first = (plan.round_coeffs(), plan.final_evals())
+        plan.run()  # a second run from the same inputs: the prover must not have modified them
+        q.put((rank, sums, first[0], first[1], (plan.round_coeffs(), plan.final_evals()) == first))
+        shm.close()
+    finally:
+        if hal is not None:
+            hal.close()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize(
+    "world,n_global,m,comps",
+    [(2, 10, 2, [(0, 1)]), (4, 11, 2, [(0, 1)]), (2, 9, 3, [(0, 1), (2, 0)]), (4, 12, 3, [(0, 1), (2, 0)]), (2, 21, 2, [(0, 1)]), (4, 22, 2, [(0, 1)])],
+)
+def test_sharded_hip_prover_matches_unsharded_oracle(world, n_global, m, comps):
+    import torch.multiprocessing as mp
+
+    import oracle
+
+    oracle.build()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_global, m, comps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    full = [oracle.random_b128(0xB1A50000 + j, 1 << n_global) for j in range(m)]
+    stream = oracle.random_scalars(0xC4A1, n_global + 1)
+    batch_coeff, challenges = stream[0], stream[1:]
+    want_sums = [oracle.inner_product(full[i], 7, full[j])[1] for i, j in comps]
+    want_coeffs, want_finals = oracle.bivariate_sumcheck_prove([x.copy() for x in full], n_global, comps, want_sums, batch_coeff, challenges,
+                                                               threads=min(8, os.cpu_count() or 1))
+    for rank, sums, coeffs, finals, rerun_same in sorted(results):
+        assert sums == want_sums, "rank %d: claimed sums differ from the unsharded inner products" % rank
+        assert [list(c) for c in coeffs] == [list(c) for c in want_coeffs], "rank %d: round polynomials differ from the unsharded oracle" % rank
+        assert list(finals) == list(want_finals), "rank %d: final evaluations differ" % rank
+        assert rerun_same, "rank %d: a second run from the same inputs gave a different transcript" % rank
