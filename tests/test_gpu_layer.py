@@ -213,7 +213,7 @@ def test_inner_product_validation(hal):
 
 
 # ---- test_generic_single_left_fold / right_fold (layer.rs:572-724)
-@pytest.mark.parametrize("level", [0, 3, 4, 5, 7])
+@pytest.mark.parametrize("level", [0, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("log_q", [1, 3])
 @pytest.mark.parametrize("left", [True, False])
 def test_fold_left_right(hal, oracle, level, log_q, left):
