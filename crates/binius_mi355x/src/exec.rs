@@ -135,7 +135,7 @@ impl<'a> Mi355xExec<'a> {
 	fn launch_recorded<R>(
 		&mut self,
 		mem_maps: &[KernelMemMap<'_, B128, Mi355xMemory>],
-		record: impl FnOnce(&mut Recorder, usize, Vec<KernelBuffer<'_, B128, RecMem>>) -> Result<R, Error>,
+		record: impl for<'k> FnOnce(&'k mut Recorder, usize, Vec<KernelBuffer<'k, B128, RecMem>>) -> Result<R, Error>,
 		ret_ids: impl FnOnce(&R) -> Vec<u32>,
 	) -> Result<Vec<B128>, Error> {
 		self.flush_lines()?;
