@@ -1,0 +1,97 @@
+// binius_amd/csrc/abi_common.hpp -- pieces shared by the translation units of the extern "C" boundary
+// (abi.cpp: context, copies, deferral; abi_kernels.cpp: the recorded-kernel dispatcher; abi_ops.cpp: the
+// executor ops, Merkle and NTT entry points).  Not part of the public interface.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "internal.hpp"
+
+using bn::f128;
+
+// brackets the launches issued in its scope with two events when profiling is on
+struct prof_scope {
+	bn_ctx *ctx;
+	int idx = -1;
+	prof_scope(bn_ctx *c, int cls) : ctx(c)
+	{
+		if (!c->prof_on) return;
+		auto get = [&]() {
+			hipEvent_t e = nullptr;
+			if (!c->ev_pool.empty()) {
+				e = c->ev_pool.back();
+				c->ev_pool.pop_back();
+			} else {
+				hipEventCreateWithFlags(&e, hipEventDisableSystemFence);
+			}
+			return e;
+		};
+		bn_ctx::prof_rec r{cls, get(), get()};
+		hipEventRecord(r.a, c->stream);
+		c->prof.push_back(r);
+		idx = (int)c->prof.size() - 1;
+	}
+	~prof_scope()
+	{
+		if (idx >= 0) hipEventRecord(ctx->prof[idx].b, ctx->stream);
+	}
+};
+
+#define BN_REQUIRE(cond, msg)                                                  \
+	do {                                                                       \
+		if (!(cond))                                                           \
+			return bn::fail(BN_ERR_INPUT_VALIDATION, std::string("input validation: ") + (msg)); \
+	} while (0)
+
+
+namespace bnabi {
+// ---- deferral machinery (defined in abi.cpp)
+int flush_copies(bn_ctx *ctx);
+int flush_pending(bn_ctx *ctx, bool keep_tail = false, bool publish_tiny = false);
+int tail_cancel(bn_ctx *ctx);
+std::vector<unsigned char> recipe_bytes(const bn::fin_args &a);
+// resident tail kernel: command / status words in the pinned mailbox
+inline volatile uint64_t *tail_cmd(bn_ctx *ctx) { return &ctx->h_mail[80].lo; }
+inline volatile uint64_t *tail_status(bn_ctx *ctx) { return &ctx->h_mail[82].lo; }
+// ---- small helpers shared by the op entry points (abi.cpp)
+int publish_result(bn_ctx *ctx, uint32_t n_groups, bn_f128 *h_out);
+int upload_ptrs(bn_ctx *ctx, const void *const *ptrs, uint32_t n, const void ***d_ptrs);
+int ensure_d_steps(const bn_expr *e);
+} // namespace bnabi
+using namespace bnabi;
+
+// Every entry point also makes the context's device current on the calling thread: scratch buffers, NTT
+// tables and pinned staging are allocated lazily inside calls, and a worker thread (or a process that
+// drives several GPUs) would otherwise put them on whatever device that thread last used.
+struct bn_enter_guard {
+	std::lock_guard<std::recursive_mutex> lock;
+	explicit bn_enter_guard(bn_ctx *c) : lock(c->mu) { (void)hipSetDevice(c->device); }
+};
+#define BN_ENTER(ctx) bn_enter_guard bn_enter_lock_(ctx)
+#define BN_FLUSH(ctx)                    \
+	do {                                 \
+		int rc_ = flush_pending(ctx);    \
+		(ctx)->mirror.valid = false;     \
+		if (rc_) return rc_;             \
+	} while (0)
+
+static inline bool is_pow2(uint64_t n) { return n && !(n & (n - 1)); }
+static inline uint32_t ilog2(uint64_t n)
+{
+	uint32_t l = 0;
+	while (n > 1) {
+		n >>= 1;
+		l++;
+	}
+	return l;
+}
+static inline f128 to_f(const bn_f128 *p) { return f128{p->lo, p->hi}; }
+static inline bool valid_tower_level(uint32_t l) { return l == 0 || (l >= 3 && l <= 7); } // tower_macro.rs:9-15

@@ -1,0 +1,579 @@
+// binius_amd/csrc/abi_kernels.cpp -- the recorded-kernel dispatcher behind accumulate_kernels / map_kernels
+// (bn_kernel_launch): validates the op list, recognises the round-evaluation shapes, decides between the
+// fused fold + evaluation kernels (matrix-core or 9-lane), the resident tail and the generic forms, and
+// finalizes on the device.  Also log_chunks_range / pick_log_chunks and the device XOR of gathered partials.
+#include "abi_common.hpp"
+
+extern "C" {
+
+// ---------------------------------------------------------------------------------- kernels
+static uint32_t map_log_len(const bn_memmap &m) { return m.kind == BN_MAP_LOCAL ? m.log_size : ilog2(m.len); }
+
+int bn_log_chunks_range(const bn_memmap *maps, uint32_t n_maps, uint32_t *start, uint32_t *end)
+{
+	BN_REQUIRE(maps && n_maps > 0 && start && end, "log_chunks_range needs at least one mapping");
+	uint32_t e = ~0u;
+	for (uint32_t i = 0; i < n_maps; i++) {
+		uint32_t hi;
+		if (maps[i].kind == BN_MAP_LOCAL) {
+			hi = maps[i].log_size;
+		} else {
+			BN_REQUIRE(is_pow2(maps[i].len), "mapped buffer length must be a power of two");
+			uint32_t log_data = ilog2(maps[i].len);
+			uint32_t lm = maps[i].log_min_chunk_size; // max(.., log2 ALIGNMENT = 0)
+			if (lm > log_data) lm = log_data;
+			hi = log_data - lm;
+		}
+		if (hi < e) e = hi;
+	}
+	*start = 0;
+	*end = e;
+	return BN_OK;
+}
+
+int bn_pick_log_chunks(const bn_memmap *maps, uint32_t n_maps, uint32_t *log_chunks)
+{
+	uint32_t s, e;
+	int rc = bn_log_chunks_range(maps, n_maps, &s, &e);
+	if (rc) return rc;
+	// One logical chunk: the grid itself is the parallel decomposition and the cross-workgroup
+	// XOR reduction is done on the device, so the closure is recorded once over whole buffers.
+	*log_chunks = s;
+	return BN_OK;
+}
+
+namespace {
+// how a kernel-buffer slice is realised on the device
+struct slice_view {
+	const char *p = nullptr; // direct data
+	const char *q = nullptr; // if non-null: value = p ^ q (a Local buffer defined by ADD and not materialised)
+	bool zero = false;       // untouched Local buffer
+	uint64_t len = 0;
+};
+} // namespace
+
+int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const bn_kop *ops, uint32_t n_ops,
+                     const uint32_t *ret_values, uint32_t n_ret, uint32_t log_chunks, bn_f128 *h_out, void *d_out)
+{
+	BN_REQUIRE(ctx && maps && n_maps > 0, "kernel launch needs at least one mapping");
+	BN_ENTER(ctx);
+	uint32_t lo_c, hi_c;
+	int rc = bn_log_chunks_range(maps, n_maps, &lo_c, &hi_c);
+	if (rc) return rc;
+	BN_REQUIRE(log_chunks == 0, "this backend records kernels with log_chunks = bn_pick_log_chunks() = 0");
+	BN_REQUIRE(n_ret <= 64, "too many returned values");
+	hipStream_t s = ctx->stream;
+
+	// A deferred fold survives into this launch only if the kernel has the calculate_round_evals
+	// shape (two bivariate-product sums, Local "lo + hi" operands, nothing written to memory); the
+	// launch site below then checks that it reads exactly the folded arrays.
+	if (!ctx->pend.active) BN_FLUSH(ctx); // (deferred copies; a parked tail kernel without a fold to run)
+	if (ctx->pend.active) {
+		uint32_t n_sum = 0;
+		bool pure = n_ret > 0 && ctx->pend.count == 2;
+		for (uint32_t o = 0; o < n_ops && pure; o++) {
+			const bn_kop &op = ops[o];
+			if (op.kind == BN_KOP_SUM_COMPOSITION) {
+				n_sum++;
+				if (!op.expr || op.expr->shape != bn_expr::PRODUCT || op.expr->product_vars.size() != 2) pure = false;
+			} else if (op.kind == BN_KOP_ADD) {
+				if (op.dst.buf >= n_maps || maps[op.dst.buf].kind != BN_MAP_LOCAL) pure = false;
+			} else if (op.kind != BN_KOP_DECL_VALUE) {
+				pure = false;
+			}
+		}
+		if (!pure || n_sum != 2) BN_FLUSH(ctx);
+	}
+
+	// Local buffers are virtual until something forces them into memory.
+	struct local_state {
+		bool defined = false;           // written by an ADD covering the whole buffer
+		const char *p = nullptr, *q = nullptr;
+		char *mem = nullptr;            // materialised storage
+	};
+	std::vector<local_state> loc(n_maps);
+	std::vector<uint64_t> buf_len(n_maps);
+	size_t local_bytes = 0;
+	for (uint32_t i = 0; i < n_maps; i++) {
+		buf_len[i] = maps[i].kind == BN_MAP_LOCAL ? ((uint64_t)1 << maps[i].log_size) : maps[i].len;
+		if (maps[i].kind == BN_MAP_LOCAL) local_bytes += buf_len[i] * sizeof(f128);
+	}
+	(void)map_log_len;
+
+	// Do we need real memory for Local buffers?  Only if a Local is read/written in a way the
+	// virtual form cannot express (partial slices, ADD_ASSIGN into it, ADD of virtual operands).
+	bool need_materialise = false;
+	for (uint32_t o = 0; o < n_ops && !need_materialise; o++) {
+		const bn_kop &op = ops[o];
+		auto whole = [&](const bn_kslice &sl) { return sl.off == 0 && sl.len == buf_len[sl.buf]; };
+		if (op.kind == BN_KOP_ADD) {
+			BN_REQUIRE(op.dst.buf < n_maps && op.src1.buf < n_maps && op.src2.buf < n_maps, "slice refers to an unknown buffer");
+			if (maps[op.dst.buf].kind == BN_MAP_LOCAL) {
+				if (!whole(op.dst) || maps[op.src1.buf].kind == BN_MAP_LOCAL || maps[op.src2.buf].kind == BN_MAP_LOCAL)
+					need_materialise = true;
+			}
+		} else if (op.kind == BN_KOP_ADD_ASSIGN) {
+			BN_REQUIRE(op.dst.buf < n_maps && op.src1.buf < n_maps, "slice refers to an unknown buffer");
+			if (maps[op.dst.buf].kind == BN_MAP_LOCAL || maps[op.src1.buf].kind == BN_MAP_LOCAL)
+				need_materialise = true;
+		} else if (op.kind == BN_KOP_SUM_COMPOSITION) {
+			BN_REQUIRE(op.expr, "sum_composition_evals without a compiled expression");
+			for (uint32_t r = 0; r < op.n_rows; r++) {
+				BN_REQUIRE(op.rows[r].buf < n_maps, "slice refers to an unknown buffer");
+				if (maps[op.rows[r].buf].kind == BN_MAP_LOCAL && !whole(op.rows[r]))
+					need_materialise = true;
+			}
+			if (op.expr->shape != bn_expr::PRODUCT)
+				for (uint32_t r = 0; r < op.n_rows; r++)
+					if (maps[op.rows[r].buf].kind == BN_MAP_LOCAL)
+						need_materialise = true;
+		}
+	}
+	if (need_materialise && local_bytes) {
+		char *mem = (char *)bn::ctx_scratch(ctx, local_bytes);
+		if (!mem)
+			return bn::fail(BN_ERR_ALLOC, "allocation error: allocator is out of memory (Local kernel buffers)");
+		BN_HIP(hipMemsetAsync(mem, 0, local_bytes, s)); // "initialized with zeros", layer.rs:154-156
+		size_t off = 0;
+		for (uint32_t i = 0; i < n_maps; i++)
+			if (maps[i].kind == BN_MAP_LOCAL) {
+				loc[i].mem = mem + off;
+				off += buf_len[i] * sizeof(f128);
+			}
+	}
+
+	auto view = [&](const bn_kslice &sl) -> slice_view {
+		slice_view v;
+		v.len = sl.len;
+		const bn_memmap &m = maps[sl.buf];
+		if (m.kind != BN_MAP_LOCAL) {
+			v.p = (const char *)m.d_data + sl.off * sizeof(f128);
+		} else if (loc[sl.buf].mem) {
+			v.p = loc[sl.buf].mem + sl.off * sizeof(f128);
+		} else if (loc[sl.buf].defined) {
+			v.p = loc[sl.buf].p;
+			v.q = loc[sl.buf].q;
+		} else {
+			v.zero = true;
+		}
+		return v;
+	};
+
+	// device accumulators: S slots in the mailbox [0, 64), values in [64, 128)
+	uint32_t n_values = 0;
+	for (uint32_t o = 0; o < n_ops; o++)
+		if (ops[o].kind == BN_KOP_DECL_VALUE && ops[o].value + 1 > n_values) n_values = ops[o].value + 1;
+	BN_REQUIRE(n_values <= (uint32_t)bn::kFinMaxValues, "too many kernel values");
+	for (uint32_t i = 0; i < n_ret; i++)
+		BN_REQUIRE(ret_values[i] < n_values, "returned value was never declared");
+	std::vector<f128> h_values(n_values ? n_values : 1, bn::f128_zero());
+	std::vector<bn::fin_term> terms;
+	uint32_t n_slots = 0;
+	bool finalized_in_kernel = false;
+	uint64_t fused_seq = 0;
+	f128 *d_S = ctx->d_result;         // [0,64)
+	f128 *d_rets = ctx->d_result + 96;  // [96,128)
+	bool has_sum = false;
+	for (uint32_t o = 0; o < n_ops; o++) has_sum |= ops[o].kind == BN_KOP_SUM_COMPOSITION;
+	if (!ctx->s_clean && has_sum) {
+		BN_HIP(hipMemsetAsync(d_S, 0, 64 * sizeof(f128), s));
+		ctx->s_clean = true;
+	}
+	const bool was_clean_or_zeroed = ctx->s_clean;
+	ctx->s_clean = false; // until the finalize kernel of THIS call has re-zeroed the slots it used
+
+	for (uint32_t o = 0; o < n_ops; o++) {
+		const bn_kop &op = ops[o];
+		switch (op.kind) {
+		case BN_KOP_DECL_VALUE:
+			h_values[op.value] = f128{op.scalar.lo, op.scalar.hi};
+			break;
+		case BN_KOP_ADD: {
+			BN_REQUIRE(maps[op.dst.buf].kind != BN_MAP_CHUNKED, "add: destination buffer is read-only");
+			BN_REQUIRE(op.src1.len == op.dst.len && op.src2.len == op.dst.len, "add: slice lengths differ");
+			BN_REQUIRE(op.dst.off + op.dst.len <= buf_len[op.dst.buf] && op.src1.off + op.src1.len <= buf_len[op.src1.buf] &&
+			               op.src2.off + op.src2.len <= buf_len[op.src2.buf],
+			           "add: slice out of range");
+			if (maps[op.dst.buf].kind == BN_MAP_LOCAL && !loc[op.dst.buf].mem) {
+				// virtual definition: dst := src1 ^ src2 (never touches HBM)
+				slice_view a = view(op.src1), b = view(op.src2);
+				loc[op.dst.buf].defined = true;
+				loc[op.dst.buf].p = a.p;
+				loc[op.dst.buf].q = b.p;
+			} else {
+				slice_view a = view(op.src1), b = view(op.src2), d = view(op.dst);
+				BN_REQUIRE(!a.q && !b.q && !a.zero && !b.zero, "add: unsupported operand form");
+				BN_HIP(bn::launch_add(s, (void *)d.p, a.p, b.p, op.dst.len));
+			}
+			break;
+		}
+		case BN_KOP_ADD_ASSIGN: {
+			BN_REQUIRE(maps[op.dst.buf].kind != BN_MAP_CHUNKED, "add_assign: destination buffer is read-only");
+			BN_REQUIRE(op.src1.len == op.dst.len, "add_assign: slice lengths differ");
+			BN_REQUIRE(op.dst.off + op.dst.len <= buf_len[op.dst.buf] && op.src1.off + op.src1.len <= buf_len[op.src1.buf],
+			           "add_assign: slice out of range");
+			slice_view a = view(op.src1), d = view(op.dst);
+			BN_REQUIRE(!a.q && !a.zero && !d.q && !d.zero, "add_assign: unsupported operand form");
+			BN_HIP(bn::launch_add_assign(s, (void *)d.p, a.p, op.dst.len));
+			break;
+		}
+		case BN_KOP_SUM_COMPOSITION: {
+			BN_REQUIRE(op.value < n_values, "sum_composition_evals: accumulator was never declared");
+			BN_REQUIRE(op.n_rows >= op.expr->n_vars, "composition does not match the number of input rows");
+			BN_REQUIRE(op.expr->steps.size() <= 64, "circuit too large for this backend (max 64 steps)");
+			const uint64_t row_len = op.n_rows ? op.rows[0].len : 0;
+			for (uint32_t r = 0; r < op.n_rows; r++) {
+				BN_REQUIRE(op.rows[r].len == row_len, "sum_composition_evals: rows differ in length");
+				BN_REQUIRE(op.rows[r].off + op.rows[r].len <= buf_len[op.rows[r].buf], "sum_composition_evals: slice out of range");
+			}
+			BN_REQUIRE(n_slots + 2 <= 64, "too many sum_composition_evals in one kernel");
+			const uint32_t slot = n_slots;
+			if (op.expr->shape == bn_expr::PRODUCT) {
+				// fused pairing: if the NEXT sum op uses the same expression and its factors are the
+				// "infinity" versions (Local = lo + hi with hi == this op's row) of this op's factors,
+				// do both with one pass over the data.
+				const uint32_t k = (uint32_t)op.expr->product_vars.size();
+				const void *hi[4] = {nullptr, nullptr, nullptr, nullptr}, *lo[4] = {nullptr, nullptr, nullptr, nullptr};
+				bool direct = true;
+				std::vector<slice_view> fv(k);
+				for (uint32_t j = 0; j < k; j++) {
+					fv[j] = view(op.rows[op.expr->product_vars[j]]);
+					if (fv[j].q || fv[j].zero) direct = false;
+				}
+				// look ahead for the partner op (skipping ADD ops that define Locals and DECLs)
+				int partner = -1;
+				if (direct) {
+					for (uint32_t o2 = o + 1; o2 < n_ops; o2++) {
+						if (ops[o2].kind == BN_KOP_SUM_COMPOSITION) {
+							if (ops[o2].expr == op.expr && ops[o2].n_rows == op.n_rows) partner = (int)o2;
+							break;
+						}
+						if (ops[o2].kind == BN_KOP_ADD_ASSIGN) break;
+					}
+				}
+				bool fused = false;
+				if (partner >= 0) {
+					// evaluate the intervening ADD / DECL ops now (they only define virtual Locals)
+					bool ok = true;
+					for (uint32_t o2 = o + 1; o2 < (uint32_t)partner && ok; o2++) {
+						const bn_kop &mid = ops[o2];
+						if (mid.kind == BN_KOP_DECL_VALUE) continue;
+						if (mid.kind != BN_KOP_ADD || maps[mid.dst.buf].kind != BN_MAP_LOCAL || loc[mid.dst.buf].mem) ok = false;
+					}
+					if (ok) {
+						// tentatively compute partner views
+						std::vector<local_state> saved = loc;
+						for (uint32_t o2 = o + 1; o2 < (uint32_t)partner; o2++) {
+							const bn_kop &mid = ops[o2];
+							if (mid.kind != BN_KOP_ADD) continue;
+							slice_view a = view(mid.src1), b = view(mid.src2);
+							if (a.q || b.q || a.zero || b.zero) { ok = false; break; }
+							loc[mid.dst.buf].defined = true;
+							loc[mid.dst.buf].p = a.p;
+							loc[mid.dst.buf].q = b.p;
+						}
+						const bn_kop &pop = ops[partner];
+						for (uint32_t j = 0; j < k && ok; j++) {
+							slice_view pv = view(pop.rows[op.expr->product_vars[j]]);
+							if (pv.len != row_len || pv.zero) { ok = false; break; }
+							hi[j] = fv[j].p;
+							if (!pv.q && pv.p == fv[j].p) {
+								lo[j] = nullptr; // same factor at both points
+							} else if (pv.q && pv.q == fv[j].p) {
+								lo[j] = pv.p;    // Local = lo + hi
+							} else if (pv.q && pv.p == fv[j].p) {
+								lo[j] = pv.q;
+							} else {
+								ok = false;
+							}
+						}
+						if (ok) {
+							BN_REQUIRE(n_slots + 2 <= 64, "too many sum_composition_evals in one kernel");
+							const bn_kop &pop2 = ops[partner];
+							BN_REQUIRE(pop2.value < n_values, "sum_composition_evals: accumulator was never declared");
+							// DECLs between the two ops
+							for (uint32_t o2 = o + 1; o2 < (uint32_t)partner; o2++)
+								if (ops[o2].kind == BN_KOP_DECL_VALUE)
+									h_values[ops[o2].value] = f128{ops[o2].scalar.lo, ops[o2].scalar.hi};
+							terms.push_back(bn::fin_term{op.value, slot, f128{op.scalar.lo, op.scalar.hi}});
+							terms.push_back(bn::fin_term{pop2.value, slot + 1, f128{pop2.scalar.lo, pop2.scalar.hi}});
+							// If this pair is the whole kernel (the calculate_round_evals shape), the finalize
+							// step rides in the same launch: the last workgroup folds and publishes the values.
+							bool in_kernel = false;
+							if ((uint32_t)partner + 1 == n_ops && n_slots == 0 && n_ret > 0 && n_ret <= (uint32_t)bn::kFinMaxRets &&
+							    n_values <= (uint32_t)bn::kFinMaxValues) {
+								bn::fin_fuse fz{};
+								fz.args.n_terms = 2;
+								fz.args.n_values = n_values;
+								fz.args.n_ret = n_ret;
+								fz.args.n_slots = 2;
+								fz.args.seq = h_out ? ++ctx->mail_seq : 0;
+								fz.args.terms[0] = terms[terms.size() - 2];
+								fz.args.terms[1] = terms[terms.size() - 1];
+								for (uint32_t v = 0; v < n_values; v++) fz.args.init[v] = h_values[v];
+								for (uint32_t r = 0; r < n_ret; r++) fz.args.ret_ids[r] = ret_values[r];
+								fz.S = d_S;
+								fz.rets = d_out ? (f128 *)d_out : d_rets;
+								fz.mail = ctx->d_mail;
+								fz.counter = ctx->d_ticket;
+								hipError_t fe = hipErrorNotSupported;
+								if (ctx->pend.active) {
+									// fold + evaluate in one pass: this launch reads the halves of exactly the two
+									// arrays the deferred fold writes (evals_1 directly behind evals_0, in place)
+									const bn_ctx::pending_fold &pf = ctx->pend;
+									auto reads_folded = [&](uint32_t j, uint32_t i) {
+										return lo[j] == pf.x0[i] && (const char *)hi[j] == (const char *)lo[j] + row_len * sizeof(f128);
+									};
+									int perm = -1;
+									if (k == 2 && pf.n == 2 * row_len && pf.x0[0] != pf.x0[1] && lo[0] && lo[1]) {
+										if (reads_folded(0, 0) && reads_folded(1, 1)) perm = 0;
+										else if (reads_folded(0, 1) && reads_folded(1, 0)) perm = 1;
+									}
+									if (perm >= 0) {
+										bn::foldeval_args fa{};
+										for (uint32_t j = 0; j < 2; j++) {
+											const uint32_t i = perm ? 1 - j : j;
+											fa.x0[j] = pf.src0[i];
+											fa.x1[j] = pf.x1[i];
+											fa.out[j] = pf.x0[i];
+										}
+										const uint64_t n_in = 2 * pf.n;
+										// (a) a resident tail kernel is parked for exactly this round: hand it z
+										if (ctx->tail.active) {
+											bn_ctx::tail_state &tl = ctx->tail;
+											const bool same = h_out && !d_out && n_in == tl.n_in_next && fa.x0[0] == fa.out[0] && fa.x0[1] == fa.out[1] &&
+											                  ((fa.out[0] == tl.out[0] && fa.out[1] == tl.out[1]) || (fa.out[0] == tl.out[1] && fa.out[1] == tl.out[0])) &&
+											                  fz.args.seq == tl.seq0 + tl.round + 1 && recipe_bytes(fz.args) == tl.recipe &&
+											                  __atomic_load_n(tail_status(ctx), __ATOMIC_ACQUIRE) != tl.id;
+											if (same) {
+												tl.round++;
+												ctx->h_mail[81].lo = pf.z.lo;
+												ctx->h_mail[81].hi = pf.z.hi;
+												__atomic_store_n(tail_cmd(ctx), (tl.id << 20) | tl.round, __ATOMIC_RELEASE);
+												volatile uint64_t *seqw = &ctx->h_mail[64].lo;
+												bool got = false;
+												for (uint64_t spins = 0;; spins++) {
+													if (__atomic_load_n(seqw, __ATOMIC_ACQUIRE) == fz.args.seq) { got = true; break; }
+													if (__atomic_load_n(tail_status(ctx), __ATOMIC_ACQUIRE) == tl.id) {
+														// the kernel left (bounded spin ran out) -- did it answer first?
+														got = __atomic_load_n(seqw, __ATOMIC_ACQUIRE) == fz.args.seq;
+														break;
+													}
+													if (spins > (1ull << 26)) {
+														// neither word moves: the kernel faulted or the device hangs.  Same fallback as
+														// the other mailbox waits: let the stream report it.
+														tl.active = false;
+														BN_HIP(hipStreamSynchronize(s));
+														return bn::fail(BN_ERR_DEVICE, "device error: resident tail kernel stopped answering");
+													}
+												}
+												if (got) {
+													for (uint32_t r = 0; r < n_ret; r++) {
+														h_out[r].lo = __atomic_load_n(&ctx->h_mail[r].lo, __ATOMIC_RELAXED);
+														h_out[r].hi = __atomic_load_n(&ctx->h_mail[r].hi, __ATOMIC_RELAXED);
+													}
+													ctx->pend.active = false;
+													tl.n_in_next = n_in >> 1;
+													if (n_in <= 4) tl.active = false; // it has just run its last round and exits
+													ctx->s_clean = true;
+													return BN_OK;
+												}
+												tl.active = false; // gone without doing this round: run it the normal way
+												BN_HIP(hipStreamSynchronize(s));
+											} else {
+												rc = tail_cancel(ctx);
+												if (rc) return rc;
+											}
+										}
+										// (b) small arrays: start a resident tail kernel with this round
+										if (fe == hipErrorNotSupported && h_out && !d_out && ctx->tail_max_n_in && n_in <= ctx->tail_max_n_in && n_in >= 8) {
+											bn_ctx::tail_state &tl = ctx->tail;
+											const uint64_t id = ++ctx->tail_counter;
+											prof_scope ps(ctx, BN_PROF_TAIL);
+											fe = bn::launch_foldeval_tail(s, fa, n_in, pf.z, d_S + slot, fz, (const uint64_t *)&ctx->d_mail[80].lo,
+											                              (uint64_t *)&ctx->d_mail[82].lo, id);
+											if (fe == hipSuccess) {
+												tl.active = true;
+												tl.id = id;
+												tl.round = 0;
+												tl.n_in_next = n_in >> 1;
+												tl.out[0] = fa.out[0];
+												tl.out[1] = fa.out[1];
+												tl.seq0 = fz.args.seq;
+												tl.recipe = recipe_bytes(fz.args);
+												ctx->pend.active = false;
+											}
+										}
+										// (c) one fused kernel for this round
+										if (fe == hipErrorNotSupported) {
+											const bool mfma = bn::mfma_applies(ctx->n_cu, n_in >> 2);
+											prof_scope ps(ctx, mfma ? BN_PROF_FOLD_EVAL_MFMA : (bn::foldeval9_is_small(ctx->n_cu, n_in) ? BN_PROF_FOLD_EVAL_SMALL : BN_PROF_FOLD_EVAL));
+											fe = mfma ? bn::launch_foldeval_mfma(s, ctx->n_cu, fa, n_in, pf.z, d_S + slot, &fz)
+											          : bn::launch_foldeval9(s, ctx->n_cu, fa, n_in, pf.z, d_S + slot, &fz);
+											if (fe == hipSuccess) ctx->pend.active = false;
+										}
+									} else if (ctx->tail.active) {
+										rc = tail_cancel(ctx);
+										if (rc) return rc;
+									}
+									if (ctx->pend.active) BN_FLUSH(ctx);
+								}
+								if (fe == hipErrorNotSupported) {
+									prof_scope ps(ctx, k == 2 && bn::mfma_applies(ctx->n_cu, row_len) ? BN_PROF_ROUND_EVAL_MFMA : BN_PROF_ROUND_EVAL);
+									fe = bn::launch_roundeval_product(s, ctx->n_cu, hi, lo, k, row_len, d_S + slot, &fz);
+								}
+								if (fe == hipSuccess) {
+									in_kernel = true;
+									finalized_in_kernel = true;
+									fused_seq = fz.args.seq;
+								} else if (fe != hipErrorNotSupported) {
+									return bn::hip_fail(fe, "launch_roundeval_product (fused finalize)");
+								} else if (h_out) {
+									--ctx->mail_seq;
+								}
+							}
+							if (!in_kernel) {
+								BN_FLUSH(ctx);
+								prof_scope ps(ctx, BN_PROF_ROUND_EVAL);
+								BN_HIP(bn::launch_roundeval_product(s, ctx->n_cu, hi, lo, k, row_len, d_S + slot, nullptr));
+							}
+							n_slots += 2;
+							o = (uint32_t)partner; // consumed
+							fused = true;
+						} else {
+							loc = saved;
+						}
+					}
+				}
+				if (!fused) {
+					// single job: factors may be direct or virtual (p ^ q)
+					bool any_virtual = false;
+					for (uint32_t j = 0; j < k; j++)
+						if (fv[j].q) any_virtual = true;
+					bool any_zero = false;
+					for (uint32_t j = 0; j < k; j++)
+						if (fv[j].zero) any_zero = true;
+					if (any_zero || row_len == 0) {
+						// a factor is identically zero: contributes nothing
+					} else if (!any_virtual) {
+						BN_FLUSH(ctx);
+						const void *rows[4];
+						for (uint32_t j = 0; j < k; j++) rows[j] = fv[j].p;
+						BN_HIP(bn::launch_sum_product(s, ctx->n_cu, rows, k, row_len, d_S + slot));
+						terms.push_back(bn::fin_term{op.value, slot, f128{op.scalar.lo, op.scalar.hi}});
+						terms.push_back(bn::fin_term{op.value, slot + 1, f128{op.scalar.lo, op.scalar.hi}});
+					} else {
+						// "infinity" job alone: low group = p, high group = p ^ q; only the high sum is wanted
+						BN_FLUSH(ctx);
+						for (uint32_t j = 0; j < k; j++) {
+							hi[j] = fv[j].p;
+							lo[j] = fv[j].q; // nullptr => same at both
+						}
+						BN_HIP(bn::launch_roundeval_product(s, ctx->n_cu, hi, lo, k, row_len, d_S + slot, nullptr));
+						terms.push_back(bn::fin_term{op.value, slot + 1, f128{op.scalar.lo, op.scalar.hi}});
+					}
+					n_slots += 2;
+				}
+			} else {
+				// generic circuit: interpreter over materialised rows
+				std::vector<const void *> rows(op.n_rows);
+				for (uint32_t r = 0; r < op.n_rows; r++) {
+					slice_view v = view(op.rows[r]);
+					BN_REQUIRE(!v.q && !v.zero, "generic composition over an unmaterialised Local buffer");
+					rows[r] = v.p;
+				}
+				const void **d_ptrs = nullptr;
+				rc = upload_ptrs(ctx, rows.data(), op.n_rows, &d_ptrs);
+				if (rc) return rc;
+				rc = ensure_d_steps(op.expr);
+				if (rc) return rc;
+				BN_HIP(bn::launch_sum_composition_generic(s, ctx->n_cu, d_ptrs, op.n_rows, row_len, op.expr->d_steps,
+				                                          (uint32_t)op.expr->steps.size(), d_S + slot));
+				// the pointer table is reused by the next generic op: keep the stream ordered
+				BN_HIP(hipStreamSynchronize(s));
+				terms.push_back(bn::fin_term{op.value, slot, f128{op.scalar.lo, op.scalar.hi}});
+				n_slots += 2;
+			}
+			break;
+		}
+		default:
+			return bn::fail(BN_ERR_INPUT_VALIDATION, "input validation: unknown kernel op");
+		}
+	}
+
+	rc = flush_pending(ctx, /*keep_tail=*/true); // (a launch that ended up reading nothing)
+	if (rc) return rc;
+	if (n_ret == 0) {
+		if (n_slots == 0) ctx->s_clean = was_clean_or_zeroed; // no accumulator was touched by this launch
+		return BN_OK;
+	}
+
+	// finalize on device: values = init ^ sum coeff*S ; rets gathered into d_rets (and d_out).
+	// Everything the kernel needs travels as a by-value kernel argument (no staging copies).
+	BN_REQUIRE(terms.size() <= (size_t)bn::kFinMaxTerms, "kernel has too many sum_composition_evals terms");
+	BN_REQUIRE(n_values <= (uint32_t)bn::kFinMaxValues, "too many kernel values");
+	BN_REQUIRE(n_ret <= (uint32_t)bn::kFinMaxRets, "too many returned values");
+	bn::fin_args fa{};
+	fa.n_terms = (uint32_t)terms.size();
+	fa.n_values = n_values;
+	fa.n_ret = n_ret;
+	for (size_t t = 0; t < terms.size(); t++) fa.terms[t] = terms[t];
+	for (uint32_t v = 0; v < n_values; v++) fa.init[v] = h_values[v];
+	for (uint32_t r = 0; r < n_ret; r++) fa.ret_ids[r] = ret_values[r];
+	fa.n_slots = n_slots;
+	fa.seq = finalized_in_kernel ? fused_seq : (h_out ? ++ctx->mail_seq : 0);
+	f128 *rets = d_out ? (f128 *)d_out : d_rets;
+	if (!finalized_in_kernel)
+		BN_HIP(bn::launch_finalize(s, fa, d_S, rets, ctx->d_mail));
+	ctx->s_clean = true; // stream-ordered: the next launch on this stream sees zeroed slots
+	if (h_out) {
+		// spin on the sequence word the kernel publishes after the values (fine-grained host memory)
+		volatile uint64_t *seqw = &ctx->h_mail[64].lo;
+		const uint64_t want = fa.seq;
+		uint64_t spins = 0;
+		while (__atomic_load_n(seqw, __ATOMIC_ACQUIRE) != want) {
+			if (++spins > (1ull << 22)) {
+				// not there yet: fall back to a stream sync so device errors surface instead of hanging
+				BN_HIP(hipStreamSynchronize(s));
+				if (__atomic_load_n(seqw, __ATOMIC_ACQUIRE) != want)
+					return bn::fail(BN_ERR_DEVICE, "device error: result mailbox was not published");
+				break;
+			}
+		}
+		for (uint32_t r = 0; r < n_ret; r++) {
+			h_out[r].lo = __atomic_load_n(&ctx->h_mail[r].lo, __ATOMIC_RELAXED);
+			h_out[r].hi = __atomic_load_n(&ctx->h_mail[r].hi, __ATOMIC_RELAXED);
+		}
+	}
+	return BN_OK;
+}
+
+// A small region of fine-grained pinned host memory that the device can read directly (32
+// elements): inputs of a few elements can be handed to kernels without an upload.  Not part of the
+// reference interface (used for the residual instance of the sharded prover).
+int bn_xor_reduce(bn_ctx *ctx, const void *d_vals, uint32_t n_groups, uint32_t group_len, bn_f128 *h_out)
+{
+	BN_REQUIRE(ctx && d_vals && h_out, "null argument");
+	BN_ENTER(ctx);
+	BN_FLUSH(ctx);
+	BN_REQUIRE(group_len >= 1 && group_len <= 64 && n_groups >= 1, "xor_reduce: group_len must be in 1..64");
+	const uint64_t seq = ++ctx->mail_seq;
+	BN_HIP(bn::launch_xor_publish(ctx->stream, (const f128 *)d_vals, n_groups, group_len, ctx->d_result + 96, ctx->d_mail, seq));
+	volatile uint64_t *seqw = &ctx->h_mail[64].lo;
+	uint64_t spins = 0;
+	while (__atomic_load_n(seqw, __ATOMIC_ACQUIRE) != seq) {
+		if (++spins > (1ull << 22)) {
+			BN_HIP(hipStreamSynchronize(ctx->stream));
+			if (__atomic_load_n(seqw, __ATOMIC_ACQUIRE) != seq)
+				return bn::fail(BN_ERR_DEVICE, "device error: result mailbox was not published");
+			break;
+		}
+	}
+	for (uint32_t r = 0; r < group_len; r++) {
+		h_out[r].lo = __atomic_load_n(&ctx->h_mail[r].lo, __ATOMIC_RELAXED);
+		h_out[r].hi = __atomic_load_n(&ctx->h_mail[r].hi, __ATOMIC_RELAXED);
+	}
+	return BN_OK;
+}
+
+} // extern "C"

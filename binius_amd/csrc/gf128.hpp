@@ -18,7 +18,7 @@
 #pragma once
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define BN_HD __host__ __device__
 #else
 #define BN_HD
