@@ -504,6 +504,51 @@ def test_context_is_safe_to_call_from_several_threads(hal, oracle):
     assert not errs
 
 
+def test_fresh_thread_allocating_entry_points(oracle):
+    """per-call allocations (NTT scratch and tables, fri_fold scratch, pinned gather staging,
+    Local kernel buffers) happen on the CALLING thread's current device; every entry point therefore makes
+    the context's device current first.  A freshly spawned thread that has never touched HIP drives a
+    fresh context through the lazily allocating paths; with two GPUs the context lives on the last one."""
+    import threading
+
+    import torch
+
+    import binius_amd
+
+    dev = torch.cuda.device_count() - 1
+    out = {}
+
+    def work():
+        try:
+            ctx = binius_amd.Context(dev, 1 << 18)
+            alloc = ctx.dev_alloc()
+            # NTT (scratch + cached tables)
+            log_y = 14
+            s = binius_amd.ntt_s_evals(5, log_y)
+            data = oracle.splitmix_words(0x77, (1 << log_y) // 2).view(np.uint32).copy()
+            want = data.copy()
+            assert oracle.ntt_forward(want, 5, 5, oracle.ntt_s_evals(5, log_y), log_y, 0, log_y, 0) == 0
+            d = alloc.alloc((1 << log_y) // 4)
+            ctx.copy_h2d(data.view(np.uint64).reshape(-1, 2), d)
+            ctx.ntt_forward(d.ptr, 5, 5, s, log_y, 0, log_y, 0)
+            got = ctx.copy_d2h(d).reshape(-1).view(np.uint32)
+            out["ntt"] = bool(np.array_equal(got, want))
+            # inner product over a subfield (scratch) and a fold
+            a, b = oracle.random_b128(1, 1 << 6), oracle.random_b128(2, 1 << 10)
+            da, db = alloc.alloc(1 << 6), alloc.alloc(1 << 10)
+            ctx.copy_h2d(a, da)
+            ctx.copy_h2d(b, db)
+            out["ip"] = ctx.inner_product(da, 3, db) == oracle.inner_product(a, 3, b)[1]
+            ctx.close()
+        except Exception as ex:  # noqa: BLE001
+            out["err"] = repr(ex)
+
+    t = threading.Thread(target=work)
+    t.start()
+    t.join()
+    assert out == {"ntt": True, "ip": True}, out
+
+
 @pytest.mark.parametrize("log_n", [1, 4, 9, 13])
 def test_product_circuit_layers(hal, oracle, log_n):
     """ProductCircuitLayers::compute (core/src/protocols/prodcheck/prove.rs:24-77): every layer is the

@@ -41,7 +41,8 @@ def main():
         for _ in range(args.reps):
             hal.kernel_launch(maps, ops, rets, lc, want_host=True)
         p = hal.prof_end()
-        re_ms = p["round_eval"][0] / p["round_eval"][1]
+        re_tot = p["round_eval"][0] + p["round_eval_mfma"][0]
+        re_ms = re_tot / (p["round_eval"][1] + p["round_eval_mfma"][1])
         # fold of one multilinear of size N into scratch (copy first so inputs stay intact)
         e0, e1 = mls[0].split_half()
         f = scratch[0].slice(0, N // 2)
