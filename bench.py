@@ -178,6 +178,23 @@ def main():
             dt = float(t.item())
         return dt
 
+    # First run of the default transport, guarded: if the RCCL exchange cannot run on this node (communicator
+    # or collective error on ANY rank), every rank switches to the shared-memory exchange together and the
+    # line says so -- a scaling line with a documented fallback beats none.
+    if dist is not None and exchange == "rccl":
+        ok = 1
+        try:
+            plan.run()
+        except Exception as ex:  # noqa: BLE001
+            print("[bench] rank %d: RCCL exchange failed (%s)" % (rank, ex), file=sys.stderr)
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            if shm is None:
+                raise SystemExit("RCCL exchange failed and no shared-memory segment is available")
+            exchange = "shm (fallback: the RCCL exchange raised an error on this node)"
+            plan = make_plan("shm")
     for _ in range(args.warmup):
         plan.run()
     # ---- timed region: exactly K steps, barrier + synchronize on both sides, MAX over ranks
@@ -201,7 +218,7 @@ def main():
     # ---- the other transport, same steps (all ranks on one node): reported beside the default, never as `value`
     alt = None
     if dist is not None and not args.no_alt_exchange and world > 1:
-        other = "shm" if exchange == "rccl" else "rccl"
+        other = "shm" if exchange == "rccl" else ("rccl" if exchange == "shm" else None)
         if (other == "shm" and shm is not None) or (other == "rccl" and rccl is not None):
             plan_alt = make_plan(other)
             plan_alt.run()
@@ -360,7 +377,8 @@ def main():
             "n_vars_global": n_global,
             "multilinears": m,
             "sharding": ("low index bits (last-bound variables), one 32-byte exchange per round: "
-                         + ("host shared memory" if exchange == "shm" else "RCCL all_gather on the context's stream + device XOR")) if dist is not None else "none",
+                         + ("host shared memory" if exchange.startswith("shm") else "RCCL all_gather on the context's stream + device XOR")
+                         + (" -- " + exchange if exchange.startswith("shm (") else "")) if dist is not None else "none",
         },
         "alt_exchange": alt,
         "bit_exact_check": bool(ok),
