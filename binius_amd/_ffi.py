@@ -22,6 +22,8 @@ _ERR_NAMES = {1: "InputValidation", 2: "Alloc", 3: "DeviceError", 4: "CoreLibErr
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libbinius_amd.so")
 MASK64 = (1 << 64) - 1
+ORDER_LOW_TO_HIGH, ORDER_HIGH_TO_LOW = 0, 1  # EvaluationOrder (crates/math/src/fold.rs)
+HAL_ML_FOLDED, HAL_ML_TRANSPARENT = 0, 1
 NTT_MAX_DIM = 64
 
 
@@ -53,6 +55,31 @@ class MemMap(C.Structure):
         ("d_data", C.c_void_p),
         ("len", C.c_uint64),
         ("log_size", C.c_uint32),
+    ]
+
+
+class HalMultilinear(C.Structure):
+    """bn_hal_multilinear: SumcheckMultilinear::{Folded, Transparent} (crates/hal/src/common.rs)."""
+
+    _fields_ = [
+        ("kind", C.c_uint32),
+        ("tower_level", C.c_uint32),
+        ("d_evals", C.c_void_p),
+        ("len", C.c_uint64),
+        ("suffix_eval", F128),
+        ("n_vars_ml", C.c_uint32),
+    ]
+
+
+class HalEvaluator(C.Structure):
+    """bn_hal_evaluator: what a SumcheckEvaluator contributes to one round (crates/hal/src/sumcheck_evaluator.rs)."""
+
+    _fields_ = [
+        ("composition", C.c_void_p),
+        ("composition_at_infinity", C.c_void_p),
+        ("eval_point_start", C.c_uint32),
+        ("eval_point_end", C.c_uint32),
+        ("d_eq_ind", C.c_void_p),
     ]
 
 
@@ -120,6 +147,8 @@ def lib():
         "bn_log_chunks_range": [C.POINTER(MemMap), u32, C.POINTER(u32), C.POINTER(u32)],
         "bn_pick_log_chunks": [C.POINTER(MemMap), u32, C.POINTER(u32)],
         "bn_kernel_launch": [vp, C.POINTER(MemMap), u32, C.POINTER(KOp), u32, C.POINTER(u32), u32, u32, PF, vp],
+        "bn_hal_round_evals": [vp, u32, u32, vp, u32, C.POINTER(HalMultilinear), u32, C.POINTER(HalEvaluator), u32, PF, u32, PF],
+        "bn_hal_fold_multilinear": [vp, u32, u32, C.POINTER(HalMultilinear), PF, vp, u32, vp, u64, C.POINTER(u64)],
         "bn_ntt_forward": [vp, vp, u32, u32, C.POINTER(u64), u32, u32, u32, u32, u64, u32, u32],
         "bn_ntt_inverse": [vp, vp, u32, u32, C.POINTER(u64), u32, u32, u32, u32, u64, u32, u32],
         "bn_ntt_s_evals": [u32, u32, C.POINTER(u64)],
@@ -154,6 +183,7 @@ ABI_SYMBOLS = [
     "bn_kernel_launch", "bn_ntt_forward", "bn_ntt_inverse", "bn_ntt_s_evals", "bn_scalar_mul", "bn_scalar_invert",
     "bn_timer_begin", "bn_timer_end_ms", "bn_prof_begin", "bn_prof_end", "bn_xor_reduce", "bn_host_scratch",
     "bn_merkle_build", "bn_groestl256_leaves", "bn_groestl256_compress_layer", "bn_gather_d2h",
+    "bn_hal_round_evals", "bn_hal_fold_multilinear",
 ]
 
 
@@ -486,6 +516,53 @@ class Context:
 
     def fold_right(self, mat, tower_level, vec, out):
         _check(lib().bn_fold_right(self._h, mat.ptr, mat.len, tower_level, vec.ptr, vec.len, out.ptr, out.len))
+
+    # ---- the old HAL (binius_hal::ComputationBackend, crates/hal/src/backend.rs:35-84) on device-resident multilinears
+    @staticmethod
+    def _hal_ml(ml):
+        """ml: ('folded', DevSlice, suffix_eval) | ('transparent', DevSlice of packed values, tower_level, n_vars_ml)."""
+        m = HalMultilinear()
+        if ml[0] == "folded":
+            m.kind, m.d_evals, m.len, m.suffix_eval = HAL_ML_FOLDED, ml[1].ptr, ml[1].len, to_f128(ml[2])
+        else:
+            m.kind, m.d_evals, m.len, m.tower_level, m.n_vars_ml = HAL_ML_TRANSPARENT, ml[1].ptr, ml[1].len, ml[2], ml[3]
+        return m
+
+    def hal_round_evals(self, order, n_vars, tensor_query, multilinears, evaluators, nontrivial_points):
+        """sumcheck_compute_round_evals (backend.rs:52-67).  evaluators: dicts {composition: Expr, composition_at_infinity:
+        Expr, start, end, eq_ind: DevSlice | None}; tensor_query: DevSlice of the query expansion or None.  Returns one list
+        of values per evaluator (its evaluation point indices start..end)."""
+        mls = (HalMultilinear * max(1, len(multilinears)))(*[self._hal_ml(m) for m in multilinears])
+        evs = (HalEvaluator * max(1, len(evaluators)))()
+        total = 0
+        for k, e in enumerate(evaluators):
+            evs[k].composition = e["composition"].handle
+            evs[k].composition_at_infinity = e["composition_at_infinity"].handle
+            evs[k].eval_point_start, evs[k].eval_point_end = e["start"], e["end"]
+            evs[k].d_eq_ind = e["eq_ind"].ptr if e.get("eq_ind") is not None else None
+            total += max(0, e["end"] - e["start"])
+        pts = _f128_array(list(nontrivial_points))
+        out = (F128 * max(1, total))()
+        q_ptr = tensor_query.ptr if tensor_query is not None else None
+        q_vars = (tensor_query.len.bit_length() - 1) if tensor_query is not None else 0
+        _check(lib().bn_hal_round_evals(self._h, order, n_vars, q_ptr, q_vars, mls, len(multilinears), evs, len(evaluators), pts,
+                                        len(nontrivial_points), out))
+        res, off = [], 0
+        for e in evaluators:
+            cnt = max(0, e["end"] - e["start"])
+            res.append([from_f128(out[off + t]) for t in range(cnt)])
+            off += cnt
+        return res
+
+    def hal_fold_multilinear(self, order, n_vars, multilinear, challenge, tensor_query, out):
+        """One multilinear of sumcheck_fold_multilinears (backend.rs:69-78): returns the number of evaluations written."""
+        m = self._hal_ml(multilinear)
+        z = to_f128(challenge)
+        n = C.c_uint64()
+        q_ptr = tensor_query.ptr if tensor_query is not None else None
+        q_vars = (tensor_query.len.bit_length() - 1) if tensor_query is not None else 0
+        _check(lib().bn_hal_fold_multilinear(self._h, order, n_vars, C.byref(m), C.byref(z), q_ptr, q_vars, out.ptr, out.len, C.byref(n)))
+        return n.value
 
     def fri_fold(self, s_evals, tw_level, log_domain, log_len, log_batch_size, challenges, data_in, data_out):
         ch = _f128_array(list(challenges))

@@ -1,0 +1,199 @@
+// binius_amd/csrc/abi_hal.cpp -- extern "C" entry points of the OLD hardware abstraction layer
+// (binius_hal::ComputationBackend, crates/hal/src/backend.rs:35-84) for device-resident multilinears:
+// bn_hal_round_evals = sumcheck_compute_round_evals (crates/hal/src/sumcheck_round_calculation.rs:45-330),
+// bn_hal_fold_multilinear = one multilinear of sumcheck_fold_multilinears (crates/hal/src/sumcheck_folding.rs:16-237).
+//
+// Routing: the shapes the v2 provers spend their time in -- every evaluator a product of two FULL Folded multilinears
+// evaluated at X = 1 and X = infinity in High-to-Low order, optionally times an equality-indicator table -- are exactly
+// what the ComputeLayer path evaluates, and run on its kernels (matrix-core Gram kernels from 2^17 points, 9-lane
+// kernels below).  Everything else (other compositions, more evaluation points, Low-to-High order, truncated
+// multilinears) runs the general kernels of kernels_hal.hip.  Transparent multilinears are first partially evaluated at
+// the tensor query into context scratch (evaluate_partial_low / _high = the fold_right / fold_left kernels): the
+// reference does the same thing subcube by subcube to save memory (sumcheck_round_calculation.rs:404-418, 496-518).
+#include "abi_common.hpp"
+
+namespace {
+
+bool is_product2(const bn_expr *e) { return e && e->shape == bn_expr::PRODUCT && e->product_vars.size() == 2; }
+
+// Transparent multilinear -> 2^n_vars large-field values at `dst` under the query
+int materialise(bn_ctx *ctx, uint32_t order, uint32_t n_vars, const bn_hal_multilinear &ml, const void *d_query, uint32_t query_vars, void *d_one,
+                void *dst)
+{
+	BN_REQUIRE(valid_tower_level(ml.tower_level), "unsupported value of tower_level");
+	BN_REQUIRE(ml.n_vars_ml == n_vars + query_vars, "transparent multilinear: n_vars_ml must equal n_vars + query variables");
+	BN_REQUIRE(ml.len << (7 - ml.tower_level) == (uint64_t)1 << ml.n_vars_ml, "transparent multilinear: packed length does not match n_vars_ml");
+	BN_REQUIRE(query_vars == 0 || d_query, "tensor query missing while a multilinear is still transparent");
+	const void *q = query_vars ? d_query : d_one;
+	const uint64_t q_len = (uint64_t)1 << query_vars, out_len = (uint64_t)1 << n_vars;
+	if (order == BN_ORDER_LOW_TO_HIGH)
+		BN_HIP(bn::launch_fold_right(ctx->stream, ctx->n_cu, ml.d_evals, ml.tower_level, q, q_len, dst, out_len));
+	else
+		BN_HIP(bn::launch_fold_left(ctx->stream, ctx->n_cu, ml.d_evals, ml.tower_level, q, q_len, dst, out_len));
+	return BN_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int bn_hal_round_evals(bn_ctx *ctx, uint32_t order, uint32_t n_vars, const void *d_tensor_query, uint32_t query_vars,
+                       const bn_hal_multilinear *mls, uint32_t n_mls, const bn_hal_evaluator *evs, uint32_t n_evs,
+                       const bn_f128 *h_points, uint32_t n_points, bn_f128 *h_out)
+{
+	BN_REQUIRE(ctx && h_out && (mls || n_mls == 0) && (evs || n_evs == 0), "null argument");
+	BN_ENTER(ctx);
+	BN_FLUSH(ctx);
+	BN_REQUIRE(order == BN_ORDER_LOW_TO_HIGH || order == BN_ORDER_HIGH_TO_LOW, "unknown evaluation order");
+	BN_REQUIRE(n_vars > 0 && n_vars < 40, "computing round evaluations requires at least a single variable");
+	BN_REQUIRE(n_mls <= (uint32_t)bn::kHalMaxMl && n_evs <= (uint32_t)bn::kHalMaxEv, "too many multilinears or evaluators in one call");
+	uint32_t pt_lo = 0, pt_hi = 0, total = 0;
+	for (uint32_t e = 0; e < n_evs; e++) {
+		BN_REQUIRE(evs[e].composition && evs[e].composition_at_infinity, "evaluator without a composition");
+		BN_REQUIRE(evs[e].eval_point_start <= evs[e].eval_point_end, "empty evaluation point range");
+		BN_REQUIRE(evs[e].composition->n_vars <= n_mls && evs[e].composition_at_infinity->n_vars <= n_mls,
+		           "composition uses more variables than there are multilinears");
+		BN_REQUIRE(evs[e].composition->steps.size() <= 64 && evs[e].composition_at_infinity->steps.size() <= 64, "composition too large");
+		if (e == 0 || evs[e].eval_point_start < pt_lo) pt_lo = evs[e].eval_point_start;
+		if (e == 0 || evs[e].eval_point_end > pt_hi) pt_hi = evs[e].eval_point_end;
+		total += evs[e].eval_point_end - evs[e].eval_point_start;
+	}
+	// Error::IncorrectNontrivialEvalPointsLength (sumcheck_round_calculation.rs:121-125)
+	BN_REQUIRE(n_points == (pt_hi > 3 ? pt_hi - 3 : 0), "nontrivial evaluation points: incorrect length");
+	BN_REQUIRE(n_points <= (uint32_t)bn::kHalMaxPts && total <= 64, "too many evaluation points");
+	BN_REQUIRE(n_points == 0 || h_points, "null argument");
+	if (total == 0) return BN_OK;
+
+	const uint64_t full = (uint64_t)1 << n_vars, half = full >> 1;
+	// ---- Transparent multilinears: partial evaluation at the query into scratch
+	uint32_t n_tr = 0;
+	for (uint32_t k = 0; k < n_mls; k++) {
+		BN_REQUIRE(mls[k].kind == BN_HAL_ML_FOLDED || mls[k].kind == BN_HAL_ML_TRANSPARENT, "unknown multilinear kind");
+		BN_REQUIRE(mls[k].d_evals || mls[k].len == 0, "multilinear without evaluations");
+		if (mls[k].kind == BN_HAL_ML_TRANSPARENT) n_tr++;
+	}
+	char *scr = nullptr;
+	if (n_tr) {
+		scr = (char *)bn::ctx_scratch(ctx, ((size_t)n_tr * full + 1) * sizeof(f128));
+		if (!scr) return bn::fail(BN_ERR_ALLOC, "allocation error: allocator is out of memory (scratch)");
+		BN_HIP(bn::launch_fill(ctx->stream, scr + (size_t)n_tr * full * sizeof(f128), 1, bn::f128_one()));
+	}
+	bn::hal_round_args a{};
+	a.n_ml = n_mls;
+	a.n_ev = n_evs;
+	a.pt_lo = pt_lo;
+	a.pt_hi = pt_hi;
+	a.order = order;
+	a.n_vars = n_vars;
+	bool all_full = true;
+	uint32_t t = 0;
+	for (uint32_t k = 0; k < n_mls; k++) {
+		if (mls[k].kind == BN_HAL_ML_TRANSPARENT) {
+			void *dst = scr + (size_t)t++ * full * sizeof(f128);
+			int rc = materialise(ctx, order, n_vars, mls[k], d_tensor_query, query_vars, scr + (size_t)n_tr * full * sizeof(f128), dst);
+			if (rc) return rc;
+			a.ml[k].evals = (const uint4 *)dst;
+			a.ml[k].len = full;
+			a.ml[k].suffix = bn::f128_zero();
+		} else {
+			a.ml[k].evals = (const uint4 *)mls[k].d_evals;
+			a.ml[k].len = mls[k].len < full ? mls[k].len : full;
+			a.ml[k].suffix = to_f(&mls[k].suffix_eval);
+			if (a.ml[k].len != full) all_full = false;
+		}
+	}
+	for (uint32_t p = 0; p < n_points; p++) a.pts[p] = to_f(&h_points[p]);
+
+	f128 *d_acc = ctx->d_result; // 64 accumulator slots (slots 0..63 of the result area)
+	ctx->s_clean = false;
+	BN_HIP(hipMemsetAsync(d_acc, 0, 64 * sizeof(f128), ctx->stream));
+
+	// ---- the fast shape: products of two full multilinears at X = 1 / infinity, High-to-Low
+	bool fast = order == BN_ORDER_HIGH_TO_LOW && all_full && pt_lo >= 1 && pt_hi <= 3 && n_vars >= 2;
+	for (uint32_t e = 0; e < n_evs && fast; e++)
+		fast = is_product2(evs[e].composition) && is_product2(evs[e].composition_at_infinity) &&
+		       evs[e].composition->product_vars == evs[e].composition_at_infinity->product_vars;
+	if (fast) {
+		uint32_t off = 0;
+		for (uint32_t e = 0; e < n_evs; e++) {
+			const uint32_t s0 = evs[e].eval_point_start, s1 = evs[e].eval_point_end;
+			if (s1 > s0) {
+				const uint32_t va = evs[e].composition->product_vars[0], vb = evs[e].composition->product_vars[1];
+				const char *pa = (const char *)a.ml[va].evals, *pb = (const char *)a.ml[vb].evals;
+				// the kernels accumulate (S_1, S_inf) into two adjacent slots: slot 32 + 2e, 33 + 2e, copied below
+				f128 *pair = d_acc + 32 + 2 * e;
+				const void *hi[3] = {pa + half * 16, pb + half * 16, evs[e].d_eq_ind};
+				const void *lo[3] = {pa, pb, nullptr};
+				BN_HIP(bn::launch_roundeval_product(ctx->stream, ctx->n_cu, hi, lo, evs[e].d_eq_ind ? 3 : 2, half, pair, nullptr));
+				for (uint32_t p = s0; p < s1; p++)
+					BN_HIP(hipMemcpyAsync(d_acc + off + (p - s0), pair + (p - 1), sizeof(f128), hipMemcpyDeviceToDevice, ctx->stream));
+			}
+			off += s1 - s0;
+		}
+	} else {
+		uint32_t off = 0;
+		for (uint32_t e = 0; e < n_evs; e++) {
+			int rc = ensure_d_steps(evs[e].composition);
+			if (rc) return rc;
+			rc = ensure_d_steps(evs[e].composition_at_infinity);
+			if (rc) return rc;
+			a.ev[e].steps = evs[e].composition->d_steps;
+			a.ev[e].n_steps = (uint32_t)evs[e].composition->steps.size();
+			a.ev[e].steps_inf = evs[e].composition_at_infinity->d_steps;
+			a.ev[e].n_steps_inf = (uint32_t)evs[e].composition_at_infinity->steps.size();
+			a.ev[e].pt_start = evs[e].eval_point_start;
+			a.ev[e].pt_end = evs[e].eval_point_end;
+			a.ev[e].eq = (const uint4 *)evs[e].d_eq_ind;
+			a.ev[e].out_off = off;
+			off += evs[e].eval_point_end - evs[e].eval_point_start;
+		}
+		BN_HIP(bn::launch_hal_round_evals(ctx->stream, ctx->n_cu, a, d_acc));
+	}
+	BN_HIP(hipMemcpyAsync(h_out, d_acc, total * sizeof(f128), hipMemcpyDeviceToHost, ctx->stream));
+	BN_HIP(hipStreamSynchronize(ctx->stream));
+	BN_HIP(hipMemsetAsync(d_acc, 0, 64 * sizeof(f128), ctx->stream));
+	ctx->s_clean = true;
+	return BN_OK;
+}
+
+int bn_hal_fold_multilinear(bn_ctx *ctx, uint32_t order, uint32_t n_vars, const bn_hal_multilinear *ml, const bn_f128 *challenge,
+                            const void *d_tensor_query, uint32_t query_vars, void *d_out, uint64_t out_cap, uint64_t *out_len)
+{
+	BN_REQUIRE(ctx && ml && challenge && out_len && (d_out || out_cap == 0), "null argument");
+	BN_ENTER(ctx);
+	BN_FLUSH(ctx);
+	BN_REQUIRE(order == BN_ORDER_LOW_TO_HIGH || order == BN_ORDER_HIGH_TO_LOW, "unknown evaluation order");
+	BN_REQUIRE(n_vars > 0 && n_vars < 40, "folding requires at least a single variable");
+	const uint64_t full = (uint64_t)1 << n_vars, half = full >> 1;
+	if (ml->kind == BN_HAL_ML_TRANSPARENT) {
+		// switchover (sumcheck_folding.rs:58-112, 164-216): partial evaluation at the query that already holds this
+		// round's challenge
+		BN_REQUIRE(query_vars > 0 && d_tensor_query, "tensor query missing while a multilinear is still transparent");
+		BN_REQUIRE(out_cap >= half, "output buffer too small");
+		bn_hal_multilinear t = *ml;
+		int rc = materialise(ctx, order, n_vars - 1, t, d_tensor_query, query_vars, nullptr, d_out);
+		if (rc) return rc;
+		*out_len = half;
+		return BN_OK;
+	}
+	BN_REQUIRE(ml->kind == BN_HAL_ML_FOLDED, "unknown multilinear kind");
+	const uint64_t len = ml->len < full ? ml->len : full;
+	const f128 z = to_f(challenge), sfx = to_f(&ml->suffix_eval);
+	const uint64_t n_out = order == BN_ORDER_LOW_TO_HIGH ? (len + 1) / 2 : (len < half ? len : half);
+	BN_REQUIRE(out_cap >= n_out, "output buffer too small");
+	if (order == BN_ORDER_LOW_TO_HIGH && n_out) {
+		const char *a = (const char *)ml->d_evals, *b = (const char *)d_out;
+		BN_REQUIRE(b + n_out * 16 <= a || a + len * 16 <= b, "Low-to-High fold: output must not overlap the input");
+	}
+	prof_scope ps(ctx, BN_PROF_FOLD);
+	if (order == BN_ORDER_HIGH_TO_LOW && len == full && d_out == ml->d_evals) {
+		// the ComputeLayer shape: in-place fold of the two halves
+		BN_HIP(bn::launch_extrapolate_line(ctx->stream, ctx->n_cu, d_out, (const char *)ml->d_evals + half * 16, half, z));
+	} else {
+		BN_HIP(bn::launch_hal_fold_lerp(ctx->stream, ctx->n_cu, ml->d_evals, len, sfx, order, half, z, d_out, n_out));
+	}
+	*out_len = n_out;
+	return BN_OK;
+}
+
+} // extern "C"

@@ -197,6 +197,28 @@ hipError_t launch_roundeval_mfma_pair(hipStream_t s, int n_cu, const void *a_hi,
 hipError_t launch_roundeval_mfma_split(hipStream_t s, int n_cu, const void *a, const void *b, uint64_t n, uint64_t split_off, f128 *d_out);
 hipError_t launch_foldeval_mfma(hipStream_t s, int n_cu, const foldeval_args &fa, uint64_t n_in, f128 z, f128 *d_out, const fin_fuse *fuse);
 
+// ---- kernels_hal.hip: general forms of the old HAL's round calculation and lerp fold (abi_hal.cpp)
+constexpr int kHalMaxMl = 16, kHalMaxEv = 8, kHalMaxPts = 13;
+struct hal_round_args {
+	struct ml_t {
+		const uint4 *evals;
+		uint64_t len;
+		f128 suffix;
+	} ml[kHalMaxMl];
+	struct ev_t {
+		const bn_step *steps, *steps_inf;
+		uint32_t n_steps, n_steps_inf;
+		uint32_t pt_start, pt_end;
+		const uint4 *eq;
+		uint32_t out_off;
+	} ev[kHalMaxEv];
+	f128 pts[kHalMaxPts]; // evaluation points of index 3, 4, ...
+	uint32_t n_ml, n_ev, pt_lo, pt_hi, order, n_vars;
+};
+hipError_t launch_hal_round_evals(hipStream_t s, int n_cu, const hal_round_args &a, f128 *d_out);
+hipError_t launch_hal_fold_lerp(hipStream_t s, int n_cu, const void *evals, uint64_t len, f128 suffix, uint32_t order, uint64_t half, f128 z,
+                                void *out, uint64_t n_out);
+
 // ---- kernels_misc.hip
 hipError_t launch_inner_product(hipStream_t s, int n_cu, const void *a, uint32_t tower_level, const void *b,
                                 uint64_t b_len, f128 *d_out);

@@ -90,6 +90,33 @@ pub struct bn_kop {
 
 pub const BN_PROF_N: usize = 10;
 
+// ---- the old HAL (binius_hal::ComputationBackend) on device-resident multilinears
+pub const BN_ORDER_LOW_TO_HIGH: u32 = 0;
+pub const BN_ORDER_HIGH_TO_LOW: u32 = 1;
+pub const BN_HAL_ML_FOLDED: u32 = 0;
+pub const BN_HAL_ML_TRANSPARENT: u32 = 1;
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct bn_hal_multilinear {
+	pub kind: u32,
+	pub tower_level: u32,
+	pub d_evals: *const c_void,
+	pub len: u64,
+	pub suffix_eval: bn_f128,
+	pub n_vars_ml: u32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct bn_hal_evaluator {
+	pub composition: *const bn_expr,
+	pub composition_at_infinity: *const bn_expr,
+	pub eval_point_start: u32,
+	pub eval_point_end: u32,
+	pub d_eq_ind: *const c_void,
+}
+
 unsafe extern "C" {
 	pub fn bn_last_error() -> *const c_char;
 	pub fn bn_version() -> *const c_char;
@@ -194,6 +221,33 @@ unsafe extern "C" {
 		log_chunks: u32,
 		h_out: *mut bn_f128,
 		d_out: *mut c_void,
+	) -> c_int;
+
+	pub fn bn_hal_round_evals(
+		ctx: *mut bn_ctx,
+		order: u32,
+		n_vars: u32,
+		d_tensor_query: *const c_void,
+		query_vars: u32,
+		mls: *const bn_hal_multilinear,
+		n_mls: u32,
+		evaluators: *const bn_hal_evaluator,
+		n_evaluators: u32,
+		h_nontrivial_points: *const bn_f128,
+		n_points: u32,
+		h_out: *mut bn_f128,
+	) -> c_int;
+	pub fn bn_hal_fold_multilinear(
+		ctx: *mut bn_ctx,
+		order: u32,
+		n_vars: u32,
+		ml: *const bn_hal_multilinear,
+		challenge: *const bn_f128,
+		d_tensor_query: *const c_void,
+		query_vars: u32,
+		d_out: *mut c_void,
+		out_cap: u64,
+		out_len: *mut u64,
 	) -> c_int;
 
 	pub fn bn_ntt_forward(

@@ -16,6 +16,7 @@
 
 pub mod exec;
 pub mod ffi;
+pub mod hal;
 pub mod holder;
 pub mod memory;
 pub mod recorder;
@@ -32,6 +33,7 @@ use binius_math::{ArithCircuit, ArithCircuitStep};
 
 pub use crate::{
 	exec::{Mi355xExec, Mi355xExpr},
+	hal::{DevEvaluator, DevMultilinear},
 	holder::Mi355xLayerHolder,
 	memory::{DevSlice, DevSliceMut, Mi355xMemory},
 };
@@ -78,7 +80,7 @@ pub(crate) fn default_device() -> i32 {
 
 /// The compute layer: one backend context (device, stream, scratch, optional arena).
 pub struct Mi355xLayer {
-	ctx: *mut bn_ctx,
+	pub(crate) ctx: *mut bn_ctx,
 }
 
 // Every entry point of the C ABI takes the context's lock and makes its device current; the trait lets the

@@ -174,6 +174,46 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 /* ---- AdditiveNTT (crates/ntt/src/additive_ntt.rs:102, 128): data is 2^(log_x+log_y+log_z)
  * elements of T_elem_level (elem_level 5 = BinaryField32b ... 7 = BinaryField128b), transform along
  * y; twiddles in T_tw_level given as the on-the-fly basis (see bn_fri_fold). */
+/* ---- the OLD hardware abstraction layer: binius_hal::ComputationBackend (crates/hal/src/backend.rs:35-84), which the
+ * v2 provers (zerocheck, evalcheck, RegularSumcheckProver) still run on, for device-resident multilinears.
+ *   tensor_product_full_query   = bn_fill(1 element) + bn_tensor_expand            (cpu.rs:36-41)
+ *   evaluate_partial_high       = bn_fold_left, evaluate_partial_low = bn_fold_right (multilinear_extension.rs:253-341)
+ *   sumcheck_compute_round_evals = bn_hal_round_evals                               (sumcheck_round_calculation.rs:45-330)
+ *   sumcheck_fold_multilinears   = bn_hal_fold_multilinear per multilinear           (sumcheck_folding.rs:16-237)
+ * The trait takes its evaluators as trait objects; what crosses the boundary instead is their content: the
+ * composition and its leading term as compiled circuits, the range of evaluation point indices, and the optional
+ * equality-indicator table (RegularSumcheckEvaluator, regular_sumcheck.rs:219-282; eq_ind Evaluator, eq_ind.rs:646-735).
+ * The switchover bookkeeping (switchover_round countdown, Transparent -> Folded) stays with the host-side state, as
+ * in the reference (sumcheck_multilinear.rs:8-76).  Constant evaluation suffixes of EVALUATORS are not supported
+ * (const_eval_suffix must be 0); constant suffixes of Folded multilinears are. */
+enum { BN_ORDER_LOW_TO_HIGH = 0, BN_ORDER_HIGH_TO_LOW = 1 };  /* binius_math::EvaluationOrder */
+enum { BN_HAL_ML_FOLDED = 0, BN_HAL_ML_TRANSPARENT = 1 };     /* SumcheckMultilinear */
+typedef struct {
+	uint32_t kind;
+	uint32_t tower_level;  /* TRANSPARENT: level of the packed subfield values (0, 3..7) */
+	const void *d_evals;   /* FOLDED: `len` evaluations; TRANSPARENT: the 2^n_vars_ml subfield values, packed into F */
+	uint64_t len;          /* FOLDED: stored evaluations (the rest of the 2^n_vars cube equals suffix_eval); TRANSPARENT: F elements */
+	bn_f128 suffix_eval;   /* FOLDED */
+	uint32_t n_vars_ml;    /* TRANSPARENT: variables of the multilinear = n_vars + query_vars */
+} bn_hal_multilinear;
+typedef struct {
+	const bn_expr *composition;
+	const bn_expr *composition_at_infinity;     /* ArithCircuit::leading_term */
+	uint32_t eval_point_start, eval_point_end;  /* SumcheckEvaluator::eval_point_indices: 0 -> X=0, 1 -> X=1, 2 -> infinity, 3+k -> point k */
+	const void *d_eq_ind;                       /* NULL, or 2^(n_vars-1) factors (eq_ind partial evaluations) */
+} bn_hal_evaluator;
+/* h_out: evaluator by evaluator, one value per evaluation point index of its range.  d_tensor_query: the query
+ * EXPANSION (2^query_vars elements) that TRANSPARENT multilinears are partially evaluated at (low variables for
+ * BN_ORDER_LOW_TO_HIGH, high variables for BN_ORDER_HIGH_TO_LOW); NULL when query_vars == 0. */
+int bn_hal_round_evals(bn_ctx *ctx, uint32_t order, uint32_t n_vars, const void *d_tensor_query, uint32_t query_vars,
+                       const bn_hal_multilinear *mls, uint32_t n_mls, const bn_hal_evaluator *evaluators, uint32_t n_evaluators,
+                       const bn_f128 *h_nontrivial_points, uint32_t n_points, bn_f128 *h_out);
+/* FOLDED: single-variable lerp fold in the given order (d_out may be d_evals for BN_ORDER_HIGH_TO_LOW, must not overlap it
+ * for BN_ORDER_LOW_TO_HIGH).  TRANSPARENT, at its switchover round: partial evaluation at the query, which already holds
+ * this round's challenge (n_vars_ml = n_vars - 1 + query_vars).  *out_len evaluations are written. */
+int bn_hal_fold_multilinear(bn_ctx *ctx, uint32_t order, uint32_t n_vars, const bn_hal_multilinear *ml, const bn_f128 *challenge,
+                            const void *d_tensor_query, uint32_t query_vars, void *d_out, uint64_t out_cap, uint64_t *out_len);
+
 int bn_ntt_forward(bn_ctx *ctx, void *d_data, uint32_t elem_level, uint32_t tw_level, const uint64_t *h_s_evals,
                    uint32_t log_domain, uint32_t log_x, uint32_t log_y, uint32_t log_z, uint64_t coset,
                    uint32_t coset_bits, uint32_t skip_rounds);

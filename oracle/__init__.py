@@ -576,3 +576,86 @@ def fast_bivariate_sumcheck_prove(multilins, n_vars, comps, sums, batch_coeff, c
     assert rc == 0
     co = arr_to_ints(rc_out)
     return [co[3 * r : 3 * r + 3] for r in range(n_vars)], arr_to_ints(fe)
+
+
+# ------------------------------------------------------------------ old HAL (crates/hal) restatement: hal_ref.c
+ORDER_LOW_TO_HIGH, ORDER_HIGH_TO_LOW = 0, 1
+HAL_ML_FOLDED, HAL_ML_TRANSPARENT = 0, 1
+
+
+class HalMultilinear(C.Structure):
+    _fields_ = [
+        ("kind", C.c_uint32),
+        ("tower_level", C.c_uint32),
+        ("evals", C.c_void_p),
+        ("len", C.c_uint64),
+        ("suffix_eval", B128),
+        ("n_vars_ml", C.c_uint32),
+    ]
+
+
+class HalEvaluator(C.Structure):
+    _fields_ = [
+        ("composition", C.POINTER(Step)),
+        ("n_steps", C.c_uint64),
+        ("composition_at_infinity", C.POINTER(Step)),
+        ("n_steps_inf", C.c_uint64),
+        ("eval_point_start", C.c_uint32),
+        ("eval_point_end", C.c_uint32),
+        ("eq_ind", C.c_void_p),
+    ]
+
+
+def _hal_ml(ml):
+    """ml: ('folded', evals_array, suffix_eval) | ('transparent', packed_array, tower_level, n_vars_ml)."""
+    m = HalMultilinear()
+    if ml[0] == "folded":
+        m.kind, m.evals, m.len, m.suffix_eval = HAL_ML_FOLDED, ml[1].ctypes.data, ml[1].shape[0], to_b128(ml[2])
+    else:
+        m.kind, m.evals, m.len, m.tower_level, m.n_vars_ml = HAL_ML_TRANSPARENT, ml[1].ctypes.data, ml[1].shape[0], ml[2], ml[3]
+    return m
+
+
+def hal_round_evals(order, n_vars, tensor_query, multilinears, evaluators, nontrivial_points):
+    """evaluators: list of dicts {steps, steps_inf, start, end, eq_ind (array or None)}.  Returns (rc, [[values per point] per evaluator])."""
+    L = lib()
+    L.ref_hal_round_evals.argtypes = [C.c_int, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(HalMultilinear), C.c_uint32, C.POINTER(HalEvaluator),
+                                      C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
+    mls = (HalMultilinear * max(1, len(multilinears)))(*[_hal_ml(m) for m in multilinears])
+    keep = []
+    evs = (HalEvaluator * max(1, len(evaluators)))()
+    total = 0
+    for i, e in enumerate(evaluators):
+        st, si = make_steps(e["steps"]), make_steps(e["steps_inf"])
+        keep += [st, si]
+        evs[i].composition, evs[i].n_steps = st, len(e["steps"])
+        evs[i].composition_at_infinity, evs[i].n_steps_inf = si, len(e["steps_inf"])
+        evs[i].eval_point_start, evs[i].eval_point_end = e["start"], e["end"]
+        evs[i].eq_ind = e["eq_ind"].ctypes.data if e.get("eq_ind") is not None else None
+        total += e["end"] - e["start"]
+    q = tensor_query if tensor_query is not None else arr(1)
+    query_vars = (q.shape[0].bit_length() - 1) if tensor_query is not None else 0
+    pts = ints_to_arr(list(nontrivial_points)) if len(nontrivial_points) else arr(1)
+    out = arr(max(1, total))
+    rc = L.ref_hal_round_evals(order, n_vars, q.ctypes.data, query_vars, mls, len(multilinears), evs, len(evaluators), pts.ctypes.data,
+                               len(nontrivial_points), out.ctypes.data)
+    vals = arr_to_ints(out)
+    res, off = [], 0
+    for e in evaluators:
+        res.append(vals[off : off + e["end"] - e["start"]])
+        off += e["end"] - e["start"]
+    return rc, res
+
+
+def hal_fold_multilinear(order, n_vars, multilinear, challenge, tensor_query=None):
+    """Returns (rc, folded evaluations as an (n, 2) uint64 array)."""
+    L = lib()
+    L.ref_hal_fold_multilinear.argtypes = [C.c_int, C.c_uint32, C.POINTER(HalMultilinear), B128, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64,
+                                           C.POINTER(C.c_uint64)]
+    m = _hal_ml(multilinear)
+    q = tensor_query if tensor_query is not None else arr(1)
+    query_vars = (q.shape[0].bit_length() - 1) if tensor_query is not None else 0
+    out = arr(1 << n_vars)
+    n = C.c_uint64(0)
+    rc = L.ref_hal_fold_multilinear(order, n_vars, C.byref(m), to_b128(challenge), q.ctypes.data, query_vars, out.ctypes.data, out.shape[0], C.byref(n))
+    return rc, out[: n.value].copy()

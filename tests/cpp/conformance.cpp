@@ -11,9 +11,11 @@
 
 #include "../../binius_amd/host/callers.hpp"
 #include "../../binius_amd/host/fri.hpp"
+#include "../../binius_amd/host/hal_backend.hpp"
 #include "../../binius_amd/host/merkle.hpp"
 #include "../../binius_amd/host/sumcheck.hpp"
 extern "C" {
+#include "../../oracle/hal_ref.h"
 #include "../../oracle/layer_ref.h"
 #include "../../oracle/merkle_ref.h"
 #include "../../oracle/ntt_ref.h"
@@ -38,7 +40,7 @@ static std::vector<B128> random_vec(uint64_t seed, size_t n)
 	ref_splitmix_fill(seed, reinterpret_cast<uint64_t *>(v.data()), 2 * n);
 	return v;
 }
-static const ref_b128 *R(const std::vector<B128> &v) { return reinterpret_cast<const ref_b128 *>(v.data()); }
+[[maybe_unused]] static const ref_b128 *R(const std::vector<B128> &v) { return reinterpret_cast<const ref_b128 *>(v.data()); }
 static ref_b128 *R(std::vector<B128> &v) { return reinterpret_cast<ref_b128 *>(v.data()); }
 static ref_b128 r1(B128 x) { return ref_b128{x.lo, x.hi}; }
 static B128 b1(ref_b128 x) { return B128(x.lo, x.hi); }
@@ -648,6 +650,100 @@ static void test_prodcheck_and_ring_switch_callers(Env &e)
 	}
 }
 
+// The old HAL driven the way ProverState drives it (prover_state.rs:138-265): a degree-2 composition a * b + c over one
+// large-field multilinear, one B32-packed multilinear that switches over after round 1 and one truncated multilinear
+// with a constant suffix; every round's evaluations (X = 1, infinity and one interpolation-domain point) and the
+// folded state are compared with the oracle's restatement of CpuBackend driven through the same rounds.
+static void test_old_hal_prover_state(Env &e)
+{
+	for (EvaluationOrder order : {EvaluationOrder::LowToHigh, EvaluationOrder::HighToLow}) {
+		ComputeData d = e.holder.to_data();
+		const size_t n_vars = 9, n = (size_t)1 << n_vars, level = 5, sw = 2;
+		auto a = random_vec(0x01DA, n), packed = random_vec(0x01DB, n >> (7 - level)), c = random_vec(0x01DC, 300);
+		const B128 c_suffix = random_vec(0x01DD, 1)[0];
+		auto zs = random_vec(0x01DE, n_vars + 1);
+		FSliceMut da = d.dev_alloc.alloc(a.size()), dp = d.dev_alloc.alloc(packed.size()), dc = d.dev_alloc.alloc(c.size());
+		d.hal->copy_h2d(a, da);
+		d.hal->copy_h2d(packed, dp);
+		d.hal->copy_h2d(c, dc);
+		const ArithCircuit comp = ArithCircuit::var(0) * ArithCircuit::var(1) + ArithCircuit::var(2);
+		const ArithCircuit lead = ArithCircuit::var(0) * ArithCircuit::var(1);
+		Mi355xBackend backend(*d.hal);
+		SumcheckEvaluator ev;
+		ev.composition = d.hal->compile_expr(comp);
+		ev.composition_at_infinity = d.hal->compile_expr(lead);
+		ev.eval_point_start = 1;
+		ev.eval_point_end = 4;
+		ProverState st(backend, d.dev_alloc, order, n_vars,
+		               {SumcheckMultilinear::folded(C(da)), SumcheckMultilinear::transparent(SubfieldSlice(C(dp), level), n_vars, sw),
+		                SumcheckMultilinear::folded(C(dc), c_suffix)},
+		               {zs[n_vars]});
+		// the oracle's state
+		std::vector<std::vector<B128>> h = {a, packed, c};
+		std::vector<ref_hal_multilinear> rm(3);
+		rm[0] = ref_hal_multilinear{REF_HAL_ML_FOLDED, 0, R(h[0]), h[0].size(), ref_b128{0, 0}, 0};
+		rm[1] = ref_hal_multilinear{REF_HAL_ML_TRANSPARENT, (uint32_t)level, R(h[1]), h[1].size(), ref_b128{0, 0}, (uint32_t)n_vars};
+		rm[2] = ref_hal_multilinear{REF_HAL_ML_FOLDED, 0, R(h[2]), h[2].size(), r1(c_suffix), 0};
+		size_t rounds_to_switch = sw;
+		std::vector<B128> challenges, query;
+		const ref_step *cs = reinterpret_cast<const ref_step *>(comp.steps().data()), *ls = reinterpret_cast<const ref_step *>(lead.steps().data());
+		for (size_t r = 0; r < n_vars; r++) {
+			const size_t nv = n_vars - r;
+			auto got = st.calculate_round_evals({ev});
+			ref_hal_evaluator re{cs, comp.steps().size(), ls, lead.steps().size(), 1, 4, nullptr};
+			std::vector<B128> want(3);
+			const ref_b128 pt = r1(zs[n_vars]);
+			CHECK(ref_hal_round_evals((int)order, (uint32_t)nv, query.empty() ? nullptr : R(query), (uint32_t)challenges.size(), rm.data(), 3, &re, 1, &pt, 1,
+			                          R(want)) == 0);
+			CHECK(got.size() == 1 && got[0].evals == want);
+			// fold
+			const B128 z = zs[r];
+			st.fold(z);
+			if (order == EvaluationOrder::LowToHigh) challenges.push_back(z); else challenges.insert(challenges.begin(), z);
+			const bool transparent = rm[1].kind == REF_HAL_ML_TRANSPARENT;
+			if (transparent) {
+				query.assign((size_t)1 << challenges.size(), B128());
+				query[0] = B128::ONE();
+				CHECK(ref_tensor_expand(R(query), query.size(), 0, R(challenges), challenges.size(), 1) == 0);
+			}
+			for (size_t j = 0; j < 3; j++) {
+				if (j == 1 && transparent && rounds_to_switch > 0) {
+					rounds_to_switch--;
+					continue;
+				}
+				std::vector<B128> out((size_t)1 << (nv - 1));
+				uint64_t n_out = 0;
+				CHECK(ref_hal_fold_multilinear((int)order, (uint32_t)nv, &rm[j], r1(z), query.empty() ? nullptr : R(query), (uint32_t)challenges.size(), R(out),
+				                               out.size(), &n_out) == 0);
+				out.resize(n_out);
+				h[j] = out;
+				rm[j] = ref_hal_multilinear{REF_HAL_ML_FOLDED, 0, R(h[j]), h[j].size(), rm[j].kind == REF_HAL_ML_FOLDED ? rm[j].suffix_eval : ref_b128{0, 0}, 0};
+			}
+			if (rm[1].kind == REF_HAL_ML_FOLDED) { // the query is dropped once nothing is transparent (prover_state.rs:182-184)
+				query.clear();
+				challenges.clear();
+			}
+			// device state == oracle state
+			for (size_t j = 0; j < 3; j++) {
+				const auto &m = st.multilinears()[j];
+				if (rm[j].kind == REF_HAL_ML_TRANSPARENT) {
+					CHECK(m.kind == SumcheckMultilinear::Transparent);
+					continue;
+				}
+				CHECK(m.kind == SumcheckMultilinear::Folded && m.large_field_folded_evals.len_ == h[j].size());
+				if (!h[j].empty()) {
+					std::vector<B128> dev(h[j].size());
+					d.hal->copy_d2h(m.large_field_folded_evals, dev);
+					CHECK(dev == h[j]);
+				}
+			}
+		}
+		auto fin = st.finish(*d.hal);
+		CHECK(fin.size() == 3);
+		for (size_t j = 0; j < 3; j++) CHECK(fin[j] == (h[j].empty() ? b1(rm[j].suffix_eval) : h[j][0]));
+	}
+}
+
 int main()
 {
 	struct T {
@@ -674,6 +770,7 @@ int main()
 	    {"test_binary_merkle_vcs_commit_prove_open_correctly", test_binary_merkle_vcs},
 	    {"test_fri_commit_fold_query_device_resident", test_fri_commit_fold_query},
 	    {"test_prodcheck_layers_and_ring_switch_eq_ind", test_prodcheck_and_ring_switch_callers},
+	    {"test_old_hal_prover_state_both_orders_with_switchover", test_old_hal_prover_state},
 	};
 	int failed = 0;
 	try {

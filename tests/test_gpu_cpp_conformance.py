@@ -17,7 +17,7 @@ def test_cpp_conformance_suite():
     print(p.stdout)
     print(p.stderr)
     assert p.returncode == 0, p.stdout[-3000:]
-    assert "19/19 conformance tests passed" in p.stdout
+    assert "20/20 conformance tests passed" in p.stdout
 
 
 def test_cpp_conformance_binary_is_built():

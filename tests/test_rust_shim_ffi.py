@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 C_SCALARS = {"int": "c_int", "uint32_t": "u32", "uint64_t": "u64", "float": "f32", "double": "f64", "char": "c_char", "void": "c_void",
              "bn_f128": "bn_f128", "bn_ctx": "bn_ctx", "bn_expr": "bn_expr", "bn_step": "bn_step", "bn_memmap": "bn_memmap", "bn_kslice": "bn_kslice",
-             "bn_kop": "bn_kop"}
+             "bn_kop": "bn_kop", "bn_hal_multilinear": "bn_hal_multilinear", "bn_hal_evaluator": "bn_hal_evaluator"}
 
 
 def _strip_comments(text):
@@ -107,7 +107,7 @@ def test_extern_block_matches_the_header():
 def test_repr_c_structs_match_the_header():
     _, h_structs = parse_header()
     _, r_structs = parse_rust()
-    for name in ("bn_f128", "bn_step", "bn_memmap", "bn_kslice", "bn_kop"):
+    for name in ("bn_f128", "bn_step", "bn_memmap", "bn_kslice", "bn_kop", "bn_hal_multilinear", "bn_hal_evaluator"):
         assert h_structs[name] == r_structs[name], "%s: header %s != ffi.rs %s" % (name, h_structs[name], r_structs[name])
 
 
@@ -120,7 +120,8 @@ def test_constants_match_the_header():
             assert int(m.group(1)) == int(val), name
     for name in ("BN_OK", "BN_ERR_INPUT_VALIDATION", "BN_ERR_ALLOC", "BN_ERR_DEVICE", "BN_ERR_CORE_LIB", "BN_STEP_ADD", "BN_STEP_MUL", "BN_STEP_POW",
                  "BN_STEP_CONST", "BN_STEP_VAR", "BN_MAP_CHUNKED", "BN_MAP_CHUNKED_MUT", "BN_MAP_LOCAL", "BN_KOP_DECL_VALUE",
-                 "BN_KOP_SUM_COMPOSITION", "BN_KOP_ADD", "BN_KOP_ADD_ASSIGN", "BN_PROF_N"):
+                 "BN_KOP_SUM_COMPOSITION", "BN_KOP_ADD", "BN_KOP_ADD_ASSIGN", "BN_PROF_N", "BN_ORDER_LOW_TO_HIGH", "BN_ORDER_HIGH_TO_LOW",
+                 "BN_HAL_ML_FOLDED", "BN_HAL_ML_TRANSPARENT"):
         assert re.search(r"pub const %s: \w+ = \d+;" % name, r), "ffi.rs lacks %s" % name
     assert re.search(r"#define BN_NTT_MAX_DIM 64", h) and re.search(r"pub const BN_NTT_MAX_DIM: usize = 64;", r)
 
