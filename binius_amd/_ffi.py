@@ -137,6 +137,7 @@ def lib():
         "bn_expr_n_vars": [vp, C.POINTER(u32)],
         "bn_extrapolate_line": [vp, vp, u64, vp, u64, PF],
         "bn_extrapolate_line_batch": [vp, C.POINTER(vp), C.POINTER(vp), u32, u64, PF],
+        "bn_extrapolate_line_batch_scaled": [vp, C.POINTER(vp), C.POINTER(vp), u32, u64, PF, u32, PF],
         "bn_tensor_expand": [vp, vp, u64, u32, PF, u32],
         "bn_inner_product": [vp, vp, u64, u32, vp, u64, PF],
         "bn_fold_left": [vp, vp, u64, u32, vp, u64, vp, u64],
@@ -183,7 +184,7 @@ ABI_SYMBOLS = [
     "bn_kernel_launch", "bn_ntt_forward", "bn_ntt_inverse", "bn_ntt_s_evals", "bn_scalar_mul", "bn_scalar_invert",
     "bn_timer_begin", "bn_timer_end_ms", "bn_prof_begin", "bn_prof_end", "bn_xor_reduce", "bn_host_scratch",
     "bn_merkle_build", "bn_groestl256_leaves", "bn_groestl256_compress_layer", "bn_gather_d2h",
-    "bn_hal_round_evals", "bn_hal_fold_multilinear",
+    "bn_hal_round_evals", "bn_hal_fold_multilinear", "bn_extrapolate_line_batch_scaled",
 ]
 
 
@@ -501,6 +502,14 @@ class Context:
         p1 = (C.c_void_p * len(evals_1))(*[b.ptr for b in evals_1])
         zz = to_f128(z)
         _check(lib().bn_extrapolate_line_batch(self._h, p0, p1, len(evals_0), n, C.byref(zz)))
+
+    def extrapolate_line_batch_scaled(self, evals_0, evals_1, z, scale_mask, hi_scale):
+        """Extension: the batch fold, then the upper half of every folded array whose bit is set times hi_scale."""
+        n = evals_0[0].len
+        p0 = (C.c_void_p * len(evals_0))(*[a.ptr for a in evals_0])
+        p1 = (C.c_void_p * len(evals_1))(*[b.ptr for b in evals_1])
+        zz, hs = to_f128(z), to_f128(hi_scale)
+        _check(lib().bn_extrapolate_line_batch_scaled(self._h, p0, p1, len(evals_0), n, C.byref(zz), scale_mask, C.byref(hs)))
 
     def tensor_expand(self, log_n, coordinates, data):
         c = _f128_array(list(coordinates))

@@ -117,6 +117,10 @@ class MlecheckPlan:
         if rc != 0:
             raise BnError(rc, host_lib().bnh_last_error().decode())
 
+    def last_mode(self):
+        """1: WeightedMLEcheckProver ran; 0: the literal BivariateMLEcheckProver mirror."""
+        return host_lib().bnh_mlecheck_last_mode()
+
     def round_coeffs(self):
         return [[from_f128(self.coeffs[4 * r + i]) for i in range(4)] for r in range(self.n_vars)]
 

@@ -108,7 +108,7 @@ int flush_pending(bn_ctx *ctx, bool keep_tail, bool publish_tiny)
 		const uint64_t seq = ++ctx->mail_seq;
 		prof_scope ps(ctx, BN_PROF_FOLD);
 		BN_HIP(bn::launch_fold_publish(ctx->stream, ctx->pend.x0, ctx->pend.src0, ctx->pend.x1, ctx->pend.count, (uint32_t)ctx->pend.n,
-		                               ctx->pend.z, ctx->d_mail, seq));
+		                               ctx->pend.z, ctx->d_mail, seq, ctx->pend.scale_mask, ctx->pend.hi_scale));
 		ctx->mirror.valid = true;
 		ctx->mirror.seq = seq;
 		ctx->mirror.count = ctx->pend.count;
@@ -125,6 +125,9 @@ int flush_pending(bn_ctx *ctx, bool keep_tail, bool publish_tiny)
 	}
 	prof_scope ps(ctx, BN_PROF_FOLD);
 	BN_HIP(bn::launch_extrapolate_line_batch(ctx->stream, ctx->n_cu, fb, ctx->pend.count, ctx->pend.n, ctx->pend.z));
+	for (uint32_t i = 0; i < ctx->pend.count; i++)
+		if ((ctx->pend.scale_mask >> i) & 1)
+			BN_HIP(bn::launch_scale(ctx->stream, ctx->n_cu, (char *)ctx->pend.x0[i] + (ctx->pend.n / 2) * sizeof(f128), ctx->pend.n / 2, ctx->pend.hi_scale));
 	return BN_OK;
 }
 // one call at a time per context (the trait allows the host to call from several threads: rayon join/map)
@@ -538,9 +541,17 @@ int bn_extrapolate_line(bn_ctx *ctx, void *d_evals_0, uint64_t n0, const void *d
 int bn_extrapolate_line_batch(bn_ctx *ctx, void *const *d_evals_0, const void *const *d_evals_1, uint32_t count, uint64_t n,
                               const bn_f128 *z)
 {
+	return bn_extrapolate_line_batch_scaled(ctx, d_evals_0, d_evals_1, count, n, z, 0, nullptr);
+}
+
+int bn_extrapolate_line_batch_scaled(bn_ctx *ctx, void *const *d_evals_0, const void *const *d_evals_1, uint32_t count, uint64_t n,
+                                     const bn_f128 *z, uint32_t scale_mask, const bn_f128 *hi_scale)
+{
 	BN_REQUIRE(ctx && z && d_evals_0 && d_evals_1, "null argument");
 	BN_ENTER(ctx);
 	BN_REQUIRE(count <= (uint32_t)bn::kFoldBatchMax, "too many slices in one extrapolate_line batch");
+	BN_REQUIRE(scale_mask == 0 || (hi_scale && (n & 1) == 0 && (scale_mask >> count) == 0),
+	           "scaled fold: needs a scale, an even length and a mask within the batch");
 	if (count == 0) return BN_OK;
 	ctx->mirror.valid = false;
 	// deferred copies whose destination is one of the evals_0 are absorbed (every one of them must
@@ -592,6 +603,8 @@ int bn_extrapolate_line_batch(bn_ctx *ctx, void *const *d_evals_0, const void *c
 	ctx->pend.count = count;
 	ctx->pend.n = n;
 	ctx->pend.z = to_f(z);
+	ctx->pend.scale_mask = scale_mask;
+	ctx->pend.hi_scale = scale_mask ? to_f(hi_scale) : f128{0, 0};
 	for (uint32_t i = 0; i < count; i++) {
 		ctx->pend.x0[i] = d_evals_0[i];
 		ctx->pend.x1[i] = d_evals_1[i];

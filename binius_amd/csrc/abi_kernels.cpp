@@ -336,8 +336,14 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 											fa.x0[j] = pf.src0[i];
 											fa.x1[j] = pf.x1[i];
 											fa.out[j] = pf.x0[i];
+											if ((pf.scale_mask >> i) & 1) fa.scale_mask |= 1u << j;
 										}
+										fa.hi_scale = pf.hi_scale;
 										const uint64_t n_in = 2 * pf.n;
+										if (fa.scale_mask && ctx->tail.active) { // the resident tail kernel folds without a scale
+											rc = tail_cancel(ctx);
+											if (rc) return rc;
+										}
 										// (a) a resident tail kernel is parked for exactly this round: hand it z
 										if (ctx->tail.active) {
 											bn_ctx::tail_state &tl = ctx->tail;
@@ -386,7 +392,7 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 											}
 										}
 										// (b) small arrays: start a resident tail kernel with this round
-										if (fe == hipErrorNotSupported && h_out && !d_out && ctx->tail_max_n_in && n_in <= ctx->tail_max_n_in && n_in >= 8) {
+										if (fe == hipErrorNotSupported && !fa.scale_mask && h_out && !d_out && ctx->tail_max_n_in && n_in <= ctx->tail_max_n_in && n_in >= 8) {
 											bn_ctx::tail_state &tl = ctx->tail;
 											const uint64_t id = ++ctx->tail_counter;
 											prof_scope ps(ctx, BN_PROF_TAIL);

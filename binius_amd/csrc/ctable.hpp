@@ -192,4 +192,14 @@ __device__ __forceinline__ uint4 ctable_mul_pinned(const ctable_smem &s, uint4 x
 	return acc;
 }
 
+// A second nibble table that exists only in the kernel variants that need one (no LDS in the others)
+template <bool ON>
+struct ctable_opt {
+	ctable_smem t;
+	__device__ __forceinline__ ctable_smem &get() { return t; }
+};
+template <>
+struct ctable_opt<false> {
+};
+
 } // namespace bn

@@ -58,6 +58,8 @@ struct bn_ctx {
 		uint32_t count = 0;
 		uint64_t n = 0;
 		bn::f128 z{0, 0};
+		uint32_t scale_mask = 0; // bit i: the upper half of folded array i is multiplied by hi_scale (bn_extrapolate_line_batch_scaled)
+		bn::f128 hi_scale{0, 0};
 		void *x0[8] = {};        // evals_0: written in place ...
 		const void *x1[8] = {};
 		const void *src0[8] = {}; // ... and read from here (== x0 unless a deferred copy_d2d fed it)
@@ -126,7 +128,8 @@ struct fold_batch {
 };
 hipError_t launch_extrapolate_line_batch(hipStream_t s, int n_cu, const fold_batch &b, uint32_t count, uint64_t n, f128 z);
 hipError_t launch_fold_publish(hipStream_t s, void *const *x0, const void *const *src0, const void *const *x1, uint32_t count, uint32_t n,
-                               f128 z, f128 *d_mail, uint64_t seq);
+                               f128 z, f128 *d_mail, uint64_t seq, uint32_t scale_mask = 0, f128 hi_scale = f128{0, 0});
+hipError_t launch_scale(hipStream_t s, int n_cu, void *x, uint64_t n, f128 c); // x[i] *= c
 hipError_t launch_tensor_expand(hipStream_t s, int n_cu, void *data, uint32_t log_n, const f128 *coords, uint32_t k);
 
 // ---- kernels_roundeval.hip
@@ -178,6 +181,10 @@ struct foldeval_args {
 	const void *x0[2];
 	const void *x1[2];
 	void *out[2];
+	// bn_extrapolate_line_batch_scaled: bit j set -> the upper half of out[j] (the elements the next round reads as
+	// "evaluation at 1") is multiplied by hi_scale after the fold
+	uint32_t scale_mask;
+	f128 hi_scale;
 };
 bool foldeval9_is_small(int n_cu, uint64_t n_in);
 hipError_t launch_foldeval9(hipStream_t s, int n_cu, const foldeval_args &fa, uint64_t n_in, f128 z, f128 *d_out, const fin_fuse *fuse);

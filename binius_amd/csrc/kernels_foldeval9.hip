@@ -129,7 +129,7 @@ __device__ __forceinline__ void eval_staged(uint4 *wt, const eval_layout &lay, u
 // leaves the wave's 32 accumulator planes in acc.  wt = this wave's LDS tile (kWaveQ uint4).
 template <bool PREFETCH = true>
 __device__ __forceinline__ void foldeval_wave(const foldeval_args &fa, uint64_t n_in, const ctable_smem &tab, uint4 *wt,
-                                              uint64_t wave_global, uint64_t n_waves, uint32_t (&acc)[32])
+                                              uint64_t wave_global, uint64_t n_waves, uint32_t (&acc)[32], const ctable_smem *tab_hs = nullptr)
 {
 	const unsigned lane = threadIdx.x & 63;
 	const eval_layout lay = make_eval_layout(lane);
@@ -182,7 +182,9 @@ __device__ __forceinline__ void foldeval_wave(const foldeval_args &fa, uint64_t 
 #pragma unroll
 		for (int t = 0; t < kSlots; t++) {
 			const unsigned pt = lane + 64 * (t & 1);
-			const uint4 f = xor4(x0[t], ctable_mul<8>(tab, xor4(x0[t], x1[t])));
+			uint4 f = xor4(x0[t], ctable_mul<8>(tab, xor4(x0[t], x1[t])));
+			// slot t: array t >> 2, half (t >> 1) & 1 -- the scaled fold multiplies the upper half of a marked array
+			if (tab_hs && ((t >> 1) & 1) && ((fa.scale_mask >> (t >> 2)) & 1)) f = ctable_mul<8>(*tab_hs, f);
 			if (pt < kBatch) {
 				if (pt < left)
 					((uint4 *)fa.out[t >> 2] + qoff(t, p0))[pt] = f;
@@ -201,17 +203,23 @@ __device__ __forceinline__ void foldeval_wave(const foldeval_args &fa, uint64_t 
 
 }
 
-template <int WAVES>
+template <int WAVES, bool SCALED = false>
 __global__ __launch_bounds__(256, WAVES) void k_foldeval9(foldeval_args fa, uint64_t n_in, f128 z, f128 *out, fin_fuse fz)
 {
 	__shared__ uint4 tile[4][kWaveQ];
 	__shared__ ctable_smem tab;
+	__shared__ ctable_opt<SCALED> tab_hs;
+	const ctable_smem *hs = nullptr;
+	if constexpr (SCALED) {
+		ctable_build(tab_hs.get(), fa.hi_scale);
+		hs = &tab_hs.get();
+	}
 	ctable_build(tab, z);
 	const unsigned lane = threadIdx.x & 63;
 	const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const unsigned g = lane / 9, c = lane - g * 9;
 	uint32_t acc[32];
-	foldeval_wave(fa, n_in, tab, tile[wave], (uint64_t)blockIdx.x * 4 + wave, (uint64_t)gridDim.x * 4, acc);
+	foldeval_wave(fa, n_in, tab, tile[wave], (uint64_t)blockIdx.x * 4 + wave, (uint64_t)gridDim.x * 4, acc, hs);
 	re9::tail<4>(acc, lane < 63, c, g, wave, lane, out, fz, fz.args.seq);
 }
 
@@ -220,10 +228,12 @@ __global__ __launch_bounds__(256, WAVES) void k_foldeval9(foldeval_args fa, uint
 // of a batch (1600 instructions) cost 3 us on one wave; here the four waves of the workgroup fold one
 // quadrant each (2 slots), with the loads in flight while the nibble tables are built, and wave 0
 // evaluates the batch.
+template <bool SCALED>
 __global__ __launch_bounds__(256, 2) void k_foldeval9_small(foldeval_args fa, uint64_t n_in, f128 z, f128 *out, fin_fuse fz)
 {
 	__shared__ uint4 tile[kWaveQ];
 	__shared__ ctable_smem tab;
+	__shared__ ctable_opt<SCALED> tab_hs;
 	const unsigned lane = threadIdx.x & 63;
 	const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const unsigned g = lane / 9, c = lane - g * 9;
@@ -246,14 +256,18 @@ __global__ __launch_bounds__(256, 2) void k_foldeval9_small(foldeval_args fa, ui
 		x0[sub] = v0;
 		x1[sub] = v1;
 	}
+	if constexpr (SCALED) ctable_build(tab_hs.get(), fa.hi_scale);
 	ctable_build(tab, z); // the loads above are in flight meanwhile
+	const bool scaled_quadrant = SCALED && (wave & 1) && ((fa.scale_mask >> (wave >> 1)) & 1); // (wave-uniform)
 	if (threadIdx.x < kBlkQ)
 		tile[kZeroBlk * kBlkQ + threadIdx.x] = uint4{0, 0, 0, 0};
 #pragma unroll
 	for (int sub = 0; sub < 2; sub++) {
 		const unsigned pt = lane + 64 * sub;
 		if (sub == 1 && left <= 64) break; // (uniform) nothing in the second slot
-		const uint4 f = xor4(x0[sub], ctable_mul(tab, xor4(x0[sub], x1[sub])));
+		uint4 f = xor4(x0[sub], ctable_mul(tab, xor4(x0[sub], x1[sub])));
+		if constexpr (SCALED)
+			if (scaled_quadrant) f = ctable_mul(tab_hs.get(), f);
 		if (pt < kBatch) {
 			if (pt < left) qd[pt] = f;
 			tile[(wave >> 1) * kArrQ + (wave & 1) * kBatch + pt] = f;
@@ -363,11 +377,17 @@ hipError_t launch_foldeval9(hipStream_t s, int n_cu, const foldeval_args &fa, ui
 	const uint64_t cap = (uint64_t)n_cu * 2;
 	if (foldeval9_is_small(n_cu, n_in)) {
 		// small round: one workgroup per batch, the four waves share the fold (latency, not throughput)
-		hipLaunchKernelGGL(k_foldeval9_small, dim3((unsigned)n_batches), dim3(256), 0, s, fa, n_in, z, d_out, fz);
+		if (fa.scale_mask)
+			hipLaunchKernelGGL(k_foldeval9_small<true>, dim3((unsigned)n_batches), dim3(256), 0, s, fa, n_in, z, d_out, fz);
+		else
+			hipLaunchKernelGGL(k_foldeval9_small<false>, dim3((unsigned)n_batches), dim3(256), 0, s, fa, n_in, z, d_out, fz);
 		return hipGetLastError();
 	}
 	if (blocks > cap) blocks = cap;
-	hipLaunchKernelGGL((k_foldeval9<2>), dim3((unsigned)blocks), dim3(256), 0, s, fa, n_in, z, d_out, fz);
+	if (fa.scale_mask)
+		hipLaunchKernelGGL((k_foldeval9<2, true>), dim3((unsigned)blocks), dim3(256), 0, s, fa, n_in, z, d_out, fz);
+	else
+		hipLaunchKernelGGL((k_foldeval9<2, false>), dim3((unsigned)blocks), dim3(256), 0, s, fa, n_in, z, d_out, fz);
 	return hipGetLastError();
 }
 

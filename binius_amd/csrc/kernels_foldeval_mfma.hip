@@ -28,10 +28,14 @@ namespace bn {
 
 using namespace gram;
 
+// SC: 0 = plain fold; 1 / 2 = the upper half of folded array 0 / 1 is multiplied by fa.hi_scale (a fifth constant
+// multiplication per point, through a second nibble table) before it is stored and staged.
+template <int SC>
 __global__ __launch_bounds__(256, 2) void k_foldeval_mfma(foldeval_args fa, uint64_t n_in, f128 z, f128 *out, fin_fuse fz)
 {
 	__shared__ __attribute__((aligned(16))) uint32_t T[2][kTileW];
 	__shared__ ctable_smem tab;
+	__shared__ ctable_opt<SC != 0> tab_hs;
 	const unsigned lane = threadIdx.x & 63;
 	const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const stage_role sr = make_stage_role(wave, lane);
@@ -59,6 +63,7 @@ __global__ __launch_bounds__(256, 2) void k_foldeval_mfma(foldeval_args fa, uint
 	};
 	uint64_t t = blockIdx.x;
 	if (t < n_tiles) load(t);
+	if constexpr (SC != 0) ctable_build(tab_hs.get(), fa.hi_scale);
 	ctable_build(tab, z); // the loads above are in flight meanwhile; ends with a barrier
 
 	// One iteration: fold tile tt (VALU + LDS lookups) with, when GRAM, the Gram k-steps of the previous
@@ -81,6 +86,7 @@ __global__ __launch_bounds__(256, 2) void k_foldeval_mfma(foldeval_args fa, uint
 		}
 		f[1] = xor4(x0[1], ctable_mul_pinned<4>(tab, xor4(x0[1], x1[1])));
 		load1(tn, 1); // this quadrant of the next tile flies from here on
+		if constexpr (SC == 1) f[1] = ctable_mul_pinned<4>(tab_hs.get(), f[1]);
 		if (GRAM) {
 			gram_step<2>(Tp, gr, gp, acc);
 			gram_step<3>(Tp, gr, gp, acc);
@@ -93,6 +99,7 @@ __global__ __launch_bounds__(256, 2) void k_foldeval_mfma(foldeval_args fa, uint
 		}
 		f[3] = xor4(x0[3], ctable_mul_pinned<4>(tab, xor4(x0[3], x1[3])));
 		load1(tn, 3); // this quadrant of the next tile flies from here on
+		if constexpr (SC == 2) f[3] = ctable_mul_pinned<4>(tab_hs.get(), f[3]);
 		if (GRAM) {
 			gram_step<6>(Tp, gr, gp, acc);
 			gram_step<7>(Tp, gr, gp, acc);
@@ -133,7 +140,13 @@ hipError_t launch_foldeval_mfma(hipStream_t s, int n_cu, const foldeval_args &fa
 	if (fuse) fz = *fuse;
 	const uint64_t n_tiles = ((n_in >> 2) + kTP - 1) / kTP;
 	const uint64_t cap = (uint64_t)n_cu * 2;
-	hipLaunchKernelGGL(k_foldeval_mfma, dim3((unsigned)(n_tiles < cap ? n_tiles : cap)), dim3(256), 0, s, fa, n_in, z, d_out, fz);
+	const dim3 grid((unsigned)(n_tiles < cap ? n_tiles : cap));
+	switch (fa.scale_mask) {
+	case 0: hipLaunchKernelGGL(k_foldeval_mfma<0>, grid, dim3(256), 0, s, fa, n_in, z, d_out, fz); break;
+	case 1: hipLaunchKernelGGL(k_foldeval_mfma<1>, grid, dim3(256), 0, s, fa, n_in, z, d_out, fz); break;
+	case 2: hipLaunchKernelGGL(k_foldeval_mfma<2>, grid, dim3(256), 0, s, fa, n_in, z, d_out, fz); break;
+	default: return hipErrorNotSupported; // both arrays scaled: the caller runs fold, scale and evaluation separately
+	}
 	return hipGetLastError();
 }
 

@@ -194,7 +194,8 @@ struct fold_publish_args {
 	const void *src0[kFoldBatchMax];
 	const void *x1[kFoldBatchMax];
 };
-__global__ __launch_bounds__(256) void k_fold_publish(fold_publish_args fb, uint32_t count, uint32_t n, f128 z, f128 *mail, uint64_t seq)
+__global__ __launch_bounds__(256) void k_fold_publish(fold_publish_args fb, uint32_t count, uint32_t n, f128 z, f128 *mail, uint64_t seq,
+                                                      uint32_t scale_mask, f128 hi_scale)
 {
 	__shared__ ctable_smem tab;
 	ctable_build(tab, z);
@@ -202,7 +203,8 @@ __global__ __launch_bounds__(256) void k_fold_publish(fold_publish_args fb, uint
 	if (i < count * n) {
 		const unsigned arr = i / n, j = i - arr * n;
 		const uint4 a = ((const uint4 *)fb.src0[arr])[j], b = ((const uint4 *)fb.x1[arr])[j];
-		const uint4 f = xor4(a, ctable_mul(tab, xor4(a, b)));
+		uint4 f = xor4(a, ctable_mul(tab, xor4(a, b)));
+		if (((scale_mask >> arr) & 1) && 2 * j >= n) f = to_u4(mul_slow(to_f128(f), hi_scale)); // (a handful of elements)
 		((uint4 *)fb.x0[arr])[j] = f;
 		const f128 v = to_f128(f);
 		__hip_atomic_store(&mail[i].lo, v.lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(256) void k_fold_publish(fold_publish_args fb, uint
 }
 
 hipError_t launch_fold_publish(hipStream_t s, void *const *x0, const void *const *src0, const void *const *x1, uint32_t count, uint32_t n,
-                               f128 z, f128 *d_mail, uint64_t seq)
+                               f128 z, f128 *d_mail, uint64_t seq, uint32_t scale_mask, f128 hi_scale)
 {
 	if (count == 0 || n == 0 || count > (uint32_t)kFoldBatchMax || (uint64_t)count * n > 64) return hipErrorNotSupported;
 	fold_publish_args fb{};
@@ -223,7 +225,24 @@ hipError_t launch_fold_publish(hipStream_t s, void *const *x0, const void *const
 		fb.src0[i] = src0[i];
 		fb.x1[i] = x1[i];
 	}
-	hipLaunchKernelGGL(k_fold_publish, dim3(1), dim3(256), 0, s, fb, count, n, z, d_mail, seq);
+	hipLaunchKernelGGL(k_fold_publish, dim3(1), dim3(256), 0, s, fb, count, n, z, d_mail, seq, scale_mask, hi_scale);
+	return hipGetLastError();
+}
+
+// x[i] *= c in place (the stand-alone form of the upper-half scaling of bn_extrapolate_line_batch_scaled; the fused
+// fold + evaluation kernels do it on the folded registers)
+__global__ __launch_bounds__(256) void k_scale(uint4 *__restrict__ x, uint64_t n, f128 c)
+{
+	__shared__ ctable_smem tab;
+	ctable_build(tab, c);
+	for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256)
+		x[i] = ctable_mul(tab, x[i]);
+}
+
+hipError_t launch_scale(hipStream_t s, int n_cu, void *x, uint64_t n, f128 c)
+{
+	if (n == 0) return hipSuccess;
+	hipLaunchKernelGGL(k_scale, dim3(grid_for(n, 256, n_cu, 8)), dim3(256), 0, s, (uint4 *)x, n, c);
 	return hipGetLastError();
 }
 

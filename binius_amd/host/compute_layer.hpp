@@ -572,11 +572,24 @@ public:
 	{
 		if (evals_0.len_ != evals_1.len_) throw Error(Error::InputValidation, "evals_0 and evals_1 must be the same length");
 		if (batching_) {
-			pending_.push_back(PendingLine{evals_0.ptr, evals_1.ptr, evals_0.len_, z});
+			pending_.push_back(PendingLine{evals_0.ptr, evals_1.ptr, evals_0.len_, z, false, B128()});
 			return;
 		}
 		bn_f128 zz = z.raw();
 		check(bn_extrapolate_line(ctx_, evals_0.ptr, evals_0.len_, evals_1.ptr, evals_1.len_, &zz));
+	}
+	// Extension (bn_extrapolate_line_batch_scaled): extrapolate_line, then the upper half of evals_0 times hi_scale
+	void extrapolate_line_scaled(FSliceMut &evals_0, FSlice evals_1, B128 z, B128 hi_scale)
+	{
+		if (evals_0.len_ != evals_1.len_) throw Error(Error::InputValidation, "evals_0 and evals_1 must be the same length");
+		if (batching_) {
+			pending_.push_back(PendingLine{evals_0.ptr, evals_1.ptr, evals_0.len_, z, true, hi_scale});
+			return;
+		}
+		void *e0 = evals_0.ptr;
+		const void *e1 = evals_1.ptr;
+		const bn_f128 zz = z.raw(), hs = hi_scale.raw();
+		check(bn_extrapolate_line_batch_scaled(ctx_, &e0, &e1, 1, evals_0.len_, &zz, 1, &hs));
 	}
 	void compute_composite(const SlicesBatch<FSlice> &inputs, FSliceMut &output, const ExprEval &composition)
 	{
@@ -602,6 +615,8 @@ private:
 		const void *e1;
 		size_t len;
 		B128 z;
+		bool scaled = false;
+		B128 hi_scale{};
 	};
 	void flush_pending()
 	{
@@ -612,13 +627,20 @@ private:
 			std::vector<void *> e0;
 			std::vector<const void *> e1;
 			size_t j = i;
-			while (j < todo.size() && e0.size() < 8 && todo[j].len == todo[i].len && todo[j].z == todo[i].z) {
+			uint32_t mask = 0;
+			B128 hs{};
+			while (j < todo.size() && e0.size() < 8 && todo[j].len == todo[i].len && todo[j].z == todo[i].z &&
+			       !(todo[j].scaled && mask && !(todo[j].hi_scale == hs))) {
+				if (todo[j].scaled) {
+					mask |= 1u << e0.size();
+					hs = todo[j].hi_scale;
+				}
 				e0.push_back(todo[j].e0);
 				e1.push_back(todo[j].e1);
 				j++;
 			}
-			bn_f128 zz = todo[i].z.raw();
-			check(bn_extrapolate_line_batch(ctx_, e0.data(), e1.data(), (uint32_t)e0.size(), todo[i].len, &zz));
+			const bn_f128 zz = todo[i].z.raw(), hsr = hs.raw();
+			check(bn_extrapolate_line_batch_scaled(ctx_, e0.data(), e1.data(), (uint32_t)e0.size(), todo[i].len, &zz, mask, mask ? &hsr : nullptr));
 			i = j;
 		}
 	}

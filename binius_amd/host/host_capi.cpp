@@ -391,6 +391,9 @@ int bnh_bivariate_sumcheck_prove(bn_ctx *ctx, uint32_t n_vars, uint32_t m, const
 	}
 }
 
+static thread_local int g_mlecheck_mode = -1;
+int bnh_mlecheck_last_mode(void) { return g_mlecheck_mode; }
+
 // One complete BivariateMLEcheckProver run (v3/bivariate_mlecheck.rs) behind a C call.
 //   d_eq_ind             2^(n_vars-1) elements: tensor expansion of eq_ind_challenges[0 .. n_vars-1)
 //   round_coeffs_out     [4 * n_vars] (degree-3 round polynomials)
@@ -415,14 +418,55 @@ int bnh_bivariate_mlecheck_prove(bn_ctx *ctx, uint32_t n_vars, uint32_t m, const
 		}
 		for (uint32_t i = 0; i < n_vars; i++) eqc.emplace_back(eq_ind_challenges[i].lo, eq_ind_challenges[i].hi);
 		const B128 bc(batch_coeff->lo, batch_coeff->hi);
-		BivariateMLEcheckProver prover(hal, dev_alloc, host_alloc, n_vars, comps, sv, mls,
-		                               FSlice{d_eq_ind, (size_t)1 << (n_vars ? n_vars - 1 : 0)}, eqc);
-		for (uint32_t r = 0; r < n_vars; r++) {
-			std::vector<B128> rc = prover.execute(bc);
-			for (size_t i = 0; i < 4 && i < rc.size(); i++) round_coeffs_out[4 * r + i] = rc[i].raw();
-			prover.fold(B128(challenges[r].lo, challenges[r].hi));
+		const FSlice eq_table{d_eq_ind, (size_t)1 << (n_vars ? n_vars - 1 : 0)};
+		auto run = [&](auto &prover) {
+			for (uint32_t r = 0; r < n_vars; r++) {
+				std::vector<B128> rc = prover.execute(bc);
+				for (size_t i = 0; i < 4 && i < rc.size(); i++) round_coeffs_out[4 * r + i] = rc[i].raw();
+				prover.fold(B128(challenges[r].lo, challenges[r].hi));
+			}
+			return prover.finish();
+		};
+		// The weighted prover (sumcheck.hpp) when it applies: a proper 2-colouring of the compositions, invertible
+		// indicator coordinates, enough scratch, and a table that IS the tensor expansion of the coordinates (the
+		// constructor's contract: "an existing tensor expansion for eq_ind_challenges", bivariate_mlecheck.rs:69-71 --
+		// spot-checked here on n_vars + 17 entries because the weighted prover derives the later tables from the
+		// coordinates instead of folding the given one).
+		std::vector<bool> weighted;
+		const char *mode = getenv("BN_MLECHECK");
+		if (!(mode && std::string(mode) == "eager") && n_vars >= 2 && n_comps > 0) {
+			weighted = WeightedMLEcheckProver::colouring(m, comps);
+			bool any = false;
+			for (bool w : weighted) any = any || w;
+			if (!any || !WeightedMLEcheckProver::coordinates_invertible(eqc, n_vars) ||
+			    WeightedMLEcheckProver::required_device_memory(weighted, n_vars) > scratch_elems)
+				weighted.clear();
 		}
-		std::vector<B128> fin = prover.finish();
+		if (!weighted.empty()) {
+			std::vector<uint64_t> offs{0, eq_table.len() - 1};
+			for (uint32_t i = 0; i + 1 < n_vars; i++) offs.push_back((uint64_t)1 << i);
+			uint64_t lcg = eqc[0].raw().lo ^ 0x9E3779B97F4A7C15ull; // a few more, spread over the table
+			for (int k = 0; k < 16; k++) {
+				lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
+				offs.push_back((lcg >> 20) & (eq_table.len() - 1));
+			}
+			std::vector<B128> got(offs.size());
+			check(bn_gather_d2h(ctx, d_eq_ind, offs.data(), offs.size(), 1, reinterpret_cast<bn_f128 *>(got.data())));
+			for (size_t k = 0; k < offs.size() && !weighted.empty(); k++) {
+				B128 want = B128::ONE();
+				for (uint32_t i = 0; i + 1 < n_vars; i++) want = want * (((offs[k] >> i) & 1) ? eqc[i] : B128::ONE() - eqc[i]);
+				if (!(got[k] == want)) weighted.clear();
+			}
+		}
+		std::vector<B128> fin;
+		g_mlecheck_mode = weighted.empty() ? 0 : 1;
+		if (!weighted.empty()) {
+			WeightedMLEcheckProver prover(hal, dev_alloc, host_alloc, n_vars, comps, sv, mls, eq_table, eqc, weighted);
+			fin = run(prover);
+		} else {
+			BivariateMLEcheckProver prover(hal, dev_alloc, host_alloc, n_vars, comps, sv, mls, eq_table, eqc);
+			fin = run(prover);
+		}
 		for (uint32_t j = 0; j <= m; j++) final_evals_out[j] = fin[j].raw();
 		return 0;
 	} catch (const Error &e) {

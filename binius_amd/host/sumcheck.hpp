@@ -395,4 +395,230 @@ private:
 	std::vector<B128> eq_ind_challenges_;
 };
 
+// ------------------------------------------------------------------------------------------------------------------
+// BivariateMLEcheckProver, same statement and same transcript, with the equality indicator carried INSIDE one factor
+// of every composition instead of being multiplied in at every hypercube point of every round.
+//
+// The reference's round r sums  eq_r(x') * a_r(X, x') * b_r(X, x')  over x' (bivariate_mlecheck.rs:391-520): three
+// multilinears, two chained GF(2^128) products per point, and the 2^(n-1-r)-entry indicator table is folded next to
+// the multilinears (:195-254).  Here one factor of each composition is replaced ONCE by
+//     S_0(v, x') = a(v, x') * eq_0(x')                       (one element-wise product pass, compute_composite)
+// and from then on the round is the plain bivariate product round of S and b -- the kernel the sumcheck prover runs,
+// matrix-core Gram products and the fused fold + evaluation pass included.  What keeps S consistent:
+//     eq_r(u, x'') = eq_{r+1}(x'') * (u ? zeta : 1 - zeta)    zeta = eq_ind_challenges[index of u]
+// so after the fold with the round challenge, S_{r+1}(u, x'') = lambda * a_{r+1}(u, x'') * eq_{r+1}(x'') holds with
+// ONE scalar lambda for both halves once the upper half (u = 1) is multiplied by (1 - zeta) / zeta:
+// extrapolate_line_scaled.  lambda grows by (1 - zeta) per round and is divided out of the two round evaluations and
+// of the final evaluation on the host.  Exact field arithmetic: the transcript is the reference's, bit for bit.
+//
+// Applicable when the compositions' graph has a proper 2-colouring (every product has exactly one weighted factor)
+// and no indicator coordinate is 0 or 1 (zeta and 1 - zeta are inverted); the caller falls back to
+// BivariateMLEcheckProver otherwise.  Device memory: 2^n per weighted multilinear, 2^(n-1) per other one.
+class WeightedMLEcheckProver {
+public:
+	// colouring[i] = true: multilinear i carries the indicator.  Empty result = no proper colouring.
+	static std::vector<bool> colouring(size_t n_multilinears, const std::vector<IndexCompositionBivariate> &compositions)
+	{
+		std::vector<int> col(n_multilinears, -1);
+		std::vector<bool> none;
+		// components in index order; the first vertex of a component is left unweighted unless that puts more
+		// arrays on the weighted side than the other choice (weighted arrays cost twice the memory)
+		for (size_t root = 0; root < n_multilinears; root++) {
+			if (col[root] >= 0) continue;
+			std::vector<size_t> comp{root};
+			col[root] = 0;
+			bool touched = false;
+			for (size_t h = 0; h < comp.size(); h++)
+				for (const auto &c : compositions)
+					for (int side = 0; side < 2; side++)
+						if (c.indices[side] == comp[h]) {
+							touched = true;
+							const size_t o = c.indices[1 - side];
+							if (o >= n_multilinears) return none;
+							if (col[o] < 0) {
+								col[o] = 1 - col[comp[h]];
+								comp.push_back(o);
+							} else if (col[o] == col[comp[h]]) {
+								return none; // odd cycle (or a square a * a)
+							}
+						}
+			if (!touched) continue; // not in any composition: folded like an unweighted one
+			size_t ones = 0;
+			for (size_t v : comp) ones += col[v] == 1;
+			if (2 * ones > comp.size())
+				for (size_t v : comp) col[v] = 1 - col[v];
+			// a component with a composition has at least one vertex of each colour
+		}
+		std::vector<bool> out(n_multilinears);
+		for (size_t i = 0; i < n_multilinears; i++) out[i] = col[i] == 1;
+		return out;
+	}
+	static bool coordinates_invertible(const std::vector<B128> &eq_ind_challenges, size_t n_vars)
+	{
+		for (size_t i = 0; i + 1 < n_vars; i++)
+			if (eq_ind_challenges[i] == B128::ZERO() || eq_ind_challenges[i] == B128::ONE()) return false;
+		return true;
+	}
+	static size_t required_device_memory(const std::vector<bool> &weighted, size_t n_vars)
+	{
+		size_t total = 0;
+		for (bool w : weighted) total += w ? (size_t)1 << n_vars : (size_t)1 << (n_vars ? n_vars - 1 : 0);
+		return total;
+	}
+
+	WeightedMLEcheckProver(ComputeLayer &hal, DeviceBumpAllocator &dev_alloc, HostBumpAllocator &host_alloc, size_t n_vars,
+	                       const std::vector<IndexCompositionBivariate> &compositions, const std::vector<B128> &sums,
+	                       const std::vector<FSlice> &multilins, FSlice eq_ind_partial_evals, std::vector<B128> eq_ind_challenges,
+	                       std::vector<bool> weighted)
+	    : hal_(hal), dev_alloc_(dev_alloc), host_alloc_(host_alloc), n_vars_initial_(n_vars), n_vars_remaining_(n_vars),
+	      eq_ind_challenges_(std::move(eq_ind_challenges)), weighted_(std::move(weighted))
+	{
+		for (const auto &ml : multilins)
+			if (ml.len() != (size_t)1 << n_vars) throw SumcheckError("NumberOfVariablesMismatch");
+		if (eq_ind_partial_evals.len() != (size_t)1 << (n_vars ? n_vars - 1 : 0)) throw SumcheckError("IncorrectEqIndPartialEvalsSize");
+		if (weighted_.size() != multilins.size()) throw SumcheckError("colouring does not match the multilinears");
+		for (const auto &c : compositions) {
+			if (weighted_[c.indices[0]] == weighted_[c.indices[1]]) throw SumcheckError("composition without exactly one weighted factor");
+			evaluators_.push_back(hal.compile_expr(c.expression()));
+		}
+		state_ = InitialSums;
+		sums_or_coeffs_ = sums;
+		// S_0 = a * eq_0 on both halves of every weighted multilinear
+		const ExprEval prod = hal.compile_expr(ArithCircuit::var(0) * ArithCircuit::var(1));
+		const size_t half = eq_ind_partial_evals.len();
+		for (size_t i = 0; i < multilins.size(); i++) {
+			if (!weighted_[i]) {
+				multilins_.push_back(Multilin{true, FSliceMut{const_cast<void *>(multilins[i].ptr), multilins[i].len_}});
+				continue;
+			}
+			if (n_vars == 0) { // a single value, no indicator variables: nothing to weight
+				multilins_.push_back(Multilin{true, FSliceMut{const_cast<void *>(multilins[i].ptr), multilins[i].len_}});
+				continue;
+			}
+			FSliceMut s = dev_alloc_.alloc(multilins[i].len());
+			auto in = ComputeMemory::split_half(multilins[i]);
+			auto out = ComputeMemory::split_half_mut(s);
+			hal.execute([&](ComputeLayerExecutor &exec) {
+				exec.compute_composite(SlicesBatch<FSlice>({in.first, eq_ind_partial_evals}, half), out.first, prod);
+				exec.compute_composite(SlicesBatch<FSlice>({in.second, eq_ind_partial_evals}, half), out.second, prod);
+				return std::vector<B128>{};
+			});
+			multilins_.push_back(Multilin{false, s}); // our own buffer: folded in place from the first round on
+		}
+	}
+	size_t n_vars() const { return n_vars_initial_; }
+
+	std::vector<B128> execute(B128 batch_coeff)
+	{
+		std::vector<FSlice> mls;
+		for (const auto &m : multilins_) mls.push_back(FSlice{m.evals.ptr, m.evals.len_});
+		std::vector<B128> round_evals = calculate_round_evals(hal_, n_vars_remaining_, batch_coeff, mls, evaluators_);
+		const B128 lambda_inv = lambda_.invert_or_zero();
+		for (auto &e : round_evals) e = e * lambda_inv;
+		B128 batched_sum;
+		switch (state_) {
+		case Coeffs: throw SumcheckError("ExpectedFold");
+		case InitialSums: batched_sum = evaluate_univariate(sums_or_coeffs_, batch_coeff); break;
+		default: batched_sum = batched_sum_; break;
+		}
+		// from here on: BivariateMLEcheckProver::execute (:273-318) unchanged
+		const B128 alpha = eq_ind_challenges_[n_vars_remaining_ - 1];
+		const B128 y_1 = round_evals[0], y_inf = round_evals[1];
+		const B128 y_0 = (batched_sum - y_1 * alpha) * (B128::ONE() - alpha).invert_or_zero();
+		const B128 c_0 = y_0, c_2 = y_inf, c_1 = y_1 - c_0 - c_2;
+		const std::vector<B128> prime{c_0, c_1, c_2};
+		state_ = Coeffs;
+		sums_or_coeffs_ = prime;
+		const B128 k0 = B128::ONE() - alpha, k1 = alpha.dbl() - B128::ONE();
+		std::vector<B128> coeffs(4, B128::ZERO());
+		for (size_t d = 0; d < 3; d++) {
+			coeffs[d] = coeffs[d] + prime[d] * k0;
+			coeffs[d + 1] = coeffs[d + 1] + prime[d] * k1;
+		}
+		for (auto &c : coeffs) c = c * eq_ind_prefix_eval_;
+		return coeffs;
+	}
+
+	void fold(B128 challenge)
+	{
+		if (n_vars_remaining_ == 0) throw SumcheckError("ExpectedFinish");
+		if (state_ != Coeffs) throw SumcheckError("ExpectedExecution");
+		batched_sum_ = evaluate_univariate(sums_or_coeffs_, challenge);
+		state_ = BatchedSum;
+		eq_ind_prefix_eval_ = eq_ind_prefix_eval_ * eq(eq_ind_challenges_[n_vars_remaining_ - 1], challenge);
+		// the variable that splits the folded arrays becomes the next round variable: level its two halves
+		const bool scale = n_vars_remaining_ >= 2;
+		B128 hi_scale = B128::ONE();
+		if (scale) {
+			const B128 zeta = eq_ind_challenges_[n_vars_remaining_ - 2];
+			hi_scale = (B128::ONE() - zeta) * zeta.invert_or_zero();
+			lambda_ = lambda_ * (B128::ONE() - zeta);
+		}
+		std::vector<FoldArgs> prepared;
+		for (size_t i = 0; i < multilins_.size(); i++) {
+			auto &m = multilins_[i];
+			if (m.pre_fold) {
+				auto halves = ComputeMemory::split_half(FSlice{m.evals.ptr, m.evals.len_});
+				FSliceMut folded = dev_alloc_.alloc((size_t)1 << (n_vars_remaining_ - 1));
+				hal_.copy_d2d(halves.first, folded);
+				prepared.push_back(FoldArgs{folded, halves.second, scale && weighted_[i]});
+			} else {
+				auto halves = ComputeMemory::split_half_mut(m.evals);
+				prepared.push_back(FoldArgs{halves.first, ComputeMemory::to_const(halves.second), scale && weighted_[i]});
+			}
+		}
+		hal_.execute([&](ComputeLayerExecutor &exec) {
+			multilins_ = exec.map(prepared.begin(), prepared.end(), [&](ComputeLayerExecutor &e, FoldArgs &a) {
+				if (a.scaled)
+					e.extrapolate_line_scaled(a.evals_0, a.evals_1, challenge, hi_scale);
+				else
+					e.extrapolate_line(a.evals_0, a.evals_1, challenge);
+				return Multilin{false, a.evals_0};
+			});
+			return std::vector<B128>{};
+		});
+		n_vars_remaining_ -= 1;
+	}
+
+	std::vector<B128> finish()
+	{
+		if (state_ == Coeffs) throw SumcheckError("ExpectedFold");
+		if (n_vars_remaining_ != 0) throw SumcheckError("ExpectedExecution");
+		HostSliceMut buffer = host_alloc_.alloc(multilins_.size());
+		for (size_t i = 0; i < multilins_.size(); i++)
+			hal_.copy_d2h(FSlice{multilins_[i].evals.ptr, multilins_[i].evals.len_}, &buffer[i], 1);
+		std::vector<B128> res(buffer.ptr, buffer.ptr + multilins_.size());
+		const B128 lambda_inv = lambda_.invert_or_zero();
+		for (size_t i = 0; i < res.size(); i++)
+			if (weighted_[i]) res[i] = res[i] * lambda_inv;
+		res.push_back(eq_ind_prefix_eval_);
+		return res;
+	}
+
+private:
+	struct Multilin {
+		bool pre_fold;
+		FSliceMut evals;
+	};
+	struct FoldArgs {
+		FSliceMut evals_0;
+		FSlice evals_1;
+		bool scaled;
+	};
+	enum State { Coeffs, InitialSums, BatchedSum };
+	ComputeLayer &hal_;
+	DeviceBumpAllocator &dev_alloc_;
+	HostBumpAllocator &host_alloc_;
+	size_t n_vars_initial_, n_vars_remaining_;
+	std::vector<Multilin> multilins_;
+	std::vector<ExprEval> evaluators_;
+	State state_;
+	std::vector<B128> sums_or_coeffs_;
+	B128 batched_sum_;
+	B128 eq_ind_prefix_eval_ = B128::ONE();
+	B128 lambda_ = B128::ONE();
+	std::vector<B128> eq_ind_challenges_;
+	std::vector<bool> weighted_;
+};
+
 } // namespace binius_amd

@@ -146,6 +146,16 @@ unsafe extern "C" {
 		n: u64,
 		z: *const bn_f128,
 	) -> c_int;
+	pub fn bn_extrapolate_line_batch_scaled(
+		ctx: *mut bn_ctx,
+		d_evals_0: *const *mut c_void,
+		d_evals_1: *const *const c_void,
+		count: u32,
+		n: u64,
+		z: *const bn_f128,
+		scale_mask: u32,
+		hi_scale: *const bn_f128,
+	) -> c_int;
 	pub fn bn_tensor_expand(ctx: *mut bn_ctx, d_data: *mut c_void, data_len: u64, log_n: u32, h_coords: *const bn_f128, k: u32) -> c_int;
 	pub fn bn_inner_product(
 		ctx: *mut bn_ctx,

@@ -101,6 +101,14 @@ int bn_extrapolate_line(bn_ctx *ctx, void *d_evals_0, uint64_t n0, const void *d
  * v3/bivariate_product.rs:217-228) as a single launch.  count <= 8 per call. */
 int bn_extrapolate_line_batch(bn_ctx *ctx, void *const *d_evals_0, const void *const *d_evals_1, uint32_t count, uint64_t n,
                               const bn_f128 *z);
+/* Extension (not a trait method): the same batch fold, after which the UPPER half of every folded array i with bit i of
+ * scale_mask set is multiplied by *hi_scale (n even).  Deferred and fused with the next round evaluation exactly like
+ * bn_extrapolate_line_batch.  It lets a prover keep a multilinear pre-multiplied by the equality indicator across
+ * rounds (the weighted MLE-check prover of binius_amd/host/sumcheck.hpp): when the variable that
+ * splits the folded array becomes the round variable, its two halves carry the factors (1 - zeta) and zeta of that
+ * variable's indicator coordinate; multiplying the upper half by (1 - zeta) / zeta levels them. */
+int bn_extrapolate_line_batch_scaled(bn_ctx *ctx, void *const *d_evals_0, const void *const *d_evals_1, uint32_t count, uint64_t n,
+                                     const bn_f128 *z, uint32_t scale_mask, const bn_f128 *hi_scale);
 /* tensor_expand (layer.rs:291): data[..2^(log_n+k)] = data[..2^log_n] (x) (1-r_0,r_0) (x) ...
  * The upper half of every pass is OVERWRITTEN (y = prod), as in FastCpuLayer and
  * math/src/tensor_prod_eq_ind.rs:35-77.  The scalar CpuLayer ACCUMULATES into it instead (*y += prod,

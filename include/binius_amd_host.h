@@ -52,11 +52,18 @@ int bnh_bivariate_sumcheck_prove(bn_ctx *ctx, uint32_t n_vars, uint32_t m, const
 
 /* d_eq_ind: 2^(n_vars-1) elements = tensor expansion of eq_ind_challenges[0 .. n_vars-1);
  * round_coeffs_out[4 * n_vars] (degree-3 round polynomials); final_evals_out[m + 1] (the last one is
- * eq_ind_prefix_eval); d_scratch: (m + 1) * 2^(n_vars-1) elements */
+ * eq_ind_prefix_eval); d_scratch: (m + 1) * 2^(n_vars-1) elements (the weighted prover needs 2^n_vars per weighted
+ * multilinear and 2^(n_vars-1) per other one, and is not used when the scratch is smaller than that) */
 int bnh_bivariate_mlecheck_prove(bn_ctx *ctx, uint32_t n_vars, uint32_t m, const void *const *d_multilins, const void *d_eq_ind,
                                  const bn_f128 *eq_ind_challenges, void *d_scratch, uint64_t scratch_elems, uint32_t n_comps,
                                  const uint32_t *comp_indices, const bn_f128 *sums, const bn_f128 *batch_coeff,
                                  const bn_f128 *challenges, bn_f128 *round_coeffs_out, bn_f128 *final_evals_out);
+
+/* which prover the calling thread's last bnh_bivariate_mlecheck_prove ran: 1 = WeightedMLEcheckProver (the indicator
+ * carried inside one factor of every composition; plain bivariate rounds on the matrix cores), 0 = the literal mirror
+ * BivariateMLEcheckProver (no proper 2-colouring of the compositions, an indicator coordinate equal to 0 or 1, too
+ * little scratch, n_vars < 2, a table that is not the expansion of the coordinates, or BN_MLECHECK=eager), -1 = none yet */
+int bnh_mlecheck_last_mode(void);
 
 /* FRI commit phase (commit_interleaved, crates/core/src/protocols/fri/prove.rs:88-198), every fold round
  * (FRIFolder::execute_fold_round, :307-432) and finalize (:444-482) through the C++ mirror

@@ -478,3 +478,121 @@ def test_independent_provers_share_the_gpu(oracle):
     for hal, _ in ctxs:
         hal.close()
     assert not errors, errors
+
+
+# ---- the weighted MLE-check prover (binius_amd/host/sumcheck.hpp WeightedMLEcheckProver) and its one new device op
+@pytest.mark.parametrize("log_n", [1, 2, 5, 6, 11, 16, 19])
+@pytest.mark.parametrize("mask", [1, 2, 3, 5])
+def test_extrapolate_line_batch_scaled(hal, oracle, log_n, mask):
+    """bn_extrapolate_line_batch_scaled: the batch fold, then the upper half of every marked array times hi_scale.
+    Expected from the oracle's extrapolate_line and an element-wise product."""
+    alloc = hal.dev_alloc()
+    n, count = 1 << log_n, 3
+    x0 = [oracle.random_b128(0x5CA0 + 8 * log_n + i, n) for i in range(count)]
+    x1 = [oracle.random_b128(0x5CB0 + 8 * log_n + i, n) for i in range(count)]
+    z, hs = oracle.random_scalars(0x5CC0 + mask, 2)
+    d0, d1 = [upload(hal, alloc, a) for a in x0], [upload(hal, alloc, b) for b in x1]
+    hal.extrapolate_line_batch_scaled(d0, d1, z, mask, hs)
+    for i in range(count):
+        want = x0[i].copy()
+        assert oracle.extrapolate_line(want, x1[i], z) == 0
+        if (mask >> i) & 1:
+            want[n // 2 :] = oracle.mul_vec(np.ascontiguousarray(want[n // 2 :]), oracle.ints_to_arr([hs] * (n // 2)))
+        assert np.array_equal(hal.copy_d2h(d0[i]), want), "array %d" % i
+        assert np.array_equal(hal.copy_d2h(d1[i]), x1[i])
+
+
+def test_extrapolate_line_batch_scaled_validation(hal, oracle):
+    from binius_amd import BnError
+
+    alloc = hal.dev_alloc()
+    a, b = alloc.alloc(3), alloc.alloc(3)
+    with pytest.raises(BnError):  # odd length
+        hal.extrapolate_line_batch_scaled([a], [b], 3, 1, 5)
+    a, b = alloc.alloc(4), alloc.alloc(4)
+    with pytest.raises(BnError):  # mask outside the batch
+        hal.extrapolate_line_batch_scaled([a], [b], 3, 2, 5)
+
+
+def _mlecheck_instance(hal, oracle, alloc, n_vars, m, comps, seed, eq_ch=None):
+    from binius_amd.sumcheck import eq_ind_partial_eval
+
+    mls = [oracle.random_b128(seed + j, 1 << n_vars) for j in range(m)]
+    if eq_ch is None:
+        eq_ch = oracle.random_scalars(seed ^ 0xE9, n_vars)
+    full = oracle.arr(1 << n_vars)
+    full[0] = (1, 0)
+    oracle.tensor_expand(full, 0, eq_ch)
+    sums = []
+    for i, j in comps:
+        p = oracle.mul_vec(oracle.mul_vec(mls[i], mls[j]), full)
+        sums.append(int(np.bitwise_xor.reduce(p[:, 0])) | (int(np.bitwise_xor.reduce(p[:, 1])) << 64))
+    d = [upload(hal, alloc, x) for x in mls]
+    eq_dev = eq_ind_partial_eval(hal, alloc, eq_ch[: n_vars - 1])
+    return mls, d, eq_ch, eq_dev, sums
+
+
+@pytest.mark.parametrize(
+    "n_vars,m,comps",
+    [(2, 2, [(0, 1)]), (3, 2, [(1, 0)]), (10, 2, [(0, 1)]), (11, 4, [(0, 1), (2, 1), (2, 3)]), (13, 3, [(0, 1), (2, 0)]), (12, 5, [(0, 1), (3, 4)]),
+     (15, 2, [(0, 1)]), (18, 2, [(1, 0)]), (19, 3, [(0, 1), (1, 2)])],
+)
+def test_weighted_mlecheck_prover_matches_oracle(hal, oracle, n_vars, m, comps):
+    """The transcript of the weighted prover is the reference prover's, bit for bit: single compositions (the fused
+    fold + evaluation kernels with the scaled fold: 9-lane small / 9-lane / matrix-core by size), several compositions
+    sharing multilinears (batch fold + scale pass + generic evaluation), multilinears outside every composition."""
+    from binius_amd._host import MlecheckPlan
+
+    alloc = hal.dev_alloc()
+    mls, d, eq_ch, eq_dev, sums = _mlecheck_instance(hal, oracle, alloc, n_vars, m, comps, 0x3D3D00 + n_vars)
+    eq_host = hal.copy_d2h(eq_dev)
+    scratch = alloc.alloc(m * (1 << n_vars))
+    stream = oracle.random_scalars(0xC4A3, n_vars + 1)
+    bc, ch = stream[0], stream[1:]
+    plan = MlecheckPlan(hal, n_vars, d, eq_dev, eq_ch, scratch, comps, sums, bc, ch)
+    plan.run()
+    assert plan.last_mode() == 1, "the weighted prover did not run"
+    want_coeffs, want_finals = oracle.bivariate_mlecheck_prove([x.copy() for x in mls], n_vars, eq_host.copy(), eq_ch, comps, sums, bc, ch)
+    assert plan.round_coeffs() == want_coeffs
+    assert plan.final_evals() == want_finals
+    for j in range(m):
+        assert np.array_equal(hal.copy_d2h(d[j]), mls[j])  # inputs are never modified
+    assert np.array_equal(hal.copy_d2h(eq_dev), eq_host)
+    plan.run()
+    assert plan.round_coeffs() == want_coeffs and plan.final_evals() == want_finals
+
+
+@pytest.mark.parametrize("case", ["zeta_zero", "zeta_one", "odd_cycle", "square", "small_scratch", "foreign_table", "eager_env"])
+def test_weighted_mlecheck_prover_falls_back(hal, oracle, case, monkeypatch):
+    """Where the weighted prover does not apply the literal mirror runs, with the same transcript."""
+    from binius_amd._host import MlecheckPlan
+
+    n_vars, m, comps = 9, 3, [(0, 1), (1, 2)]
+    eq_ch = oracle.random_scalars(0x3E3E, n_vars)
+    if case == "zeta_zero":
+        eq_ch[3] = 0
+    elif case == "zeta_one":
+        eq_ch[0] = 1
+    elif case == "odd_cycle":
+        comps = [(0, 1), (1, 2), (2, 0)]
+    elif case == "square":
+        comps = [(0, 1), (2, 2)]
+    elif case == "eager_env":
+        monkeypatch.setenv("BN_MLECHECK", "eager")
+    alloc = hal.dev_alloc()
+    mls, d, eq_ch, eq_dev, sums = _mlecheck_instance(hal, oracle, alloc, n_vars, m, comps, 0x3E3E00, eq_ch)
+    if case == "foreign_table":  # an entry the spot check reads is not the expansion's: the table is used as given
+        t = hal.copy_d2h(eq_dev)
+        t[4] ^= 1
+        hal.copy_h2d(t, eq_dev)
+    eq_host = hal.copy_d2h(eq_dev)
+    scratch = alloc.alloc((m + 1) * (1 << n_vars) // 2 if case == "small_scratch" else m * (1 << n_vars))
+    stream = oracle.random_scalars(0xC4A4, n_vars + 1)
+    bc, ch = stream[0], stream[1:]
+    plan = MlecheckPlan(hal, n_vars, d, eq_dev, eq_ch, scratch, comps, sums, bc, ch)
+    plan.run()
+    # (0,1),(1,2) colours 1 weighted, 0 and 2 not: 2^n + 2 * 2^(n-1) = 4 * 2^(n-1) = the small scratch exactly -> still weighted
+    assert plan.last_mode() == (1 if case == "small_scratch" else 0)
+    want_coeffs, want_finals = oracle.bivariate_mlecheck_prove([x.copy() for x in mls], n_vars, eq_host.copy(), eq_ch, comps, sums, bc, ch)
+    assert plan.round_coeffs() == want_coeffs
+    assert plan.final_evals() == want_finals

@@ -32,4 +32,8 @@ for _ in range(a.steps):
     plan.run()
 hal.sync()
 ms = (time.perf_counter() - t0) * 1e3 / a.steps
-print(json.dumps({"op": "bivariate MLE-check prove, n_vars=%d, m=2" % n_vars, "ms": round(ms, 4), "elems_per_s": round(m * n / ms * 1e3)}))
+hal.prof_begin()
+plan.run()
+prof = {k: {"ms": round(v[0], 4), "launches": v[1]} for k, v in hal.prof_end().items() if v[1]}
+print(json.dumps({"op": "bivariate MLE-check prove, n_vars=%d, m=2" % n_vars, "prover": "weighted" if plan.last_mode() == 1 else "literal",
+                  "ms": round(ms, 4), "elems_per_s": round(m * n / ms * 1e3), "kernels": prof}))
