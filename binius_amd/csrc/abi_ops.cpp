@@ -156,6 +156,9 @@ int bn_pairwise_product_reduce(bn_ctx *ctx, const void *d_in, uint64_t n, void *
 	BN_REQUIRE(n_rounds == log_n, "round_outputs.len() does not match the expected length");
 	for (uint32_t r = 0; r < n_rounds; r++)
 		BN_REQUIRE(round_lens[r] == ((uint64_t)1 << (log_n - r - 1)), "round_outputs[i].len() has the wrong size");
+	// One launch per level.  (Walking the last <= 12 levels inside one workgroup was measured in round 2: 233 vs 225 us at
+	// 2^20 -- a level is one dependent chain of ~2400 instructions per wave-batch, ~10 us with or without a launch in
+	// front of it)
 	const void *src = d_in;
 	for (uint32_t r = 0; r < n_rounds; r++) {
 		BN_HIP(bn::launch_mul9(ctx->stream, ctx->n_cu, src, 2, src, 2, 1, d_round_outs[r], round_lens[r]));

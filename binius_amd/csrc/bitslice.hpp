@@ -128,6 +128,53 @@ __device__ __forceinline__ void bs_mul(const uint32_t *a, const uint32_t *b, uin
 	}
 }
 
+// out = a * b at level K with the three half-size products of every level >= SEQ issued strictly one after the other
+// (scheduling barriers in between) and the operands of the middle product formed only when it is their turn.  The
+// plain recursion above leaves ~1000 independent AND/XOR to the scheduler, which interleaves the sub-products and keeps
+// ~200 temporaries alive; sequenced, a level-5 product needs its operands, its result and ~60 temporaries.
+// out must not alias a or b.
+template <int K, int SEQ = 4>
+__device__ __forceinline__ void bs_mul_seq(const uint32_t *a, const uint32_t *b, uint32_t *out)
+{
+	if constexpr (K < SEQ) {
+		bs_mul<K>(a, b, out);
+	} else {
+		constexpr int H = 1 << (K - 1);
+		uint32_t z[H];
+		bs_mul_seq<K - 1, SEQ>(a, b, z); // z0
+#pragma unroll
+		for (int i = 0; i < H; i++) {
+			out[i] = z[i];
+			out[H + i] = z[i];
+		}
+		__builtin_amdgcn_sched_barrier(0);
+		{
+			uint32_t z2[H], za[H];
+			bs_mul_seq<K - 1, SEQ>(a + H, b + H, z2);
+			bs_mul_alpha<K - 1>(z2, za);
+#pragma unroll
+			for (int i = 0; i < H; i++) {
+				out[i] ^= z2[i];
+				out[H + i] = xor3(out[H + i], z2[i], za[i]);
+			}
+		}
+		__builtin_amdgcn_sched_barrier(0);
+		{
+			uint32_t sa[H], sb[H];
+#pragma unroll
+			for (int i = 0; i < H; i++) {
+				sa[i] = a[i] ^ a[H + i];
+				sb[i] = b[i] ^ b[H + i];
+			}
+			bs_mul_seq<K - 1, SEQ>(sa, sb, z); // z1
+#pragma unroll
+			for (int i = 0; i < H; i++)
+				out[H + i] ^= z[i];
+		}
+		__builtin_amdgcn_sched_barrier(0);
+	}
+}
+
 // acc ^= a * b at level K, where acc has 2^K planes.
 template <int K>
 __device__ __forceinline__ void bs_mac(const uint32_t *a, const uint32_t *b, uint32_t *acc)

@@ -31,23 +31,23 @@ constexpr int kZero = kBlocks;   // zero block
 constexpr int kWaveQ4 = (kBlocks + 1) * kQ;
 } // namespace
 
-// Occupancy: with the rebuild phase the kernel needs > 256 registers at its peak; at 2 waves per SIMD
-// the compiler spills ~1 KiB per lane to scratch and a batch takes 55 us (measured), at 1 wave per
-// SIMD the spills go to AGPRs (v_accvgpr moves) and nothing touches memory.
+// Occupancy: 194 registers, two waves per SIMD.  (Until round 2 this kernel ran at one wave per SIMD with 210 values
+// parked in AGPRs: the rebuild phase laundered its LDS offsets against ONE word of every four-plane result, which left
+// the scheduler free to sink the other three XOR chains of every ds_read_b128 to the end of the phase -- ~200 read
+// results waiting in registers.  The offsets are now laundered against all four words.)
 // STRIDE (in elements, the same for a and b) is a template parameter so that row addresses are one
 // base pointer plus immediates; a run-time stride makes the compiler keep 32 64-bit offsets alive
 // (spilled to scratch: measured 1.3 KiB per lane).
+// The wave-batches wave_global, wave_global + n_waves, ... of one element-wise product; wt = this wave's LDS tile.
 template <int STRIDE>
-__global__ __launch_bounds__(256, 1) void k_mul9(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b,
-                                                uint32_t *__restrict__ out, uint64_t n)
+__device__ __forceinline__ void mul9_batches(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b, uint32_t *__restrict__ out,
+                                             uint64_t n, uint64_t wave_global, uint64_t n_waves, uint4 *wt)
 {
-	__shared__ uint4 tile[4][kWaveQ4];
-	const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const unsigned lane = threadIdx.x & 63;
 	const unsigned g = lane / 9, c = lane - g * 9;
 	const bool live = lane < 63;
 	const bool loader = live && c < 8;
 	const bool builder = live && c < 4;
-	uint4 *wt = tile[wave];
 	if (lane < kQ)
 		wt[kZero * kQ + lane] = uint4{0, 0, 0, 0};
 
@@ -91,8 +91,6 @@ __global__ __launch_bounds__(256, 1) void k_mul9(const uint32_t *__restrict__ a,
 	// an opaque copy of g: hoisted out of the loop they are 15 more live registers across the
 	// multiplication and push the kernel into scratch (measured: 55 us per batch instead of ~5).
 	const uint64_t n_batches = (n + kWB - 1) / kWB;
-	const uint64_t wave_global = (uint64_t)blockIdx.x * 4 + wave;
-	const uint64_t n_waves = (uint64_t)gridDim.x * 4;
 
 	for (uint64_t bt = wave_global; bt < n_batches; bt += n_waves) {
 		const uint64_t base = bt * kWB + gg; // element of row j: base + 7*j
@@ -179,7 +177,7 @@ __global__ __launch_bounds__(256, 1) void k_mul9(const uint32_t *__restrict__ a,
 					y.x ^= t.x; y.y ^= t.y; y.z ^= t.z; y.w ^= t.w;
 				}
 				t1[4 * q] ^= y.x; t1[4 * q + 1] ^= y.y; t1[4 * q + 2] ^= y.z; t1[4 * q + 3] ^= y.w; // Y + alpha(W)
-				if (q & 1) asm volatile("" : "+v"(gl) : "v"(t1[4 * q]));
+				asm volatile("" : "+v"(gl) : "v"(t1[4 * q]), "v"(t1[4 * q + 1]), "v"(t1[4 * q + 2]), "v"(t1[4 * q + 3]));
 			}
 			bs_mul_alpha<5>(t1, t0); // t0 = alpha(Y) + alpha^2(W)
 			asm volatile("" : "+v"(gl) : "v"(t0[31]));
@@ -193,7 +191,7 @@ __global__ __launch_bounds__(256, 1) void k_mul9(const uint32_t *__restrict__ a,
 					x.x ^= t.x; x.y ^= t.y; x.z ^= t.z; x.w ^= t.w;
 				}
 				r[4 * q] = t0[4 * q] ^ x.x; r[4 * q + 1] = t0[4 * q + 1] ^ x.y; r[4 * q + 2] = t0[4 * q + 2] ^ x.z; r[4 * q + 3] = t0[4 * q + 3] ^ x.w;
-				asm volatile("" : "+v"(gl) : "v"(r[4 * q]));
+				asm volatile("" : "+v"(gl) : "v"(r[4 * q]), "v"(r[4 * q + 1]), "v"(r[4 * q + 2]), "v"(r[4 * q + 3]));
 			}
 		}
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -215,13 +213,22 @@ __global__ __launch_bounds__(256, 1) void k_mul9(const uint32_t *__restrict__ a,
 	}
 }
 
+template <int STRIDE>
+__global__ __launch_bounds__(256, 2) void k_mul9(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b,
+                                                uint32_t *__restrict__ out, uint64_t n)
+{
+	__shared__ uint4 tile[4][kWaveQ4];
+	const unsigned wave = threadIdx.x >> 6;
+	mul9_batches<STRIDE>(a, b, out, n, (uint64_t)blockIdx.x * 4 + wave, (uint64_t)gridDim.x * 4, tile[wave]);
+}
+
 hipError_t launch_mul9(hipStream_t s, int n_cu, const void *a, uint64_t a_stride, const void *b, uint64_t b_stride, uint64_t b_off,
                        void *out, uint64_t n)
 {
 	if (n == 0) return hipSuccess;
 	const uint64_t n_batches = (n + kWB - 1) / kWB;
 	uint64_t blocks = (n_batches + 3) / 4;
-	const uint64_t cap = (uint64_t)n_cu; // one workgroup per CU: the kernel is built for 1 wave per SIMD (AGPR spill space instead of scratch)
+	const uint64_t cap = (uint64_t)n_cu * 2; // two workgroups per CU = two waves per SIMD
 	if (blocks > cap) blocks = cap;
 	const uint32_t *pb = (const uint32_t *)b + b_off * 4;
 	if (a_stride == 1 && b_stride == 1)

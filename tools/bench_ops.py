@@ -58,6 +58,7 @@ fo = alloc.alloc(n >> (lb + 3))
 timed("fri_fold log_len=%d log_batch=4, 3 fold rounds" % (a.log_n - lb), lambda: hal.fri_fold(s5, 5, 28, a.log_n - lb, lb, ch, A, fo), 16 * n + 16 * (n >> 7))
 small = 1 << 20
 timed("compute_composite a*b, 2^20", lambda: hal.compute_composite([A.slice(0, small), B.slice(0, small)], Cc.slice(0, small), expr), 48 * small)
+timed("compute_composite a*b, 2^%d" % (a.log_n - 1), lambda: hal.compute_composite([A.slice(0, half), B.slice(0, half)], Cc.slice(0, half), expr), 48 * half)
 outs = [alloc.alloc(small >> (r + 1)) for r in range(20)] if alloc.capacity() > small else None
 if outs:
     timed("pairwise_product_reduce 2^20", lambda: hal.pairwise_product_reduce(A.slice(0, small), outs), 16 * small * 2)

@@ -10,7 +10,7 @@
 
 using namespace bn;
 
-template <bool TRANSPOSE, int WAVES>
+template <bool TRANSPOSE, int WAVES, int SEQ = 0>
 __global__ __launch_bounds__(256, WAVES) void k(uint32_t *out, int iters)
 {
 	uint32_t A[32], B[32], acc[32];
@@ -23,7 +23,10 @@ __global__ __launch_bounds__(256, WAVES) void k(uint32_t *out, int iters)
 	for (int it = 0; it < iters; it++) {
 		uint32_t P[32];
 		if (TRANSPOSE) transpose32(A);
-		bs_mul<5>(A, B, P);
+		if constexpr (SEQ)
+			bs_mul_seq<5, SEQ>(A, B, P);
+		else
+			bs_mul<5>(A, B, P);
 #pragma unroll
 		for (int i = 0; i < 32; i++) {
 			acc[i] ^= P[i];
@@ -37,7 +40,7 @@ __global__ __launch_bounds__(256, WAVES) void k(uint32_t *out, int iters)
 	out[blockIdx.x * 256 + threadIdx.x] = v;
 }
 
-template <bool T, int W>
+template <bool T, int W, int SEQ = 0>
 static void run(const char *name, int blocks_per_cu)
 {
 	uint32_t *d;
@@ -46,9 +49,9 @@ static void run(const char *name, int blocks_per_cu)
 	hipEvent_t a, b;
 	hipEventCreate(&a);
 	hipEventCreate(&b);
-	hipLaunchKernelGGL((k<T, W>), dim3(256 * blocks_per_cu), dim3(256), 0, 0, d, 10);
+	hipLaunchKernelGGL((k<T, W, SEQ>), dim3(256 * blocks_per_cu), dim3(256), 0, 0, d, 10);
 	hipEventRecord(a);
-	hipLaunchKernelGGL((k<T, W>), dim3(256 * blocks_per_cu), dim3(256), 0, 0, d, iters);
+	hipLaunchKernelGGL((k<T, W, SEQ>), dim3(256 * blocks_per_cu), dim3(256), 0, 0, d, iters);
 	hipEventRecord(b);
 	hipEventSynchronize(b);
 	float ms;
@@ -65,5 +68,14 @@ int main()
 	run<false, 2>("bs_mul<5>+acc", 2);
 	run<true, 2>("transpose32+bs_mul<5>+acc", 1);
 	run<true, 2>("transpose32+bs_mul<5>+acc", 2);
+	run<false, 1>("bs_mul<5>+acc (1-wave build)", 1);
+	run<false, 2, 5>("bs_mul_seq<5,5>+acc", 1);
+	run<false, 2, 5>("bs_mul_seq<5,5>+acc", 2);
+	run<false, 2, 4>("bs_mul_seq<5,4>+acc", 1);
+	run<false, 2, 4>("bs_mul_seq<5,4>+acc", 2);
+	run<false, 2, 3>("bs_mul_seq<5,3>+acc", 1);
+	run<false, 2, 3>("bs_mul_seq<5,3>+acc", 2);
+	run<false, 3, 4>("bs_mul_seq<5,4>+acc (3-wave build)", 3);
+	run<false, 3, 3>("bs_mul_seq<5,3>+acc (3-wave build)", 3);
 	return 0;
 }
