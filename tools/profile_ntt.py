@@ -1,5 +1,12 @@
 #!/usr/bin/env python3
-"""Time the forward additive NTT (config 3: 2^24 BinaryField32b, shape {0,24,0}) and others."""
+"""Time the forward additive NTT (config 3: 2^24 BinaryField32b, shape {0,24,0}) and others.
+
+The transform is VALU-bound, so besides the HBM figure the last line is a JSON roofline block with
+"bound": "valu": algorithmic lane-operations = (L - 5) bit-sliced layers x 2^(L-6) plane-set butterflies x 1290
+lane-operations each (instruction count of the compiled butterfly loop of k_ntt_bs_pass: 754 v_xor + 360 v_bitop3 + 40
+v_and + 31 v_bfe + ~100 of twiddle construction and LDS addressing; one lane-operation processes 32 elements) plus the
+word-level head (5 layers x 2^(L-1) butterflies x ~30 lane-operations), against the measured integer VALU peak of
+60 T lane-operations/s (profiles/r01/valu_issue_rate.txt)."""
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -34,4 +41,12 @@ for _ in range(a.reps):
     ms = p["ntt"][0]
     print("forward NTT 2^%d x %d-bit: %.3f ms  (%.1f GB/s of the 2*w*2^L algorithmic bytes, %.2f%% of 8 TB/s)" % (
         a.log_n, 1 << a.elem_level, ms, 2 * nbytes / ms / 1e6, 2 * nbytes / ms / 1e6 / 80))
+import json
+L = a.log_n
+cols = 1 << (a.elem_level - 5)  # a larger field is 2 or 4 interleaved B32 columns
+lane_ops = cols * ((L - 5) * (1 << (L - 6)) * 1290 + 5 * (1 << (L - 1)) * 30)
+print(json.dumps({"op": "forward NTT 2^%d x B%d" % (L, 1 << a.elem_level), "ms": round(ms, 4),
+                  "roofline": {"bound": "valu", "achieved": round(lane_ops / ms / 1e9, 2), "peak": 60.0, "unit": "T lane-op/s",
+                               "frac": round(lane_ops / ms / 1e9 / 60.0, 4), "lane_ops": lane_ops},
+                  "hbm": {"algorithmic_bytes": 2 * nbytes, "GBps": round(2 * nbytes / ms / 1e6, 1)}}))
 hal.close()
