@@ -128,6 +128,24 @@ class MlecheckPlan:
         return [from_f128(self.final[j]) for j in range(self.m + 1)]
 
 
+class FRIParams:
+    """Parameters of a FRI instance as bnh_fri_commit_fold takes them (the arithmetic of FRIParams,
+    crates/core/src/protocols/fri/common.rs:84-190; validation happens in the C++ mirror, binius_amd/host/fri.hpp)."""
+
+    def __init__(self, log_dim, log_inv_rate, log_batch_size, fold_arities, n_test_queries):
+        self.log_dim, self.log_inv_rate, self.log_batch_size = log_dim, log_inv_rate, log_batch_size
+        self.fold_arities, self.n_test_queries = list(fold_arities), n_test_queries
+
+    def rs_log_len(self):
+        return self.log_dim + self.log_inv_rate
+
+    def n_fold_rounds(self):
+        return self.log_dim + self.log_batch_size
+
+    def n_final_challenges(self):
+        return self.n_fold_rounds() - sum(self.fold_arities)
+
+
 class FriPlan:
     """FRI commit phase + every fold round + finalize through the compiled C++ mirror (bnh_fri_commit_fold,
     binius_amd/host/fri.hpp).  `scratch` takes the codeword, the folded codewords and the Merkle trees."""

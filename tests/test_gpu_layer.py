@@ -549,47 +549,3 @@ def test_fresh_thread_allocating_entry_points(oracle):
     assert out == {"ntt": True, "ip": True}, out
 
 
-@pytest.mark.parametrize("log_n", [1, 4, 9, 13])
-def test_product_circuit_layers(hal, oracle, log_n):
-    """ProductCircuitLayers::compute (core/src/protocols/prodcheck/prove.rs:24-77): every layer is the
-    element-wise product of the halves of the layer below; the top is the product of all values."""
-    from binius_amd.prodcheck import ProductCircuitLayers
-
-    alloc = hal.dev_alloc()
-    evals = rnd(oracle, 0x9C0D + log_n, 1 << log_n)
-    d = upload(hal, alloc, evals)
-    pcl = ProductCircuitLayers.compute(d, hal, alloc)
-    layers = pcl.layers()
-    assert len(layers) == log_n and [l.len for l in layers] == [1 << (i + 1) for i in range(log_n)]
-    cur = evals
-    want = []
-    for _ in range(log_n):
-        want.append(cur)
-        half = cur.shape[0] // 2
-        cur = oracle.mul_vec(cur[:half].copy(), cur[half:].copy())
-    want.reverse()
-    for got, w in zip(layers, want):
-        assert np.array_equal(hal.copy_d2h(got), w)
-    assert pcl.product == to_int(cur)
-
-
-# ---- ring-switching equality indicator (crates/core/src/ring_switch/eq_ind.rs:123-141;
-# compute_test_utils/src/ring_switch.rs): tensor_expand + fold_right over the subfield limbs
-@pytest.mark.parametrize("n_vars,kappa", [(4, 7), (8, 4), (10, 2), (13, 2), (11, 0)])
-def test_ring_switch_eq_ind_multilinear_extension(hal, oracle, n_vars, kappa):
-    from binius_amd.ring_switch import RingSwitchEqInd
-
-    z_vals = oracle.random_scalars(0x515 + n_vars, n_vars)
-    coeffs = oracle.random_scalars(0x516 + kappa, 1 << kappa)
-    mixing = oracle.random_scalars(0x517, 1)[0]
-    alloc = hal.dev_alloc()
-    rs = RingSwitchEqInd(z_vals, coeffs, mixing, kappa)
-    mle = rs.multilinear_extension(hal, rs.precompute_values(hal, alloc))
-    got = hal.copy_d2h(mle)
-    # oracle composition
-    evals = oracle.arr(1 << n_vars)
-    evals[0, 0], evals[0, 1] = mixing & ((1 << 64) - 1), mixing >> 64
-    assert oracle.tensor_expand(evals, 0, z_vals) == 0
-    want = oracle.arr(1 << n_vars)
-    assert oracle.fold_right(evals, 7 - kappa, oracle.ints_to_arr(coeffs), want) == 0
-    assert np.array_equal(got, want)

@@ -55,7 +55,9 @@ def test_calculate_round_evals(hal, oracle, n_vars, m, n_comps):
 
 @pytest.mark.parametrize("n_vars,m,n_comps", [(1, 2, 1), (3, 2, 1), (8, 8, 8), (12, 2, 1), (16, 2, 1), (14, 3, 2)])
 def test_bivariate_sumcheck_prove(hal, oracle, n_vars, m, n_comps):
-    from binius_amd.sumcheck import BivariateSumcheckProver
+    """generic_test_bivariate_sumcheck_prove_verify (compute_test_utils bivariate_sumcheck.rs): the prover mirror
+    (binius_amd/host/sumcheck.hpp) over the HIP backend, transcript against the oracle and the verifier's checks."""
+    from binius_amd._host import SumcheckPlan
 
     alloc = hal.dev_alloc()
     mls = [oracle.random_b128(0xB1A50000 + j, 1 << n_vars) for j in range(m)]
@@ -70,17 +72,15 @@ def test_bivariate_sumcheck_prove(hal, oracle, n_vars, m, n_comps):
     stream = oracle.random_scalars(0xC4A1, n_vars + 1)
     batch_coeff, challenges = stream[0], stream[1:]
 
-    prover = BivariateSumcheckProver(hal, alloc, n_vars, d, comps, sums)
+    plan = SumcheckPlan(hal, n_vars, d, alloc.alloc(max(1, m << max(0, n_vars - 1))), comps, sums, batch_coeff, challenges)
+    plan.run()
+    got_coeffs, final = plan.round_coeffs(), plan.final_evals()
     running = oracle.evaluate_univariate(sums, batch_coeff)
-    got_coeffs = []
     for r in range(n_vars):
-        rc = prover.execute(batch_coeff)
+        rc = got_coeffs[r]
         # verifier check: P(0) + P(1) == running sum
         assert rc[0] ^ (rc[0] ^ rc[1] ^ rc[2]) == running
         running = oracle.evaluate_univariate(rc, challenges[r])
-        got_coeffs.append(rc)
-        prover.fold(challenges[r])
-    final = prover.finish()
 
     ref_mls = [x.copy() for x in mls]
     want_coeffs, want_final = oracle.bivariate_sumcheck_prove(ref_mls, n_vars, comps, sums, batch_coeff, challenges)
@@ -131,11 +131,11 @@ def test_mlecheck_round_evals(hal, oracle):
 
 
 def test_sumcheck_full_size_properties(oracle):
-    """BASELINE config 2 size (n = 24, m = 2): size-independent properties -- the sumcheck
-    verifier's round checks and the final product check -- plus oracle spot checks of the first
-    round (multi-threaded CPU port) and of the folded prefix."""
+    """BASELINE config 2 size (n = 24, m = 2): size-independent properties -- the sumcheck verifier's round checks
+    and the final product check on the compiled prover's transcript -- plus oracle spot checks of the first round
+    (multi-threaded CPU port) and of the first fold."""
     import binius_amd
-    from binius_amd.sumcheck import BivariateSumcheckProver
+    from binius_amd._host import SumcheckPlan
 
     n_vars, m = 24, 2
     n = 1 << n_vars
@@ -149,24 +149,27 @@ def test_sumcheck_full_size_properties(oracle):
         assert rc == 0
         stream = oracle.random_scalars(0xC4A1, n_vars + 1)
         batch_coeff, challenges = stream[0], stream[1:]
-        prover = BivariateSumcheckProver(hal, alloc, n_vars, d, [(0, 1)], [s])
+        scratch = alloc.alloc(m * (n // 2))
+        plan = SumcheckPlan(hal, n_vars, d, scratch, [(0, 1)], [s], batch_coeff, challenges)
+        plan.run()
+        coeffs, final = plan.round_coeffs(), plan.final_evals()
         running = s
         for r in range(n_vars):
-            rcf = prover.execute(batch_coeff)
+            rcf = coeffs[r]
             if r == 0:
                 assert rcf[2] == ev[1] and (running ^ rcf[0]) == ev[0]  # y_inf, y_1 vs the oracle
             assert rcf[0] ^ (rcf[0] ^ rcf[1] ^ rcf[2]) == running
             running = oracle.evaluate_univariate(rcf, challenges[r])
-            prover.fold(challenges[r])
-            if r == 0:
-                # fold spot check: first 4096 folded elements of each multilinear
-                for j in range(m):
-                    got = hal.copy_d2h(prover.multilins[j][1].slice(0, 4096))
-                    e0 = mls[j][:4096].copy()
-                    oracle.extrapolate_line(e0, mls[j][n // 2 : n // 2 + 4096], challenges[0])
-                    assert np.array_equal(got, e0)
-        final = prover.finish()
         assert oracle.mul(final[0], final[1]) == running
+        # fold spot check at this size: the first 4096 folded elements of each multilinear
+        for j in range(m):
+            lo, hi = d[j].split_half()
+            out = scratch.slice(0, n // 2)
+            hal.copy_d2d(lo, out)
+            hal.extrapolate_line(out, hi, challenges[0])
+            e0 = mls[j][:4096].copy()
+            oracle.extrapolate_line(e0, mls[j][n // 2 : n // 2 + 4096], challenges[0])
+            assert np.array_equal(hal.copy_d2h(out.slice(0, 4096)), e0)
     finally:
         hal.close()
 
@@ -366,12 +369,15 @@ def test_tiny_fold_results_are_mirrored_to_the_host(hal, oracle):
 
 
 @pytest.mark.parametrize("n_vars,m,comps", [(1, 2, [(0, 1)]), (2, 2, [(0, 1)]), (8, 8, [(0, 1), (2, 5), (7, 7), (3, 4)]), (13, 3, [(0, 1), (2, 0)])])
-def test_bivariate_mlecheck_prove(hal, oracle, n_vars, m, comps):
-    """generic_test_bivariate_mlecheck_prove_verify (compute_test_utils bivariate_sumcheck.rs:313-458):
-    the MLE-check prover over the HIP backend -- round polynomials (degree 3) and final values
-    bit-exact against the oracle's restatement of v3/bivariate_mlecheck.rs."""
-    from binius_amd.sumcheck import BivariateMLEcheckProver, eq_ind_partial_eval
+def test_bivariate_mlecheck_prove(hal, oracle, n_vars, m, comps, monkeypatch):
+    """generic_test_bivariate_mlecheck_prove_verify (compute_test_utils bivariate_sumcheck.rs:313-458): the literal
+    MLE-check prover mirror (BN_MLECHECK=eager: BivariateMLEcheckProver of binius_amd/host/sumcheck.hpp, the trait-op
+    sequence of the reference) over the HIP backend -- round polynomials (degree 3) and final values bit-exact
+    against the oracle's restatement of v3/bivariate_mlecheck.rs."""
+    from binius_amd._host import MlecheckPlan
+    from binius_amd.sumcheck import eq_ind_partial_eval
 
+    monkeypatch.setenv("BN_MLECHECK", "eager")
     alloc = hal.dev_alloc()
     mls = [oracle.random_b128(0x3C3C00 + j, 1 << n_vars) for j in range(m)]
     eq_ch = oracle.random_scalars(0x3C3C00 ^ 0xE9, n_vars)
@@ -387,15 +393,12 @@ def test_bivariate_mlecheck_prove(hal, oracle, n_vars, m, comps):
     eq_host = hal.copy_d2h(eq_dev)
     stream = oracle.random_scalars(0xC4A2, n_vars + 1)
     bc, ch = stream[0], stream[1:]
-    prover = BivariateMLEcheckProver(hal, alloc, n_vars, d, comps, sums, eq_dev, eq_ch)
-    got = []
-    for r in range(n_vars):
-        got.append(prover.execute(bc))
-        prover.fold(ch[r])
-    finals = prover.finish()
+    plan = MlecheckPlan(hal, n_vars, d, eq_dev, eq_ch, alloc.alloc(max(1, (m + 1) << max(0, n_vars - 1))), comps, sums, bc, ch)
+    plan.run()
+    assert plan.last_mode() == 0
     want_coeffs, want_finals = oracle.bivariate_mlecheck_prove([x.copy() for x in mls], n_vars, eq_host.copy(), eq_ch, comps, sums, bc, ch)
-    assert got == want_coeffs
-    assert finals == want_finals
+    assert plan.round_coeffs() == want_coeffs
+    assert plan.final_evals() == want_finals
     for j in range(m):  # PreFold inputs are never modified
         assert np.array_equal(hal.copy_d2h(d[j]), mls[j])
 

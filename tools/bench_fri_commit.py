@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
-"""End-to-end timing of the device-resident FRI commit phase (binius_amd/fri.py commit_interleaved:
-message repeat + batched additive NTT + Groestl Merkle tree, root read back) and of the fold phase
-(fri_fold + commitment per oracle), at a prover-sized shape.  One JSON line per phase; inputs from
-binius_amd.synthetic."""
-import argparse, json, os, sys, time
+"""End-to-end timing of the device-resident FRI commit phase (commit_interleaved: message repeat + batched additive NTT
++ Groestl Merkle tree, root read back) and of the fold phase (fri_fold + commitment per oracle), at a prover-sized
+shape, through the compiled C++ mirror (binius_amd/host/fri.hpp behind bnh_fri_commit_fold).  One JSON line; inputs
+from binius_amd.synthetic."""
+import argparse, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import binius_amd
-from binius_amd import fri, synthetic
-from binius_amd.merkle import BinaryMerkleTreeProver
+from binius_amd import synthetic
+from binius_amd._host import FRIParams, FriPlan
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--log-dim", type=int, default=20)
@@ -19,39 +19,18 @@ a = ap.parse_args()
 log_msg = a.log_dim + a.log_batch
 n_arities = (log_msg - 1) // a.arity
 while n_arities * a.arity >= log_msg: n_arities -= 1
-p = fri.FRIParams(a.log_dim, a.log_inv_rate, a.log_batch, [a.arity] * n_arities, n_test_queries=100)
+p = FRIParams(a.log_dim, a.log_inv_rate, a.log_batch, [a.arity] * n_arities, n_test_queries=100)
 n_msg = 1 << log_msg
 n_code = n_msg << a.log_inv_rate
 hal = binius_amd.Context(0, n_msg + 3 * n_code + (1 << 16))
-ntt = fri.AdditiveNTT(p.rs_log_len())
 base = hal.dev_alloc()
 d_msg = base.alloc(n_msg)
 hal.copy_h2d(synthetic.random_b128(0xF21, n_msg), d_msg)
 challenges = synthetic.random_scalars(0xC4A, p.n_fold_rounds())
-
-
-def run_once():
-    alloc = base.subscope_allocator()
-    merkle = BinaryMerkleTreeProver(hal, alloc)
-    hal.sync(); t0 = time.perf_counter()
-    out = fri.commit_interleaved(hal, alloc, p, ntt, merkle, d_msg)
-    hal.sync(); t1 = time.perf_counter()
-    folder = fri.FRIFolder(hal, p, ntt, merkle, out.codeword, out.committed)
-    for ch in challenges:
-        folder.execute_fold_round(alloc, ch)
-    terminate, qp = folder.finalize()
-    hal.sync(); t2 = time.perf_counter()
-    return (t1 - t0) * 1e3, (t2 - t1) * 1e3
-
-
-from binius_amd._host import FriPlan
-plan = FriPlan(hal, p, d_msg, base.subscope_allocator().alloc(3 * n_code), challenges)
+plan = FriPlan(hal, p, d_msg, base.alloc(3 * n_code), challenges)
 cs = [plan.run() for _ in range(a.reps + 1)][1:]
-ts = [run_once() for _ in range(a.reps + 1)][1:]
-commit_ms = min(t[0] for t in ts); fold_ms = min(t[1] for t in ts)
+commit_ms, fold_ms = min(c[0] for c in cs), min(c[1] for c in cs)
 shape = "log_dim %d, log_batch %d, log_inv_rate %d, arities %s" % (a.log_dim, a.log_batch, a.log_inv_rate, p.fold_arities)
-print(json.dumps({"op": "FRI commit phase (RS encode + Merkle tree, root read back), " + shape, "ms": round(commit_ms, 3),
-                  "codeword_MiB": n_code * 16 >> 20, "codeword_GBps": round(16 * n_code / commit_ms / 1e6, 1)}))
-print(json.dumps({"op": "the same through the compiled C++ mirror (bnh_fri_commit_fold)", "commit_ms": round(min(c[0] for c in cs), 3),
-                  "fold_ms": round(min(c[1] for c in cs), 3)}))
-print(json.dumps({"op": "FRI fold phase (%d rounds, %d oracles committed), " % (p.n_fold_rounds(), p.n_oracles()) + shape, "ms": round(fold_ms, 3)}))
+print(json.dumps({"op": "FRI commit phase (RS encode + Merkle tree, root read back) and fold phase (%d rounds), " % p.n_fold_rounds() + shape,
+                  "commit_ms": round(commit_ms, 3), "fold_ms": round(fold_ms, 3), "codeword_MiB": n_code * 16 >> 20,
+                  "commit_codeword_GBps": round(16 * n_code / commit_ms / 1e6, 1)}))
