@@ -35,6 +35,17 @@ def host_lib():
             C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p), C.c_void_p, C.POINTER(F128), C.c_void_p, C.c_uint64,
             C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(F128), C.POINTER(F128), C.POINTER(F128), C.POINTER(F128), C.POINTER(F128),
         ]
+        L.bnh_mlecheck_new.restype = C.c_int
+        L.bnh_mlecheck_new.argtypes = [
+            C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p), C.c_void_p, C.POINTER(F128), C.c_void_p, C.c_uint64,
+            C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(F128), C.POINTER(C.c_void_p),
+        ]
+        L.bnh_mlecheck_execute.argtypes = [C.c_void_p, C.POINTER(F128), C.POINTER(F128)]
+        L.bnh_mlecheck_fold.argtypes = [C.c_void_p, C.POINTER(F128)]
+        L.bnh_mlecheck_finish.argtypes = [C.c_void_p, C.POINTER(F128)]
+        L.bnh_mlecheck_free.argtypes = [C.c_void_p]
+        L.bnh_mlecheck_free.restype = None
+        L.bnh_mlecheck_last_mode.restype = C.c_int
         L.bnh_fri_commit_fold.restype = C.c_int
         L.bnh_fri_commit_fold.argtypes = [
             C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
@@ -126,6 +137,47 @@ class MlecheckPlan:
 
     def final_evals(self):
         return [from_f128(self.final[j]) for j in range(self.m + 1)]
+
+
+class MlecheckProver:
+    """The MLE-check prover behind its handle (bnh_mlecheck_*): SumcheckProver::{execute, fold, finish} one call each,
+    challenges supplied round by round."""
+
+    def __init__(self, hal, n_vars, multilins, eq_ind, eq_ind_challenges, scratch, comps, sums):
+        self.m = len(multilins)
+        ptrs = (C.c_void_p * self.m)(*[s.ptr for s in multilins])
+        flat = [i for pair in comps for i in pair]
+        cc = (C.c_uint32 * max(1, len(flat)))(*flat)
+        self._h = C.c_void_p()
+        self._keep = (multilins, eq_ind, scratch)
+        rc = host_lib().bnh_mlecheck_new(hal._h, n_vars, self.m, ptrs, eq_ind.ptr, _f128_array(list(eq_ind_challenges)), scratch.ptr, scratch.len,
+                                         len(comps), cc, _f128_array(list(sums)), C.byref(self._h))
+        self._check(rc)
+        self.mode = host_lib().bnh_mlecheck_last_mode()
+
+    @staticmethod
+    def _check(rc):
+        if rc != 0:
+            raise BnError(rc, host_lib().bnh_last_error().decode())
+
+    def execute(self, batch_coeff):
+        bc, out = to_f128(batch_coeff), (F128 * 4)()
+        self._check(host_lib().bnh_mlecheck_execute(self._h, C.byref(bc), out))
+        return [from_f128(out[i]) for i in range(4)]
+
+    def fold(self, challenge):
+        z = to_f128(challenge)
+        self._check(host_lib().bnh_mlecheck_fold(self._h, C.byref(z)))
+
+    def finish(self):
+        out = (F128 * (self.m + 1))()
+        self._check(host_lib().bnh_mlecheck_finish(self._h, out))
+        return [from_f128(out[j]) for j in range(self.m + 1)]
+
+    def close(self):
+        if self._h:
+            host_lib().bnh_mlecheck_free(self._h)
+            self._h = C.c_void_p()
 
 
 class FRIParams:

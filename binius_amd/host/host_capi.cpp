@@ -394,20 +394,31 @@ int bnh_bivariate_sumcheck_prove(bn_ctx *ctx, uint32_t n_vars, uint32_t m, const
 static thread_local int g_mlecheck_mode = -1;
 int bnh_mlecheck_last_mode(void) { return g_mlecheck_mode; }
 
-// One complete BivariateMLEcheckProver run (v3/bivariate_mlecheck.rs) behind a C call.
+// ---- MLE-check prover behind a handle: SumcheckProver::{execute, fold, finish} (prove/batch_sumcheck.rs:38-70) one
+// call each, so that a host whose challenges come out of a transcript can drive it round by round.
 //   d_eq_ind             2^(n_vars-1) elements: tensor expansion of eq_ind_challenges[0 .. n_vars-1)
-//   round_coeffs_out     [4 * n_vars] (degree-3 round polynomials)
-//   final_evals_out      [m + 1]      (the last one is eq_ind_prefix_eval)
-int bnh_bivariate_mlecheck_prove(bn_ctx *ctx, uint32_t n_vars, uint32_t m, const void *const *d_multilins, const void *d_eq_ind,
-                                 const bn_f128 *eq_ind_challenges, void *d_scratch, uint64_t scratch_elems, uint32_t n_comps,
-                                 const uint32_t *comp_indices, const bn_f128 *sums, const bn_f128 *batch_coeff,
-                                 const bn_f128 *challenges, bn_f128 *round_coeffs_out, bn_f128 *final_evals_out)
+struct bnh_mlecheck {
+	ComputeLayer hal;
+	DeviceBumpAllocator dev_alloc;
+	std::vector<B128> host_mem;
+	HostBumpAllocator host_alloc;
+	std::unique_ptr<WeightedMLEcheckProver> weighted;
+	std::unique_ptr<BivariateMLEcheckProver> literal;
+	uint32_t m;
+	bnh_mlecheck(bn_ctx *ctx, void *d_scratch, uint64_t scratch_elems, uint32_t m_)
+	    : hal(ctx), dev_alloc(FSliceMut{d_scratch, (size_t)scratch_elems}), host_mem(m_ + 4),
+	      host_alloc(HostSliceMut{host_mem.data(), host_mem.size()}), m(m_)
+	{
+	}
+};
+
+int bnh_mlecheck_new(bn_ctx *ctx, uint32_t n_vars, uint32_t m, const void *const *d_multilins, const void *d_eq_ind,
+                     const bn_f128 *eq_ind_challenges, void *d_scratch, uint64_t scratch_elems, uint32_t n_comps,
+                     const uint32_t *comp_indices, const bn_f128 *sums, bnh_mlecheck **out)
 {
 	try {
-		ComputeLayer hal(ctx);
-		DeviceBumpAllocator dev_alloc(FSliceMut{d_scratch, (size_t)scratch_elems});
-		std::vector<B128> host_mem(m + 4);
-		HostBumpAllocator host_alloc(HostSliceMut{host_mem.data(), host_mem.size()});
+		if (!out) throw Error(Error::InputValidation, "null argument");
+		std::unique_ptr<bnh_mlecheck> h(new bnh_mlecheck(ctx, d_scratch, scratch_elems, m));
 		std::vector<FSlice> mls;
 		for (uint32_t j = 0; j < m; j++) mls.push_back(FSlice{d_multilins[j], (size_t)1 << n_vars});
 		std::vector<IndexCompositionBivariate> comps;
@@ -417,16 +428,7 @@ int bnh_bivariate_mlecheck_prove(bn_ctx *ctx, uint32_t n_vars, uint32_t m, const
 			sv.emplace_back(sums[c].lo, sums[c].hi);
 		}
 		for (uint32_t i = 0; i < n_vars; i++) eqc.emplace_back(eq_ind_challenges[i].lo, eq_ind_challenges[i].hi);
-		const B128 bc(batch_coeff->lo, batch_coeff->hi);
 		const FSlice eq_table{d_eq_ind, (size_t)1 << (n_vars ? n_vars - 1 : 0)};
-		auto run = [&](auto &prover) {
-			for (uint32_t r = 0; r < n_vars; r++) {
-				std::vector<B128> rc = prover.execute(bc);
-				for (size_t i = 0; i < 4 && i < rc.size(); i++) round_coeffs_out[4 * r + i] = rc[i].raw();
-				prover.fold(B128(challenges[r].lo, challenges[r].hi));
-			}
-			return prover.finish();
-		};
 		// The weighted prover (sumcheck.hpp) when it applies: a proper 2-colouring of the compositions, invertible
 		// indicator coordinates, enough scratch, and a table that IS the tensor expansion of the coordinates (the
 		// constructor's contract: "an existing tensor expansion for eq_ind_challenges", bivariate_mlecheck.rs:69-71 --
@@ -458,16 +460,12 @@ int bnh_bivariate_mlecheck_prove(bn_ctx *ctx, uint32_t n_vars, uint32_t m, const
 				if (!(got[k] == want)) weighted.clear();
 			}
 		}
-		std::vector<B128> fin;
 		g_mlecheck_mode = weighted.empty() ? 0 : 1;
-		if (!weighted.empty()) {
-			WeightedMLEcheckProver prover(hal, dev_alloc, host_alloc, n_vars, comps, sv, mls, eq_table, eqc, weighted);
-			fin = run(prover);
-		} else {
-			BivariateMLEcheckProver prover(hal, dev_alloc, host_alloc, n_vars, comps, sv, mls, eq_table, eqc);
-			fin = run(prover);
-		}
-		for (uint32_t j = 0; j <= m; j++) final_evals_out[j] = fin[j].raw();
+		if (!weighted.empty())
+			h->weighted.reset(new WeightedMLEcheckProver(h->hal, h->dev_alloc, h->host_alloc, n_vars, comps, sv, mls, eq_table, eqc, weighted));
+		else
+			h->literal.reset(new BivariateMLEcheckProver(h->hal, h->dev_alloc, h->host_alloc, n_vars, comps, sv, mls, eq_table, eqc));
+		*out = h.release();
 		return 0;
 	} catch (const Error &e) {
 		g_err = e.what();
@@ -476,6 +474,81 @@ int bnh_bivariate_mlecheck_prove(bn_ctx *ctx, uint32_t n_vars, uint32_t m, const
 		g_err = e.what();
 		return BN_ERR_CORE_LIB;
 	}
+}
+
+// coeffs_out[4]: the round polynomial (degree 3)
+int bnh_mlecheck_execute(bnh_mlecheck *h, const bn_f128 *batch_coeff, bn_f128 *coeffs_out)
+{
+	try {
+		if (!h || !batch_coeff || !coeffs_out) throw Error(Error::InputValidation, "null argument");
+		const B128 bc(batch_coeff->lo, batch_coeff->hi);
+		const std::vector<B128> rc = h->weighted ? h->weighted->execute(bc) : h->literal->execute(bc);
+		for (size_t i = 0; i < 4; i++) coeffs_out[i] = i < rc.size() ? rc[i].raw() : bn_f128{0, 0};
+		return 0;
+	} catch (const Error &e) {
+		g_err = e.what();
+		return (int)e.kind();
+	} catch (const std::exception &e) {
+		g_err = e.what();
+		return BN_ERR_CORE_LIB;
+	}
+}
+
+int bnh_mlecheck_fold(bnh_mlecheck *h, const bn_f128 *challenge)
+{
+	try {
+		if (!h || !challenge) throw Error(Error::InputValidation, "null argument");
+		const B128 z(challenge->lo, challenge->hi);
+		if (h->weighted)
+			h->weighted->fold(z);
+		else
+			h->literal->fold(z);
+		return 0;
+	} catch (const Error &e) {
+		g_err = e.what();
+		return (int)e.kind();
+	} catch (const std::exception &e) {
+		g_err = e.what();
+		return BN_ERR_CORE_LIB;
+	}
+}
+
+// final_evals_out[m + 1]: the multilinears' evaluations, then eq_ind_prefix_eval.  The handle stays valid (free it).
+int bnh_mlecheck_finish(bnh_mlecheck *h, bn_f128 *final_evals_out)
+{
+	try {
+		if (!h || !final_evals_out) throw Error(Error::InputValidation, "null argument");
+		const std::vector<B128> fin = h->weighted ? h->weighted->finish() : h->literal->finish();
+		for (uint32_t j = 0; j <= h->m; j++) final_evals_out[j] = fin[j].raw();
+		return 0;
+	} catch (const Error &e) {
+		g_err = e.what();
+		return (int)e.kind();
+	} catch (const std::exception &e) {
+		g_err = e.what();
+		return BN_ERR_CORE_LIB;
+	}
+}
+
+void bnh_mlecheck_free(bnh_mlecheck *h) { delete h; }
+
+// One complete BivariateMLEcheckProver run (v3/bivariate_mlecheck.rs) behind a C call.
+//   round_coeffs_out     [4 * n_vars] (degree-3 round polynomials)
+//   final_evals_out      [m + 1]      (the last one is eq_ind_prefix_eval)
+int bnh_bivariate_mlecheck_prove(bn_ctx *ctx, uint32_t n_vars, uint32_t m, const void *const *d_multilins, const void *d_eq_ind,
+                                 const bn_f128 *eq_ind_challenges, void *d_scratch, uint64_t scratch_elems, uint32_t n_comps,
+                                 const uint32_t *comp_indices, const bn_f128 *sums, const bn_f128 *batch_coeff,
+                                 const bn_f128 *challenges, bn_f128 *round_coeffs_out, bn_f128 *final_evals_out)
+{
+	bnh_mlecheck *h = nullptr;
+	int rc = bnh_mlecheck_new(ctx, n_vars, m, d_multilins, d_eq_ind, eq_ind_challenges, d_scratch, scratch_elems, n_comps, comp_indices, sums, &h);
+	for (uint32_t r = 0; rc == 0 && r < n_vars; r++) {
+		rc = bnh_mlecheck_execute(h, batch_coeff, round_coeffs_out + 4 * r);
+		if (rc == 0) rc = bnh_mlecheck_fold(h, &challenges[r]);
+	}
+	if (rc == 0) rc = bnh_mlecheck_finish(h, final_evals_out);
+	bnh_mlecheck_free(h);
+	return rc;
 }
 
 // FRI commit phase + all fold rounds + finalize through the C++ mirror (fri.hpp), everything on the device.

@@ -6,4 +6,8 @@ fn main() {
 		println!("cargo:rustc-link-arg=-Wl,-rpath,{dir}");
 	}
 	println!("cargo:rustc-link-lib=dylib=binius_amd");
+	// the compiled provers behind src/mlecheck.rs (include/binius_amd_host.h)
+	if std::env::var("CARGO_FEATURE_PROVERS").is_ok() {
+		println!("cargo:rustc-link-lib=dylib=binius_amd_host");
+	}
 }

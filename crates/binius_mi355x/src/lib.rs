@@ -19,6 +19,8 @@ pub mod ffi;
 pub mod hal;
 pub mod holder;
 pub mod memory;
+#[cfg(feature = "provers")]
+pub mod mlecheck;
 pub mod recorder;
 
 use std::{ffi::CStr, os::raw::c_int, ptr};

@@ -59,7 +59,19 @@ int bnh_bivariate_mlecheck_prove(bn_ctx *ctx, uint32_t n_vars, uint32_t m, const
                                  const uint32_t *comp_indices, const bn_f128 *sums, const bn_f128 *batch_coeff,
                                  const bn_f128 *challenges, bn_f128 *round_coeffs_out, bn_f128 *final_evals_out);
 
-/* which prover the calling thread's last bnh_bivariate_mlecheck_prove ran: 1 = WeightedMLEcheckProver (the indicator
+/* The same prover behind a handle, one call per SumcheckProver method (prove/batch_sumcheck.rs:38-70): for hosts whose
+ * challenges come out of a transcript round by round -- what the Rust shim's Mi355xMLEcheckProver binds
+ * (crates/binius_mi355x/src/mlecheck.rs).  execute: coeffs_out[4]; finish: final_evals_out[m + 1]. */
+typedef struct bnh_mlecheck bnh_mlecheck;
+int bnh_mlecheck_new(bn_ctx *ctx, uint32_t n_vars, uint32_t m, const void *const *d_multilins, const void *d_eq_ind,
+                     const bn_f128 *eq_ind_challenges, void *d_scratch, uint64_t scratch_elems, uint32_t n_comps,
+                     const uint32_t *comp_indices, const bn_f128 *sums, bnh_mlecheck **out);
+int bnh_mlecheck_execute(bnh_mlecheck *prover, const bn_f128 *batch_coeff, bn_f128 *coeffs_out);
+int bnh_mlecheck_fold(bnh_mlecheck *prover, const bn_f128 *challenge);
+int bnh_mlecheck_finish(bnh_mlecheck *prover, bn_f128 *final_evals_out);
+void bnh_mlecheck_free(bnh_mlecheck *prover);
+
+/* which prover the calling thread's last bnh_mlecheck_new / bnh_bivariate_mlecheck_prove chose: 1 = WeightedMLEcheckProver (the indicator
  * carried inside one factor of every composition; plain bivariate rounds on the matrix cores), 0 = the literal mirror
  * BivariateMLEcheckProver (no proper 2-colouring of the compositions, an indicator coordinate equal to 0 or 1, too
  * little scratch, n_vars < 2, a table that is not the expansion of the coordinates, or BN_MLECHECK=eager), -1 = none yet */

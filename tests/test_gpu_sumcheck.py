@@ -599,3 +599,39 @@ def test_weighted_mlecheck_prover_falls_back(hal, oracle, case, monkeypatch):
     want_coeffs, want_finals = oracle.bivariate_mlecheck_prove([x.copy() for x in mls], n_vars, eq_host.copy(), eq_ch, comps, sums, bc, ch)
     assert plan.round_coeffs() == want_coeffs
     assert plan.final_evals() == want_finals
+
+
+@pytest.mark.parametrize("n_vars,m,comps,eager", [(9, 2, [(0, 1)], False), (12, 3, [(0, 1), (1, 2)], False), (7, 2, [(1, 1)], False), (9, 2, [(0, 1)], True)])
+def test_mlecheck_prover_handle_round_by_round(hal, oracle, n_vars, m, comps, eager, monkeypatch):
+    """bnh_mlecheck_new / execute / fold / finish: the prover driven the way a transcript drives it -- every challenge
+    is handed over only after the round polynomial it depends on has been returned -- with the reference's phase
+    errors (ExpectedFold / ExpectedExecution / ExpectedFinish, bivariate_mlecheck.rs:273-372)."""
+    from binius_amd import BnError
+    from binius_amd._host import MlecheckProver
+
+    if eager:
+        monkeypatch.setenv("BN_MLECHECK", "eager")
+    alloc = hal.dev_alloc()
+    mls, d, eq_ch, eq_dev, sums = _mlecheck_instance(hal, oracle, alloc, n_vars, m, comps, 0x3F3F00 + n_vars)
+    eq_host = hal.copy_d2h(eq_dev)
+    stream = oracle.random_scalars(0xC4A5, n_vars + 1)
+    bc, ch = stream[0], stream[1:]
+    want_coeffs, want_finals = oracle.bivariate_mlecheck_prove([x.copy() for x in mls], n_vars, eq_host.copy(), eq_ch, comps, sums, bc, ch)
+    prover = MlecheckProver(hal, n_vars, d, eq_dev, eq_ch, alloc.alloc(m << n_vars), comps, sums)
+    try:
+        assert prover.mode == (0 if eager or comps == [(1, 1)] else 1)
+        with pytest.raises(BnError, match="ExpectedExecution"):
+            prover.fold(ch[0])
+        for r in range(n_vars):
+            assert prover.execute(bc) == want_coeffs[r]
+            with pytest.raises(BnError, match="ExpectedFold"):
+                prover.execute(bc)
+            if r == n_vars - 1:
+                with pytest.raises(BnError, match="ExpectedFold"):
+                    prover.finish()
+            prover.fold(ch[r])
+        with pytest.raises(BnError, match="ExpectedFinish"):
+            prover.fold(ch[0])
+        assert prover.finish() == want_finals
+    finally:
+        prover.close()

@@ -126,6 +126,19 @@ def test_constants_match_the_header():
     assert re.search(r"#define BN_NTT_MAX_DIM 64", h) and re.search(r"pub const BN_NTT_MAX_DIM: usize = 64;", r)
 
 
+def test_mlecheck_prover_binding_matches_the_host_header():
+    """src/mlecheck.rs declares the bnh_mlecheck_* entry points of include/binius_amd_host.h with the same arity."""
+    h = _strip_comments(open(os.path.join(ROOT, "include", "binius_amd_host.h")).read())
+    r = _strip_comments(open(os.path.join(ROOT, "crates", "binius_mi355x", "src", "mlecheck.rs")).read())
+    for name in ("bnh_mlecheck_new", "bnh_mlecheck_execute", "bnh_mlecheck_fold", "bnh_mlecheck_finish", "bnh_mlecheck_free"):
+        hm = re.search(r"\b%s\s*\(([^;]*?)\)\s*;" % name, h, flags=re.S)
+        rm = re.search(r"fn %s\s*\((.*?)\)\s*(?:->\s*c_int)?;" % name, r, flags=re.S)
+        assert hm and rm, name
+        assert len([a for a in hm.group(1).split(",") if a.strip()]) == len([a for a in rm.group(1).split(",") if a.strip()]), name
+    for m in ("n_vars", "evaluation_order", "execute", "fold", "finish"):  # SumcheckProver (prove/batch_sumcheck.rs:38-70)
+        assert re.search(r"\bfn %s\b[^;{]*\{" % m, r, flags=re.S), m
+
+
 def test_every_trait_method_is_written_out():
     """No elided bodies: every method of the three traits (crates/compute/src/layer.rs:22-590) appears as a
     `fn` with a body in the shim."""
