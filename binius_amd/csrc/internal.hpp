@@ -184,6 +184,7 @@ struct foldeval_args {
 	// bn_extrapolate_line_batch_scaled: bit j set -> the upper half of out[j] (the elements the next round reads as
 	// "evaluation at 1") is multiplied by hi_scale after the fold
 	uint32_t scale_mask;
+	uint32_t xcd_tiles; // k_foldeval_mfma: XCD-contiguous tile order (set by the launcher)
 	f128 hi_scale;
 };
 bool foldeval9_is_small(int n_cu, uint64_t n_in);

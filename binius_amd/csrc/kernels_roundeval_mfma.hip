@@ -23,7 +23,7 @@ using namespace gram;
 template <bool SPLIT>
 __global__ __launch_bounds__(256, 2) void k_roundeval_mfma(const uint4 *__restrict__ a_hi, const uint4 *__restrict__ a_lo,
                                                            const uint4 *__restrict__ b_hi, const uint4 *__restrict__ b_lo, uint64_t n,
-                                                           f128 *out, fin_fuse fz)
+                                                           f128 *out, fin_fuse fz, uint32_t xcd_tiles)
 {
 	constexpr int kTiles = 2; // tiles per iteration: 32 KiB of loads in flight per workgroup, one barrier per 512 points
 	__shared__ __attribute__((aligned(16))) uint32_t T[2][kTiles][kTileW];
@@ -35,7 +35,16 @@ __global__ __launch_bounds__(256, 2) void k_roundeval_mfma(const uint4 *__restri
 	v16i acc[kAccTiles];
 	acc_zero(acc);
 
-	const uint64_t n_groups = (n + kTiles * kTP - 1) / (kTiles * kTP);
+	const uint64_t n_groups_all = (n + kTiles * kTP - 1) / (kTiles * kTP);
+	// group order: XCD x = blockIdx.x & 7 takes the x-th contiguous eighth of the groups (see kernels_foldeval_mfma.hip)
+	uint64_t gbase = 0, gstride = gridDim.x, n_groups = n_groups_all, g0 = blockIdx.x;
+	if (xcd_tiles && (gridDim.x & 7) == 0) {
+		const uint64_t chunk = (n_groups_all + 7) >> 3;
+		gbase = (blockIdx.x & 7) * chunk;
+		gstride = gridDim.x >> 3;
+		g0 = blockIdx.x >> 3;
+		n_groups = gbase >= n_groups_all ? 0 : (n_groups_all - gbase < chunk ? n_groups_all - gbase : chunk);
+	}
 	// a_hi, a_lo, b_hi, b_lo of this lane's point in each tile of the group.  One tile of 16 KiB in flight
 	// per workgroup covers only ~2.7 us of HBM latency at 3 TB/s -- what a loaded HBM takes to answer.
 	// (a lane past the end loads element 0 and zeroes it when the tile is staged: nothing depends on a
@@ -44,7 +53,7 @@ __global__ __launch_bounds__(256, 2) void k_roundeval_mfma(const uint4 *__restri
 	auto load = [&](uint64_t g) {
 #pragma unroll
 		for (int i = 0; i < kTiles; i++) {
-			const uint64_t pt = (g * kTiles + i) * kTP + threadIdx.x;
+			const uint64_t pt = ((gbase + g) * kTiles + i) * kTP + threadIdx.x;
 			const uint64_t e = pt < n ? pt : 0;
 			x[i][0] = a_hi[e];
 			x[i][1] = a_lo[e];
@@ -55,7 +64,7 @@ __global__ __launch_bounds__(256, 2) void k_roundeval_mfma(const uint4 *__restri
 	auto stage = [&](uint64_t g, uint32_t (*Tb)[kTileW]) {
 #pragma unroll
 		for (int i = 0; i < kTiles; i++) {
-			if ((g * kTiles + i) * kTP + threadIdx.x >= n) {
+			if (((gbase + g) * kTiles + i) * kTP + threadIdx.x >= n) {
 #pragma unroll
 				for (int k = 0; k < 4; k++)
 					x[i][k] = uint4{0, 0, 0, 0};
@@ -65,15 +74,15 @@ __global__ __launch_bounds__(256, 2) void k_roundeval_mfma(const uint4 *__restri
 		}
 	};
 
-	uint64_t g = blockIdx.x;
+	uint64_t g = g0;
 	unsigned buf = 0;
 	if (g < n_groups) {
 		load(g);
 		stage(g, T[0]);
 	}
 	__syncthreads();
-	for (; g < n_groups; g += gridDim.x) {
-		const uint64_t gn = g + gridDim.x;
+	for (; g < n_groups; g += gstride) {
+		const uint64_t gn = g + gstride;
 #ifndef GRAM_DBG
 #define GRAM_DBG 0
 #endif
@@ -117,8 +126,12 @@ static hipError_t launch_mfma(hipStream_t s, int n_cu, const void *a_hi, const v
 	if (fuse) fz = *fuse;
 	if (n == 0 && fuse) return hipErrorNotSupported; // nothing to launch: the caller finalizes separately
 	if (n == 0) return hipSuccess;
+	static const uint32_t xcd_tiles = [] {
+		const char *e = getenv("BN_XCD_TILES");
+		return (uint32_t)!(e && e[0] == '0');
+	}();
 	hipLaunchKernelGGL((k_roundeval_mfma<SPLIT>), dim3(grid_mfma(n, n_cu)), dim3(256), 0, s, (const uint4 *)a_hi, (const uint4 *)a_lo,
-	                   (const uint4 *)b_hi, (const uint4 *)b_lo, n, d_out, fz);
+	                   (const uint4 *)b_hi, (const uint4 *)b_lo, n, d_out, fz, xcd_tiles);
 	return hipGetLastError();
 }
 
