@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256, 2) void k_foldeval_mfma(foldeval_args fa, uint
 	// Tile order.  Consecutive workgroup ids go to different XCDs (round robin), so XCD x = b & 7 takes the x-th
 	// contiguous eighth of the tiles and its 64 workgroups stride through that eighth: at any time an XCD (its L2, its
 	// share of the fabric) works on twelve contiguous 256 KiB windows instead of every eighth tile of twelve 2 MiB
-	// windows.  +1.7 % on the large launches (n = 28: 0.529 -> 0.539 of the roofline, A/B on one box, twice).
+	// windows.  +1 ... +2.7 % on the large launches at n = 28, depending on the box (A/B runs alternating on three).
 	// BN_XCD_TILES=0: workgroup b takes tiles b, b + G, ... .
 	uint64_t tbase = 0, tstride = gridDim.x, tlimit = n_tiles, t0 = blockIdx.x;
 	if (fa.xcd_tiles && (gridDim.x & 7) == 0) {
