@@ -34,6 +34,9 @@ import os
 import sys
 import time
 
+# the host driver of the GPU boxes only supports dmabuf IPC (RCCL / shared device memory across the ranks)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -140,9 +143,24 @@ def main():
         if rccl_possible:
             # the per-round collective is issued from the compiled host loop: ncclAllGather of the 32-byte
             # partial on the context's stream, communicator bootstrapped over the torch process group
-            rccl = RcclComm(dist, rank, world)
-            d_partial = reducer.local.data_ptr()
-            d_gathered = reducer.gathered.data_ptr()
+            try:
+                rccl = RcclComm(dist, rank, world)
+                ok = 1
+            except Exception as ex:  # noqa: BLE001
+                print("[bench] rank %d: RCCL communicator unavailable (%s)" % (rank, ex), file=sys.stderr)
+                rccl, ok = None, 0
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                if rccl is not None:
+                    rccl.destroy()
+                rccl = None
+                if shm is None:
+                    raise SystemExit("neither the RCCL communicator nor the shared-memory segment is available")
+                exchange = "shm (fallback: the RCCL communicator could not be created on this node)"
+            else:
+                d_partial = reducer.local.data_ptr()
+                d_gathered = reducer.gathered.data_ptr()
         elif exchange == "rccl":
             raise SystemExit("BN_EXCHANGE=rccl needs the nccl process-group backend")
 
@@ -158,7 +176,7 @@ def main():
         torch.cuda.synchronize()
 
     def make_plan(kind):
-        use_shm = kind == "shm"
+        use_shm = kind.startswith("shm")
         return SumcheckPlan(hal, n_vars, d_in, scratch, [(0, 1)], [claim], batch_coeff, challenges[:n_global], None,
                             0 if use_shm else d_partial, None if (use_shm or rccl is None) else rccl.handle, world,
                             0 if use_shm else d_gathered, shm.handle if use_shm else None, tail_rounds=log_world > 0)
@@ -181,7 +199,7 @@ def main():
     # First run of the default transport, guarded: if the RCCL exchange cannot run on this node (communicator
     # or collective error on ANY rank), every rank switches to the shared-memory exchange together and the
     # line says so -- a scaling line with a documented fallback beats none.
-    if dist is not None and exchange == "rccl":
+    if dist is not None and exchange == "rccl" and rccl is not None:
         ok = 1
         try:
             plan.run()
