@@ -48,8 +48,8 @@ PMC_FILE = os.path.join("profiles", "r02", "bench_pmc.json")  # tools/pmc_bench.
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--n-vars", type=int, default=28, help="variables of the GLOBAL instance (28: north star; 24: BASELINE configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="diagnostic: no per-launch hipEvents in the timed region (no roofline block)")
