@@ -635,3 +635,38 @@ def test_mlecheck_prover_handle_round_by_round(hal, oracle, n_vars, m, comps, ea
         assert prover.finish() == want_finals
     finally:
         prover.close()
+
+
+@pytest.mark.parametrize("log_n", [6, 12, 15, 19])
+@pytest.mark.parametrize("mask", [0, 1, 2, 3])
+def test_scaled_fold_followed_by_round_evaluation(hal, oracle, log_n, mask):
+    """The deferred (scaled) batch fold fused with the round evaluation that reads the folded arrays -- every mask,
+    including both arrays scaled (no fused kernel: fold, scale pass and evaluation run separately) -- gives what the
+    operations give one after the other."""
+    from binius_amd.sumcheck import bivariate_product_expr, calculate_round_evals
+
+    alloc = hal.dev_alloc()
+    n = 1 << log_n
+    x = [oracle.random_b128(0x5D00 + 4 * log_n + j, n) for j in range(2)]
+    z, hs = oracle.random_scalars(0x5D80 + mask, 2)
+    d = [upload(hal, alloc, v) for v in x]
+    lo = [s.slice(0, n // 2) for s in d]
+    hi = [s.slice(n // 2, n) for s in d]
+    if mask:
+        hal.extrapolate_line_batch_scaled(lo, hi, z, mask, hs)
+    else:
+        hal.extrapolate_line_batch(lo, hi, z)
+    expr = bivariate_product_expr(hal, 0, 1)
+    got = calculate_round_evals(hal, log_n - 1, [1], lo, [expr])
+    want_arrays = []
+    for j in range(2):
+        w = x[j][: n // 2].copy()
+        assert oracle.extrapolate_line(w, x[j][n // 2 :].copy(), z) == 0
+        if (mask >> j) & 1:
+            w[n // 4 :] = oracle.mul_vec(np.ascontiguousarray(w[n // 4 :]), oracle.ints_to_arr([hs] * (n // 4)))
+        want_arrays.append(w)
+    rc, want = oracle.round_evals(want_arrays, log_n - 1, [(0, 1)], 1)
+    assert rc == 0 and got == want
+    for j in range(2):
+        assert np.array_equal(hal.copy_d2h(lo[j]), want_arrays[j])
+    expr.free()
