@@ -3,10 +3,10 @@
 // bn_hal_round_evals = sumcheck_compute_round_evals (crates/hal/src/sumcheck_round_calculation.rs:45-330),
 // bn_hal_fold_multilinear = one multilinear of sumcheck_fold_multilinears (crates/hal/src/sumcheck_folding.rs:16-237).
 //
-// Routing: the shapes the v2 provers spend their time in -- every evaluator a product of two FULL Folded multilinears
-// evaluated at X = 1 and X = infinity in High-to-Low order, optionally times an equality-indicator table -- are exactly
-// what the ComputeLayer path evaluates, and run on its kernels (matrix-core Gram kernels from 2^17 points, 9-lane
-// kernels below).  Everything else (other compositions, more evaluation points, Low-to-High order, truncated
+// Routing: the shapes the v2 provers spend their time in -- every evaluator a product of two (or three) FULL Folded
+// multilinears evaluated at X = 1 and X = infinity in High-to-Low order, optionally times an equality-indicator table
+// -- are exactly what the ComputeLayer path evaluates, and run on its kernels (two factors: matrix-core Gram kernels
+// from 2^17 points, 9-lane kernels below; more: the bit-sliced product-sum kernel).  Everything else (other compositions, more evaluation points, Low-to-High order, truncated
 // multilinears) runs the general kernels of kernels_hal.hip.  Transparent multilinears are first partially evaluated at
 // the tensor query into context scratch (evaluate_partial_low / _high = the fold_right / fold_left kernels): the
 // reference does the same thing subcube by subcube to save memory (sumcheck_round_calculation.rs:404-418, 496-518).
@@ -14,7 +14,12 @@
 
 namespace {
 
-bool is_product2(const bn_expr *e) { return e && e->shape == bn_expr::PRODUCT && e->product_vars.size() == 2; }
+// a product of 2 or 3 multilinears (with the equality indicator as one more factor: at most the four factors the
+// product-sum kernels take)
+bool is_product(const bn_expr *e, bool with_eq)
+{
+	return e && e->shape == bn_expr::PRODUCT && e->product_vars.size() >= 2 && e->product_vars.size() + (with_eq ? 1 : 0) <= 4;
+}
 
 // Transparent multilinear -> 2^n_vars large-field values at `dst` under the query
 int materialise(bn_ctx *ctx, uint32_t order, uint32_t n_vars, const bn_hal_multilinear &ml, const void *d_query, uint32_t query_vars, void *d_one,
@@ -111,20 +116,25 @@ int bn_hal_round_evals(bn_ctx *ctx, uint32_t order, uint32_t n_vars, const void 
 	// ---- the fast shape: products of two full multilinears at X = 1 / infinity, High-to-Low
 	bool fast = order == BN_ORDER_HIGH_TO_LOW && all_full && pt_lo >= 1 && pt_hi <= 3 && n_vars >= 2;
 	for (uint32_t e = 0; e < n_evs && fast; e++)
-		fast = is_product2(evs[e].composition) && is_product2(evs[e].composition_at_infinity) &&
+		fast = is_product(evs[e].composition, evs[e].d_eq_ind != nullptr) && is_product(evs[e].composition_at_infinity, evs[e].d_eq_ind != nullptr) &&
 		       evs[e].composition->product_vars == evs[e].composition_at_infinity->product_vars;
 	if (fast) {
 		uint32_t off = 0;
 		for (uint32_t e = 0; e < n_evs; e++) {
 			const uint32_t s0 = evs[e].eval_point_start, s1 = evs[e].eval_point_end;
 			if (s1 > s0) {
-				const uint32_t va = evs[e].composition->product_vars[0], vb = evs[e].composition->product_vars[1];
-				const char *pa = (const char *)a.ml[va].evals, *pb = (const char *)a.ml[vb].evals;
 				// the kernels accumulate (S_1, S_inf) into two adjacent slots: slot 32 + 2e, 33 + 2e, copied below
 				f128 *pair = d_acc + 32 + 2 * e;
-				const void *hi[3] = {pa + half * 16, pb + half * 16, evs[e].d_eq_ind};
-				const void *lo[3] = {pa, pb, nullptr};
-				BN_HIP(bn::launch_roundeval_product(ctx->stream, ctx->n_cu, hi, lo, evs[e].d_eq_ind ? 3 : 2, half, pair, nullptr));
+				const void *hi[4] = {nullptr, nullptr, nullptr, nullptr}, *lo[4] = {nullptr, nullptr, nullptr, nullptr};
+				uint32_t k = 0;
+				for (uint32_t v : evs[e].composition->product_vars) {
+					const char *p = (const char *)a.ml[v].evals;
+					hi[k] = p + half * 16;
+					lo[k] = p;
+					k++;
+				}
+				if (evs[e].d_eq_ind) hi[k++] = evs[e].d_eq_ind; // (lo = NULL: the same factor at both evaluation points)
+				BN_HIP(bn::launch_roundeval_product(ctx->stream, ctx->n_cu, hi, lo, k, half, pair, nullptr));
 				for (uint32_t p = s0; p < s1; p++)
 					BN_HIP(hipMemcpyAsync(d_acc + off + (p - s0), pair + (p - 1), sizeof(f128), hipMemcpyDeviceToDevice, ctx->stream));
 			}

@@ -100,6 +100,22 @@ def test_round_evals_fast_shape(hal, oracle, n_vars, with_eq):
         assert got2 == got
 
 
+@pytest.mark.parametrize("n_vars", [3, 9, 14])
+@pytest.mark.parametrize("with_eq", [False, True])
+def test_round_evals_fast_shape_three_factors(hal, oracle, n_vars, with_eq):
+    """Products of three full multilinears (a * b * c, a^2 * b), with or without the equality indicator: routed to the
+    bit-sliced product-sum kernel."""
+    n = 1 << n_vars
+    x = [oracle.random_b128(0x12E0 + j, n) for j in range(3)]
+    eq = oracle.random_b128(0x12F0, n // 2) if with_eq else None
+    abc = [("var", 0), ("var", 1), ("mul", 0, 1), ("var", 2), ("mul", 2, 3)]
+    aab = [("var", 0), ("var", 0), ("mul", 0, 1), ("var", 1), ("mul", 2, 3)]
+    evaluators = [{"steps": abc, "steps_inf": abc, "start": 1, "end": 3, "eq_ind": eq},
+                  {"steps": aab, "steps_inf": aab, "start": 2, "end": 3, "eq_ind": eq}]
+    got, want = both(hal, oracle, 1, n_vars, None, [("folded", v, 0) for v in x], evaluators, [])
+    assert got == want
+
+
 @pytest.mark.parametrize("order", [0, 1])
 @pytest.mark.parametrize("level", [0, 3, 4, 5, 6, 7])
 def test_round_evals_transparent(hal, oracle, order, level):
