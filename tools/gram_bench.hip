@@ -70,7 +70,7 @@ int main(int argc, char **argv)
 	hipEvent_t ea, eb;
 	(void)hipEventCreate(&ea);
 	(void)hipEventCreate(&eb);
-	for (int rep = 0; rep < (prof ? 1 : 4); rep++) {
+	for (int rep = 0; rep < (prof ? 3 : 4); rep++) {
 		(void)hipMemset(d_out, 0, 32);
 		(void)hipEventRecord(ea);
 		(void)launch_roundeval_mfma_pair(0, 256, d[0], d[1], d[2], d[3], n, d_out, nullptr);
@@ -84,7 +84,7 @@ int main(int argc, char **argv)
 	const f128 z{0x0123456789abcdefull, 0xfedcba9876543210ull};
 	for (uint64_t N : {1024ull, 4096ull + 8, 1ull << 16, 1ull << 18}) {
 		if (N > n_host || prof) continue;
-		foldeval_args fa;
+		foldeval_args fa{};
 		fa.x0[0] = d[0]; fa.x1[0] = d[0] + N / 2; fa.out[0] = d[1];
 		fa.x0[1] = d[2]; fa.x1[1] = d[2] + N / 2; fa.out[1] = d[3];
 		(void)hipMemset(d_out, 0, 32);
@@ -112,10 +112,10 @@ int main(int argc, char **argv)
 	}
 	{
 		// timing: in place on a = d[0], b = d[2] (N = n elements each)
-		foldeval_args fa;
+		foldeval_args fa{};
 		fa.x0[0] = d[0]; fa.x1[0] = d[0] + n / 2; fa.out[0] = d[0];
 		fa.x0[1] = d[2]; fa.x1[1] = d[2] + n / 2; fa.out[1] = d[2];
-		for (int rep = 0; rep < (prof ? 1 : 4); rep++) {
+		for (int rep = 0; rep < (prof ? 3 : 4); rep++) {
 			(void)hipMemset(d_out, 0, 32);
 			(void)hipEventRecord(ea);
 			(void)launch_foldeval_mfma(0, 256, fa, n, z, d_out, nullptr);
