@@ -10,6 +10,9 @@
 // multilinears) runs the general kernels of kernels_hal.hip.  Transparent multilinears are first partially evaluated at
 // the tensor query into context scratch (evaluate_partial_low / _high = the fold_right / fold_left kernels): the
 // reference does the same thing subcube by subcube to save memory (sumcheck_round_calculation.rs:404-418, 496-518).
+#include <algorithm>
+#include <map>
+
 #include "abi_common.hpp"
 
 namespace {
@@ -19,6 +22,75 @@ namespace {
 bool is_product(const bn_expr *e, bool with_eq)
 {
 	return e && e->shape == bn_expr::PRODUCT && e->product_vars.size() >= 2 && e->product_vars.size() + (with_eq ? 1 : 0) <= 4;
+}
+
+// An ArithCircuit as a sum of monomials  coeff * prod(vars)  over GF(2^128) (variables may repeat: a^2 * b is the
+// multiset {a, a, b}).  Empty result = too large for the routed path (more than kMaxTerms monomials / degree > 3 / a
+// power above 3): the caller falls back to the interpreter kernel.
+struct monomial {
+	std::vector<uint32_t> vars; // sorted
+	f128 coeff;
+};
+constexpr size_t kMaxTerms = 12;
+bool expand_poly(const bn_expr *e, std::vector<monomial> &out)
+{
+	typedef std::map<std::vector<uint32_t>, f128> poly;
+	std::vector<poly> val(e->steps.size());
+	auto add_term = [](poly &p, const std::vector<uint32_t> &v, f128 c) {
+		if (c == bn::f128_zero()) return;
+		auto it = p.find(v);
+		if (it == p.end()) {
+			p.emplace(v, c);
+		} else {
+			it->second ^= c;
+			if (it->second == bn::f128_zero()) p.erase(it);
+		}
+	};
+	auto mul = [&](const poly &x, const poly &y, poly &r) -> bool {
+		for (const auto &tx : x)
+			for (const auto &ty : y) {
+				std::vector<uint32_t> v = tx.first;
+				v.insert(v.end(), ty.first.begin(), ty.first.end());
+				std::sort(v.begin(), v.end());
+				if (v.size() > 3) return false;
+				add_term(r, v, bn::mul_slow(tx.second, ty.second));
+			}
+		return r.size() <= 4 * kMaxTerms;
+	};
+	for (size_t i = 0; i < e->steps.size(); i++) {
+		const bn_step &st = e->steps[i];
+		poly &r = val[i];
+		switch (st.kind) {
+		case BN_STEP_VAR: r[{st.a}] = bn::f128_one(); break;
+		case BN_STEP_CONST: add_term(r, {}, f128{st.cst.lo, st.cst.hi}); break;
+		case BN_STEP_ADD:
+			if (st.a >= i || st.b >= i) return false;
+			r = val[st.a];
+			for (const auto &t : val[st.b]) add_term(r, t.first, t.second);
+			break;
+		case BN_STEP_MUL:
+			if (st.a >= i || st.b >= i) return false;
+			if (!mul(val[st.a], val[st.b], r)) return false;
+			break;
+		case BN_STEP_POW: {
+			if (st.a >= i || st.b > 3) return false;
+			poly acc;
+			acc[{}] = bn::f128_one();
+			for (uint64_t k = 0; k < st.b; k++) {
+				poly nxt;
+				if (!mul(acc, val[st.a], nxt)) return false;
+				acc.swap(nxt);
+			}
+			r = acc;
+			break;
+		}
+		default: return false;
+		}
+	}
+	out.clear();
+	if (e->steps.empty()) return true;
+	for (const auto &t : val.back()) out.push_back(monomial{t.first, t.second});
+	return out.size() <= kMaxTerms;
 }
 
 // Transparent multilinear -> 2^n_vars large-field values at `dst` under the query
@@ -79,7 +151,8 @@ int bn_hal_round_evals(bn_ctx *ctx, uint32_t order, uint32_t n_vars, const void 
 	}
 	char *scr = nullptr;
 	if (n_tr) {
-		scr = (char *)bn::ctx_scratch(ctx, ((size_t)n_tr * full + 1) * sizeof(f128));
+		// (+ half a cube for the all-ones table of the routed path below: the block must not move once it holds data)
+		scr = (char *)bn::ctx_scratch(ctx, ((size_t)n_tr * full + 1 + half) * sizeof(f128));
 		if (!scr) return bn::fail(BN_ERR_ALLOC, "allocation error: allocator is out of memory (scratch)");
 		BN_HIP(bn::launch_fill(ctx->stream, scr + (size_t)n_tr * full * sizeof(f128), 1, bn::f128_one()));
 	}
@@ -113,33 +186,78 @@ int bn_hal_round_evals(bn_ctx *ctx, uint32_t order, uint32_t n_vars, const void 
 	ctx->s_clean = false;
 	BN_HIP(hipMemsetAsync(d_acc, 0, 64 * sizeof(f128), ctx->stream));
 
-	// ---- the fast shape: products of two full multilinears at X = 1 / infinity, High-to-Low
+	// ---- the routed shapes: full Folded multilinears, High-to-Low, evaluation points 1 and infinity, every composition a
+	// sum of monomials of at most three multilinears (two next to an equality indicator).  Every DISTINCT monomial
+	// (x indicator table) is ONE pass of the ComputeLayer's product-sum kernels, which return the sums at both points;
+	// the coefficients are applied to the 16-byte sums on the host.
+	struct term_job {
+		std::vector<uint32_t> vars;
+		const void *eq;
+	};
+	std::vector<term_job> jobs;
+	std::vector<std::vector<monomial>> p1(n_evs), pinf(n_evs);
+	char *ones = nullptr;
 	bool fast = order == BN_ORDER_HIGH_TO_LOW && all_full && pt_lo >= 1 && pt_hi <= 3 && n_vars >= 2;
-	for (uint32_t e = 0; e < n_evs && fast; e++)
-		fast = is_product(evs[e].composition, evs[e].d_eq_ind != nullptr) && is_product(evs[e].composition_at_infinity, evs[e].d_eq_ind != nullptr) &&
-		       evs[e].composition->product_vars == evs[e].composition_at_infinity->product_vars;
+	auto job_of = [&](const std::vector<uint32_t> &vars, const void *eq) -> int {
+		for (size_t j = 0; j < jobs.size(); j++)
+			if (jobs[j].vars == vars && jobs[j].eq == eq) return (int)j;
+		jobs.push_back(term_job{vars, eq});
+		return (int)jobs.size() - 1;
+	};
+	for (uint32_t e = 0; e < n_evs && fast; e++) {
+		fast = expand_poly(evs[e].composition, p1[e]) && expand_poly(evs[e].composition_at_infinity, pinf[e]);
+		for (const auto *pl : {&p1[e], &pinf[e]})
+			for (const auto &t : *pl) {
+				if (t.vars.size() + (evs[e].d_eq_ind ? 1 : 0) > 3) fast = false; // (one slot is kept for the all-ones factor)
+				if (fast) job_of(t.vars, evs[e].d_eq_ind);
+			}
+		if (jobs.size() > 15) fast = false;
+	}
 	if (fast) {
+		// a monomial with fewer than two factors is padded with an all-ones table (sum of v = sum of v * 1)
+		bool need_ones = false;
+		for (const auto &j : jobs)
+			if (j.vars.size() + (j.eq ? 1 : 0) < 2) need_ones = true;
+		if (need_ones) {
+			if (!scr) {
+				scr = (char *)bn::ctx_scratch(ctx, (1 + half) * sizeof(f128));
+				if (!scr) return bn::fail(BN_ERR_ALLOC, "allocation error: allocator is out of memory (scratch)");
+			}
+			ones = scr + ((size_t)n_tr * full + 1) * sizeof(f128);
+			BN_HIP(bn::launch_fill(ctx->stream, ones, half, bn::f128_one()));
+		}
+	}
+	if (fast) {
+		// slots 32 + 2 j, 33 + 2 j: (S_1, S_inf) of job j
+		for (size_t j = 0; j < jobs.size(); j++) {
+			const void *hi[4] = {nullptr, nullptr, nullptr, nullptr}, *lo[4] = {nullptr, nullptr, nullptr, nullptr};
+			uint32_t k = 0;
+			for (uint32_t v : jobs[j].vars) {
+				const char *p = (const char *)a.ml[v].evals;
+				hi[k] = p + half * 16;
+				lo[k] = p;
+				k++;
+			}
+			if (jobs[j].eq) hi[k++] = jobs[j].eq; // (lo = NULL: the same factor at both evaluation points)
+			while (k < 2) hi[k++] = ones;
+			BN_HIP(bn::launch_roundeval_product(ctx->stream, ctx->n_cu, hi, lo, k, half, d_acc + 32 + 2 * j, nullptr));
+		}
+		std::vector<f128> sums(2 * jobs.size());
+		BN_HIP(hipMemcpyAsync(sums.data(), d_acc + 32, sums.size() * sizeof(f128), hipMemcpyDeviceToHost, ctx->stream));
+		BN_HIP(hipStreamSynchronize(ctx->stream));
 		uint32_t off = 0;
 		for (uint32_t e = 0; e < n_evs; e++) {
-			const uint32_t s0 = evs[e].eval_point_start, s1 = evs[e].eval_point_end;
-			if (s1 > s0) {
-				// the kernels accumulate (S_1, S_inf) into two adjacent slots: slot 32 + 2e, 33 + 2e, copied below
-				f128 *pair = d_acc + 32 + 2 * e;
-				const void *hi[4] = {nullptr, nullptr, nullptr, nullptr}, *lo[4] = {nullptr, nullptr, nullptr, nullptr};
-				uint32_t k = 0;
-				for (uint32_t v : evs[e].composition->product_vars) {
-					const char *p = (const char *)a.ml[v].evals;
-					hi[k] = p + half * 16;
-					lo[k] = p;
-					k++;
-				}
-				if (evs[e].d_eq_ind) hi[k++] = evs[e].d_eq_ind; // (lo = NULL: the same factor at both evaluation points)
-				BN_HIP(bn::launch_roundeval_product(ctx->stream, ctx->n_cu, hi, lo, k, half, pair, nullptr));
-				for (uint32_t p = s0; p < s1; p++)
-					BN_HIP(hipMemcpyAsync(d_acc + off + (p - s0), pair + (p - 1), sizeof(f128), hipMemcpyDeviceToDevice, ctx->stream));
+			for (uint32_t p = evs[e].eval_point_start; p < evs[e].eval_point_end; p++) {
+				f128 v = bn::f128_zero();
+				for (const auto &t : (p == 1 ? p1[e] : pinf[e]))
+					v ^= bn::mul_slow(t.coeff, sums[2 * job_of(t.vars, evs[e].d_eq_ind) + (p - 1)]);
+				h_out[off + (p - evs[e].eval_point_start)] = bn_f128{v.lo, v.hi};
 			}
-			off += s1 - s0;
+			off += evs[e].eval_point_end - evs[e].eval_point_start;
 		}
+		BN_HIP(hipMemsetAsync(d_acc, 0, 64 * sizeof(f128), ctx->stream));
+		ctx->s_clean = true;
+		return BN_OK;
 	} else {
 		uint32_t off = 0;
 		for (uint32_t e = 0; e < n_evs; e++) {

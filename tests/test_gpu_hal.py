@@ -116,6 +116,47 @@ def test_round_evals_fast_shape_three_factors(hal, oracle, n_vars, with_eq):
     assert got == want
 
 
+@pytest.mark.parametrize("n_vars", [2, 5, 11, 18])
+def test_round_evals_routed_sums_of_products(hal, oracle, n_vars):
+    """Compositions that are sums of monomials (a * b + c, a * b * c + a, K * b^3 + a, a * b + K, a single variable),
+    with and without an equality indicator, at X = 1 and infinity over full multilinears: one product-sum pass per
+    distinct monomial, coefficients applied on the host.  (Zerocheck-style constraints take this route.)"""
+    n = 1 << n_vars
+    x = [oracle.random_b128(0x18A0 + j, n) for j in range(3)]
+    eq = oracle.random_b128(0x18B0, n // 2)
+    K = 0x0123456789ABCDEF0FEDCBA987654321
+    ab_plus_k = [("var", 0), ("var", 1), ("mul", 0, 1), ("const", K), ("add", 2, 3)]
+    lin = [("var", 2)]
+    kab = [("const", K), ("var", 0), ("mul", 0, 1), ("var", 1), ("mul", 2, 3)]  # K * a * b
+    evaluators = [
+        {"steps": AB_PLUS_C, "steps_inf": AB, "start": 1, "end": 3, "eq_ind": None},
+        {"steps": ABC_PLUS_A, "steps_inf": ABC, "start": 1, "end": 3, "eq_ind": None},
+        {"steps": SQ_PLUS, "steps_inf": SQ_INF, "start": 2, "end": 3, "eq_ind": None},
+        {"steps": AB_PLUS_C, "steps_inf": AB, "start": 1, "end": 3, "eq_ind": eq},
+        {"steps": ab_plus_k, "steps_inf": AB, "start": 1, "end": 2, "eq_ind": eq},
+        {"steps": ab_plus_k, "steps_inf": AB, "start": 1, "end": 3, "eq_ind": None},
+        {"steps": lin, "steps_inf": lin, "start": 1, "end": 3, "eq_ind": eq},
+        {"steps": kab, "steps_inf": kab, "start": 1, "end": 3, "eq_ind": None},
+    ]
+    got, want = both(hal, oracle, 1, n_vars, None, [("folded", v, 0) for v in x], evaluators, [])
+    assert got == want
+
+
+def test_round_evals_routed_with_transparent_inputs(hal, oracle):
+    """The routed path on top of materialised Transparent multilinears (the all-ones table shares their scratch block)."""
+    n_vars, q_vars, level = 10, 2, 5
+    n_ml = n_vars + q_vars
+    packed = oracle.random_b128(0x19A0, (1 << n_ml) >> (7 - level))
+    query = oracle.arr(1 << q_vars)
+    query[0, 0] = 1
+    oracle.tensor_expand(query, 0, oracle.random_scalars(0x19B0, q_vars))
+    other = [oracle.random_b128(0x19C0 + j, 1 << n_vars) for j in range(2)]
+    evaluators = [{"steps": AB_PLUS_C, "steps_inf": AB, "start": 1, "end": 3, "eq_ind": None}]
+    mls = [("transparent", packed, level, n_ml), ("folded", other[0], 0), ("folded", other[1], 0)]
+    got, want = both(hal, oracle, 1, n_vars, query, mls, evaluators, [])
+    assert got == want
+
+
 @pytest.mark.parametrize("order", [0, 1])
 @pytest.mark.parametrize("level", [0, 3, 4, 5, 6, 7])
 def test_round_evals_transparent(hal, oracle, order, level):
