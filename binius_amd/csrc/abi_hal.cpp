@@ -3,26 +3,21 @@
 // bn_hal_round_evals = sumcheck_compute_round_evals (crates/hal/src/sumcheck_round_calculation.rs:45-330),
 // bn_hal_fold_multilinear = one multilinear of sumcheck_fold_multilinears (crates/hal/src/sumcheck_folding.rs:16-237).
 //
-// Routing: the shapes the v2 provers spend their time in -- every evaluator a product of two (or three) FULL Folded
-// multilinears evaluated at X = 1 and X = infinity in High-to-Low order, optionally times an equality-indicator table
-// -- are exactly what the ComputeLayer path evaluates, and run on its kernels (two factors: matrix-core Gram kernels
-// from 2^17 points, 9-lane kernels below; more: the bit-sliced product-sum kernel).  Everything else (other compositions, more evaluation points, Low-to-High order, truncated
-// multilinears) runs the general kernels of kernels_hal.hip.  Transparent multilinears are first partially evaluated at
-// the tensor query into context scratch (evaluate_partial_low / _high = the fold_right / fold_left kernels): the
-// reference does the same thing subcube by subcube to save memory (sumcheck_round_calculation.rs:404-418, 496-518).
+// Routing: compositions that are sums of monomials of at most three FULL multilinears (two next to an equality-indicator
+// table), evaluated at X = 1 and X = infinity in High-to-Low order -- the bivariate products of the v2 provers, the
+// zerocheck-style constraints a * b + c -- are sums of what the ComputeLayer path evaluates and run on its kernels, one
+// pass per distinct monomial (two factors: matrix-core Gram kernels from 2^17 points, 9-lane kernels below; more: the
+// bit-sliced product-sum kernel).  Everything else (more evaluation points, Low-to-High order, truncated multilinears,
+// larger compositions) runs the general kernels of kernels_hal.hip.  Transparent multilinears are first partially
+// evaluated at the tensor query into context scratch (evaluate_partial_low / _high = the fold_right / fold_left
+// kernels): the reference does the same thing subcube by subcube to save memory
+// (sumcheck_round_calculation.rs:404-418, 496-518).
 #include <algorithm>
 #include <map>
 
 #include "abi_common.hpp"
 
 namespace {
-
-// a product of 2 or 3 multilinears (with the equality indicator as one more factor: at most the four factors the
-// product-sum kernels take)
-bool is_product(const bn_expr *e, bool with_eq)
-{
-	return e && e->shape == bn_expr::PRODUCT && e->product_vars.size() >= 2 && e->product_vars.size() + (with_eq ? 1 : 0) <= 4;
-}
 
 // An ArithCircuit as a sum of monomials  coeff * prod(vars)  over GF(2^128) (variables may repeat: a^2 * b is the
 // multiset {a, a, b}).  Empty result = too large for the routed path (more than kMaxTerms monomials / degree > 3 / a
