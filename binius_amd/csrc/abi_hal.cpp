@@ -146,8 +146,8 @@ int bn_hal_round_evals(bn_ctx *ctx, uint32_t order, uint32_t n_vars, const void 
 	}
 	char *scr = nullptr;
 	if (n_tr) {
-		// (+ half a cube for the all-ones table of the routed path below: the block must not move once it holds data)
-		scr = (char *)bn::ctx_scratch(ctx, ((size_t)n_tr * full + 1 + half) * sizeof(f128));
+		// (+ a cube for the all-ones and all-zeros tables of the routed path below: the block must not move once it holds data)
+		scr = (char *)bn::ctx_scratch(ctx, ((size_t)n_tr * full + 1 + full) * sizeof(f128));
 		if (!scr) return bn::fail(BN_ERR_ALLOC, "allocation error: allocator is out of memory (scratch)");
 		BN_HIP(bn::launch_fill(ctx->stream, scr + (size_t)n_tr * full * sizeof(f128), 1, bn::f128_one()));
 	}
@@ -191,7 +191,7 @@ int bn_hal_round_evals(bn_ctx *ctx, uint32_t order, uint32_t n_vars, const void 
 	};
 	std::vector<term_job> jobs;
 	std::vector<std::vector<monomial>> p1(n_evs), pinf(n_evs);
-	char *ones = nullptr;
+	char *ones = nullptr, *zeros = nullptr;
 	bool fast = order == BN_ORDER_HIGH_TO_LOW && all_full && pt_lo >= 1 && pt_hi <= 3 && n_vars >= 2;
 	auto job_of = [&](const std::vector<uint32_t> &vars, const void *eq) -> int {
 		for (size_t j = 0; j < jobs.size(); j++)
@@ -209,17 +209,22 @@ int bn_hal_round_evals(bn_ctx *ctx, uint32_t order, uint32_t n_vars, const void 
 		if (jobs.size() > 15) fast = false;
 	}
 	if (fast) {
-		// a monomial with fewer than two factors is padded with an all-ones table (sum of v = sum of v * 1)
-		bool need_ones = false;
+		// A monomial with fewer than two factors is padded with an all-ones table (sum of v = sum of v * 1), and a
+		// two-factor job one of whose factors is the same at both points (the indicator, the ones) gets an all-zeros
+		// table as that factor's partner, (f + 0) = f: it then has the shape of the bivariate round evaluation and runs on
+		// the matrix cores instead of the generic product-sum kernel.
+		bool need_tables = false;
 		for (const auto &j : jobs)
-			if (j.vars.size() + (j.eq ? 1 : 0) < 2) need_ones = true;
-		if (need_ones) {
+			if (j.vars.size() + (j.eq ? 1 : 0) <= 2 && (j.eq || j.vars.size() < 2)) need_tables = true;
+		if (need_tables) {
 			if (!scr) {
-				scr = (char *)bn::ctx_scratch(ctx, (1 + half) * sizeof(f128));
+				scr = (char *)bn::ctx_scratch(ctx, (1 + full) * sizeof(f128));
 				if (!scr) return bn::fail(BN_ERR_ALLOC, "allocation error: allocator is out of memory (scratch)");
 			}
 			ones = scr + ((size_t)n_tr * full + 1) * sizeof(f128);
+			zeros = ones + half * sizeof(f128);
 			BN_HIP(bn::launch_fill(ctx->stream, ones, half, bn::f128_one()));
+			BN_HIP(hipMemsetAsync(zeros, 0, half * sizeof(f128), ctx->stream));
 		}
 	}
 	if (fast) {
@@ -235,6 +240,9 @@ int bn_hal_round_evals(bn_ctx *ctx, uint32_t order, uint32_t n_vars, const void 
 			}
 			if (jobs[j].eq) hi[k++] = jobs[j].eq; // (lo = NULL: the same factor at both evaluation points)
 			while (k < 2) hi[k++] = ones;
+			if (k == 2)
+				for (uint32_t f = 0; f < 2; f++)
+					if (!lo[f]) lo[f] = zeros;
 			BN_HIP(bn::launch_roundeval_product(ctx->stream, ctx->n_cu, hi, lo, k, half, d_acc + 32 + 2 * j, nullptr));
 		}
 		std::vector<f128> sums(2 * jobs.size());
