@@ -42,6 +42,7 @@ struct ntt_bs_tables {
 	uint32_t pat[32][32];  // [l][j]: c-dependent part of the twiddle planes of lower layer l
 	uint32_t rows[32][32]; // [l][bit]: basis value of bit `bit` of the block index i >> (l+1)
 	uint32_t tconst[32];   // [l]: coset contribution (uniform)
+	uint32_t sub8[32];     // [l]: 1 if every twiddle of lower layer l lies in GF(2^8) (planes 8..31 of T are zero)
 };
 
 typedef unsigned int u4v __attribute__((ext_vector_type(4)));
@@ -60,6 +61,28 @@ __device__ __forceinline__ void butterfly_planes(uint32_t (&U)[32], uint32_t (&V
 			V[j] ^= U[j];
 	}
 	bs_mul<5>(V, T, M);
+#pragma unroll
+	for (int j = 0; j < 32; j++) {
+		U[j] ^= M[j];
+		if (!INV) V[j] ^= U[j];
+	}
+}
+
+// The same butterfly when the twiddle lies in the subfield GF(2^8) = T_3 (only planes 0..7 of T can be set): a T_3
+// scalar acts on the four T_3 limbs of a T_5 element separately (binary_field.rs:361-393), so the product is four
+// 8-plane products (4 x 27 AND) instead of one 32-plane product (243 AND).
+template <bool INV>
+__device__ __forceinline__ void butterfly_planes_sub8(uint32_t (&U)[32], uint32_t (&V)[32], const uint32_t (&T)[32])
+{
+	uint32_t M[32];
+	if (INV) {
+#pragma unroll
+		for (int j = 0; j < 32; j++)
+			V[j] ^= U[j];
+	}
+#pragma unroll
+	for (int i = 0; i < 4; i++)
+		bs_mul<3>(V + 8 * i, T, M + 8 * i);
 #pragma unroll
 	for (int j = 0; j < 32; j++) {
 		U[j] ^= M[j];
@@ -269,7 +292,10 @@ __global__ __launch_bounds__(256, 2) void k_ntt_bs_pass(uint4 *__restrict__ bs, 
 #pragma unroll
 		for (int j = 0; j < 32; j++)
 			T[j] = tb->pat[l][j] ^ (uint32_t)__builtin_amdgcn_sbfe((int)tbase, j, 1);
-		butterfly_planes<INV>(U, V, T);
+		if (tb->sub8[l]) // (uniform)
+			butterfly_planes_sub8<INV>(U, V, T);
+		else
+			butterfly_planes<INV>(U, V, T);
 #pragma unroll
 		for (int k = 0; k < 8; k++) {
 			tile3[s_u * kSetQ + k] = u4v{U[4 * k], U[4 * k + 1], U[4 * k + 2], U[4 * k + 3]};
@@ -373,6 +399,11 @@ static hipError_t run_ntt_bs(hipStream_t s, void *data, const uint64_t *h_s_eval
 		for (uint32_t bit = 0; bit < NB - l - 1 && bit < 32; bit++)
 			tb.rows[l][bit] = host_twiddle(h_s_evals, log_domain, base + l, (uint64_t)1 << bit);
 		tb.tconst[l] = host_twiddle(h_s_evals, log_domain, base + l, coset << (L - 1 - l));
+		uint32_t any = tb.tconst[l];
+		for (uint32_t c = 0; c < 32; c++) any |= host_twiddle(h_s_evals, log_domain, base + l, (uint64_t)c << (NB - l - 1));
+		for (uint32_t bit = 0; bit < 32; bit++) any |= tb.rows[l][bit];
+		static const bool no_sub8 = getenv("BN_NTT_NO_SUB8") != nullptr;
+		tb.sub8[l] = (any < 256 && !no_sub8) ? 1u : 0u;
 	}
 	e = hipMemcpyAsync(d_tb, &tb, sizeof(tb), hipMemcpyHostToDevice, s);
 	if (e != hipSuccess) return e;
