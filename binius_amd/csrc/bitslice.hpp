@@ -32,6 +32,12 @@ __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c)
 	return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
 }
 
+// (a & b) ^ c in one v_bitop3_b32
+__device__ __forceinline__ uint32_t andxor(uint32_t a, uint32_t b, uint32_t c)
+{
+	return __builtin_amdgcn_bitop3_b32(a, b, c, 0x6A);
+}
+
 __device__ __forceinline__ void transpose32(uint32_t (&r)[32])
 {
 	// j = 16 and j = 8 move whole bytes: one v_perm_b32 per output (selector byte k picks byte k of
@@ -103,10 +109,26 @@ __device__ __forceinline__ void bs_mul(const uint32_t *a, const uint32_t *b, uin
 	if constexpr (K == 0) {
 		out[0] = a[0] & b[0];
 	} else if constexpr (K == 1) {
-		// GF(4): lo = a0b0 ^ a1b1 ; hi = (a0^a1)(b0^b1) ^ a0b0      (alpha_0 = 1)
-		uint32_t z0 = a[0] & b[0];
-		out[0] = (a[1] & b[1]) ^ z0;
-		out[1] = ((a[0] ^ a[1]) & (b[0] ^ b[1])) ^ z0;
+		// GF(4), alpha_0 = 1: lo = a0b0 ^ a1b1 ; hi = a0b1 ^ a1b0 ^ a1b1.  Schoolbook on the 3-input LUT: every
+		// monomial after the first is one (x & y) ^ acc, 4 ops against 5 for the Karatsuba form.
+		const uint32_t t = a[1] & b[1];
+		out[0] = andxor(a[0], b[0], t);
+		out[1] = andxor(a[1], b[0], andxor(a[0], b[1], t));
+	} else if constexpr (K == 2) {
+		// GF(16) = GF(4)[X]/(X^2 + X*X_0 + 1), written out over the bits: 19 ops against 24 for a Karatsuba level over
+		// three GF(4) products (the pre-additions disappear, the recombination rides in the and-xor chains).
+		//   z  = a_hi * b_hi                              (GF(4), 4 ops)
+		//   lo = a_lo * b_lo ^ z                          (chains seeded with z)
+		//   hi = a_lo * b_hi ^ a_hi * b_lo ^ z * X_0,     z * X_0 = (z1, z0 ^ z1)
+		const uint32_t t = a[3] & b[3];
+		const uint32_t z0 = andxor(a[2], b[2], t);
+		const uint32_t z1 = andxor(a[3], b[2], andxor(a[2], b[3], t));
+		out[0] = andxor(a[1], b[1], andxor(a[0], b[0], z0));
+		out[1] = andxor(a[1], b[1], andxor(a[1], b[0], andxor(a[0], b[1], z1)));
+		// a1b3 ^ a3b1 is common to both high bits
+		const uint32_t s0 = andxor(a[3], b[1], a[1] & b[3]) ^ z1;
+		out[2] = andxor(a[2], b[0], andxor(a[0], b[2], s0));
+		out[3] = andxor(a[3], b[0], andxor(a[2], b[1], andxor(a[1], b[2], andxor(a[0], b[3], s0 ^ z0))));
 	} else {
 		constexpr int H = 1 << (K - 1);
 		uint32_t z0[H], z2[H], z1[H], sa[H], sb[H], za[H];
