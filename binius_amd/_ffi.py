@@ -157,6 +157,7 @@ def lib():
         "bn_scalar_invert": [PF, PF],
         "bn_prof_begin": [vp],
         "bn_prof_end": [vp, C.POINTER(C.c_double), C.POINTER(u64)],
+        "bn_arm_counters": [vp, C.POINTER(u64)],
         "bn_xor_reduce": [vp, vp, u32, u32, PF],
         "bn_host_scratch": [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)],
         "bn_merkle_build": [vp, vp, u64, u64, vp],
@@ -182,7 +183,7 @@ ABI_SYMBOLS = [
     "bn_extrapolate_line", "bn_extrapolate_line_batch", "bn_tensor_expand", "bn_inner_product", "bn_fold_left", "bn_fold_right", "bn_fri_fold",
     "bn_compute_composite", "bn_pairwise_product_reduce", "bn_log_chunks_range", "bn_pick_log_chunks",
     "bn_kernel_launch", "bn_ntt_forward", "bn_ntt_inverse", "bn_ntt_s_evals", "bn_scalar_mul", "bn_scalar_invert",
-    "bn_timer_begin", "bn_timer_end_ms", "bn_prof_begin", "bn_prof_end", "bn_xor_reduce", "bn_host_scratch",
+    "bn_timer_begin", "bn_timer_end_ms", "bn_prof_begin", "bn_prof_end", "bn_arm_counters", "bn_xor_reduce", "bn_host_scratch",
     "bn_merkle_build", "bn_groestl256_leaves", "bn_groestl256_compress_layer", "bn_gather_d2h",
     "bn_hal_round_evals", "bn_hal_fold_multilinear", "bn_extrapolate_line_batch_scaled",
 ]
@@ -457,6 +458,12 @@ class Context:
         cnt = (C.c_uint64 * len(self.PROF_CLASSES))()
         _check(lib().bn_prof_end(self._h, ms, cnt))
         return {k: (ms[i], int(cnt[i])) for i, k in enumerate(self.PROF_CLASSES)}
+
+    def arm_counters(self):
+        """Armed rounds (csrc/arm.hpp): {hits, cancels, expired} since the context was created."""
+        c = (C.c_uint64 * 3)()
+        _check(lib().bn_arm_counters(self._h, c))
+        return {"hits": int(c[0]), "cancels": int(c[1]), "expired": int(c[2])}
 
     # ---- ComputeLayer
     def copy_h2d(self, src, dst):

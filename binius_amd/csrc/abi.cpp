@@ -64,6 +64,16 @@ int tail_cancel(bn_ctx *ctx)
 	return BN_OK;
 }
 
+// An armed kernel that will not be used: tell it to leave.  Nothing to wait for -- it exits without having touched
+// anything, and whatever the caller enqueues next is ordered behind it by the stream.
+void arm_cancel(bn_ctx *ctx)
+{
+	if (!ctx->arm.active) return;
+	ctx->arm.active = false;
+	ctx->arm_cancels++;
+	__atomic_store_n(arm_cmd(ctx), (ctx->arm.id << 2) | 2ull, __ATOMIC_RELEASE);
+}
+
 std::vector<unsigned char> recipe_bytes(const bn::fin_args &a)
 {
 	bn::fin_args r;
@@ -97,6 +107,7 @@ int flush_pending(bn_ctx *ctx, bool keep_tail, bool publish_tiny)
 		int rc = tail_cancel(ctx);
 		if (rc) return rc;
 	}
+	if (!keep_tail) arm_cancel(ctx);
 	if (!ctx->pend_copies.empty()) {
 		int rc = flush_copies(ctx);
 		if (rc) return rc;
@@ -208,6 +219,9 @@ int bn_ctx_create(int device, uint64_t arena_elems, bn_ctx **out)
 	ctx->s_clean = true;
 	BN_HIP(hipMalloc((void **)&ctx->d_ticket, sizeof(unsigned)));
 	BN_HIP(hipMemset(ctx->d_ticket, 0, sizeof(unsigned)));
+	BN_HIP(hipMalloc((void **)&ctx->d_arm_relay, 8 * sizeof(uint64_t)));
+	BN_HIP(hipMemset(ctx->d_arm_relay, 0, 8 * sizeof(uint64_t)));
+	if (const char *a = getenv("BN_ARM")) ctx->arm_enabled = atoi(a) != 0;
 	BN_HIP(hipMalloc((void **)&ctx->d_mul8, 65536));
 	BN_HIP(bn::launch_build_mul8(ctx->stream, ctx->d_mul8));
 	if (arena_elems) {
@@ -233,8 +247,10 @@ int bn_ctx_destroy(bn_ctx *ctx)
 	if (!ctx)
 		return BN_OK;
 	hipSetDevice(ctx->device);
+	arm_cancel(ctx);
 	if (ctx->stream)
 		hipStreamSynchronize(ctx->stream);
+	if (ctx->d_arm_relay) hipFree(ctx->d_arm_relay);
 	if (ctx->ntt_cache) {
 		bn::ntt_bs_cache *nc = (bn::ntt_bs_cache *)ctx->ntt_cache;
 		if (nc->d_tables) hipFree(nc->d_tables);
@@ -594,6 +610,17 @@ int bn_extrapolate_line_batch_scaled(bn_ctx *ctx, void *const *d_evals_0, const 
 			};
 			keep_tail = (continues(0, 0) && continues(1, 1)) || (continues(0, 1) && continues(1, 0));
 		}
+		// ... and so does an armed round (same order of the two arrays, same scale mask; z and the scale are its input)
+		if (ctx->arm.active) {
+			const bn_ctx::arm_state &am = ctx->arm;
+			bool same = count == 2 && 2 * n == am.n_in && scale_mask == am.scale_mask;
+			for (uint32_t j = 0; j < 2 && same; j++)
+				same = d_evals_0[j] == am.out[j] && src0[j] == am.x0[j] && d_evals_1[j] == am.x1[j];
+			if (same)
+				keep_tail = true;
+			else
+				arm_cancel(ctx);
+		}
 		int rc_ = flush_pending(ctx, keep_tail);
 		if (rc_) return rc_;
 	}
@@ -611,6 +638,16 @@ int bn_extrapolate_line_batch_scaled(bn_ctx *ctx, void *const *d_evals_0, const 
 		ctx->pend.src0[i] = src0[i];
 	}
 	if (!ctx->lazy_fold) BN_FLUSH(ctx);
+	return BN_OK;
+}
+
+int bn_arm_counters(bn_ctx *ctx, uint64_t *counters)
+{
+	BN_REQUIRE(ctx && counters, "null argument");
+	BN_ENTER(ctx);
+	counters[BN_ARM_HITS] = ctx->arm_hits;
+	counters[BN_ARM_CANCELS] = ctx->arm_cancels;
+	counters[BN_ARM_EXPIRED] = ctx->arm_expired;
 	return BN_OK;
 }
 

@@ -61,6 +61,10 @@ std::vector<unsigned char> recipe_bytes(const bn::fin_args &a);
 // resident tail kernel: command / status words in the pinned mailbox
 inline volatile uint64_t *tail_cmd(bn_ctx *ctx) { return &ctx->h_mail[80].lo; }
 inline volatile uint64_t *tail_status(bn_ctx *ctx) { return &ctx->h_mail[82].lo; }
+// armed round: command block in the pinned mailbox (layout: arm.hpp)
+inline volatile uint64_t *arm_cmd(bn_ctx *ctx) { return &ctx->h_mail[84].lo; }
+inline volatile uint64_t *arm_status(bn_ctx *ctx) { return &ctx->h_mail[87].lo; }
+void arm_cancel(bn_ctx *ctx);
 // ---- small helpers shared by the op entry points (abi.cpp)
 int publish_result(bn_ctx *ctx, uint32_t n_groups, bn_f128 *h_out);
 int upload_ptrs(bn_ctx *ctx, const void *const *ptrs, uint32_t n, const void ***d_ptrs);

@@ -3,6 +3,7 @@
 // fused fold + evaluation kernels (matrix-core or 9-lane), the resident tail and the generic forms, and
 // finalizes on the device.  Also log_chunks_range / pick_log_chunks and the device XOR of gathered partials.
 #include "abi_common.hpp"
+#include "arm.hpp"
 
 extern "C" {
 
@@ -344,6 +345,95 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 											rc = tail_cancel(ctx);
 											if (rc) return rc;
 										}
+										// arm the kernel of the round after (fa_, n_in_, seq_) behind whatever runs that round
+										// (arm.hpp): same arrays in place, half the size, same recipe, next sequence number
+										auto arm_next = [&](const bn::foldeval_args &fa_, uint64_t n_in_, const bn::fin_fuse &fz_) {
+											const uint64_t n_next = n_in_ >> 1;
+											if (!ctx->arm_enabled || ctx->prof_on || !h_out || d_out || n_next < 4 || (n_next & 3) ||
+											    bn::mfma_applies(ctx->n_cu, n_next >> 2) || ctx->tail_max_n_in)
+												return;
+											bn_ctx::arm_state &am = ctx->arm;
+											bn::foldeval_args fn{};
+											for (uint32_t j = 0; j < 2; j++) {
+												fn.x0[j] = fa_.out[j];
+												fn.x1[j] = (const char *)fa_.out[j] + (n_next >> 1) * sizeof(f128);
+												fn.out[j] = fa_.out[j];
+											}
+											fn.scale_mask = fa_.scale_mask;
+											bn::fin_fuse fzn = fz_;
+											fzn.args.seq = fz_.args.seq + 1;
+											bn::arm_args aa{};
+											aa.h_cmd = (const uint64_t *)&ctx->d_mail[84].lo;
+											aa.h_status = (uint64_t *)&ctx->d_mail[87].lo;
+											aa.d_relay = ctx->d_arm_relay;
+											aa.id = ++ctx->arm_counter;
+											if (bn::launch_foldeval9(s, ctx->n_cu, fn, n_next, f128{0, 0}, d_S + slot, &fzn, &aa) != hipSuccess) {
+												(void)hipGetLastError();
+												return;
+											}
+											am.active = true;
+											am.id = aa.id;
+											am.n_in = n_next;
+											for (uint32_t j = 0; j < 2; j++) {
+												am.x0[j] = fn.x0[j];
+												am.x1[j] = fn.x1[j];
+												am.out[j] = fn.out[j];
+											}
+											am.scale_mask = fn.scale_mask;
+											am.seq = fzn.args.seq;
+											am.d_sums = d_S + slot;
+											am.recipe = recipe_bytes(fzn.args);
+										};
+										// (a0) the kernel of this round is already on the device, armed: hand it z
+										if (ctx->arm.active) {
+											bn_ctx::arm_state &am = ctx->arm;
+											bool same = h_out && !d_out && n_in == am.n_in && fa.scale_mask == am.scale_mask && fz.args.seq == am.seq &&
+											            d_S + slot == am.d_sums;
+											for (uint32_t j = 0; j < 2 && same; j++)
+												same = fa.x0[j] == am.x0[j] && fa.x1[j] == am.x1[j] && fa.out[j] == am.out[j];
+											if (same) same = recipe_bytes(fz.args) == am.recipe;
+											if (!same) {
+												arm_cancel(ctx);
+											} else {
+												const uint64_t id = am.id;
+												am.active = false;
+												ctx->h_mail[85].lo = pf.z.lo;
+												ctx->h_mail[85].hi = pf.z.hi;
+												ctx->h_mail[86].lo = pf.hi_scale.lo;
+												ctx->h_mail[86].hi = pf.hi_scale.hi;
+												__atomic_store_n(arm_cmd(ctx), (id << 2) | 1ull, __ATOMIC_RELEASE);
+												arm_next(fa, n_in, fz); // the round after this one queues up while this one runs
+												volatile uint64_t *seqw = &ctx->h_mail[64].lo;
+												bool got = false;
+												for (uint64_t spins = 0;; spins++) {
+													if (__atomic_load_n(seqw, __ATOMIC_ACQUIRE) == fz.args.seq) { got = true; break; }
+													if ((spins & 63) == 63 && __atomic_load_n(arm_status(ctx), __ATOMIC_ACQUIRE) == id) {
+														// the kernel gave up waiting (bounded spin) -- did it answer first?
+														got = __atomic_load_n(seqw, __ATOMIC_ACQUIRE) == fz.args.seq;
+														break;
+													}
+													if (spins > (1ull << 26)) {
+														arm_cancel(ctx);
+														BN_HIP(hipStreamSynchronize(s));
+														return bn::fail(BN_ERR_DEVICE, "device error: armed round kernel stopped answering");
+													}
+												}
+												if (got) {
+													for (uint32_t r = 0; r < n_ret; r++) {
+														h_out[r].lo = __atomic_load_n(&ctx->h_mail[r].lo, __ATOMIC_RELAXED);
+														h_out[r].hi = __atomic_load_n(&ctx->h_mail[r].hi, __ATOMIC_RELAXED);
+													}
+													ctx->pend.active = false;
+													ctx->s_clean = true;
+													ctx->arm_hits++;
+													return BN_OK;
+												}
+												// it left without running the round: the one queued behind it must leave too, then
+												// this round runs the normal way
+												ctx->arm_expired++;
+												arm_cancel(ctx);
+											}
+										}
 										// (a) a resident tail kernel is parked for exactly this round: hand it z
 										if (ctx->tail.active) {
 											bn_ctx::tail_state &tl = ctx->tail;
@@ -416,7 +506,10 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 											prof_scope ps(ctx, mfma ? BN_PROF_FOLD_EVAL_MFMA : (bn::foldeval9_is_small(ctx->n_cu, n_in) ? BN_PROF_FOLD_EVAL_SMALL : BN_PROF_FOLD_EVAL));
 											fe = mfma ? bn::launch_foldeval_mfma(s, ctx->n_cu, fa, n_in, pf.z, d_S + slot, &fz)
 											          : bn::launch_foldeval9(s, ctx->n_cu, fa, n_in, pf.z, d_S + slot, &fz);
-											if (fe == hipSuccess) ctx->pend.active = false;
+											if (fe == hipSuccess) {
+												ctx->pend.active = false;
+												arm_next(fa, n_in, fz);
+											}
 										}
 									} else if (ctx->tail.active) {
 										rc = tail_cancel(ctx);

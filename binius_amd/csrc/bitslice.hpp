@@ -103,18 +103,27 @@ __device__ __forceinline__ void bs_mul_alpha(const uint32_t *a, uint32_t *out)
 }
 
 // out = a * b, level K (2^K planes each).  out must not alias a or b.
-template <int K>
+// LUT = true writes the two lowest levels out on the 3-input LUT (880 instructions at K = 5); LUT = false keeps the
+// Karatsuba recursion down to GF(4) (1015 instructions, but shorter live ranges: the and-xor chains of the LUT form
+// keep all eight inputs of a GF(16) product alive to the end, which is what tips the fused fold + evaluate kernels of
+// kernels_foldeval9.hip -- already at the 256-register limit -- into scratch: 0 -> 242 spilled registers).
+template <int K, bool LUT = true>
 __device__ __forceinline__ void bs_mul(const uint32_t *a, const uint32_t *b, uint32_t *out)
 {
 	if constexpr (K == 0) {
 		out[0] = a[0] & b[0];
+	} else if constexpr (K == 1 && !LUT) {
+		// GF(4): lo = a0b0 ^ a1b1 ; hi = (a0^a1)(b0^b1) ^ a0b0      (alpha_0 = 1)
+		uint32_t z0 = a[0] & b[0];
+		out[0] = (a[1] & b[1]) ^ z0;
+		out[1] = ((a[0] ^ a[1]) & (b[0] ^ b[1])) ^ z0;
 	} else if constexpr (K == 1) {
 		// GF(4), alpha_0 = 1: lo = a0b0 ^ a1b1 ; hi = a0b1 ^ a1b0 ^ a1b1.  Schoolbook on the 3-input LUT: every
 		// monomial after the first is one (x & y) ^ acc, 4 ops against 5 for the Karatsuba form.
 		const uint32_t t = a[1] & b[1];
 		out[0] = andxor(a[0], b[0], t);
 		out[1] = andxor(a[1], b[0], andxor(a[0], b[1], t));
-	} else if constexpr (K == 2) {
+	} else if constexpr (K == 2 && LUT) {
 		// GF(16) = GF(4)[X]/(X^2 + X*X_0 + 1), written out over the bits: 19 ops against 24 for a Karatsuba level over
 		// three GF(4) products (the pre-additions disappear, the recombination rides in the and-xor chains).
 		//   z  = a_hi * b_hi                              (GF(4), 4 ops)
@@ -132,14 +141,14 @@ __device__ __forceinline__ void bs_mul(const uint32_t *a, const uint32_t *b, uin
 	} else {
 		constexpr int H = 1 << (K - 1);
 		uint32_t z0[H], z2[H], z1[H], sa[H], sb[H], za[H];
-		bs_mul<K - 1>(a, b, z0);
-		bs_mul<K - 1>(a + H, b + H, z2);
+		bs_mul<K - 1, LUT>(a, b, z0);
+		bs_mul<K - 1, LUT>(a + H, b + H, z2);
 #pragma unroll
 		for (int i = 0; i < H; i++) {
 			sa[i] = a[i] ^ a[H + i];
 			sb[i] = b[i] ^ b[H + i];
 		}
-		bs_mul<K - 1>(sa, sb, z1);
+		bs_mul<K - 1, LUT>(sa, sb, z1);
 		bs_mul_alpha<K - 1>(z2, za);
 #pragma unroll
 		for (int i = 0; i < H; i++) {

@@ -11,6 +11,19 @@
 #include "gf128.hpp"
 #include "internal.hpp"
 
+// tools/small_round_phases.hip defines BN_PHASE_TS: thread 0 of workgroup 0 stamps the 100 MHz wall clock at the
+// phase boundaries of a small round (never defined in the library build)
+#ifdef BN_PHASE_TS
+__device__ uint64_t bn_phase_ts[16];
+#define BN_TS(i)                                                             \
+	do {                                                                     \
+		if (blockIdx.x == 0 && threadIdx.x == 0) ::bn_phase_ts[i] = wall_clock64(); \
+	} while (0)
+#else
+#define BN_TS(i)
+#endif
+#define BN_FTS(i) BN_TS(i)
+
 namespace bn {
 
 __device__ __forceinline__ uint32_t fin_wave_xor(uint32_t v)
@@ -50,6 +63,7 @@ __device__ __forceinline__ void finalize_body(const fin_args &a, f128 *S, f128 *
 		fin_S[tid] = s;
 	}
 	__syncthreads();
+	BN_FTS(9);
 	const unsigned grp = tid >> 7, l128 = tid & 127;
 	for (uint32_t t0 = 0; t0 < a.n_terms; t0 += n_groups) {
 		const uint32_t t = t0 + grp;
@@ -84,6 +98,7 @@ __device__ __forceinline__ void finalize_body(const fin_args &a, f128 *S, f128 *
 		}
 		__syncthreads();
 	}
+	BN_FTS(10);
 	if (tid < a.n_ret) {
 		const f128 v = fin_values[a.ret_ids[tid]];
 		rets[tid] = v;
@@ -98,9 +113,162 @@ __device__ __forceinline__ void finalize_body(const fin_args &a, f128 *S, f128 *
 		__hip_atomic_store(&S[tid].lo, (uint64_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		__hip_atomic_store(&S[tid].hi, (uint64_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	}
+	BN_FTS(11);
 	if (seq) {
 		// n_ret <= 8: the value stores above were issued by lanes of wave 0; the release below makes
 		// wave 0 drain them (vmcnt) and write them through before the sequence word
+		if (tid == 0)
+			__hip_atomic_store(&mail[64].lo, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+	}
+}
+
+// ---- finalize arguments staged in LDS -----------------------------------------------------------------------------
+// fin_fuse travels as a kernel argument (1.3 KiB).  Read where it is needed -- at the very end of the kernel -- every
+// field is a fresh round trip to the kernarg segment, and they depend on one another (n_terms -> terms[t].slot ->
+// S[slot] -> terms[t].coeff -> ...): ~2.3 us of a 13 us small round (tools/small_round_phases.hip).  The latency-shaped
+// kernels therefore issue all those loads at kernel entry (fin_prefetch), park them in LDS once the first barrier has
+// passed anyway (fin_commit) and finalize from there (finalize_cached).
+struct fin_cache {
+	f128 coeff[kFinMaxTerms];
+	f128 init[kFinMaxValues];
+	uint32_t slot[kFinMaxTerms], value[kFinMaxTerms];
+	uint32_t ret_ids[kFinMaxRets];
+	uint32_t n_terms, n_values, n_ret, n_slots;
+	uint32_t all_one; // every batch coefficient is 1: value = init ^ XOR of its sums, no multiplication
+	f128 *S, *rets, *mail;
+	unsigned *counter;
+};
+struct fin_pref {
+	f128 coeff, init;
+	uint32_t slot, value, ret_id;
+};
+
+// every thread of the workgroup (>= 64 threads); only the first kFinMaxTerms lanes load
+__device__ __forceinline__ fin_pref fin_prefetch(const fin_fuse &fz)
+{
+	fin_pref r{};
+	const unsigned tid = threadIdx.x;
+	if (tid < kFinMaxTerms) {
+		r.coeff = fz.args.terms[tid].coeff;
+		r.slot = fz.args.terms[tid].slot;
+		r.value = fz.args.terms[tid].value;
+		r.init = fz.args.init[tid & (kFinMaxValues - 1)];
+		r.ret_id = fz.args.ret_ids[tid & (kFinMaxRets - 1)];
+	}
+	return r;
+}
+
+// a workgroup barrier must separate this from finalize_cached (every kernel has several)
+__device__ __forceinline__ void fin_commit(const fin_fuse &fz, const fin_pref &r, fin_cache &c)
+{
+	const unsigned tid = threadIdx.x;
+	if (tid < 64) {
+		const uint32_t n_terms = fz.args.n_terms;
+		const bool one = tid >= n_terms || (r.coeff.lo == 1 && r.coeff.hi == 0);
+		const bool all = __all(one);
+		if (tid < kFinMaxTerms) {
+			c.coeff[tid] = r.coeff;
+			c.slot[tid] = r.slot;
+			c.value[tid] = r.value;
+		}
+		if (tid < kFinMaxValues) c.init[tid] = r.init;
+		if (tid < kFinMaxRets) c.ret_ids[tid] = r.ret_id;
+		if (tid == 0) {
+			c.n_terms = n_terms;
+			c.n_values = fz.args.n_values;
+			c.n_ret = fz.args.n_ret;
+			c.n_slots = fz.args.n_slots;
+			c.all_one = all ? 1u : 0u;
+			c.S = fz.S;
+			c.rets = fz.rets;
+			c.mail = fz.mail;
+			c.counter = fz.counter;
+		}
+	}
+}
+
+// finalize_body with every argument taken from LDS.  Same contract: all threads of a workgroup of >= 128 threads.
+__device__ __forceinline__ void finalize_cached(const fin_cache &c, uint64_t seq, const f128 *S_local = nullptr)
+{
+	__shared__ f128 fc_S[kFinMaxTerms];
+	__shared__ uint64_t fc_red[4][2][2];
+	__shared__ f128 fc_values[kFinMaxValues];
+	const unsigned tid = threadIdx.x;
+	const uint32_t n_terms = c.n_terms, n_values = c.n_values, n_ret = c.n_ret;
+	f128 *S = c.S, *rets = c.rets, *mail = c.mail;
+	if (tid < n_terms) {
+		const uint32_t slot = c.slot[tid];
+		f128 s;
+		if (S_local) {
+			s = S_local[slot];
+		} else {
+			s.lo = __hip_atomic_load(&S[slot].lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			s.hi = __hip_atomic_load(&S[slot].hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		fc_S[tid] = s;
+	}
+	__syncthreads();
+	BN_FTS(9);
+	if (c.all_one) {
+		// the single-claim path: no batch coefficient to multiply by
+		if (tid < n_values) {
+			f128 v = c.init[tid];
+			for (uint32_t t = 0; t < n_terms; t++)
+				if (c.value[t] == tid) v ^= fc_S[t];
+			fc_values[tid] = v;
+		}
+		__syncthreads();
+	} else {
+		const unsigned n_groups = blockDim.x >= 512 ? 4u : (blockDim.x >= 256 ? 2u : 1u);
+		if (tid < n_values) fc_values[tid] = c.init[tid];
+		const unsigned grp = tid >> 7, l128 = tid & 127;
+		for (uint32_t t0 = 0; t0 < n_terms; t0 += n_groups) {
+			const uint32_t t = t0 + grp;
+			f128 cf = f128_zero();
+			if (grp < n_groups && t < n_terms) {
+				const f128 s = fc_S[t];
+				const f128 coeff = c.coeff[t];
+				if (coeff.lo == 1 && coeff.hi == 0) {
+					if (l128 == 0) cf = s;
+				} else {
+					const uint64_t word = l128 < 64 ? s.lo : s.hi;
+					if ((word >> (l128 & 63)) & 1) cf = mul_basis(coeff, l128);
+				}
+			}
+			uint32_t w[4] = {(uint32_t)cf.lo, (uint32_t)(cf.lo >> 32), (uint32_t)cf.hi, (uint32_t)(cf.hi >> 32)};
+#pragma unroll
+			for (int q = 0; q < 4; q++)
+				w[q] = fin_wave_xor(w[q]);
+			if (grp < n_groups && (tid & 63) == 0) {
+				fc_red[grp][l128 >> 6][0] = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
+				fc_red[grp][l128 >> 6][1] = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
+			}
+			__syncthreads();
+			if (tid == 0) {
+				for (unsigned gq = 0; gq < n_groups && t0 + gq < n_terms; gq++) {
+					const uint32_t v = c.value[t0 + gq];
+					fc_values[v].lo ^= fc_red[gq][0][0] ^ fc_red[gq][1][0];
+					fc_values[v].hi ^= fc_red[gq][0][1] ^ fc_red[gq][1][1];
+				}
+			}
+			__syncthreads();
+		}
+	}
+	BN_FTS(10);
+	if (tid < n_ret) {
+		const f128 v = fc_values[c.ret_ids[tid]];
+		rets[tid] = v;
+		if (seq) {
+			__hip_atomic_store(&mail[tid].lo, v.lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			__hip_atomic_store(&mail[tid].hi, v.hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		}
+	}
+	if (!S_local && tid < c.n_slots) {
+		__hip_atomic_store(&S[tid].lo, (uint64_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		__hip_atomic_store(&S[tid].hi, (uint64_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
+	BN_FTS(11);
+	if (seq) {
 		if (tid == 0)
 			__hip_atomic_store(&mail[64].lo, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 	}

@@ -269,7 +269,8 @@ __device__ __forceinline__ f128 kara64(uint64_t Z0, uint64_t Z2, uint64_t Z1p)
 // global accumulators and, if asked, the last workgroup runs the fused finalize -- the same protocol as
 // re9::tail (device-scope atomics only, no fences).
 // C/D layout of the 32x32 MFMA: column n = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
-__device__ __forceinline__ void tail(const v16i (&acc)[kAccTiles], unsigned wave, unsigned lane, f128 *out, const fin_fuse &fz, uint64_t seq)
+__device__ __forceinline__ void tail(const v16i (&acc)[kAccTiles], unsigned wave, unsigned lane, f128 *out, const fin_fuse &fz, uint64_t seq,
+                                     const fin_cache *fc = nullptr)
 {
 	__shared__ uint32_t Gc[4][kAccTiles][64]; // [wave = (pr, h)][tile = 2 s + i][lane]: 16 parity bits
 	__shared__ uint64_t z3[2][3];
@@ -303,9 +304,15 @@ __device__ __forceinline__ void tail(const v16i (&acc)[kAccTiles], unsigned wave
 	if (tid < 2)
 		s_loc[tid] = kara64(z3[tid][0], z3[tid][1], z3[tid][2]);
 	__syncthreads();
-	if (fz.counter && gridDim.x == 1 && out == fz.S) {
+	// fc: the finalize arguments were staged in LDS at kernel entry (finalize.hpp)
+	unsigned *const counter = fc ? fc->counter : fz.counter;
+	f128 *const S = fc ? fc->S : fz.S;
+	if (counter && gridDim.x == 1 && out == S) {
 		// single workgroup: the sums never leave the chip -- finalize straight from LDS
-		finalize_body(fz.args, fz.S, fz.rets, fz.mail, seq, s_loc);
+		if (fc)
+			finalize_cached(*fc, seq, s_loc);
+		else
+			finalize_body(fz.args, fz.S, fz.rets, fz.mail, seq, s_loc);
 		return;
 	}
 	if (tid < 4) {
@@ -313,19 +320,22 @@ __device__ __forceinline__ void tail(const v16i (&acc)[kAccTiles], unsigned wave
 		if (v)
 			atomicXor(reinterpret_cast<unsigned long long *>(out) + tid, (unsigned long long)v);
 	}
-	if (fz.counter) {
+	if (counter) {
 		__shared__ unsigned is_last;
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		__syncthreads();
 		if (tid == 0) {
-			const unsigned t = atomicAdd(fz.counter, 1u);
+			const unsigned t = atomicAdd(counter, 1u);
 			is_last = (t == gridDim.x - 1) ? 1u : 0u;
 		}
 		__syncthreads();
 		if (is_last) {
-			finalize_body(fz.args, fz.S, fz.rets, fz.mail, seq);
+			if (fc)
+				finalize_cached(*fc, seq);
+			else
+				finalize_body(fz.args, fz.S, fz.rets, fz.mail, seq);
 			if (tid == 0)
-				__hip_atomic_store(fz.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				__hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
 	}
 }

@@ -98,6 +98,23 @@ struct bn_ctx {
 	} tail;
 	uint64_t tail_counter = 0;
 	uint64_t tail_max_n_in = 0; // BN_TAIL_MAX_LOG2=3..12 enables the resident tail (off by default: see DESIGN.md)
+	// armed round (arm.hpp): the kernel of the NEXT small round, enqueued behind the current one and waiting for its
+	// challenge on the command block h_mail[84..87]
+	struct arm_state {
+		bool active = false;
+		uint64_t id = 0;
+		uint64_t n_in = 0;
+		const void *x0[2] = {}, *x1[2] = {};
+		void *out[2] = {};
+		uint32_t scale_mask = 0;
+		uint64_t seq = 0;      // the mailbox sequence number it will publish
+		bn::f128 *d_sums = nullptr; // its accumulator slots
+		std::vector<unsigned char> recipe;
+	} arm;
+	uint64_t arm_counter = 0;
+	uint64_t *d_arm_relay = nullptr; // device memory, 8 words
+	bool arm_enabled = true;         // BN_ARM=0 turns the armed rounds off
+	uint64_t arm_hits = 0, arm_cancels = 0, arm_expired = 0;
 };
 
 namespace bn {
@@ -188,7 +205,9 @@ struct foldeval_args {
 	f128 hi_scale;
 };
 bool foldeval9_is_small(int n_cu, uint64_t n_in);
-hipError_t launch_foldeval9(hipStream_t s, int n_cu, const foldeval_args &fa, uint64_t n_in, f128 z, f128 *d_out, const fin_fuse *fuse);
+struct arm_args; // arm.hpp: non-null = an armed launch (z and hi_scale arrive through the command block)
+hipError_t launch_foldeval9(hipStream_t s, int n_cu, const foldeval_args &fa, uint64_t n_in, f128 z, f128 *d_out, const fin_fuse *fuse,
+                            const arm_args *armed = nullptr);
 hipError_t launch_foldeval_tail(hipStream_t s, const foldeval_args &fa, uint64_t n_in, f128 z, f128 *d_out, const fin_fuse &fz,
                                 const uint64_t *d_cmd, uint64_t *d_status, uint64_t tail_id);
 hipError_t launch_roundeval9_eq(hipStream_t s, int n_cu, const void *a_hi, const void *a_lo, const void *b_hi, const void *b_lo,

@@ -23,6 +23,7 @@
 
 #include <type_traits>
 
+#include "arm.hpp"
 #include "ctable.hpp"
 #include "re9.hpp"
 
@@ -118,8 +119,9 @@ __device__ __forceinline__ void eval_staged(uint4 *wt, const eval_layout &lay, u
 	}
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 	__builtin_amdgcn_wave_barrier();
+	BN_TS(4);
 	uint32_t P[32];
-	bs_mul<5>(A, B, P);
+	bs_mul<5, false>(A, B, P); // the Karatsuba form: see bitslice.hpp (register pressure)
 #pragma unroll
 	for (int p = 0; p < 32; p++)
 		acc[p] ^= P[p];
@@ -204,23 +206,32 @@ __device__ __forceinline__ void foldeval_wave(const foldeval_args &fa, uint64_t 
 }
 
 template <int WAVES, bool SCALED = false>
-__global__ __launch_bounds__(256, WAVES) void k_foldeval9(foldeval_args fa, uint64_t n_in, f128 z, f128 *out, fin_fuse fz)
+__global__ __launch_bounds__(256, WAVES) void k_foldeval9(foldeval_args fa, uint64_t n_in, f128 z, f128 *out, fin_fuse fz, arm_args arm)
 {
 	__shared__ uint4 tile[4][kWaveQ];
 	__shared__ ctable_smem tab;
 	__shared__ ctable_opt<SCALED> tab_hs;
+	__shared__ fin_cache fcache;
+	const uint64_t seq = fz.args.seq;
+	const fin_pref fpre = fin_prefetch(fz); // the finalize arguments wait in LDS for the tail (finalize.hpp)
+	if (arm.h_cmd) { // (uniform) armed launch: the challenge arrives through the command block (arm.hpp)
+		f128 hs_in;
+		if (!arm_wait(arm, z, hs_in)) return;
+		fa.hi_scale = hs_in;
+	}
 	const ctable_smem *hs = nullptr;
 	if constexpr (SCALED) {
 		ctable_build(tab_hs.get(), fa.hi_scale);
 		hs = &tab_hs.get();
 	}
 	ctable_build(tab, z);
+	fin_commit(fz, fpre, fcache);
 	const unsigned lane = threadIdx.x & 63;
 	const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const unsigned g = lane / 9, c = lane - g * 9;
 	uint32_t acc[32];
 	foldeval_wave(fa, n_in, tab, tile[wave], (uint64_t)blockIdx.x * 4 + wave, (uint64_t)gridDim.x * 4, acc, hs);
-	re9::tail<4>(acc, lane < 63, c, g, wave, lane, out, fz, fz.args.seq);
+	re9::tail<4>(acc, lane < 63, c, g, wave, lane, out, fz, seq, &fcache);
 }
 
 // Latency-shaped variant for small rounds (every batch gets its own workgroup: n_batches <= 2 per CU).
@@ -229,11 +240,14 @@ __global__ __launch_bounds__(256, WAVES) void k_foldeval9(foldeval_args fa, uint
 // quadrant each (2 slots), with the loads in flight while the nibble tables are built, and wave 0
 // evaluates the batch.
 template <bool SCALED>
-__global__ __launch_bounds__(256, 2) void k_foldeval9_small(foldeval_args fa, uint64_t n_in, f128 z, f128 *out, fin_fuse fz)
+__global__ __launch_bounds__(256, 2) void k_foldeval9_small(foldeval_args fa, uint64_t n_in, f128 z, f128 *out, fin_fuse fz, arm_args arm)
 {
 	__shared__ uint4 tile[kWaveQ];
 	__shared__ ctable_smem tab;
 	__shared__ ctable_opt<SCALED> tab_hs;
+	__shared__ fin_cache fcache;
+	BN_TS(0);
+	const uint64_t seq = fz.args.seq;
 	const unsigned lane = threadIdx.x & 63;
 	const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const unsigned g = lane / 9, c = lane - g * 9;
@@ -256,8 +270,16 @@ __global__ __launch_bounds__(256, 2) void k_foldeval9_small(foldeval_args fa, ui
 		x0[sub] = v0;
 		x1[sub] = v1;
 	}
+	const fin_pref fpre = fin_prefetch(fz); // the finalize arguments: in flight with the data
+	if (arm.h_cmd) { // (uniform) armed launch: data and arguments are on their way, the challenge is what is missing (arm.hpp)
+		f128 hs_in;
+		if (!arm_wait(arm, z, hs_in)) return;
+		fa.hi_scale = hs_in;
+	}
 	if constexpr (SCALED) ctable_build(tab_hs.get(), fa.hi_scale);
+	BN_TS(1);
 	ctable_build(tab, z); // the loads above are in flight meanwhile
+	BN_TS(2);
 	const bool scaled_quadrant = SCALED && (wave & 1) && ((fa.scale_mask >> (wave >> 1)) & 1); // (wave-uniform)
 	if (threadIdx.x < kBlkQ)
 		tile[kZeroBlk * kBlkQ + threadIdx.x] = uint4{0, 0, 0, 0};
@@ -275,7 +297,9 @@ __global__ __launch_bounds__(256, 2) void k_foldeval9_small(foldeval_args fa, ui
 	}
 	if (left <= 64 && lane < kBatch - 64) // second slot skipped: its staging rows must still read as zero
 		tile[(wave >> 1) * kArrQ + (wave & 1) * kBatch + 64 + lane] = uint4{0, 0, 0, 0};
+	fin_commit(fz, fpre, fcache);
 	__syncthreads();
+	BN_TS(3);
 	uint32_t acc[32];
 #pragma unroll
 	for (int p = 0; p < 32; p++)
@@ -284,7 +308,9 @@ __global__ __launch_bounds__(256, 2) void k_foldeval9_small(foldeval_args fa, ui
 		const eval_layout lay = make_eval_layout(lane);
 		eval_staged(tile, lay, acc, []() {});
 	}
-	re9::tail<4>(acc, lane < 63, c, g, wave, lane, out, fz, fz.args.seq);
+	BN_TS(5);
+	re9::tail<4>(acc, lane < 63, c, g, wave, lane, out, fz, seq, &fcache);
+	BN_TS(8);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -366,8 +392,11 @@ bool foldeval9_is_small(int n_cu, uint64_t n_in)
 
 // For both arrays j: out_j[i] = x0_j[i] + z * (x1_j[i] - x0_j[i]), i < n_in/2 (out_j may be x0_j), and
 // accumulate the next round's (S_1, S_inf) of out_0 * out_1 into d_out[0], d_out[1].  n_in >= 4.
-hipError_t launch_foldeval9(hipStream_t s, int n_cu, const foldeval_args &fa, uint64_t n_in, f128 z, f128 *d_out, const fin_fuse *fuse)
+hipError_t launch_foldeval9(hipStream_t s, int n_cu, const foldeval_args &fa, uint64_t n_in, f128 z, f128 *d_out, const fin_fuse *fuse,
+                            const arm_args *armed)
 {
+	arm_args arm{};
+	if (armed) arm = *armed;
 	if (n_in < 4 || (n_in & 3)) return hipErrorNotSupported;
 	fin_fuse fz{};
 	if (fuse) fz = *fuse;
@@ -378,16 +407,16 @@ hipError_t launch_foldeval9(hipStream_t s, int n_cu, const foldeval_args &fa, ui
 	if (foldeval9_is_small(n_cu, n_in)) {
 		// small round: one workgroup per batch, the four waves share the fold (latency, not throughput)
 		if (fa.scale_mask)
-			hipLaunchKernelGGL(k_foldeval9_small<true>, dim3((unsigned)n_batches), dim3(256), 0, s, fa, n_in, z, d_out, fz);
+			hipLaunchKernelGGL(k_foldeval9_small<true>, dim3((unsigned)n_batches), dim3(256), 0, s, fa, n_in, z, d_out, fz, arm);
 		else
-			hipLaunchKernelGGL(k_foldeval9_small<false>, dim3((unsigned)n_batches), dim3(256), 0, s, fa, n_in, z, d_out, fz);
+			hipLaunchKernelGGL(k_foldeval9_small<false>, dim3((unsigned)n_batches), dim3(256), 0, s, fa, n_in, z, d_out, fz, arm);
 		return hipGetLastError();
 	}
 	if (blocks > cap) blocks = cap;
 	if (fa.scale_mask)
-		hipLaunchKernelGGL((k_foldeval9<2, true>), dim3((unsigned)blocks), dim3(256), 0, s, fa, n_in, z, d_out, fz);
+		hipLaunchKernelGGL((k_foldeval9<2, true>), dim3((unsigned)blocks), dim3(256), 0, s, fa, n_in, z, d_out, fz, arm);
 	else
-		hipLaunchKernelGGL((k_foldeval9<2, false>), dim3((unsigned)blocks), dim3(256), 0, s, fa, n_in, z, d_out, fz);
+		hipLaunchKernelGGL((k_foldeval9<2, false>), dim3((unsigned)blocks), dim3(256), 0, s, fa, n_in, z, d_out, fz, arm);
 	return hipGetLastError();
 }
 

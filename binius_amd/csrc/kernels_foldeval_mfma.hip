@@ -37,6 +37,8 @@ __global__ __launch_bounds__(256, 2) void k_foldeval_mfma(foldeval_args fa, uint
 	__shared__ __attribute__((aligned(16))) uint32_t T[2][kTileW];
 	__shared__ ctable_smem tab;
 	__shared__ ctable_opt<SC != 0> tab_hs;
+	__shared__ fin_cache fcache;
+	const uint64_t seq = fz.args.seq;
 	const unsigned lane = threadIdx.x & 63;
 	const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const stage_role sr = make_stage_role(wave, lane);
@@ -77,8 +79,13 @@ __global__ __launch_bounds__(256, 2) void k_foldeval_mfma(foldeval_args fa, uint
 	};
 	uint64_t t = t0;
 	if (t < tlimit) load(t);
-	if constexpr (SC != 0) ctable_build(tab_hs.get(), fa.hi_scale);
-	ctable_build(tab, z); // the loads above are in flight meanwhile; ends with a barrier
+	{
+		// the finalize arguments travel with the first tile and wait in LDS for the tail (finalize.hpp)
+		const fin_pref fpre = fin_prefetch(fz);
+		if constexpr (SC != 0) ctable_build(tab_hs.get(), fa.hi_scale);
+		ctable_build(tab, z); // the loads above are in flight meanwhile; ends with a barrier
+		fin_commit(fz, fpre, fcache);
+	}
 
 	// One iteration: fold tile tt (VALU + LDS lookups) with, when GRAM, the Gram k-steps of the previous
 	// tile (in Tp) between the four constant multiplications (matrix pipe); the folded registers go to HBM
@@ -142,7 +149,7 @@ __global__ __launch_bounds__(256, 2) void k_foldeval_mfma(foldeval_args fa, uint
 		}
 		gram_tile(T[buf], gr, acc);
 	}
-	gram::tail(acc, wave, lane, out, fz, fz.args.seq);
+	gram::tail(acc, wave, lane, out, fz, seq, &fcache);
 }
 
 // For both arrays j: out_j[i] = x0_j[i] + z * (x1_j[i] - x0_j[i]), i < n_in/2 (out_j may be x0_j), and

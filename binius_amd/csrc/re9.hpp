@@ -63,7 +63,7 @@ __device__ __forceinline__ unsigned combo_mask(unsigned c)
 // Must be called by all NW*64 threads of the workgroup.
 template <int NW = 4>
 __device__ __forceinline__ void tail(const uint32_t (&acc)[32], bool live, unsigned c, unsigned g, unsigned wave, unsigned lane,
-                                     f128 *out, const fin_fuse &fz, uint64_t seq)
+                                     f128 *out, const fin_fuse &fz, uint64_t seq, const fin_cache *fc = nullptr)
 {
 	__shared__ uint32_t red[NW][2][9][8];
 	__shared__ uint64_t wsum[NW][4];
@@ -79,6 +79,7 @@ __device__ __forceinline__ void tail(const uint32_t (&acc)[32], bool live, unsig
 		red[wave][1][c][g] = s_hi;
 	}
 	__syncthreads();
+	BN_TS(6);
 	if (lane < 2) {
 		// lane q of every wave recombines stream q of that wave
 		uint32_t pc[9];
@@ -98,7 +99,12 @@ __device__ __forceinline__ void tail(const uint32_t (&acc)[32], bool live, unsig
 		wsum[wave][2 * lane + 1] = S.hi;
 	}
 	__syncthreads();
-	if (fz.counter && gridDim.x == 1 && out == fz.S) {
+	BN_TS(7);
+	// fc: the finalize arguments were staged in LDS at kernel entry (finalize.hpp) -- nothing below touches the
+	// kernarg segment then
+	unsigned *const counter = fc ? fc->counter : fz.counter;
+	f128 *const S = fc ? fc->S : fz.S;
+	if (counter && gridDim.x == 1 && out == S) {
 		// single workgroup: the sums never leave the chip -- finalize straight from LDS
 		__shared__ f128 s_loc[2];
 		if (threadIdx.x < 4) {
@@ -109,7 +115,10 @@ __device__ __forceinline__ void tail(const uint32_t (&acc)[32], bool live, unsig
 			reinterpret_cast<uint64_t *>(s_loc)[threadIdx.x] = v;
 		}
 		__syncthreads();
-		finalize_body(fz.args, fz.S, fz.rets, fz.mail, seq, s_loc);
+		if (fc)
+			finalize_cached(*fc, seq, s_loc);
+		else
+			finalize_body(fz.args, fz.S, fz.rets, fz.mail, seq, s_loc);
 		return;
 	}
 	if (threadIdx.x < 4) {
@@ -120,7 +129,7 @@ __device__ __forceinline__ void tail(const uint32_t (&acc)[32], bool live, unsig
 		if (v)
 			atomicXor(reinterpret_cast<unsigned long long *>(out) + threadIdx.x, (unsigned long long)v);
 	}
-	if (fz.counter) {
+	if (counter) {
 		// fused finalize: release our partial, take a ticket; the last workgroup folds the sums into
 		// the kernel's values and publishes them (same body as k_finalize)
 		// No release/acquire FENCES here (an agent-scope release writes back the whole L2: several
@@ -131,15 +140,18 @@ __device__ __forceinline__ void tail(const uint32_t (&acc)[32], bool live, unsig
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		__syncthreads();
 		if (threadIdx.x == 0) {
-			const unsigned t = atomicAdd(fz.counter, 1u);
+			const unsigned t = atomicAdd(counter, 1u);
 			is_last = (t == gridDim.x - 1) ? 1u : 0u;
 		}
 		__syncthreads();
 		if (is_last) {
 			// S is read with agent-scope atomic loads inside finalize_body (they bypass the L1)
-			finalize_body(fz.args, fz.S, fz.rets, fz.mail, seq);
+			if (fc)
+				finalize_cached(*fc, seq);
+			else
+				finalize_body(fz.args, fz.S, fz.rets, fz.mail, seq);
 			if (threadIdx.x == 0)
-				__hip_atomic_store(fz.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				__hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
 	}
 }

@@ -89,6 +89,7 @@ pub struct bn_kop {
 }
 
 pub const BN_PROF_N: usize = 10;
+pub const BN_ARM_N: usize = 3;
 
 // ---- the old HAL (binius_hal::ComputationBackend) on device-resident multilinears
 pub const BN_ORDER_LOW_TO_HIGH: u32 = 0;
@@ -304,4 +305,5 @@ unsafe extern "C" {
 	pub fn bn_xor_reduce(ctx: *mut bn_ctx, d_vals: *const c_void, n_groups: u32, group_len: u32, h_out: *mut bn_f128) -> c_int;
 	pub fn bn_prof_begin(ctx: *mut bn_ctx) -> c_int;
 	pub fn bn_prof_end(ctx: *mut bn_ctx, ms_by_class: *mut f64, launches_by_class: *mut u64) -> c_int;
+	pub fn bn_arm_counters(ctx: *mut bn_ctx, counters: *mut u64) -> c_int;
 }

@@ -283,6 +283,15 @@ enum { BN_PROF_ROUND_EVAL = 0, BN_PROF_FOLD = 1, BN_PROF_TENSOR_EXPAND = 2, BN_P
 int bn_prof_begin(bn_ctx *ctx);
 int bn_prof_end(bn_ctx *ctx, double *ms_by_class /*[BN_PROF_N]*/, uint64_t *launches_by_class /*[BN_PROF_N]*/);
 
+/* Armed rounds (binius_amd/csrc/arm.hpp): behind the fused fold + evaluation kernel of a small sumcheck round the
+ * dispatcher enqueues the kernel of the NEXT round, which waits on the device for its challenge; the caller's next
+ * extrapolate_line + accumulate_kernels pair then costs a write to pinned memory instead of a launch.  Purely an
+ * execution detail of bn_extrapolate_line_batch + bn_kernel_launch (the results are those of the unarmed path; BN_ARM=0
+ * turns it off).  Counters since context creation: rounds served by an armed kernel, armed kernels that were cancelled
+ * because the next call was something else, armed kernels that gave up waiting. */
+enum { BN_ARM_HITS = 0, BN_ARM_CANCELS = 1, BN_ARM_EXPIRED = 2, BN_ARM_N = 3 };
+int bn_arm_counters(bn_ctx *ctx, uint64_t *counters /*[BN_ARM_N]*/);
+
 #ifdef __cplusplus
 }
 #endif
