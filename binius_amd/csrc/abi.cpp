@@ -648,6 +648,8 @@ int bn_arm_counters(bn_ctx *ctx, uint64_t *counters)
 	counters[BN_ARM_HITS] = ctx->arm_hits;
 	counters[BN_ARM_CANCELS] = ctx->arm_cancels;
 	counters[BN_ARM_EXPIRED] = ctx->arm_expired;
+	counters[BN_ARM_NS_WAIT] = ctx->arm_ns_wait;
+	counters[BN_ARM_NS_LAUNCH] = ctx->arm_ns_launch;
 	return BN_OK;
 }
 

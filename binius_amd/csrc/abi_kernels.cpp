@@ -5,6 +5,8 @@
 #include "abi_common.hpp"
 #include "arm.hpp"
 
+#include <chrono>
+
 extern "C" {
 
 // ---------------------------------------------------------------------------------- kernels
@@ -402,7 +404,9 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 												ctx->h_mail[86].lo = pf.hi_scale.lo;
 												ctx->h_mail[86].hi = pf.hi_scale.hi;
 												__atomic_store_n(arm_cmd(ctx), (id << 2) | 1ull, __ATOMIC_RELEASE);
+												const auto t_go = std::chrono::steady_clock::now();
 												arm_next(fa, n_in, fz); // the round after this one queues up while this one runs
+												const auto t_armed = std::chrono::steady_clock::now();
 												volatile uint64_t *seqw = &ctx->h_mail[64].lo;
 												bool got = false;
 												for (uint64_t spins = 0;; spins++) {
@@ -426,6 +430,8 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 													ctx->pend.active = false;
 													ctx->s_clean = true;
 													ctx->arm_hits++;
+													ctx->arm_ns_launch += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t_armed - t_go).count();
+													ctx->arm_ns_wait += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_go).count();
 													return BN_OK;
 												}
 												// it left without running the round: the one queued behind it must leave too, then

@@ -258,7 +258,7 @@ def test_deferred_fold_is_invisible(hal, oracle):
     assert got == oracle.inner_product(fa, 7, fb)[1]
 
 
-def _rounds_with_oracle(hal, oracle, n_vars, disturb=None, seed=0x7A110000):
+def _rounds_with_oracle(hal, oracle, n_vars, disturb=None, seed=0x7A110000, disturb_after_fold=None):
     """Drive evaluate -> fold -> evaluate ... through the Python mirror (fold as one batch, the shape
     the ABI fuses and, for small arrays, hands to the resident tail kernel) and check every round's
     (y_1, y_inf) and the final folded values against the oracle.  disturb(round) may poke the
@@ -280,6 +280,8 @@ def _rounds_with_oracle(hal, oracle, n_vars, disturb=None, seed=0x7A110000):
             disturb(r, d)
         halves = [x.split_half() for x in d]
         hal.extrapolate_line_batch([lo for lo, _ in halves], [hi for _, hi in halves], zs[r])
+        if disturb_after_fold is not None:
+            disturb_after_fold(r, d)
         nxt = []
         for x in cur:
             f = x[: len(x) // 2].copy()
@@ -338,6 +340,108 @@ def test_resident_tail_times_out_safely(hal_tail, oracle):
             time.sleep(8.0)
 
     _rounds_with_oracle(hal, oracle, 9, disturb)
+
+
+# ---- armed rounds (csrc/arm.hpp): behind the fused kernel of a small round the dispatcher enqueues the kernel of the
+# next round, which waits on the device for its challenge.  Every round above already runs that way (the default);
+# these tests pin the protocol's edges.
+
+
+@pytest.mark.parametrize("n_vars", [3, 5, 12, 17])
+def test_armed_rounds_serve_the_small_rounds(hal, oracle, n_vars):
+    """Round 0 is a plain evaluation, round 1 the first fused launch; from round 2 on every (small) round is answered by
+    a kernel that was already on the device."""
+    c0 = hal.arm_counters()
+    _rounds_with_oracle(hal, oracle, n_vars, seed=0xA4A40000 + n_vars)
+    c1 = hal.arm_counters()
+    hits, expired = c1["hits"] - c0["hits"], c1["expired"] - c0["expired"]
+    # (the oracle's own rounds at 2^16 elements take about as long as the armed kernel is willing to wait)
+    assert hits + expired == n_vars - 2
+    if n_vars <= 12:
+        assert expired == 0
+
+
+def test_armed_round_is_cancelled_by_other_calls(hal, oracle):
+    """Any call that is not the predicted fold + evaluation pair sends the waiting kernel home (it has touched nothing);
+    the round then runs as an ordinary launch and the next one is armed again."""
+    def after_eval(r, d):
+        if r in (2, 3, 7):
+            hal.copy_d2h(d[0].slice(0, 1))
+        if r == 5:
+            hal.sync()
+
+    def after_fold(r, d):
+        if r in (4, 8):
+            hal.copy_d2h(d[1].slice(0, 1))  # forces the deferred fold out on its own
+
+    c0 = hal.arm_counters()
+    _rounds_with_oracle(hal, oracle, 12, after_eval, seed=0xA4A50000, disturb_after_fold=after_fold)
+    c1 = hal.arm_counters()
+    assert c1["cancels"] - c0["cancels"] >= 5  # (round 5 follows a fold that ran on its own: not fused, so nothing was armed)
+    assert 0 < c1["hits"] - c0["hits"] < 10
+
+
+def test_armed_round_with_other_arrays_is_cancelled(hal, oracle):
+    """The prediction is 'the same two arrays, in place, half the size'.  Two sumchecks that take turns on one context
+    (fold + evaluate of A, then fold + evaluate of B, ...) miss it every time: each fused launch arms a kernel for its
+    own next round, the other instance's fold cancels it -- and everybody still gets the right answers."""
+    from binius_amd.sumcheck import bivariate_product_expr, calculate_round_evals
+
+    n_vars = 9
+    alloc = hal.dev_alloc()
+    inst = []
+    for k in range(2):
+        mls = [oracle.random_b128(0xA4A60000 + 16 * k + j, 1 << n_vars) for j in range(2)]
+        inst.append({"cur": [x.copy() for x in mls], "d": [upload(hal, alloc, x) for x in mls]})
+    zs = oracle.random_scalars(0xA4A6, 2 * n_vars)
+    expr = bivariate_product_expr(hal, 0, 1)
+    c0 = hal.arm_counters()
+    for r in range(n_vars):
+        for k, it in enumerate(inst):
+            if r > 0:
+                z = zs[2 * (r - 1) + k]
+                halves = [x.split_half() for x in it["d"]]
+                hal.extrapolate_line_batch([lo for lo, _ in halves], [hi for _, hi in halves], z)
+                nxt = []
+                for x in it["cur"]:
+                    f = x[: len(x) // 2].copy()
+                    assert oracle.extrapolate_line(f, x[len(x) // 2 :].copy(), z) == 0
+                    nxt.append(f)
+                it["cur"] = nxt
+                it["d"] = [lo for lo, _ in halves]
+            nv = n_vars - r
+            got = calculate_round_evals(hal, nv, [1], it["d"], [expr])
+            rc, want = oracle.round_evals(it["cur"], nv, [(0, 1)], 1)
+            assert rc == 0 and got == want, f"instance {k} round {r}"
+    c1 = hal.arm_counters()
+    assert c1["hits"] == c0["hits"] and c1["cancels"] - c0["cancels"] >= 2 * (n_vars - 3)
+
+
+def test_armed_round_times_out_safely(hal, oracle):
+    """A host that stops talking cannot hang the GPU: the armed kernel leaves after a bounded spin (~50 ms), says so in
+    the status word, and the round it was meant for runs as an ordinary launch."""
+    import time
+
+    def disturb(r, d):
+        if r in (3, 6):
+            time.sleep(0.5)
+
+    c0 = hal.arm_counters()
+    _rounds_with_oracle(hal, oracle, 10, disturb, seed=0xA4A70000)
+    c1 = hal.arm_counters()
+    assert c1["expired"] - c0["expired"] == 2
+
+
+def test_rounds_with_arming_switched_off(oracle, monkeypatch):
+    import binius_amd
+
+    monkeypatch.setenv("BN_ARM", "0")
+    ctx = binius_amd.Context(0, 1 << 17)
+    try:
+        _rounds_with_oracle(ctx, oracle, 11, seed=0xA4A80000)
+        assert ctx.arm_counters()["hits"] == 0
+    finally:
+        ctx.close()
 
 
 def test_tiny_fold_results_are_mirrored_to_the_host(hal, oracle):

@@ -32,7 +32,13 @@ def main():
             plan.run()
         hal.sync()
         dt = time.perf_counter() - t0
-        print(json.dumps({"n_vars": n_vars, "us_per_sumcheck": round(dt / iters * 1e6, 2), "us_per_round": round(dt / iters / n_vars * 1e6, 2)}))
+        c = hal.arm_counters()
+        rec = {"n_vars": n_vars, "us_per_sumcheck": round(dt / iters * 1e6, 2), "us_per_round": round(dt / iters / n_vars * 1e6, 2)}
+        if c["hits"]:  # armed rounds (csrc/arm.hpp): host time from handing over z to seeing the result, per armed round
+            rec["armed_rounds"] = c["hits"]
+            rec["us_go_to_result"] = round(c["ns_wait"] / c["hits"] / 1e3, 2)
+            rec["us_of_which_enqueue_next"] = round(c["ns_launch"] / c["hits"] / 1e3, 2)
+        print(json.dumps(rec))
     hal.close()
 
 
