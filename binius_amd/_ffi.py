@@ -461,9 +461,9 @@ class Context:
 
     def arm_counters(self):
         """Armed rounds (csrc/arm.hpp): {hits, cancels, expired} since the context was created."""
-        c = (C.c_uint64 * 5)()
+        c = (C.c_uint64 * 6)()
         _check(lib().bn_arm_counters(self._h, c))
-        return {"hits": int(c[0]), "cancels": int(c[1]), "expired": int(c[2]), "ns_wait": int(c[3]), "ns_launch": int(c[4])}
+        return {"hits": int(c[0]), "cancels": int(c[1]), "expired": int(c[2]), "ns_wait": int(c[3]), "ns_launch": int(c[4]), "ns_parse": int(c[5])}
 
     # ---- ComputeLayer
     def copy_h2d(self, src, dst):

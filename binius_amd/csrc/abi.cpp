@@ -650,6 +650,7 @@ int bn_arm_counters(bn_ctx *ctx, uint64_t *counters)
 	counters[BN_ARM_EXPIRED] = ctx->arm_expired;
 	counters[BN_ARM_NS_WAIT] = ctx->arm_ns_wait;
 	counters[BN_ARM_NS_LAUNCH] = ctx->arm_ns_launch;
+	counters[BN_ARM_NS_PARSE] = ctx->arm_ns_parse;
 	return BN_OK;
 }
 

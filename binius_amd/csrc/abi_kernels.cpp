@@ -59,6 +59,7 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
                      const uint32_t *ret_values, uint32_t n_ret, uint32_t log_chunks, bn_f128 *h_out, void *d_out)
 {
 	BN_REQUIRE(ctx && maps && n_maps > 0, "kernel launch needs at least one mapping");
+	const auto t_enter = std::chrono::steady_clock::now();
 	BN_ENTER(ctx);
 	uint32_t lo_c, hi_c;
 	int rc = bn_log_chunks_range(maps, n_maps, &lo_c, &hi_c);
@@ -431,6 +432,7 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 													ctx->s_clean = true;
 													ctx->arm_hits++;
 													ctx->arm_ns_launch += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t_armed - t_go).count();
+													ctx->arm_ns_parse += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t_go - t_enter).count();
 													ctx->arm_ns_wait += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_go).count();
 													return BN_OK;
 												}

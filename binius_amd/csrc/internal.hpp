@@ -115,6 +115,7 @@ struct bn_ctx {
 	uint64_t *d_arm_relay = nullptr; // device memory, 8 words
 	bool arm_enabled = true;         // BN_ARM=0 turns the armed rounds off
 	uint64_t arm_hits = 0, arm_cancels = 0, arm_expired = 0;
+	uint64_t arm_ns_parse = 0; // entry of bn_kernel_launch -> challenge handed over
 	uint64_t arm_ns_wait = 0, arm_ns_launch = 0; // go -> mailbox seen; of which: enqueueing the next armed kernel
 };
 

@@ -289,8 +289,9 @@ int bn_prof_end(bn_ctx *ctx, double *ms_by_class /*[BN_PROF_N]*/, uint64_t *laun
  * execution detail of bn_extrapolate_line_batch + bn_kernel_launch (the results are those of the unarmed path; BN_ARM=0
  * turns it off).  Counters since context creation: rounds served by an armed kernel, armed kernels that were cancelled
  * because the next call was something else, armed kernels that gave up waiting; host nanoseconds between handing over
- * a challenge and seeing the round's result, and the part of that spent enqueueing the next armed kernel. */
-enum { BN_ARM_HITS = 0, BN_ARM_CANCELS = 1, BN_ARM_EXPIRED = 2, BN_ARM_NS_WAIT = 3, BN_ARM_NS_LAUNCH = 4, BN_ARM_N = 5 };
+ * a challenge and seeing the round's result, the part of that spent enqueueing the next armed kernel, and the time from
+ * the entry of bn_kernel_launch to handing the challenge over (validation + recognising the round). */
+enum { BN_ARM_HITS = 0, BN_ARM_CANCELS = 1, BN_ARM_EXPIRED = 2, BN_ARM_NS_WAIT = 3, BN_ARM_NS_LAUNCH = 4, BN_ARM_NS_PARSE = 5, BN_ARM_N = 6 };
 int bn_arm_counters(bn_ctx *ctx, uint64_t *counters /*[BN_ARM_N]*/);
 
 #ifdef __cplusplus

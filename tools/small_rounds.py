@@ -38,6 +38,7 @@ def main():
             rec["armed_rounds"] = c["hits"]
             rec["us_go_to_result"] = round(c["ns_wait"] / c["hits"] / 1e3, 2)
             rec["us_of_which_enqueue_next"] = round(c["ns_launch"] / c["hits"] / 1e3, 2)
+            rec["us_launch_entry_to_go"] = round(c["ns_parse"] / c["hits"] / 1e3, 2)
         print(json.dumps(rec))
     hal.close()
 
