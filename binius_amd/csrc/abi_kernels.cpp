@@ -46,6 +46,7 @@ int bn_pick_log_chunks(const bn_memmap *maps, uint32_t n_maps, uint32_t *log_chu
 }
 
 namespace {
+constexpr uint64_t kArmMaxIn = 1ull << 19; // largest round (elements per array before the fold) that is armed
 // how a kernel-buffer slice is realised on the device
 struct slice_view {
 	const char *p = nullptr; // direct data
@@ -352,7 +353,9 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 										// (arm.hpp): same arrays in place, half the size, same recipe, next sequence number
 										auto arm_next = [&](const bn::foldeval_args &fa_, uint64_t n_in_, const bn::fin_fuse &fz_) {
 											const uint64_t n_next = n_in_ >> 1;
-											if (!ctx->arm_enabled || ctx->prof_on || !h_out || d_out || n_next < 4 || (n_next & 3) ||
+											// only latency-shaped rounds: a launch is nothing next to a kernel of 2^20 elements, and the
+											// host waits for long kernels with a stream synchronisation, which an armed kernel would hold up
+											if (!ctx->arm_enabled || ctx->prof_on || !h_out || d_out || n_next < 4 || (n_next & 3) || n_next > kArmMaxIn ||
 											    bn::mfma_applies(ctx->n_cu, n_next >> 2) || ctx->tail_max_n_in)
 												return;
 											bn_ctx::arm_state &am = ctx->arm;
@@ -641,6 +644,8 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 		while (__atomic_load_n(seqw, __ATOMIC_ACQUIRE) != want) {
 			if (++spins > (1ull << 22)) {
 				// not there yet: fall back to a stream sync so device errors surface instead of hanging
+				// (an armed kernel queued behind this launch would sit out its whole timeout inside that sync)
+				arm_cancel(ctx);
 				BN_HIP(hipStreamSynchronize(s));
 				if (__atomic_load_n(seqw, __ATOMIC_ACQUIRE) != want)
 					return bn::fail(BN_ERR_DEVICE, "device error: result mailbox was not published");

@@ -43,7 +43,7 @@ __device__ __forceinline__ bool arm_wait(const arm_args &arm, f128 &z, f128 &hi_
 		uint64_t zl = 0, zh = 0, hl = 0, hh = 0;
 		if (blockIdx.x == 0) {
 			bool timed_out = true;
-			for (uint32_t spins = 0; spins < (1u << 15); spins++) {
+			for (uint32_t spins = 0; spins < (1u << 12); spins++) { // ~1.4 us per poll: gives up after ~6 ms
 				const uint64_t w = __hip_atomic_load(arm.h_cmd, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
 				if ((w >> 2) >= arm.id) {
 					timed_out = false;

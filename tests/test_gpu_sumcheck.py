@@ -355,7 +355,7 @@ def test_armed_rounds_serve_the_small_rounds(hal, oracle, n_vars):
     _rounds_with_oracle(hal, oracle, n_vars, seed=0xA4A40000 + n_vars)
     c1 = hal.arm_counters()
     hits, expired = c1["hits"] - c0["hits"], c1["expired"] - c0["expired"]
-    # (the oracle's own rounds at 2^16 elements take about as long as the armed kernel is willing to wait)
+    # (the oracle's own rounds at 2^14 elements and more take longer than the armed kernel is willing to wait)
     assert hits + expired == n_vars - 2
     if n_vars <= 12:
         assert expired == 0
@@ -418,7 +418,7 @@ def test_armed_round_with_other_arrays_is_cancelled(hal, oracle):
 
 
 def test_armed_round_times_out_safely(hal, oracle):
-    """A host that stops talking cannot hang the GPU: the armed kernel leaves after a bounded spin (~50 ms), says so in
+    """A host that stops talking cannot hang the GPU: the armed kernel leaves after a bounded spin (~6 ms), says so in
     the status word, and the round it was meant for runs as an ordinary launch."""
     import time
 
