@@ -2,7 +2,7 @@
 """Time the forward additive NTT (config 3: 2^24 BinaryField32b, shape {0,24,0}) and others.
 
 The transform is VALU-bound, so besides the HBM figure the last line is a JSON roofline block with
-"bound": "valu": algorithmic lane-operations = (L - 5) bit-sliced layers x 2^(L-6) plane-set butterflies x 1155
+"bound": "valu": algorithmic lane-operations = (L - 5) bit-sliced layers x 2^(L-6) plane-set butterflies x 1014
 lane-operations each (instruction count of the compiled butterfly loop of k_ntt_bs_pass: the 880-instruction product of
 bitslice.hpp -- 1015 until the GF(4)/GF(16) levels were written out on the 3-input LUT --, 64 XORs of the butterfly,
 ~210 of twiddle construction, bit-field extracts and LDS addressing; one lane-operation processes 32 elements) plus the
@@ -45,7 +45,7 @@ for _ in range(a.reps):
 import json
 L = a.log_n
 cols = 1 << (a.elem_level - 5)  # a larger field is 2 or 4 interleaved B32 columns
-lane_ops = cols * ((L - 5) * (1 << (L - 6)) * 1155 + 5 * (1 << (L - 1)) * 30)
+lane_ops = cols * ((L - 5) * (1 << (L - 6)) * 1014 + 5 * (1 << (L - 1)) * 30)
 print(json.dumps({"op": "forward NTT 2^%d x B%d" % (L, 1 << a.elem_level), "ms": round(ms, 4),
                   "roofline": {"bound": "valu", "achieved": round(lane_ops / ms / 1e9, 2), "peak": 60.0, "unit": "T lane-op/s",
                                "frac": round(lane_ops / ms / 1e9 / 60.0, 4), "lane_ops": lane_ops},
