@@ -46,7 +46,8 @@ int bn_pick_log_chunks(const bn_memmap *maps, uint32_t n_maps, uint32_t *log_chu
 }
 
 namespace {
-constexpr uint64_t kArmMaxIn = 1ull << 19; // largest round (elements per array before the fold) that is armed
+constexpr uint64_t kArmMaxIn = 1ull << 19;     // largest round (elements per array before the fold) that is armed ...
+constexpr uint64_t kArmMaxInMfma = 1ull << 21; // ... when it runs on the matrix-core kernel (60 us at 2^21: a launch is 10 % of that)
 // how a kernel-buffer slice is realised on the device
 struct slice_view {
 	const char *p = nullptr; // direct data
@@ -355,8 +356,9 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 											const uint64_t n_next = n_in_ >> 1;
 											// only latency-shaped rounds: a launch is nothing next to a kernel of 2^20 elements, and the
 											// host waits for long kernels with a stream synchronisation, which an armed kernel would hold up
-											if (!ctx->arm_enabled || ctx->prof_on || !h_out || d_out || n_next < 4 || (n_next & 3) || n_next > kArmMaxIn ||
-											    bn::mfma_applies(ctx->n_cu, n_next >> 2) || ctx->tail_max_n_in)
+											const bool mfma_next = bn::mfma_applies(ctx->n_cu, n_next >> 2);
+											if (!ctx->arm_enabled || ctx->prof_on || !h_out || d_out || n_next < 4 || (n_next & 3) ||
+											    n_next > (mfma_next ? kArmMaxInMfma : kArmMaxIn) || (mfma_next && fa_.scale_mask == 3) || ctx->tail_max_n_in)
 												return;
 											bn_ctx::arm_state &am = ctx->arm;
 											bn::foldeval_args fn{};
@@ -373,7 +375,9 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 											aa.h_status = (uint64_t *)&ctx->d_mail[87].lo;
 											aa.d_relay = ctx->d_arm_relay;
 											aa.id = ++ctx->arm_counter;
-											if (bn::launch_foldeval9(s, ctx->n_cu, fn, n_next, f128{0, 0}, d_S + slot, &fzn, &aa) != hipSuccess) {
+											const hipError_t ae = mfma_next ? bn::launch_foldeval_mfma(s, ctx->n_cu, fn, n_next, f128{0, 0}, d_S + slot, &fzn, &aa)
+											                                : bn::launch_foldeval9(s, ctx->n_cu, fn, n_next, f128{0, 0}, d_S + slot, &fzn, &aa);
+											if (ae != hipSuccess) {
 												(void)hipGetLastError();
 												return;
 											}

@@ -22,6 +22,7 @@
 #include <cstdlib>
 #include <type_traits>
 
+#include "arm.hpp"
 #include "ctable.hpp"
 #include "gram.hpp"
 
@@ -32,7 +33,7 @@ using namespace gram;
 // SC: 0 = plain fold; 1 / 2 = the upper half of folded array 0 / 1 is multiplied by fa.hi_scale (a fifth constant
 // multiplication per point, through a second nibble table) before it is stored and staged.
 template <int SC>
-__global__ __launch_bounds__(256, 2) void k_foldeval_mfma(foldeval_args fa, uint64_t n_in, f128 z, f128 *out, fin_fuse fz)
+__global__ __launch_bounds__(256, 2) void k_foldeval_mfma(foldeval_args fa, uint64_t n_in, f128 z, f128 *out, fin_fuse fz, arm_args arm)
 {
 	__shared__ __attribute__((aligned(16))) uint32_t T[2][kTileW];
 	__shared__ ctable_smem tab;
@@ -82,6 +83,11 @@ __global__ __launch_bounds__(256, 2) void k_foldeval_mfma(foldeval_args fa, uint
 	{
 		// the finalize arguments travel with the first tile and wait in LDS for the tail (finalize.hpp)
 		const fin_pref fpre = fin_prefetch(fz);
+		if (arm.h_cmd) { // (uniform) armed launch of a mid-size round: the challenge arrives through the command block (arm.hpp)
+			f128 hs_in;
+			if (!arm_wait(arm, z, hs_in)) return;
+			fa.hi_scale = hs_in;
+		}
 		if constexpr (SC != 0) ctable_build(tab_hs.get(), fa.hi_scale);
 		ctable_build(tab, z); // the loads above are in flight meanwhile; ends with a barrier
 		fin_commit(fz, fpre, fcache);
@@ -154,8 +160,11 @@ __global__ __launch_bounds__(256, 2) void k_foldeval_mfma(foldeval_args fa, uint
 
 // For both arrays j: out_j[i] = x0_j[i] + z * (x1_j[i] - x0_j[i]), i < n_in/2 (out_j may be x0_j), and
 // accumulate the next round's (S_1, S_inf) of out_0 * out_1 into d_out[0], d_out[1].  n_in >= 4.
-hipError_t launch_foldeval_mfma(hipStream_t s, int n_cu, const foldeval_args &fa, uint64_t n_in, f128 z, f128 *d_out, const fin_fuse *fuse)
+hipError_t launch_foldeval_mfma(hipStream_t s, int n_cu, const foldeval_args &fa, uint64_t n_in, f128 z, f128 *d_out, const fin_fuse *fuse,
+                                const arm_args *armed)
 {
+	arm_args arm{};
+	if (armed) arm = *armed;
 	if (n_in < 4 || (n_in & 3)) return hipErrorNotSupported;
 	fin_fuse fz{};
 	if (fuse) fz = *fuse;
@@ -169,9 +178,9 @@ hipError_t launch_foldeval_mfma(hipStream_t s, int n_cu, const foldeval_args &fa
 	foldeval_args fx = fa;
 	fx.xcd_tiles = xcd_tiles;
 	switch (fa.scale_mask) {
-	case 0: hipLaunchKernelGGL(k_foldeval_mfma<0>, grid, dim3(256), 0, s, fx, n_in, z, d_out, fz); break;
-	case 1: hipLaunchKernelGGL(k_foldeval_mfma<1>, grid, dim3(256), 0, s, fx, n_in, z, d_out, fz); break;
-	case 2: hipLaunchKernelGGL(k_foldeval_mfma<2>, grid, dim3(256), 0, s, fx, n_in, z, d_out, fz); break;
+	case 0: hipLaunchKernelGGL(k_foldeval_mfma<0>, grid, dim3(256), 0, s, fx, n_in, z, d_out, fz, arm); break;
+	case 1: hipLaunchKernelGGL(k_foldeval_mfma<1>, grid, dim3(256), 0, s, fx, n_in, z, d_out, fz, arm); break;
+	case 2: hipLaunchKernelGGL(k_foldeval_mfma<2>, grid, dim3(256), 0, s, fx, n_in, z, d_out, fz, arm); break;
 	default: return hipErrorNotSupported; // both arrays scaled: the caller runs fold, scale and evaluation separately
 	}
 	return hipGetLastError();
