@@ -6,6 +6,7 @@
 // No arithmetic fallback lives here: every op is a HIP kernel launch.  Host-side field arithmetic
 // is used only for O(log n) metadata (twiddle basis = OnTheFlyTwiddleAccess::generate).
 #include "abi_common.hpp"
+#include "hostmul.hpp"
 
 // ---------------------------------------------------------------------------------- errors
 namespace {
@@ -672,7 +673,7 @@ int bn_host_scratch(bn_ctx *ctx, void **h_ptr, void **d_ptr, uint64_t *elems)
 int bn_scalar_mul(const bn_f128 *a, const bn_f128 *b, bn_f128 *out)
 {
 	BN_REQUIRE(a && b && out, "null argument");
-	f128 r = bn::mul_slow(to_f(a), to_f(b));
+	f128 r = bn::mul_host(to_f(a), to_f(b)); // hostmul.hpp: table-based tower Karatsuba
 	out->lo = r.lo;
 	out->hi = r.hi;
 	return BN_OK;

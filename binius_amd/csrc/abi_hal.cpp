@@ -16,6 +16,7 @@
 #include <map>
 
 #include "abi_common.hpp"
+#include "hostmul.hpp"
 
 namespace {
 
@@ -48,7 +49,7 @@ bool expand_poly(const bn_expr *e, std::vector<monomial> &out)
 				v.insert(v.end(), ty.first.begin(), ty.first.end());
 				std::sort(v.begin(), v.end());
 				if (v.size() > 3) return false;
-				add_term(r, v, bn::mul_slow(tx.second, ty.second));
+				add_term(r, v, bn::mul_host(tx.second, ty.second));
 			}
 		return r.size() <= 4 * kMaxTerms;
 	};
@@ -253,7 +254,7 @@ int bn_hal_round_evals(bn_ctx *ctx, uint32_t order, uint32_t n_vars, const void 
 			for (uint32_t p = evs[e].eval_point_start; p < evs[e].eval_point_end; p++) {
 				f128 v = bn::f128_zero();
 				for (const auto &t : (p == 1 ? p1[e] : pinf[e]))
-					v ^= bn::mul_slow(t.coeff, sums[2 * job_of(t.vars, evs[e].d_eq_ind) + (p - 1)]);
+					v ^= bn::mul_host(t.coeff, sums[2 * job_of(t.vars, evs[e].d_eq_ind) + (p - 1)]);
 				h_out[off + (p - evs[e].eval_point_start)] = bn_f128{v.lo, v.hi};
 			}
 			off += evs[e].eval_point_end - evs[e].eval_point_start;
