@@ -269,13 +269,15 @@ __device__ __forceinline__ f128 kara64(uint64_t Z0, uint64_t Z2, uint64_t Z1p)
 // global accumulators and, if asked, the last workgroup runs the fused finalize -- the same protocol as
 // re9::tail (device-scope atomics only, no fences).
 // C/D layout of the 32x32 MFMA: column n = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
+// Gc[wave = (pr, h)][tile = 2 s + i][lane]: the 16 parity bits of the lane's accumulator registers of that tile
+typedef uint32_t gram_parity[4][kAccTiles][64];
+__device__ __forceinline__ void tail_finish(gram_parity &Gc, unsigned wave, unsigned lane, f128 *out, const fin_fuse &fz, uint64_t seq,
+                                            const fin_cache *fc);
+
 __device__ __forceinline__ void tail(const v16i (&acc)[kAccTiles], unsigned wave, unsigned lane, f128 *out, const fin_fuse &fz, uint64_t seq,
                                      const fin_cache *fc = nullptr)
 {
-	__shared__ uint32_t Gc[4][kAccTiles][64]; // [wave = (pr, h)][tile = 2 s + i][lane]: 16 parity bits
-	__shared__ uint64_t z3[2][3];
-	__shared__ f128 s_loc[2];
-	const unsigned tid = threadIdx.x;
+	__shared__ gram_parity Gc;
 	const unsigned b0 = 4 * (lane >> 5) + (lane & 7);
 #pragma unroll
 	for (int t = 0; t < kAccTiles; t++) {
@@ -285,6 +287,16 @@ __device__ __forceinline__ void tail(const v16i (&acc)[kAccTiles], unsigned wave
 			v |= (((uint32_t)acc[t][r] >> (b0 + (r & 3))) & 1u) << r;
 		Gc[wave][t][lane] = v;
 	}
+	tail_finish(Gc, wave, lane, out, fz, seq, fc);
+}
+
+// everything after the parity bits: shared by the int8 form above and the FP4 form (kernels_roundeval_fp4.hip)
+__device__ __forceinline__ void tail_finish(gram_parity &Gc, unsigned wave, unsigned lane, f128 *out, const fin_fuse &fz, uint64_t seq,
+                                            const fin_cache *fc)
+{
+	__shared__ uint64_t z3[2][3];
+	__shared__ f128 s_loc[2];
+	const unsigned tid = threadIdx.x;
 	__syncthreads();
 	// column n' = 32 h + n of matrix (pr, s) as a GF(2^64) element (bit p = G[p][n']); z = sum_n' col * e_n'
 	for (unsigned task = wave; task < 6; task += 4) {

@@ -1,0 +1,346 @@
+// binius_amd/csrc/kernels_roundeval_fp4.hip -- round evaluation of the bivariate product (round 0: no fold before it)
+// with the GF(2) Gram products of gram.hpp on the FP4 matrix path: v_mfma_scale_f32_32x32x64_f8f6f4 with both operands
+// E2M1 runs K = 64 in the time the int8 instruction takes for K = 32 (tools/fp4_probe.hip: 14.6 ns against 15.4 ns per
+// instruction and SIMD), and a register holds eight K-entries instead of four, so the operand masks per point halve
+// as well.  Same mathematics as kernels_roundeval_mfma.hip (one Karatsuba level, six accumulator tiles per wave, the
+// tail of gram.hpp); what changes is the operand encoding:
+//
+//  * An operand entry is a NIBBLE of the data with one bit kept: code 0001 = 0.5, 0010 = 1, 0100 = 2 (E2M1; the probe
+//    confirms the subnormal).  Bit 3 of a nibble is the sign bit of the format -- 1000 decodes to -0 -- so the staging
+//    also writes, per pair of limbs, a word W3 that carries bit 3 of limb 2q at position 2 and bit 3 of limb 2q + 1 at
+//    position 1; the rows / columns that belong to bit 3 read W3 instead of the data word (a per-lane LDS offset, no
+//    extra instruction) and mask it like everybody else.
+//  * Products are 2^(e_row + e_col), the f32 accumulator of an entry holds count * 2^(e_row + e_col) exactly (count <
+//    2^24: a workgroup sees at most 2^22 points), and the parity wanted is bit 0 of the count.
+//  * K order: operand position (lane half, register, nibble) of A meets the same position of B (probe), so any
+//    arrangement of the 64 points of a k-step works as long as u and v use the same one.
+//
+// LDS tile of 256 points, 24 KiB: T4[set 0..3][limb 0..3][k-step 0..3][nibble index 0..7][8 words], a word = that nibble
+// of the limb for eight points; W3[set][limb pair 0..1][k-step][nibble index][8 words].  A reader lane (row i, k half)
+// takes the 16 bytes at nibble index i >> 2, words 4 * khalf ..: eight lanes broadcast each chunk.
+// Staging: lane = point.  The 8 x 8 nibble transpose across eight lanes is three exchanges -- 16-bit halves with lane
+// 7 - j (DPP row_half_mirror), bytes with lane j ^ 1, nibbles with lane j ^ 2 (DPP quad_perm) -- the upper four lanes
+// taking their decisions from the mirrored index so that every lane ends up with the same point order.
+#include <hip/hip_runtime.h>
+
+#include "gram.hpp"
+
+namespace bn {
+
+using namespace gram;
+
+namespace {
+
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+constexpr int kT4W = 4096;         // words of the data part of a tile
+constexpr int kTile4W = 4096 + 2048; // + the bit-3 words
+
+struct stage4_role {
+	uint32_t sel1, sel2, rot3, keep3;
+	unsigned st_off;  // word offset of this lane's word inside a (set, limb) group: k-step, nibble index, point group
+	unsigned st_off3; // the same inside a (set, limb pair) group of bit-3 words (rotated by half a block, see make_gram4_role)
+};
+__device__ __forceinline__ stage4_role make_stage4_role()
+{
+	const unsigned tid = threadIdx.x;
+	const unsigned j = tid & 7, jj = j < 4 ? j : 7 - j;
+	stage4_role r;
+	r.sel1 = j < 4 ? 0x05040100u : 0x03020706u;
+	r.sel2 = (jj & 1) ? 0x03070105u : 0x06020400u;
+	r.rot3 = (jj & 2) ? 4u : 28u;
+	r.keep3 = (jj & 2) ? 0xF0F0F0F0u : 0x0F0F0F0Fu;
+	const unsigned cidx = (j < 4 ? 0u : 4u) + ((jj & 1) << 1) + ((jj >> 1) & 1); // the nibble index lane j ends up holding
+	const unsigned g = tid >> 3;
+	r.st_off = (g >> 3) * 64 + cidx * 8 + (g & 7);
+	r.st_off3 = (g >> 3) * 64 + ((cidx * 8 + (g & 7) + 32) & 63);
+	return r;
+}
+
+// word x of this lane's point -> the word whose nibble i is nibble c(j) of x in the i-th lane (fixed order) of the
+// group of eight; c(j) = [0, 2, 1, 3, 7, 5, 6, 4][j]
+__device__ __forceinline__ uint32_t nib_tr(uint32_t x, const stage4_role &sr)
+{
+	const uint32_t p1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x141, 0xF, 0xF, true); // row_half_mirror: lane 7 - j
+	const uint32_t a = __builtin_amdgcn_perm(p1, x, sr.sel1);
+	const uint32_t p2 = (uint32_t)__builtin_amdgcn_mov_dpp((int)a, 0xB1, 0xF, 0xF, true); // quad_perm [1,0,3,2]
+	const uint32_t b = __builtin_amdgcn_perm(p2, a, sr.sel2);
+	const uint32_t p3 = (uint32_t)__builtin_amdgcn_mov_dpp((int)b, 0x4E, 0xF, 0xF, true); // quad_perm [2,3,0,1]
+	const uint32_t rot = __builtin_amdgcn_alignbit(p3, p3, sr.rot3);
+	return __builtin_amdgcn_bitop3_b32(sr.keep3, b, rot, 0xCA); // (keep & b) | (~keep & rot)
+}
+
+// the four limbs of one element of set `set` -> four data words + two bit-3 words
+__device__ __forceinline__ void stage4_elem(uint32_t *T, const stage4_role &sr, unsigned set, uint4 e)
+{
+	uint32_t *dst = T + set * 1024 + sr.st_off;
+	const uint32_t y0 = nib_tr(e.x, sr), y1 = nib_tr(e.y, sr), y2 = nib_tr(e.z, sr), y3 = nib_tr(e.w, sr);
+	dst[0 * 256] = y0;
+	dst[1 * 256] = y1;
+	dst[2 * 256] = y2;
+	dst[3 * 256] = y3;
+	uint32_t *dw = T + kT4W + set * 512 + sr.st_off3;
+	dw[0] = ((y0 >> 1) & 0x44444444u) | ((y1 >> 2) & 0x22222222u);
+	dw[256] = ((y2 >> 1) & 0x44444444u) | ((y3 >> 2) & 0x22222222u);
+}
+
+struct gram4_role {
+	unsigned pr, h;
+	unsigned u_off[4], v_off[2]; // word offsets of this lane's 16 bytes, k-step 0: u limbs 0..3, v limbs h and 2 + h
+	uint32_t m_even, m_odd;      // masks for even / odd limbs (they differ only for the bit-3 rows)
+	int e_row[2], e_col;         // exponent of this lane's column weight; of a register's row weight: see tail4
+};
+__device__ __forceinline__ gram4_role make_gram4_role(unsigned wave, unsigned lane)
+{
+	gram4_role g;
+	g.pr = wave >> 1;
+	g.h = wave & 1;
+	const unsigned i = lane & 31, kh = lane >> 5, c = i >> 2, s = i & 3;
+	// (the bit-3 words sit half a block further inside their 256-byte block than the data words of the same nibble index: a
+	// group of 16 lanes -- 12 data readers, 4 bit-3 readers -- then touches 8 distinct 16-byte chunks in 8 distinct bank groups)
+	const unsigned in_blk = s < 3 ? c * 8 + kh * 4 : ((c * 8 + kh * 4 + 32) & 63);
+	const unsigned us = 2 * g.pr, vs = 2 * g.pr + 1;
+#pragma unroll
+	for (unsigned w = 0; w < 4; w++)
+		g.u_off[w] = s < 3 ? us * 1024 + w * 256 + in_blk : kT4W + us * 512 + (w >> 1) * 256 + in_blk;
+#pragma unroll
+	for (unsigned q = 0; q < 2; q++) {
+		const unsigned w = g.h + 2 * q;
+		g.v_off[q] = s < 3 ? vs * 1024 + w * 256 + in_blk : kT4W + vs * 512 + (w >> 1) * 256 + in_blk;
+	}
+	g.m_even = s < 3 ? 0x11111111u << s : 0x44444444u;
+	g.m_odd = s < 3 ? 0x11111111u << s : 0x22222222u;
+	g.e_col = s < 3 ? (int)s - 1 : (g.h ? 0 : 1);
+	return g;
+}
+
+__device__ __forceinline__ void acc4_zero(v16f (&acc)[kAccTiles])
+{
+#pragma unroll
+	for (int t = 0; t < kAccTiles; t++)
+#pragma unroll
+		for (int r = 0; r < 16; r++)
+			acc[t][r] = 0.0f;
+}
+
+#define BN_GRAM4_MFMA(t, A, B)                                                                                                             \
+	acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(v8i{(A).x, (A).y, (A).z, (A).w, 0, 0, 0, 0}, v8i{(B).x, (B).y, (B).z, (B).w, 0, 0, 0, 0}, \
+	                                                         acc[t], 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F)
+
+// One k-step (64 points): 6 ds_read_b128, 36 bitwise VALU, 6 MFMAs; the operands of k-step ks + 1 are requested before the
+// MFMAs of k-step ks are issued (second register set).
+struct gram4_pipe {
+	v4i u[4], v[2];
+};
+__device__ __forceinline__ void gram4_load(const uint32_t *T, const gram4_role &g, int ks, v4i (&u)[4], v4i (&v)[2])
+{
+#pragma unroll
+	for (int w = 0; w < 4; w++)
+		u[w] = *reinterpret_cast<const v4i *>(T + g.u_off[w] + ks * 64);
+	v[0] = *reinterpret_cast<const v4i *>(T + g.v_off[0] + ks * 64);
+	v[1] = *reinterpret_cast<const v4i *>(T + g.v_off[1] + ks * 64);
+}
+template <int KS>
+__device__ __forceinline__ void gram4_step(const uint32_t *T, const gram4_role &g, gram4_pipe &p, v16f (&acc)[kAccTiles])
+{
+	v4i un[4], vn[2];
+	if (KS < 3) {
+		gram4_load(T, g, KS + 1, un, vn);
+		asm volatile("" ::: "memory");
+		__builtin_amdgcn_sched_barrier(0);
+	}
+	const uint32_t me = g.m_even, mo = g.m_odd, mh = g.h ? mo : me;
+	{
+		const v4i B = and4(p.v[0], mh);
+		BN_GRAM4_MFMA(0, and4(p.u[0], me), B);
+		BN_GRAM4_MFMA(1, and4(p.u[1], mo), B);
+	}
+	{
+		const v4i B = and4(p.v[1], mh);
+		BN_GRAM4_MFMA(2, and4(p.u[2], me), B);
+		BN_GRAM4_MFMA(3, and4(p.u[3], mo), B);
+	}
+	{
+		const v4i B = xand4(p.v[0], p.v[1], mh);
+		BN_GRAM4_MFMA(4, xand4(p.u[0], p.u[2], me), B);
+		BN_GRAM4_MFMA(5, xand4(p.u[1], p.u[3], mo), B);
+	}
+	if (KS < 3) {
+		__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+		for (int w = 0; w < 4; w++)
+			p.u[w] = un[w];
+		p.v[0] = vn[0];
+		p.v[1] = vn[1];
+	}
+}
+__device__ __forceinline__ void gram4_tile(const uint32_t *T, const gram4_role &g, v16f (&acc)[kAccTiles])
+{
+	gram4_pipe p;
+	gram4_load(T, g, 0, p.u, p.v);
+	gram4_step<0>(T, g, p, acc);
+	gram4_step<1>(T, g, p, acc);
+	gram4_step<2>(T, g, p, acc);
+	gram4_step<3>(T, g, p, acc);
+}
+
+// parity bits out of the f32 accumulators, then the common tail.  Register r of a tile is row (r & 3) + 8 (r >> 2) +
+// 4 (lane >> 5): its bit position inside the nibble is r & 3; tile t = 2 s + i has rows from an even (i = 0) or odd limb.
+__device__ __forceinline__ void tail4(const v16f (&acc)[kAccTiles], const gram4_role &g, unsigned wave, unsigned lane, f128 *out,
+                                      const fin_fuse &fz, uint64_t seq)
+{
+	__shared__ gram_parity Gc;
+#pragma unroll
+	for (int t = 0; t < kAccTiles; t++) {
+		uint32_t v = 0;
+#pragma unroll
+		for (int r = 0; r < 16; r++) {
+			const int sr = r & 3;
+			const int e_row = sr < 3 ? sr - 1 : ((t & 1) ? 0 : 1);
+			const int cnt = (int)__builtin_amdgcn_ldexpf(acc[t][r], -(e_row + g.e_col));
+			v |= ((uint32_t)cnt & 1u) << r;
+		}
+		Gc[wave][t][lane] = v;
+	}
+	tail_finish(Gc, wave, lane, out, fz, seq, nullptr);
+}
+
+} // namespace
+
+// Element loads go straight into LDS (global_load_lds_dwordx4: no registers held while they fly), THREE tiles ahead: with
+// K = 64 the Gram k-steps of a tile take ~0.5 us, a fraction of what a loaded HBM takes to answer, and a second register
+// set for a deeper register prefetch does not survive next to 96 accumulator registers (two loop bodies: 101 - 191
+// spilled registers in three shapes).  48 KiB of raw elements + the 24 KiB operand tile per workgroup, two workgroups
+// per CU; per tile two barriers: raw -> operand tile (VALU), then the Gram k-steps (matrix pipe) -- the two workgroups
+// of a CU interleave the two phases.
+constexpr int kRawSlots = 3;
+#ifdef BN_FP4_PHASES
+__device__ unsigned long long fp4_phase_cycles[8];
+#define FP4_CLK(i)                                                 \
+	do {                                                           \
+		const unsigned long long now_ = clock64();                 \
+		if (threadIdx.x == 0 && blockIdx.x == 0) fp4_phase_cycles[i] += now_ - last_; \
+		last_ = now_;                                              \
+	} while (0)
+#else
+#define FP4_CLK(i)
+#endif
+__global__ __launch_bounds__(256, 2) void k_roundeval_fp4(const uint4 *__restrict__ a_hi, const uint4 *__restrict__ a_lo,
+                                                          const uint4 *__restrict__ b_hi, const uint4 *__restrict__ b_lo, uint64_t n, f128 *out,
+                                                          fin_fuse fz, uint32_t xcd_tiles)
+{
+	__shared__ __attribute__((aligned(16))) uint32_t T[kTile4W];
+	__shared__ uint4 raw[kRawSlots][4][kTP];
+	const unsigned lane = threadIdx.x & 63;
+	const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const stage4_role sr = make_stage4_role();
+	const gram4_role gr = make_gram4_role(wave, lane);
+
+	v16f acc[kAccTiles];
+	acc4_zero(acc);
+
+	const uint64_t n_tiles_all = (n + kTP - 1) / kTP;
+	// tile order: XCD x = blockIdx.x & 7 takes the x-th contiguous eighth of the tiles (see kernels_foldeval_mfma.hip)
+	uint64_t tbase = 0, tstride = gridDim.x, n_tiles = n_tiles_all, t0 = blockIdx.x;
+	if (xcd_tiles && (gridDim.x & 7) == 0) {
+		const uint64_t chunk = (n_tiles_all + 7) >> 3;
+		tbase = (blockIdx.x & 7) * chunk;
+		tstride = gridDim.x >> 3;
+		t0 = blockIdx.x >> 3;
+		n_tiles = tbase >= n_tiles_all ? 0 : (n_tiles_all - tbase < chunk ? n_tiles_all - tbase : chunk);
+	}
+	// this wave's 64 points of tile t into raw[slot]: four 1-KiB requests (a lane past the end fetches element 0: zeroed below).
+	// Inline assembly on purpose: the compiler waits for EVERY outstanding LDS-DMA load before any LDS read or workgroup
+	// fence it can see (it cannot tell raw[] from T[]), which would take the three-tile prefetch down to none; here the
+	// waits are the explicit s_waitcnt below.
+	const uint32_t raw_base = (uint32_t)(uintptr_t)(&raw[0][0][0]) + wave * 64 * 16;
+	auto fetch = [&](uint64_t t, unsigned slot) {
+		const uint64_t pt = (tbase + t) * kTP + threadIdx.x;
+		const uint64_t e = pt < n ? pt : 0;
+		const uint32_t l0 = __builtin_amdgcn_readfirstlane(raw_base + slot * (4 * kTP * 16));
+		asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(a_hi + e), "s"(l0) : "memory");
+		asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(a_lo + e), "s"(l0 + 1 * kTP * 16) : "memory");
+		asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(b_hi + e), "s"(l0 + 2 * kTP * 16) : "memory");
+		asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(b_lo + e), "s"(l0 + 3 * kTP * 16) : "memory");
+	};
+	// workgroup barrier that waits for this wave's LDS traffic only (not for the LDS-DMA loads in flight)
+	auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+	uint64_t t = t0;
+#pragma unroll
+	for (int k = 0; k < kRawSlots; k++)
+		if (t + k * tstride < n_tiles) fetch(t + k * tstride, k);
+	unsigned slot = 0;
+#ifdef BN_FP4_PHASES
+	unsigned long long last_ = clock64();
+#endif
+	for (; t < n_tiles; t += tstride) {
+		// the loads of tile t are the oldest outstanding ones of this wave: wait for them, not for the younger tiles'
+		const unsigned younger = (t + tstride < n_tiles ? 1u : 0u) + (t + 2 * tstride < n_tiles ? 1u : 0u);
+		if (younger == 2)
+			asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+		else if (younger == 1)
+			asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+		else
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		FP4_CLK(0);
+		lds_barrier(); // raw[slot] complete (every wave waited for its own part); the previous tile's k-steps are done with T
+		FP4_CLK(1);
+#ifndef BN_FP4_ONLY_LOADS
+		{
+			uint4 x[4];
+#pragma unroll
+			for (int k = 0; k < 4; k++)
+				x[k] = raw[slot][k][threadIdx.x];
+			if ((tbase + t + 1) * kTP > n) { // (uniform) the ragged last tile: lanes past the end contribute zeros
+				if ((tbase + t) * kTP + threadIdx.x >= n) {
+#pragma unroll
+					for (int k = 0; k < 4; k++)
+						x[k] = uint4{0, 0, 0, 0};
+				}
+			}
+			stage4_elem(T, sr, 0, x[0]);
+			stage4_elem(T, sr, 2, uint4{x[0].x ^ x[1].x, x[0].y ^ x[1].y, x[0].z ^ x[1].z, x[0].w ^ x[1].w});
+			stage4_elem(T, sr, 1, x[2]);
+			stage4_elem(T, sr, 3, uint4{x[2].x ^ x[3].x, x[2].y ^ x[3].y, x[2].z ^ x[3].z, x[2].w ^ x[3].w});
+		}
+#endif
+		// this wave has read its part of raw[slot] (its own lanes' points only): refill it with the tile three ahead
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+		FP4_CLK(2);
+		if (t + kRawSlots * tstride < n_tiles) fetch(t + kRawSlots * tstride, slot);
+		lds_barrier(); // T staged
+		FP4_CLK(3);
+#ifndef BN_FP4_ONLY_LOADS
+		gram4_tile(T, gr, acc);
+#endif
+		FP4_CLK(4);
+		slot = slot == kRawSlots - 1 ? 0 : slot + 1;
+	}
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	__syncthreads();
+	tail4(acc, gr, wave, lane, out, fz, fz.args.seq);
+}
+
+// d_out[0] ^= sum_i a_hi[i]*b_hi[i] ; d_out[1] ^= sum_i (a_lo[i]^a_hi[i])*(b_lo[i]^b_hi[i])
+hipError_t launch_roundeval_fp4_pair(hipStream_t s, int n_cu, const void *a_hi, const void *a_lo, const void *b_hi, const void *b_lo, uint64_t n,
+                                     f128 *d_out, const fin_fuse *fuse)
+{
+	fin_fuse fz{};
+	if (fuse) fz = *fuse;
+	if (n == 0) return hipErrorNotSupported;
+	const uint64_t n_tiles = (n + kTP - 1) / kTP;
+	const uint64_t cap = (uint64_t)n_cu * 2;
+	const unsigned grid = (unsigned)(n_tiles < cap ? n_tiles : cap);
+	if ((n_tiles + grid - 1) / grid > (1ull << 14)) return hipErrorNotSupported; // 2^22 points per workgroup: the f32 counts stay exact
+	static const uint32_t xcd_tiles = [] {
+		const char *e = getenv("BN_XCD_TILES");
+		return (uint32_t)!(e && e[0] == '0');
+	}();
+	hipLaunchKernelGGL(k_roundeval_fp4, dim3(grid), dim3(256), 0, s, (const uint4 *)a_hi, (const uint4 *)a_lo, (const uint4 *)b_hi,
+	                   (const uint4 *)b_lo, n, d_out, fz, xcd_tiles);
+	return hipGetLastError();
+}
+
+} // namespace bn

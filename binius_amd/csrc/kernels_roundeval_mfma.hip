@@ -139,6 +139,19 @@ static hipError_t launch_mfma(hipStream_t s, int n_cu, const void *a_hi, const v
 hipError_t launch_roundeval_mfma_pair(hipStream_t s, int n_cu, const void *a_hi, const void *a_lo, const void *b_hi, const void *b_lo,
                                       uint64_t n, f128 *d_out, const fin_fuse *fuse)
 {
+	// large evaluations (round 0 of a big sumcheck) go to the FP4 matrix path: twice the k-depth per instruction and three
+	// tiles of loads in flight through LDS (kernels_roundeval_fp4.hip).  BN_FP4=0: the int8 kernel at every size;
+	// BN_FP4_MIN_LOG2: smallest log2(points) for the FP4 kernel.
+	static const int fp4_min_log2 = [] {
+		const char *e = getenv("BN_FP4");
+		if (e && e[0] == '0') return 64;
+		const char *m = getenv("BN_FP4_MIN_LOG2");
+		return m ? atoi(m) : 25;
+	}();
+	if (fp4_min_log2 < 64 && n >= ((uint64_t)1 << fp4_min_log2)) {
+		const hipError_t e = launch_roundeval_fp4_pair(s, n_cu, a_hi, a_lo, b_hi, b_lo, n, d_out, fuse);
+		if (e != hipErrorNotSupported) return e;
+	}
 	return launch_mfma<false>(s, n_cu, a_hi, a_lo, b_hi, b_lo, n, d_out, fuse);
 }
 

@@ -774,3 +774,26 @@ def test_scaled_fold_followed_by_round_evaluation(hal, oracle, log_n, mask):
     for j in range(2):
         assert np.array_equal(hal.copy_d2h(lo[j]), want_arrays[j])
     expr.free()
+
+
+def test_fp4_matrix_path_on_the_small_shapes():
+    """Round evaluations of 2^25 points and more run on the FP4 matrix path (csrc/kernels_roundeval_fp4.hip: E2M1
+    operands, f32 counts, element loads through LDS).  At those sizes it is checked by the bench's own bit-exact check and
+    by test_gpu_at_size; here the same parity tests once more with the switch at zero (BN_FP4_MIN_LOG2=0: every
+    matrix-core round evaluation, ragged sizes included), in a fresh process because the switch is read once."""
+    import os
+    import subprocess
+    import sys
+
+    if os.environ.get("BN_FP4_MIN_LOG2") == "0":
+        pytest.skip("already the inner run")
+    env = dict(os.environ, BN_FP4_MIN_LOG2="0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run(
+        [sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_sumcheck.py"), os.path.join(root, "tests", "test_gpu_hal.py"),
+         os.path.join(root, "tests", "test_gpu_at_size.py"), "-x", "-q", "-m", "gpu",
+         "-k", "calculate_round_evals or compiled_host_prover or compiled_sumcheck_plan_n20 or provers_agree_at_2p23 or fast_shape or routed or full_size"],
+        env=env, cwd=root, capture_output=True, text=True, timeout=1200,
+    )
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+    assert " passed" in p.stdout

@@ -3,6 +3,7 @@
 // Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -Ibinius_amd/csrc -Iinclude tools/gram_bench.hip -o tools/gram_bench
 #include "../binius_amd/csrc/kernels_roundeval_mfma.hip"
 #include "../binius_amd/csrc/kernels_foldeval_mfma.hip"
+#include "../binius_amd/csrc/kernels_roundeval_fp4.hip"
 
 #include <cstdio>
 #include <cstdlib>
@@ -20,6 +21,7 @@ static uint64_t sm64(uint64_t &s)
 
 int main(int argc, char **argv)
 {
+	setenv("BN_FP4", "0", 1); // launch_roundeval_mfma_pair stays the int8 kernel here: it is the reference of the FP4 one
 	const int log_n = argc > 1 ? atoi(argv[1]) : 24;
 	const uint64_t n = 1ull << log_n;
 	std::vector<f128> h[4];
@@ -51,6 +53,16 @@ int main(int argc, char **argv)
 		const bool ok = got[0] == e1 && got[1] == ei && e == hipSuccess;
 		bad += !ok;
 		printf("pair  n=%llu: %s\n", (unsigned long long)nc, ok ? "OK" : "MISMATCH");
+		{
+			// the same sums on the FP4 matrix path
+			(void)hipMemset(d_out, 0, 32);
+			const hipError_t e4 = launch_roundeval_fp4_pair(0, 256, d[0], d[1], d[2], d[3], nc, d_out, nullptr);
+			f128 g4[2];
+			(void)hipMemcpy(g4, d_out, 32, hipMemcpyDeviceToHost);
+			const bool ok4 = g4[0] == e1 && g4[1] == ei && e4 == hipSuccess;
+			bad += !ok4;
+			printf("fp4   n=%llu: %s\n", (unsigned long long)nc, ok4 ? "OK" : "MISMATCH");
+		}
 		// split: sums over [0,nc/2) and [nc/2, nc/2*2)
 		const uint64_t hn = nc / 2;
 		if (hn) {
@@ -79,6 +91,45 @@ int main(int argc, char **argv)
 		float ms;
 		(void)hipEventElapsedTime(&ms, ea, eb);
 		printf("pair n=2^%d: %.3f ms  %.2f G points/s  %.2f TB/s algorithmic (64 B/point)\n", log_n, ms, n / ms * 1e-6, n * 64.0 / ms * 1e-9);
+	}
+	{
+		// FP4 form against the int8 form at full size (the host product is too slow there), then its timing
+		f128 ref[2], g4[2];
+		(void)hipMemset(d_out, 0, 32);
+		(void)launch_roundeval_mfma_pair(0, 256, d[0], d[1], d[2], d[3], n, d_out, nullptr);
+		(void)hipMemcpy(ref, d_out, 32, hipMemcpyDeviceToHost);
+		(void)hipMemset(d_out, 0, 32);
+		(void)launch_roundeval_fp4_pair(0, 256, d[0], d[1], d[2], d[3], n, d_out, nullptr);
+		(void)hipMemcpy(g4, d_out, 32, hipMemcpyDeviceToHost);
+		const bool ok = ref[0] == g4[0] && ref[1] == g4[1];
+		bad += !ok;
+		printf("fp4 vs int8 at n=2^%d: %s\n", log_n, ok ? "OK" : "MISMATCH");
+#ifdef BN_FP4_PHASES
+		{
+			unsigned long long z8[8] = {0}, c8[8];
+			(void)hipMemcpyToSymbol(HIP_SYMBOL(bn::fp4_phase_cycles), z8, sizeof(z8));
+			(void)hipMemset(d_out, 0, 32);
+			(void)launch_roundeval_fp4_pair(0, 256, d[0], d[1], d[2], d[3], n, d_out, nullptr);
+			(void)hipDeviceSynchronize();
+			(void)hipMemcpyFromSymbol(c8, HIP_SYMBOL(bn::fp4_phase_cycles), sizeof(c8));
+			const double tiles = (double)((n + 255) / 256) / 512.0;
+			printf("fp4 phases, cycles per tile (workgroup 0, wave 0): wait loads %.0f, barrier 1 %.0f, stage %.0f, barrier 2 %.0f, gram %.0f\n",
+			       c8[0] / tiles, c8[1] / tiles, c8[2] / tiles, c8[3] / tiles, c8[4] / tiles);
+		}
+#endif
+		for (int rep = 0; rep < (prof ? 3 : 4); rep++) {
+			hipEvent_t ea, eb;
+			(void)hipEventCreate(&ea);
+			(void)hipEventCreate(&eb);
+			(void)hipMemset(d_out, 0, 32);
+			(void)hipEventRecord(ea);
+			(void)launch_roundeval_fp4_pair(0, 256, d[0], d[1], d[2], d[3], n, d_out, nullptr);
+			(void)hipEventRecord(eb);
+			(void)hipEventSynchronize(eb);
+			float ms;
+			(void)hipEventElapsedTime(&ms, ea, eb);
+			printf("fp4  n=2^%d: %.3f ms  %.2f G points/s  %.2f TB/s algorithmic (64 B/point)\n", log_n, ms, n / ms * 1e-6, n * 64.0 / ms * 1e-9);
+		}
 	}
 	// ---- fused fold + evaluation: arrays a = d[0], b = d[2] of N elements, folded into d[1], d[3]
 	const f128 z{0x0123456789abcdefull, 0xfedcba9876543210ull};
