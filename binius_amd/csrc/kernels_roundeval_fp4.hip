@@ -16,8 +16,9 @@
 //    arrangement of the 64 points of a k-step works as long as u and v use the same one.
 //
 // LDS tile of 256 points, 24 KiB: T4[set 0..3][limb 0..3][k-step 0..3][nibble index 0..7][8 words], a word = that nibble
-// of the limb for eight points; W3[set][limb pair 0..1][k-step][nibble index][8 words].  A reader lane (row i, k half)
-// takes the 16 bytes at nibble index i >> 2, words 4 * khalf ..: eight lanes broadcast each chunk.
+// of the limb for eight points; W3[set][limb pair 0..1][k-step][nibble index][8 words]; inside a 64-word block the 16-byte
+// chunk of (nibble index c, k half) sits at chunk c + 8 * khalf (conflict-free for the staging writes and the operand
+// reads alike, PMC-checked).  A reader lane (row i, k half) takes the chunk of nibble index i >> 2: lanes broadcast.
 // Staging: lane = point.  The 8 x 8 nibble transpose across eight lanes is three exchanges -- 16-bit halves with lane
 // 7 - j (DPP row_half_mirror), bytes with lane j ^ 1, nibbles with lane j ^ 2 (DPP quad_perm) -- the upper four lanes
 // taking their decisions from the mirrored index so that every lane ends up with the same point order.
@@ -53,8 +54,12 @@ __device__ __forceinline__ stage4_role make_stage4_role()
 	r.keep3 = (jj & 2) ? 0xF0F0F0F0u : 0x0F0F0F0Fu;
 	const unsigned cidx = (j < 4 ? 0u : 4u) + ((jj & 1) << 1) + ((jj >> 1) & 1); // the nibble index lane j ends up holding
 	const unsigned g = tid >> 3;
-	r.st_off = (g >> 3) * 64 + cidx * 8 + (g & 7);
-	r.st_off3 = (g >> 3) * 64 + ((cidx * 8 + (g & 7) + 32) & 63);
+	// inside a 64-word block: 16-byte chunk (nibble index + 8 * k half), word = point group & 3.  The 32 lanes of a half wave
+	// (eight nibble indices x four point groups) then write 32 consecutive banks; the bit-3 words sit four chunks further
+	// round (mod 8), see make_gram4_role.
+	const unsigned gq = g & 7;
+	r.st_off = (g >> 3) * 64 + (cidx + 8 * (gq >> 2)) * 4 + (gq & 3);
+	r.st_off3 = (g >> 3) * 64 + (((cidx + 4) & 7) + 8 * (gq >> 2)) * 4 + (gq & 3);
 	return r;
 }
 
@@ -97,9 +102,9 @@ __device__ __forceinline__ gram4_role make_gram4_role(unsigned wave, unsigned la
 	g.pr = wave >> 1;
 	g.h = wave & 1;
 	const unsigned i = lane & 31, kh = lane >> 5, c = i >> 2, s = i & 3;
-	// (the bit-3 words sit half a block further inside their 256-byte block than the data words of the same nibble index: a
-	// group of 16 lanes -- 12 data readers, 4 bit-3 readers -- then touches 8 distinct 16-byte chunks in 8 distinct bank groups)
-	const unsigned in_blk = s < 3 ? c * 8 + kh * 4 : ((c * 8 + kh * 4 + 32) & 63);
+	// (a group of 16 lanes -- 12 data readers of four nibble indices, 4 bit-3 readers -- touches 8 distinct 16-byte chunks in 8
+	// distinct bank groups: the bit-3 chunk of nibble index c sits where the data chunk of c + 4 would)
+	const unsigned in_blk = s < 3 ? (c + 8 * kh) * 4 : (((c + 4) & 7) + 8 * kh) * 4;
 	const unsigned us = 2 * g.pr, vs = 2 * g.pr + 1;
 #pragma unroll
 	for (unsigned w = 0; w < 4; w++)
