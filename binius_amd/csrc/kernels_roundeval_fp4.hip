@@ -133,61 +133,41 @@ __device__ __forceinline__ void acc4_zero(v16f (&acc)[kAccTiles])
 	acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(v8i{(A).x, (A).y, (A).z, (A).w, 0, 0, 0, 0}, v8i{(B).x, (B).y, (B).z, (B).w, 0, 0, 0, 0}, \
 	                                                         acc[t], 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F)
 
-// One k-step (64 points): 6 ds_read_b128, 36 bitwise VALU, 6 MFMAs; the operands of k-step ks + 1 are requested before the
-// MFMAs of k-step ks are issued (second register set).
-struct gram4_pipe {
-	v4i u[4], v[2];
-};
-__device__ __forceinline__ void gram4_load(const uint32_t *T, const gram4_role &g, int ks, v4i (&u)[4], v4i (&v)[2])
+// One k-step (64 points): 6 ds_read_b128, 36 bitwise VALU, 6 MFMAs.  No second operand register set (three waves per SIMD
+// at <= 168 registers hide the LDS latency of a k-step better than a prefetch at two waves does).
+template <int KS>
+__device__ __forceinline__ void gram4_step(const uint32_t *T, const gram4_role &g, v16f (&acc)[kAccTiles])
 {
+	v4i u[4], v[2];
 #pragma unroll
 	for (int w = 0; w < 4; w++)
-		u[w] = *reinterpret_cast<const v4i *>(T + g.u_off[w] + ks * 64);
-	v[0] = *reinterpret_cast<const v4i *>(T + g.v_off[0] + ks * 64);
-	v[1] = *reinterpret_cast<const v4i *>(T + g.v_off[1] + ks * 64);
-}
-template <int KS>
-__device__ __forceinline__ void gram4_step(const uint32_t *T, const gram4_role &g, gram4_pipe &p, v16f (&acc)[kAccTiles])
-{
-	v4i un[4], vn[2];
-	if (KS < 3) {
-		gram4_load(T, g, KS + 1, un, vn);
-		asm volatile("" ::: "memory");
-		__builtin_amdgcn_sched_barrier(0);
-	}
+		u[w] = *reinterpret_cast<const v4i *>(T + g.u_off[w] + KS * 64);
+	v[0] = *reinterpret_cast<const v4i *>(T + g.v_off[0] + KS * 64);
+	v[1] = *reinterpret_cast<const v4i *>(T + g.v_off[1] + KS * 64);
 	const uint32_t me = g.m_even, mo = g.m_odd, mh = g.h ? mo : me;
 	{
-		const v4i B = and4(p.v[0], mh);
-		BN_GRAM4_MFMA(0, and4(p.u[0], me), B);
-		BN_GRAM4_MFMA(1, and4(p.u[1], mo), B);
+		const v4i B = and4(v[0], mh);
+		BN_GRAM4_MFMA(0, and4(u[0], me), B);
+		BN_GRAM4_MFMA(1, and4(u[1], mo), B);
 	}
 	{
-		const v4i B = and4(p.v[1], mh);
-		BN_GRAM4_MFMA(2, and4(p.u[2], me), B);
-		BN_GRAM4_MFMA(3, and4(p.u[3], mo), B);
+		const v4i B = and4(v[1], mh);
+		BN_GRAM4_MFMA(2, and4(u[2], me), B);
+		BN_GRAM4_MFMA(3, and4(u[3], mo), B);
 	}
 	{
-		const v4i B = xand4(p.v[0], p.v[1], mh);
-		BN_GRAM4_MFMA(4, xand4(p.u[0], p.u[2], me), B);
-		BN_GRAM4_MFMA(5, xand4(p.u[1], p.u[3], mo), B);
+		const v4i B = xand4(v[0], v[1], mh);
+		BN_GRAM4_MFMA(4, xand4(u[0], u[2], me), B);
+		BN_GRAM4_MFMA(5, xand4(u[1], u[3], mo), B);
 	}
-	if (KS < 3) {
-		__builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-		for (int w = 0; w < 4; w++)
-			p.u[w] = un[w];
-		p.v[0] = vn[0];
-		p.v[1] = vn[1];
-	}
+	__builtin_amdgcn_sched_barrier(0);
 }
 __device__ __forceinline__ void gram4_tile(const uint32_t *T, const gram4_role &g, v16f (&acc)[kAccTiles])
 {
-	gram4_pipe p;
-	gram4_load(T, g, 0, p.u, p.v);
-	gram4_step<0>(T, g, p, acc);
-	gram4_step<1>(T, g, p, acc);
-	gram4_step<2>(T, g, p, acc);
-	gram4_step<3>(T, g, p, acc);
+	gram4_step<0>(T, g, acc);
+	gram4_step<1>(T, g, acc);
+	gram4_step<2>(T, g, acc);
+	gram4_step<3>(T, g, acc);
 }
 
 // parity bits out of the f32 accumulators, then the common tail.  Register r of a tile is row (r & 3) + 8 (r >> 2) +
@@ -219,7 +199,7 @@ __device__ __forceinline__ void tail4(const v16f (&acc)[kAccTiles], const gram4_
 // spilled registers in three shapes).  48 KiB of raw elements + the 24 KiB operand tile per workgroup, two workgroups
 // per CU; per tile two barriers: raw -> operand tile (VALU), then the Gram k-steps (matrix pipe) -- the two workgroups
 // of a CU interleave the two phases.
-constexpr int kRawSlots = 3;
+constexpr int kRawSlots = 1;
 #ifdef BN_FP4_PHASES
 __device__ unsigned long long fp4_phase_cycles[8];
 #define FP4_CLK(i)                                                 \
@@ -231,7 +211,7 @@ __device__ unsigned long long fp4_phase_cycles[8];
 #else
 #define FP4_CLK(i)
 #endif
-__global__ __launch_bounds__(256, 2) void k_roundeval_fp4(const uint4 *__restrict__ a_hi, const uint4 *__restrict__ a_lo,
+__global__ __launch_bounds__(256, 3) void k_roundeval_fp4(const uint4 *__restrict__ a_hi, const uint4 *__restrict__ a_lo,
                                                           const uint4 *__restrict__ b_hi, const uint4 *__restrict__ b_lo, uint64_t n, f128 *out,
                                                           fin_fuse fz, uint32_t xcd_tiles)
 {
@@ -272,56 +252,40 @@ __global__ __launch_bounds__(256, 2) void k_roundeval_fp4(const uint4 *__restric
 	// workgroup barrier that waits for this wave's LDS traffic only (not for the LDS-DMA loads in flight)
 	auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
-	uint64_t t = t0;
-#pragma unroll
-	for (int k = 0; k < kRawSlots; k++)
-		if (t + k * tstride < n_tiles) fetch(t + k * tstride, k);
-	unsigned slot = 0;
-#ifdef BN_FP4_PHASES
-	unsigned long long last_ = clock64();
-#endif
-	for (; t < n_tiles; t += tstride) {
-		// the loads of tile t are the oldest outstanding ones of this wave: wait for them, not for the younger tiles'
-		const unsigned younger = (t + tstride < n_tiles ? 1u : 0u) + (t + 2 * tstride < n_tiles ? 1u : 0u);
-		if (younger == 2)
-			asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-		else if (younger == 1)
-			asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-		else
+	// tile t out of the raw slot into registers (each wave reads what its own lanes fetched), zeros past the end; the slot is
+	// refilled at once with the tile after it, which then has a whole iteration to arrive
+	uint4 x[4];
+	auto take = [&](uint64_t tt) {
+		if (tt < n_tiles) {
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-		FP4_CLK(0);
-		lds_barrier(); // raw[slot] complete (every wave waited for its own part); the previous tile's k-steps are done with T
-		FP4_CLK(1);
-#ifndef BN_FP4_ONLY_LOADS
-		{
-			uint4 x[4];
 #pragma unroll
 			for (int k = 0; k < 4; k++)
-				x[k] = raw[slot][k][threadIdx.x];
-			if ((tbase + t + 1) * kTP > n) { // (uniform) the ragged last tile: lanes past the end contribute zeros
-				if ((tbase + t) * kTP + threadIdx.x >= n) {
+				x[k] = raw[0][k][threadIdx.x];
+			if ((tbase + tt + 1) * kTP > n) { // (uniform) the ragged last tile: lanes past the end contribute zeros
+				if ((tbase + tt) * kTP + threadIdx.x >= n) {
 #pragma unroll
 					for (int k = 0; k < 4; k++)
 						x[k] = uint4{0, 0, 0, 0};
 				}
 			}
-			stage4_elem(T, sr, 0, x[0]);
-			stage4_elem(T, sr, 2, uint4{x[0].x ^ x[1].x, x[0].y ^ x[1].y, x[0].z ^ x[1].z, x[0].w ^ x[1].w});
-			stage4_elem(T, sr, 1, x[2]);
-			stage4_elem(T, sr, 3, uint4{x[2].x ^ x[3].x, x[2].y ^ x[3].y, x[2].z ^ x[3].z, x[2].w ^ x[3].w});
+			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+			if (tt + tstride < n_tiles) fetch(tt + tstride, 0);
 		}
-#endif
-		// this wave has read its part of raw[slot] (its own lanes' points only): refill it with the tile three ahead
-		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-		FP4_CLK(2);
-		if (t + kRawSlots * tstride < n_tiles) fetch(t + kRawSlots * tstride, slot);
+	};
+	uint64_t t = t0;
+	if (t < n_tiles) {
+		fetch(t, 0);
+		take(t);
+	}
+	for (; t < n_tiles; t += tstride) {
+		lds_barrier(); // the previous tile's k-steps are done with T
+		stage4_elem(T, sr, 0, x[0]);
+		stage4_elem(T, sr, 2, uint4{x[0].x ^ x[1].x, x[0].y ^ x[1].y, x[0].z ^ x[1].z, x[0].w ^ x[1].w});
+		stage4_elem(T, sr, 1, x[2]);
+		stage4_elem(T, sr, 3, uint4{x[2].x ^ x[3].x, x[2].y ^ x[3].y, x[2].z ^ x[3].z, x[2].w ^ x[3].w});
 		lds_barrier(); // T staged
-		FP4_CLK(3);
-#ifndef BN_FP4_ONLY_LOADS
 		gram4_tile(T, gr, acc);
-#endif
-		FP4_CLK(4);
-		slot = slot == kRawSlots - 1 ? 0 : slot + 1;
+		take(t + tstride);
 	}
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	__syncthreads();
@@ -336,7 +300,7 @@ hipError_t launch_roundeval_fp4_pair(hipStream_t s, int n_cu, const void *a_hi, 
 	if (fuse) fz = *fuse;
 	if (n == 0) return hipErrorNotSupported;
 	const uint64_t n_tiles = (n + kTP - 1) / kTP;
-	const uint64_t cap = (uint64_t)n_cu * 2;
+	const uint64_t cap = (uint64_t)n_cu * 3; // three workgroups per CU (47 KiB of LDS, <= 168 registers)
 	const unsigned grid = (unsigned)(n_tiles < cap ? n_tiles : cap);
 	if ((n_tiles + grid - 1) / grid > (1ull << 14)) return hipErrorNotSupported; // 2^22 points per workgroup: the f32 counts stay exact
 	static const uint32_t xcd_tiles = [] {
