@@ -777,7 +777,7 @@ def test_scaled_fold_followed_by_round_evaluation(hal, oracle, log_n, mask):
 
 
 def test_fp4_matrix_path_on_the_small_shapes():
-    """Round evaluations of 2^25 points and more run on the FP4 matrix path (csrc/kernels_roundeval_fp4.hip: E2M1
+    """Round evaluations of 2^20 points and more run on the FP4 matrix path (csrc/kernels_roundeval_fp4.hip: E2M1
     operands, f32 counts, element loads through LDS).  At those sizes it is checked by the bench's own bit-exact check and
     by test_gpu_at_size; here the same parity tests once more with the switch at zero (BN_FP4_MIN_LOG2=0: every
     matrix-core round evaluation, ragged sizes included), in a fresh process because the switch is read once."""
