@@ -226,6 +226,7 @@ hipError_t launch_roundeval_mfma_pair(hipStream_t s, int n_cu, const void *a_hi,
 // the same sums on the FP4 matrix path (kernels_roundeval_fp4.hip): round 0 of a sumcheck
 hipError_t launch_roundeval_fp4_pair(hipStream_t s, int n_cu, const void *a_hi, const void *a_lo, const void *b_hi, const void *b_lo,
                                      uint64_t n, f128 *d_out, const fin_fuse *fuse);
+hipError_t launch_roundeval_fp4_split(hipStream_t s, int n_cu, const void *a, const void *b, uint64_t n, uint64_t split_off, f128 *d_out);
 hipError_t launch_roundeval_mfma_split(hipStream_t s, int n_cu, const void *a, const void *b, uint64_t n, uint64_t split_off, f128 *d_out);
 hipError_t launch_foldeval_mfma(hipStream_t s, int n_cu, const foldeval_args &fa, uint64_t n_in, f128 z, f128 *d_out, const fin_fuse *fuse,
                                 const arm_args *armed = nullptr);

@@ -211,6 +211,9 @@ __device__ unsigned long long fp4_phase_cycles[8];
 #else
 #define FP4_CLK(i)
 #endif
+// MIX: the second pair of sets holds hi ^ lo (evaluation at infinity); otherwise lo itself (two independent products: the
+// two halves of an inner product).
+template <bool MIX>
 __global__ __launch_bounds__(256, 3) void k_roundeval_fp4(const uint4 *__restrict__ a_hi, const uint4 *__restrict__ a_lo,
                                                           const uint4 *__restrict__ b_hi, const uint4 *__restrict__ b_lo, uint64_t n, f128 *out,
                                                           fin_fuse fz, uint32_t xcd_tiles)
@@ -280,9 +283,9 @@ __global__ __launch_bounds__(256, 3) void k_roundeval_fp4(const uint4 *__restric
 	for (; t < n_tiles; t += tstride) {
 		lds_barrier(); // the previous tile's k-steps are done with T
 		stage4_elem(T, sr, 0, x[0]);
-		stage4_elem(T, sr, 2, uint4{x[0].x ^ x[1].x, x[0].y ^ x[1].y, x[0].z ^ x[1].z, x[0].w ^ x[1].w});
+		stage4_elem(T, sr, 2, MIX ? uint4{x[0].x ^ x[1].x, x[0].y ^ x[1].y, x[0].z ^ x[1].z, x[0].w ^ x[1].w} : x[1]);
 		stage4_elem(T, sr, 1, x[2]);
-		stage4_elem(T, sr, 3, uint4{x[2].x ^ x[3].x, x[2].y ^ x[3].y, x[2].z ^ x[3].z, x[2].w ^ x[3].w});
+		stage4_elem(T, sr, 3, MIX ? uint4{x[2].x ^ x[3].x, x[2].y ^ x[3].y, x[2].z ^ x[3].z, x[2].w ^ x[3].w} : x[3]);
 		lds_barrier(); // T staged
 		gram4_tile(T, gr, acc);
 		take(t + tstride);
@@ -292,9 +295,9 @@ __global__ __launch_bounds__(256, 3) void k_roundeval_fp4(const uint4 *__restric
 	tail4(acc, gr, wave, lane, out, fz, fz.args.seq);
 }
 
-// d_out[0] ^= sum_i a_hi[i]*b_hi[i] ; d_out[1] ^= sum_i (a_lo[i]^a_hi[i])*(b_lo[i]^b_hi[i])
-hipError_t launch_roundeval_fp4_pair(hipStream_t s, int n_cu, const void *a_hi, const void *a_lo, const void *b_hi, const void *b_lo, uint64_t n,
-                                     f128 *d_out, const fin_fuse *fuse)
+template <bool MIX>
+static hipError_t launch_fp4(hipStream_t s, int n_cu, const void *a_hi, const void *a_lo, const void *b_hi, const void *b_lo, uint64_t n, f128 *d_out,
+                             const fin_fuse *fuse)
 {
 	fin_fuse fz{};
 	if (fuse) fz = *fuse;
@@ -307,9 +310,23 @@ hipError_t launch_roundeval_fp4_pair(hipStream_t s, int n_cu, const void *a_hi, 
 		const char *e = getenv("BN_XCD_TILES");
 		return (uint32_t)!(e && e[0] == '0');
 	}();
-	hipLaunchKernelGGL(k_roundeval_fp4, dim3(grid), dim3(256), 0, s, (const uint4 *)a_hi, (const uint4 *)a_lo, (const uint4 *)b_hi,
+	hipLaunchKernelGGL(k_roundeval_fp4<MIX>, dim3(grid), dim3(256), 0, s, (const uint4 *)a_hi, (const uint4 *)a_lo, (const uint4 *)b_hi,
 	                   (const uint4 *)b_lo, n, d_out, fz, xcd_tiles);
 	return hipGetLastError();
+}
+
+// d_out[0] ^= sum_i a_hi[i]*b_hi[i] ; d_out[1] ^= sum_i (a_lo[i]^a_hi[i])*(b_lo[i]^b_hi[i])
+hipError_t launch_roundeval_fp4_pair(hipStream_t s, int n_cu, const void *a_hi, const void *a_lo, const void *b_hi, const void *b_lo, uint64_t n,
+                                     f128 *d_out, const fin_fuse *fuse)
+{
+	return launch_fp4<true>(s, n_cu, a_hi, a_lo, b_hi, b_lo, n, d_out, fuse);
+}
+
+// d_out[0] ^= sum_{i<n} a[i]*b[i] ; d_out[1] ^= sum_{i<n} a[i+split]*b[i+split]
+hipError_t launch_roundeval_fp4_split(hipStream_t s, int n_cu, const void *a, const void *b, uint64_t n, uint64_t split_off, f128 *d_out)
+{
+	const char *a2 = (const char *)a + split_off * 16, *b2 = (const char *)b + split_off * 16;
+	return launch_fp4<false>(s, n_cu, a, a2, b, b2, n, d_out, nullptr);
 }
 
 } // namespace bn

@@ -135,20 +135,25 @@ static hipError_t launch_mfma(hipStream_t s, int n_cu, const void *a_hi, const v
 	return hipGetLastError();
 }
 
-// d_out[0] ^= sum_i a_hi[i]*b_hi[i] ; d_out[1] ^= sum_i (a_lo[i]^a_hi[i])*(b_lo[i]^b_hi[i])
-hipError_t launch_roundeval_mfma_pair(hipStream_t s, int n_cu, const void *a_hi, const void *a_lo, const void *b_hi, const void *b_lo,
-                                      uint64_t n, f128 *d_out, const fin_fuse *fuse)
+// Evaluations of 2^20 points and more go to the FP4 matrix path (kernels_roundeval_fp4.hip): twice the k-depth per
+// instruction, half the operand masks per point, element loads through LDS-DMA, three workgroups per CU.  BN_FP4=0: the int8
+// kernel at every size; BN_FP4_MIN_LOG2: smallest log2(points) for the FP4 kernel.
+static bool fp4_applies(uint64_t n)
 {
-	// large evaluations (round 0 of a big sumcheck) go to the FP4 matrix path: twice the k-depth per instruction and three
-	// tiles of loads in flight through LDS (kernels_roundeval_fp4.hip).  BN_FP4=0: the int8 kernel at every size;
-	// BN_FP4_MIN_LOG2: smallest log2(points) for the FP4 kernel.
 	static const int fp4_min_log2 = [] {
 		const char *e = getenv("BN_FP4");
 		if (e && e[0] == '0') return 64;
 		const char *m = getenv("BN_FP4_MIN_LOG2");
 		return m ? atoi(m) : 20; // measured: equal at 2^19 points, 10 - 25 % faster from 2^20 on (profiles/r02/fp4_crossover.txt)
 	}();
-	if (fp4_min_log2 < 64 && n >= ((uint64_t)1 << fp4_min_log2)) {
+	return fp4_min_log2 < 64 && n >= ((uint64_t)1 << fp4_min_log2);
+}
+
+// d_out[0] ^= sum_i a_hi[i]*b_hi[i] ; d_out[1] ^= sum_i (a_lo[i]^a_hi[i])*(b_lo[i]^b_hi[i])
+hipError_t launch_roundeval_mfma_pair(hipStream_t s, int n_cu, const void *a_hi, const void *a_lo, const void *b_hi, const void *b_lo,
+                                      uint64_t n, f128 *d_out, const fin_fuse *fuse)
+{
+	if (fp4_applies(n)) {
 		const hipError_t e = launch_roundeval_fp4_pair(s, n_cu, a_hi, a_lo, b_hi, b_lo, n, d_out, fuse);
 		if (e != hipErrorNotSupported) return e;
 	}
@@ -158,6 +163,10 @@ hipError_t launch_roundeval_mfma_pair(hipStream_t s, int n_cu, const void *a_hi,
 // d_out[0] ^= sum_{i<n} a[i]*b[i] ; d_out[1] ^= sum_{i<n} a[i+split]*b[i+split]
 hipError_t launch_roundeval_mfma_split(hipStream_t s, int n_cu, const void *a, const void *b, uint64_t n, uint64_t split_off, f128 *d_out)
 {
+	if (fp4_applies(n)) {
+		const hipError_t e = launch_roundeval_fp4_split(s, n_cu, a, b, n, split_off, d_out);
+		if (e != hipErrorNotSupported) return e;
+	}
 	const char *a2 = (const char *)a + split_off * 16, *b2 = (const char *)b + split_off * 16;
 	return launch_mfma<true>(s, n_cu, a, a2, b, b2, n, d_out, nullptr);
 }

@@ -792,7 +792,7 @@ def test_fp4_matrix_path_on_the_small_shapes():
     p = subprocess.run(
         [sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_sumcheck.py"), os.path.join(root, "tests", "test_gpu_hal.py"),
          os.path.join(root, "tests", "test_gpu_at_size.py"), "-x", "-q", "-m", "gpu",
-         "-k", "calculate_round_evals or compiled_host_prover or compiled_sumcheck_plan_n20 or provers_agree_at_2p23 or fast_shape or routed or full_size"],
+         "-k", "calculate_round_evals or compiled_host_prover or compiled_sumcheck_plan_n20 or provers_agree_at_2p23 or fast_shape or routed or full_size or inner_product"],
         env=env, cwd=root, capture_output=True, text=True, timeout=1200,
     )
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
