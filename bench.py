@@ -268,7 +268,8 @@ def main():
     #   fold alone              24*m*2^r                                        (the last fold, r = 1)
     # The ABI decides per launch which kernel runs; the launch counts per class say what actually ran.
     # Classes (include/binius_amd.h BN_PROF_*), as rocprof lists the kernel symbols:
-    #   round_eval_mfma  k_roundeval_mfma   round 0 on the matrix cores        fold_eval_mfma   k_foldeval_mfma  (>= 2 tiles of 256 points per CU)
+    #   round_eval_mfma  k_roundeval_fp4 (>= 2^20 points: FP4 matrix path) / k_roundeval_mfma (int8; BN_FP4=0)   round 0 on the matrix cores
+    #                                                                          fold_eval_mfma   k_foldeval_mfma  (>= 2 tiles of 256 points per CU)
     #   round_eval       k_roundeval9       round 0, 9-lane VALU kernel        fold_eval        k_foldeval9<2>   (the next size down)
     #   fold             k_extrapolate_line / k_fold_publish (last fold)       fold_eval_small  k_foldeval9_small (one workgroup per batch: latency-shaped)
     #                                                                          tail             k_foldeval_tail  (resident; opt-in)
@@ -291,8 +292,10 @@ def main():
     else:
         re_bytes_each = None
         fold_bytes = sum(24 * (1 << r) for r in range(1, n_vars + 1)) * m * K
+    # round 0 has 2^(n_vars - 1) points: from 2^20 on it runs on the FP4 matrix path (csrc/kernels_roundeval_mfma.hip fp4_applies)
+    fp4_round0 = os.environ.get("BN_FP4", "1")[:1] != "0" and n_vars - 1 >= int(os.environ.get("BN_FP4_MIN_LOG2", "20"))
     label = {
-        "round_eval_mfma": "k_roundeval_mfma(round_eval)",
+        "round_eval_mfma": "k_roundeval_fp4(round_eval)" if fp4_round0 else "k_roundeval_mfma(round_eval)",
         "round_eval": "k_roundeval9(round_eval)",
         "fold": "k_extrapolate_line(fold)",
         "fold_eval_mfma": "k_foldeval_mfma(fold+round_eval)",
