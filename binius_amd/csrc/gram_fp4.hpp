@@ -1,0 +1,176 @@
+// binius_amd/csrc/gram_fp4.hpp -- the GF(2) Gram products of gram.hpp on the FP4 matrix path: operand encoding, staging
+// (nibble transpose), Gram k-steps and the parity read-out shared by kernels_roundeval_fp4.hip (round evaluation alone) and
+// the FP4 form of the fused fold + evaluation kernel (kernels_foldeval_mfma.hip).  The design notes are at the top of
+// kernels_roundeval_fp4.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "gram.hpp"
+
+namespace bn {
+namespace gram4 {
+
+using namespace gram;
+
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+constexpr int kT4W = 4096;         // words of the data part of a tile
+constexpr int kTile4W = 4096 + 2048; // + the bit-3 words
+
+struct stage4_role {
+	uint32_t sel1, sel2, rot3, keep3;
+	unsigned st_off;  // word offset of this lane's word inside a (set, limb) group: k-step, nibble index, point group
+	unsigned st_off3; // the same inside a (set, limb pair) group of bit-3 words (rotated by half a block, see make_gram4_role)
+};
+__device__ __forceinline__ stage4_role make_stage4_role()
+{
+	const unsigned tid = threadIdx.x;
+	const unsigned j = tid & 7, jj = j < 4 ? j : 7 - j;
+	stage4_role r;
+	r.sel1 = j < 4 ? 0x05040100u : 0x03020706u;
+	r.sel2 = (jj & 1) ? 0x03070105u : 0x06020400u;
+	r.rot3 = (jj & 2) ? 4u : 28u;
+	r.keep3 = (jj & 2) ? 0xF0F0F0F0u : 0x0F0F0F0Fu;
+	const unsigned cidx = (j < 4 ? 0u : 4u) + ((jj & 1) << 1) + ((jj >> 1) & 1); // the nibble index lane j ends up holding
+	const unsigned g = tid >> 3;
+	// inside a 64-word block: 16-byte chunk (nibble index + 8 * k half), word = point group & 3.  The 32 lanes of a half wave
+	// (eight nibble indices x four point groups) then write 32 consecutive banks; the bit-3 words sit four chunks further
+	// round (mod 8), see make_gram4_role.
+	const unsigned gq = g & 7;
+	r.st_off = (g >> 3) * 64 + (cidx + 8 * (gq >> 2)) * 4 + (gq & 3);
+	r.st_off3 = (g >> 3) * 64 + (((cidx + 4) & 7) + 8 * (gq >> 2)) * 4 + (gq & 3);
+	return r;
+}
+
+// word x of this lane's point -> the word whose nibble i is nibble c(j) of x in the i-th lane (fixed order) of the
+// group of eight; c(j) = [0, 2, 1, 3, 7, 5, 6, 4][j]
+__device__ __forceinline__ uint32_t nib_tr(uint32_t x, const stage4_role &sr)
+{
+	const uint32_t p1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x141, 0xF, 0xF, true); // row_half_mirror: lane 7 - j
+	const uint32_t a = __builtin_amdgcn_perm(p1, x, sr.sel1);
+	const uint32_t p2 = (uint32_t)__builtin_amdgcn_mov_dpp((int)a, 0xB1, 0xF, 0xF, true); // quad_perm [1,0,3,2]
+	const uint32_t b = __builtin_amdgcn_perm(p2, a, sr.sel2);
+	const uint32_t p3 = (uint32_t)__builtin_amdgcn_mov_dpp((int)b, 0x4E, 0xF, 0xF, true); // quad_perm [2,3,0,1]
+	const uint32_t rot = __builtin_amdgcn_alignbit(p3, p3, sr.rot3);
+	return __builtin_amdgcn_bitop3_b32(sr.keep3, b, rot, 0xCA); // (keep & b) | (~keep & rot)
+}
+
+// the four limbs of one element of set `set` -> four data words + two bit-3 words
+__device__ __forceinline__ void stage4_elem(uint32_t *T, const stage4_role &sr, unsigned set, uint4 e)
+{
+	uint32_t *dst = T + set * 1024 + sr.st_off;
+	const uint32_t y0 = nib_tr(e.x, sr), y1 = nib_tr(e.y, sr), y2 = nib_tr(e.z, sr), y3 = nib_tr(e.w, sr);
+	dst[0 * 256] = y0;
+	dst[1 * 256] = y1;
+	dst[2 * 256] = y2;
+	dst[3 * 256] = y3;
+	uint32_t *dw = T + kT4W + set * 512 + sr.st_off3;
+	dw[0] = ((y0 >> 1) & 0x44444444u) | ((y1 >> 2) & 0x22222222u);
+	dw[256] = ((y2 >> 1) & 0x44444444u) | ((y3 >> 2) & 0x22222222u);
+}
+
+struct gram4_role {
+	unsigned pr, h;
+	unsigned u_off[4], v_off[2]; // word offsets of this lane's 16 bytes, k-step 0: u limbs 0..3, v limbs h and 2 + h
+	uint32_t m_even, m_odd;      // masks for even / odd limbs (they differ only for the bit-3 rows)
+	int e_row[2], e_col;         // exponent of this lane's column weight; of a register's row weight: see tail4
+};
+__device__ __forceinline__ gram4_role make_gram4_role(unsigned wave, unsigned lane)
+{
+	gram4_role g;
+	g.pr = wave >> 1;
+	g.h = wave & 1;
+	const unsigned i = lane & 31, kh = lane >> 5, c = i >> 2, s = i & 3;
+	// (a group of 16 lanes -- 12 data readers of four nibble indices, 4 bit-3 readers -- touches 8 distinct 16-byte chunks in 8
+	// distinct bank groups: the bit-3 chunk of nibble index c sits where the data chunk of c + 4 would)
+	const unsigned in_blk = s < 3 ? (c + 8 * kh) * 4 : (((c + 4) & 7) + 8 * kh) * 4;
+	const unsigned us = 2 * g.pr, vs = 2 * g.pr + 1;
+#pragma unroll
+	for (unsigned w = 0; w < 4; w++)
+		g.u_off[w] = s < 3 ? us * 1024 + w * 256 + in_blk : kT4W + us * 512 + (w >> 1) * 256 + in_blk;
+#pragma unroll
+	for (unsigned q = 0; q < 2; q++) {
+		const unsigned w = g.h + 2 * q;
+		g.v_off[q] = s < 3 ? vs * 1024 + w * 256 + in_blk : kT4W + vs * 512 + (w >> 1) * 256 + in_blk;
+	}
+	g.m_even = s < 3 ? 0x11111111u << s : 0x44444444u;
+	g.m_odd = s < 3 ? 0x11111111u << s : 0x22222222u;
+	g.e_col = s < 3 ? (int)s - 1 : (g.h ? 0 : 1);
+	return g;
+}
+
+__device__ __forceinline__ void acc4_zero(v16f (&acc)[kAccTiles])
+{
+#pragma unroll
+	for (int t = 0; t < kAccTiles; t++)
+#pragma unroll
+		for (int r = 0; r < 16; r++)
+			acc[t][r] = 0.0f;
+}
+
+#define BN_GRAM4_MFMA(t, A, B)                                                                                                             \
+	acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(v8i{(A).x, (A).y, (A).z, (A).w, 0, 0, 0, 0}, v8i{(B).x, (B).y, (B).z, (B).w, 0, 0, 0, 0}, \
+	                                                         acc[t], 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F)
+
+// One k-step (64 points): 6 ds_read_b128, 36 bitwise VALU, 6 MFMAs.  No second operand register set (three waves per SIMD
+// at <= 168 registers hide the LDS latency of a k-step better than a prefetch at two waves does).
+template <int KS>
+__device__ __forceinline__ void gram4_step(const uint32_t *T, const gram4_role &g, v16f (&acc)[kAccTiles])
+{
+	v4i u[4], v[2];
+#pragma unroll
+	for (int w = 0; w < 4; w++)
+		u[w] = *reinterpret_cast<const v4i *>(T + g.u_off[w] + KS * 64);
+	v[0] = *reinterpret_cast<const v4i *>(T + g.v_off[0] + KS * 64);
+	v[1] = *reinterpret_cast<const v4i *>(T + g.v_off[1] + KS * 64);
+	const uint32_t me = g.m_even, mo = g.m_odd, mh = g.h ? mo : me;
+	{
+		const v4i B = and4(v[0], mh);
+		BN_GRAM4_MFMA(0, and4(u[0], me), B);
+		BN_GRAM4_MFMA(1, and4(u[1], mo), B);
+	}
+	{
+		const v4i B = and4(v[1], mh);
+		BN_GRAM4_MFMA(2, and4(u[2], me), B);
+		BN_GRAM4_MFMA(3, and4(u[3], mo), B);
+	}
+	{
+		const v4i B = xand4(v[0], v[1], mh);
+		BN_GRAM4_MFMA(4, xand4(u[0], u[2], me), B);
+		BN_GRAM4_MFMA(5, xand4(u[1], u[3], mo), B);
+	}
+	__builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void gram4_tile(const uint32_t *T, const gram4_role &g, v16f (&acc)[kAccTiles])
+{
+	gram4_step<0>(T, g, acc);
+	gram4_step<1>(T, g, acc);
+	gram4_step<2>(T, g, acc);
+	gram4_step<3>(T, g, acc);
+}
+
+// parity bits out of the f32 accumulators, then the common tail.  Register r of a tile is row (r & 3) + 8 (r >> 2) +
+// 4 (lane >> 5): its bit position inside the nibble is r & 3; tile t = 2 s + i has rows from an even (i = 0) or odd limb.
+__device__ __forceinline__ void tail4(const v16f (&acc)[kAccTiles], const gram4_role &g, unsigned wave, unsigned lane, f128 *out,
+                                      const fin_fuse &fz, uint64_t seq, const fin_cache *fc = nullptr)
+{
+	__shared__ gram_parity Gc;
+#pragma unroll
+	for (int t = 0; t < kAccTiles; t++) {
+		uint32_t v = 0;
+#pragma unroll
+		for (int r = 0; r < 16; r++) {
+			const int sr = r & 3;
+			const int e_row = sr < 3 ? sr - 1 : ((t & 1) ? 0 : 1);
+			const int cnt = (int)__builtin_amdgcn_ldexpf(acc[t][r], -(e_row + g.e_col));
+			v |= ((uint32_t)cnt & 1u) << r;
+		}
+		Gc[wave][t][lane] = v;
+	}
+	tail_finish(Gc, wave, lane, out, fz, seq, fc);
+}
+
+
+} // namespace gram4
+} // namespace bn

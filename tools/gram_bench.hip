@@ -11,6 +11,22 @@
 
 using namespace bn;
 
+// every element different (SplitMix64 of its index)
+__global__ void k_fill_random(f128 *p, uint64_t n, uint64_t seed)
+{
+	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+		uint64_t z = seed + 2 * i * 0x9E3779B97F4A7C15ull, w[2];
+		for (int k = 0; k < 2; k++) {
+			z += 0x9E3779B97F4A7C15ull;
+			uint64_t x = z;
+			x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+			x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+			w[k] = x ^ (x >> 31);
+		}
+		p[i] = f128{w[0], w[1]};
+	}
+}
+
 static uint64_t sm64(uint64_t &s)
 {
 	uint64_t z = (s += 0x9E3779B97F4A7C15ull);
@@ -31,10 +47,24 @@ int main(int argc, char **argv)
 	for (int k = 0; k < 4; k++) {
 		h[k].resize(n_host);
 		for (uint64_t i = 0; i < n_host; i++) h[k][i] = f128{sm64(seed), sm64(seed)};
-		(void)hipMalloc(&d[k], n * 16);
+		// GRAM_ONE_ARENA=1: the four arrays back to back in ONE allocation (the way a prover's arena lays them out)
+		static f128 *arena = nullptr;
+		if (getenv("GRAM_ONE_ARENA")) {
+			if (!arena) (void)hipMalloc(&arena, 4 * n * 16);
+			d[k] = arena + k * n;
+		} else {
+			(void)hipMalloc(&d[k], n * 16);
+		}
 		for (uint64_t off = 0; off < n; off += n_host) // repeat the host block
 			(void)hipMemcpy(d[k] + off, h[k].data(), n_host * 16, hipMemcpyHostToDevice);
 	}
+	// Beyond the host block the arrays are filled on the device with distinct values.  (Until late in round 2 the host block
+	// was simply repeated: then x[i] == x[i + N/2] for every N/2 that is a multiple of the block, the fused kernel folds
+	// x0 + z * 0, every table lookup of the constant multiplication hits entry 0 -- one broadcast -- and the kernel looks
+	// 15 % faster than it is on a prover's data.  GRAM_REPEAT=1 brings that data back.)
+	if (!getenv("GRAM_REPEAT") && n > n_host)
+		for (int k = 0; k < 4; k++)
+			hipLaunchKernelGGL(k_fill_random, dim3(4096), dim3(256), 0, 0, d[k] + n_host, n - n_host, 0x1234567ull * (k + 1));
 	f128 *d_out;
 	(void)hipMalloc(&d_out, 32);
 	int bad = 0;
@@ -175,6 +205,41 @@ int main(int argc, char **argv)
 			float ms;
 			(void)hipEventElapsedTime(&ms, ea, eb);
 			printf("fused N=2^%d: %.3f ms  %.2f TB/s algorithmic (48 B/element)\n", log_n, ms, n * 48.0 / ms * 1e-9);
+		}
+		if (argc > 4) {
+			// interleaved with the round-evaluation kernel, the way a step of the prover alternates them: does one kernel's
+			// power draw cost the next one its clock?
+			hipEvent_t e[4];
+			for (auto &x : e) (void)hipEventCreate(&x);
+			for (int it = 0; it < atoi(argv[4]); it++) {
+				(void)hipEventRecord(e[0]);
+				(void)launch_roundeval_fp4_pair(0, 256, d[0], d[1], d[2], d[3], n, d_out, nullptr);
+				(void)hipEventRecord(e[1]);
+				(void)launch_foldeval_mfma(0, 256, fa, n, z, d_out, nullptr);
+				(void)hipEventRecord(e[2]);
+				(void)launch_foldeval_mfma(0, 256, fa, n, z, d_out, nullptr);
+				(void)hipEventRecord(e[3]);
+				(void)hipEventSynchronize(e[3]);
+				float m0, m1, m2;
+				(void)hipEventElapsedTime(&m0, e[0], e[1]);
+				(void)hipEventElapsedTime(&m1, e[1], e[2]);
+				(void)hipEventElapsedTime(&m2, e[2], e[3]);
+				printf("interleaved %d: fp4 round eval %.3f ms, fused %.3f ms, fused again %.3f ms\n", it, m0, m1, m2);
+			}
+		}
+		if (argc > 3) {
+			// sustained: argv[3] launches back to back (the way a prover issues them), ten at a time between two events -- does
+			// the rate of the isolated launches above hold once the chip has been busy for a while?
+			const int reps = atoi(argv[3]);
+			for (int blk = 0; blk < reps / 10; blk++) {
+				(void)hipEventRecord(ea);
+				for (int r = 0; r < 10; r++) (void)launch_foldeval_mfma(0, 256, fa, n, z, d_out, nullptr);
+				(void)hipEventRecord(eb);
+				(void)hipEventSynchronize(eb);
+				float ms;
+				(void)hipEventElapsedTime(&ms, ea, eb);
+				printf("fused N=2^%d sustained, launches %d..%d: %.3f ms each  %.2f TB/s\n", log_n, 10 * blk, 10 * blk + 9, ms / 10, n * 48.0 / (ms / 10) * 1e-9);
+			}
 		}
 	}
 	printf("%s\n", bad ? "FAILED" : "ALL OK");
