@@ -162,6 +162,30 @@ def test_compiled_sumcheck_plan_n20(hal, oracle):
         assert np.array_equal(hal.copy_d2h(d[j]), mls[j])  # PreFold inputs are never modified
 
 
+def test_compiled_sumcheck_plan_n22_fp4_round0(oracle):
+    """From 2^20 points a round evaluation runs on the FP4 matrix path (csrc/kernels_roundeval_fp4.hip); at n = 22 that is
+    round 0 (2^21 points) and round 1's inner evaluation of the claim below (2^21 points per half).  The whole transcript
+    against the oracle's prover."""
+    import binius_amd
+    from binius_amd._host import SumcheckPlan
+
+    n_vars, m, comps = 22, 2, [(0, 1)]
+    with binius_amd.Context(0, 4 << n_vars) as hal:
+        alloc = hal.dev_alloc()
+        mls = [rnd(oracle, 0xF4F40000 + j, 1 << n_vars) for j in range(m)]
+        d = [upload(hal, alloc, x) for x in mls]
+        scratch = alloc.alloc(m * (1 << n_vars) // 2)
+        claim = hal.inner_product(d[0], 7, d[1])  # 2^21 points per half: the FP4 kernel's split form
+        assert claim == oracle.inner_product(mls[0], 7, mls[1])[1]
+        stream = oracle.random_scalars(0xC4A1, n_vars + 1)
+        batch_coeff, challenges = stream[0], stream[1:]
+        plan = SumcheckPlan(hal, n_vars, d, scratch, comps, [claim], batch_coeff, challenges)
+        plan.run()
+        want_coeffs, want_final = oracle.bivariate_sumcheck_prove([x.copy() for x in mls], n_vars, comps, [claim], batch_coeff, challenges, threads=8)
+        assert plan.round_coeffs() == want_coeffs
+        assert plan.final_evals() == want_final
+
+
 def test_compiled_mlecheck_plan_n20(hal, oracle):
     from binius_amd._host import MlecheckPlan
     from binius_amd.sumcheck import eq_ind_partial_eval
