@@ -46,6 +46,42 @@ int bn_pick_log_chunks(const bn_memmap *maps, uint32_t n_maps, uint32_t *log_chu
 }
 
 namespace {
+// a * b * eq at prover sizes (the MLE-check round evaluation an unchanged BivariateMLEcheckProver records,
+// v3/bivariate_mlecheck.rs:391-520).  The three-factor 9-lane kernel pays two chained bit-sliced products per point
+// (0.11 of the roofline); the product is linear in b, so two element-wise passes fold the indicator into b --
+// t1 = b_hi * eq, t2 = b_lo * eq, (b_lo + b_hi) * eq = t1 + t2 -- and the bivariate matrix-core kernel does the rest:
+// S_1 = sum a_hi * t1, S_inf = sum (a_lo + a_hi) * (t2 + t1).  2 * n elements of context scratch (not while Local
+// buffers live there); BN_EQ_ROUTE=0 keeps the three-factor kernel.
+hipError_t roundeval_product_routed(bn_ctx *ctx, bool scratch_free, const void *const *hi, const void *const *lo, uint32_t k, uint64_t n,
+                                    f128 *d_out, const bn::fin_fuse *fuse)
+{
+	static const bool route = [] {
+		const char *e = getenv("BN_EQ_ROUTE");
+		return !(e && e[0] == '0');
+	}();
+	if (route && scratch_free && k == 3 && n >= (1ull << 20) && bn::mfma_applies(ctx->n_cu, n)) {
+		int same = -1, n_same = 0;
+		for (int j = 0; j < 3; j++)
+			if (!lo[j]) {
+				same = j;
+				n_same++;
+			}
+		if (n_same == 1) {
+			const int x = (same + 1) % 3, y = (same + 2) % 3;
+			char *t = (char *)bn::ctx_scratch(ctx, 2 * n * sizeof(f128));
+			if (t) {
+				void *t1 = t, *t2 = t + n * sizeof(f128);
+				hipError_t e = bn::launch_mul9(ctx->stream, ctx->n_cu, hi[y], 1, hi[same], 1, 0, t1, n);
+				if (e != hipSuccess) return e;
+				e = bn::launch_mul9(ctx->stream, ctx->n_cu, lo[y], 1, hi[same], 1, 0, t2, n);
+				if (e != hipSuccess) return e;
+				return bn::launch_roundeval_mfma_pair(ctx->stream, ctx->n_cu, hi[x], lo[x], t1, t2, n, d_out, fuse);
+			}
+		}
+	}
+	return bn::launch_roundeval_product(ctx->stream, ctx->n_cu, hi, lo, k, n, d_out, fuse);
+}
+
 constexpr uint64_t kArmMaxIn = 1ull << 19;     // largest round (elements per array before the fold) that is armed ...
 constexpr uint64_t kArmMaxInMfma = 1ull << 21; // ... when it runs on the matrix-core kernel (60 us at 2^21: a launch is 10 % of that)
 // how a kernel-buffer slice is realised on the device
@@ -534,7 +570,7 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 								}
 								if (fe == hipErrorNotSupported) {
 									prof_scope ps(ctx, k == 2 && bn::mfma_applies(ctx->n_cu, row_len) ? BN_PROF_ROUND_EVAL_MFMA : BN_PROF_ROUND_EVAL);
-									fe = bn::launch_roundeval_product(s, ctx->n_cu, hi, lo, k, row_len, d_S + slot, &fz);
+									fe = roundeval_product_routed(ctx, !need_materialise, hi, lo, k, row_len, d_S + slot, &fz);
 								}
 								if (fe == hipSuccess) {
 									in_kernel = true;
@@ -549,7 +585,7 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 							if (!in_kernel) {
 								BN_FLUSH(ctx);
 								prof_scope ps(ctx, BN_PROF_ROUND_EVAL);
-								BN_HIP(bn::launch_roundeval_product(s, ctx->n_cu, hi, lo, k, row_len, d_S + slot, nullptr));
+								BN_HIP(roundeval_product_routed(ctx, !need_materialise, hi, lo, k, row_len, d_S + slot, nullptr));
 							}
 							n_slots += 2;
 							o = (uint32_t)partner; // consumed

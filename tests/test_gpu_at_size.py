@@ -114,12 +114,15 @@ def test_pairwise_product_reduce_2p20(hal, oracle):
         assert np.array_equal(hal.copy_d2h(o), e)
 
 
-def test_mlecheck_round_evals_n20(hal, oracle):
-    """v3/bivariate_mlecheck.rs:391-520 at 2^20: product * eq_ind, eq table of 2^19 entries."""
+@pytest.mark.parametrize("n_vars", [LOG, LOG + 1])
+def test_mlecheck_round_evals_n20(hal, oracle, n_vars):
+    """v3/bivariate_mlecheck.rs:391-520 at 2^20: product * eq_ind, eq table of 2^19 entries (the three-factor 9-lane kernel);
+    at 2^21 the evaluation has 2^20 points and is routed: the indicator folded into b by two element-wise passes, then the
+    bivariate matrix-core kernel (abi_kernels.cpp roundeval_product_routed)."""
     from binius_amd.sumcheck import calculate_round_evals, eq_ind_partial_eval
 
     alloc = hal.dev_alloc()
-    n_vars, m = LOG, 2
+    m = 2
     mls = [rnd(oracle, 0xB1A50000 + j, 1 << n_vars) for j in range(m)]
     d = [upload(hal, alloc, x) for x in mls]
     point = oracle.random_scalars(0xE9, n_vars - 1)
