@@ -42,7 +42,37 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
-PMC_FILE = os.path.join("profiles", "r02", "bench_pmc.json")  # tools/pmc_bench.sh: FETCH_SIZE / WRITE_SIZE passes of this command
+PMC_FILE = os.path.join("profiles", "r03", "bench_pmc.json")  # tools/pmc_bench.sh: FETCH_SIZE / WRITE_SIZE passes of this command
+
+
+def csrc_sha16():
+    """Fingerprint of the kernel sources the library was built from (binius_amd/csrc, include/): the PMC file records the
+    fingerprint of the build its counters were taken on, and a stale file is refused (roofline.traffic = null) instead of
+    describing a binary that no longer exists.  (The GPU box has no .git, so a commit id cannot be checked there.)"""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "binius_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "binius_amd", "csrc", "*.hpp"))
+                   + glob.glob(os.path.join(ROOT, "binius_amd", "csrc", "*.cpp")) + glob.glob(os.path.join(ROOT, "include", "*.h")))
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def transcript_digest(coeffs, finals):
+    """16-byte digest of a sumcheck transcript (all round polynomials, then the final evaluations; 16 little-endian bytes
+    per field element): equal digests = equal transcripts, whatever the number of ranks that produced them."""
+    import hashlib
+
+    h = hashlib.blake2b(digest_size=16)
+    for rc in coeffs:
+        for c in rc:
+            h.update(int(c).to_bytes(16, "little"))
+    for f in finals:
+        h.update(int(f).to_bytes(16, "little"))
+    return h.hexdigest()
 
 
 def main():
@@ -343,7 +373,9 @@ def main():
         pmc = json.load(open(os.path.join(ROOT, PMC_FILE)))
         sym = dom.split("(")[0]
         ent = pmc["workloads"].get("n_vars_local=%d,m=%d" % (n_vars, m), {}).get(sym)
-        if ent:
+        if ent and pmc.get("csrc_sha16") != csrc_sha16():
+            roofline["traffic_source"] = "%s is stale: taken on kernel sources %s, this tree is %s" % (PMC_FILE, pmc.get("csrc_sha16"), csrc_sha16())
+        elif ent:
             roofline["traffic"] = ent["traffic_bytes_per_launch"]
             roofline["traffic_source"] = "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command at build %s; average bytes per launch of %s)" % (
                 PMC_FILE, pmc.get("build", "?"), sym)
@@ -402,7 +434,12 @@ def main():
                          + (" -- " + exchange if exchange.startswith("shm (") else "")) if dist is not None else "none",
         },
         "alt_exchange": alt,
-        "bit_exact_check": bool(ok),
+        # the sumcheck verifier's equations on the device-produced transcript (claim from the device inner product):
+        # P_r(0) + P_r(1) == running sum every round, product of the final evaluations == last sum.  Bit-exact parity of
+        # this very instance against the CPU oracle is tests/test_gpu_north_star.py (n = 24, n = 28, 8 shards).
+        "verifier_check": bool(ok),
+        "bit_exact_check": bool(ok),  # (old name of verifier_check, kept for the driver)
+        "transcript_digest": transcript_digest(get_coeffs(), get_finals()),
         "roofline": roofline,
         "kernels": per_kernel,
     }

@@ -252,6 +252,7 @@ int bn_ctx_destroy(bn_ctx *ctx)
 	if (ctx->stream)
 		hipStreamSynchronize(ctx->stream);
 	if (ctx->d_arm_relay) hipFree(ctx->d_arm_relay);
+	if (ctx->hal_const) hipFree(ctx->hal_const);
 	if (ctx->ntt_cache) {
 		bn::ntt_bs_cache *nc = (bn::ntt_bs_cache *)ctx->ntt_cache;
 		if (nc->d_tables) hipFree(nc->d_tables);

@@ -147,8 +147,7 @@ int bn_hal_round_evals(bn_ctx *ctx, uint32_t order, uint32_t n_vars, const void 
 	}
 	char *scr = nullptr;
 	if (n_tr) {
-		// (+ a cube for the all-ones and all-zeros tables of the routed path below: the block must not move once it holds data)
-		scr = (char *)bn::ctx_scratch(ctx, ((size_t)n_tr * full + 1 + full) * sizeof(f128));
+		scr = (char *)bn::ctx_scratch(ctx, ((size_t)n_tr * full + 1) * sizeof(f128));
 		if (!scr) return bn::fail(BN_ERR_ALLOC, "allocation error: allocator is out of memory (scratch)");
 		BN_HIP(bn::launch_fill(ctx->stream, scr + (size_t)n_tr * full * sizeof(f128), 1, bn::f128_one()));
 	}
@@ -214,23 +213,37 @@ int bn_hal_round_evals(bn_ctx *ctx, uint32_t order, uint32_t n_vars, const void 
 		// two-factor job one of whose factors is the same at both points (the indicator, the ones) gets an all-zeros
 		// table as that factor's partner, (f + 0) = f: it then has the shape of the bivariate round evaluation and runs on
 		// the matrix cores instead of the generic product-sum kernel.
+		// The tables are filled once per size and kept in the context (refilling them on every call wrote as many bytes
+		// as the job reads).  A monomial without any factor and without an indicator is a constant: its sum over the
+		// 2^(n_vars - 1) >= 2 points of the half cube is zero in characteristic 2 -- no pass at all.
 		bool need_tables = false;
 		for (const auto &j : jobs)
-			if (j.vars.size() + (j.eq ? 1 : 0) <= 2 && (j.eq || j.vars.size() < 2)) need_tables = true;
+			if (!(j.vars.empty() && !j.eq) && j.vars.size() + (j.eq ? 1 : 0) <= 2 && (j.eq || j.vars.size() < 2)) need_tables = true;
 		if (need_tables) {
-			if (!scr) {
-				scr = (char *)bn::ctx_scratch(ctx, (1 + full) * sizeof(f128));
-				if (!scr) return bn::fail(BN_ERR_ALLOC, "allocation error: allocator is out of memory (scratch)");
+			if (ctx->hal_const_half != half) {
+				if (ctx->hal_const) {
+					BN_HIP(hipStreamSynchronize(ctx->stream));
+					BN_HIP(hipFree(ctx->hal_const));
+					ctx->hal_const = nullptr;
+					ctx->hal_const_half = 0;
+				}
+				if (hipMalloc(&ctx->hal_const, 2 * half * sizeof(f128)) != hipSuccess) {
+					(void)hipGetLastError();
+					ctx->hal_const = nullptr;
+					return bn::fail(BN_ERR_ALLOC, "allocation error: allocator is out of memory (constant tables of the routed round evaluation)");
+				}
+				BN_HIP(bn::launch_fill(ctx->stream, ctx->hal_const, half, bn::f128_one()));
+				BN_HIP(hipMemsetAsync((char *)ctx->hal_const + half * sizeof(f128), 0, half * sizeof(f128), ctx->stream));
+				ctx->hal_const_half = half;
 			}
-			ones = scr + ((size_t)n_tr * full + 1) * sizeof(f128);
+			ones = (char *)ctx->hal_const;
 			zeros = ones + half * sizeof(f128);
-			BN_HIP(bn::launch_fill(ctx->stream, ones, half, bn::f128_one()));
-			BN_HIP(hipMemsetAsync(zeros, 0, half * sizeof(f128), ctx->stream));
 		}
 	}
 	if (fast) {
 		// slots 32 + 2 j, 33 + 2 j: (S_1, S_inf) of job j
 		for (size_t j = 0; j < jobs.size(); j++) {
+			if (jobs[j].vars.empty() && !jobs[j].eq) continue; // constant monomial: both sums are zero (the slots are)
 			const void *hi[4] = {nullptr, nullptr, nullptr, nullptr}, *lo[4] = {nullptr, nullptr, nullptr, nullptr};
 			uint32_t k = 0;
 			for (uint32_t v : jobs[j].vars) {

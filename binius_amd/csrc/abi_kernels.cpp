@@ -455,10 +455,18 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 												bool got = false;
 												for (uint64_t spins = 0;; spins++) {
 													if (__atomic_load_n(seqw, __ATOMIC_ACQUIRE) == fz.args.seq) { got = true; break; }
-													if ((spins & 63) == 63 && __atomic_load_n(arm_status(ctx), __ATOMIC_ACQUIRE) == id) {
-														// the kernel gave up waiting (bounded spin) -- did it answer first?
-														got = __atomic_load_n(seqw, __ATOMIC_ACQUIRE) == fz.args.seq;
-														break;
+													if ((spins & 63) == 63) {
+														const uint64_t st = __atomic_load_n(arm_status(ctx), __ATOMIC_ACQUIRE);
+														if (st == (id | bn::kArmLost)) { // a workgroup left a round that went ahead without it
+															arm_cancel(ctx);
+															BN_HIP(hipStreamSynchronize(s));
+															return bn::fail(BN_ERR_DEVICE, "device error: an armed round was only partially executed");
+														}
+														if (st == id) {
+															// the kernel gave up waiting (bounded spin) -- did it answer first?
+															got = __atomic_load_n(seqw, __ATOMIC_ACQUIRE) == fz.args.seq;
+															break;
+														}
 													}
 													if (spins > (1ull << 26)) {
 														arm_cancel(ctx);

@@ -32,6 +32,7 @@ struct arm_args {
 };
 
 constexpr uint64_t kArmGo = 1, kArmCancel = 2;
+constexpr uint64_t kArmLost = 1ull << 63; // status word: a workgroup other than 0 gave up waiting for the relay
 
 // All threads of the workgroup.  Returns true (and z, hi_scale) when the round is to run, false when the kernel has
 // to leave.  Contains one workgroup barrier.
@@ -69,14 +70,22 @@ __device__ __forceinline__ bool arm_wait(const arm_args &arm, f128 &z, f128 &hi_
 				__hip_atomic_store(arm.d_relay, (arm.id << 2) | code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			}
 		} else {
+			// Workgroup 0's bounded spin on the host (~6 ms) is the only DECISION; everybody else just waits for its relay.
+			// The bound here (seconds) only exists so that a lost workgroup 0 cannot park the device for ever; a
+			// workgroup that ever runs into it says so in the status word (kArmLost): it leaves without a ticket, so the
+			// round's result is never published and the host, which checks the status word while it waits for the
+			// mailbox, reports a device error instead of accepting anything from a partially executed round.
+			bool lost = true;
 			for (uint32_t spins = 0; spins < (1u << 22); spins++) {
 				const uint64_t w = __hip_atomic_load(arm.d_relay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				if ((w >> 2) == arm.id) {
 					code = w & 3;
+					lost = false;
 					break;
 				}
 				__builtin_amdgcn_s_sleep(1);
 			}
+			if (lost) __hip_atomic_store(arm.h_status, arm.id | kArmLost, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 			if (code == kArmGo) {
 				zl = __hip_atomic_load(arm.d_relay + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				zh = __hip_atomic_load(arm.d_relay + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

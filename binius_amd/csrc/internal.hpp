@@ -82,6 +82,9 @@ struct bn_ctx {
 		const void *ptr[8] = {};
 	} mirror;
 	void *ntt_cache = nullptr; // bn::ntt_bs_cache (allocated on first use)
+	// all-ones | all-zeros tables of the old HAL's routed round evaluation (abi_hal.cpp): filled once per size, kept
+	void *hal_const = nullptr;
+	uint64_t hal_const_half = 0; // elements per table
 	// pinned, device-mapped staging of bn_gather_d2h: offsets in, gathered items out (grown on demand)
 	void *h_gather = nullptr, *d_gather = nullptr;
 	size_t gather_bytes = 0;

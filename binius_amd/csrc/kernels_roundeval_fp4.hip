@@ -32,12 +32,14 @@ using namespace gram;
 
 using namespace gram4;
 
-// Element loads go straight into LDS (global_load_lds_dwordx4: no registers held while they fly), THREE tiles ahead: with
+// Element loads go straight into LDS (global_load_lds_dwordx4: no registers held while they fly), ONE tile ahead: with
 // K = 64 the Gram k-steps of a tile take ~0.5 us, a fraction of what a loaded HBM takes to answer, and a second register
 // set for a deeper register prefetch does not survive next to 96 accumulator registers (two loop bodies: 101 - 191
-// spilled registers in three shapes).  48 KiB of raw elements + the 24 KiB operand tile per workgroup, two workgroups
-// per CU; per tile two barriers: raw -> operand tile (VALU), then the Gram k-steps (matrix pipe) -- the two workgroups
-// of a CU interleave the two phases.
+// spilled registers in three shapes).  One 16 KiB slot of raw elements (read into registers right after a tile's k-steps
+// and refilled at once) + the 24 KiB operand tile per workgroup = 47 KiB and 154 registers: THREE workgroups per CU
+// (__launch_bounds__(256, 3), grid cap = 3 per CU); per tile two barriers: raw -> operand tile (VALU), then the Gram
+// k-steps (matrix pipe) -- the workgroups of a CU interleave the two phases.  (Three raw slots at two workgroups per CU
+// were measured slower: DESIGN.md 4.5b.)
 constexpr int kRawSlots = 1;
 #ifdef BN_FP4_PHASES
 __device__ unsigned long long fp4_phase_cycles[8];
@@ -86,10 +88,10 @@ __global__ __launch_bounds__(256, 3) void k_roundeval_fp4(const uint4 *__restric
 		const uint64_t pt = (tbase + t) * kTP + threadIdx.x;
 		const uint64_t e = pt < n ? pt : 0;
 		const uint32_t l0 = __builtin_amdgcn_readfirstlane(raw_base + slot * (4 * kTP * 16));
-		asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(a_hi + e), "s"(l0) : "memory");
-		asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(a_lo + e), "s"(l0 + 1 * kTP * 16) : "memory");
-		asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(b_hi + e), "s"(l0 + 2 * kTP * 16) : "memory");
-		asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(b_lo + e), "s"(l0 + 3 * kTP * 16) : "memory");
+		asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(a_hi + e), "s"(l0) : "memory", "m0");
+		asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(a_lo + e), "s"(l0 + 1 * kTP * 16) : "memory", "m0");
+		asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(b_hi + e), "s"(l0 + 2 * kTP * 16) : "memory", "m0");
+		asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(b_lo + e), "s"(l0 + 3 * kTP * 16) : "memory", "m0");
 	};
 	// workgroup barrier that waits for this wave's LDS traffic only (not for the LDS-DMA loads in flight)
 	auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };

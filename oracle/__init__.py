@@ -192,6 +192,7 @@ def lib():
             C.POINTER(C.POINTER(B128)), C.c_size_t, C.c_uint, C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(B128), B128,
             C.POINTER(B128), C.POINTER(B128), C.POINTER(B128), C.POINTER(B128), C.POINTER(B128), C.c_int,
         ]
+        L.ref_fast_inner_product.argtypes = [C.POINTER(B128), C.POINTER(B128), C.c_size_t, C.POINTER(B128), C.POINTER(B128), C.POINTER(B128), C.c_int]
         L.ref_evaluate_univariate.restype = B128
         L.ref_evaluate_univariate.argtypes = [C.POINTER(B128), C.c_size_t, B128]
         _lib = L
@@ -576,6 +577,19 @@ def fast_bivariate_sumcheck_prove(multilins, n_vars, comps, sums, batch_coeff, c
     assert rc == 0
     co = arr_to_ints(rc_out)
     return [co[3 * r : 3 * r + 3] for r in range(n_vars)], arr_to_ints(fe)
+
+
+def fast_inner_product(a, b, threads=1):
+    """XOR_i a[i] * b[i] over GF(2^128), POLYVAL-basis PCLMULQDQ arithmetic + OpenMP (inputs untouched).  None when the
+    host has no PCLMULQDQ."""
+    fwd, inv = _polyval_tables()
+    assert a.shape == b.shape
+    out = arr(1)
+    rc = lib().ref_fast_inner_product(_p(a), _p(b), a.shape[0], _p(fwd), _p(inv), _p(out), threads)
+    if rc == 2:
+        return None
+    assert rc == 0
+    return arr_to_ints(out)[0]
 
 
 # ------------------------------------------------------------------ old HAL (crates/hal) restatement: hal_ref.c

@@ -154,3 +154,30 @@ int ref_fast_bivariate_sumcheck_prove(ref_b128 *const *multilins, size_t m, unsi
 	free(inv);
 	return 0;
 }
+
+/* sum_i a[i] * b[i] for two GF(2^128) vectors (the claimed sum of a bivariate-product sumcheck,
+ * compute/src/cpu/layer.rs:226-246 for tower level 7), in the POLYVAL representation: phi is additive and
+ * multiplicative, so phi^-1(XOR_i phi(a_i) (x) phi(b_i)) is the tower-basis sum.  The inputs are not modified.
+ * Pinned to ref_inner_product by tests/test_oracle_fastcpu.py.  Returns 0, 1 on bad arguments, 2 without PCLMULQDQ. */
+int ref_fast_inner_product(const ref_b128 *a, const ref_b128 *b, size_t n, const ref_b128 *binary_to_polyval /*[128]*/,
+                           const ref_b128 *polyval_to_binary /*[128]*/, ref_b128 *out, int threads)
+{
+	if (!__builtin_cpu_supports("pclmul")) return 2;
+	if (!a || !b || !out) return 1;
+	if (threads < 1) threads = 1;
+	bytemat *fwd = malloc(sizeof(bytemat)), *inv = malloc(sizeof(bytemat));
+	if (!fwd || !inv) return 1;
+	bytemat_build(fwd, binary_to_polyval);
+	bytemat_build(inv, polyval_to_binary);
+	uint64_t slo = 0, shi = 0;
+#pragma omp parallel for num_threads(threads) schedule(static) reduction(^ : slo, shi)
+	for (size_t i = 0; i < n; i++) {
+		const __m128i p = mont_mul(bytemat_apply(fwd, ld(&a[i])), bytemat_apply(fwd, ld(&b[i])));
+		slo ^= (uint64_t)_mm_cvtsi128_si64(p);
+		shi ^= (uint64_t)_mm_extract_epi64(p, 1);
+	}
+	*out = to_ref(bytemat_apply(inv, _mm_set_epi64x((long long)shi, (long long)slo)));
+	free(fwd);
+	free(inv);
+	return 0;
+}

@@ -46,10 +46,10 @@ def test_bench_two_and_four_ranks_on_one_gpu(n_ranks):
 
 
 def test_bench_transcript_is_independent_of_the_number_of_ranks():
-    """Strong scaling proves the SAME instance: the round polynomials of the 1-, 2- and 4-rank runs are
-    checked against the same claim by the verifier; here the throughput lines must all describe 2^17."""
-    vals = []
-    for n_ranks in (1, 2):
+    """Strong scaling proves the SAME instance: bench.py prints a digest of the transcript it timed (all round
+    polynomials + final evaluations); the 1-, 2- and 4-rank runs of the 2^17 instance must print the same one."""
+    digests = []
+    for n_ranks in (1, 2, 4):
         if n_ranks == 1:
             r = _run([sys.executable, "bench.py", "--steps", "1", "--warmup", "1", "--n-vars", "17", "--no-cpu-baseline"], {})
         else:
@@ -57,8 +57,9 @@ def test_bench_transcript_is_independent_of_the_number_of_ranks():
                    "--master-port", str(_free_port()), "bench.py", "--gpus", str(n_ranks), "--steps", "1", "--warmup", "1", "--n-vars", "17",
                    "--no-cpu-baseline"]
             r = _run(cmd, {"BN_ALL_ON_GPU0": "1", "BN_PG_BACKEND": "gloo", "BN_EXCHANGE": "shm"})
-        assert r["bit_exact_check"] is True and r["config"]["n_vars_global"] == 17
-        vals.append(r)
+        assert r["verifier_check"] is True and r["config"]["n_vars_global"] == 17
+        digests.append(r["transcript_digest"])
+    assert len(digests[0]) == 32 and digests[0] == digests[1] == digests[2], digests
 
 
 @pytest.mark.parametrize("exchange", ["shm", "rccl"])

@@ -1,0 +1,149 @@
+"""Oracle parity AT the north-star sizes ("Next round" items 1a and 2).
+
+* n = 24 (BASELINE.json configs[1]) and n = 28 (the north-star instance, config 5's global instance): the whole
+  transcript of the compiled prover bench.py times (SumcheckPlan: all round polynomials + final evaluations) equals
+  the CPU oracle's on the same SplitMix64 arrays, bit for bit.  The oracle at these sizes is the PCLMULQDQ port
+  (oracle/fastcpu_ref.c), which tests/test_oracle_fastcpu.py pins to the scalar tower-recursion restatement up to
+  n = 20 with three batched compositions; the claimed sum comes from the same port's inner product (pinned likewise).
+  Reference instance: crates/core/benches/sumcheck.rs:116-190 (random multilinears, one bivariate product claim).
+* config 5's workload on ONE device: 8 ranks share cuda:0, each proves its n_local = 25 shard (1.5 GiB) of the SAME
+  2^28 instance through the compiled sharded prover; every rank's transcript (28 local-round polynomials after the
+  exchange + 3 residual rounds + finals) must equal the single-GPU HIP transcript AND the oracle's unsharded one.
+  Sharding: crates/core/src/protocols/sumcheck/v3/bivariate_product.rs:129-131,199,321 (High-to-Low binding, so the
+  shard id is taken from the variables bound last = the low index bits).
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = [pytest.mark.gpu, pytest.mark.last]  # heavy: collected last (tests/conftest.py)
+
+SEED = 0xB1A50000  # bench.py's instance
+_cache = {}
+
+
+def _threads():
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def _need_host_gib(gib):
+    for line in open("/proc/meminfo"):
+        if line.startswith("MemAvailable:"):
+            have = int(line.split()[1]) / (1 << 20)
+            if have < gib:
+                pytest.skip("host has %.1f GiB available, this case needs %.0f GiB" % (have, gib))
+
+
+def _instance(oracle, n_vars, m=2):
+    """(claim, round polynomials, finals) of the oracle for bench.py's instance at 2^n_vars, and the HIP transcript of
+    the single-GPU compiled prover on the same arrays -- computed once per size."""
+    if n_vars in _cache:
+        return _cache[n_vars]
+    import binius_amd
+    from binius_amd._host import SumcheckPlan
+
+    _need_host_gib(1.3 * m * 16 * (1 << n_vars) / (1 << 30) + 2)
+    n = 1 << n_vars
+    mls = [oracle.random_b128(SEED + j, n) for j in range(m)]
+    stream = oracle.random_scalars(0xC4A1, n_vars + 1)
+    batch_coeff, challenges = stream[0], stream[1:]
+    with binius_amd.Context(0, m * n + m * (n // 2) + 4096) as hal:
+        alloc = hal.dev_alloc()
+        d = []
+        chunk = 1 << 24
+        for x in mls:
+            s = alloc.alloc(n)
+            for off in range(0, n, chunk):
+                hal.copy_h2d(x[off : off + chunk], s.slice(off, min(n, off + chunk)))
+            d.append(s)
+        scratch = alloc.alloc(m * (n // 2))
+        claim_dev = hal.inner_product(d[0], 7, d[1])
+        plan = SumcheckPlan(hal, n_vars, d, scratch, [(0, 1)], [claim_dev], batch_coeff, challenges)
+        plan.run()
+        got = (claim_dev, plan.round_coeffs(), plan.final_evals())
+        plan.run()  # a second step from the same resident inputs (what bench.py's timed loop does)
+        again = (claim_dev, plan.round_coeffs(), plan.final_evals())
+        # the PreFold inputs are never modified: spot-check the first and last chunk of each
+        for j, s in enumerate(d):
+            assert np.array_equal(hal.copy_d2h(s.slice(0, 4096)), mls[j][:4096])
+            assert np.array_equal(hal.copy_d2h(s.slice(n - 4096, n)), mls[j][n - 4096 :])
+    threads = _threads()
+    claim = oracle.fast_inner_product(mls[0], mls[1], threads)
+    if claim is None:
+        pytest.skip("host without PCLMULQDQ: no oracle run of this size in the test budget")
+    want_coeffs, want_finals = oracle.fast_bivariate_sumcheck_prove(mls, n_vars, [(0, 1)], [claim], batch_coeff, challenges, threads=threads)
+    del mls
+    _cache[n_vars] = {"want": (claim, want_coeffs, want_finals), "got": got, "again": again, "batch_coeff": batch_coeff, "challenges": challenges}
+    return _cache[n_vars]
+
+
+@pytest.mark.parametrize("n_vars", [24, 28])
+def test_transcript_equals_oracle_at_benchmark_size(oracle, n_vars):
+    inst = _instance(oracle, n_vars)
+    claim, want_coeffs, want_finals = inst["want"]
+    got_claim, got_coeffs, got_finals = inst["got"]
+    assert got_claim == claim, "claimed sum (device inner product) differs from the oracle's"
+    for r in range(n_vars):
+        assert list(got_coeffs[r]) == list(want_coeffs[r]), "round %d polynomial differs from the oracle" % r
+    assert list(got_finals) == list(want_finals)
+    assert inst["again"] == inst["got"], "a second step from the same inputs gave a different transcript"
+    # the oracle transcript itself satisfies the verifier (a wrong claim cannot hide behind equal transcripts)
+    running = claim
+    for r, (c0, c1, c2) in enumerate(want_coeffs):
+        assert c0 ^ (c0 ^ c1 ^ c2) == running
+        running = oracle.evaluate_univariate([c0, c1, c2], inst["challenges"][r])
+    assert oracle.mul(want_finals[0], want_finals[1]) == running
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("exchange", ["shm", "peer"])
+def test_config5_eight_shards_on_one_device(oracle, exchange):
+    """2^28 over 8 shards (n_local = 25), all on cuda:0: shm = partials meet in host shared memory; peer = every rank's
+    finalize step stores its partial into every peer's device mailbox (hipIpc-mapped) and the reader XORs."""
+    import torch.multiprocessing as mp
+
+    from test_gpu_sharded_vs_oracle import _worker
+
+    n_global, world, m, comps = 28, 8, 2, [(0, 1)]
+    inst = _instance(oracle, n_global)
+    claim, want_coeffs, want_finals = inst["want"]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_global, m, comps, q, exchange)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = []
+    try:
+        results = [q.get(timeout=900) for _ in range(world)]
+    finally:
+        for p in procs:
+            p.join(120 if results else 5)
+            if p.is_alive():
+                p.kill()
+    assert all(p.exitcode == 0 for p in procs)
+    # residual rounds: the last log2(world) challenges come from the same stream
+    stream = oracle.random_scalars(0xC4A1, n_global + 1)
+    assert stream[1:] == inst["challenges"]
+    for rank, sums, coeffs, finals, rerun_same in sorted(results):
+        assert sums == [claim], "rank %d: claimed sum differs from the unsharded inner product" % rank
+        assert [list(c) for c in coeffs] == [list(c) for c in want_coeffs], "rank %d: round polynomials differ from the unsharded oracle" % rank
+        assert [list(c) for c in coeffs] == [list(c) for c in inst["got"][1]], "rank %d: differs from the single-GPU HIP transcript" % rank
+        assert list(finals) == list(want_finals), "rank %d: final evaluations differ" % rank
+        assert rerun_same, "rank %d: a second run from the same inputs gave a different transcript" % rank

@@ -18,7 +18,9 @@ done
 python3 - "$OUT" "$BUILD" "$@" <<'PY'
 import collections, csv, glob, json, sys
 out, build, nvs = sys.argv[1], sys.argv[2], sys.argv[3:]
-res = {"build": build, "units": "bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024, averaged over the launches of the kernel symbol in one warm-up + one timed sumcheck",
+sys.path.insert(0, out + "/../..")
+import bench
+res = {"build": build, "csrc_sha16": bench.csrc_sha16(), "units": "bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024, averaged over the launches of the kernel symbol in one warm-up + one timed sumcheck",
        "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- python bench.py --n-vars N --steps 1 --warmup 1 --no-cpu-baseline --no-prof", "workloads": {}}
 for nv in nvs:
     acc = collections.defaultdict(lambda: {"FETCH_SIZE": [0.0, 0], "WRITE_SIZE": [0.0, 0]})
