@@ -16,11 +16,13 @@ N = 8).  The GLOBAL instance is fixed, so N > 1 is STRONG scaling: the hypercube
 LAST-bound variables (low index bits under High-to-Low binding), rank g owns the
 global indices = g mod N as one contiguous local array of 2^(28 - log2 N) elements per multilinear --
 a shard of the SAME SplitMix64 instance the single-GPU run proves (synthetic.random_b128_shard).
-Every round each rank evaluates its shard and the N partial (y_1, y_inf) pairs are combined with ONE
-device-side RCCL collective (ncclAllGather of 32 bytes on the context's stream + a one-workgroup XOR;
-RCCL has no XOR reduction); after the local rounds one ncclAllGather per multilinear rebuilds the
-N-element residual instance and the last log2 N rounds run on it.  The host-shared-memory exchange
-(BN_EXCHANGE=shm) is timed beside it and reported as `alt_exchange`.  `--n-vars 24` gives
+Every round each rank evaluates its shard and the N partial (y_1, y_inf) pairs are combined by ONE collective inside
+the round's kernel: the finalizing workgroup stores its 32-byte partial into every peer's device mailbox (hipIpc-mapped
+fine-grained memory, xGMI stores on a node) and XORs what the peers stored ("peer", csrc/finalize.hpp); after the local
+rounds the N-element residual instance is rebuilt once and the last log2 N rounds run on it.  The RCCL form (one
+ncclAllGather of 32 bytes per round on the context's stream + a one-workgroup XOR) and the host-shared-memory form are
+timed beside it and reported in `alt_exchange`, with the per-round cost of each exchange over the shard proven alone.
+`--n-vars 24` gives
 BASELINE.json configs[1].  Inputs are generated once, uploaded before the timed region and never
 modified (the prover's first fold copies, like the reference's PreFold -> PostFold).  Challenges
 come from a fixed SplitMix64 stream instead of a Groestl transcript (host-side protocol code, out of
@@ -113,14 +115,17 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(local_rank)
-    # per-round exchange of the ranks' 32-byte partials: "rccl" (one ncclAllGather per round on the device,
-    # the default wherever RCCL runs) or "shm" (host shared memory; all ranks on one node)
+    # per-round exchange of the ranks' 32-byte partials:
+    #   "peer"  every rank's finalize step stores its partial into every peer's device mailbox (hipIpc-mapped fine-grained
+    #           memory: xGMI stores on a node) and XORs what the peers stored -- ONE hand-written collective per round, inside
+    #           the round's kernel; the small rounds stay armed.  The default.
+    #   "rccl"  one ncclAllGather per round on the context's stream + a one-workgroup XOR + readback (timed beside it)
+    #   "shm"   the partials meet in host shared memory (timed beside it)
     rccl_possible = dist is not None and dist.get_backend() == "nccl"
-    exchange = os.environ.get("BN_EXCHANGE", "rccl" if rccl_possible else "shm")
-
+    exchange = os.environ.get("BN_EXCHANGE", "peer")
     import binius_amd
     from binius_amd import synthetic  # SplitMix64 input streams (numpy)
-    from binius_amd._host import RcclComm, ShmExchange, SumcheckPlan
+    from binius_amd._host import PeerExchange, RcclComm, ShmExchange, SumcheckPlan
 
     m = 2
     log_world = world.bit_length() - 1
@@ -148,51 +153,59 @@ def main():
     F = binius_amd.HostField
     scratch = alloc.alloc(m * (n // 2) + 8 * world + 64)  # folded copies (+ the residual instance and its folded copies)
 
-    shm, rccl, reducer = None, None, None
+    shm, rccl, reducer, peer = None, None, None, None
     d_partial, d_gathered = 0, 0
+    available = []
     if dist is not None:
         from binius_amd.distributed import ShardedRoundReducer
 
+        flag_dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+
+        def everybody(ok):
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=flag_dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return int(flag.item()) == 1
+
         reducer = ShardedRoundReducer(hal, dist, world)  # device buffers of the RCCL exchange + scalar all-gathers
-        # the shared-memory segment (alt exchange, or the primary one under BN_EXCHANGE=shm / gloo)
+        # the shared-memory segment: the "shm" exchange, and the one-off rebuild of the residual instance under "peer"
         if local_world == world:
             try:
                 shm = ShmExchange(dist, rank, world)
-                ok = 1
             except Exception as ex:  # noqa: BLE001
                 print("[bench] rank %d: shared-memory exchange unavailable (%s)" % (rank, ex), file=sys.stderr)
-                shm, ok = None, 0
-            flag = torch.tensor([ok], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 0:
+                shm = None
+            if not everybody(shm is not None):
                 if shm is not None:
                     shm.close()
                 shm = None
-        if exchange == "shm" and shm is None:
-            exchange = "rccl"
+        if shm is not None:
+            available.append("shm")
+            try:
+                peer = PeerExchange(hal, dist, rank, world)  # (collective: every rank learns whether all of them connected)
+                available.insert(0, "peer")
+            except Exception as ex:  # noqa: BLE001
+                print("[bench] rank %d: peer exchange unavailable (%s)" % (rank, ex), file=sys.stderr)
+                peer = None
         if rccl_possible:
             # the per-round collective is issued from the compiled host loop: ncclAllGather of the 32-byte
             # partial on the context's stream, communicator bootstrapped over the torch process group
             try:
                 rccl = RcclComm(dist, rank, world)
-                ok = 1
             except Exception as ex:  # noqa: BLE001
                 print("[bench] rank %d: RCCL communicator unavailable (%s)" % (rank, ex), file=sys.stderr)
-                rccl, ok = None, 0
-            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 0:
+                rccl = None
+            if not everybody(rccl is not None):
                 if rccl is not None:
                     rccl.destroy()
                 rccl = None
-                if shm is None:
-                    raise SystemExit("neither the RCCL communicator nor the shared-memory segment is available")
-                exchange = "shm (fallback: the RCCL communicator could not be created on this node)"
             else:
                 d_partial = reducer.local.data_ptr()
                 d_gathered = reducer.gathered.data_ptr()
-        elif exchange == "rccl":
-            raise SystemExit("BN_EXCHANGE=rccl needs the nccl process-group backend")
+                available.append("rccl")
+        if not available:
+            raise SystemExit("no exchange is available on this node (shared memory, peer mailboxes and RCCL all failed)")
+        if exchange not in available:
+            exchange = "%s (fallback: %s is not available on this node)" % (available[0], exchange)
 
     # the claimed sum (not timed): inner product on the device, combined across ranks
     claim = hal.inner_product(d_in[0], 7, d_in[1])
@@ -206,10 +219,14 @@ def main():
         torch.cuda.synchronize()
 
     def make_plan(kind):
-        use_shm = kind.startswith("shm")
-        return SumcheckPlan(hal, n_vars, d_in, scratch, [(0, 1)], [claim], batch_coeff, challenges[:n_global], None,
-                            0 if use_shm else d_partial, None if (use_shm or rccl is None) else rccl.handle, world,
-                            0 if use_shm else d_gathered, shm.handle if use_shm else None, tail_rounds=log_world > 0)
+        kind = kind.split(" ")[0]
+        if kind == "solo":  # diagnostic: the local shard alone, no exchange, no residual rounds (its transcript means nothing)
+            return SumcheckPlan(hal, n_vars, d_in, scratch, [(0, 1)], [claim], batch_coeff, challenges[:n_vars])
+        if kind == "rccl":
+            return SumcheckPlan(hal, n_vars, d_in, scratch, [(0, 1)], [claim], batch_coeff, challenges[:n_global], None, d_partial, rccl.handle, world,
+                                d_gathered, None, tail_rounds=log_world > 0)
+        return SumcheckPlan(hal, n_vars, d_in, scratch, [(0, 1)], [claim], batch_coeff, challenges[:n_global], None, 0, None, world, 0, shm.handle,
+                            tail_rounds=log_world > 0, peer=(kind == "peer"))
 
     plan = make_plan(exchange) if dist is not None else SumcheckPlan(hal, n_vars, d_in, scratch, [(0, 1)], [claim], batch_coeff, challenges[:n_global])
 
@@ -226,23 +243,25 @@ def main():
             dt = float(t.item())
         return dt
 
-    # First run of the default transport, guarded: if the RCCL exchange cannot run on this node (communicator
-    # or collective error on ANY rank), every rank switches to the shared-memory exchange together and the
-    # line says so -- a scaling line with a documented fallback beats none.
-    if dist is not None and exchange == "rccl" and rccl is not None:
-        ok = 1
-        try:
-            plan.run()
-        except Exception as ex:  # noqa: BLE001
-            print("[bench] rank %d: RCCL exchange failed (%s)" % (rank, ex), file=sys.stderr)
-            ok = 0
-        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:
-            if shm is None:
-                raise SystemExit("RCCL exchange failed and no shared-memory segment is available")
-            exchange = "shm (fallback: the RCCL exchange raised an error on this node)"
-            plan = make_plan("shm")
+    # First run of the default exchange, guarded: if it cannot run on this node (an error on ANY rank), every rank
+    # switches to the next available one together and the line says so -- a scaling line with a documented fallback
+    # beats none.
+    if dist is not None:
+        while True:
+            ok = True
+            try:
+                plan.run()
+            except Exception as ex:  # noqa: BLE001
+                print("[bench] rank %d: exchange %s failed (%s)" % (rank, exchange.split(" ")[0], ex), file=sys.stderr)
+                ok = False
+            if everybody(ok):
+                break
+            failed = exchange.split(" ")[0]
+            available.remove(failed)
+            if not available:
+                raise SystemExit("every exchange failed on this node")
+            exchange = "%s (fallback: the %s exchange raised an error on this node)" % (available[0], failed)
+            plan = make_plan(exchange)
     for _ in range(args.warmup):
         plan.run()
     # ---- timed region: exactly K steps, barrier + synchronize on both sides, MAX over ranks
@@ -263,17 +282,36 @@ def main():
         barrier()
         elapsed_prof = time.perf_counter() - t2
         prof = hal.prof_end()
-    # ---- the other transport, same steps (all ranks on one node): reported beside the default, never as `value`
+    # ---- the other exchanges, same steps, and the local shard with no exchange at all (diagnostic): reported beside the
+    # default, never as `value`.  exchange_us_per_round = (step with the exchange - step of the shard alone) / rounds.
     alt = None
-    if dist is not None and not args.no_alt_exchange and world > 1:
-        other = "shm" if exchange == "rccl" else ("rccl" if exchange == "shm" else None)
-        if (other == "shm" and shm is not None) or (other == "rccl" and rccl is not None):
+    if dist is not None and not args.no_alt_exchange:
+        alt = []
+        solo = make_plan("solo")
+        solo.run()
+        dt_solo = timed(solo, args.steps)
+        n_rounds = n_global
+        main_kind = exchange.split(" ")[0]
+        for other in available:
+            if other == main_kind:
+                continue
             plan_alt = make_plan(other)
-            plan_alt.run()
+            ok_alt = True
+            try:
+                plan_alt.run()
+            except Exception as ex:  # noqa: BLE001
+                print("[bench] rank %d: exchange %s failed (%s)" % (rank, other, ex), file=sys.stderr)
+                ok_alt = False
+            if not everybody(ok_alt):
+                alt.append({"exchange": other, "error": "failed on this node"})
+                continue
             dt_alt = timed(plan_alt, args.steps)
             same = plan_alt.round_coeffs() == get_coeffs() and plan_alt.final_evals() == get_finals()
-            alt = {"exchange": other, "ms_per_step": dt_alt * 1e3 / args.steps, "value": m * (1 << n_global) * args.steps / dt_alt,
-                   "same_transcript_as_default": bool(same)}
+            alt.append({"exchange": other, "ms_per_step": dt_alt * 1e3 / args.steps, "value": m * (1 << n_global) * args.steps / dt_alt,
+                        "same_transcript_as_default": bool(same),
+                        "exchange_us_per_round": round((dt_alt - dt_solo) * 1e6 / args.steps / n_rounds, 2)})
+        alt.append({"exchange": "none (the local shard alone, no residual rounds: diagnostic)", "ms_per_step": dt_solo * 1e3 / args.steps})
+        alt.append({"exchange": main_kind + " (the default: `value`)", "exchange_us_per_round": round((elapsed - dt_solo) * 1e6 / args.steps / n_rounds, 2)})
 
     # correctness of what was timed (N = 1: the sumcheck verifier's final check, on the device values)
     # the sumcheck verifier on what was timed (all ranks hold the same transcript):
@@ -430,8 +468,9 @@ def main():
             "n_vars_global": n_global,
             "multilinears": m,
             "sharding": ("low index bits (last-bound variables), one 32-byte exchange per round: "
-                         + ("host shared memory" if exchange.startswith("shm") else "RCCL all_gather on the context's stream + device XOR")
-                         + (" -- " + exchange if exchange.startswith("shm (") else "")) if dist is not None else "none",
+                         + {"peer": "device mailboxes (every rank's finalize step stores its partial into every peer's hipIpc-mapped mailbox and XORs the world's)",
+                            "shm": "host shared memory", "rccl": "RCCL all_gather on the context's stream + device XOR"}[exchange.split(" ")[0]]
+                         + (" -- " + exchange if " (" in exchange else "")) if dist is not None else "none",
         },
         "alt_exchange": alt,
         # the sumcheck verifier's equations on the device-produced transcript (claim from the device inner product):
@@ -516,6 +555,8 @@ def main():
         print(json.dumps(out))
     if rccl is not None:
         rccl.destroy()
+    if peer is not None:
+        peer.close()
     if shm is not None:
         shm.close()
     hal.close()

@@ -63,9 +63,12 @@ class SumcheckPlan:
     """Pre-marshalled arguments of one prove so repeated runs have no per-call Python work."""
 
     def __init__(self, hal, n_vars, multilins, scratch, comps, sums, batch_coeff, challenges, reduce=None, d_partial=0,
-                 rccl_comm=None, world=1, d_gathered=0, shm=None, tail_rounds=False):
+                 rccl_comm=None, world=1, d_gathered=0, shm=None, tail_rounds=False, peer=False):
         """tail_rounds (shm or RCCL exchange): `challenges` holds n_vars + log2(world) values and the run
-        also does the residual rounds; round_coeffs() then has n_vars + log2(world) entries."""
+        also does the residual rounds; round_coeffs() then has n_vars + log2(world) entries.
+        peer: the ranks' partial round evaluations are XORed on the devices inside the kernels' finalize step (the
+        context must hold a connected PeerExchange); `shm` then only rebuilds the residual instance."""
+        self.peer = bool(peer)
         self.hal = hal
         self.n_vars = n_vars
         self.m = len(multilins)
@@ -91,7 +94,7 @@ class SumcheckPlan:
         rc = host_lib().bnh_bivariate_sumcheck_prove(
             self.hal._h, self.n_vars, self.m, self.ptrs, self.scratch.ptr, self.scratch.len, self.n_comps, self.comps,
             self.sums, C.byref(self.bc), self.ch, self.coeffs, self.final, self.reduce, None, self.d_partial,
-            self.rccl_comm, self.world, self.d_gathered, self.shm, 1 if self.tail_rounds else 0,
+            self.rccl_comm, self.world, self.d_gathered, self.shm, (1 if self.tail_rounds else 0) | (2 if self.peer else 0),
         )
         if rc != 0:
             raise BnError(rc, host_lib().bnh_last_error().decode())
@@ -280,6 +283,47 @@ class ShmExchange:
         if self.handle:
             host_lib().bnh_shm_close(self.handle)
             self.handle = C.c_void_p()
+
+
+class PeerExchange:
+    """Device-resident exchange of the round evaluations (include/binius_amd.h bn_peer_*, csrc/finalize.hpp): every rank
+    owns a mailbox in fine-grained device memory, hipIpc-mapped into all ranks of the node (peers on the same device on a
+    one-GPU box, xGMI peers on a node); the handles travel over the torch.distributed group.  Once connected, a
+    SumcheckPlan(..., peer=True) on this context has its local rounds reduced across the ranks inside the kernels."""
+
+    def __init__(self, hal, dist, rank, world):
+        from ._ffi import _check
+
+        self.hal, self.world, self.rank = hal, world, rank
+        self.created = False
+        buf = C.create_string_buffer(64)
+        _check(lib().bn_peer_create(hal._h, world, rank, buf))
+        self.created = True
+        try:
+            handles = [None] * world
+            dist.all_gather_object(handles, bytes(buf.raw))
+            _check(lib().bn_peer_connect(hal._h, b"".join(handles)))
+            ok = 1
+        except Exception:  # noqa: BLE001 -- every rank has to learn that one of them failed
+            ok = 0
+        flags = [None] * world
+        dist.all_gather_object(flags, ok)
+        if not all(flags):
+            self.close()
+            raise BnError(3, "peer exchange: rank(s) %s could not map the peers' mailboxes" % [i for i, f in enumerate(flags) if not f])
+        dist.barrier()  # nobody writes into a mailbox that its owner has not mapped and zeroed
+
+    def rounds(self):
+        from ._ffi import _check
+
+        st = (C.c_uint64 * 2)()
+        _check(lib().bn_peer_stats(self.hal._h, st))
+        return int(st[0])
+
+    def close(self):
+        if self.created:
+            lib().bn_peer_destroy(self.hal._h)
+            self.created = False
 
 
 class RcclComm:

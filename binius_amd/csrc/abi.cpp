@@ -243,6 +243,109 @@ int bn_ctx_create(int device, uint64_t arena_elems, bn_ctx **out)
 	return BN_OK;
 }
 
+// ---------------------------------------------------------------------------------- peer exchange (finalize.hpp)
+static_assert(BN_PEER_MAX_WORLD == bn::kPeerMaxWorld && BN_PEER_MAILBOX_BYTES == bn::kPeerMailboxBytes, "header constants out of step");
+static_assert(BN_PEER_HANDLE_BYTES >= sizeof(hipIpcMemHandle_t), "hipIpc handle does not fit");
+
+static void peer_release(bn_ctx *ctx)
+{
+	bn_ctx::peer_state &ps = ctx->peer;
+	for (uint32_t w = 0; w < ps.world; w++)
+		if (ps.box[w] && w != ps.rank) (void)hipIpcCloseMemHandle(ps.box[w]);
+	if (ps.own) (void)hipFree(ps.own);
+	(void)hipGetLastError();
+	ps = bn_ctx::peer_state{};
+}
+
+int bn_peer_create(bn_ctx *ctx, uint32_t world, uint32_t rank, uint8_t *handle_out)
+{
+	BN_REQUIRE(ctx && handle_out, "null argument");
+	BN_ENTER(ctx);
+	BN_FLUSH(ctx);
+	BN_REQUIRE(world >= 1 && world <= (uint32_t)bn::kPeerMaxWorld && rank < world, "peer exchange: world must be 1..16 and rank < world");
+	BN_REQUIRE(!ctx->peer.own, "peer exchange: already created on this context");
+	// fine-grained (uncached at the device's L2) so that system-scope stores from the peers and system-scope loads of the
+	// owner meet in memory; plain hipMalloc memory is cached non-coherently with respect to other agents
+	void *p = nullptr;
+	hipError_t e = hipExtMallocWithFlags(&p, bn::kPeerMailboxBytes, hipDeviceMallocUncached);
+	if (e != hipSuccess) {
+		(void)hipGetLastError();
+		e = hipExtMallocWithFlags(&p, bn::kPeerMailboxBytes, hipDeviceMallocFinegrained);
+	}
+	if (e != hipSuccess) return bn::hip_fail(e, "hipExtMallocWithFlags (peer mailbox)");
+	e = hipMemset(p, 0, bn::kPeerMailboxBytes);
+	hipIpcMemHandle_t h;
+	if (e == hipSuccess) e = hipIpcGetMemHandle(&h, p);
+	if (e != hipSuccess) {
+		(void)hipFree(p);
+		return bn::hip_fail(e, "hipIpcGetMemHandle (peer mailbox)");
+	}
+	std::memset(handle_out, 0, BN_PEER_HANDLE_BYTES);
+	std::memcpy(handle_out, &h, sizeof(h));
+	ctx->peer.world = world;
+	ctx->peer.rank = rank;
+	ctx->peer.own = p;
+	ctx->peer.box[rank] = p;
+	return BN_OK;
+}
+
+int bn_peer_connect(bn_ctx *ctx, const uint8_t *handles)
+{
+	BN_REQUIRE(ctx && handles, "null argument");
+	BN_ENTER(ctx);
+	bn_ctx::peer_state &ps = ctx->peer;
+	BN_REQUIRE(ps.own && !ps.connected, "peer exchange: bn_peer_create first (and connect once)");
+	for (uint32_t w = 0; w < ps.world; w++) {
+		if (w == ps.rank) continue;
+		hipIpcMemHandle_t h;
+		std::memcpy(&h, handles + (size_t)w * BN_PEER_HANDLE_BYTES, sizeof(h));
+		void *p = nullptr;
+		hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+		if (e != hipSuccess) {
+			for (uint32_t v = 0; v < w; v++)
+				if (v != ps.rank && ps.box[v]) {
+					(void)hipIpcCloseMemHandle(ps.box[v]);
+					ps.box[v] = nullptr;
+				}
+			return bn::hip_fail(e, "hipIpcOpenMemHandle (peer mailbox)");
+		}
+		ps.box[w] = p;
+	}
+	ps.connected = true;
+	return BN_OK;
+}
+
+int bn_peer_set_active(bn_ctx *ctx, int on)
+{
+	BN_REQUIRE(ctx, "null argument");
+	BN_ENTER(ctx);
+	BN_FLUSH(ctx);
+	BN_REQUIRE(!on || ctx->peer.connected, "peer exchange: not connected");
+	if (ctx->peer.active != (on != 0)) arm_cancel(ctx); // (a kernel armed under the other setting would publish the wrong thing)
+	ctx->peer.active = on != 0;
+	return BN_OK;
+}
+
+int bn_peer_stats(bn_ctx *ctx, uint64_t *stats)
+{
+	BN_REQUIRE(ctx && stats, "null argument");
+	BN_ENTER(ctx);
+	stats[0] = ctx->peer.round;
+	stats[1] = ctx->peer.connected ? ctx->peer.world : 0;
+	return BN_OK;
+}
+
+int bn_peer_destroy(bn_ctx *ctx)
+{
+	BN_REQUIRE(ctx, "null argument");
+	BN_ENTER(ctx);
+	BN_FLUSH(ctx);
+	arm_cancel(ctx);
+	BN_HIP(hipStreamSynchronize(ctx->stream));
+	peer_release(ctx);
+	return BN_OK;
+}
+
 int bn_ctx_destroy(bn_ctx *ctx)
 {
 	if (!ctx)
@@ -251,6 +354,7 @@ int bn_ctx_destroy(bn_ctx *ctx)
 	arm_cancel(ctx);
 	if (ctx->stream)
 		hipStreamSynchronize(ctx->stream);
+	peer_release(ctx);
 	if (ctx->d_arm_relay) hipFree(ctx->d_arm_relay);
 	if (ctx->hal_const) hipFree(ctx->hal_const);
 	if (ctx->ntt_cache) {

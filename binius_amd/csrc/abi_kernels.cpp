@@ -358,6 +358,15 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 								fz.rets = d_out ? (f128 *)d_out : d_rets;
 								fz.mail = ctx->d_mail;
 								fz.counter = ctx->d_ticket;
+								const bool peer_on = ctx->peer.active;
+								if (peer_on) {
+									// the finalize step of this launch reduces the returned values across the ranks (bn_peer_*)
+									BN_REQUIRE(h_out && !d_out, "peer exchange: a reduced launch returns to the host");
+									fz.peer.world = ctx->peer.world;
+									fz.peer.rank = ctx->peer.rank;
+									for (uint32_t w = 0; w < ctx->peer.world; w++) fz.peer.box[w] = (uint64_t *)ctx->peer.box[w];
+									fz.peer.round = ++ctx->peer.round;
+								}
 								hipError_t fe = hipErrorNotSupported;
 								if (ctx->pend.active) {
 									// fold + evaluate in one pass: this launch reads the halves of exactly the two
@@ -406,6 +415,7 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 											fn.scale_mask = fa_.scale_mask;
 											bn::fin_fuse fzn = fz_;
 											fzn.args.seq = fz_.args.seq + 1;
+											fzn.peer.round = fz_.peer.round + 1; // (unused unless fz_.peer.world > 1)
 											bn::arm_args aa{};
 											aa.h_cmd = (const uint64_t *)&ctx->d_mail[84].lo;
 											aa.h_status = (uint64_t *)&ctx->d_mail[87].lo;
@@ -427,6 +437,7 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 											}
 											am.scale_mask = fn.scale_mask;
 											am.seq = fzn.args.seq;
+											am.peer_round = fzn.peer.world > 1 ? fzn.peer.round : 0;
 											am.d_sums = d_S + slot;
 											am.recipe = recipe_bytes(fzn.args);
 										};
@@ -434,7 +445,7 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 										if (ctx->arm.active) {
 											bn_ctx::arm_state &am = ctx->arm;
 											bool same = h_out && !d_out && n_in == am.n_in && fa.scale_mask == am.scale_mask && fz.args.seq == am.seq &&
-											            d_S + slot == am.d_sums;
+											            d_S + slot == am.d_sums && am.peer_round == (fz.peer.world > 1 ? fz.peer.round : 0);
 											for (uint32_t j = 0; j < 2 && same; j++)
 												same = fa.x0[j] == am.x0[j] && fa.x1[j] == am.x1[j] && fa.out[j] == am.out[j];
 											if (same) same = recipe_bytes(fz.args) == am.recipe;
@@ -475,6 +486,10 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 													}
 												}
 												if (got) {
+													if (peer_on && __atomic_load_n(&ctx->h_mail[65].lo, __ATOMIC_RELAXED) == fz.peer.round) {
+														arm_cancel(ctx);
+														return bn::fail(BN_ERR_DEVICE, "device error: peer exchange timed out waiting for a rank");
+													}
 													for (uint32_t r = 0; r < n_ret; r++) {
 														h_out[r].lo = __atomic_load_n(&ctx->h_mail[r].lo, __ATOMIC_RELAXED);
 														h_out[r].hi = __atomic_load_n(&ctx->h_mail[r].hi, __ATOMIC_RELAXED);
@@ -496,7 +511,7 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 										// (a) a resident tail kernel is parked for exactly this round: hand it z
 										if (ctx->tail.active) {
 											bn_ctx::tail_state &tl = ctx->tail;
-											const bool same = h_out && !d_out && n_in == tl.n_in_next && fa.x0[0] == fa.out[0] && fa.x0[1] == fa.out[1] &&
+											const bool same = !peer_on && h_out && !d_out && n_in == tl.n_in_next && fa.x0[0] == fa.out[0] && fa.x0[1] == fa.out[1] &&
 											                  ((fa.out[0] == tl.out[0] && fa.out[1] == tl.out[1]) || (fa.out[0] == tl.out[1] && fa.out[1] == tl.out[0])) &&
 											                  fz.args.seq == tl.seq0 + tl.round + 1 && recipe_bytes(fz.args) == tl.recipe &&
 											                  __atomic_load_n(tail_status(ctx), __ATOMIC_ACQUIRE) != tl.id;
@@ -541,7 +556,7 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 											}
 										}
 										// (b) small arrays: start a resident tail kernel with this round
-										if (fe == hipErrorNotSupported && !fa.scale_mask && h_out && !d_out && ctx->tail_max_n_in && n_in <= ctx->tail_max_n_in && n_in >= 8) {
+										if (fe == hipErrorNotSupported && !peer_on && !fa.scale_mask && h_out && !d_out && ctx->tail_max_n_in && n_in <= ctx->tail_max_n_in && n_in >= 8) {
 											bn_ctx::tail_state &tl = ctx->tail;
 											const uint64_t id = ++ctx->tail_counter;
 											prof_scope ps(ctx, BN_PROF_TAIL);
@@ -586,8 +601,9 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 									fused_seq = fz.args.seq;
 								} else if (fe != hipErrorNotSupported) {
 									return bn::hip_fail(fe, "launch_roundeval_product (fused finalize)");
-								} else if (h_out) {
-									--ctx->mail_seq;
+								} else {
+									if (h_out) --ctx->mail_seq;
+									if (peer_on) --ctx->peer.round;
 								}
 							}
 							if (!in_kernel) {
@@ -681,8 +697,12 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 	fa.n_slots = n_slots;
 	fa.seq = finalized_in_kernel ? fused_seq : (h_out ? ++ctx->mail_seq : 0);
 	f128 *rets = d_out ? (f128 *)d_out : d_rets;
-	if (!finalized_in_kernel)
+	if (!finalized_in_kernel) {
+		if (ctx->peer.active)
+			return bn::fail(BN_ERR_INPUT_VALIDATION, "input validation: with the peer exchange active only launches of the round-evaluation shape (one pair of "
+			                                      "product sums returned to the host) can be reduced across the ranks");
 		BN_HIP(bn::launch_finalize(s, fa, d_S, rets, ctx->d_mail));
+	}
 	ctx->s_clean = true; // stream-ordered: the next launch on this stream sees zeroed slots
 	if (h_out) {
 		// spin on the sequence word the kernel publishes after the values (fine-grained host memory)
@@ -699,6 +719,10 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 					return bn::fail(BN_ERR_DEVICE, "device error: result mailbox was not published");
 				break;
 			}
+		}
+		if (ctx->peer.active && finalized_in_kernel && __atomic_load_n(&ctx->h_mail[65].lo, __ATOMIC_RELAXED) == ctx->peer.round) {
+			arm_cancel(ctx);
+			return bn::fail(BN_ERR_DEVICE, "device error: peer exchange timed out waiting for a rank");
 		}
 		for (uint32_t r = 0; r < n_ret; r++) {
 			h_out[r].lo = __atomic_load_n(&ctx->h_mail[r].lo, __ATOMIC_RELAXED);

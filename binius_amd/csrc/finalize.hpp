@@ -34,6 +34,54 @@ __device__ __forceinline__ uint32_t fin_wave_xor(uint32_t v)
 	return v;
 }
 
+// ---- cross-rank reduction (fin_peer, internal.hpp) -------------------------------------------------------------------
+// Wave 0 of the finalizing workgroup; vals[0 .. n_ret) in LDS hold this rank's returned values on entry and the XOR over
+// all ranks on exit.  Lane p < world talks to rank p: it stores the values into slot `rank` of p's mailbox (system-scope
+// stores into fine-grained memory, the round number last with release semantics), then waits for slot p of its OWN
+// mailbox to show this round's number and reads rank p's values.  Two parities: a rank can be at most one round ahead
+// of the slowest reader (it needs everybody's round r + 1 values, which they send after reading round r).  The wait
+// is bounded (a rank that died cannot park the device): on a timeout the function returns false and the caller
+// reports it through mail[65].
+__device__ __forceinline__ bool peer_exchange(f128 *vals, uint32_t n_ret, uint64_t *const *box, uint32_t world, uint32_t rank, uint64_t round)
+{
+	const unsigned p = threadIdx.x; // < 64
+	const unsigned par = (unsigned)(round & 1);
+	bool ok = true;
+	const uint64_t *src = nullptr;
+	if (p < world) {
+		uint64_t *dst = box[p] + (size_t)(par * kPeerMaxWorld + rank) * kPeerSlotWords;
+		for (uint32_t r = 0; r < n_ret; r++) {
+			__hip_atomic_store(dst + 2 * r, vals[r].lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			__hip_atomic_store(dst + 2 * r + 1, vals[r].hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		}
+		__hip_atomic_store(dst + 16, round, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+		src = box[rank] + (size_t)(par * kPeerMaxWorld + p) * kPeerSlotWords;
+		uint32_t spins = 0;
+		while (__hip_atomic_load(src + 16, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != round) {
+			if (++spins > (1u << 21)) { // ~1 us per look: gives up after a couple of seconds
+				ok = false;
+				break;
+			}
+			__builtin_amdgcn_s_sleep(1);
+		}
+	}
+	ok = __all(ok);
+	for (uint32_t r = 0; r < n_ret; r++) {
+		uint64_t lo = 0, hi = 0;
+		if (p < world && ok) {
+			lo = __hip_atomic_load(src + 2 * r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			hi = __hip_atomic_load(src + 2 * r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		}
+#pragma unroll
+		for (int m = 8; m >= 1; m >>= 1) { // world <= 16
+			lo ^= __shfl_xor(lo, m, 64);
+			hi ^= __shfl_xor(hi, m, 64);
+		}
+		if (p == 0) vals[r] = f128{lo, hi};
+	}
+	return ok;
+}
+
 // Must be called by EVERY thread of a workgroup with >= 128 threads (it contains barriers).
 // S_local == nullptr: the raw sums are in global memory (S, XOR-accumulated by all workgroups) and are
 // read with agent-scope atomic loads, all terms at once (one memory round trip), then re-zeroed.
@@ -42,7 +90,7 @@ __device__ __forceinline__ uint32_t fin_wave_xor(uint32_t v)
 // Term t is folded in by 128 threads (lane i contributes bit_i(S) ? coeff * 2^i : 0, gf128.hpp
 // mul_basis); a workgroup of 256 threads handles two terms per pass.
 __device__ __forceinline__ void finalize_body(const fin_args &a, f128 *S, f128 *rets, f128 *mail, uint64_t seq,
-                                              const f128 *S_local = nullptr)
+                                              const f128 *S_local = nullptr, const fin_peer *peer = nullptr)
 {
 	__shared__ f128 fin_S[kFinMaxTerms];
 	__shared__ uint64_t fin_red[4][2][2];   // [term group][wave in group][lo/hi]
@@ -99,6 +147,19 @@ __device__ __forceinline__ void finalize_body(const fin_args &a, f128 *S, f128 *
 		__syncthreads();
 	}
 	BN_FTS(10);
+	if (peer && peer->world > 1) {
+		// returned values of this rank -> XOR over all ranks (the barriers are uniform: peer is a kernel argument)
+		__shared__ f128 fin_pv[kFinMaxRets];
+		if (tid < a.n_ret) fin_pv[tid] = fin_values[a.ret_ids[tid]];
+		__syncthreads();
+		if (tid < 64) {
+			const bool ok = peer_exchange(fin_pv, a.n_ret, peer->box, peer->world, peer->rank, peer->round);
+			if (!ok && tid == 0 && seq) __hip_atomic_store(&mail[65].lo, peer->round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		}
+		__syncthreads();
+		if (tid < a.n_ret) fin_values[a.ret_ids[tid]] = fin_pv[tid];
+		__syncthreads();
+	}
 	if (tid < a.n_ret) {
 		const f128 v = fin_values[a.ret_ids[tid]];
 		rets[tid] = v;
@@ -137,10 +198,14 @@ struct fin_cache {
 	uint32_t all_one; // every batch coefficient is 1: value = init ^ XOR of its sums, no multiplication
 	f128 *S, *rets, *mail;
 	unsigned *counter;
+	uint64_t *peer_box[kPeerMaxWorld];
+	uint32_t peer_world, peer_rank;
+	uint64_t peer_round;
 };
 struct fin_pref {
 	f128 coeff, init;
 	uint32_t slot, value, ret_id;
+	uint64_t *peer_box;
 };
 
 // every thread of the workgroup (>= 64 threads); only the first kFinMaxTerms lanes load
@@ -154,6 +219,7 @@ __device__ __forceinline__ fin_pref fin_prefetch(const fin_fuse &fz)
 		r.value = fz.args.terms[tid].value;
 		r.init = fz.args.init[tid & (kFinMaxValues - 1)];
 		r.ret_id = fz.args.ret_ids[tid & (kFinMaxRets - 1)];
+		r.peer_box = fz.peer.box[tid & (kPeerMaxWorld - 1)];
 	}
 	return r;
 }
@@ -173,7 +239,11 @@ __device__ __forceinline__ void fin_commit(const fin_fuse &fz, const fin_pref &r
 		}
 		if (tid < kFinMaxValues) c.init[tid] = r.init;
 		if (tid < kFinMaxRets) c.ret_ids[tid] = r.ret_id;
+		if (tid < kPeerMaxWorld) c.peer_box[tid] = r.peer_box;
 		if (tid == 0) {
+			c.peer_world = fz.peer.world;
+			c.peer_rank = fz.peer.rank;
+			c.peer_round = fz.peer.round;
 			c.n_terms = n_terms;
 			c.n_values = fz.args.n_values;
 			c.n_ret = fz.args.n_ret;
@@ -255,6 +325,18 @@ __device__ __forceinline__ void finalize_cached(const fin_cache &c, uint64_t seq
 		}
 	}
 	BN_FTS(10);
+	if (c.peer_world > 1) {
+		__shared__ f128 fc_pv[kFinMaxRets];
+		if (tid < n_ret) fc_pv[tid] = fc_values[c.ret_ids[tid]];
+		__syncthreads();
+		if (tid < 64) {
+			const bool ok = peer_exchange(fc_pv, n_ret, c.peer_box, c.peer_world, c.peer_rank, c.peer_round);
+			if (!ok && tid == 0 && seq) __hip_atomic_store(&mail[65].lo, c.peer_round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		}
+		__syncthreads();
+		if (tid < n_ret) fc_values[c.ret_ids[tid]] = fc_pv[tid];
+		__syncthreads();
+	}
 	if (tid < n_ret) {
 		const f128 v = fc_values[c.ret_ids[tid]];
 		rets[tid] = v;

@@ -324,7 +324,7 @@ __device__ __forceinline__ void tail_finish(gram_parity &Gc, unsigned wave, unsi
 		if (fc)
 			finalize_cached(*fc, seq, s_loc);
 		else
-			finalize_body(fz.args, fz.S, fz.rets, fz.mail, seq, s_loc);
+			finalize_body(fz.args, fz.S, fz.rets, fz.mail, seq, s_loc, &fz.peer);
 		return;
 	}
 	if (tid < 4) {
@@ -345,7 +345,7 @@ __device__ __forceinline__ void tail_finish(gram_parity &Gc, unsigned wave, unsi
 			if (fc)
 				finalize_cached(*fc, seq);
 			else
-				finalize_body(fz.args, fz.S, fz.rets, fz.mail, seq);
+				finalize_body(fz.args, fz.S, fz.rets, fz.mail, seq, nullptr, &fz.peer);
 			if (tid == 0)
 				__hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}

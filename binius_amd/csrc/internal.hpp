@@ -21,6 +21,10 @@ struct bn_expr {
 	int device = 0;
 };
 
+namespace bn {
+constexpr int kPeerMaxWorld = 16; // ranks of one node that can share a peer exchange (finalize.hpp)
+}
+
 struct bn_ctx {
 	std::recursive_mutex mu; // serialises the entry points of this context
 	int device = 0;
@@ -111,6 +115,7 @@ struct bn_ctx {
 		void *out[2] = {};
 		uint32_t scale_mask = 0;
 		uint64_t seq = 0;      // the mailbox sequence number it will publish
+		uint64_t peer_round = 0; // the peer-exchange round it will take part in (0: none)
 		bn::f128 *d_sums = nullptr; // its accumulator slots
 		std::vector<unsigned char> recipe;
 	} arm;
@@ -120,6 +125,14 @@ struct bn_ctx {
 	uint64_t arm_hits = 0, arm_cancels = 0, arm_expired = 0;
 	uint64_t arm_ns_parse = 0; // entry of bn_kernel_launch -> challenge handed over
 	uint64_t arm_ns_wait = 0, arm_ns_launch = 0; // go -> mailbox seen; of which: enqueueing the next armed kernel
+	// cross-rank reduction inside the finalize step (bn_peer_*, finalize.hpp peer_exchange)
+	struct peer_state {
+		uint32_t world = 0, rank = 0;
+		void *own = nullptr;                       // this rank's mailbox (fine-grained device memory)
+		void *box[bn::kPeerMaxWorld] = {};         // every rank's mailbox as mapped here (box[rank] == own)
+		bool connected = false, active = false;    // active: reduce the round evaluations launched from now on
+		uint64_t round = 0;                        // rounds executed so far (monotonic for the life of the attachment)
+	} peer;
 };
 
 namespace bn {
@@ -179,6 +192,19 @@ struct fin_args {
 hipError_t launch_finalize(hipStream_t s, const fin_args &args, f128 *d_S, f128 *d_rets, f128 *d_mail);
 hipError_t launch_xor_publish(hipStream_t s, const f128 *d_vals, uint32_t n_groups, uint32_t group_len, f128 *d_rets, f128 *d_mail,
                               uint64_t seq);
+// Cross-rank reduction of the returned values inside the finalize step (sharded sumcheck, SURVEY.md section 8e;
+// bn_peer_*): every rank owns a mailbox in fine-grained device memory that all ranks of the node have mapped
+// (hipIpc; over xGMI between devices).  The finalizing workgroup stores this rank's returned values into its slot of
+// EVERY rank's mailbox, waits until all `world` slots of its own mailbox carry this round's number, and publishes
+// the XOR.  Mailbox = [2 (round parity)][kPeerMaxWorld (writer rank)][kPeerSlotWords] 64-bit words; slot words
+// 0 .. 2 n_ret - 1 = values, word 16 = round number (written last, release).
+constexpr int kPeerSlotWords = 24;
+constexpr size_t kPeerMailboxBytes = 2 * kPeerMaxWorld * kPeerSlotWords * sizeof(uint64_t);
+struct fin_peer {
+	uint64_t *box[kPeerMaxWorld]; // device-visible mailbox of every rank (box[rank] = this rank's own)
+	uint32_t world, rank;         // world <= 1: no exchange
+	uint64_t round;               // >= 1, the same on every rank, +1 per reduced launch
+};
 // fused form: the last workgroup to finish (device-scope ticket counter) runs the finalize body
 struct fin_fuse {
 	fin_args args;
@@ -186,6 +212,7 @@ struct fin_fuse {
 	f128 *rets;
 	f128 *mail;
 	unsigned *counter; // zero before the launch; the last workgroup resets it
+	fin_peer peer;
 };
 // generic: sum_i C(rows[0][i], ..) over a circuit, XOR-accumulated into d_out[0]
 hipError_t launch_sum_composition_generic(hipStream_t s, int n_cu, const void *const *d_rows_dev, uint32_t n_rows,

@@ -118,7 +118,7 @@ __device__ __forceinline__ void tail(const uint32_t (&acc)[32], bool live, unsig
 		if (fc)
 			finalize_cached(*fc, seq, s_loc);
 		else
-			finalize_body(fz.args, fz.S, fz.rets, fz.mail, seq, s_loc);
+			finalize_body(fz.args, fz.S, fz.rets, fz.mail, seq, s_loc, &fz.peer);
 		return;
 	}
 	if (threadIdx.x < 4) {
@@ -149,7 +149,7 @@ __device__ __forceinline__ void tail(const uint32_t (&acc)[32], bool live, unsig
 			if (fc)
 				finalize_cached(*fc, seq);
 			else
-				finalize_body(fz.args, fz.S, fz.rets, fz.mail, seq);
+				finalize_body(fz.args, fz.S, fz.rets, fz.mail, seq, nullptr, &fz.peer);
 			if (threadIdx.x == 0)
 				__hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}

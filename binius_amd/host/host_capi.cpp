@@ -197,6 +197,27 @@ int bnh_bivariate_sumcheck_prove(bn_ctx *ctx, uint32_t n_vars, uint32_t m, const
                                  bn_f128 *final_evals_out, bnh_round_reduce_fn reduce, void *reduce_user, void *d_partial,
                                  void *rccl_comm, int world, void *d_gathered, void *shm, int tail_rounds)
 {
+	// tail_rounds: bit 0 = run the residual rounds inside this call; bit 1 = "peer" exchange: the ranks' partial round
+	// evaluations are XORed on the devices, inside the kernels' finalize step (bn_peer_*; the context must be connected),
+	// and the host sees the global (y_1, y_inf) in its own mailbox -- `shm` then only carries the one-off rebuild of the
+	// residual instance
+	const bool peer = (tail_rounds & 2) != 0;
+	tail_rounds &= 1;
+	struct peer_scope { // local rounds reduced, everything else local
+		bn_ctx *c;
+		bool on = false;
+		void set(bool v)
+		{
+			if (v != on) {
+				if (bn_peer_set_active(c, v ? 1 : 0) != 0) throw Error(Error::DeviceError, bn_last_error());
+				on = v;
+			}
+		}
+		~peer_scope()
+		{
+			if (on) (void)bn_peer_set_active(c, 0);
+		}
+	} peer_guard{ctx};
 	try {
 		ComputeLayer hal(ctx);
 		DeviceBumpAllocator dev_alloc(FSliceMut{d_scratch, (size_t)scratch_elems});
@@ -211,7 +232,7 @@ int bnh_bivariate_sumcheck_prove(bn_ctx *ctx, uint32_t n_vars, uint32_t m, const
 			sv.emplace_back(sums[c].lo, sums[c].hi);
 		}
 		const B128 bc(batch_coeff->lo, batch_coeff->hi);
-		if (!reduce && !rccl_comm && !shm) {
+		if (!reduce && !rccl_comm && !shm && !peer) {
 			BivariateSumcheckProver prover(hal, dev_alloc, host_alloc, n_vars, comps, sv, mls);
 			for (uint32_t r = 0; r < n_vars; r++) {
 				std::vector<B128> rc = prover.execute(bc);
@@ -251,8 +272,8 @@ int bnh_bivariate_sumcheck_prove(bn_ctx *ctx, uint32_t n_vars, uint32_t m, const
 				const std::vector<B128> part = calculate_round_evals(hal, rem, bc, cmls, evaluators);
 				const uint64_t mine[4] = {part[0].raw().lo, part[0].raw().hi, part[1].raw().lo, part[1].raw().hi};
 				std::vector<uint64_t> all((size_t)4 * world);
-				const int n_src = exchange ? world : 1;
-				if (exchange) {
+				const int n_src = (exchange && !peer) ? world : 1;
+				if (exchange && !peer) {
 					if (bnh_shm_allgather(shm, mine, 4, all.data())) throw Error(Error::DeviceError, g_err);
 				} else {
 					for (int i = 0; i < 4; i++) all[i] = mine[i];
@@ -330,7 +351,12 @@ int bnh_bivariate_sumcheck_prove(bn_ctx *ctx, uint32_t n_vars, uint32_t m, const
 			pre_fold = false;
 		}
 		};
+		if (peer) {
+			if (!shm) throw Error(Error::InputValidation, "the peer exchange needs the shared-memory segment for the residual instance");
+			peer_guard.set(true);
+		}
 		do_rounds(n_vars, true, challenges, round_coeffs_out);
+		peer_guard.set(false);
 		uint32_t log_world = 0;
 		while ((1 << (log_world + 1)) <= world) log_world++;
 		if (rccl_comm && !shm && tail_rounds && log_world > 0) {

@@ -251,6 +251,28 @@ int bn_host_scratch(bn_ctx *ctx, void **h_ptr, void **d_ptr, uint64_t *elems);
  * the multi-GPU prover (RCCL has no XOR reduction). */
 int bn_xor_reduce(bn_ctx *ctx, const void *d_vals, uint32_t n_groups, uint32_t group_len, bn_f128 *h_out);
 
+/* ---- Cross-rank reduction of round evaluations inside the kernel's finalize step (one process
+ * per GPU, the hypercube sharded on the last-bound variables; the only exchange of a sumcheck round is one partial
+ * (y_1, y_inf) per rank -- crates/core/src/protocols/sumcheck/v3/bivariate_product.rs:303-408 is a sum over hypercube
+ * points, so the shards' sums add).  Not part of the reference interface.
+ *   bn_peer_create   allocates this rank's mailbox (BN_PEER_MAILBOX_BYTES of fine-grained device memory) and returns
+ *                    its hipIpc handle (BN_PEER_HANDLE_BYTES) for the caller to hand to the other ranks of the node
+ *   bn_peer_connect  maps every rank's mailbox (handles[world][BN_PEER_HANDLE_BYTES], rank-major; the own entry is
+ *                    ignored) -- same-device peers on a one-GPU box, xGMI peers on a node
+ *   bn_peer_set_active(1)  from now on every bn_kernel_launch of the round-evaluation shape that returns to the host
+ *                    returns the XOR over all ranks of the values it would have returned alone: the finalizing workgroup
+ *                    stores its values into every peer's mailbox, waits for the world's, XORs (csrc/finalize.hpp
+ *                    peer_exchange).  All ranks must issue the same sequence of such launches.  Values declared with a
+ *                    non-zero initial value are XORed in once per rank.  Any other launch shape fails loudly while
+ *                    active.  (0): back to local results (e.g. for the residual rounds every rank runs identically).
+ *   bn_peer_stats    stats[0] = reduced launches so far */
+enum { BN_PEER_HANDLE_BYTES = 64, BN_PEER_MAX_WORLD = 16, BN_PEER_MAILBOX_BYTES = 2 * 16 * 24 * 8 };
+int bn_peer_create(bn_ctx *ctx, uint32_t world, uint32_t rank, uint8_t *handle_out /*[BN_PEER_HANDLE_BYTES]*/);
+int bn_peer_connect(bn_ctx *ctx, const uint8_t *handles /*[world][BN_PEER_HANDLE_BYTES]*/);
+int bn_peer_set_active(bn_ctx *ctx, int on);
+int bn_peer_stats(bn_ctx *ctx, uint64_t *stats /*[2]*/);
+int bn_peer_destroy(bn_ctx *ctx);
+
 /* ---- Merkle commitment of a BinaryField128b vector with Groestl-256.
  * BinaryMerkleTreeProver::commit (crates/core/src/merkle_tree/prover.rs:47-62) =
  * binary_merkle_tree::build (binary_merkle_tree.rs:27-101) with H = Groestl256

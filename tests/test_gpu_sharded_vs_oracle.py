@@ -30,7 +30,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n_global, m, comps, q):
+def _worker(rank, world, port, n_global, m, comps, q, exchange="shm"):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -65,6 +65,13 @@ def _worker(rank, world, port, n_global, m, comps, q):
         stream = synthetic.random_scalars(0xC4A1, n_global + 1)
         batch_coeff, challenges = stream[0], stream[1:]
         shm = ShmExchange(dist, rank, world)
+        peer = None
+        if exchange == "peer":
+            from binius_amd._host import PeerExchange
+
+            peer = PeerExchange(hal, dist, rank, world)  # device mailboxes, hipIpc-mapped into every rank
+        else:
+            assert exchange == "shm"
         sums = [shm.xor_scalars([hal.inner_product(d_in[i], 7, d_in[j])])[0] for i, j in comps]
         plan = SumcheckPlan(hal, n_local, d_in, scratch, comps, sums, batch_coeff, challenges[:n_global], None, 0, None, world, 0,
                             shm.handle, tail_rounds=True)
@@ -72,6 +79,9 @@ def _worker(rank, world, port, n_global, m, comps, q):
         first = (plan.round_coeffs(), plan.final_evals())
         plan.run()  # a second run from the same inputs: the prover must not have modified them
         q.put((rank, sums, first[0], first[1], (plan.round_coeffs(), plan.final_evals()) == first))
+        if peer is not None:
+            assert peer.rounds() > 0, "the peer exchange was never used"
+            peer.close()
         shm.close()
     finally:
         if hal is not None:

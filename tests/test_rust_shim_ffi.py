@@ -8,7 +8,7 @@ import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-C_SCALARS = {"int": "c_int", "uint32_t": "u32", "uint64_t": "u64", "float": "f32", "double": "f64", "char": "c_char", "void": "c_void",
+C_SCALARS = {"int": "c_int", "uint8_t": "u8", "uint32_t": "u32", "uint64_t": "u64", "float": "f32", "double": "f64", "char": "c_char", "void": "c_void",
              "bn_f128": "bn_f128", "bn_ctx": "bn_ctx", "bn_expr": "bn_expr", "bn_step": "bn_step", "bn_memmap": "bn_memmap", "bn_kslice": "bn_kslice",
              "bn_kop": "bn_kop", "bn_hal_multilinear": "bn_hal_multilinear", "bn_hal_evaluator": "bn_hal_evaluator"}
 
