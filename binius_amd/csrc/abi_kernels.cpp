@@ -697,11 +697,20 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 	fa.n_slots = n_slots;
 	fa.seq = finalized_in_kernel ? fused_seq : (h_out ? ++ctx->mail_seq : 0);
 	f128 *rets = d_out ? (f128 *)d_out : d_rets;
+	bool peer_standalone = false;
 	if (!finalized_in_kernel) {
-		if (ctx->peer.active)
-			return bn::fail(BN_ERR_INPUT_VALIDATION, "input validation: with the peer exchange active only launches of the round-evaluation shape (one pair of "
-			                                      "product sums returned to the host) can be reduced across the ranks");
-		BN_HIP(bn::launch_finalize(s, fa, d_S, rets, ctx->d_mail));
+		bn::fin_peer pr{};
+		if (ctx->peer.active) {
+			// (several batched compositions, or any other shape the fused finalize does not cover: the stand-alone finalize
+			// kernel does the same reduction)
+			BN_REQUIRE(h_out && !d_out, "peer exchange: a reduced launch returns to the host");
+			pr.world = ctx->peer.world;
+			pr.rank = ctx->peer.rank;
+			for (uint32_t w = 0; w < ctx->peer.world; w++) pr.box[w] = (uint64_t *)ctx->peer.box[w];
+			pr.round = ++ctx->peer.round;
+			peer_standalone = true;
+		}
+		BN_HIP(bn::launch_finalize(s, fa, d_S, rets, ctx->d_mail, &pr));
 	}
 	ctx->s_clean = true; // stream-ordered: the next launch on this stream sees zeroed slots
 	if (h_out) {
@@ -720,7 +729,7 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 				break;
 			}
 		}
-		if (ctx->peer.active && finalized_in_kernel && __atomic_load_n(&ctx->h_mail[65].lo, __ATOMIC_RELAXED) == ctx->peer.round) {
+		if (ctx->peer.active && (finalized_in_kernel || peer_standalone) && __atomic_load_n(&ctx->h_mail[65].lo, __ATOMIC_RELAXED) == ctx->peer.round) {
 			arm_cancel(ctx);
 			return bn::fail(BN_ERR_DEVICE, "device error: peer exchange timed out waiting for a rank");
 		}

@@ -189,7 +189,8 @@ struct fin_args {
 	uint32_t ret_ids[kFinMaxRets];
 };
 // values[v] = init[v] ^ XOR_t coeff_t * S[slot_t], then rets[i] = values[ret_ids[i]]
-hipError_t launch_finalize(hipStream_t s, const fin_args &args, f128 *d_S, f128 *d_rets, f128 *d_mail);
+struct fin_peer; // below: cross-rank reduction of the returned values (nullptr / world <= 1: none)
+hipError_t launch_finalize(hipStream_t s, const fin_args &args, f128 *d_S, f128 *d_rets, f128 *d_mail, const fin_peer *peer = nullptr);
 hipError_t launch_xor_publish(hipStream_t s, const f128 *d_vals, uint32_t n_groups, uint32_t group_len, f128 *d_rets, f128 *d_mail,
                               uint64_t seq);
 // Cross-rank reduction of the returned values inside the finalize step (sharded sumcheck, SURVEY.md section 8e;

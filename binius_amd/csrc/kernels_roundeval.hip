@@ -332,14 +332,16 @@ hipError_t launch_compute_composite_generic(hipStream_t s, const void *const *d_
 }
 
 // ---- finalize: value[v] = init ^ XOR_t coeff_t * S[slot_t]; rets gathered ---------------------
-__global__ __launch_bounds__(128) void k_finalize(fin_args a, f128 *S, f128 *rets, f128 *mail)
+__global__ __launch_bounds__(128) void k_finalize(fin_args a, f128 *S, f128 *rets, f128 *mail, fin_peer peer)
 {
-	finalize_body(a, S, rets, mail, a.seq);
+	finalize_body(a, S, rets, mail, a.seq, nullptr, &peer);
 }
 
-hipError_t launch_finalize(hipStream_t s, const fin_args &args, f128 *d_S, f128 *d_rets, f128 *d_mail)
+hipError_t launch_finalize(hipStream_t s, const fin_args &args, f128 *d_S, f128 *d_rets, f128 *d_mail, const fin_peer *peer)
 {
-	hipLaunchKernelGGL(k_finalize, dim3(1), dim3(128), 0, s, args, d_S, d_rets, d_mail);
+	fin_peer pr{};
+	if (peer) pr = *peer;
+	hipLaunchKernelGGL(k_finalize, dim3(1), dim3(128), 0, s, args, d_S, d_rets, d_mail, pr);
 	return hipGetLastError();
 }
 

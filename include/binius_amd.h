@@ -259,12 +259,12 @@ int bn_xor_reduce(bn_ctx *ctx, const void *d_vals, uint32_t n_groups, uint32_t g
  *                    its hipIpc handle (BN_PEER_HANDLE_BYTES) for the caller to hand to the other ranks of the node
  *   bn_peer_connect  maps every rank's mailbox (handles[world][BN_PEER_HANDLE_BYTES], rank-major; the own entry is
  *                    ignored) -- same-device peers on a one-GPU box, xGMI peers on a node
- *   bn_peer_set_active(1)  from now on every bn_kernel_launch of the round-evaluation shape that returns to the host
+ *   bn_peer_set_active(1)  from now on every bn_kernel_launch that returns values to the host (h_out)
  *                    returns the XOR over all ranks of the values it would have returned alone: the finalizing workgroup
  *                    stores its values into every peer's mailbox, waits for the world's, XORs (csrc/finalize.hpp
  *                    peer_exchange).  All ranks must issue the same sequence of such launches.  Values declared with a
- *                    non-zero initial value are XORed in once per rank.  Any other launch shape fails loudly while
- *                    active.  (0): back to local results (e.g. for the residual rounds every rank runs identically).
+ *                    non-zero initial value are XORed in once per rank.  (0): back to local results (e.g. for the residual
+ *                    rounds every rank runs identically).
  *   bn_peer_stats    stats[0] = reduced launches so far */
 enum { BN_PEER_HANDLE_BYTES = 64, BN_PEER_MAX_WORLD = 16, BN_PEER_MAILBOX_BYTES = 2 * 16 * 24 * 8 };
 int bn_peer_create(bn_ctx *ctx, uint32_t world, uint32_t rank, uint8_t *handle_out /*[BN_PEER_HANDLE_BYTES]*/);

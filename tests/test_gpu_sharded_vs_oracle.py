@@ -3,8 +3,9 @@
 A global SplitMix64 instance is sharded with shard_indices (rank g owns the global indices = g mod G,
 crates/core/src/protocols/sumcheck/v3/bivariate_product.rs:129-131,199,321: High-to-Low binding, so the
 shard id is taken from the variables bound last); 2 and 4 ranks share cuda:0 (process group over gloo,
-per-round exchange through host shared memory -- RCCL refuses several ranks on one device; its
-transport differs from this one only in how the 32-byte partials travel).  Every rank runs the compiled
+per-round exchange through host shared memory ("shm") or through the peers' hipIpc-mapped device mailboxes inside
+the kernels' finalize step ("peer", csrc/finalize.hpp) -- RCCL refuses several ranks on one device; its transport
+differs only in how the 32-byte partials travel).  Every rank runs the compiled
 prover of bench.py (SumcheckPlan: fused fold + evaluation kernels, residual rounds inside the call) on
 ITS shard; the round polynomials and final evaluations must equal oracle.bivariate_sumcheck_prove on the
 unsharded arrays, bit for bit.  A rank whose contribution was dropped or mis-indexed cannot pass.
@@ -74,7 +75,7 @@ def _worker(rank, world, port, n_global, m, comps, q, exchange="shm"):
             assert exchange == "shm"
         sums = [shm.xor_scalars([hal.inner_product(d_in[i], 7, d_in[j])])[0] for i, j in comps]
         plan = SumcheckPlan(hal, n_local, d_in, scratch, comps, sums, batch_coeff, challenges[:n_global], None, 0, None, world, 0,
-                            shm.handle, tail_rounds=True)
+                            shm.handle, tail_rounds=True, peer=peer is not None)
         plan.run()
         first = (plan.round_coeffs(), plan.final_evals())
         plan.run()  # a second run from the same inputs: the prover must not have modified them
@@ -93,7 +94,8 @@ def _worker(rank, world, port, n_global, m, comps, q, exchange="shm"):
     "world,n_global,m,comps",
     [(2, 10, 2, [(0, 1)]), (4, 11, 2, [(0, 1)]), (2, 9, 3, [(0, 1), (2, 0)]), (4, 12, 3, [(0, 1), (2, 0)]), (2, 21, 2, [(0, 1)]), (4, 22, 2, [(0, 1)])],
 )
-def test_sharded_hip_prover_matches_unsharded_oracle(world, n_global, m, comps):
+@pytest.mark.parametrize("exchange", ["shm", "peer"])
+def test_sharded_hip_prover_matches_unsharded_oracle(world, n_global, m, comps, exchange):
     import torch.multiprocessing as mp
 
     import oracle
@@ -102,7 +104,7 @@ def test_sharded_hip_prover_matches_unsharded_oracle(world, n_global, m, comps):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_global, m, comps, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_global, m, comps, q, exchange)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=300) for _ in range(world)]
