@@ -107,6 +107,9 @@ def main():
         # (RCCL refuses that; the shared-memory exchange does not need it)
         if os.environ.get("BN_ALL_ON_GPU0") == "1":
             local_rank = 0
+            # ranks that share a device must not arm rounds (csrc/arm.hpp): an armed kernel waits ON the device, and several
+            # processes' worth of waiting workgroups leave no compute units for the kernels the challenges depend on
+            os.environ.setdefault("BN_ARM", "0")
         backend = os.environ.get("BN_PG_BACKEND", "nccl")
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
@@ -341,6 +344,7 @@ def main():
     #   round_eval       k_roundeval9       round 0, 9-lane VALU kernel        fold_eval        k_foldeval9<2>   (the next size down)
     #   fold             k_extrapolate_line / k_fold_publish (last fold)       fold_eval_small  k_foldeval9_small (one workgroup per batch: latency-shaped)
     #                                                                          tail             k_foldeval_tail  (resident; opt-in)
+    #                                                                          fold_eval8       k_foldeval8      (two rounds per launch: the small rounds)
     K = args.steps
     counts = {c: prof[c][1] // K if K else 0 for c in prof}
     # the fused launches of a step, largest round first: mfma, then k_foldeval9<2>, then small, then tail
@@ -351,7 +355,11 @@ def main():
         f = counts.get(c, 0)
         fused_bytes[c] = sum(24 * m * (1 << r) for r in range(r_hi - f + 1, r_hi + 1)) * K
         r_hi -= f
-    fused = sum(counts.get(c, 0) for c in order) + counts.get("tail", 0) > 0
+    # two-round launches (k_foldeval8, kernels_foldeval8.hip): the first folds once (pre-fold size 2^r_hi), every later one
+    # folds twice -- 2^(r_hi - 1), 2^(r_hi - 3), ... -- each reads its arrays once and writes half of them: 24*m*n_in
+    f8 = counts.get("fold_eval8", 0)
+    fused_bytes["fold_eval8"] = sum(24 * m * (1 << r) for r in ([r_hi] + [r_hi - 1 - 2 * i for i in range(f8 - 1)] if f8 else []) if r >= 2) * K
+    fused = sum(counts.get(c, 0) for c in order) + counts.get("tail", 0) + f8 > 0
     tl_bytes = sum(24 * m * (1 << r) for r in range(2, r_hi + 1)) * K if counts.get("tail", 0) else 0
     n_re = counts.get("round_eval", 0) + counts.get("round_eval_mfma", 0)
     if fused:
@@ -369,6 +377,7 @@ def main():
         "fold_eval_mfma": "k_foldeval_mfma(fold+round_eval)",
         "fold_eval": "k_foldeval9(fold+round_eval)",
         "fold_eval_small": "k_foldeval9_small(fold+round_eval, <= 2 batches per CU)",
+        "fold_eval8": "k_foldeval8(two rounds per launch: 1-2 folds + the eight quarter sums; the small rounds)",
         "tail": "k_foldeval_tail(resident, rounds <= 2^12)",
     }
     kernels = {}
@@ -382,7 +391,7 @@ def main():
                 bytes_c = sum(16 * m * (1 << r) for r in range(1, n_vars + 1)) * K
             kernels[label[c]] = (bytes_c, ms_c, cnt_c)
     kernels[label["fold"]] = (fold_bytes, prof["fold"][0], prof["fold"][1])
-    for c in order:
+    for c in order + ["fold_eval8"]:
         if prof[c][1]:
             kernels[label[c]] = (fused_bytes[c], prof[c][0], prof[c][1])
     if prof["tail"][1]:

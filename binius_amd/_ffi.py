@@ -454,7 +454,8 @@ class Context:
         _check(lib().bn_timer_end_ms(self._h, C.byref(ms)))
         return ms.value
 
-    PROF_CLASSES = ("round_eval", "fold", "tensor_expand", "ntt", "other", "fold_eval", "tail", "fold_eval_small", "fold_eval_mfma", "round_eval_mfma")
+    PROF_CLASSES = ("round_eval", "fold", "tensor_expand", "ntt", "other", "fold_eval", "tail", "fold_eval_small", "fold_eval_mfma", "round_eval_mfma",
+                    "fold_eval8")
 
     def prof_begin(self):
         _check(lib().bn_prof_begin(self._h))
@@ -466,10 +467,12 @@ class Context:
         return {k: (ms[i], int(cnt[i])) for i, k in enumerate(self.PROF_CLASSES)}
 
     def arm_counters(self):
-        """Armed rounds (csrc/arm.hpp): {hits, cancels, expired} since the context was created."""
-        c = (C.c_uint64 * 6)()
+        """Armed rounds (csrc/arm.hpp): {hits, cancels, expired} since the context was created; two-round launches
+        (csrc/kernels_foldeval8.hip): their number and the rounds the host answered from their precomputed sums."""
+        c = (C.c_uint64 * 8)()
         _check(lib().bn_arm_counters(self._h, c))
-        return {"hits": int(c[0]), "cancels": int(c[1]), "expired": int(c[2]), "ns_wait": int(c[3]), "ns_launch": int(c[4]), "ns_parse": int(c[5])}
+        return {"hits": int(c[0]), "cancels": int(c[1]), "expired": int(c[2]), "ns_wait": int(c[3]), "ns_launch": int(c[4]), "ns_parse": int(c[5]),
+                "hosted": int(c[6]), "two_round": int(c[7])}
 
     # ---- ComputeLayer
     def copy_h2d(self, src, dst):

@@ -75,6 +75,35 @@ void arm_cancel(bn_ctx *ctx)
 	__atomic_store_n(arm_cmd(ctx), (ctx->arm.id << 2) | 2ull, __ATOMIC_RELEASE);
 }
 
+bool pre_matches(const bn_ctx::precomp_state &pre, const bn_ctx::pending_fold &pf)
+{
+	if (!pre.valid || pre.consumed || pf.count != 2 || pf.scale_mask || 2 * pf.n != pre.m) return false;
+	auto is = [&](uint32_t i, int j) { return pf.src0[i] == pre.lo[j] && pf.x1[i] == pre.hi[j]; };
+	return (is(0, 0) && is(1, 1)) || (is(0, 1) && is(1, 0));
+}
+
+int flush_first_fold(bn_ctx *ctx)
+{
+	if (!ctx->pend.active || !ctx->pend2.active) return BN_OK;
+	arm_cancel(ctx); // (a kernel armed for the pair of folds cannot run half of it)
+	const bn_ctx::pending_fold &pf = ctx->pend;
+	bn::fold_batch fb{};
+	for (uint32_t i = 0; i < pf.count; i++) {
+		fb.x0[i] = pf.x0[i];
+		fb.x1[i] = pf.x1[i];
+		if (pf.src0[i] != pf.x0[i])
+			BN_HIP(hipMemcpyAsync(pf.x0[i], pf.src0[i], pf.n * sizeof(f128), hipMemcpyDeviceToDevice, ctx->stream));
+	}
+	{
+		prof_scope ps(ctx, BN_PROF_FOLD);
+		BN_HIP(bn::launch_extrapolate_line_batch(ctx->stream, ctx->n_cu, fb, pf.count, pf.n, pf.z));
+	}
+	ctx->pend = ctx->pend2; // (pend2 keeps its fields: callers may still hold a reference to them)
+	ctx->pend2.active = false;
+	ctx->pre.valid = false;
+	return BN_OK;
+}
+
 std::vector<unsigned char> recipe_bytes(const bn::fin_args &a)
 {
 	bn::fin_args r;
@@ -113,8 +142,39 @@ int flush_pending(bn_ctx *ctx, bool keep_tail, bool publish_tiny)
 		int rc = flush_copies(ctx);
 		if (rc) return rc;
 	}
+	ctx->pre.valid = false; // the precomputed next-round sums die with any call that is not the one they were made for
 	if (!ctx->pend.active) return BN_OK;
 	ctx->pend.active = false;
+	if (ctx->pend2.active) {
+		// two folds were deferred (a round in between was answered from precomputed sums): in place, one after the other
+		// -- or, when the caller is a host read of a handful of elements, both in ONE launch that also mirrors the results
+		ctx->pend2.active = false;
+		const bn_ctx::pending_fold &p1 = ctx->pend, &p2 = ctx->pend2;
+		if (publish_tiny && (uint64_t)p2.count * p2.n <= 64 && !p1.scale_mask && !p2.scale_mask) {
+			const uint64_t seq = ++ctx->mail_seq;
+			prof_scope ps(ctx, BN_PROF_FOLD);
+			BN_HIP(bn::launch_fold2_publish(ctx->stream, p1.x0, p1.src0, p1.x1, p1.count, (uint32_t)p2.n, p1.z, p2.z, ctx->d_mail, seq));
+			ctx->mirror.valid = true;
+			ctx->mirror.seq = seq;
+			ctx->mirror.count = p2.count;
+			ctx->mirror.n = (uint32_t)p2.n;
+			for (uint32_t i = 0; i < p2.count; i++) ctx->mirror.ptr[i] = p2.x0[i];
+			return BN_OK;
+		}
+		for (int k = 0; k < 2; k++) {
+			const bn_ctx::pending_fold &pf = k ? p2 : p1;
+			bn::fold_batch fb{};
+			for (uint32_t i = 0; i < pf.count; i++) {
+				fb.x0[i] = pf.x0[i];
+				fb.x1[i] = pf.x1[i];
+				if (pf.src0[i] != pf.x0[i])
+					BN_HIP(hipMemcpyAsync(pf.x0[i], pf.src0[i], pf.n * sizeof(f128), hipMemcpyDeviceToDevice, ctx->stream));
+			}
+			prof_scope ps(ctx, BN_PROF_FOLD);
+			BN_HIP(bn::launch_extrapolate_line_batch(ctx->stream, ctx->n_cu, fb, pf.count, pf.n, pf.z));
+		}
+		return BN_OK;
+	}
 	if (publish_tiny && (uint64_t)ctx->pend.count * ctx->pend.n <= 64) {
 		// the caller is a host read: fold and mirror the (few) results into the mailbox in one launch
 		const uint64_t seq = ++ctx->mail_seq;
@@ -223,6 +283,7 @@ int bn_ctx_create(int device, uint64_t arena_elems, bn_ctx **out)
 	BN_HIP(hipMalloc((void **)&ctx->d_arm_relay, 8 * sizeof(uint64_t)));
 	BN_HIP(hipMemset(ctx->d_arm_relay, 0, 8 * sizeof(uint64_t)));
 	if (const char *a = getenv("BN_ARM")) ctx->arm_enabled = atoi(a) != 0;
+	if (const char *a = getenv("BN_TWO_ROUND")) ctx->two_round = atoi(a) != 0;
 	BN_HIP(hipMalloc((void **)&ctx->d_mul8, 65536));
 	BN_HIP(bn::launch_build_mul8(ctx->stream, ctx->d_mul8));
 	if (arena_elems) {
@@ -556,6 +617,15 @@ int bn_copy_d2d(bn_ctx *ctx, const void *d_src, uint64_t src_len, void *d_dst, u
 	BN_REQUIRE(src_len == dst_len, "precondition: src and dst buffers must have the same length");
 	if (src_len == 0) return BN_OK;
 	ctx->mirror.valid = false;
+	if (ctx->pre.valid) {
+		// a copy INTO the arrays the precomputed next-round sums describe makes them stale (a copy out of them -- the first
+		// fold's "copy evals_0 into a fresh buffer" -- does not)
+		const char *d0 = (const char *)d_dst, *d1 = d0 + dst_len * sizeof(f128);
+		const size_t half = (size_t)(ctx->pre.m / 2) * sizeof(f128);
+		for (int j = 0; j < 2; j++)
+			for (const void *b : {ctx->pre.lo[j], ctx->pre.hi[j]})
+				if (d0 < (const char *)b + half && (const char *)b < d1) ctx->pre.valid = false;
+	}
 	if (ctx->lazy_fold && !ctx->pend.active && ctx->pend_copies.size() < 8) {
 		// deferred: a fold into d_dst may absorb it (see bn_ctx::pending_copy)
 		ctx->pend_copies.push_back({d_src, d_dst, src_len});
@@ -676,6 +746,30 @@ int bn_extrapolate_line_batch_scaled(bn_ctx *ctx, void *const *d_evals_0, const 
 	           "scaled fold: needs a scale, an even length and a mask within the batch");
 	if (count == 0) return BN_OK;
 	ctx->mirror.valid = false;
+	// A fold is already deferred, the round evaluation of its output has just been answered from the precomputed sums of
+	// a two-round launch (abi_kernels.cpp), and this batch folds that output in place: keep BOTH -- the next round
+	// evaluation folds twice in one pass (kernels_foldeval8.hip).
+	if (ctx->pend.active && !ctx->pend2.active && ctx->pre.valid && ctx->pre.consumed && ctx->lazy_fold && count == 2 && ctx->pend.count == 2 &&
+	    scale_mask == 0 && ctx->pend.scale_mask == 0 && 2 * n == ctx->pend.n && ctx->pend_copies.empty()) {
+		bool chained = true;
+		for (uint32_t i = 0; i < 2 && chained; i++)
+			chained = d_evals_0[i] == ctx->pend.x0[i] && (const char *)d_evals_1[i] == (const char *)ctx->pend.x0[i] + n * sizeof(f128);
+		if (chained) {
+			bn_ctx::pending_fold &p2 = ctx->pend2;
+			p2.active = true;
+			p2.count = 2;
+			p2.n = n;
+			p2.z = to_f(z);
+			p2.scale_mask = 0;
+			p2.hi_scale = f128{0, 0};
+			for (uint32_t i = 0; i < 2; i++) {
+				p2.x0[i] = d_evals_0[i];
+				p2.x1[i] = d_evals_1[i];
+				p2.src0[i] = d_evals_0[i];
+			}
+			return BN_OK; // (an armed two-round kernel keeps waiting: it is armed for exactly this pair of folds)
+		}
+	}
 	// deferred copies whose destination is one of the evals_0 are absorbed (every one of them must
 	// be, otherwise they all run now, in issue order)
 	const void *src0[bn::kFoldBatchMax];
@@ -719,7 +813,8 @@ int bn_extrapolate_line_batch_scaled(bn_ctx *ctx, void *const *d_evals_0, const 
 		// ... and so does an armed round (same order of the two arrays, same scale mask; z and the scale are its input)
 		if (ctx->arm.active) {
 			const bn_ctx::arm_state &am = ctx->arm;
-			bool same = count == 2 && 2 * n == am.n_in && scale_mask == am.scale_mask;
+			// (a two-fold kernel is armed for the pair pend + pend2: this batch would be its FIRST fold)
+			bool same = count == 2 && 2 * n == am.n_in && scale_mask == am.scale_mask && !ctx->pend.active;
 			for (uint32_t j = 0; j < 2 && same; j++)
 				same = d_evals_0[j] == am.out[j] && src0[j] == am.x0[j] && d_evals_1[j] == am.x1[j];
 			if (same)
@@ -727,8 +822,20 @@ int bn_extrapolate_line_batch_scaled(bn_ctx *ctx, void *const *d_evals_0, const 
 			else
 				arm_cancel(ctx);
 		}
+		// the next-round sums of a two-round launch survive exactly one call: the fold of the arrays they describe
+		bn_ctx::pending_fold probe;
+		probe.count = count;
+		probe.n = n;
+		probe.scale_mask = scale_mask;
+		for (uint32_t i = 0; i < count; i++) {
+			probe.src0[i] = src0[i];
+			probe.x1[i] = d_evals_1[i];
+		}
+		// (deferred copies that were not absorbed run inside flush_pending and may write the very arrays the sums describe)
+		const bool keep_pre = !ctx->pend.active && ctx->lazy_fold && ctx->pend_copies.empty() && pre_matches(ctx->pre, probe);
 		int rc_ = flush_pending(ctx, keep_tail);
 		if (rc_) return rc_;
+		ctx->pre.valid = keep_pre;
 	}
 	// Deferred: the next API call launches it -- or, if that call is the round evaluation of exactly
 	// these arrays, both run as one kernel (kernels_foldeval9.hip).
@@ -757,6 +864,8 @@ int bn_arm_counters(bn_ctx *ctx, uint64_t *counters)
 	counters[BN_ARM_NS_WAIT] = ctx->arm_ns_wait;
 	counters[BN_ARM_NS_LAUNCH] = ctx->arm_ns_launch;
 	counters[BN_ARM_NS_PARSE] = ctx->arm_ns_parse;
+	counters[BN_ARM_HOSTED] = ctx->two_round_hosted;
+	counters[BN_ARM_TWO_ROUND] = ctx->two_round_launches;
 	return BN_OK;
 }
 

@@ -65,6 +65,10 @@ inline volatile uint64_t *tail_status(bn_ctx *ctx) { return &ctx->h_mail[82].lo;
 inline volatile uint64_t *arm_cmd(bn_ctx *ctx) { return &ctx->h_mail[84].lo; }
 inline volatile uint64_t *arm_status(bn_ctx *ctx) { return &ctx->h_mail[87].lo; }
 void arm_cancel(bn_ctx *ctx);
+// two deferred folds (two-round launches): run the first one now, the second becomes the deferred one
+int flush_first_fold(bn_ctx *ctx);
+// the deferred fold `pf` folds exactly the arrays the precomputed next-round sums describe
+bool pre_matches(const bn_ctx::precomp_state &pre, const bn_ctx::pending_fold &pf);
 // ---- small helpers shared by the op entry points (abi.cpp)
 int publish_result(bn_ctx *ctx, uint32_t n_groups, bn_f128 *h_out);
 int upload_ptrs(bn_ctx *ctx, const void *const *ptrs, uint32_t n, const void ***d_ptrs);

@@ -4,6 +4,7 @@
 // finalizes on the device.  Also log_chunks_range / pick_log_chunks and the device XOR of gathered partials.
 #include "abi_common.hpp"
 #include "arm.hpp"
+#include "hostmul.hpp"
 
 #include <chrono>
 
@@ -84,6 +85,202 @@ hipError_t roundeval_product_routed(bn_ctx *ctx, bool scratch_free, const void *
 
 constexpr uint64_t kArmMaxIn = 1ull << 19;     // largest round (elements per array before the fold) that is armed ...
 constexpr uint64_t kArmMaxInMfma = 1ull << 21; // ... when it runs on the matrix-core kernel (60 us at 2^21: a launch is 10 % of that)
+// ---- two rounds per launch (kernels_foldeval8.hip) ------------------------------------------------------------------
+// largest Y (elements per array after the folds of the launch): one 64-point workgroup per CU, 256 CUs
+// (BN_TWO_ROUND_MAX_LOG2, 2 .. 20, moves the limit: measurement knob)
+uint64_t two_round_max_m()
+{
+	static const uint64_t v = [] {
+		const char *e = getenv("BN_TWO_ROUND_MAX_LOG2");
+		const int l = e ? atoi(e) : 16;
+		return (uint64_t)1 << (l < 2 ? 2 : (l > 20 ? 20 : l));
+	}();
+	return v;
+}
+bool two_round_size_ok(uint64_t m) { return m >= 4 && (m & 3) == 0 && m <= two_round_max_m(); }
+// the caller's request must be the plain pair (y_1, y_inf) with ONE batch coefficient (the precomputed sums of the next
+// round mix slots of both) -- what calculate_round_evals records for one bivariate product claim
+bool two_round_recipe_ok(const bn::fin_args &a)
+{
+	return a.n_terms == 2 && a.n_ret >= 1 && a.n_ret <= 2 && a.terms[0].coeff == a.terms[1].coeff;
+}
+bn::fin_fuse two_round_recipe(const bn::fin_fuse &fz)
+{
+	bn::fin_fuse f8 = fz;
+	f8.args = bn::fin_args{};
+	f8.args.n_terms = f8.args.n_values = f8.args.n_ret = f8.args.n_slots = 8;
+	f8.args.seq = fz.args.seq;
+	for (uint32_t i = 0; i < 8; i++) {
+		f8.args.terms[i] = bn::fin_term{i, i, fz.args.terms[0].coeff};
+		f8.args.ret_ids[i] = i;
+	}
+	return f8;
+}
+struct two_round_req {
+	bn::foldeval8_args fa;
+	f128 z1{0, 0}, z2{0, 0};
+	const void *lo[2] = {}, *hi[2] = {}; // the halves of Y, the arrays the eight sums describe
+	uint64_t m = 0;                      // elements of Y
+};
+
+// Arms the launch AFTER a two-round kernel that leaves Y = (lo | hi, m elements): two folds in place, Y'' of m / 4.
+void arm_two_round_next(bn_ctx *ctx, const two_round_req &rq, const bn::fin_fuse &f8, f128 *d_S)
+{
+	if (!ctx->arm_enabled || ctx->prof_on || ctx->tail_max_n_in || !two_round_size_ok(rq.m >> 2)) return;
+	bn::foldeval8_args fn{};
+	for (int j = 0; j < 2; j++) {
+		fn.x0[j] = rq.lo[j];
+		fn.x1[j] = rq.hi[j];
+		fn.out[j] = const_cast<void *>(rq.lo[j]);
+	}
+	fn.n_in = rq.m;
+	fn.n_folds = 2;
+	bn::fin_fuse fzn = f8;
+	fzn.args.seq = f8.args.seq + 1;
+	fzn.peer.round = f8.peer.round + 1;
+	bn::arm_args aa{};
+	aa.h_cmd = (const uint64_t *)&ctx->d_mail[84].lo;
+	aa.h_status = (uint64_t *)&ctx->d_mail[87].lo;
+	aa.d_relay = ctx->d_arm_relay;
+	aa.id = ++ctx->arm_counter;
+	if (bn::launch_foldeval8(ctx->stream, fn, f128{0, 0}, f128{0, 0}, d_S, &fzn, &aa) != hipSuccess) {
+		(void)hipGetLastError();
+		return;
+	}
+	bn_ctx::arm_state &am = ctx->arm;
+	am.active = true;
+	am.id = aa.id;
+	am.n_in = fn.n_in;
+	am.nf = 2;
+	for (int j = 0; j < 2; j++) {
+		am.x0[j] = fn.x0[j];
+		am.x1[j] = fn.x1[j];
+		am.out[j] = fn.out[j];
+	}
+	am.scale_mask = 0;
+	am.seq = fzn.args.seq;
+	am.peer_round = fzn.peer.world > 1 ? fzn.peer.round : 0;
+	am.d_sums = d_S;
+	am.recipe = recipe_bytes(fzn.args);
+}
+
+// Runs the two-round kernel for the caller's (y_1, y_inf) request `fz` (finalize recipe, mailbox sequence number and peer
+// round already assigned), through an armed kernel when the one waiting on the device is exactly this launch; returns the
+// caller's values in h_out and leaves the next round's quadratics in ctx->pre.
+int two_round_launch(bn_ctx *ctx, const two_round_req &rq, const bn::fin_fuse &fz, const f128 *init, uint32_t n_values, const uint32_t *ret_values,
+                     uint32_t n_ret, bn_f128 *h_out, f128 *d_S, std::chrono::steady_clock::time_point t_enter)
+{
+	hipStream_t s = ctx->stream;
+	const bn::fin_fuse f8 = two_round_recipe(fz);
+	volatile uint64_t *seqw = &ctx->h_mail[64].lo;
+	bool got = false;
+	if (ctx->arm.active) {
+		bn_ctx::arm_state &am = ctx->arm;
+		bool same = am.nf == rq.fa.n_folds && am.nf != 0 && am.n_in == rq.fa.n_in && am.seq == f8.args.seq && am.d_sums == d_S &&
+		            am.peer_round == (f8.peer.world > 1 ? f8.peer.round : 0);
+		for (int j = 0; j < 2 && same; j++) same = am.x0[j] == rq.fa.x0[j] && am.x1[j] == rq.fa.x1[j] && am.out[j] == rq.fa.out[j];
+		if (same) same = recipe_bytes(f8.args) == am.recipe;
+		if (!same) {
+			arm_cancel(ctx);
+		} else {
+			const uint64_t id = am.id;
+			am.active = false;
+			ctx->h_mail[85].lo = rq.z1.lo;
+			ctx->h_mail[85].hi = rq.z1.hi;
+			ctx->h_mail[86].lo = rq.z2.lo; // (the second challenge travels in the hi_scale slot of the command block)
+			ctx->h_mail[86].hi = rq.z2.hi;
+			__atomic_store_n(arm_cmd(ctx), (id << 2) | 1ull, __ATOMIC_RELEASE);
+			const auto t_go = std::chrono::steady_clock::now();
+			arm_two_round_next(ctx, rq, f8, d_S);
+			const auto t_armed = std::chrono::steady_clock::now();
+			for (uint64_t spins = 0;; spins++) {
+				if (__atomic_load_n(seqw, __ATOMIC_ACQUIRE) == f8.args.seq) {
+					got = true;
+					break;
+				}
+				if ((spins & 63) == 63) {
+					const uint64_t st = __atomic_load_n(arm_status(ctx), __ATOMIC_ACQUIRE);
+					if (st == (id | bn::kArmLost)) {
+						arm_cancel(ctx);
+						BN_HIP(hipStreamSynchronize(s));
+						return bn::fail(BN_ERR_DEVICE, "device error: an armed round was only partially executed");
+					}
+					if (st == id) { // it gave up waiting (bounded spin) -- did it answer first?
+						got = __atomic_load_n(seqw, __ATOMIC_ACQUIRE) == f8.args.seq;
+						break;
+					}
+				}
+				if (spins > (1ull << 26)) {
+					arm_cancel(ctx);
+					BN_HIP(hipStreamSynchronize(s));
+					return bn::fail(BN_ERR_DEVICE, "device error: armed round kernel stopped answering");
+				}
+			}
+			if (got) {
+				ctx->arm_hits++;
+				ctx->arm_ns_launch += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t_armed - t_go).count();
+				ctx->arm_ns_parse += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t_go - t_enter).count();
+				ctx->arm_ns_wait += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_go).count();
+			} else {
+				ctx->arm_expired++;
+				arm_cancel(ctx); // the one queued behind it must leave too; the round runs the ordinary way
+			}
+		}
+	}
+	if (!got) {
+		{
+			prof_scope ps(ctx, BN_PROF_FOLD_EVAL8);
+			BN_HIP(bn::launch_foldeval8(s, rq.fa, rq.z1, rq.z2, d_S, &f8, nullptr));
+		}
+		if (rq.fa.n_folds) arm_two_round_next(ctx, rq, f8, d_S); // (after round 0 the first fold goes to a buffer we have not seen yet)
+		uint64_t spins = 0;
+		while (__atomic_load_n(seqw, __ATOMIC_ACQUIRE) != f8.args.seq) {
+			if (++spins > (1ull << 22)) {
+				arm_cancel(ctx);
+				BN_HIP(hipStreamSynchronize(s));
+				if (__atomic_load_n(seqw, __ATOMIC_ACQUIRE) != f8.args.seq)
+					return bn::fail(BN_ERR_DEVICE, "device error: result mailbox was not published");
+				break;
+			}
+		}
+	}
+	if (f8.peer.world > 1 && __atomic_load_n(&ctx->h_mail[65].lo, __ATOMIC_RELAXED) == f8.peer.round) {
+		arm_cancel(ctx);
+		return bn::fail(BN_ERR_DEVICE, "device error: peer exchange timed out waiting for a rank");
+	}
+	f128 E[8];
+	for (int i = 0; i < 8; i++) {
+		E[i].lo = __atomic_load_n(&ctx->h_mail[i].lo, __ATOMIC_RELAXED);
+		E[i].hi = __atomic_load_n(&ctx->h_mail[i].hi, __ATOMIC_RELAXED);
+	}
+	// slots (kernels_foldeval8.hip): 0 = a2 b2, 1 = (a0+a2)(b0+b2), 2 = a3 b3 = P(1), 3 = (a1+a3)(b1+b3) = P2, 4 = P0, 5 = Q0, 6 = Q(1), 7 = Q2
+	f128 vals[bn::kFinMaxValues];
+	for (uint32_t v = 0; v < n_values; v++) vals[v] = init[v];
+	vals[fz.args.terms[0].value] ^= E[0] ^ E[2];
+	vals[fz.args.terms[1].value] ^= E[1] ^ E[3];
+	for (uint32_t r = 0; r < n_ret; r++) h_out[r] = bn_f128{vals[ret_values[r]].lo, vals[ret_values[r]].hi};
+	bn_ctx::precomp_state &pre = ctx->pre;
+	pre.valid = true;
+	pre.consumed = false;
+	for (int j = 0; j < 2; j++) {
+		pre.lo[j] = rq.lo[j];
+		pre.hi[j] = rq.hi[j];
+	}
+	pre.m = rq.m;
+	pre.P0 = E[4];
+	pre.P1v = E[2];
+	pre.P2 = E[3];
+	pre.Q0 = E[5];
+	pre.Q1v = E[6];
+	pre.Q2 = E[7];
+	pre.recipe = recipe_bytes(fz.args);
+	ctx->pend.active = false;
+	ctx->pend2.active = false;
+	ctx->s_clean = true;
+	ctx->two_round_launches++;
+	return BN_OK;
+}
+
 // how a kernel-buffer slice is realised on the device
 struct slice_view {
 	const char *p = nullptr; // direct data
@@ -125,6 +322,13 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 			}
 		}
 		if (!pure || n_sum != 2) BN_FLUSH(ctx);
+		// two folds are deferred but the launch cannot fold twice (the two-round kernel needs >= 4 elements and a host result):
+		// the first one runs now, the second stays deferred for the one-round kernels
+		if (ctx->pend.active && ctx->pend2.active &&
+		    !(ctx->two_round && h_out && !d_out && two_round_size_ok(ctx->pend2.n))) {
+			rc = flush_first_fold(ctx);
+			if (rc) return rc;
+		}
 	}
 
 	// Local buffers are virtual until something forces them into memory.
@@ -371,7 +575,8 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 								if (ctx->pend.active) {
 									// fold + evaluate in one pass: this launch reads the halves of exactly the two
 									// arrays the deferred fold writes (evals_1 directly behind evals_0, in place)
-									const bn_ctx::pending_fold &pf = ctx->pend;
+									const bool two = ctx->pend2.active;
+									const bn_ctx::pending_fold &pf = two ? ctx->pend2 : ctx->pend; // the LAST deferred fold: its output is what this launch reads
 									auto reads_folded = [&](uint32_t j, uint32_t i) {
 										return lo[j] == pf.x0[i] && (const char *)hi[j] == (const char *)lo[j] + row_len * sizeof(f128);
 									};
@@ -391,6 +596,50 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 										}
 										fa.hi_scale = pf.hi_scale;
 										const uint64_t n_in = 2 * pf.n;
+										const bool two_ok = ctx->two_round && h_out && !d_out && !fa.scale_mask && !ctx->tail_max_n_in && !ctx->tail.active &&
+										                    two_round_recipe_ok(fz.args) && two_round_size_ok(pf.n);
+										// (h) the next-round quadratics of the previous two-round launch describe exactly the arrays this fold
+										// folds: the host answers -- y(z) = c0 + z c1 + z^2 c2 at the fold's challenge -- and the fold stays deferred
+										if (!two && h_out && !d_out && pre_matches(ctx->pre, pf) && two_round_recipe_ok(fz.args) && recipe_bytes(fz.args) == ctx->pre.recipe) {
+											const bn_ctx::precomp_state &pre = ctx->pre;
+											const f128 z = pf.z, zz = bn::mul_host(z, z);
+											const f128 y1 = pre.P0 ^ bn::mul_host(z, pre.P0 ^ pre.P1v ^ pre.P2) ^ bn::mul_host(zz, pre.P2);
+											const f128 yi = pre.Q0 ^ bn::mul_host(z, pre.Q0 ^ pre.Q1v ^ pre.Q2) ^ bn::mul_host(zz, pre.Q2);
+											f128 vals[bn::kFinMaxValues];
+											for (uint32_t v = 0; v < n_values; v++) vals[v] = h_values[v];
+											vals[fz.args.terms[0].value] ^= y1;
+											vals[fz.args.terms[1].value] ^= yi;
+											for (uint32_t r = 0; r < n_ret; r++) h_out[r] = bn_f128{vals[ret_values[r]].lo, vals[ret_values[r]].hi};
+											ctx->pre.consumed = true;
+											--ctx->mail_seq; // (no launch, no mailbox traffic: the armed kernel behind us keeps its sequence number)
+											if (peer_on) --ctx->peer.round;
+											ctx->s_clean = was_clean_or_zeroed;
+											ctx->two_round_hosted++;
+											return BN_OK;
+										}
+										// (t) two rounds per launch (kernels_foldeval8.hip): both deferred folds, or the one, then the eight sums
+										if (two_ok) {
+											const bn_ctx::pending_fold &p1 = ctx->pend;
+											two_round_req rq{};
+											for (uint32_t j = 0; j < 2; j++) {
+												const uint32_t i = perm ? 1 - j : j;
+												rq.fa.x0[j] = p1.src0[i];
+												rq.fa.x1[j] = p1.x1[i];
+												rq.fa.out[j] = p1.x0[i];
+												rq.lo[j] = pf.x0[i];
+												rq.hi[j] = (const char *)pf.x0[i] + (pf.n / 2) * sizeof(f128);
+											}
+											rq.fa.n_in = 2 * p1.n;
+											rq.fa.n_folds = two ? 2 : 1;
+											rq.z1 = p1.z;
+											rq.z2 = two ? pf.z : f128{0, 0};
+											rq.m = pf.n;
+											return two_round_launch(ctx, rq, fz, h_values.data(), n_values, ret_values, n_ret, h_out, d_S + slot, t_enter);
+										}
+										if (two) { // (two_round_size_ok was checked at entry; something else rules the two-round kernel out)
+											rc = flush_first_fold(ctx);
+											if (rc) return rc;
+										}
 										if (fa.scale_mask && ctx->tail.active) { // the resident tail kernel folds without a scale
 											rc = tail_cancel(ctx);
 											if (rc) return rc;
@@ -402,6 +651,46 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 											// only latency-shaped rounds: a launch is nothing next to a kernel of 2^20 elements, and the
 											// host waits for long kernels with a stream synchronisation, which an armed kernel would hold up
 											const bool mfma_next = bn::mfma_applies(ctx->n_cu, n_next >> 2);
+											if (ctx->arm_enabled && !ctx->prof_on && h_out && !d_out && ctx->two_round && !fa_.scale_mask && !ctx->tail_max_n_in &&
+											    two_round_recipe_ok(fz_.args) && two_round_size_ok(n_next >> 1)) {
+												// the next round will be a two-round launch with ONE fold (its arrays: the halves written now)
+												bn::foldeval8_args f8a{};
+												for (uint32_t j = 0; j < 2; j++) {
+													f8a.x0[j] = fa_.out[j];
+													f8a.x1[j] = (const char *)fa_.out[j] + (n_next >> 1) * sizeof(f128);
+													f8a.out[j] = fa_.out[j];
+												}
+												f8a.n_in = n_next;
+												f8a.n_folds = 1;
+												bn::fin_fuse fzn = two_round_recipe(fz_);
+												fzn.args.seq = fz_.args.seq + 1;
+												fzn.peer.round = fz_.peer.round + 1;
+												bn::arm_args aa{};
+												aa.h_cmd = (const uint64_t *)&ctx->d_mail[84].lo;
+												aa.h_status = (uint64_t *)&ctx->d_mail[87].lo;
+												aa.d_relay = ctx->d_arm_relay;
+												aa.id = ++ctx->arm_counter;
+												if (bn::launch_foldeval8(s, f8a, f128{0, 0}, f128{0, 0}, d_S + slot, &fzn, &aa) != hipSuccess) {
+													(void)hipGetLastError();
+													return;
+												}
+												bn_ctx::arm_state &am = ctx->arm;
+												am.active = true;
+												am.id = aa.id;
+												am.n_in = n_next;
+												am.nf = 1;
+												for (uint32_t j = 0; j < 2; j++) {
+													am.x0[j] = f8a.x0[j];
+													am.x1[j] = f8a.x1[j];
+													am.out[j] = f8a.out[j];
+												}
+												am.scale_mask = 0;
+												am.seq = fzn.args.seq;
+												am.peer_round = fzn.peer.world > 1 ? fzn.peer.round : 0;
+												am.d_sums = d_S + slot;
+												am.recipe = recipe_bytes(fzn.args);
+												return;
+											}
 											if (!ctx->arm_enabled || ctx->prof_on || !h_out || d_out || n_next < 4 || (n_next & 3) ||
 											    n_next > (mfma_next ? kArmMaxInMfma : kArmMaxIn) || (mfma_next && fa_.scale_mask == 3) || ctx->tail_max_n_in)
 												return;
@@ -430,6 +719,7 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 											am.active = true;
 											am.id = aa.id;
 											am.n_in = n_next;
+											am.nf = 0;
 											for (uint32_t j = 0; j < 2; j++) {
 												am.x0[j] = fn.x0[j];
 												am.x1[j] = fn.x1[j];
@@ -444,7 +734,7 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 										// (a0) the kernel of this round is already on the device, armed: hand it z
 										if (ctx->arm.active) {
 											bn_ctx::arm_state &am = ctx->arm;
-											bool same = h_out && !d_out && n_in == am.n_in && fa.scale_mask == am.scale_mask && fz.args.seq == am.seq &&
+											bool same = am.nf == 0 && h_out && !d_out && n_in == am.n_in && fa.scale_mask == am.scale_mask && fz.args.seq == am.seq &&
 											            d_S + slot == am.d_sums && am.peer_round == (fz.peer.world > 1 ? fz.peer.round : 0);
 											for (uint32_t j = 0; j < 2 && same; j++)
 												same = fa.x0[j] == am.x0[j] && fa.x1[j] == am.x1[j] && fa.out[j] == am.out[j];
@@ -590,6 +880,24 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 										if (rc) return rc;
 									}
 									if (ctx->pend.active) BN_FLUSH(ctx);
+								}
+								// round 0 of a small sumcheck, nothing to fold: the two-round kernel on the inputs themselves -- when the
+								// number of variables is even, so that the chain of two-round launches ends on four elements (with an
+								// odd number this round runs alone and the chain starts with the first fold)
+								if (fe == hipErrorNotSupported && !ctx->pend.active && k == 2 && lo[0] && lo[1] && lo[0] != lo[1] && ctx->two_round && ctx->lazy_fold && h_out && !d_out &&
+								    !ctx->tail_max_n_in && two_round_recipe_ok(fz.args) && two_round_size_ok(2 * row_len) && (ilog2(2 * row_len) & 1) == 0) {
+									two_round_req rq{};
+									for (uint32_t j = 0; j < 2; j++) {
+										rq.fa.x0[j] = lo[j];
+										rq.fa.x1[j] = hi[j];
+										rq.fa.out[j] = nullptr;
+										rq.lo[j] = lo[j];
+										rq.hi[j] = hi[j];
+									}
+									rq.fa.n_in = 2 * row_len;
+									rq.fa.n_folds = 0;
+									rq.m = 2 * row_len;
+									return two_round_launch(ctx, rq, fz, h_values.data(), n_values, ret_values, n_ret, h_out, d_S + slot, t_enter);
 								}
 								if (fe == hipErrorNotSupported) {
 									prof_scope ps(ctx, k == 2 && bn::mfma_applies(ctx->n_cu, row_len) ? BN_PROF_ROUND_EVAL_MFMA : BN_PROF_ROUND_EVAL);

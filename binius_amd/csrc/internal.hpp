@@ -68,6 +68,19 @@ struct bn_ctx {
 		const void *x1[8] = {};
 		const void *src0[8] = {}; // ... and read from here (== x0 unless a deferred copy_d2d fed it)
 	} pend;
+	// a SECOND deferred fold, chained in place on pend's output: exists only between the call that answered a round from
+	// the precomputed sums below and the next round evaluation, which then folds twice (kernels_foldeval8.hip)
+	pending_fold pend2;
+	// the next round's evaluations as quadratics in the next challenge, left by a two-round launch
+	struct precomp_state {
+		bool valid = false, consumed = false;
+		const void *lo[2] = {}, *hi[2] = {}; // the halves of the two arrays the sums describe ...
+		uint64_t m = 0;                      // ... m elements each
+		bn::f128 P0{0, 0}, P1v{0, 0}, P2{0, 0}, Q0{0, 0}, Q1v{0, 0}, Q2{0, 0}; // coefficient applied; P1v = P(1), Q1v = Q(1)
+		std::vector<unsigned char> recipe;   // of the caller's two-sum request
+	} pre;
+	bool two_round = true;       // BN_TWO_ROUND=0 turns the two-round launches off
+	uint64_t two_round_hosted = 0, two_round_launches = 0; // rounds answered by the host from the sums / launches of the kernel
 	// deferred copy_d2d (the "allocate a new buffer for the folded evaluations and copy in evals_0"
 	// of the first fold, v3/bivariate_product.rs:196-206): absorbed by the fold that overwrites its
 	// destination, which then reads evals_0 from the copy's source
@@ -116,6 +129,7 @@ struct bn_ctx {
 		uint32_t scale_mask = 0;
 		uint64_t seq = 0;      // the mailbox sequence number it will publish
 		uint64_t peer_round = 0; // the peer-exchange round it will take part in (0: none)
+		uint32_t nf = 0;         // 0: a one-round kernel (k_foldeval9*, k_foldeval_mfma); 1, 2: k_foldeval8 with that many folds
 		bn::f128 *d_sums = nullptr; // its accumulator slots
 		std::vector<unsigned char> recipe;
 	} arm;
@@ -243,6 +257,21 @@ hipError_t launch_foldeval9(hipStream_t s, int n_cu, const foldeval_args &fa, ui
                             const arm_args *armed = nullptr);
 hipError_t launch_foldeval_tail(hipStream_t s, const foldeval_args &fa, uint64_t n_in, f128 z, f128 *d_out, const fin_fuse &fz,
                                 const uint64_t *d_cmd, uint64_t *d_status, uint64_t tail_id);
+// ---- kernels_foldeval8.hip: two rounds per launch for the small rounds -- 0, 1 or 2 folds, then the eight quarter sums
+// that answer this round AND (as a quadratic in the next challenge) the next one
+struct foldeval8_args {
+	const void *x0[2]; // n_folds >= 1: lower / upper half of the arrays before the first fold (n_in elements);
+	const void *x1[2]; // n_folds == 0: lower / upper half of Y itself
+	void *out[2];      // n_folds >= 1: where Y (n_in >> n_folds elements) is written (may be x0)
+	uint64_t n_in;
+	uint32_t n_folds;
+};
+hipError_t launch_foldeval8(hipStream_t s, const foldeval8_args &fa, f128 z1, f128 z2, f128 *d_out8, const fin_fuse *fuse,
+                            const arm_args *armed = nullptr);
+// the last two folds of a sumcheck in one launch (4 n_out -> n_out elements per array, count * n_out <= 64), mirrored into
+// the mailbox like launch_fold_publish
+hipError_t launch_fold2_publish(hipStream_t s, void *const *out, const void *const *src0, const void *const *x1, uint32_t count, uint32_t n_out,
+                                f128 z1, f128 z2, f128 *d_mail, uint64_t seq);
 hipError_t launch_roundeval9_eq(hipStream_t s, int n_cu, const void *a_hi, const void *a_lo, const void *b_hi, const void *b_lo,
                                 const void *eq, uint64_t n, f128 *d_out, const fin_fuse *fuse);
 hipError_t launch_roundeval9_split(hipStream_t s, int n_cu, const void *a, const void *b, uint64_t n, uint64_t split_off,

@@ -1,0 +1,278 @@
+// binius_amd/csrc/kernels_foldeval8.hip -- TWO sumcheck rounds per launch for the latency-shaped (small) rounds.
+//
+// A small round is a dependent chain: challenge -> fold -> products -> sums -> host (~10 us of kernel however few the
+// elements are, tools/small_round_phases.hip).  The chain can serve two rounds.  Let Y be the arrays after the fold(s)
+// of this launch, M elements each, in quarters Y0 | Y1 | Y2 | Y3 of Q = M / 4.  This round's evaluations
+// (v3/bivariate_product.rs:303-408) are sums over the half cube,
+//     y_1   = sum a2 b2 + sum a3 b3                      y_inf = sum (a0+a2)(b0+b2) + sum (a1+a3)(b1+b3),
+// and after the NEXT challenge z the arrays are Y' = (Y0 + z (Y0+Y2) | Y1 + z (Y1+Y3)), whose evaluations are
+// quadratics in z with coefficients that are sums of the same kind (character 2: P(1) = P0 + P1 + P2):
+//     y_1'(z)   = P0 + z P1 + z^2 P2,   P0 = sum a1 b1,            P(1) = sum a3 b3,            P2 = sum (a1+a3)(b1+b3)
+//     y_inf'(z) = Q0 + z Q1 + z^2 Q2,   Q0 = sum (a0+a1)(b0+b1),   Q(1) = sum (a2+a3)(b2+b3),   Q2 = sum (a0+..+a3)(b0+..+b3)
+// Eight sums over Q points instead of two over 2 Q -- the same number of products as this round and the next together
+// would cost (2 M against M + M/2 is a third more), but ONE chain: the host answers the next round itself (four scalar
+// multiplications, abi_kernels.cpp) and the launch after that folds TWICE (both challenges are known by then):
+//     X' = X0 + z1 (X0 + X1)  (n_in/2 elements),   Y = X'0 + z2 (X'0 + X'1)  (n_in/4 elements, written in place; the upper
+//     half of X' is written too, so that memory ends up exactly as after two separate in-place folds).
+//
+// One workgroup of 8 waves per 64 quarter-points = 512 elements of Y, one per thread: (array, quarter) = wave, point =
+// lane; 2^n_folds coalesced 16-byte loads per thread (issued before an armed launch waits for its challenges), the
+// nibble tables of z1 and z2 built side by side by the two halves of the workgroup, the folded element to memory and
+// into an LDS stage.  Waves 0..3 then take one PAIR of sums each with the [H*H | (L+H)*(L+H)] packing of the 9-lane
+// kernels (re9.hpp), reading their rows from the stage:
+//     wave 0: H = Y2, L = Y0 -> s0 = a2 b2,          s2 = (a0+a2)(b0+b2)        wave 2: H = Y1,    L = Y0    -> s4 = P0,   s5 = Q0
+//     wave 1: H = Y3, L = Y1 -> s1 = a3 b3 = P(1),   s3 = (a1+a3)(b1+b3) = P2   wave 3: H = Y2+Y3, L = Y0+Y1 -> s6 = Q(1), s7 = Q2
+// so the four products of a batch run on four SIMDs at once.  Accumulator slot 2 w + stream: the finalize recipe of this
+// kernel is fixed (eight values = coefficient x slot, abi_kernels.cpp), the host combines.
+#include <hip/hip_runtime.h>
+
+#include "arm.hpp"
+#include "ctable.hpp"
+#include "re9.hpp"
+
+namespace bn {
+
+namespace {
+constexpr int kPts = 64;                 // quarter-points per workgroup
+constexpr int kG8 = 4;                   // 9-lane groups per evaluating wave (16 points each)
+constexpr int kRowsPad = 65;             // stage rows per (array, quarter) block: 64 + 1 (blocks 16 banks apart)
+constexpr int kBlk = re9::kBlkQ;         // 9 uint4 per (limb, group) block of the exchange tile
+constexpr int kZero8 = 8 * kG8;          // zero block index
+constexpr int kTile8 = (kZero8 + 1) * kBlk;
+
+struct lay8 {
+	unsigned off_a[4], off_b[4];
+	unsigned off_w;
+	bool loader, live;
+	unsigned g, c;
+};
+
+__device__ __forceinline__ lay8 make_lay8(unsigned lane)
+{
+	lay8 l;
+	l.g = lane / 9;
+	l.c = lane - l.g * 9;
+	l.live = lane < 9 * kG8;
+	l.loader = l.live && l.c < 8;
+	const unsigned mask = l.live ? re9::combo_mask(l.c) : 0u;
+#pragma unroll
+	for (int s = 0; s < 4; s++) {
+		const bool use = (mask >> s) & 1;
+		l.off_a[s] = (use ? (unsigned)(s * kG8 + l.g) : (unsigned)kZero8) * kBlk;
+		l.off_b[s] = (use ? (unsigned)((4 + s) * kG8 + l.g) : (unsigned)kZero8) * kBlk;
+	}
+	l.off_w = (l.loader ? (l.c * kG8 + l.g) : 0u) * kBlk;
+	return l;
+}
+
+// One pair of sums for one wave: rows H (and H2), L (and L2) of the stage, n_valid points; leaves the lane's 32
+// accumulator planes in acc (low 16 bits: H*H, high 16 bits: (L+H)*(L+H)).
+__device__ __forceinline__ void eval_pair(const uint4 *stage, uint4 *wt, const lay8 &lay, unsigned h0, int h1, unsigned l0, int l1, unsigned n_valid,
+                                          uint32_t (&acc)[32])
+{
+	const uint32_t *stw = reinterpret_cast<const uint32_t *>(stage);
+	const unsigned lane = threadIdx.x & 63;
+	if (lane < kBlk) wt[kZero8 * kBlk + lane] = uint4{0, 0, 0, 0};
+	// loader lane (g, c): word column c & 3 of array c >> 2, rows 4 j + g (banks: 4 g + (c & 3) + 16 (c >> 2): all distinct)
+	const unsigned a = (lay.c >> 2) & 1, wc = lay.c & 3, g = lay.live ? lay.g : 0;
+	const unsigned bh0 = ((a * 4 + h0) * kRowsPad + g) * 4 + wc, bl0 = ((a * 4 + l0) * kRowsPad + g) * 4 + wc;
+	const unsigned bh1 = ((a * 4 + (unsigned)(h1 < 0 ? 0 : h1)) * kRowsPad + g) * 4 + wc, bl1 = ((a * 4 + (unsigned)(l1 < 0 ? 0 : l1)) * kRowsPad + g) * 4 + wc;
+	uint32_t r[32];
+#pragma unroll
+	for (int j = 0; j < 16; j++) {
+		uint32_t h = stw[bh0 + 16 * j], l = stw[bl0 + 16 * j];
+		if (h1 >= 0) { // (wave-uniform)
+			h ^= stw[bh1 + 16 * j];
+			l ^= stw[bl1 + 16 * j];
+		}
+		const bool ok = (unsigned)(4 * j) + g < n_valid;
+		r[j] = ok ? h : 0u;
+		r[16 + j] = ok ? (l ^ h) : 0u;
+	}
+	transpose32(r);
+	if (lay.loader) {
+#pragma unroll
+		for (int q = 0; q < 8; q++)
+			wt[lay.off_w + q] = uint4{r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]};
+	}
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+	uint32_t A[32], B[32];
+#pragma unroll
+	for (int q = 0; q < 8; q++) {
+		const uint4 a0 = wt[lay.off_a[0] + q], a1 = wt[lay.off_a[1] + q], a2 = wt[lay.off_a[2] + q], a3 = wt[lay.off_a[3] + q];
+		const uint4 y0 = wt[lay.off_b[0] + q], y1 = wt[lay.off_b[1] + q], y2 = wt[lay.off_b[2] + q], y3 = wt[lay.off_b[3] + q];
+		A[4 * q] = xor3(a0.x, a1.x, a2.x) ^ a3.x;
+		A[4 * q + 1] = xor3(a0.y, a1.y, a2.y) ^ a3.y;
+		A[4 * q + 2] = xor3(a0.z, a1.z, a2.z) ^ a3.z;
+		A[4 * q + 3] = xor3(a0.w, a1.w, a2.w) ^ a3.w;
+		B[4 * q] = xor3(y0.x, y1.x, y2.x) ^ y3.x;
+		B[4 * q + 1] = xor3(y0.y, y1.y, y2.y) ^ y3.y;
+		B[4 * q + 2] = xor3(y0.z, y1.z, y2.z) ^ y3.z;
+		B[4 * q + 3] = xor3(y0.w, y1.w, y2.w) ^ y3.w;
+	}
+	bs_mul<5>(A, B, acc);
+}
+
+// Workgroup tail for eight sums: wave w < 4 holds the planes of slots 2 w (low halves) and 2 w + 1 (high halves).
+// Collapse, recombine the nine limb products per slot, XOR into out[0..8) (or keep them in LDS when the launch is a
+// single workgroup) and run the fused finalize in the last workgroup.  All 512 threads.
+__device__ __forceinline__ void tail8(const uint32_t (&acc)[32], const lay8 &lay, unsigned wave, unsigned lane, f128 *out, const fin_fuse &fz, uint64_t seq,
+                                      const fin_cache &fc)
+{
+	__shared__ uint32_t red[4][2][9][kG8];
+	__shared__ uint64_t wsum[4][4];
+	if (wave < 4) {
+		uint32_t s_lo = 0, s_hi = 0;
+#pragma unroll
+		for (int p = 0; p < 32; p++) {
+			s_lo |= (__popc(acc[p] & 0xFFFFu) & 1u) << p;
+			s_hi |= (__popc(acc[p] >> 16) & 1u) << p;
+		}
+		if (lay.live) {
+			red[wave][0][lay.c][lay.g] = s_lo;
+			red[wave][1][lay.c][lay.g] = s_hi;
+		}
+	}
+	__syncthreads();
+	if (wave < 4 && lane < 2) {
+		uint32_t pc[9];
+#pragma unroll
+		for (int cc = 0; cc < 9; cc++) {
+			uint32_t v = 0;
+#pragma unroll
+			for (int gg = 0; gg < kG8; gg++)
+				v ^= red[wave][lane][cc][gg];
+			pc[cc] = v;
+		}
+		const uint64_t Z0 = re9::combine32(pc[0], pc[1], pc[2]);
+		const uint64_t Z2 = re9::combine32(pc[3], pc[4], pc[5]);
+		const uint64_t Z1p = re9::combine32(pc[6], pc[7], pc[8]);
+		const f128 S = re9::combine64(Z0, Z2, Z1p);
+		wsum[wave][2 * lane] = S.lo;
+		wsum[wave][2 * lane + 1] = S.hi;
+	}
+	__syncthreads();
+	unsigned *const counter = fc.counter;
+	if (counter && gridDim.x == 1 && out == fc.S) {
+		// single workgroup: the sums never leave the chip (wsum is laid out exactly as f128 S_local[8])
+		finalize_cached(fc, seq, reinterpret_cast<const f128 *>(&wsum[0][0]));
+		return;
+	}
+	if (threadIdx.x < 16) {
+		const uint64_t v = wsum[threadIdx.x >> 2][threadIdx.x & 3];
+		if (v) atomicXor(reinterpret_cast<unsigned long long *>(out) + threadIdx.x, (unsigned long long)v);
+	}
+	if (counter) {
+		// same ticket protocol as re9::tail (device-scope atomics only, no fences)
+		__shared__ unsigned is_last;
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			const unsigned t = atomicAdd(counter, 1u);
+			is_last = (t == gridDim.x - 1) ? 1u : 0u;
+		}
+		__syncthreads();
+		if (is_last) {
+			finalize_cached(fc, seq);
+			if (threadIdx.x == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+	}
+}
+} // namespace
+
+template <int NF>
+__global__ __launch_bounds__(512, 1) void k_foldeval8(foldeval8_args fa, f128 z1, f128 z2, f128 *out, fin_fuse fz, arm_args arm)
+{
+	__shared__ uint4 stage[8 * kRowsPad];
+	__shared__ uint4 tile[4][kTile8];
+	__shared__ ctable_smem tab[NF == 2 ? 2 : 1];
+	__shared__ fin_cache fcache;
+	const uint64_t seq = fz.args.seq;
+	const unsigned tid = threadIdx.x, lane = tid & 63;
+	const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const uint64_t m = fa.n_in >> NF, q = m >> 2; // elements of Y, quarter-points
+	const uint64_t p0 = (uint64_t)blockIdx.x * kPts;
+	const unsigned n_valid = (unsigned)((q - p0) < (uint64_t)kPts ? (q - p0) : (uint64_t)kPts);
+	// this thread's element of Y: array wave >> 2, quarter wave & 3, point lane
+	const unsigned arr = wave >> 2, qt = wave & 3;
+	const uint64_t i = (uint64_t)qt * q + p0 + lane;
+	const bool have = lane < n_valid;
+	uint4 v[4] = {uint4{0, 0, 0, 0}, uint4{0, 0, 0, 0}, uint4{0, 0, 0, 0}, uint4{0, 0, 0, 0}};
+	if (have) {
+		const uint4 *x0 = (const uint4 *)fa.x0[arr], *x1 = (const uint4 *)fa.x1[arr];
+		if constexpr (NF == 0) {
+			v[0] = i < (m >> 1) ? x0[i] : x1[i - (m >> 1)]; // Y itself: x0 | x1 are its halves
+		} else if constexpr (NF == 1) {
+			v[0] = x0[i];
+			v[1] = x1[i];
+		} else {
+			v[0] = x0[i];
+			v[1] = x1[i];
+			v[2] = x0[i + m];
+			v[3] = x1[i + m];
+		}
+	}
+	const fin_pref fpre = fin_prefetch(fz);
+	if (arm.h_cmd) { // (uniform) armed launch: the data is on its way, the challenges are what is missing (arm.hpp)
+		f128 z2_in;
+		if (!arm_wait(arm, z1, z2_in)) return;
+		z2 = z2_in;
+	}
+	if constexpr (NF == 2)
+		ctable_build_group(tab[tid >> 8], (tid >> 8) ? z2 : z1, tid & 255, 256); // both tables at once
+	else if constexpr (NF == 1)
+		ctable_build(tab[0], z1);
+	uint4 y = v[0], u_hi{0, 0, 0, 0};
+	if constexpr (NF >= 1) y = xor4(v[0], ctable_mul(tab[0], xor4(v[0], v[1])));
+	if constexpr (NF == 2) {
+		u_hi = xor4(v[2], ctable_mul(tab[0], xor4(v[2], v[3]))); // X'[i + m]
+		y = xor4(y, ctable_mul(tab[1], xor4(y, u_hi)));
+	}
+	if (have) {
+		if constexpr (NF >= 1) ((uint4 *)fa.out[arr])[i] = y;
+		if constexpr (NF == 2) ((uint4 *)fa.out[arr])[i + m] = u_hi; // memory ends up exactly as after two separate in-place folds
+		stage[(arr * 4 + qt) * kRowsPad + lane] = y;
+	}
+	fin_commit(fz, fpre, fcache);
+	__syncthreads();
+	uint32_t acc[32];
+#pragma unroll
+	for (int p = 0; p < 32; p++)
+		acc[p] = 0;
+	const lay8 lay = make_lay8(lane);
+	if (wave < 4) {
+		// (wave-uniform selectors)       H        H2                L        L2
+		const unsigned h0 = wave == 0 ? 2u : (wave == 1 ? 3u : (wave == 2 ? 1u : 2u));
+		const unsigned l0 = wave == 1 ? 1u : 0u;
+		eval_pair(stage, tile[wave], lay, h0, wave == 3 ? 3 : -1, l0, wave == 3 ? 1 : -1, n_valid, acc);
+	}
+	tail8(acc, lay, wave, lane, out, fz, seq, fcache);
+}
+
+// Y = the arrays after fa.n_folds folds (0: x0 | x1 are the halves of Y, nothing is written; 1: X0 + z1 (X0 + X1);
+// 2: that folded once more with z2), M = n_in >> n_folds elements each, M >= 4 a multiple of 4; d_out[0..8) ^= the
+// eight sums in slot order (header comment).  The stage holds one 64-point batch per workgroup, one workgroup per CU:
+// the launcher's own bound is far above what the dispatcher sends (abi_kernels.cpp two_round_size_ok).
+hipError_t launch_foldeval8(hipStream_t s, const foldeval8_args &fa, f128 z1, f128 z2, f128 *d_out, const fin_fuse *fuse, const arm_args *armed)
+{
+	if (fa.n_folds > 2) return hipErrorNotSupported;
+	const uint64_t m = fa.n_in >> fa.n_folds;
+	if (m < 4 || (m & 3) || (m << fa.n_folds) != fa.n_in) return hipErrorNotSupported;
+	const uint64_t q = m >> 2, blocks = (q + kPts - 1) / kPts;
+	if (blocks > 4096) return hipErrorNotSupported;
+	arm_args arm{};
+	if (armed) arm = *armed;
+	fin_fuse fz{};
+	if (fuse) fz = *fuse;
+	if (!fz.counter) return hipErrorNotSupported; // the eight sums are always finalized in the kernel
+	switch (fa.n_folds) {
+	case 0: hipLaunchKernelGGL(k_foldeval8<0>, dim3((unsigned)blocks), dim3(512), 0, s, fa, z1, z2, d_out, fz, arm); break;
+	case 1: hipLaunchKernelGGL(k_foldeval8<1>, dim3((unsigned)blocks), dim3(512), 0, s, fa, z1, z2, d_out, fz, arm); break;
+	default: hipLaunchKernelGGL(k_foldeval8<2>, dim3((unsigned)blocks), dim3(512), 0, s, fa, z1, z2, d_out, fz, arm); break;
+	}
+	return hipGetLastError();
+}
+
+} // namespace bn

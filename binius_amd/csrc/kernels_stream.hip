@@ -229,6 +229,46 @@ hipError_t launch_fold_publish(hipStream_t s, void *const *x0, const void *const
 	return hipGetLastError();
 }
 
+// The last TWO folds of a sumcheck in one launch (a round between them was answered from precomputed sums, abi_kernels.cpp):
+// X (4 n_out elements: src0 | x1 are its halves) -> X' = X0 + z1 (X0 + X1) -> Y = X'0 + z2 (X'0 + X'1), n_out elements.
+// Memory ends up exactly as after two separate in-place folds: Y in out[0, n_out), the upper half of X' in
+// out[n_out, 2 n_out).  The two nibble tables are built side by side by the two halves of the workgroup.
+__global__ __launch_bounds__(256) void k_fold2_publish(fold_publish_args fb, uint32_t count, uint32_t n_out, f128 z1, f128 z2, f128 *mail, uint64_t seq)
+{
+	__shared__ ctable_smem tab[2];
+	ctable_build_group(tab[threadIdx.x >> 7], (threadIdx.x >> 7) ? z2 : z1, threadIdx.x & 127, 128);
+	const unsigned i = threadIdx.x;
+	if (i < count * n_out) {
+		const unsigned arr = i / n_out, j = i - arr * n_out;
+		const uint4 *lo = (const uint4 *)fb.src0[arr], *hi = (const uint4 *)fb.x1[arr];
+		const uint4 a0 = lo[j], b0 = hi[j], a1 = lo[j + n_out], b1 = hi[j + n_out];
+		const uint4 u = xor4(a0, ctable_mul(tab[0], xor4(a0, b0)));
+		const uint4 v = xor4(a1, ctable_mul(tab[0], xor4(a1, b1)));
+		const uint4 f = xor4(u, ctable_mul(tab[1], xor4(u, v)));
+		((uint4 *)fb.x0[arr])[j] = f;
+		((uint4 *)fb.x0[arr])[j + n_out] = v;
+		const f128 r = to_f128(f);
+		__hip_atomic_store(&mail[i].lo, r.lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		__hip_atomic_store(&mail[i].hi, r.hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+	}
+	if (i == 0)
+		__hip_atomic_store(&mail[64].lo, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+hipError_t launch_fold2_publish(hipStream_t s, void *const *out, const void *const *src0, const void *const *x1, uint32_t count, uint32_t n_out,
+                                f128 z1, f128 z2, f128 *d_mail, uint64_t seq)
+{
+	if (count == 0 || n_out == 0 || count > (uint32_t)kFoldBatchMax || (uint64_t)count * n_out > 64) return hipErrorNotSupported;
+	fold_publish_args fb{};
+	for (uint32_t i = 0; i < count; i++) {
+		fb.x0[i] = out[i];
+		fb.src0[i] = src0[i];
+		fb.x1[i] = x1[i];
+	}
+	hipLaunchKernelGGL(k_fold2_publish, dim3(1), dim3(256), 0, s, fb, count, n_out, z1, z2, d_mail, seq);
+	return hipGetLastError();
+}
+
 // x[i] *= c in place (the stand-alone form of the upper-half scaling of bn_extrapolate_line_batch_scaled; the fused
 // fold + evaluation kernels do it on the folded registers)
 __global__ __launch_bounds__(256) void k_scale(uint4 *__restrict__ x, uint64_t n, f128 c)

@@ -88,8 +88,8 @@ pub struct bn_kop {
 	pub dst: bn_kslice,
 }
 
-pub const BN_PROF_N: usize = 10;
-pub const BN_ARM_N: usize = 6;
+pub const BN_PROF_N: usize = 11;
+pub const BN_ARM_N: usize = 8;
 
 // ---- the old HAL (binius_hal::ComputationBackend) on device-resident multilinears
 pub const BN_ORDER_LOW_TO_HIGH: u32 = 0;

@@ -301,7 +301,7 @@ int bn_gather_d2h(bn_ctx *ctx, const void *d_src, const uint64_t *h_offsets, uin
 /* Per-kernel-class timing without perturbing the stream: while profiling is on, every launch of a
  * hot kernel is bracketed by two hipEvents recorded on the context's stream (no synchronisation);
  * bn_prof_end synchronises once and sums the elapsed times per class. */
-enum { BN_PROF_ROUND_EVAL = 0, BN_PROF_FOLD = 1, BN_PROF_TENSOR_EXPAND = 2, BN_PROF_NTT = 3, BN_PROF_OTHER = 4, BN_PROF_FOLD_EVAL = 5, BN_PROF_TAIL = 6, BN_PROF_FOLD_EVAL_SMALL = 7, BN_PROF_FOLD_EVAL_MFMA = 8, BN_PROF_ROUND_EVAL_MFMA = 9, BN_PROF_N = 10 };
+enum { BN_PROF_ROUND_EVAL = 0, BN_PROF_FOLD = 1, BN_PROF_TENSOR_EXPAND = 2, BN_PROF_NTT = 3, BN_PROF_OTHER = 4, BN_PROF_FOLD_EVAL = 5, BN_PROF_TAIL = 6, BN_PROF_FOLD_EVAL_SMALL = 7, BN_PROF_FOLD_EVAL_MFMA = 8, BN_PROF_ROUND_EVAL_MFMA = 9, BN_PROF_FOLD_EVAL8 = 10, BN_PROF_N = 11 };
 int bn_prof_begin(bn_ctx *ctx);
 int bn_prof_end(bn_ctx *ctx, double *ms_by_class /*[BN_PROF_N]*/, uint64_t *launches_by_class /*[BN_PROF_N]*/);
 
@@ -313,7 +313,7 @@ int bn_prof_end(bn_ctx *ctx, double *ms_by_class /*[BN_PROF_N]*/, uint64_t *laun
  * because the next call was something else, armed kernels that gave up waiting; host nanoseconds between handing over
  * a challenge and seeing the round's result, the part of that spent enqueueing the next armed kernel, and the time from
  * the entry of bn_kernel_launch to handing the challenge over (validation + recognising the round). */
-enum { BN_ARM_HITS = 0, BN_ARM_CANCELS = 1, BN_ARM_EXPIRED = 2, BN_ARM_NS_WAIT = 3, BN_ARM_NS_LAUNCH = 4, BN_ARM_NS_PARSE = 5, BN_ARM_N = 6 };
+enum { BN_ARM_HITS = 0, BN_ARM_CANCELS = 1, BN_ARM_EXPIRED = 2, BN_ARM_NS_WAIT = 3, BN_ARM_NS_LAUNCH = 4, BN_ARM_NS_PARSE = 5, BN_ARM_HOSTED = 6, BN_ARM_TWO_ROUND = 7, BN_ARM_N = 8 };
 int bn_arm_counters(bn_ctx *ctx, uint64_t *counters /*[BN_ARM_N]*/);
 
 #ifdef __cplusplus

@@ -35,6 +35,11 @@ def _worker(rank, world, port, n_global, m, comps, q, exchange="shm"):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    if world >= 8:
+        # Ranks that SHARE a device must not arm rounds (csrc/arm.hpp): an armed kernel waits on the device for its
+        # challenge, and eight processes' worth of waiting workgroups leave no compute units for the kernels whose results
+        # those challenges depend on (on a node every rank has its own device and the question does not arise).
+        os.environ["BN_ARM"] = "0"
     import torch
     import torch.distributed as dist
 

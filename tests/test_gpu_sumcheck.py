@@ -347,6 +347,27 @@ def test_resident_tail_times_out_safely(hal_tail, oracle):
 # these tests pin the protocol's edges.
 
 
+@pytest.fixture(scope="module")
+def hal_one_round():
+    """A context with the two-round launches switched off (BN_TWO_ROUND=0, read at context creation): every small round is one
+    launch of the one-round kernels, which is what the counters below count."""
+    import os
+
+    import binius_amd
+
+    old = os.environ.get("BN_TWO_ROUND")
+    os.environ["BN_TWO_ROUND"] = "0"
+    try:
+        ctx = binius_amd.Context(0, 1 << 19)
+    finally:
+        if old is None:
+            os.environ.pop("BN_TWO_ROUND", None)
+        else:
+            os.environ["BN_TWO_ROUND"] = old
+    yield ctx
+    ctx.close()
+
+
 def _needs_arming():
     import os
 
@@ -356,9 +377,10 @@ def _needs_arming():
 
 @pytest.mark.last
 @pytest.mark.parametrize("n_vars", [3, 5, 12, 17])
-def test_armed_rounds_serve_the_small_rounds(hal, oracle, n_vars):
+def test_armed_rounds_serve_the_small_rounds(hal_one_round, oracle, n_vars):
     """Round 0 is a plain evaluation, round 1 the first fused launch; from round 2 on every (small) round is answered by
     a kernel that was already on the device."""
+    hal = hal_one_round
     _needs_arming()
     c0 = hal.arm_counters()
     _rounds_with_oracle(hal, oracle, n_vars, seed=0xA4A40000 + n_vars)
@@ -371,9 +393,10 @@ def test_armed_rounds_serve_the_small_rounds(hal, oracle, n_vars):
 
 
 @pytest.mark.last
-def test_armed_round_is_cancelled_by_other_calls(hal, oracle):
+def test_armed_round_is_cancelled_by_other_calls(hal_one_round, oracle):
     """Any call that is not the predicted fold + evaluation pair sends the waiting kernel home (it has touched nothing);
     the round then runs as an ordinary launch and the next one is armed again."""
+    hal = hal_one_round
     _needs_arming()
     def after_eval(r, d):
         if r in (2, 3, 7):
@@ -393,10 +416,11 @@ def test_armed_round_is_cancelled_by_other_calls(hal, oracle):
 
 
 @pytest.mark.last
-def test_armed_round_with_other_arrays_is_cancelled(hal, oracle):
+def test_armed_round_with_other_arrays_is_cancelled(hal_one_round, oracle):
     """The prediction is 'the same two arrays, in place, half the size'.  Two sumchecks that take turns on one context
     (fold + evaluate of A, then fold + evaluate of B, ...) miss it every time: each fused launch arms a kernel for its
     own next round, the other instance's fold cancels it -- and everybody still gets the right answers."""
+    hal = hal_one_round
     _needs_arming()
     from binius_amd.sumcheck import bivariate_product_expr, calculate_round_evals
 
@@ -431,9 +455,10 @@ def test_armed_round_with_other_arrays_is_cancelled(hal, oracle):
 
 
 @pytest.mark.last
-def test_armed_round_times_out_safely(hal, oracle):
+def test_armed_round_times_out_safely(hal_one_round, oracle):
     """A host that stops talking cannot hang the GPU: the armed kernel leaves after a bounded spin (~6 ms), says so in
     the status word, and the round it was meant for runs as an ordinary launch."""
+    hal = hal_one_round
     _needs_arming()
     import time
 
