@@ -125,7 +125,9 @@ def main():
     #   "rccl"  one ncclAllGather per round on the context's stream + a one-workgroup XOR + readback (timed beside it)
     #   "shm"   the partials meet in host shared memory (timed beside it)
     rccl_possible = dist is not None and dist.get_backend() == "nccl"
-    exchange = os.environ.get("BN_EXCHANGE", "peer")
+    # BN_EXCHANGE=auto (the default): every exchange that works on this node is tried for two untimed steps before the
+    # warm-up and the fastest one (MAX over ranks) becomes the default; the choice and all trial times are reported.
+    exchange = os.environ.get("BN_EXCHANGE", "auto")
     import binius_amd
     from binius_amd import synthetic  # SplitMix64 input streams (numpy)
     from binius_amd._host import PeerExchange, RcclComm, ShmExchange, SumcheckPlan
@@ -207,7 +209,7 @@ def main():
                 available.append("rccl")
         if not available:
             raise SystemExit("no exchange is available on this node (shared memory, peer mailboxes and RCCL all failed)")
-        if exchange not in available:
+        if exchange != "auto" and exchange not in available:
             exchange = "%s (fallback: %s is not available on this node)" % (available[0], exchange)
 
     # the claimed sum (not timed): inner product on the device, combined across ranks
@@ -231,7 +233,10 @@ def main():
         return SumcheckPlan(hal, n_vars, d_in, scratch, [(0, 1)], [claim], batch_coeff, challenges[:n_global], None, 0, None, world, 0, shm.handle,
                             tail_rounds=log_world > 0, peer=(kind == "peer"))
 
-    plan = make_plan(exchange) if dist is not None else SumcheckPlan(hal, n_vars, d_in, scratch, [(0, 1)], [claim], batch_coeff, challenges[:n_global])
+    if dist is None:
+        plan = SumcheckPlan(hal, n_vars, d_in, scratch, [(0, 1)], [claim], batch_coeff, challenges[:n_global])
+    else:
+        plan = make_plan(exchange) if exchange != "auto" else None  # (auto: chosen below)
 
     def timed(pl, steps):
         barrier()
@@ -246,6 +251,27 @@ def main():
             dt = float(t.item())
         return dt
 
+    trials = None
+    if dist is not None and exchange == "auto":
+        # ---- pick the exchange by measurement (untimed: before the warm-up).  A candidate that raises on any rank is dropped.
+        trials = {}
+        for cand in list(available):
+            pl = make_plan(cand)
+            ok = True
+            try:
+                pl.run()
+            except Exception as ex:  # noqa: BLE001
+                print("[bench] rank %d: exchange %s failed (%s)" % (rank, cand, ex), file=sys.stderr)
+                ok = False
+            if not everybody(ok):
+                available.remove(cand)
+                trials[cand] = None
+                continue
+            trials[cand] = timed(pl, 2) * 1e3 / 2
+        if not available:
+            raise SystemExit("every exchange failed on this node")
+        exchange = min(available, key=lambda c: trials[c])
+        plan = make_plan(exchange)
     # First run of the default exchange, guarded: if it cannot run on this node (an error on ANY rank), every rank
     # switches to the next available one together and the line says so -- a scaling line with a documented fallback
     # beats none.
@@ -314,7 +340,8 @@ def main():
                         "same_transcript_as_default": bool(same),
                         "exchange_us_per_round": round((dt_alt - dt_solo) * 1e6 / args.steps / n_rounds, 2)})
         alt.append({"exchange": "none (the local shard alone, no residual rounds: diagnostic)", "ms_per_step": dt_solo * 1e3 / args.steps})
-        alt.append({"exchange": main_kind + " (the default: `value`)", "exchange_us_per_round": round((elapsed - dt_solo) * 1e6 / args.steps / n_rounds, 2)})
+        alt.append({"exchange": main_kind + " (the default: `value`)", "exchange_us_per_round": round((elapsed - dt_solo) * 1e6 / args.steps / n_rounds, 2),
+                    "chosen_by": "measurement before the warm-up: ms per step " + json.dumps(trials) if trials is not None else "BN_EXCHANGE"})
 
     # correctness of what was timed (N = 1: the sumcheck verifier's final check, on the device values)
     # the sumcheck verifier on what was timed (all ranks hold the same transcript):

@@ -54,10 +54,15 @@ __device__ __forceinline__ bool peer_exchange(f128 *vals, uint32_t n_ret, uint64
 			__hip_atomic_store(dst + 2 * r, vals[r].lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 			__hip_atomic_store(dst + 2 * r + 1, vals[r].hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 		}
-		__hip_atomic_store(dst + 16, round, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+		// No release / acquire FENCES: a system-scope release writes the whole L2 back and an acquire invalidates it (measured:
+		// +6 us per round on one device).  Every word of the mailbox is only ever touched by system-scope atomics on
+		// fine-grained memory, which are performed at the memory itself, in program order per lane once the lane has drained its
+		// stores (vmcnt(0)) -- the same argument as for the relay of arm.hpp and the ticket of re9.hpp.
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__hip_atomic_store(dst + 16, round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 		src = box[rank] + (size_t)(par * kPeerMaxWorld + p) * kPeerSlotWords;
 		uint32_t spins = 0;
-		while (__hip_atomic_load(src + 16, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != round) {
+		while (__hip_atomic_load(src + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != round) {
 			if (++spins > (1u << 21)) { // ~1 us per look: gives up after a couple of seconds
 				ok = false;
 				break;
@@ -176,10 +181,12 @@ __device__ __forceinline__ void finalize_body(const fin_args &a, f128 *S, f128 *
 	}
 	BN_FTS(11);
 	if (seq) {
-		// n_ret <= 8: the value stores above were issued by lanes of wave 0; the release below makes
-		// wave 0 drain them (vmcnt) and write them through before the sequence word
+		// n_ret <= 8: the value stores above were issued by lanes of wave 0 (system-scope atomics into fine-grained host
+		// memory: they do not sit in the L2); the wave drains them (vmcnt(0)) and then writes the sequence word -- posted
+		// writes to one destination keep their order.  (A release here would write the whole L2 back first.)
+		if (tid < 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		if (tid == 0)
-			__hip_atomic_store(&mail[64].lo, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+			__hip_atomic_store(&mail[64].lo, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 	}
 }
 
@@ -351,8 +358,9 @@ __device__ __forceinline__ void finalize_cached(const fin_cache &c, uint64_t seq
 	}
 	BN_FTS(11);
 	if (seq) {
+		if (tid < 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (as in finalize_body: no release fence)
 		if (tid == 0)
-			__hip_atomic_store(&mail[64].lo, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+			__hip_atomic_store(&mail[64].lo, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 	}
 }
 

@@ -89,6 +89,7 @@ __device__ __forceinline__ void eval_pair(const uint4 *stage, uint4 *wt, const l
 		r[j] = ok ? h : 0u;
 		r[16 + j] = ok ? (l ^ h) : 0u;
 	}
+	BN_TS(4);
 	transpose32(r);
 	if (lay.loader) {
 #pragma unroll
@@ -112,7 +113,9 @@ __device__ __forceinline__ void eval_pair(const uint4 *stage, uint4 *wt, const l
 		B[4 * q + 2] = xor3(y0.z, y1.z, y2.z) ^ y3.z;
 		B[4 * q + 3] = xor3(y0.w, y1.w, y2.w) ^ y3.w;
 	}
+	BN_TS(5);
 	bs_mul<5>(A, B, acc);
+	BN_TS(6);
 }
 
 // Workgroup tail for eight sums: wave w < 4 holds the planes of slots 2 w (low halves) and 2 w + 1 (high halves).
@@ -154,6 +157,7 @@ __device__ __forceinline__ void tail8(const uint32_t (&acc)[32], const lay8 &lay
 		wsum[wave][2 * lane + 1] = S.hi;
 	}
 	__syncthreads();
+	BN_TS(7);
 	unsigned *const counter = fc.counter;
 	if (counter && gridDim.x == 1 && out == fc.S) {
 		// single workgroup: the sums never leave the chip (wsum is laid out exactly as f128 S_local[8])
@@ -189,6 +193,7 @@ __global__ __launch_bounds__(512, 1) void k_foldeval8(foldeval8_args fa, f128 z1
 	__shared__ uint4 tile[4][kTile8];
 	__shared__ ctable_smem tab[NF == 2 ? 2 : 1];
 	__shared__ fin_cache fcache;
+	BN_TS(0);
 	const uint64_t seq = fz.args.seq;
 	const unsigned tid = threadIdx.x, lane = tid & 63;
 	const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -215,6 +220,7 @@ __global__ __launch_bounds__(512, 1) void k_foldeval8(foldeval8_args fa, f128 z1
 		}
 	}
 	const fin_pref fpre = fin_prefetch(fz);
+	BN_TS(1);
 	if (arm.h_cmd) { // (uniform) armed launch: the data is on its way, the challenges are what is missing (arm.hpp)
 		f128 z2_in;
 		if (!arm_wait(arm, z1, z2_in)) return;
@@ -224,6 +230,7 @@ __global__ __launch_bounds__(512, 1) void k_foldeval8(foldeval8_args fa, f128 z1
 		ctable_build_group(tab[tid >> 8], (tid >> 8) ? z2 : z1, tid & 255, 256); // both tables at once
 	else if constexpr (NF == 1)
 		ctable_build(tab[0], z1);
+	BN_TS(2);
 	uint4 y = v[0], u_hi{0, 0, 0, 0};
 	if constexpr (NF >= 1) y = xor4(v[0], ctable_mul(tab[0], xor4(v[0], v[1])));
 	if constexpr (NF == 2) {
@@ -237,6 +244,7 @@ __global__ __launch_bounds__(512, 1) void k_foldeval8(foldeval8_args fa, f128 z1
 	}
 	fin_commit(fz, fpre, fcache);
 	__syncthreads();
+	BN_TS(3);
 	uint32_t acc[32];
 #pragma unroll
 	for (int p = 0; p < 32; p++)
@@ -249,6 +257,7 @@ __global__ __launch_bounds__(512, 1) void k_foldeval8(foldeval8_args fa, f128 z1
 		eval_pair(stage, tile[wave], lay, h0, wave == 3 ? 3 : -1, l0, wave == 3 ? 1 : -1, n_valid, acc);
 	}
 	tail8(acc, lay, wave, lane, out, fz, seq, fcache);
+	BN_TS(8);
 }
 
 // Y = the arrays after fa.n_folds folds (0: x0 | x1 are the halves of Y, nothing is written; 1: X0 + z1 (X0 + X1);

@@ -334,6 +334,105 @@ __global__ __launch_bounds__(256) void k_fri_pass(const uint4 *in, uint4 *out, u
 	}
 }
 
+// C (2 or 3) consecutive challenges in ONE pass: a thread folds 2^C adjacent elements down to one, all levels in registers.
+// The separate passes move (1 + 1/2)(1 + 1/2 + 1/4 + ...) = 3 N elements through HBM for N inputs; here a pass reads N and writes
+// N / 2^C.  What made the first attempt at this lose (four 16-byte loads per lane at a 64-byte lane stride
+// quarter the efficiency of every request) is taken out by staging: the workgroup loads its 256 * 2^C contiguous elements
+// with fully coalesced 16-byte loads into LDS (rows padded to 2^C + 1 elements: conflict-free 128-bit reads at the lane stride)
+// and each thread picks its run from there.  One nibble table per challenge (10 KiB each) stays resident; no barrier between
+// the levels.  Same arithmetic, same order of operations per pair as k_fri_pass.
+struct fri_level {
+	f128 r;
+	const uint64_t *s_row; // twiddle basis of this level's fold round (nullptr: an interleave challenge, no butterfly)
+	int n_bits;
+};
+template <int C>
+struct fri_levels {
+	fri_level l[C];
+};
+// NTT = false: every level is an interleave challenge (no butterfly code in the kernel at all: the walk through the twiddle
+// field and its chain of mulx multiples is what pushes the general form to 200+ spilled registers; it only ever runs on the
+// arrays the interleave passes have already shrunk).
+template <int TW, int C, bool NTT>
+__global__ __launch_bounds__(256, 2) void k_fri_pass_multi(const uint4 *in, uint4 *out, uint64_t n_out, fri_levels<C> lv)
+{
+	constexpr int E = 1 << C, ROW = E + 1;
+	__shared__ ctable_smem tab[C];
+	__shared__ uint64_t s_basis[C][64];
+	__shared__ uint4 stage[256 * ROW];
+#pragma unroll
+	for (int c = 0; c < C; c++) ctable_build(tab[c], lv.l[c].r);
+	if (threadIdx.x < 64) {
+#pragma unroll
+		for (int c = 0; c < C; c++)
+			s_basis[c][threadIdx.x] = (lv.l[c].s_row && (int)threadIdx.x < lv.l[c].n_bits) ? lv.l[c].s_row[threadIdx.x] : 0;
+	}
+	__syncthreads();
+	const uint64_t n_blocks = (n_out + 255) / 256;
+	for (uint64_t b = blockIdx.x; b < n_blocks; b += gridDim.x) {
+		const uint64_t k0 = b * 256;                      // first output of this block
+		const uint64_t in0 = k0 << C, n_in = n_out << C;  // its inputs: 256 * E contiguous elements
+#pragma unroll
+		for (int j = 0; j < E; j++) {
+			const unsigned e = j * 256 + threadIdx.x; // coalesced
+			if (in0 + e < n_in) stage[(e >> C) * ROW + (e & (E - 1))] = in[in0 + e];
+		}
+		__syncthreads();
+		const uint64_t k = k0 + threadIdx.x;
+		if (k < n_out) {
+			uint4 x[E];
+			const uint4 *row = stage + threadIdx.x * ROW;
+#pragma unroll
+			for (int j = 0; j < E; j++) x[j] = row[j];
+#pragma unroll
+			for (int c = 0; c < C; c++) {
+				const int cnt = E >> (c + 1); // outputs of this level per thread
+#pragma unroll
+				for (int j = 0; j < E / 2; j++) {
+					if (j < cnt) {
+						uint4 u = x[2 * j], v = x[2 * j + 1];
+						if (NTT && lv.l[c].s_row) { // (uniform)
+							const uint64_t kk = (k << (C - 1 - c)) + j; // pair index in the whole array at this level
+							uint64_t t = 0;
+							for (int bb = 0; bb < lv.l[c].n_bits; bb++)
+								if ((kk >> bb) & 1) t ^= s_basis[c][bb];
+							v = xor4(v, u);
+							u = xor4(u, to_u4(mul_walk<TW>(to_f128(v), t)));
+						}
+						x[j] = xor4(u, ctable_mul<8>(tab[c], xor4(u, v)));
+						// one pair at a time: left alone the scheduler hoists the lookups of all pairs of a level to the front
+						// and spills hundreds of registers (the same effect as in the fused fold + evaluation kernel)
+						__builtin_amdgcn_sched_barrier(0);
+					}
+				}
+			}
+			out[k] = x[0];
+		}
+		__syncthreads(); // the stage is refilled by the next block
+	}
+}
+
+template <int TW>
+hipError_t run_fri_multi(hipStream_t s, int C, unsigned g, const uint4 *src, uint4 *dst, uint64_t n_out, const fri_level *lv)
+{
+	bool ntt = false;
+	for (int c = 0; c < C; c++) ntt = ntt || lv[c].s_row != nullptr;
+	if (C == 3) {
+		fri_levels<3> a{{lv[0], lv[1], lv[2]}};
+		if (ntt)
+			hipLaunchKernelGGL((k_fri_pass_multi<TW, 3, true>), dim3(g), dim3(256), 0, s, src, dst, n_out, a);
+		else
+			hipLaunchKernelGGL((k_fri_pass_multi<0, 3, false>), dim3(g), dim3(256), 0, s, src, dst, n_out, a);
+	} else {
+		fri_levels<2> a{{lv[0], lv[1]}};
+		if (ntt)
+			hipLaunchKernelGGL((k_fri_pass_multi<TW, 2, true>), dim3(g), dim3(256), 0, s, src, dst, n_out, a);
+		else
+			hipLaunchKernelGGL((k_fri_pass_multi<0, 2, false>), dim3(g), dim3(256), 0, s, src, dst, n_out, a);
+	}
+	return hipGetLastError();
+}
+
 hipError_t launch_fri_fold(hipStream_t s, const uint64_t *d_s_evals, uint32_t tw_level, uint32_t log_domain,
                            uint32_t log_len, uint32_t log_batch, const f128 *h_challenges, uint32_t n_challenges,
                            const void *in, void *out, uint64_t out_len, void *scratch)
@@ -345,29 +444,65 @@ hipError_t launch_fri_fold(hipStream_t s, const uint64_t *d_s_evals, uint32_t tw
 	const uint4 *src = (const uint4 *)in;
 	uint64_t cur = in_len;
 	uint32_t ll = log_len;
-	for (uint32_t c = 0; c < n_challenges; c++) {
-		const uint64_t n_out = cur / 2;
-		uint4 *dst = (c + 1 == n_challenges) ? (uint4 *)out : ((c & 1) ? buf1 : buf0);
-		const int ntt_pass = c >= log_batch;
-		// twiddles of get_subspace_eval(ll, .) = s_evals[log_domain - ll], which has log_domain-1-(log_domain-ll)=ll-1 bits
-		const uint64_t *row = d_s_evals + (uint64_t)(log_domain - ll) * BN_NTT_MAX_DIM;
-		const int n_bits = ntt_pass ? (int)ll - 1 : 0;
-		uint64_t want = (n_out + 255) / 256;
-		unsigned g = (unsigned)(want < 2048 ? want : 2048);
-		if (g < 1) g = 1;
-		const f128 r = h_challenges[c];
-		switch (tw_level) {
-		case 3: hipLaunchKernelGGL(k_fri_pass<3>, dim3(g), dim3(256), 0, s, src, dst, n_out, r, ntt_pass, row, n_bits); break;
-		case 4: hipLaunchKernelGGL(k_fri_pass<4>, dim3(g), dim3(256), 0, s, src, dst, n_out, r, ntt_pass, row, n_bits); break;
-		case 5: hipLaunchKernelGGL(k_fri_pass<5>, dim3(g), dim3(256), 0, s, src, dst, n_out, r, ntt_pass, row, n_bits); break;
-		case 6: hipLaunchKernelGGL(k_fri_pass<6>, dim3(g), dim3(256), 0, s, src, dst, n_out, r, ntt_pass, row, n_bits); break;
-		default: return hipErrorInvalidValue;
+	static const bool multi = [] {
+		const char *e = getenv("BN_FRI_MULTI");
+		return !(e && e[0] == '0');
+	}();
+	uint32_t c = 0, pass = 0;
+	while (c < n_challenges) {
+		// challenges per pass: three at a time (then two, then one) while the pass is large enough to be a streaming pass
+		// (three interleave challenges per pass; two as soon as a butterfly level is among them -- the general kernel with
+		// three levels spills -- and one at a time for B64 twiddles)
+		uint32_t C = 1;
+		if (multi && cur >= (1u << 14)) {
+			const uint32_t left = n_challenges - c, inter = c < log_batch ? log_batch - c : 0;
+			if (inter >= 2)
+				C = inter >= 3 ? 3 : 2;
+			else if (tw_level <= 5 && left >= 2)
+				C = 2;
 		}
-		hipError_t e = hipGetLastError();
+		const uint64_t n_out = cur >> C;
+		uint4 *dst = (c + C == n_challenges) ? (uint4 *)out : ((pass & 1) ? buf1 : buf0);
+		fri_level lv[3];
+		for (uint32_t q = 0; q < C; q++) {
+			const bool ntt_pass = c + q >= log_batch;
+			lv[q].r = h_challenges[c + q];
+			// twiddles of get_subspace_eval(ll, .) = s_evals[log_domain - ll], which has log_domain-1-(log_domain-ll)=ll-1 bits
+			lv[q].s_row = ntt_pass ? d_s_evals + (uint64_t)(log_domain - ll) * BN_NTT_MAX_DIM : nullptr;
+			lv[q].n_bits = ntt_pass ? (int)ll - 1 : 0;
+			if (ntt_pass) ll -= 1;
+		}
+		hipError_t e;
+		if (C == 1) {
+			uint64_t want = (n_out + 255) / 256;
+			unsigned g = (unsigned)(want < 2048 ? want : 2048);
+			if (g < 1) g = 1;
+			const int ntt_pass = lv[0].s_row != nullptr;
+			const uint64_t *row = ntt_pass ? lv[0].s_row : d_s_evals;
+			switch (tw_level) {
+			case 3: hipLaunchKernelGGL(k_fri_pass<3>, dim3(g), dim3(256), 0, s, src, dst, n_out, lv[0].r, ntt_pass, row, lv[0].n_bits); break;
+			case 4: hipLaunchKernelGGL(k_fri_pass<4>, dim3(g), dim3(256), 0, s, src, dst, n_out, lv[0].r, ntt_pass, row, lv[0].n_bits); break;
+			case 5: hipLaunchKernelGGL(k_fri_pass<5>, dim3(g), dim3(256), 0, s, src, dst, n_out, lv[0].r, ntt_pass, row, lv[0].n_bits); break;
+			case 6: hipLaunchKernelGGL(k_fri_pass<6>, dim3(g), dim3(256), 0, s, src, dst, n_out, lv[0].r, ntt_pass, row, lv[0].n_bits); break;
+			default: return hipErrorInvalidValue;
+			}
+			e = hipGetLastError();
+		} else {
+			uint64_t want = (n_out + 255) / 256;
+			unsigned g = (unsigned)(want < 512 ? want : 512); // two workgroups per CU (62 KiB of LDS each)
+			switch (tw_level) {
+			case 3: e = run_fri_multi<3>(s, (int)C, g, src, dst, n_out, lv); break;
+			case 4: e = run_fri_multi<4>(s, (int)C, g, src, dst, n_out, lv); break;
+			case 5: e = run_fri_multi<5>(s, (int)C, g, src, dst, n_out, lv); break;
+			case 6: e = run_fri_multi<6>(s, (int)C, g, src, dst, n_out, lv); break;
+			default: return hipErrorInvalidValue;
+			}
+		}
 		if (e != hipSuccess) return e;
-		if (ntt_pass) ll -= 1;
 		src = dst;
 		cur = n_out;
+		c += C;
+		pass++;
 	}
 	return hipSuccess;
 }
