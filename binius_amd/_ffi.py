@@ -469,10 +469,10 @@ class Context:
     def arm_counters(self):
         """Armed rounds (csrc/arm.hpp): {hits, cancels, expired} since the context was created; two-round launches
         (csrc/kernels_foldeval8.hip): their number and the rounds the host answered from their precomputed sums."""
-        c = (C.c_uint64 * 8)()
+        c = (C.c_uint64 * 11)()
         _check(lib().bn_arm_counters(self._h, c))
         return {"hits": int(c[0]), "cancels": int(c[1]), "expired": int(c[2]), "ns_wait": int(c[3]), "ns_launch": int(c[4]), "ns_parse": int(c[5]),
-                "hosted": int(c[6]), "two_round": int(c[7])}
+                "hosted": int(c[6]), "two_round": int(c[7]), "shadow_created": int(c[8]), "shadow_rounds": int(c[9]), "shadow_dropped": int(c[10])}
 
     # ---- ComputeLayer
     def copy_h2d(self, src, dst):

@@ -75,6 +75,122 @@ void arm_cancel(bn_ctx *ctx)
 	__atomic_store_n(arm_cmd(ctx), (ctx->arm.id << 2) | 2ull, __ATOMIC_RELEASE);
 }
 
+int shadow_check_table(bn_ctx *ctx, bool *ok)
+{
+	bn_ctx::shadow_state &sh = ctx->shadow;
+	*ok = false;
+	const uint64_t half = sh.eq_len;
+	const uint32_t K = ilog2(half);
+	// ---- table entries 0, 2^0 .. 2^(K-1)
+	const uint64_t n_items = K + 1;
+	const size_t off_bytes = ((size_t)n_items * 8 + 15) & ~(size_t)15, need = off_bytes + n_items * sizeof(f128);
+	if (need > ctx->gather_bytes) {
+		BN_HIP(hipStreamSynchronize(ctx->stream));
+		if (ctx->h_gather) hipHostFree(ctx->h_gather);
+		ctx->h_gather = nullptr;
+		ctx->gather_bytes = 0;
+		if (hipHostMalloc(&ctx->h_gather, 1 << 16, hipHostMallocMapped) != hipSuccess) {
+			(void)hipGetLastError();
+			return BN_OK;
+		}
+		BN_HIP(hipHostGetDevicePointer(&ctx->d_gather, ctx->h_gather, 0));
+		ctx->gather_bytes = 1 << 16;
+	}
+	uint64_t *offs = (uint64_t *)ctx->h_gather;
+	offs[0] = 0;
+	for (uint32_t k = 0; k < K; k++) offs[k + 1] = (uint64_t)1 << k;
+	BN_HIP(bn::launch_gather(ctx->stream, sh.eq, (const uint64_t *)ctx->d_gather, n_items, 1, (char *)ctx->d_gather + off_bytes));
+	BN_HIP(hipStreamSynchronize(ctx->stream));
+	const f128 *got = (const f128 *)((const char *)ctx->h_gather + off_bytes);
+	const f128 e0 = got[0];
+	if (e0 == f128{0, 0}) return BN_OK;
+	const f128 e0_inv = bn::invert_tower(e0);
+	std::vector<f128> rho(K);
+	sh.rho_inv.assign(K, f128{0, 0});
+	sh.one_minus_zeta.assign(K, f128{0, 0});
+	for (uint32_t k = 0; k < K; k++) {
+		rho[k] = bn::mul_host(got[k + 1], e0_inv);
+		const f128 one_plus = rho[k] ^ f128{1, 0};
+		if (rho[k] == f128{0, 0} || one_plus == f128{0, 0}) return BN_OK; // a coordinate 0 or 1: no weighting possible
+		sh.rho_inv[k] = bn::invert_tower(rho[k]);
+		sh.one_minus_zeta[k] = bn::invert_tower(one_plus); // zeta = rho (1 - zeta)  =>  1 - zeta = 1 / (1 + rho)
+	}
+	// ---- the whole table has the structure the ratios describe
+	BN_HIP(hipMemsetAsync(ctx->d_flag, 0, sizeof(unsigned), ctx->stream));
+	BN_HIP(bn::launch_check_tensor(ctx->stream, sh.eq, half, rho.data(), K, ctx->d_flag));
+	unsigned flag = 1;
+	BN_HIP(hipMemcpyAsync(&flag, ctx->d_flag, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+	BN_HIP(hipStreamSynchronize(ctx->stream));
+	*ok = flag == 0;
+	sh.checked = *ok;
+	return BN_OK;
+}
+
+hipStream_t side_stream(bn_ctx *ctx)
+{
+	if (!ctx->side) {
+		if (hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->side_ev, hipEventDisableTiming) != hipSuccess ||
+		    hipEventCreateWithFlags(&ctx->main_ev, hipEventDisableTiming) != hipSuccess) {
+			(void)hipGetLastError();
+			return ctx->stream; // (no side stream: the work simply stays in line)
+		}
+	}
+	if (!ctx->side_busy) {
+		(void)hipEventRecord(ctx->main_ev, ctx->stream);
+		(void)hipStreamWaitEvent(ctx->side, ctx->main_ev, 0);
+		ctx->side_busy = true;
+	}
+	return ctx->side;
+}
+
+int side_run_queue(bn_ctx *ctx)
+{
+	if (ctx->side_queue.empty()) return BN_OK;
+	hipStream_t st = side_stream(ctx);
+	std::vector<bn_ctx::side_op> q;
+	q.swap(ctx->side_queue);
+	for (const auto &op : q) {
+		switch (op.kind) {
+		case bn_ctx::side_op::COPY: BN_HIP(hipMemcpyAsync(op.dst, op.src, op.n * sizeof(f128), hipMemcpyDeviceToDevice, st)); break;
+		case bn_ctx::side_op::ADD_ASSIGN: BN_HIP(bn::launch_add_assign(st, op.dst, op.src, op.n)); break;
+		case bn_ctx::side_op::ADD: BN_HIP(bn::launch_add(st, op.dst, op.src, op.src2, op.n)); break;
+		case bn_ctx::side_op::FOLD: {
+			bn::fold_batch fb{};
+			fb.x0[0] = op.dst;
+			fb.x1[0] = op.src;
+			BN_HIP(bn::launch_extrapolate_line_batch(st, ctx->n_cu, fb, 1, op.n, op.z));
+			break;
+		}
+		}
+	}
+	return BN_OK;
+}
+
+void side_join(bn_ctx *ctx)
+{
+	(void)side_run_queue(ctx);
+	if (!ctx->side_busy) return;
+	(void)hipEventRecord(ctx->side_ev, ctx->side);
+	(void)hipStreamWaitEvent(ctx->stream, ctx->side_ev, 0);
+	ctx->side_busy = false;
+}
+
+bool ranges_overlap(const void *p, uint64_t n_p, const void *q, uint64_t n_q)
+{
+	const char *a = (const char *)p, *b = (const char *)q;
+	return n_p && n_q && a < b + n_q * sizeof(f128) && b < a + n_p * sizeof(f128);
+}
+
+// [p, p + n) touches none of the arrays the deferred fold reads or writes, nor the weighted shadow
+bool independent_of_pending(bn_ctx *ctx, const void *p, uint64_t n)
+{
+	const bn_ctx::pending_fold &pf = ctx->pend;
+	for (uint32_t i = 0; i < pf.count; i++)
+		if (ranges_overlap(p, n, pf.x0[i], pf.n) || ranges_overlap(p, n, pf.x1[i], pf.n) || ranges_overlap(p, n, pf.src0[i], pf.n)) return false;
+	if (ctx->shadow.valid && ctx->shadow.S && ranges_overlap(p, n, ctx->shadow.S, ctx->shadow.S_cap)) return false;
+	return true;
+}
+
 bool pre_matches(const bn_ctx::precomp_state &pre, const bn_ctx::pending_fold &pf)
 {
 	if (!pre.valid || pre.consumed || pf.count != 2 || pf.scale_mask || 2 * pf.n != pre.m) return false;
@@ -131,8 +247,9 @@ int flush_copies(bn_ctx *ctx)
 	return BN_OK;
 }
 
-int flush_pending(bn_ctx *ctx, bool keep_tail, bool publish_tiny)
+int flush_pending(bn_ctx *ctx, bool keep_tail, bool publish_tiny, bool keep_shadow)
 {
+	if (!(keep_shadow && !ctx->pend.active)) side_join(ctx); // whatever follows may read what the side stream writes
 	if (ctx->tail.active && !keep_tail) {
 		int rc = tail_cancel(ctx);
 		if (rc) return rc;
@@ -143,6 +260,14 @@ int flush_pending(bn_ctx *ctx, bool keep_tail, bool publish_tiny)
 		if (rc) return rc;
 	}
 	ctx->pre.valid = false; // the precomputed next-round sums die with any call that is not the one they were made for
+	// (keep_shadow: the end of a round evaluation that the shadow itself answered -- nothing is deferred any more;
+	// bn_extrapolate_line_batch restores the shadow when the batch is the fold it expects)
+	if (ctx->shadow.valid && !(keep_shadow && !ctx->pend.active)) {
+		BN_SHDBG("flush_pending: dropped (fold_pending=%d, pend.active=%d)", (int)ctx->shadow.fold_pending, (int)ctx->pend.active);
+		ctx->shadow.valid = false;
+		ctx->shadow.fold_pending = false;
+		ctx->shadow_dropped++;
+	}
 	if (!ctx->pend.active) return BN_OK;
 	ctx->pend.active = false;
 	if (ctx->pend2.active) {
@@ -284,6 +409,9 @@ int bn_ctx_create(int device, uint64_t arena_elems, bn_ctx **out)
 	BN_HIP(hipMemset(ctx->d_arm_relay, 0, 8 * sizeof(uint64_t)));
 	if (const char *a = getenv("BN_ARM")) ctx->arm_enabled = atoi(a) != 0;
 	if (const char *a = getenv("BN_TWO_ROUND")) ctx->two_round = atoi(a) != 0;
+	if (const char *a = getenv("BN_MLECHECK_SHADOW")) ctx->shadow_enabled = atoi(a) != 0;
+	BN_HIP(hipMalloc((void **)&ctx->d_flag, sizeof(unsigned)));
+	BN_HIP(hipMemset(ctx->d_flag, 0, sizeof(unsigned)));
 	BN_HIP(hipMalloc((void **)&ctx->d_mul8, 65536));
 	BN_HIP(bn::launch_build_mul8(ctx->stream, ctx->d_mul8));
 	if (arena_elems) {
@@ -418,6 +546,14 @@ int bn_ctx_destroy(bn_ctx *ctx)
 	peer_release(ctx);
 	if (ctx->d_arm_relay) hipFree(ctx->d_arm_relay);
 	if (ctx->hal_const) hipFree(ctx->hal_const);
+	if (ctx->side) {
+		hipStreamSynchronize(ctx->side);
+		hipStreamDestroy(ctx->side);
+		if (ctx->side_ev) hipEventDestroy(ctx->side_ev);
+		if (ctx->main_ev) hipEventDestroy(ctx->main_ev);
+	}
+	if (ctx->d_flag) hipFree(ctx->d_flag);
+	if (ctx->shadow.S) hipFree(ctx->shadow.S);
 	if (ctx->ntt_cache) {
 		bn::ntt_bs_cache *nc = (bn::ntt_bs_cache *)ctx->ntt_cache;
 		if (nc->d_tables) hipFree(nc->d_tables);
@@ -631,6 +767,29 @@ int bn_copy_d2d(bn_ctx *ctx, const void *d_src, uint64_t src_len, void *d_dst, u
 		ctx->pend_copies.push_back({d_src, d_dst, src_len});
 		return BN_OK;
 	}
+	if (ctx->pend.active && !ctx->pend2.active && ctx->pend_copies.empty() && !ctx->tail.active &&
+	    independent_of_pending(ctx, d_src, src_len) && independent_of_pending(ctx, d_dst, dst_len)) {
+		// A copy that touches none of the arrays of the deferred fold commutes with it: it runs now and the fold stays
+		// deferred (the MLE-check prover copies the lower half of its indicator table between a fold and the next round
+		// evaluation, v3/bivariate_mlecheck.rs:195-254).
+		bn_ctx::shadow_state &sh = ctx->shadow;
+		if (sh.valid) {
+			if (d_src == sh.eq && 2 * src_len == sh.eq_len) {
+				BN_SHDBG("copy of the table's lower half noted");
+				sh.eq_copy_src = d_src;
+				sh.eq_copy_dst = d_dst;
+			} else if (ranges_overlap(d_dst, dst_len, sh.eq, sh.eq_len)) {
+				sh.valid = false;
+				sh.fold_pending = false;
+				ctx->shadow_dropped++;
+			}
+		}
+		if (sh.valid)
+			ctx->side_queue.push_back({bn_ctx::side_op::COPY, d_dst, d_src, nullptr, src_len, f128{0, 0}}); // (launched behind the next round's kernel)
+		else
+			BN_HIP(hipMemcpyAsync(d_dst, d_src, src_len * sizeof(f128), hipMemcpyDeviceToDevice, ctx->stream));
+		return BN_OK;
+	}
 	BN_FLUSH(ctx);
 	BN_HIP(hipMemcpyAsync(d_dst, d_src, src_len * sizeof(f128), hipMemcpyDeviceToDevice, ctx->stream));
 	return BN_OK;
@@ -833,9 +992,55 @@ int bn_extrapolate_line_batch_scaled(bn_ctx *ctx, void *const *d_evals_0, const 
 		}
 		// (deferred copies that were not absorbed run inside flush_pending and may write the very arrays the sums describe)
 		const bool keep_pre = !ctx->pend.active && ctx->lazy_fold && ctx->pend_copies.empty() && pre_matches(ctx->pre, probe);
-		int rc_ = flush_pending(ctx, keep_tail);
+		// ... and the weighted shadow of an MLE-check (abi_kernels.cpp) survives the fold of exactly its two arrays
+		bn_ctx::shadow_state &sh = ctx->shadow;
+		int sh_ia = -1;
+		if (sh.valid && !sh.fold_pending && !ctx->pend.active && ctx->lazy_fold && count == 2 && scale_mask == 0 && n == sh.half) {
+			auto is = [&](uint32_t i, const void *lo, const void *hi) { return src0[i] == lo && d_evals_1[i] == hi; };
+			if (is(0, sh.a_lo, sh.a_hi) && is(1, sh.b_lo, sh.b_hi)) sh_ia = 0;
+			else if (is(1, sh.a_lo, sh.a_hi) && is(0, sh.b_lo, sh.b_hi)) sh_ia = 1;
+		}
+		if (sh_ia >= 0 && !sh.checked && n >= 2) {
+			// the caller goes on with this instance: is its table a tensor expansion (what the later rounds rely on)?
+			bool ok = false;
+			int rc_c = shadow_check_table(ctx, &ok);
+			if (rc_c) return rc_c;
+			if (!ok) {
+				sh_ia = -1; // (no: the shadow ends with the flush below and the literal kernels answer from here on)
+				sh.blocked_below = sh.half;
+			}
+		}
+		if (sh.valid)
+			BN_SHDBG("fold batch: count=%u n=%llu half=%llu pend=%d fp=%d match=%d (src0 %p %p x1 %p %p | a %p %p b %p %p)", count, (unsigned long long)n,
+			         (unsigned long long)sh.half, (int)ctx->pend.active, (int)sh.fold_pending, sh_ia, src0[0], count > 1 ? src0[1] : nullptr, d_evals_1[0],
+			         count > 1 ? d_evals_1[1] : nullptr, sh.a_lo, sh.a_hi, sh.b_lo, sh.b_hi);
+		// (the shadow's own fold: nothing is deferred, the shadow stays and the side stream is not joined -- its work, the folds
+		// of b and of the table, depends on nothing the main stream does in between)
+		int rc_ = flush_pending(ctx, keep_tail, false, /*keep_shadow=*/sh_ia >= 0);
 		if (rc_) return rc_;
 		ctx->pre.valid = keep_pre;
+		if (sh_ia >= 0) {
+			if (n < 2) { // the fold to one element: nothing is evaluated after it, the shadow has done its work
+				sh.valid = false;
+				side_join(ctx);
+			}
+			if (n >= 2) {
+				// the folded arrays (n elements) split next round by the variable of bit log2(n) - 1 of the table's index
+				const uint32_t kvar = ilog2(n) - 1;
+				sh.valid = true;
+				sh.fold_pending = true;
+				sh.z = to_f(z);
+				sh.ia = (uint32_t)sh_ia;
+				sh.ib = 1 - sh.ia;
+				sh.hi_scale = sh.rho_inv[kvar];
+				sh.lambda_next = bn::mul_host(sh.lambda, sh.one_minus_zeta[kvar]);
+				sh.a_lo = d_evals_0[sh.ia];
+				sh.a_hi = (const char *)d_evals_0[sh.ia] + (n / 2) * sizeof(f128);
+				sh.b_lo = d_evals_0[sh.ib];
+				sh.b_hi = (const char *)d_evals_0[sh.ib] + (n / 2) * sizeof(f128);
+				sh.half = n / 2;
+			} // else: the fold to one element -- nothing is evaluated after it, the shadow has done its work
+		}
 	}
 	// Deferred: the next API call launches it -- or, if that call is the round evaluation of exactly
 	// these arrays, both run as one kernel (kernels_foldeval9.hip).
@@ -866,6 +1071,9 @@ int bn_arm_counters(bn_ctx *ctx, uint64_t *counters)
 	counters[BN_ARM_NS_PARSE] = ctx->arm_ns_parse;
 	counters[BN_ARM_HOSTED] = ctx->two_round_hosted;
 	counters[BN_ARM_TWO_ROUND] = ctx->two_round_launches;
+	counters[BN_ARM_SHADOW_CREATED] = ctx->shadow_created;
+	counters[BN_ARM_SHADOW_ROUNDS] = ctx->shadow_rounds;
+	counters[BN_ARM_SHADOW_DROPPED] = ctx->shadow_dropped;
 	return BN_OK;
 }
 

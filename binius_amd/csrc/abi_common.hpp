@@ -52,10 +52,24 @@ struct prof_scope {
 	} while (0)
 
 
+// BN_SHADOW_DEBUG=1: one line on stderr whenever the MLE-check shadow is made, used, missed or dropped (diagnostic)
+inline bool shadow_debug()
+{
+	static const bool on = getenv("BN_SHADOW_DEBUG") != nullptr;
+	return on;
+}
+#define BN_SHDBG(...)                         \
+	do {                                      \
+		if (shadow_debug()) {                 \
+			fprintf(stderr, "[shadow] " __VA_ARGS__); \
+			fputc('\n', stderr);              \
+		}                                     \
+	} while (0)
+
 namespace bnabi {
 // ---- deferral machinery (defined in abi.cpp)
 int flush_copies(bn_ctx *ctx);
-int flush_pending(bn_ctx *ctx, bool keep_tail = false, bool publish_tiny = false);
+int flush_pending(bn_ctx *ctx, bool keep_tail = false, bool publish_tiny = false, bool keep_shadow = false);
 int tail_cancel(bn_ctx *ctx);
 std::vector<unsigned char> recipe_bytes(const bn::fin_args &a);
 // resident tail kernel: command / status words in the pinned mailbox
@@ -65,6 +79,17 @@ inline volatile uint64_t *tail_status(bn_ctx *ctx) { return &ctx->h_mail[82].lo;
 inline volatile uint64_t *arm_cmd(bn_ctx *ctx) { return &ctx->h_mail[84].lo; }
 inline volatile uint64_t *arm_status(bn_ctx *ctx) { return &ctx->h_mail[87].lo; }
 void arm_cancel(bn_ctx *ctx);
+// the context's side stream, ordered after everything enqueued on the main stream so far (first use since the last join)
+hipStream_t side_stream(bn_ctx *ctx);
+// launches what is queued for the side stream (bn_ctx::side_queue), in order
+int side_run_queue(bn_ctx *ctx);
+// the main stream waits for the side stream's work, queued work included (no host synchronisation)
+void side_join(bn_ctx *ctx);
+bool ranges_overlap(const void *p, uint64_t n_p, const void *q, uint64_t n_q);
+bool independent_of_pending(bn_ctx *ctx, const void *p, uint64_t n);
+// the MLE-check shadow's table: read eq[0], eq[2^k] to the host, derive the ratios rho_k, check the whole table against them
+// (one gather + one pass + two stream synchronisations); false: not a tensor expansion (or a coordinate 0 / 1)
+int shadow_check_table(bn_ctx *ctx, bool *ok);
 // two deferred folds (two-round launches): run the first one now, the second becomes the deferred one
 int flush_first_fold(bn_ctx *ctx);
 // the deferred fold `pf` folds exactly the arrays the precomputed next-round sums describe

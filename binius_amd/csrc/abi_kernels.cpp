@@ -281,6 +281,69 @@ int two_round_launch(bn_ctx *ctx, const two_round_req &rq, const bn::fin_fuse &f
 	return BN_OK;
 }
 
+// ---- weighted shadow of the MLE-check round evaluation ------------------------------------------------------------------
+// The literal BivariateMLEcheckProver (v3/bivariate_mlecheck.rs:145-254, 391-520) asks, every round, for the two sums of
+// a * b * eq over the halves of its arrays -- two chained products per point -- folds a and b, and folds its indicator table
+// by adding the halves.  The same numbers come out of the BIVARIATE kernels (matrix-core Gram sums, fold + evaluation in one
+// pass) if the backend keeps S = lambda * b (.) eq beside the caller's arrays: the indicator factorises over the variables,
+// eq_r(u, x'') = eq_{r+1}(x'') * (u ? zeta : 1 - zeta), so folding S with the round challenge and multiplying its upper half
+// by (1 - zeta) / zeta gives lambda (1 - zeta) * b' (.) eq' again (host/sumcheck.hpp WeightedMLEcheckProver does this above
+// the trait; here it happens below it, for an unchanged caller).  All the backend needs from the table are the ratios
+// rho_k = eq[2^k] / eq[0] = zeta_k / (1 - zeta_k), and the certainty that the table has that structure everywhere
+// (k_check_tensor, one pass).  Whatever the caller does that is not the expected call drops the shadow; the literal
+// kernels then answer as before.
+constexpr uint64_t kShadowMinHalf = 1ull << 9; // (smaller instances: the three-factor kernel is as good)
+
+// First evaluation of an instance: S = b (.) eq on both halves, in the shadow's own memory -- exactly the two element-wise
+// passes the routed three-factor evaluation makes anyway, so a lone evaluation costs what it cost before.  Whether the
+// table has the structure the LATER rounds rely on is only looked at when the caller's fold arrives (shadow_check_table).
+int shadow_begin(bn_ctx *ctx, const void *a_lo, const void *a_hi, const void *b_lo, const void *b_hi, const void *eq, uint64_t half)
+{
+	bn_ctx::shadow_state &sh = ctx->shadow;
+	sh.valid = false;
+	sh.fold_pending = false;
+	const uint32_t K = ilog2(half);
+	if (((uint64_t)1 << K) != half || K > 39) return BN_OK;
+	if (sh.S_cap < 2 * half) {
+		if (sh.S) {
+			BN_HIP(hipStreamSynchronize(ctx->stream));
+			(void)hipFree(sh.S);
+		}
+		sh.S = nullptr;
+		sh.S_cap = 0;
+		if (hipMalloc(&sh.S, 2 * half * sizeof(f128)) != hipSuccess) {
+			(void)hipGetLastError();
+			sh.S = nullptr;
+			return BN_OK; // (no shadow: the literal kernels answer)
+		}
+		sh.S_cap = 2 * half;
+	}
+	BN_HIP(bn::launch_mul9(ctx->stream, ctx->n_cu, b_lo, 1, eq, 1, 0, sh.S, half));
+	BN_HIP(bn::launch_mul9(ctx->stream, ctx->n_cu, b_hi, 1, eq, 1, 0, (char *)sh.S + half * sizeof(f128), half));
+	sh.a_lo = a_lo;
+	sh.a_hi = a_hi;
+	sh.b_lo = b_lo;
+	sh.b_hi = b_hi;
+	sh.half = half;
+	sh.eq = eq;
+	sh.eq_len = half;
+	sh.eq_copy_src = nullptr;
+	sh.eq_copy_dst = nullptr;
+	sh.lambda = f128{1, 0};
+	sh.checked = false;
+	sh.valid = true;
+	ctx->shadow_created++;
+	return BN_OK;
+}
+
+void shadow_drop(bn_ctx *ctx)
+{
+	side_join(ctx); // (whatever answers from now on reads the caller's arrays on the main stream)
+	if (ctx->shadow.valid) ctx->shadow_dropped++;
+	ctx->shadow.valid = false;
+	ctx->shadow.fold_pending = false;
+}
+
 // how a kernel-buffer slice is realised on the device
 struct slice_view {
 	const char *p = nullptr; // direct data
@@ -303,6 +366,61 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 	BN_REQUIRE(n_ret <= 64, "too many returned values");
 	hipStream_t s = ctx->stream;
 
+	// Element-wise adds on buffers that the deferred fold neither reads nor writes commute with it: they run now and the
+	// fold stays deferred (the MLE-check prover folds its indicator table -- add the upper half onto the lower -- between
+	// the fold of its multilinears and the next round evaluation, v3/bivariate_mlecheck.rs:195-254).
+	if (ctx->pend.active && !ctx->pend2.active && n_ret == 0 && n_ops > 0 && !ctx->tail.active) {
+		bool plain = true;
+		for (uint32_t o = 0; o < n_ops && plain; o++) {
+			const bn_kop &op = ops[o];
+			if (op.kind != BN_KOP_ADD_ASSIGN && op.kind != BN_KOP_ADD) plain = false;
+			for (const bn_kslice *sl : {&op.dst, &op.src1, &op.src2}) {
+				if (op.kind == BN_KOP_ADD_ASSIGN && sl == &op.src2) continue;
+				if (!plain) break;
+				if (sl->buf >= n_maps || maps[sl->buf].kind == BN_MAP_LOCAL || sl->off + sl->len > maps[sl->buf].len ||
+				    !independent_of_pending(ctx, (const char *)maps[sl->buf].d_data + sl->off * sizeof(f128), sl->len))
+					plain = false;
+			}
+			if (plain && maps[op.dst.buf].kind == BN_MAP_CHUNKED) plain = false; // (read-only mapping: the general path reports it)
+			if (plain && (op.src1.len != op.dst.len || (op.kind == BN_KOP_ADD && op.src2.len != op.dst.len))) plain = false;
+		}
+		if (plain) {
+			bn_ctx::shadow_state &sh = ctx->shadow;
+			for (uint32_t o = 0; o < n_ops; o++) {
+				const bn_kop &op = ops[o];
+				char *dst = (char *)maps[op.dst.buf].d_data + op.dst.off * sizeof(f128);
+				const char *s1 = (const char *)maps[op.src1.buf].d_data + op.src1.off * sizeof(f128);
+				if (sh.valid) {
+					// the one add the shadow expects: the table's upper half onto its lower half (in place, or onto the copy of
+					// the lower half made since the last fold); any other write into the table ends the shadow
+					const bool onto_table = (const void *)dst == sh.eq || ((const void *)dst == sh.eq_copy_dst && sh.eq_copy_src == sh.eq);
+					BN_SHDBG("independent add: dst %p len %llu src %p | eq %p len %llu copy %p->%p", (void *)dst, (unsigned long long)op.dst.len, (const void *)s1, sh.eq,
+					         (unsigned long long)sh.eq_len, sh.eq_copy_src, sh.eq_copy_dst);
+					if (op.kind == BN_KOP_ADD_ASSIGN && n_ops == 1 && onto_table && 2 * op.dst.len == sh.eq_len &&
+					    (const void *)s1 == (const char *)sh.eq + op.dst.len * sizeof(f128)) {
+						sh.eq = dst;
+						sh.eq_len = op.dst.len;
+						sh.eq_copy_src = nullptr;
+						sh.eq_copy_dst = nullptr;
+					} else if (ranges_overlap(dst, op.dst.len, sh.eq, sh.eq_len)) {
+						shadow_drop(ctx);
+					}
+				}
+				// (with a shadow alive these adds are its caller's table folds: nothing on the main stream reads the table, so they
+				// run beside the sumcheck's kernels instead of between them)
+				const char *s2 = op.kind == BN_KOP_ADD ? (const char *)maps[op.src2.buf].d_data + op.src2.off * sizeof(f128) : nullptr;
+				if (sh.valid) {
+					ctx->side_queue.push_back({op.kind == BN_KOP_ADD ? bn_ctx::side_op::ADD : bn_ctx::side_op::ADD_ASSIGN, dst, s1, s2, op.dst.len, f128{0, 0}});
+				} else if (op.kind == BN_KOP_ADD_ASSIGN) {
+					BN_HIP(bn::launch_add_assign(s, dst, s1, op.dst.len));
+				} else {
+					BN_HIP(bn::launch_add(s, dst, s1, s2, op.dst.len));
+				}
+			}
+			return BN_OK;
+		}
+	}
+
 	// A deferred fold survives into this launch only if the kernel has the calculate_round_evals
 	// shape (two bivariate-product sums, Local "lo + hi" operands, nothing written to memory); the
 	// launch site below then checks that it reads exactly the folded arrays.
@@ -314,7 +432,9 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 			const bn_kop &op = ops[o];
 			if (op.kind == BN_KOP_SUM_COMPOSITION) {
 				n_sum++;
-				if (!op.expr || op.expr->shape != bn_expr::PRODUCT || op.expr->product_vars.size() != 2) pure = false;
+				if (!op.expr || op.expr->shape != bn_expr::PRODUCT ||
+				    !(op.expr->product_vars.size() == 2 || (op.expr->product_vars.size() == 3 && ctx->shadow.valid && ctx->shadow.fold_pending)))
+					pure = false;
 			} else if (op.kind == BN_KOP_ADD) {
 				if (op.dst.buf >= n_maps || maps[op.dst.buf].kind != BN_MAP_LOCAL) pure = false;
 			} else if (op.kind != BN_KOP_DECL_VALUE) {
@@ -416,6 +536,16 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 	std::vector<bn::fin_term> terms;
 	uint32_t n_slots = 0;
 	bool finalized_in_kernel = false;
+	// the MLE-check shadow returns lambda times the caller's sums from the kernel: divided out here, on the host
+	bool out_scaled = false;
+	f128 out_mul{1, 0};
+	auto scale_out = [&]() {
+		if (!out_scaled || !h_out) return;
+		for (uint32_t r = 0; r < n_ret; r++) {
+			const f128 v = bn::mul_host(f128{h_out[r].lo, h_out[r].hi}, out_mul);
+			h_out[r] = bn_f128{v.lo, v.hi};
+		}
+	};
 	uint64_t fused_seq = 0;
 	f128 *d_S = ctx->d_result;         // [0,64)
 	f128 *d_rets = ctx->d_result + 96;  // [96,128)
@@ -478,7 +608,7 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 				// fused pairing: if the NEXT sum op uses the same expression and its factors are the
 				// "infinity" versions (Local = lo + hi with hi == this op's row) of this op's factors,
 				// do both with one pass over the data.
-				const uint32_t k = (uint32_t)op.expr->product_vars.size();
+				uint32_t k = (uint32_t)op.expr->product_vars.size(); // (the MLE-check shadow rewrites a three-factor request into a bivariate one)
 				const void *hi[4] = {nullptr, nullptr, nullptr, nullptr}, *lo[4] = {nullptr, nullptr, nullptr, nullptr};
 				bool direct = true;
 				std::vector<slice_view> fv(k);
@@ -572,6 +702,75 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 									fz.peer.round = ++ctx->peer.round;
 								}
 								hipError_t fe = hipErrorNotSupported;
+								// ---- MLE-check shape a * b * eq (one factor the same at both points): the weighted shadow
+								if (k == 3 && ctx->shadow_enabled && h_out && !d_out && !peer_on && ctx->lazy_fold) {
+									int same = -1, n_same = 0;
+									for (int j = 0; j < 3; j++)
+										if (!lo[j]) {
+											same = j;
+											n_same++;
+										}
+									bn_ctx::shadow_state &sh = ctx->shadow;
+									if (n_same == 1) {
+										int x = (same + 1) % 3, y = (same + 2) % 3;
+										auto is = [&](int xa, int yb) { return hi[xa] == sh.a_hi && lo[xa] == sh.a_lo && hi[yb] == sh.b_hi && lo[yb] == sh.b_lo; };
+										bool use = sh.valid && row_len == sh.half && sh.eq_len == row_len && hi[same] == sh.eq && (is(x, y) || is(y, x));
+										if (use && !is(x, y)) std::swap(x, y);
+										if (use && sh.fold_pending != ctx->pend.active) use = false; // (the deferred fold must be the one the shadow folds with)
+										bool zero_init = true; // (lambda is divided out of the RETURNED values: they must be pure sums)
+										for (uint32_t v = 0; v < n_values; v++) zero_init = zero_init && h_values[v] == f128{0, 0};
+										if (!zero_init) use = false;
+										BN_SHDBG("eval: rows=%llu valid=%d half=%llu eq_len=%llu eq %p/%p fp=%d pend=%d use=%d", (unsigned long long)row_len, (int)sh.valid,
+										         (unsigned long long)sh.half, (unsigned long long)sh.eq_len, hi[same], sh.eq, (int)sh.fold_pending, (int)ctx->pend.active, (int)use);
+										if (!use) {
+											if (ctx->pend.active) BN_FLUSH(ctx); // a fold the shadow is not party to runs first (and ends the shadow)
+											shadow_drop(ctx);
+											if (zero_init && row_len >= kShadowMinHalf && row_len >= sh.blocked_below && hi[x] != hi[y]) {
+												sh.blocked_below = 0;
+												rc = shadow_begin(ctx, lo[x], hi[x], lo[y], hi[y], hi[same], row_len);
+												if (rc) return rc;
+												use = sh.valid;
+											}
+										}
+										if (use) {
+											// The request becomes the bivariate round of (a, S) and takes the ordinary path below (matrix-core /
+											// 9-lane kernels, fold + evaluation in one pass, armed small rounds); lambda is divided out of the two
+											// returned values on the host, so that the finalize recipe is the caller's own in every round.
+											out_scaled = true;
+											out_mul = bn::invert_tower(sh.fold_pending ? sh.lambda_next : sh.lambda);
+											if (sh.fold_pending) {
+												// the caller's deferred fold of (a, b): b folds now, in a launch of its own on the side stream (nothing of
+												// the sumcheck reads it again before the caller does); the deferred fold becomes that of (a, S), with the
+												// upper half of S levelled by (1 - zeta) / zeta
+												bn_ctx::pending_fold &pf = ctx->pend;
+												// (queued: launched once this round's kernel has its challenge, while the host would only spin)
+												if (pf.src0[sh.ib] != pf.x0[sh.ib])
+													ctx->side_queue.push_back({bn_ctx::side_op::COPY, pf.x0[sh.ib], pf.src0[sh.ib], nullptr, pf.n, f128{0, 0}});
+												ctx->side_queue.push_back({bn_ctx::side_op::FOLD, pf.x0[sh.ib], pf.x1[sh.ib], nullptr, pf.n, pf.z});
+												bn_ctx::pending_fold q = pf;
+												q.x0[0] = pf.x0[sh.ia];
+												q.x1[0] = pf.x1[sh.ia];
+												q.src0[0] = pf.src0[sh.ia];
+												q.x0[1] = sh.S;
+												q.x1[1] = (const char *)sh.S + pf.n * sizeof(f128);
+												q.src0[1] = sh.S;
+												q.scale_mask = 2;
+												q.hi_scale = sh.hi_scale;
+												pf = q;
+												sh.fold_pending = false;
+												sh.lambda = sh.lambda_next;
+											}
+											const void *ah = hi[x], *al = lo[x];
+											hi[0] = ah;
+											lo[0] = al;
+											hi[1] = (const char *)sh.S + row_len * sizeof(f128);
+											lo[1] = sh.S;
+											hi[2] = lo[2] = nullptr;
+											k = 2;
+											ctx->shadow_rounds++;
+										}
+									}
+								}
 								if (ctx->pend.active) {
 									// fold + evaluate in one pass: this launch reads the halves of exactly the two
 									// arrays the deferred fold writes (evals_1 directly behind evals_0, in place)
@@ -752,6 +951,8 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 												const auto t_go = std::chrono::steady_clock::now();
 												arm_next(fa, n_in, fz); // the round after this one queues up while this one runs
 												const auto t_armed = std::chrono::steady_clock::now();
+												rc = side_run_queue(ctx); // (and so does the side work of a shadowed MLE-check)
+												if (rc) return rc;
 												volatile uint64_t *seqw = &ctx->h_mail[64].lo;
 												bool got = false;
 												for (uint64_t spins = 0;; spins++) {
@@ -790,6 +991,7 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 													ctx->arm_ns_launch += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t_armed - t_go).count();
 													ctx->arm_ns_parse += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t_go - t_enter).count();
 													ctx->arm_ns_wait += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_go).count();
+													scale_out();
 													return BN_OK;
 												}
 												// it left without running the round: the one queued behind it must leave too, then
@@ -836,6 +1038,7 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 													tl.n_in_next = n_in >> 1;
 													if (n_in <= 4) tl.active = false; // it has just run its last round and exits
 													ctx->s_clean = true;
+													scale_out();
 													return BN_OK;
 												}
 												tl.active = false; // gone without doing this round: run it the normal way
@@ -884,7 +1087,7 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 								// round 0 of a small sumcheck, nothing to fold: the two-round kernel on the inputs themselves -- when the
 								// number of variables is even, so that the chain of two-round launches ends on four elements (with an
 								// odd number this round runs alone and the chain starts with the first fold)
-								if (fe == hipErrorNotSupported && !ctx->pend.active && k == 2 && lo[0] && lo[1] && lo[0] != lo[1] && ctx->two_round && ctx->lazy_fold && h_out && !d_out &&
+								if (fe == hipErrorNotSupported && !out_scaled && !ctx->pend.active && k == 2 && lo[0] && lo[1] && lo[0] != lo[1] && ctx->two_round && ctx->lazy_fold && h_out && !d_out &&
 								    !ctx->tail_max_n_in && two_round_recipe_ok(fz.args) && two_round_size_ok(2 * row_len) && (ilog2(2 * row_len) & 1) == 0) {
 									two_round_req rq{};
 									for (uint32_t j = 0; j < 2; j++) {
@@ -983,7 +1186,7 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 		}
 	}
 
-	rc = flush_pending(ctx, /*keep_tail=*/true); // (a launch that ended up reading nothing)
+	rc = flush_pending(ctx, /*keep_tail=*/true, /*publish_tiny=*/false, /*keep_shadow=*/true); // (a launch that ended up reading nothing)
 	if (rc) return rc;
 	if (n_ret == 0) {
 		if (n_slots == 0) ctx->s_clean = was_clean_or_zeroed; // no accumulator was touched by this launch
@@ -1021,6 +1224,8 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 		BN_HIP(bn::launch_finalize(s, fa, d_S, rets, ctx->d_mail, &pr));
 	}
 	ctx->s_clean = true; // stream-ordered: the next launch on this stream sees zeroed slots
+	rc = side_run_queue(ctx); // (side work of a shadowed MLE-check: launched while the host would only wait for the result)
+	if (rc) return rc;
 	if (h_out) {
 		// spin on the sequence word the kernel publishes after the values (fine-grained host memory)
 		volatile uint64_t *seqw = &ctx->h_mail[64].lo;
@@ -1045,6 +1250,7 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 			h_out[r].lo = __atomic_load_n(&ctx->h_mail[r].lo, __ATOMIC_RELAXED);
 			h_out[r].hi = __atomic_load_n(&ctx->h_mail[r].hi, __ATOMIC_RELAXED);
 		}
+		scale_out();
 	}
 	return BN_OK;
 }

@@ -79,6 +79,46 @@ struct bn_ctx {
 		bn::f128 P0{0, 0}, P1v{0, 0}, P2{0, 0}, Q0{0, 0}, Q1v{0, 0}, Q2{0, 0}; // coefficient applied; P1v = P(1), Q1v = Q(1)
 		std::vector<unsigned char> recipe;   // of the caller's two-sum request
 	} pre;
+	// Weighted shadow of the MLE-check round evaluation (abi_kernels.cpp "shadow"): the literal call sequence of
+	// BivariateMLEcheckProver asks for sum a * b * eq every round; the backend keeps S = lambda * b (.) eq beside the caller's
+	// arrays and answers from the bivariate kernels on (a, S).
+	struct shadow_state {
+		bool valid = false;
+		const void *a_lo = nullptr, *a_hi = nullptr; // the halves the NEXT evaluation will pass for the plain factor ...
+		const void *b_lo = nullptr, *b_hi = nullptr; // ... and for the factor whose weighted copy S is kept
+		uint64_t half = 0;                           // elements per half (= rows of the next evaluation)
+		const void *eq = nullptr;                    // the table the next evaluation will pass, eq_len entries
+		uint64_t eq_len = 0;
+		const void *eq_copy_src = nullptr;           // a copy_d2d of the table's lower half seen since the last fold: src -> dst
+		void *eq_copy_dst = nullptr;
+		void *S = nullptr;                           // 2 * half elements (lower | upper half), own allocation
+		uint64_t S_cap = 0;                          // elements allocated
+		bn::f128 lambda{1, 0};                       // S = lambda * b (.) eq on both halves
+		std::vector<bn::f128> rho_inv, one_minus_zeta; // per variable k of the ORIGINAL table (bit k of its index)
+		bool checked = false;                        // the table's tensor structure has been verified and the ratios derived
+		uint64_t blocked_below = 0;                  // a table failed the check at this many rows: no new shadow for the smaller rounds of that instance
+		bool fold_pending = false;                   // the caller's fold of (a, b) is deferred in pend; S folds with it
+		bn::f128 z{0, 0}, hi_scale{0, 0}, lambda_next{1, 0};
+		uint32_t ia = 0, ib = 1;                     // which array of the pending batch is a / b
+	} shadow;
+	// side stream: work of a shadowed MLE-check that nothing on the main stream depends on (the fold of b, the folds of the
+	// indicator table) runs beside the sumcheck's kernels; every flush joins it back (abi.cpp side_stream / side_join)
+	hipStream_t side = nullptr;
+	hipEvent_t side_ev = nullptr, main_ev = nullptr;
+	bool side_busy = false;
+	// side work that has been asked for but not launched yet: a launch costs the host ~3 us, so it is issued while the host
+	// would otherwise spin on the round's result (right after the round's kernel has been launched or signalled), in order
+	struct side_op {
+		enum { COPY, ADD_ASSIGN, ADD, FOLD } kind;
+		void *dst;
+		const void *src, *src2;
+		uint64_t n;
+		bn::f128 z;
+	};
+	std::vector<side_op> side_queue;
+	unsigned *d_flag = nullptr;  // one word of device memory for yes/no answers of checking kernels
+	bool shadow_enabled = true;  // BN_MLECHECK_SHADOW=0 turns the shadow off
+	uint64_t shadow_created = 0, shadow_rounds = 0, shadow_dropped = 0;
 	bool two_round = true;       // BN_TWO_ROUND=0 turns the two-round launches off
 	uint64_t two_round_hosted = 0, two_round_launches = 0; // rounds answered by the host from the sums / launches of the kernel
 	// deferred copy_d2d (the "allocate a new buffer for the folded evaluations and copy in evals_0"
@@ -325,6 +365,14 @@ hipError_t launch_compute_composite_generic(hipStream_t s, const void *const *d_
 hipError_t launch_fri_fold(hipStream_t s, const uint64_t *d_s_evals, uint32_t tw_level, uint32_t log_domain,
                            uint32_t log_len, uint32_t log_batch, const f128 *h_challenges, uint32_t n_challenges,
                            const void *in, void *out, uint64_t out_len, void *scratch);
+
+// is eq[0 .. n) a tensor expansion up to a constant: eq[i] == eq[i - 2^k] * rho[k] (k = top bit of i)?  *d_flag |= 1 if not
+struct tensor_check_args {
+	f128 rho[40];
+	uint32_t first_wg[41];
+	uint32_t n_log;
+};
+hipError_t launch_check_tensor(hipStream_t s, const void *eq, uint64_t n, const f128 *rho, uint32_t n_log, unsigned *d_flag);
 
 // ---- kernels_ntt.hip
 hipError_t launch_ntt(hipStream_t s, bool inverse, void *data, uint32_t elem_level, uint32_t tw_level,

@@ -507,4 +507,57 @@ hipError_t launch_fri_fold(hipStream_t s, const uint64_t *d_s_evals, uint32_t tw
 	return hipSuccess;
 }
 
+// ---- is a table the tensor expansion of some coordinates (up to a constant)? -----------------------------------------
+// eq[i] == eq[i - 2^k] * rho_k for every i in [1, n), k = the top bit of i, rho_k = eq[2^k] / eq[0] (host).  One pass over
+// the table: workgroups are dealt to the ranges [2^k, 2^(k+1)) (a.first_wg), each builds the nibble table of its rho_k;
+// indices below 256 are checked by workgroup 0 with the generic product.  Any mismatch sets *flag.  Used once per MLE-check
+// by the weighted shadow of abi_kernels.cpp (the literal BivariateMLEcheckProver call sequence, v3/bivariate_mlecheck.rs).
+__global__ __launch_bounds__(256) void k_check_tensor(const uint4 *eq, uint64_t n, tensor_check_args a, unsigned *flag)
+{
+	__shared__ ctable_smem tab;
+	unsigned k = 8;
+	while (k + 1 < a.n_log && blockIdx.x >= a.first_wg[k + 1]) k++;
+	const bool ranged = a.n_log > 8 && blockIdx.x >= a.first_wg[8];
+	const unsigned kk = k < 40 ? k : 39;
+	ctable_build(tab, a.rho[kk]);
+	bool bad = false;
+	if (ranged) {
+		const uint64_t lo = (uint64_t)1 << k, hi = lo << 1;
+		const uint64_t part = blockIdx.x - a.first_wg[k], n_wg = a.first_wg[k + 1] - a.first_wg[k];
+		for (uint64_t i = lo + part * 256 + threadIdx.x; i < hi && i < n; i += n_wg * 256) {
+			const uint4 want = ctable_mul(tab, eq[i - lo]), got = eq[i];
+			bad = bad || want.x != got.x || want.y != got.y || want.z != got.z || want.w != got.w;
+		}
+	}
+	if (blockIdx.x == 0) { // the first 256 entries: k = 0 .. 7
+		const uint64_t i = threadIdx.x;
+		if (i >= 1 && i < n) {
+			unsigned kt = 31 - __clz((unsigned)i);
+			const f128 want = mul_slow(to_f128(eq[i - ((uint64_t)1 << kt)]), a.rho[kt]);
+			const f128 got = to_f128(eq[i]);
+			bad = bad || !(want == got);
+		}
+	}
+	if (bad) atomicOr(flag, 1u);
+}
+
+hipError_t launch_check_tensor(hipStream_t s, const void *eq, uint64_t n, const f128 *rho, uint32_t n_log, unsigned *d_flag)
+{
+	if (n_log > 40) return hipErrorNotSupported;
+	tensor_check_args a{};
+	for (uint32_t k = 0; k < n_log; k++) a.rho[k] = rho[k];
+	a.n_log = n_log;
+	uint32_t wg = 0;
+	for (uint32_t k = 0; k <= 40; k++) {
+		a.first_wg[k] = wg;
+		if (k >= 8 && k < n_log) {
+			uint64_t w = ((uint64_t)1 << k) / 2048;
+			wg += (uint32_t)(w < 1 ? 1 : (w > 128 ? 128 : w));
+		}
+	}
+	if (wg == 0) wg = 1; // tables of at most 256 entries: workgroup 0 alone
+	hipLaunchKernelGGL(k_check_tensor, dim3(wg), dim3(256), 0, s, (const uint4 *)eq, n, a, d_flag);
+	return hipGetLastError();
+}
+
 } // namespace bn
