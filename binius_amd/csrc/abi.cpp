@@ -75,52 +75,96 @@ void arm_cancel(bn_ctx *ctx)
 	__atomic_store_n(arm_cmd(ctx), (ctx->arm.id << 2) | 2ull, __ATOMIC_RELEASE);
 }
 
+// Pinned staging of the shadow's table check (the context's gather buffer, 64 KiB): offsets of eq[0], eq[2^k] | the gathered
+// entries | at +16384 the ratios and the workgroup layout of the check kernel.
+static int shadow_staging(bn_ctx *ctx)
+{
+	if (ctx->gather_bytes >= (1 << 16)) return BN_OK;
+	BN_HIP(hipStreamSynchronize(ctx->stream));
+	if (ctx->h_gather) hipHostFree(ctx->h_gather);
+	ctx->h_gather = nullptr;
+	ctx->gather_bytes = 0;
+	if (hipHostMalloc(&ctx->h_gather, 1 << 16, hipHostMallocMapped) != hipSuccess) {
+		(void)hipGetLastError();
+		return BN_ERR_ALLOC;
+	}
+	BN_HIP(hipHostGetDevicePointer(&ctx->d_gather, ctx->h_gather, 0));
+	ctx->gather_bytes = 1 << 16;
+	return BN_OK;
+}
+
+// The shadow's table, looked at when the caller's first fold arrives (a lone evaluation never pays for it): the entries
+// eq[0], eq[2^k] come to the host (one gather, one synchronisation), the ratios rho_k = eq[2^k] / eq[0] = zeta_k / (1 - zeta_k)
+// are formed, and ONE pass checks eq[i] == eq[i - 2^k] * rho_k for every entry.  Run on the main stream, in line: a version
+// that started the check beside the first round's kernels (side stream) hid the synchronisations but slowed those VALU-bound
+// kernels by about what the check costs, the lone evaluation included (0.55 -> 0.76 ms at 2^24).
 int shadow_check_table(bn_ctx *ctx, bool *ok)
 {
 	bn_ctx::shadow_state &sh = ctx->shadow;
 	*ok = false;
 	const uint64_t half = sh.eq_len;
 	const uint32_t K = ilog2(half);
-	// ---- table entries 0, 2^0 .. 2^(K-1)
-	const uint64_t n_items = K + 1;
-	const size_t off_bytes = ((size_t)n_items * 8 + 15) & ~(size_t)15, need = off_bytes + n_items * sizeof(f128);
-	if (need > ctx->gather_bytes) {
-		BN_HIP(hipStreamSynchronize(ctx->stream));
-		if (ctx->h_gather) hipHostFree(ctx->h_gather);
-		ctx->h_gather = nullptr;
-		ctx->gather_bytes = 0;
-		if (hipHostMalloc(&ctx->h_gather, 1 << 16, hipHostMallocMapped) != hipSuccess) {
-			(void)hipGetLastError();
-			return BN_OK;
-		}
-		BN_HIP(hipHostGetDevicePointer(&ctx->d_gather, ctx->h_gather, 0));
-		ctx->gather_bytes = 1 << 16;
-	}
+	// gathered: eq[0], eq[2^0] .. eq[2^(K-1)], then the first min(256, half) entries (checked here, on the host)
+	const uint64_t n_head = half < 256 ? half : 256;
+	const uint64_t n_items = K + 1 + n_head;
+	const size_t off_bytes = ((size_t)n_items * 8 + 15) & ~(size_t)15;
+	if (shadow_staging(ctx) != BN_OK || off_bytes + n_items * sizeof(f128) > 16384) return BN_OK;
 	uint64_t *offs = (uint64_t *)ctx->h_gather;
 	offs[0] = 0;
 	for (uint32_t k = 0; k < K; k++) offs[k + 1] = (uint64_t)1 << k;
+	for (uint64_t i = 0; i < n_head; i++) offs[K + 1 + i] = i;
 	BN_HIP(bn::launch_gather(ctx->stream, sh.eq, (const uint64_t *)ctx->d_gather, n_items, 1, (char *)ctx->d_gather + off_bytes));
 	BN_HIP(hipStreamSynchronize(ctx->stream));
+	// ---- what the rounds need are 1 / rho_k = eq[0] / eq[2^k] and 1 - zeta_k = 1 / (1 + rho_k) = eq[0] / (eq[0] + eq[2^k]), what
+	// the check needs is rho_k = eq[2^k] / eq[0]: 2 K + 1 inverses, taken with ONE inversion (Montgomery's trick)
 	const f128 *got = (const f128 *)((const char *)ctx->h_gather + off_bytes);
 	const f128 e0 = got[0];
 	if (e0 == f128{0, 0}) return BN_OK;
-	const f128 e0_inv = bn::invert_tower(e0);
-	std::vector<f128> rho(K);
+	const uint32_t N = 2 * K + 1;
+	std::vector<f128> v(N), pre(N + 1), vinv(N);
+	pre[0] = f128{1, 0};
+	for (uint32_t k = 0; k < K; k++) {
+		v[2 * k] = got[k + 1];
+		v[2 * k + 1] = got[k + 1] ^ e0;
+		if (v[2 * k] == f128{0, 0} || v[2 * k + 1] == f128{0, 0}) return BN_OK; // a coordinate 0 or 1: no weighting possible
+	}
+	v[2 * K] = e0;
+	for (uint32_t j = 0; j < N; j++) pre[j + 1] = bn::mul_host(pre[j], v[j]);
+	f128 inv = bn::invert_tower(pre[N]);
+	for (uint32_t j = N; j-- > 0;) {
+		vinv[j] = bn::mul_host(inv, pre[j]);
+		inv = bn::mul_host(inv, v[j]);
+	}
 	sh.rho_inv.assign(K, f128{0, 0});
 	sh.one_minus_zeta.assign(K, f128{0, 0});
+	f128 *h_rho = (f128 *)((char *)ctx->h_gather + 16384);
 	for (uint32_t k = 0; k < K; k++) {
-		rho[k] = bn::mul_host(got[k + 1], e0_inv);
-		const f128 one_plus = rho[k] ^ f128{1, 0};
-		if (rho[k] == f128{0, 0} || one_plus == f128{0, 0}) return BN_OK; // a coordinate 0 or 1: no weighting possible
-		sh.rho_inv[k] = bn::invert_tower(rho[k]);
-		sh.one_minus_zeta[k] = bn::invert_tower(one_plus); // zeta = rho (1 - zeta)  =>  1 - zeta = 1 / (1 + rho)
+		sh.rho_inv[k] = bn::mul_host(e0, vinv[2 * k]);
+		sh.one_minus_zeta[k] = bn::mul_host(e0, vinv[2 * k + 1]);
+		h_rho[k] = bn::mul_host(got[k + 1], vinv[2 * K]);
 	}
-	// ---- the whole table has the structure the ratios describe
-	BN_HIP(hipMemsetAsync(ctx->d_flag, 0, sizeof(unsigned), ctx->stream));
-	BN_HIP(bn::launch_check_tensor(ctx->stream, sh.eq, half, rho.data(), K, ctx->d_flag));
+	// the head of the table (top bit k < 8) on the host; the kernel below takes every entry from 256 on
+	const f128 *head = got + K + 1;
+	for (uint64_t i = 1; i < n_head; i++) {
+		unsigned kt = 0;
+		while ((i >> (kt + 1)) != 0) kt++;
+		if (!(bn::mul_host(head[i - ((uint64_t)1 << kt)], h_rho[kt]) == head[i])) return BN_OK;
+	}
+	// ---- the whole table has the structure the ratios describe (*d_flag is zero between checks: only a failing check writes
+	// it, and is followed by the reset below; ratios and workgroup layout travel through the pinned staging)
+	if (K <= 8) { // the whole table was the head
+		*ok = true;
+		sh.checked = true;
+		return BN_OK;
+	}
+	uint32_t *h_fw = (uint32_t *)((char *)ctx->h_gather + 16384 + 40 * sizeof(f128));
+	const uint32_t n_wg = bn::check_tensor_layout(K, h_fw);
+	BN_HIP(bn::launch_check_tensor(ctx->stream, sh.eq, half, (const f128 *)((char *)ctx->d_gather + 16384),
+	                               (const uint32_t *)((char *)ctx->d_gather + 16384 + 40 * sizeof(f128)), n_wg, K, ctx->d_flag));
 	unsigned flag = 1;
 	BN_HIP(hipMemcpyAsync(&flag, ctx->d_flag, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
 	BN_HIP(hipStreamSynchronize(ctx->stream));
+	if (flag) BN_HIP(hipMemsetAsync(ctx->d_flag, 0, sizeof(unsigned), ctx->stream));
 	*ok = flag == 0;
 	sh.checked = *ok;
 	return BN_OK;

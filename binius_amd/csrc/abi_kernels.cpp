@@ -318,8 +318,6 @@ int shadow_begin(bn_ctx *ctx, const void *a_lo, const void *a_hi, const void *b_
 		}
 		sh.S_cap = 2 * half;
 	}
-	BN_HIP(bn::launch_mul9(ctx->stream, ctx->n_cu, b_lo, 1, eq, 1, 0, sh.S, half));
-	BN_HIP(bn::launch_mul9(ctx->stream, ctx->n_cu, b_hi, 1, eq, 1, 0, (char *)sh.S + half * sizeof(f128), half));
 	sh.a_lo = a_lo;
 	sh.a_hi = a_hi;
 	sh.b_lo = b_lo;
@@ -331,6 +329,9 @@ int shadow_begin(bn_ctx *ctx, const void *a_lo, const void *a_hi, const void *b_
 	sh.eq_copy_dst = nullptr;
 	sh.lambda = f128{1, 0};
 	sh.checked = false;
+	// (whether the table has the structure the later rounds rely on is looked at when the caller's first fold arrives)
+	BN_HIP(bn::launch_mul9(ctx->stream, ctx->n_cu, b_lo, 1, eq, 1, 0, sh.S, half));
+	BN_HIP(bn::launch_mul9(ctx->stream, ctx->n_cu, b_hi, 1, eq, 1, 0, (char *)sh.S + half * sizeof(f128), half));
 	sh.valid = true;
 	ctx->shadow_created++;
 	return BN_OK;

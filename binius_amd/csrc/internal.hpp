@@ -366,13 +366,11 @@ hipError_t launch_fri_fold(hipStream_t s, const uint64_t *d_s_evals, uint32_t tw
                            uint32_t log_len, uint32_t log_batch, const f128 *h_challenges, uint32_t n_challenges,
                            const void *in, void *out, uint64_t out_len, void *scratch);
 
-// is eq[0 .. n) a tensor expansion up to a constant: eq[i] == eq[i - 2^k] * rho[k] (k = top bit of i)?  *d_flag |= 1 if not
-struct tensor_check_args {
-	f128 rho[40];
-	uint32_t first_wg[41];
-	uint32_t n_log;
-};
-hipError_t launch_check_tensor(hipStream_t s, const void *eq, uint64_t n, const f128 *rho, uint32_t n_log, unsigned *d_flag);
+// is eq[0 .. n) a tensor expansion up to a constant: eq[i] == eq[i - 2^k] * rho[k] (k = top bit of i)?  *d_flag |= 1 if not.
+// d_rho[n_log] and d_first_wg[42] (from check_tensor_layout, which returns the grid size) are read by the kernel from memory.
+uint32_t check_tensor_layout(uint32_t n_log, uint32_t *first_wg);
+hipError_t launch_check_tensor(hipStream_t s, const void *eq, uint64_t n, const f128 *d_rho, const uint32_t *d_first_wg, uint32_t n_wg, uint32_t n_log,
+                               unsigned *d_flag);
 
 // ---- kernels_ntt.hip
 hipError_t launch_ntt(hipStream_t s, bool inverse, void *data, uint32_t elem_level, uint32_t tw_level,

@@ -512,51 +512,71 @@ hipError_t launch_fri_fold(hipStream_t s, const uint64_t *d_s_evals, uint32_t tw
 // the table: workgroups are dealt to the ranges [2^k, 2^(k+1)) (a.first_wg), each builds the nibble table of its rho_k;
 // indices below 256 are checked by workgroup 0 with the generic product.  Any mismatch sets *flag.  Used once per MLE-check
 // by the weighted shadow of abi_kernels.cpp (the literal BivariateMLEcheckProver call sequence, v3/bivariate_mlecheck.rs).
-__global__ __launch_bounds__(256) void k_check_tensor(const uint4 *eq, uint64_t n, tensor_check_args a, unsigned *flag)
+// rho[k] = eq[2^k] / eq[0] (host) and the workgroup layout are read from memory (indexing a by-value argument array with a
+// run-time index makes every thread copy the array to scratch).  Four entries in
+// flight per lane: one at a time the loop is a chain of HBM
+// round trips.  (169 registers: three workgroups per CU.)
+__global__ __launch_bounds__(256, 2) void k_check_tensor(const uint4 *eq, uint64_t n, const f128 *rho, const uint32_t *first_wg, uint32_t n_log, unsigned *flag)
 {
 	__shared__ ctable_smem tab;
-	unsigned k = 8;
-	while (k + 1 < a.n_log && blockIdx.x >= a.first_wg[k + 1]) k++;
-	const bool ranged = a.n_log > 8 && blockIdx.x >= a.first_wg[8];
-	const unsigned kk = k < 40 ? k : 39;
-	ctable_build(tab, a.rho[kk]);
+	__shared__ uint32_t s_k, s_first, s_next;
+	if (threadIdx.x == 0) {
+		unsigned k = 8;
+		while (k + 1 < n_log && blockIdx.x >= first_wg[k + 1]) k++;
+		s_k = k;
+		s_first = first_wg[k];
+		s_next = first_wg[k + 1];
+	}
+	__syncthreads();
+	const unsigned k = s_k;
+	const bool ranged = n_log > 8;
+	ctable_build(tab, rho[k < n_log ? k : 0]);
 	bool bad = false;
 	if (ranged) {
 		const uint64_t lo = (uint64_t)1 << k, hi = lo << 1;
-		const uint64_t part = blockIdx.x - a.first_wg[k], n_wg = a.first_wg[k + 1] - a.first_wg[k];
-		for (uint64_t i = lo + part * 256 + threadIdx.x; i < hi && i < n; i += n_wg * 256) {
-			const uint4 want = ctable_mul(tab, eq[i - lo]), got = eq[i];
-			bad = bad || want.x != got.x || want.y != got.y || want.z != got.z || want.w != got.w;
+		const uint64_t part = blockIdx.x - s_first, n_wg = s_next - s_first;
+		for (uint64_t i0 = lo + part * 1024 + threadIdx.x; i0 < hi && i0 < n; i0 += n_wg * 1024) {
+			uint4 p[4], g[4];
+#pragma unroll
+			for (int j = 0; j < 4; j++) {
+				const uint64_t i = i0 + 256 * j;
+				const bool in = i < hi && i < n;
+				p[j] = in ? eq[i - lo] : uint4{0, 0, 0, 0};
+				g[j] = in ? eq[i] : uint4{0, 0, 0, 0};
+			}
+#pragma unroll
+			for (int j = 0; j < 4; j++) {
+				const uint4 want = ctable_mul<8>(tab, p[j]);
+				bad = bad || want.x != g[j].x || want.y != g[j].y || want.z != g[j].z || want.w != g[j].w;
+				__builtin_amdgcn_sched_barrier(0);
+			}
 		}
 	}
-	if (blockIdx.x == 0) { // the first 256 entries: k = 0 .. 7
-		const uint64_t i = threadIdx.x;
-		if (i >= 1 && i < n) {
-			unsigned kt = 31 - __clz((unsigned)i);
-			const f128 want = mul_slow(to_f128(eq[i - ((uint64_t)1 << kt)]), a.rho[kt]);
-			const f128 got = to_f128(eq[i]);
-			bad = bad || !(want == got);
-		}
-	}
+	// (the first 256 entries, k = 0 .. 7, are checked by the caller on the host: the generic product they would need here
+	// costs the whole kernel its occupancy -- 288 registers, one wave per SIMD, 130 - 180 us for 2^23 entries)
 	if (bad) atomicOr(flag, 1u);
 }
 
-hipError_t launch_check_tensor(hipStream_t s, const void *eq, uint64_t n, const f128 *rho, uint32_t n_log, unsigned *d_flag)
+// d_rho[n_log], d_first_wg[42]: device-visible copies of the ratios and of the workgroup prefix built by check_tensor_layout
+uint32_t check_tensor_layout(uint32_t n_log, uint32_t *first_wg /*[42]*/)
 {
-	if (n_log > 40) return hipErrorNotSupported;
-	tensor_check_args a{};
-	for (uint32_t k = 0; k < n_log; k++) a.rho[k] = rho[k];
-	a.n_log = n_log;
 	uint32_t wg = 0;
-	for (uint32_t k = 0; k <= 40; k++) {
-		a.first_wg[k] = wg;
+	for (uint32_t k = 0; k <= 41; k++) {
+		first_wg[k] = wg;
 		if (k >= 8 && k < n_log) {
-			uint64_t w = ((uint64_t)1 << k) / 2048;
-			wg += (uint32_t)(w < 1 ? 1 : (w > 128 ? 128 : w));
+			// a workgroup per 1024 elements, at most 1024 per range
+			uint64_t w = ((uint64_t)1 << k) / 1024;
+			wg += (uint32_t)(w < 1 ? 1 : (w > 1024 ? 1024 : w));
 		}
 	}
-	if (wg == 0) wg = 1; // tables of at most 256 entries: workgroup 0 alone
-	hipLaunchKernelGGL(k_check_tensor, dim3(wg), dim3(256), 0, s, (const uint4 *)eq, n, a, d_flag);
+	return wg ? wg : 1; // tables of at most 256 entries: workgroup 0 alone
+}
+
+hipError_t launch_check_tensor(hipStream_t s, const void *eq, uint64_t n, const f128 *d_rho, const uint32_t *d_first_wg, uint32_t n_wg, uint32_t n_log,
+                               unsigned *d_flag)
+{
+	if (n_log > 40) return hipErrorNotSupported;
+	hipLaunchKernelGGL(k_check_tensor, dim3(n_wg), dim3(256), 0, s, (const uint4 *)eq, n, d_rho, d_first_wg, n_log, d_flag);
 	return hipGetLastError();
 }
 
