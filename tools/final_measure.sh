@@ -1,26 +1,36 @@
 #!/bin/bash
-# the round's measurement batch (run through gpurun from the repo root); results in gpurun_out/final/
+# the round's measurement batch (run through gpurun from the repo root); results in gpurun_out/final/, copied to profiles/r03/
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/final
 rm -rf $O; mkdir -p $O
 cd $R
 python bench.py > $O/bench_n28.json 2> $O/bench_n28.stderr
 python bench.py --n-vars 24 --steps 5 --warmup 2 > $O/bench_n24.json 2> $O/bench_n24.stderr
-BN_EVAL=valu python bench.py --n-vars 28 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_n28_valu_kernels_BN_EVAL_valu.json 2>/dev/null
+python bench.py --n-vars 25 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_n25_one_shard_of_eight.json 2>/dev/null
+python bench.py --n-vars 20 --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_n20.json 2>/dev/null
+BN_TWO_ROUND=0 python bench.py --n-vars 24 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_n24_BN_TWO_ROUND_0.json 2>/dev/null
+BN_TWO_ROUND=0 python bench.py --n-vars 25 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_n25_BN_TWO_ROUND_0.json 2>/dev/null
 python tools/bench_ops.py > $O/ops.jsonl 2>&1
 tools/bench_mlecheck_quick.sh > $O/mlecheck_prover.jsonl 2>&1
+BN_MLECHECK_SHADOW=0 tools/bench_mlecheck_quick.sh > $O/mlecheck_prover_BN_MLECHECK_SHADOW_0.jsonl 2>&1
 python tools/profile_ntt.py --reps 3 > $O/ntt_2p24_b32.txt 2>&1
 python tools/bench_fri_commit.py > $O/fri_commit.jsonl 2>&1
-python tools/roundeval_rate.py --n-vars 24 26 27 > $O/roundeval_rate.jsonl 2>&1
 python tools/small_rounds.py > $O/small_rounds.jsonl 2>&1
-BN_ARM=0 python tools/small_rounds.py > $O/small_rounds_BN_ARM_0.jsonl 2>&1
-BN_ARM=0 python bench.py --n-vars 24 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_n24_BN_ARM_0.json 2>/dev/null
-python bench.py --n-vars 20 --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_n20.json 2>/dev/null
+BN_TWO_ROUND=0 python tools/small_rounds.py > $O/small_rounds_BN_TWO_ROUND_0.jsonl 2>&1
+tools/two_round_phases > $O/two_round_phases.txt 2>&1
 tools/small_round_phases > $O/small_round_phases.txt 2>&1
-tools/signal_latency > $O/signal_latency.txt 2>&1
 python tools/bench_hal.py > $O/hal.jsonl 2>&1
-tools/trace_bench.sh trace_n28_final --n-vars 28 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-tools/trace_bench.sh trace_n24_final --n-vars 24 --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
-tools/trace_mlecheck.sh 24 > $O/mlecheck_timeline_n24.txt 2>&1
-for t in trace_n28_final trace_n24_final; do cp $R/gpurun_out/$t/kernel_stats.csv $O/${t}_kernel_stats.csv; cp $R/gpurun_out/$t/per_launch.jsonl $O/${t}_per_launch.jsonl; cp $R/gpurun_out/$t/bench_line.json $O/${t}_bench_line.json; done
-tail -c 600 $O/bench_n28.json
+tools/trace_bench.sh final/trace_n28 --n-vars 28 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+tools/trace_bench.sh final/trace_n24 --n-vars 24 --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+for t in trace_n28 trace_n24; do cp $O/$t/kernel_stats.csv $O/bench_${t#trace_}_kernel_stats.csv; cp $O/$t/per_launch.jsonl $O/per_launch_${t#trace_}.jsonl; cp $O/$t/bench_line.json $O/bench_${t#trace_}_under_rocprof.json; done
+rm -rf $O/trace_n28 $O/trace_n24
+BN_MLECHECK=eager tools/trace_mlecheck.sh 24 > $O/mlecheck_literal_timeline_n24.txt 2>&1
+# config 5's workload and the exchanges, all ranks on this one device (diagnostic: eight processes share one GPU)
+for W in 2 4 8; do
+  BN_ALL_ON_GPU0=1 BN_PG_BACKEND=gloo timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node $W --master-addr 127.0.0.1 --master-port 2971$W bench.py --gpus $W --n-vars 13 --steps 50 --warmup 5 --no-cpu-baseline --no-prof 2>/dev/null | grep '^{' > $O/bench_${W}_ranks_on_one_gpu_n13.json
+done
+BN_ALL_ON_GPU0=1 BN_PG_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29719 bench.py --gpus 8 --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | grep '^{' > $O/bench_8_ranks_on_one_gpu_n28.json
+BUILD=$(cat $R/tools/.build_id 2>/dev/null || python -c "import bench; print(bench.csrc_sha16())")
+tools/pmc_bench.sh $BUILD 28 24 > $O/pmc_bench.log 2>&1
+cp $R/gpurun_out/bench_pmc.json $O/bench_pmc.json
+tail -c 700 $O/bench_n28.json
