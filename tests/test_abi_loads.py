@@ -146,3 +146,13 @@ def test_host_library_exports_every_declared_symbol(ffi):
     L = ctypes.CDLL(os.path.join(ROOT, "binius_amd", "libbinius_amd_host.so"))
     for s in syms:
         assert hasattr(L, s), "libbinius_amd_host.so does not export %s" % s
+
+
+def test_design_tables_are_generated_from_the_committed_profiles():
+    """DESIGN.md section 5 is generated (tools/gen_design_tables.py) from profiles/r03: hand edits or stale numbers fail here."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_design_tables.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
