@@ -95,24 +95,23 @@ static int shadow_staging(bn_ctx *ctx)
 
 // The shadow's table, looked at when the caller's first fold arrives (a lone evaluation never pays for it): the entries
 // eq[0], eq[2^k] come to the host (one gather, one synchronisation), the ratios rho_k = eq[2^k] / eq[0] = zeta_k / (1 - zeta_k)
-// are formed, and ONE pass checks eq[i] == eq[i - 2^k] * rho_k for every entry.  Run on the main stream, in line: a version
-// that started the check beside the first round's kernels (side stream) hid the synchronisations but slowed those VALU-bound
-// kernels by about what the check costs, the lone evaluation included (0.55 -> 0.76 ms at 2^24).
+// are formed, and ONE pass checks eq[i] == eq[i - 2^k] * rho_k for every entry.  On the main stream, in line.  Measured and not
+// kept: the check started beside ROUND 0 on the side stream (hides the synchronisations, slows that round's VALU-bound kernels
+// and every lone evaluation by what it costs: 0.55 -> 0.76 ms at 2^24); the check beside ROUND 1 with the verdict collected
+// when that round's result is in and the round answered again on a "no" (-25 us of 1.85 ms at n = 24, and a mid-size armed
+// kernel -- two full-register workgroups on every CU -- starves the check until its 6 ms timeout unless arming is held back).
 int shadow_check_table(bn_ctx *ctx, bool *ok)
 {
 	bn_ctx::shadow_state &sh = ctx->shadow;
 	*ok = false;
 	const uint64_t half = sh.eq_len;
 	const uint32_t K = ilog2(half);
-	// gathered: eq[0], eq[2^0] .. eq[2^(K-1)], then the first min(256, half) entries (checked here, on the host)
-	const uint64_t n_head = half < 256 ? half : 256;
-	const uint64_t n_items = K + 1 + n_head;
+	const uint64_t n_items = K + 1;
 	const size_t off_bytes = ((size_t)n_items * 8 + 15) & ~(size_t)15;
-	if (shadow_staging(ctx) != BN_OK || off_bytes + n_items * sizeof(f128) > 16384) return BN_OK;
+	if (shadow_staging(ctx) != BN_OK) return BN_OK;
 	uint64_t *offs = (uint64_t *)ctx->h_gather;
 	offs[0] = 0;
 	for (uint32_t k = 0; k < K; k++) offs[k + 1] = (uint64_t)1 << k;
-	for (uint64_t i = 0; i < n_head; i++) offs[K + 1 + i] = i;
 	BN_HIP(bn::launch_gather(ctx->stream, sh.eq, (const uint64_t *)ctx->d_gather, n_items, 1, (char *)ctx->d_gather + off_bytes));
 	BN_HIP(hipStreamSynchronize(ctx->stream));
 	// ---- what the rounds need are 1 / rho_k = eq[0] / eq[2^k] and 1 - zeta_k = 1 / (1 + rho_k) = eq[0] / (eq[0] + eq[2^k]), what
@@ -143,20 +142,8 @@ int shadow_check_table(bn_ctx *ctx, bool *ok)
 		sh.one_minus_zeta[k] = bn::mul_host(e0, vinv[2 * k + 1]);
 		h_rho[k] = bn::mul_host(got[k + 1], vinv[2 * K]);
 	}
-	// the head of the table (top bit k < 8) on the host; the kernel below takes every entry from 256 on
-	const f128 *head = got + K + 1;
-	for (uint64_t i = 1; i < n_head; i++) {
-		unsigned kt = 0;
-		while ((i >> (kt + 1)) != 0) kt++;
-		if (!(bn::mul_host(head[i - ((uint64_t)1 << kt)], h_rho[kt]) == head[i])) return BN_OK;
-	}
 	// ---- the whole table has the structure the ratios describe (*d_flag is zero between checks: only a failing check writes
 	// it, and is followed by the reset below; ratios and workgroup layout travel through the pinned staging)
-	if (K <= 8) { // the whole table was the head
-		*ok = true;
-		sh.checked = true;
-		return BN_OK;
-	}
 	uint32_t *h_fw = (uint32_t *)((char *)ctx->h_gather + 16384 + 40 * sizeof(f128));
 	const uint32_t n_wg = bn::check_tensor_layout(K, h_fw);
 	BN_HIP(bn::launch_check_tensor(ctx->stream, sh.eq, half, (const f128 *)((char *)ctx->d_gather + 16384),
@@ -202,6 +189,7 @@ int side_run_queue(bn_ctx *ctx)
 			bn::fold_batch fb{};
 			fb.x0[0] = op.dst;
 			fb.x1[0] = op.src;
+			fb.src0[0] = op.src2;
 			BN_HIP(bn::launch_extrapolate_line_batch(st, ctx->n_cu, fb, 1, op.n, op.z));
 			break;
 		}
@@ -251,8 +239,7 @@ int flush_first_fold(bn_ctx *ctx)
 	for (uint32_t i = 0; i < pf.count; i++) {
 		fb.x0[i] = pf.x0[i];
 		fb.x1[i] = pf.x1[i];
-		if (pf.src0[i] != pf.x0[i])
-			BN_HIP(hipMemcpyAsync(pf.x0[i], pf.src0[i], pf.n * sizeof(f128), hipMemcpyDeviceToDevice, ctx->stream));
+		fb.src0[i] = pf.src0[i] != pf.x0[i] ? pf.src0[i] : nullptr;
 	}
 	{
 		prof_scope ps(ctx, BN_PROF_FOLD);
@@ -336,8 +323,7 @@ int flush_pending(bn_ctx *ctx, bool keep_tail, bool publish_tiny, bool keep_shad
 			for (uint32_t i = 0; i < pf.count; i++) {
 				fb.x0[i] = pf.x0[i];
 				fb.x1[i] = pf.x1[i];
-				if (pf.src0[i] != pf.x0[i])
-					BN_HIP(hipMemcpyAsync(pf.x0[i], pf.src0[i], pf.n * sizeof(f128), hipMemcpyDeviceToDevice, ctx->stream));
+				fb.src0[i] = pf.src0[i] != pf.x0[i] ? pf.src0[i] : nullptr; // (absorbed copy: read there, write here)
 			}
 			prof_scope ps(ctx, BN_PROF_FOLD);
 			BN_HIP(bn::launch_extrapolate_line_batch(ctx->stream, ctx->n_cu, fb, pf.count, pf.n, pf.z));
@@ -361,8 +347,7 @@ int flush_pending(bn_ctx *ctx, bool keep_tail, bool publish_tiny, bool keep_shad
 	for (uint32_t i = 0; i < ctx->pend.count; i++) {
 		fb.x0[i] = ctx->pend.x0[i];
 		fb.x1[i] = ctx->pend.x1[i];
-		if (ctx->pend.src0[i] != ctx->pend.x0[i]) // absorbed copy: materialise it, then fold in place
-			BN_HIP(hipMemcpyAsync(ctx->pend.x0[i], ctx->pend.src0[i], ctx->pend.n * sizeof(f128), hipMemcpyDeviceToDevice, ctx->stream));
+		fb.src0[i] = ctx->pend.src0[i] != ctx->pend.x0[i] ? ctx->pend.src0[i] : nullptr; // absorbed copy: read there, write here
 	}
 	prof_scope ps(ctx, BN_PROF_FOLD);
 	BN_HIP(bn::launch_extrapolate_line_batch(ctx->stream, ctx->n_cu, fb, ctx->pend.count, ctx->pend.n, ctx->pend.z));

@@ -745,9 +745,8 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 												// upper half of S levelled by (1 - zeta) / zeta
 												bn_ctx::pending_fold &pf = ctx->pend;
 												// (queued: launched once this round's kernel has its challenge, while the host would only spin)
-												if (pf.src0[sh.ib] != pf.x0[sh.ib])
-													ctx->side_queue.push_back({bn_ctx::side_op::COPY, pf.x0[sh.ib], pf.src0[sh.ib], nullptr, pf.n, f128{0, 0}});
-												ctx->side_queue.push_back({bn_ctx::side_op::FOLD, pf.x0[sh.ib], pf.x1[sh.ib], nullptr, pf.n, pf.z});
+												ctx->side_queue.push_back({bn_ctx::side_op::FOLD, pf.x0[sh.ib], pf.x1[sh.ib],
+												                           pf.src0[sh.ib] != pf.x0[sh.ib] ? pf.src0[sh.ib] : nullptr, pf.n, pf.z});
 												bn_ctx::pending_fold q = pf;
 												q.x0[0] = pf.x0[sh.ia];
 												q.x1[0] = pf.x1[sh.ia];

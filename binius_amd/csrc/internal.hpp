@@ -109,7 +109,7 @@ struct bn_ctx {
 	// side work that has been asked for but not launched yet: a launch costs the host ~3 us, so it is issued while the host
 	// would otherwise spin on the round's result (right after the round's kernel has been launched or signalled), in order
 	struct side_op {
-		enum { COPY, ADD_ASSIGN, ADD, FOLD } kind;
+		enum { COPY, ADD_ASSIGN, ADD, FOLD } kind; // FOLD: dst = evals_0 (written), src = evals_1, src2 = where evals_0 is read (nullptr: dst)
 		void *dst;
 		const void *src, *src2;
 		uint64_t n;
@@ -214,6 +214,7 @@ constexpr int kFoldBatchMax = 8;
 struct fold_batch {
 	void *x0[kFoldBatchMax];
 	const void *x1[kFoldBatchMax];
+	const void *src0[kFoldBatchMax]; // nullptr: in place (evals_0 is read from x0); else evals_0 is read from here and written to x0
 };
 hipError_t launch_extrapolate_line_batch(hipStream_t s, int n_cu, const fold_batch &b, uint32_t count, uint64_t n, f128 z);
 hipError_t launch_fold_publish(hipStream_t s, void *const *x0, const void *const *src0, const void *const *x1, uint32_t count, uint32_t n,

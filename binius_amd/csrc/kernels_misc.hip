@@ -552,8 +552,8 @@ __global__ __launch_bounds__(256, 2) void k_check_tensor(const uint4 *eq, uint64
 			}
 		}
 	}
-	// (the first 256 entries, k = 0 .. 7, are checked by the caller on the host: the generic product they would need here
-	// costs the whole kernel its occupancy -- 288 registers, one wave per SIMD, 130 - 180 us for 2^23 entries)
+	// (the first 256 entries, k = 0 .. 7: k_check_tensor_head -- the generic product they need would cost this kernel its
+	// occupancy: 288 registers, one wave per SIMD, 130 - 180 us for 2^23 entries)
 	if (bad) atomicOr(flag, 1u);
 }
 
@@ -564,18 +564,33 @@ uint32_t check_tensor_layout(uint32_t n_log, uint32_t *first_wg /*[42]*/)
 	for (uint32_t k = 0; k <= 41; k++) {
 		first_wg[k] = wg;
 		if (k >= 8 && k < n_log) {
-			// a workgroup per 1024 elements, at most 1024 per range
-			uint64_t w = ((uint64_t)1 << k) / 1024;
-			wg += (uint32_t)(w < 1 ? 1 : (w > 1024 ? 1024 : w));
+			// a workgroup per 4096 elements, at most 512 per range (every workgroup builds a nibble table first: with one per
+			// 1024 elements a fifth of the kernel was table building)
+			uint64_t w = ((uint64_t)1 << k) / 4096;
+			wg += (uint32_t)(w < 1 ? 1 : (w > 512 ? 512 : w));
 		}
 	}
 	return wg ? wg : 1; // tables of at most 256 entries: workgroup 0 alone
+}
+
+// the first 256 entries (k = 0 .. 7) with the generic product, in a kernel of their own (inside k_check_tensor the product's
+// registers cost the whole kernel its occupancy)
+__global__ __launch_bounds__(256) void k_check_tensor_head(const uint4 *eq, uint64_t n, const f128 *rho, unsigned *flag)
+{
+	const uint64_t i = threadIdx.x;
+	if (i >= 1 && i < n) {
+		const unsigned kt = 31 - __clz((unsigned)i);
+		const f128 want = mul_slow(to_f128(eq[i - ((uint64_t)1 << kt)]), rho[kt]);
+		if (!(want == to_f128(eq[i]))) atomicOr(flag, 1u);
+	}
 }
 
 hipError_t launch_check_tensor(hipStream_t s, const void *eq, uint64_t n, const f128 *d_rho, const uint32_t *d_first_wg, uint32_t n_wg, uint32_t n_log,
                                unsigned *d_flag)
 {
 	if (n_log > 40) return hipErrorNotSupported;
+	hipLaunchKernelGGL(k_check_tensor_head, dim3(1), dim3(256), 0, s, (const uint4 *)eq, n, d_rho, d_flag);
+	if (n_log <= 8) return hipGetLastError();
 	hipLaunchKernelGGL(k_check_tensor, dim3(n_wg), dim3(256), 0, s, (const uint4 *)eq, n, d_rho, d_first_wg, n_log, d_flag);
 	return hipGetLastError();
 }

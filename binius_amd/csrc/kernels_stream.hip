@@ -100,15 +100,18 @@ __global__ __launch_bounds__(256) void k_extrapolate_line_batch(fold_batch fb, u
 {
 	__shared__ ctable_smem tab;
 	ctable_build(tab, z);
-	uint4 *__restrict__ x0 = (uint4 *)fb.x0[blockIdx.y];
-	const uint4 *__restrict__ x1 = (const uint4 *)fb.x1[blockIdx.y];
+	// (s0 == x0 for the in-place fold; the first fold of a prover reads evals_0 where the caller left it and writes the
+	// fresh buffer -- the "copy evals_0, then fold in place" of v3/bivariate_product.rs:196-206 in one pass)
+	uint4 *x0 = (uint4 *)fb.x0[blockIdx.y];
+	const uint4 *s0 = fb.src0[blockIdx.y] ? (const uint4 *)fb.src0[blockIdx.y] : (const uint4 *)x0;
+	const uint4 *x1 = (const uint4 *)fb.x1[blockIdx.y];
 	const uint64_t stride = (uint64_t)gridDim.x * 256;
 	uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
 	for (; i + (U - 1) * stride < n; i += U * stride) {
 		uint4 a[U], b[U];
 #pragma unroll
 		for (int u = 0; u < U; u++) {
-			a[u] = ld16<NT>(&x0[i + u * stride]);
+			a[u] = ld16<NT>(&s0[i + u * stride]);
 			b[u] = ld16<NT>(&x1[i + u * stride]);
 		}
 #pragma unroll
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(256) void k_extrapolate_line_batch(fold_batch fb, u
 			st16<NT>(&x0[i + u * stride], xor4(a[u], ctable_mul(tab, xor4(a[u], b[u]))));
 	}
 	for (; i < n; i += stride) {
-		uint4 a = x0[i], b = x1[i];
+		uint4 a = s0[i], b = x1[i];
 		x0[i] = xor4(a, ctable_mul(tab, xor4(a, b)));
 	}
 }

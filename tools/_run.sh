@@ -1,10 +1,4 @@
 cd $GRAFT_REPO_ROOT
-tools/final_measure.sh
-ls gpurun_out/final | head -50
-python -c "
-import json
-d=json.load(open('gpurun_out/final/bench_pmc.json')); print(d.get('build'), d.get('csrc_sha16'), list(d['workloads'].keys()))
-for w,v in d['workloads'].items():
-    for k,e in v.items():
-        if 'foldeval_mfma' in k or 'fp4' in k or 'foldeval8' in k: print(w,k,e)
-"
+timeout 900 python -m pytest tests/test_gpu_mlecheck_shadow.py tests/test_gpu_sumcheck.py tests/test_gpu_layer.py tests/test_gpu_lazy_vs_eager.py tests/test_gpu_two_round.py -x -q 2>&1 | tail -3
+BN_MLECHECK=eager tools/trace_mlecheck.sh 24 2>&1 | head -16
+tools/bench_mlecheck_quick.sh 2>&1 | cut -c1-140
