@@ -368,22 +368,45 @@ __global__ __launch_bounds__(256, 2) void k_fri_pass_multi(const uint4 *in, uint
 			s_basis[c][threadIdx.x] = (lv.l[c].s_row && (int)threadIdx.x < lv.l[c].n_bits) ? lv.l[c].s_row[threadIdx.x] : 0;
 	}
 	__syncthreads();
-	const uint64_t n_blocks = (n_out + 255) / 256;
-	for (uint64_t b = blockIdx.x; b < n_blocks; b += gridDim.x) {
-		const uint64_t k0 = b * 256;                      // first output of this block
-		const uint64_t in0 = k0 << C, n_in = n_out << C;  // its inputs: 256 * E contiguous elements
+	// Every WAVE works on its own blocks of 64 outputs (64 * E contiguous inputs) with its own slice of the stage and no
+	// workgroup barrier in the loop: the next block's inputs are requested (coalesced, into registers) before the current
+	// block is multiplied, and the four waves of a workgroup drift apart so that one's loads hide behind another's lookups.
+	// (With a workgroup-wide stage and two barriers per block the counters showed the waves waiting 61 % of the time with the
+	// VALU 40 % and the LDS 50 % busy: 134 us for the pass that the three passes it replaces also took.)
+	const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	uint4 *wstage = stage + wave * 64 * ROW;
+	const uint64_t n_wblocks = (n_out + 63) / 64, n_in = n_out << C;
+	const uint64_t wstride = (uint64_t)gridDim.x * 4;
+	uint64_t b = (uint64_t)blockIdx.x * 4 + wave;
+	uint4 pre[E];
+	auto fetch = [&](uint64_t blk) {
+		const uint64_t in0 = (blk * 64) << C;
 #pragma unroll
 		for (int j = 0; j < E; j++) {
-			const unsigned e = j * 256 + threadIdx.x; // coalesced
-			if (in0 + e < n_in) stage[(e >> C) * ROW + (e & (E - 1))] = in[in0 + e];
+			const uint64_t e = in0 + (uint64_t)j * 64 + lane; // coalesced
+			pre[j] = e < n_in ? in[e] : uint4{0, 0, 0, 0};
 		}
-		__syncthreads();
-		const uint64_t k = k0 + threadIdx.x;
-		if (k < n_out) {
+	};
+	if (b < n_wblocks) fetch(b);
+	for (; b < n_wblocks; b += wstride) {
+		// registers -> this wave's stage (element e of the block at row e >> C, column e & (E - 1))
+#pragma unroll
+		for (int j = 0; j < E; j++) {
+			const unsigned e = j * 64 + lane;
+			wstage[(e >> C) * ROW + (e & (E - 1))] = pre[j];
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		const uint64_t k = b * 64 + lane;
+		{
 			uint4 x[E];
-			const uint4 *row = stage + threadIdx.x * ROW;
+			const uint4 *row = wstage + lane * ROW;
 #pragma unroll
 			for (int j = 0; j < E; j++) x[j] = row[j];
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier(); // (every lane has its row in registers: the stage may be refilled)
+			if (b + wstride < n_wblocks) fetch(b + wstride); // flies while this block is multiplied
 #pragma unroll
 			for (int c = 0; c < C; c++) {
 				const int cnt = E >> (c + 1); // outputs of this level per thread
@@ -399,16 +422,16 @@ __global__ __launch_bounds__(256, 2) void k_fri_pass_multi(const uint4 *in, uint
 							v = xor4(v, u);
 							u = xor4(u, to_u4(mul_walk<TW>(to_f128(v), t)));
 						}
-						x[j] = xor4(u, ctable_mul<8>(tab[c], xor4(u, v)));
-						// one pair at a time: left alone the scheduler hoists the lookups of all pairs of a level to the front
-						// and spills hundreds of registers (the same effect as in the fused fold + evaluation kernel)
-						__builtin_amdgcn_sched_barrier(0);
+						x[j] = xor4(u, ctable_mul<NTT ? 8 : 16>(tab[c], xor4(u, v)));
+						// two pairs at a time in the interleave-only passes, one at a time next to the butterflies: left alone
+						// the scheduler hoists the lookups of ALL pairs of a level to the front and spills hundreds of registers
+						// 
+						if (NTT || (j & 1) || j + 1 == cnt) __builtin_amdgcn_sched_barrier(0);
 					}
 				}
 			}
-			out[k] = x[0];
+			if (k < n_out) out[k] = x[0];
 		}
-		__syncthreads(); // the stage is refilled by the next block
 	}
 }
 
