@@ -156,13 +156,54 @@ int bn_pairwise_product_reduce(bn_ctx *ctx, const void *d_in, uint64_t n, void *
 	BN_REQUIRE(n_rounds == log_n, "round_outputs.len() does not match the expected length");
 	for (uint32_t r = 0; r < n_rounds; r++)
 		BN_REQUIRE(round_lens[r] == ((uint64_t)1 << (log_n - r - 1)), "round_outputs[i].len() has the wrong size");
-	// One launch per level.  (Walking the last <= 12 levels inside one workgroup was measured in round 2: 233 vs 225 us at
-	// 2^20 -- a level is one dependent chain of ~2400 instructions per wave-batch, ~10 us with or without a launch in
-	// front of it)
+	// Large levels: the element-wise product (kernels_mul9.hip, at throughput), up to BN_MUL9_FUSE (2) levels per launch
+	// (k_mul9_tree: a workgroup goes on with the products under the 896 it has just stored).  From 2^15 elements down a
+	// level is one dependent chain whatever its size, and the tree is walked by workgroups that keep their subtree on the CU
+	// (kernels_pairtree.hip): up to BN_PAIRTREE_LOG_S (6) levels per launch.  (Round 2 measured the bit-sliced product itself inside one
+	// workgroup for the last 12 levels: 233 vs 225 us -- its chain is the cost)
+	static const uint32_t tree_max_log2 = [] {
+		const char *e = getenv("BN_PAIRTREE_MAX_LOG2"); // measurement knob: 0 = off
+		const int v = e ? atoi(e) : 15;
+		return (uint32_t)(v < 0 ? 0 : (v > 24 ? 24 : v));
+	}();
+	static const uint32_t tree_log_s = [] {
+		const char *e = getenv("BN_PAIRTREE_LOG_S");
+		const int v = e ? atoi(e) : 6;
+		return (uint32_t)(v < 1 ? 1 : (v > 8 ? 8 : v));
+	}();
 	const void *src = d_in;
-	for (uint32_t r = 0; r < n_rounds; r++) {
-		BN_HIP(bn::launch_mul9(ctx->stream, ctx->n_cu, src, 2, src, 2, 1, d_round_outs[r], round_lens[r]));
-		src = d_round_outs[r];
+	uint32_t r = 0;
+	static const uint32_t fuse = [] {
+		const char *e = getenv("BN_MUL9_FUSE"); // levels per launch of the element-wise kernel (1 .. 4)
+		const int v = e ? atoi(e) : 2;
+		return (uint32_t)(v < 1 ? 1 : (v > 4 ? 4 : v));
+	}();
+	while (r < n_rounds && log_n - r > tree_max_log2) {
+		uint32_t k = log_n - r - tree_max_log2; // levels left for this kernel
+		if (k > fuse) k = fuse;
+		if (k == 1) {
+			BN_HIP(bn::launch_mul9(ctx->stream, ctx->n_cu, src, 2, src, 2, 1, d_round_outs[r], round_lens[r]));
+		} else {
+			bn::mul9_tree_args ta{};
+			ta.in = (const uint32_t *)src;
+			ta.n0 = round_lens[r];
+			ta.n_levels = k;
+			for (uint32_t l = 0; l < k; l++) ta.lv[l] = (uint32_t *)d_round_outs[r + l];
+			BN_HIP(bn::launch_mul9_tree(ctx->stream, ctx->n_cu, ta));
+		}
+		r += k;
+		src = d_round_outs[r - 1];
+	}
+	while (r < n_rounds) {
+		const uint32_t log_m = log_n - r; // elements of `src`
+		const uint32_t nl = log_m < tree_log_s ? log_m : tree_log_s;
+		bn::pairtree_args pa{};
+		pa.in = (const f128 *)src;
+		pa.n_levels = nl;
+		for (uint32_t l = 0; l < nl; l++) pa.out[l] = (f128 *)d_round_outs[r + l];
+		BN_HIP(bn::launch_pairtree(ctx->stream, pa, tree_log_s, (uint64_t)1 << (log_m - nl)));
+		r += nl;
+		src = d_round_outs[r - 1];
 	}
 	return BN_OK;
 }

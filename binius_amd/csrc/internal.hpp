@@ -379,6 +379,23 @@ hipError_t launch_ntt(hipStream_t s, bool inverse, void *data, uint32_t elem_lev
                       uint64_t coset, uint32_t coset_bits, uint32_t skip_rounds);
 
 // ---- kernels_mul9.hip: out[i] = a[i*a_stride] * b[b_off + i*b_stride], bit-sliced
+// up to four adjacent levels of pairwise_product_reduce in one launch of the element-wise product (kernels_mul9.hip:
+// k_mul9_tree): level l (0-based) = products of adjacent pairs of lv[l - 1] (level 0: of `in`), n0 >> l of them, to lv[l]
+struct mul9_tree_args {
+	const uint32_t *in;
+	uint32_t *lv[4];
+	uint64_t n0;
+	uint32_t n_levels;
+};
+hipError_t launch_mul9_tree(hipStream_t s, int n_cu, const mul9_tree_args &args);
+// the small levels of pairwise_product_reduce (kernels_pairtree.hip): workgroup b walks n_levels <= log_s levels of the
+// subtree over elements [b << n_levels, (b + 1) << n_levels) of `in`; level l (1-based) goes to out[l - 1]
+struct pairtree_args {
+	const f128 *in;
+	f128 *out[8];
+	uint32_t n_levels;
+};
+hipError_t launch_pairtree(hipStream_t s, const pairtree_args &args, uint32_t log_s, uint64_t n_groups);
 hipError_t launch_mul9(hipStream_t s, int n_cu, const void *a, uint64_t a_stride, const void *b, uint64_t b_stride, uint64_t b_off,
                        void *out, uint64_t n);
 

@@ -38,23 +38,27 @@ constexpr int kWaveQ4 = (kBlocks + 1) * kQ;
 // STRIDE (in elements, the same for a and b) is a template parameter so that row addresses are one
 // base pointer plus immediates; a run-time stride makes the compiler keep 32 64-bit offsets alive
 // (spilled to scratch: measured 1.3 KiB per lane).
-// The wave-batches wave_global, wave_global + n_waves, ... of one element-wise product; wt = this wave's LDS tile.
+// The lane's constants (init) and one wave-batch of the product (batch): elements e0 .. min(e0 + 224, limit) - 1 of
+//   out[i] = a[i * STRIDE] * b[i * STRIDE]
 template <int STRIDE>
-__device__ __forceinline__ void mul9_batches(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b, uint32_t *__restrict__ out,
-                                             uint64_t n, uint64_t wave_global, uint64_t n_waves, uint4 *wt)
-{
+struct mul9_wave {
+	unsigned g, c, gg, w, mask, off_a[4], off_b[4], off_w, off_pp, setX, setY, setW;
+	bool live, loader, builder;
+	uint4 *wt;
+
+	__device__ __forceinline__ void init(uint4 *wave_tile)
+	{
+	wt = wave_tile;
 	const unsigned lane = threadIdx.x & 63;
-	const unsigned g = lane / 9, c = lane - g * 9;
-	const bool live = lane < 63;
-	const bool loader = live && c < 8;
-	const bool builder = live && c < 4;
+	g = lane / 9;
+	c = lane - g * 9;
+	live = lane < 63;
+	loader = live && c < 8;
+	builder = live && c < 4;
 	if (lane < kQ)
 		wt[kZero * kQ + lane] = uint4{0, 0, 0, 0};
 
-	const unsigned w = c & 3;
-	const uint32_t *src = ((c & 4) ? b : a) + w;
-	constexpr uint64_t stride_w = (uint64_t)STRIDE << 2; // in 32-bit words
-	unsigned mask;
+	w = c & 3;
 	switch (c) {
 	case 0: mask = 1; break;
 	case 1: mask = 2; break;
@@ -67,18 +71,17 @@ __device__ __forceinline__ void mul9_batches(const uint32_t *__restrict__ a, con
 	default: mask = 15; break;
 	}
 	if (!live) mask = 0;
-	unsigned off_a[4], off_b[4];
 #pragma unroll
 	for (int s = 0; s < 4; s++) {
 		const bool use = (mask >> s) & 1;
 		off_a[s] = (use ? (unsigned)(s * kG + g) : (unsigned)kZero) * kQ;
 		off_b[s] = (use ? (unsigned)((4 + s) * kG + g) : (unsigned)kZero) * kQ;
 	}
-	const unsigned gg = live ? g : 0;
-	const unsigned off_w = (loader ? (c * kG + gg) : 0u) * kQ;
-	const unsigned off_pp = (live ? (c * kG + g) : (unsigned)kZero) * kQ; // where this lane publishes its partial product
+	gg = live ? g : 0;
+	off_w = (loader ? (c * kG + gg) : 0u) * kQ;
+	off_pp = (live ? (c * kG + g) : (unsigned)kZero) * kQ; // where this lane publishes its partial product
 	// partial products a builder needs: X (plain), Y (through alpha), W (through alpha^2); bit k = p_k
-	unsigned setX = 0, setY = 0, setW = 0;
+	setX = setY = setW = 0;
 	if (builder) {
 		switch (c) {
 		case 0: setX = 0x01B; break;                              // p0 p1 p3 p4
@@ -87,15 +90,21 @@ __device__ __forceinline__ void mul9_batches(const uint32_t *__restrict__ a, con
 		default: setX = 0x1E7; setY = 0x0AA; setW = 0x010; break; // p0 p1 p2 p5 p6 p7 p8 ; alpha(p1 p3 p5 p7) ; alpha^2(p4)
 		}
 	}
+	}
+
 	// The slot offsets of the rebuild phase are recomputed per batch from (setX, setY, setW, g) behind
 	// an opaque copy of g: hoisted out of the loop they are 15 more live registers across the
 	// multiplication and push the kernel into scratch (measured: 55 us per batch instead of ~5).
-	const uint64_t n_batches = (n + kWB - 1) / kWB;
-
-	for (uint64_t bt = wave_global; bt < n_batches; bt += n_waves) {
-		const uint64_t base = bt * kWB + gg; // element of row j: base + 7*j
+	__device__ __forceinline__ void batch(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b, uint32_t *__restrict__ out, uint64_t e0,
+	                                      uint64_t limit)
+	{
+		constexpr uint64_t stride_w = (uint64_t)STRIDE << 2; // in 32-bit words
+		const uint32_t *src = ((c & 4) ? b : a) + w;
+		const bool full = e0 + kWB <= limit;
+		{
+		const uint64_t base = e0 + gg; // element of row j: base + 7*j
 		uint32_t r[32];
-		if ((bt + 1) * kWB <= n) {
+		if (full) {
 			const uint32_t *p = src + base * stride_w;
 #pragma unroll
 			for (int j = 0; j < 32; j++)
@@ -107,7 +116,7 @@ __device__ __forceinline__ void mul9_batches(const uint32_t *__restrict__ a, con
 #pragma unroll
 				for (int j = j0; j < j0 + 8; j++) {
 					const uint64_t e = base + 7 * (uint64_t)j;
-					const bool ok = e < n;
+					const bool ok = e < limit;
 					const uint32_t v = src[ok ? e * stride_w : 0];
 					r[j] = ok ? v : 0u;
 				}
@@ -199,18 +208,32 @@ __device__ __forceinline__ void mul9_batches(const uint32_t *__restrict__ a, con
 		transpose32(r); // planes -> word c of 32 elements
 		if (builder) {
 			uint32_t *dst = out + c + (base << 2); // builder lanes: c == word index
-			if ((bt + 1) * kWB <= n) {
+			if (full) {
 #pragma unroll
 				for (int j = 0; j < 32; j++)
 					dst[28 * j] = r[j];
 			} else {
 #pragma unroll
 				for (int j = 0; j < 32; j++)
-					if (base + 7 * (uint64_t)j < n)
+					if (base + 7 * (uint64_t)j < limit)
 						dst[28 * j] = r[j];
 			}
 		}
 	}
+}
+
+};
+
+// The wave-batches wave_global, wave_global + n_waves, ... of one element-wise product; wt = this wave's LDS tile.
+template <int STRIDE>
+__device__ __forceinline__ void mul9_batches(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b, uint32_t *__restrict__ out,
+                                             uint64_t n, uint64_t wave_global, uint64_t n_waves, uint4 *wt)
+{
+	mul9_wave<STRIDE> mw;
+	mw.init(wt);
+	const uint64_t n_batches = (n + kWB - 1) / kWB;
+	for (uint64_t bt = wave_global; bt < n_batches; bt += n_waves)
+		mw.batch(a, b, out, bt * kWB, n);
 }
 
 template <int STRIDE>
@@ -220,6 +243,36 @@ __global__ __launch_bounds__(256, 2) void k_mul9(const uint32_t *__restrict__ a,
 	__shared__ uint4 tile[4][kWaveQ4];
 	const unsigned wave = threadIdx.x >> 6;
 	mul9_batches<STRIDE>(a, b, out, n, (uint64_t)blockIdx.x * 4 + wave, (uint64_t)gridDim.x * 4, tile[wave]);
+}
+
+// Several levels of pairwise_product_reduce in one launch: a workgroup takes 4 adjacent wave-batches of the first level
+// (896 products), and -- their results being exactly the inputs of the 448 products under them -- goes on with 2 batches of
+// the next level, 1 of the third, half a batch of the fourth, before it moves to its next 896.  What a level reads was
+// stored by waves of the same workgroup (same CU, same L1: a workgroup barrier orders it); no launch between the levels
+// and no grid-wide dependency.  Level l (0-based) reads lv[l - 1] (level 0: in) and writes lv[l]; n0 = products of level 0.
+__global__ __launch_bounds__(256, 2) void k_mul9_tree(mul9_tree_args args)
+{
+	__shared__ uint4 tile[4][kWaveQ4];
+	const unsigned wave = threadIdx.x >> 6;
+	mul9_wave<2> mw;
+	mw.init(tile[wave]);
+	constexpr uint64_t kSB = 4 * kWB; // products of the first level per workgroup step
+	const uint64_t n_sb = (args.n0 + kSB - 1) / kSB;
+	for (uint64_t k = blockIdx.x; k < n_sb; k += gridDim.x) {
+		for (uint32_t l = 0; l < args.n_levels; l++) {
+			if (l) __syncthreads();
+			const uint64_t span = kSB >> l;           // products of level l under this step
+			const uint64_t n_l = args.n0 >> l;        // products of level l in all
+			const uint64_t e0 = span * k + (uint64_t)kWB * wave;
+			uint64_t limit = span * (k + 1);
+			if (limit > n_l) limit = n_l;
+			if (e0 < limit) {
+				const uint32_t *src = l ? args.lv[l - 1] : args.in;
+				mw.batch(src, src + 4, args.lv[l], e0, limit);
+			}
+		}
+		__syncthreads(); // (the LDS tiles are per wave, but the next step's first level must not overtake a wave still reading)
+	}
 }
 
 hipError_t launch_mul9(hipStream_t s, int n_cu, const void *a, uint64_t a_stride, const void *b, uint64_t b_stride, uint64_t b_off,
@@ -237,6 +290,16 @@ hipError_t launch_mul9(hipStream_t s, int n_cu, const void *a, uint64_t a_stride
 		hipLaunchKernelGGL(k_mul9<2>, dim3((unsigned)blocks), dim3(256), 0, s, (const uint32_t *)a, pb, (uint32_t *)out, n);
 	else
 		return hipErrorInvalidValue;
+	return hipGetLastError();
+}
+
+hipError_t launch_mul9_tree(hipStream_t s, int n_cu, const mul9_tree_args &args)
+{
+	if (args.n0 == 0 || args.n_levels == 0 || args.n_levels > 4) return hipErrorInvalidValue;
+	uint64_t blocks = (args.n0 + 4 * kWB - 1) / (4 * kWB);
+	const uint64_t cap = (uint64_t)n_cu * 2;
+	if (blocks > cap) blocks = cap;
+	hipLaunchKernelGGL(k_mul9_tree, dim3((unsigned)blocks), dim3(256), 0, s, args);
 	return hipGetLastError();
 }
 

@@ -292,7 +292,9 @@ def test_compute_composite_generic_circuit(hal, oracle):
 
 
 # ---- test_generic_pairwise_product_reduce (layer.rs:909-960)
-@pytest.mark.parametrize("log_n", [1, 8])
+# (every shape of the subtree walk of kernels_pairtree.hip: a lone launch of 1 .. 6 levels, chains of two and three launches,
+# and the hand-over from the element-wise product kernel above 2^15 elements)
+@pytest.mark.parametrize("log_n", [1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 12, 13, 15, 16, 17])
 def test_pairwise_product_reduce(hal, oracle, log_n):
     alloc = hal.dev_alloc()
     n = 1 << log_n
