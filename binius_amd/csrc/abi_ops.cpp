@@ -115,7 +115,7 @@ int bn_fri_fold(bn_ctx *ctx, const uint64_t *h_s_evals, uint32_t tw_level, uint3
 	std::vector<f128> ch(n_challenges);
 	for (uint32_t i = 0; i < n_challenges; i++) ch[i] = to_f(&h_challenges[i]);
 	BN_HIP(bn::launch_fri_fold(ctx->stream, d_s, tw_level, log_domain, log_len, log_batch_size, ch.data(), n_challenges, d_in,
-	                           d_out, out_len, pp));
+	                           d_out, out_len, pp, ctx->n_cu, ctx->d_mul8));
 	return BN_OK;
 }
 

@@ -365,7 +365,7 @@ hipError_t launch_compute_composite_generic(hipStream_t s, const void *const *d_
                                             uint64_t row_len, void *out, const bn_step *d_steps, uint32_t n_steps);
 hipError_t launch_fri_fold(hipStream_t s, const uint64_t *d_s_evals, uint32_t tw_level, uint32_t log_domain,
                            uint32_t log_len, uint32_t log_batch, const f128 *h_challenges, uint32_t n_challenges,
-                           const void *in, void *out, uint64_t out_len, void *scratch);
+                           const void *in, void *out, uint64_t out_len, void *scratch, int n_cu, const uint8_t *d_mul8);
 
 // is eq[0 .. n) a tensor expansion up to a constant: eq[i] == eq[i - 2^k] * rho[k] (k = top bit of i)?  *d_flag |= 1 if not.
 // d_rho[n_log] and d_first_wg[42] (from check_tensor_layout, which returns the grid size) are read by the kernel from memory.

@@ -350,16 +350,67 @@ template <int C>
 struct fri_levels {
 	fri_level l[C];
 };
-// NTT = false: every level is an interleave challenge (no butterfly code in the kernel at all: the walk through the twiddle
-// field and its chain of mulx multiples is what pushes the general form to 200+ spilled registers; it only ever runs on the
-// arrays the interleave passes have already shrunk).
-template <int TW, int C, bool NTT>
-__global__ __launch_bounds__(256, 2) void k_fri_pass_multi(const uint4 *in, uint4 *out, uint64_t n_out, fri_levels<C> lv)
+// NTT = false: every level is an interleave challenge (no butterfly code in the kernel at all).
+// NTT = true: levels with a twiddle basis do the inverse butterfly first.  The product by the per-pair twiddle t -- an element
+// of T_5 (B32) or below, acting limb-wise on the four 32-bit limbs of v (binary_field.rs:361-412) -- goes through the 64 KiB
+// GF(2^8) product table of the context, copied into LDS: Karatsuba over the tower (pairwise_recursive_arithmetic.rs:18-28)
+// from T_5 down to bytes, the four limbs side by side in the four bytes of a register so that every XOR and every
+// multiplication by X_2 of the recombination is one SWAR operation for all of them: 36 byte look-ups + ~170 instructions
+// against the 1450 of the bilinear walk (mul_walk<5>), which was 38 of the 78 us the two butterfly passes of the
+// benchmarked fold took -- and which, with its chain of mulx multiples, is what spilled 200+ registers in a three-level pass.
+template <int K>
+__device__ __forceinline__ uint32_t mulx32(uint32_t a)
+{
+	constexpr uint32_t M = (uint32_t)lo_half_mask<K>();
+	constexpr int H = 1 << K;
+	const uint32_t l0 = a & M, l1 = (a >> H) & M;
+	if constexpr (K == 0)
+		return l1 | ((l0 ^ l1) << 1);
+	else
+		return l1 | ((l0 ^ mulx32<K - 1>(l1)) << H);
+}
+// four bytes (one per limb) times the byte whose table row is `row`
+__device__ __forceinline__ uint32_t pmul8(const uint8_t *row, uint32_t r)
+{
+	const uint32_t b0 = row[r & 0xFF], b1 = row[(r >> 8) & 0xFF], b2 = row[(r >> 16) & 0xFF], b3 = row[r >> 24];
+	return b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+}
+struct p16x4 {
+	uint32_t l, h; // low / high bytes of four T_4 elements
+};
+__device__ __forceinline__ p16x4 pmul16(const uint8_t *m8, p16x4 a, uint32_t s_lo, uint32_t s_hi)
+{
+	const uint32_t z0 = pmul8(m8 + (s_lo << 8), a.l), z2 = pmul8(m8 + (s_hi << 8), a.h), z1 = pmul8(m8 + ((s_lo ^ s_hi) << 8), a.l ^ a.h);
+	const uint32_t lo = z0 ^ z2;
+	return p16x4{lo, z1 ^ lo ^ mulx32<2>(z2)}; // X_3^2 = X_3 X_2 + 1
+}
+__device__ __forceinline__ uint4 mul_tw32_tab(const uint8_t *m8, uint4 v, uint32_t t)
+{
+	// 4 x 4 byte transpose: r_i = byte i of every limb
+	const uint32_t t0 = __builtin_amdgcn_perm(v.y, v.x, 0x05010400), t1 = __builtin_amdgcn_perm(v.y, v.x, 0x07030602);
+	const uint32_t t2 = __builtin_amdgcn_perm(v.w, v.z, 0x05010400), t3 = __builtin_amdgcn_perm(v.w, v.z, 0x07030602);
+	const p16x4 a0{__builtin_amdgcn_perm(t2, t0, 0x05040100), __builtin_amdgcn_perm(t2, t0, 0x07060302)};
+	const p16x4 a1{__builtin_amdgcn_perm(t3, t1, 0x05040100), __builtin_amdgcn_perm(t3, t1, 0x07060302)};
+	const uint32_t s0 = t & 0xFF, s1 = (t >> 8) & 0xFF, s2 = (t >> 16) & 0xFF, s3 = t >> 24;
+	const p16x4 z0 = pmul16(m8, a0, s0, s1), z2 = pmul16(m8, a1, s2, s3), z1 = pmul16(m8, p16x4{a0.l ^ a1.l, a0.h ^ a1.h}, s0 ^ s2, s1 ^ s3);
+	const p16x4 lo{z0.l ^ z2.l, z0.h ^ z2.h};
+	// X_4^2 = X_4 X_3 + 1; X_3 (l + h X_3) = h + (l + h X_2) X_3
+	const p16x4 hi{z1.l ^ lo.l ^ z2.h, z1.h ^ lo.h ^ z2.l ^ mulx32<2>(z2.h)};
+	const uint32_t u0 = __builtin_amdgcn_perm(lo.h, lo.l, 0x05010400), u1 = __builtin_amdgcn_perm(lo.h, lo.l, 0x07030602);
+	const uint32_t u2 = __builtin_amdgcn_perm(hi.h, hi.l, 0x05010400), u3 = __builtin_amdgcn_perm(hi.h, hi.l, 0x07030602);
+	return uint4{__builtin_amdgcn_perm(u2, u0, 0x05040100), __builtin_amdgcn_perm(u2, u0, 0x07060302), __builtin_amdgcn_perm(u3, u1, 0x05040100),
+	             __builtin_amdgcn_perm(u3, u1, 0x07060302)};
+}
+
+// NW waves per workgroup; with NTT the workgroup also holds the 64 KiB byte table (dynamic LDS), so it is made of eight waves.
+template <int C, bool NTT, int NW>
+__global__ __launch_bounds__(NW * 64, NTT ? 1 : 2) void k_fri_pass_multi(const uint4 *in, uint4 *out, uint64_t n_out, fri_levels<C> lv, const uint4 *d_mul8)
 {
 	constexpr int E = 1 << C, ROW = E + 1;
 	__shared__ ctable_smem tab[C];
 	__shared__ uint64_t s_basis[C][64];
-	__shared__ uint4 stage[256 * ROW];
+	__shared__ uint4 stage[NW * 64 * ROW];
+	extern __shared__ __attribute__((aligned(16))) uint8_t m8[]; // NTT: 65536 bytes
 #pragma unroll
 	for (int c = 0; c < C; c++) ctable_build(tab[c], lv.l[c].r);
 	if (threadIdx.x < 64) {
@@ -367,17 +418,20 @@ __global__ __launch_bounds__(256, 2) void k_fri_pass_multi(const uint4 *in, uint
 		for (int c = 0; c < C; c++)
 			s_basis[c][threadIdx.x] = (lv.l[c].s_row && (int)threadIdx.x < lv.l[c].n_bits) ? lv.l[c].s_row[threadIdx.x] : 0;
 	}
+	if constexpr (NTT) {
+		for (unsigned i = threadIdx.x; i < 4096; i += NW * 64) reinterpret_cast<uint4 *>(m8)[i] = d_mul8[i];
+	}
 	__syncthreads();
 	// Every WAVE works on its own blocks of 64 outputs (64 * E contiguous inputs) with its own slice of the stage and no
 	// workgroup barrier in the loop: the next block's inputs are requested (coalesced, into registers) before the current
-	// block is multiplied, and the four waves of a workgroup drift apart so that one's loads hide behind another's lookups.
+	// block is multiplied, and the waves of a workgroup drift apart so that one's loads hide behind another's lookups.
 	// (With a workgroup-wide stage and two barriers per block the counters showed the waves waiting 61 % of the time with the
 	// VALU 40 % and the LDS 50 % busy: 134 us for the pass that the three passes it replaces also took.)
 	const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	uint4 *wstage = stage + wave * 64 * ROW;
 	const uint64_t n_wblocks = (n_out + 63) / 64, n_in = n_out << C;
-	const uint64_t wstride = (uint64_t)gridDim.x * 4;
-	uint64_t b = (uint64_t)blockIdx.x * 4 + wave;
+	const uint64_t wstride = (uint64_t)gridDim.x * NW;
+	uint64_t b = (uint64_t)blockIdx.x * NW + wave;
 	uint4 pre[E];
 	auto fetch = [&](uint64_t blk) {
 		const uint64_t in0 = (blk * 64) << C;
@@ -420,7 +474,7 @@ __global__ __launch_bounds__(256, 2) void k_fri_pass_multi(const uint4 *in, uint
 							for (int bb = 0; bb < lv.l[c].n_bits; bb++)
 								if ((kk >> bb) & 1) t ^= s_basis[c][bb];
 							v = xor4(v, u);
-							u = xor4(u, to_u4(mul_walk<TW>(to_f128(v), t)));
+							u = xor4(u, mul_tw32_tab(m8, v, (uint32_t)t));
 						}
 						x[j] = xor4(u, ctable_mul<NTT ? 8 : 16>(tab[c], xor4(u, v)));
 						// two pairs at a time in the interleave-only passes, one at a time next to the butterflies: left alone
@@ -435,30 +489,50 @@ __global__ __launch_bounds__(256, 2) void k_fri_pass_multi(const uint4 *in, uint
 	}
 }
 
-template <int TW>
-hipError_t run_fri_multi(hipStream_t s, int C, unsigned g, const uint4 *src, uint4 *dst, uint64_t n_out, const fri_level *lv)
+// (twiddles of at most 32 bits: B8 / B16 / B32 NTT fields)
+hipError_t run_fri_multi(hipStream_t s, int n_cu, int C, const uint4 *src, uint4 *dst, uint64_t n_out, const fri_level *lv, const uint8_t *d_mul8)
 {
 	bool ntt = false;
 	for (int c = 0; c < C; c++) ntt = ntt || lv[c].s_row != nullptr;
-	if (C == 3) {
-		fri_levels<3> a{{lv[0], lv[1], lv[2]}};
-		if (ntt)
-			hipLaunchKernelGGL((k_fri_pass_multi<TW, 3, true>), dim3(g), dim3(256), 0, s, src, dst, n_out, a);
-		else
-			hipLaunchKernelGGL((k_fri_pass_multi<0, 3, false>), dim3(g), dim3(256), 0, s, src, dst, n_out, a);
+	const uint64_t n_wblocks = (n_out + 63) / 64;
+	if (ntt) {
+		static bool attr_done = false;
+		if (!attr_done) {
+			hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fri_pass_multi<2, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+			if (e != hipSuccess) return e;
+			e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fri_pass_multi<3, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+			if (e != hipSuccess) return e;
+			attr_done = true;
+		}
+		// one workgroup per CU (the byte table)
+		if (C == 3) {
+			const uint64_t want = (n_wblocks + 3) / 4;
+			const unsigned g = (unsigned)(want < (uint64_t)n_cu ? want : (uint64_t)n_cu);
+			fri_levels<3> a{{lv[0], lv[1], lv[2]}};
+			hipLaunchKernelGGL((k_fri_pass_multi<3, true, 4>), dim3(g), dim3(256), 65536, s, src, dst, n_out, a, (const uint4 *)d_mul8);
+		} else {
+			const uint64_t want = (n_wblocks + 7) / 8;
+			const unsigned g = (unsigned)(want < (uint64_t)n_cu ? want : (uint64_t)n_cu);
+			fri_levels<2> a{{lv[0], lv[1]}};
+			hipLaunchKernelGGL((k_fri_pass_multi<2, true, 8>), dim3(g), dim3(512), 65536, s, src, dst, n_out, a, (const uint4 *)d_mul8);
+		}
 	} else {
-		fri_levels<2> a{{lv[0], lv[1]}};
-		if (ntt)
-			hipLaunchKernelGGL((k_fri_pass_multi<TW, 2, true>), dim3(g), dim3(256), 0, s, src, dst, n_out, a);
-		else
-			hipLaunchKernelGGL((k_fri_pass_multi<0, 2, false>), dim3(g), dim3(256), 0, s, src, dst, n_out, a);
+		const uint64_t want = (n_wblocks + 3) / 4;
+		const unsigned g = (unsigned)(want < (uint64_t)n_cu * 2 ? want : (uint64_t)n_cu * 2); // two workgroups per CU (62 KiB of LDS each)
+		if (C == 3) {
+			fri_levels<3> a{{lv[0], lv[1], lv[2]}};
+			hipLaunchKernelGGL((k_fri_pass_multi<3, false, 4>), dim3(g), dim3(256), 0, s, src, dst, n_out, a, nullptr);
+		} else {
+			fri_levels<2> a{{lv[0], lv[1]}};
+			hipLaunchKernelGGL((k_fri_pass_multi<2, false, 4>), dim3(g), dim3(256), 0, s, src, dst, n_out, a, nullptr);
+		}
 	}
 	return hipGetLastError();
 }
 
 hipError_t launch_fri_fold(hipStream_t s, const uint64_t *d_s_evals, uint32_t tw_level, uint32_t log_domain,
                            uint32_t log_len, uint32_t log_batch, const f128 *h_challenges, uint32_t n_challenges,
-                           const void *in, void *out, uint64_t out_len, void *scratch)
+                           const void *in, void *out, uint64_t out_len, void *scratch, int n_cu, const uint8_t *d_mul8)
 {
 	// scratch holds two ping-pong buffers of in_len/2 elements each
 	const uint64_t in_len = out_len << n_challenges;
@@ -471,6 +545,10 @@ hipError_t launch_fri_fold(hipStream_t s, const uint64_t *d_s_evals, uint32_t tw
 		const char *e = getenv("BN_FRI_MULTI");
 		return !(e && e[0] == '0');
 	}();
+	static const bool ntt_c3 = [] {
+		const char *e = getenv("BN_FRI_NTT_C3"); // measurement knob: three levels per pass next to butterflies too
+		return e && e[0] == '1';
+	}();
 	uint32_t c = 0, pass = 0;
 	while (c < n_challenges) {
 		// challenges per pass: three at a time (then two, then one) while the pass is large enough to be a streaming pass
@@ -482,7 +560,7 @@ hipError_t launch_fri_fold(hipStream_t s, const uint64_t *d_s_evals, uint32_t tw
 			if (inter >= 2)
 				C = inter >= 3 ? 3 : 2;
 			else if (tw_level <= 5 && left >= 2)
-				C = 2;
+				C = (ntt_c3 && left >= 3) ? 3 : 2;
 		}
 		const uint64_t n_out = cur >> C;
 		uint4 *dst = (c + C == n_challenges) ? (uint4 *)out : ((pass & 1) ? buf1 : buf0);
@@ -511,15 +589,8 @@ hipError_t launch_fri_fold(hipStream_t s, const uint64_t *d_s_evals, uint32_t tw
 			}
 			e = hipGetLastError();
 		} else {
-			uint64_t want = (n_out + 255) / 256;
-			unsigned g = (unsigned)(want < 512 ? want : 512); // two workgroups per CU (62 KiB of LDS each)
-			switch (tw_level) {
-			case 3: e = run_fri_multi<3>(s, (int)C, g, src, dst, n_out, lv); break;
-			case 4: e = run_fri_multi<4>(s, (int)C, g, src, dst, n_out, lv); break;
-			case 5: e = run_fri_multi<5>(s, (int)C, g, src, dst, n_out, lv); break;
-			case 6: e = run_fri_multi<6>(s, (int)C, g, src, dst, n_out, lv); break;
-			default: return hipErrorInvalidValue;
-			}
+			if (tw_level < 3 || tw_level > 6) return hipErrorInvalidValue;
+			e = run_fri_multi(s, n_cu, (int)C, src, dst, n_out, lv, d_mul8);
 		}
 		if (e != hipSuccess) return e;
 		src = dst;
