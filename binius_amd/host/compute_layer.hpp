@@ -24,7 +24,9 @@
 // except O(1) protocol scalars through bn_scalar_mul.
 #pragma once
 
+#include <chrono>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <memory>
@@ -89,6 +91,33 @@ inline void check(int rc)
 {
 	if (rc != BN_OK)
 		throw Error(static_cast<Error::Kind>(rc), bn_last_error());
+}
+
+// BNH_PROF=1: time spent inside the C ABI, by kind of call (diagnostic: what is left of a prover's wall time is this mirror)
+struct AbiProf {
+	enum Kind { LAUNCH = 0, LINE = 1, COPY = 2, SCALAR = 3, N = 4 };
+	uint64_t ns[N] = {}, calls[N] = {};
+	static bool on()
+	{
+		static const bool v = getenv("BNH_PROF") != nullptr;
+		return v;
+	}
+	static AbiProf &get()
+	{
+		static thread_local AbiProf p;
+		return p;
+	}
+};
+template <class F>
+inline int abi_timed(AbiProf::Kind k, F &&f)
+{
+	if (!AbiProf::on()) return f();
+	const auto t0 = std::chrono::steady_clock::now();
+	const int rc = f();
+	AbiProf &p = AbiProf::get();
+	p.ns[k] += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+	p.calls[k]++;
+	return rc;
 }
 
 // ---------------------------------------------------------------------------------------- memory
@@ -505,8 +534,10 @@ public:
 		for (auto v : rets) ids.push_back(v.id);
 		std::vector<bn_f128> out(ids.size() ? ids.size() : 1);
 		auto &ops = ke.finish();
-		check(bn_kernel_launch(ctx_, raw.data(), (uint32_t)raw.size(), ops.data(), (uint32_t)ops.size(), ids.data(), (uint32_t)ids.size(),
-		                       (uint32_t)log_chunks, ids.empty() ? nullptr : out.data(), nullptr));
+		check(abi_timed(AbiProf::LAUNCH, [&] {
+			return bn_kernel_launch(ctx_, raw.data(), (uint32_t)raw.size(), ops.data(), (uint32_t)ops.size(), ids.data(), (uint32_t)ids.size(),
+			                        (uint32_t)log_chunks, ids.empty() ? nullptr : out.data(), nullptr);
+		}));
 		std::vector<OpValue> res;
 		for (size_t i = 0; i < ids.size(); i++) res.emplace_back(out[i].lo, out[i].hi);
 		return res;
@@ -640,7 +671,9 @@ private:
 				j++;
 			}
 			const bn_f128 zz = todo[i].z.raw(), hsr = hs.raw();
-			check(bn_extrapolate_line_batch_scaled(ctx_, e0.data(), e1.data(), (uint32_t)e0.size(), todo[i].len, &zz, mask, mask ? &hsr : nullptr));
+			check(abi_timed(AbiProf::LINE, [&] {
+				return bn_extrapolate_line_batch_scaled(ctx_, e0.data(), e1.data(), (uint32_t)e0.size(), todo[i].len, &zz, mask, mask ? &hsr : nullptr);
+			}));
 			i = j;
 		}
 	}
@@ -689,10 +722,13 @@ public:
 	void copy_h2d(const std::vector<B128> &src, FSliceMut &dst) { copy_h2d(src.data(), src.size(), dst); }
 	void copy_d2h(FSlice src, B128 *dst, size_t dst_len)
 	{
-		check(bn_copy_d2h(ctx_, src.ptr, src.len_, reinterpret_cast<bn_f128 *>(dst), dst_len));
+		check(abi_timed(AbiProf::COPY, [&] { return bn_copy_d2h(ctx_, src.ptr, src.len_, reinterpret_cast<bn_f128 *>(dst), dst_len); }));
 	}
 	void copy_d2h(FSlice src, std::vector<B128> &dst) { copy_d2h(src, dst.data(), dst.size()); }
-	void copy_d2d(FSlice src, FSliceMut &dst) { check(bn_copy_d2d(ctx_, src.ptr, src.len_, dst.ptr, dst.len_)); }
+	void copy_d2d(FSlice src, FSliceMut &dst)
+	{
+		check(abi_timed(AbiProf::COPY, [&] { return bn_copy_d2d(ctx_, src.ptr, src.len_, dst.ptr, dst.len_); }));
+	}
 	ExprEval compile_expr(const ArithCircuit &expr)
 	{
 		bn_expr *h = nullptr;

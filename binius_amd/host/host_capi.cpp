@@ -11,6 +11,7 @@
 #include <unistd.h>
 
 #include <atomic>
+#include <cstdio>
 #include <cerrno>
 #include <cstring>
 #include <thread>
@@ -233,6 +234,8 @@ int bnh_bivariate_sumcheck_prove(bn_ctx *ctx, uint32_t n_vars, uint32_t m, const
 		}
 		const B128 bc(batch_coeff->lo, batch_coeff->hi);
 		if (!reduce && !rccl_comm && !shm && !peer) {
+			const auto t_prof = std::chrono::steady_clock::now();
+			if (AbiProf::on()) AbiProf::get() = AbiProf{};
 			BivariateSumcheckProver prover(hal, dev_alloc, host_alloc, n_vars, comps, sv, mls);
 			for (uint32_t r = 0; r < n_vars; r++) {
 				std::vector<B128> rc = prover.execute(bc);
@@ -241,6 +244,13 @@ int bnh_bivariate_sumcheck_prove(bn_ctx *ctx, uint32_t n_vars, uint32_t m, const
 			}
 			std::vector<B128> fin = prover.finish();
 			for (uint32_t j = 0; j < m; j++) final_evals_out[j] = fin[j].raw();
+			if (AbiProf::on()) { // BNH_PROF=1: where the wall time of this prove went (us): inside the C ABI by kind of call, and the rest
+				const AbiProf &p = AbiProf::get();
+				const double tot = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_prof).count();
+				fprintf(stderr, "[bnh prof] n_vars %u: total %.2f us; kernel_launch %.2f (%llu calls), extrapolate_line %.2f (%llu), copies %.2f (%llu); outside the ABI %.2f\n",
+				        n_vars, tot, p.ns[0] / 1e3, (unsigned long long)p.calls[0], p.ns[1] / 1e3, (unsigned long long)p.calls[1], p.ns[2] / 1e3,
+				        (unsigned long long)p.calls[2], tot - (p.ns[0] + p.ns[1] + p.ns[2]) / 1e3);
+			}
 			return 0;
 		}
 		// sharded variant: same state machine, round evals combined across ranks by `reduce`

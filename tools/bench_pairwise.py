@@ -3,11 +3,9 @@ import json
 import sys
 import time
 
-import numpy as np
-
 sys.path.insert(0, ".")
 import binius_amd  # noqa: E402
-import oracle  # noqa: E402  (random inputs only)
+from binius_amd import synthetic  # noqa: E402
 
 
 def main():
@@ -15,7 +13,7 @@ def main():
         alloc = hal.dev_alloc()
         for log_n in ([int(v) for v in sys.argv[1:]] or [20, 16, 12, 6]):
             n = 1 << log_n
-            x = oracle.random_b128(0x77 + log_n, n)
+            x = synthetic.random_b128(0x77 + log_n, n)
             dx = alloc.alloc(n)
             hal.copy_h2d(x, dx)
             outs = [alloc.alloc(n >> (r + 1)) for r in range(log_n)]
