@@ -130,6 +130,11 @@ def main():
     exchange = os.environ.get("BN_EXCHANGE", "auto")
     import binius_amd
     from binius_amd import synthetic  # SplitMix64 input streams (numpy)
+
+    # the thread that drives the context runs on the NUMA node the device hangs off (every small round is a host -> device ->
+    # host round trip; from the other socket each one crosses the socket interconnect too: 15.0 -> 17.1 us per two-round
+    # launch).  Before the context is created, so that its pinned mailboxes are allocated there as well.  BN_BIND_NUMA=0: off.
+    host_affinity = "unchanged (BN_BIND_NUMA=0)" if os.environ.get("BN_BIND_NUMA") == "0" else binius_amd.bind_host_thread_to_device(local_rank)
     from binius_amd._host import PeerExchange, RcclComm, ShmExchange, SumcheckPlan
 
     m = 2
@@ -503,6 +508,7 @@ def main():
             "n_vars_local": n_vars,
             "n_vars_global": n_global,
             "multilinears": m,
+            "host_affinity": host_affinity,
             "sharding": ("low index bits (last-bound variables), one 32-byte exchange per round: "
                          + {"peer": "device mailboxes (every rank's finalize step stores its partial into every peer's hipIpc-mapped mailbox and XORs the world's)",
                             "shm": "host shared memory", "rccl": "RCCL all_gather on the context's stream + device XOR"}[exchange.split(" ")[0]]

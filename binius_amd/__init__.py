@@ -15,6 +15,8 @@ from ._ffi import (  # noqa: F401
     BumpAllocator,
     Expr,
     HostField,
+    bind_host_thread_to_device,
+    device_numa_node,
     lib,
     lib_path,
     log_chunks_range,

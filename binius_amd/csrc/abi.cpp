@@ -1117,6 +1117,23 @@ int bn_host_scratch(bn_ctx *ctx, void **h_ptr, void **d_ptr, uint64_t *elems)
 	return BN_OK;
 }
 
+int bn_device_numa_node(int device, int *node)
+{
+	BN_REQUIRE(node, "null argument");
+	*node = -1;
+	char bdf[64] = {0};
+	BN_HIP(hipDeviceGetPCIBusId(bdf, (int)sizeof(bdf) - 1, device));
+	for (char *c = bdf; *c; c++)
+		if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a'); // sysfs spells the address in lower case
+	const std::string path = std::string("/sys/bus/pci/devices/") + bdf + "/numa_node";
+	if (FILE *f = fopen(path.c_str(), "r")) {
+		int v = -1;
+		if (fscanf(f, "%d", &v) == 1) *node = v;
+		fclose(f);
+	}
+	return BN_OK;
+}
+
 // XOR of n_groups device vectors of group_len (<= 64) elements, returned to the host through the
 // zero-copy mailbox.  Not part of the reference interface: it is the combine step behind the
 // per-round all_gather of the sharded prover (binius_amd/host/host_capi.cpp).

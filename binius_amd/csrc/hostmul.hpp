@@ -2,10 +2,11 @@
 // coefficient algebra of the old-HAL routing): the tower recursion of pairwise_recursive_arithmetic.rs:18-28 as
 // Karatsuba down to GF(2^8), whose 256 x 256 products come from a table built once from the bilinear walk
 // (gf128.hpp mul_walk<3>).  81 table look-ups + ~600 word operations instead of the walk's 127 mulx steps:
-// ~0.2 us instead of ~0.9 us.  A small round of the sumcheck costs the caller three of these (evaluate_univariate,
+// ~0.2 us instead of ~0.9 us (mul_host_table); on hosts with PCLMULQDQ mul_host takes the route of hostmul_clmul.cpp instead.  A small round of the sumcheck costs the caller three of these (evaluate_univariate,
 // powers of the batching coefficient), which is a tenth of the round once the launch is off the critical path (arm.hpp).
 #pragma once
 #include <cstdint>
+#include <cstdlib>
 #include <memory>
 
 #include "gf128.hpp"
@@ -49,7 +50,7 @@ inline uint64_t hostmul_k(const hostmul_table &tb, uint64_t a, uint64_t b)
 	}
 }
 
-inline f128 mul_host(f128 a, f128 b)
+inline f128 mul_host_table(f128 a, f128 b)
 {
 	const hostmul_table &tb = hostmul_tab();
 	const uint64_t z0 = hostmul_k<6>(tb, a.lo, b.lo);
@@ -57,6 +58,20 @@ inline f128 mul_host(f128 a, f128 b)
 	const uint64_t z1 = hostmul_k<6>(tb, a.lo ^ a.hi, b.lo ^ b.hi);
 	const uint64_t lo = z0 ^ z2;
 	return f128{lo, z1 ^ lo ^ mulx64<5>(z2)};
+}
+
+// The same product through PCLMULQDQ in an isomorphic power basis (hostmul_clmul.cpp: ~50 ns); available after its start-up
+// self-check against mul_host_table on a host that has the instruction.  BN_HOSTMUL=table keeps the table form.
+bool hostmul_clmul_available();
+f128 mul_host_clmul(f128 a, f128 b);
+
+inline f128 mul_host(f128 a, f128 b)
+{
+	static const bool fast = [] {
+		const char *e = getenv("BN_HOSTMUL");
+		return !(e && e[0] == 't') && hostmul_clmul_available();
+	}();
+	return fast ? mul_host_clmul(a, b) : mul_host_table(a, b);
 }
 
 } // namespace bn

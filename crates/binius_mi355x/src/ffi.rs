@@ -302,6 +302,7 @@ unsafe extern "C" {
 	pub fn bn_timer_begin(ctx: *mut bn_ctx) -> c_int;
 	pub fn bn_timer_end_ms(ctx: *mut bn_ctx, ms: *mut f32) -> c_int;
 	pub fn bn_host_scratch(ctx: *mut bn_ctx, h_ptr: *mut *mut c_void, d_ptr: *mut *mut c_void, elems: *mut u64) -> c_int;
+	pub fn bn_device_numa_node(device: c_int, node: *mut c_int) -> c_int;
 	pub fn bn_xor_reduce(ctx: *mut bn_ctx, d_vals: *const c_void, n_groups: u32, group_len: u32, h_out: *mut bn_f128) -> c_int;
 	pub fn bn_prof_begin(ctx: *mut bn_ctx) -> c_int;
 	pub fn bn_prof_end(ctx: *mut bn_ctx, ms_by_class: *mut f64, launches_by_class: *mut u64) -> c_int;

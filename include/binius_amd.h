@@ -245,6 +245,12 @@ int bn_timer_end_ms(bn_ctx *ctx, float *ms);
 /* 32 elements of fine-grained pinned host memory, readable by kernels through *d_ptr: a handful of
  * elements can be handed to the device without an upload.  Not part of the reference interface. */
 int bn_host_scratch(bn_ctx *ctx, void **h_ptr, void **d_ptr, uint64_t *elems);
+/* NUMA node of the host the device hangs off (its PCI function's numa_node in sysfs), -1 if the platform does not say.
+ * A small round is a host -> device -> host round trip (the armed kernels of csrc/arm.hpp poll pinned host memory and
+ * answer into it): from a core of the other socket every such trip crosses the socket interconnect as well -- measured
+ * 15.0 against 17.1 us per two-round launch on a 2-socket host -- so the thread that drives a context should run on this
+ * node.  The library never changes an affinity itself.  Not part of the reference interface. */
+int bn_device_numa_node(int device, int *node);
 
 /* out[i] = XOR over g < n_groups of d_vals[g * group_len + i], i < group_len <= 64, returned to the
  * host.  Not part of the reference interface: the combine step behind the per-round all_gather of

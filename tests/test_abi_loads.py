@@ -66,6 +66,31 @@ def test_host_scalar_field_matches_oracle(ffi, oracle):
     assert ffi.HostField.invert(0) == 0
 
 
+def test_host_scalar_field_table_route_matches_oracle():
+    """The same checks with BN_HOSTMUL=table (csrc/hostmul.hpp's Karatsuba-to-bytes form, the route of hosts without
+    PCLMULQDQ); the default route of this host is whatever csrc/hostmul_clmul.cpp's self-check allowed.  A fresh process:
+    the route is chosen at the first product."""
+    import subprocess
+    import sys
+
+    code = (
+        "import random, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "import oracle\n"
+        "from binius_amd._ffi import HostField as F\n"
+        "rng = random.Random(11)\n"
+        "cases = [(0, 5), (1, 1), ((1 << 128) - 1, (1 << 128) - 1)] + [(1 << i, rng.getrandbits(128)) for i in range(128)]\n"
+        "cases += [(rng.getrandbits(128), rng.getrandbits(128)) for _ in range(1500)]\n"
+        "assert all(F.mul(a, b) == oracle.mul(a, b) for a, b in cases)\n"
+        "assert all(F.mul(a, F.invert(a)) == 1 for a, _ in cases[3:200])\n"
+        "print('ok')\n"
+    ) % ROOT
+    for route in ("table", "clmul"):
+        env = dict(os.environ, BN_HOSTMUL=route)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0 and out.stdout.strip() == "ok", (route, out.stderr[-2000:])
+
+
 def test_twiddle_basis_matches_oracle(ffi, oracle):
     import numpy as np
 

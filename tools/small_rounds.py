@@ -11,6 +11,10 @@ from binius_amd._host import SumcheckPlan  # noqa: E402
 
 
 def main():
+    import os
+
+    if os.environ.get("BN_BIND_NUMA") != "0":
+        print("host thread:", binius_amd.bind_host_thread_to_device(0), file=sys.stderr)
     hal = binius_amd.Context(0, 1 << 16)
     for n_vars in (4, 8, 12):
         alloc = hal.dev_alloc()
