@@ -22,6 +22,8 @@ while n_arities * a.arity >= log_msg: n_arities -= 1
 p = FRIParams(a.log_dim, a.log_inv_rate, a.log_batch, [a.arity] * n_arities, n_test_queries=100)
 n_msg = 1 << log_msg
 n_code = n_msg << a.log_inv_rate
+if __import__("os").environ.get("BN_BIND_NUMA") != "0":
+    binius_amd.bind_host_thread_to_device(0)  # (the driving thread on the device's NUMA node)
 hal = binius_amd.Context(0, n_msg + 3 * n_code + (1 << 16))
 base = hal.dev_alloc()
 d_msg = base.alloc(n_msg)

@@ -14,6 +14,8 @@ ap.add_argument("--steps", type=int, default=5)
 a = ap.parse_args()
 n_vars, m = a.n_vars, 2
 n = 1 << n_vars
+if __import__("os").environ.get("BN_BIND_NUMA") != "0":
+    binius_amd.bind_host_thread_to_device(0)  # (the driving thread on the device's NUMA node)
 hal = binius_amd.Context(0, m * n + (m + 2) * (n // 2) + 4096)
 alloc = hal.dev_alloc()
 d = []

@@ -13,6 +13,8 @@ ap.add_argument("--log-n", type=int, default=24)
 ap.add_argument("--reps", type=int, default=5)
 a = ap.parse_args()
 n = 1 << a.log_n
+if __import__("os").environ.get("BN_BIND_NUMA") != "0":
+    binius_amd.bind_host_thread_to_device(0)  # (the driving thread on the device's NUMA node)
 hal = binius_amd.Context(0, 5 * n + (1 << 16))
 alloc = hal.dev_alloc()
 A, B, Cc, D = (alloc.alloc(n) for _ in range(4))

@@ -4,6 +4,13 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/final
 rm -rf $O; mkdir -p $O
 cd $R
+# HBM traffic first: bench.py only quotes a PMC file taken on the kernel sources it runs (csrc_sha16), and the benches below
+# should carry it -- so the fresh file is put where bench.py looks for it (on the box; the committed copy comes back through
+# gpurun_out/final/bench_pmc.json)
+BUILD=$(cat $R/tools/.build_id 2>/dev/null || python -c "import bench; print(bench.csrc_sha16())")
+tools/pmc_bench.sh $BUILD 28 24 > $O/pmc_bench.log 2>&1
+cp $R/gpurun_out/bench_pmc.json $O/bench_pmc.json
+cp $R/gpurun_out/bench_pmc.json $R/profiles/r03/bench_pmc.json
 python bench.py > $O/bench_n28.json 2> $O/bench_n28.stderr
 python bench.py --n-vars 24 --steps 5 --warmup 2 > $O/bench_n24.json 2> $O/bench_n24.stderr
 python bench.py --n-vars 25 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_n25_one_shard_of_eight.json 2>/dev/null
@@ -17,6 +24,13 @@ python tools/profile_ntt.py --reps 3 > $O/ntt_2p24_b32.txt 2>&1
 python tools/bench_fri_commit.py > $O/fri_commit.jsonl 2>&1
 python tools/small_rounds.py > $O/small_rounds.jsonl 2>&1
 BN_TWO_ROUND=0 python tools/small_rounds.py > $O/small_rounds_BN_TWO_ROUND_0.jsonl 2>&1
+BN_TWO_ROUND_MAX_LOG2=18 python tools/small_rounds.py > $O/small_rounds_BN_TWO_ROUND_MAX_LOG2_18.jsonl 2>&1
+python tools/bench_pairwise.py > $O/pairwise.jsonl 2>&1
+BN_PAIRTREE_MAX_LOG2=0 python tools/bench_pairwise.py 20 > $O/pairwise_BN_PAIRTREE_MAX_LOG2_0.jsonl 2>&1
+tools/trace_cmd.sh final/trace_pair python tools/bench_pairwise.py 20 > /dev/null 2>&1; tail -8 $O/trace_pair/per_launch.jsonl > $O/pairwise_per_launch.jsonl; rm -rf $O/trace_pair
+tools/trace_cmd.sh final/trace_fri python tools/run_fri_only.py > /dev/null 2>&1; tail -3 $O/trace_fri/per_launch.jsonl > $O/fri_fold_per_launch.jsonl; rm -rf $O/trace_fri
+{ for L in 16 17 18; do echo "== BN_TWO_ROUND_MAX_LOG2=$L"; for n in 20 24 25; do BN_TWO_ROUND_MAX_LOG2=$L python bench.py --n-vars $n --steps 20 --warmup 3 --no-cpu-baseline --no-prof 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('n=$n L=$L ms_per_step', d['ms_per_step'], d['verifier_check'], d['transcript_digest'])"; done; done
+  echo "== BN_TWO_ROUND=0"; for n in 20 24 25; do BN_TWO_ROUND=0 python bench.py --n-vars $n --steps 20 --warmup 3 --no-cpu-baseline --no-prof 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('n=$n off ms_per_step', d['ms_per_step'], d['verifier_check'], d['transcript_digest'])"; done; } > $O/two_round_step_times.txt 2>&1
 tools/two_round_phases > $O/two_round_phases.txt 2>&1
 tools/small_round_phases > $O/small_round_phases.txt 2>&1
 python tools/bench_hal.py > $O/hal.jsonl 2>&1
@@ -30,7 +44,4 @@ for W in 2 4 8; do
   BN_ALL_ON_GPU0=1 BN_PG_BACKEND=gloo timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node $W --master-addr 127.0.0.1 --master-port 2971$W bench.py --gpus $W --n-vars 13 --steps 50 --warmup 5 --no-cpu-baseline --no-prof 2>/dev/null | grep '^{' > $O/bench_${W}_ranks_on_one_gpu_n13.json
 done
 BN_ALL_ON_GPU0=1 BN_PG_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29719 bench.py --gpus 8 --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | grep '^{' > $O/bench_8_ranks_on_one_gpu_n28.json
-BUILD=$(cat $R/tools/.build_id 2>/dev/null || python -c "import bench; print(bench.csrc_sha16())")
-tools/pmc_bench.sh $BUILD 28 24 > $O/pmc_bench.log 2>&1
-cp $R/gpurun_out/bench_pmc.json $O/bench_pmc.json
 tail -c 700 $O/bench_n28.json
