@@ -1,7 +1,6 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_sumcheck.py tests/test_gpu_two_round.py tests/test_gpu_mlecheck_shadow.py tests/test_gpu_multirank.py tests/test_gpu_sharded_vs_oracle.py -x -q 2>&1 | tail -2
-for i in 1 2 3; do
- echo "two-stage $(python tools/small_rounds.py 2>/dev/null | tail -1 | cut -c1-190)"
- echo "one-stage $(BN_ARM_TWO_STAGE=0 python tools/small_rounds.py 2>/dev/null | tail -1 | cut -c1-190)"
-done
-for i in 1 2 3; do for n in 24 25; do python bench.py --n-vars $n --steps 20 --warmup 3 --no-cpu-baseline --no-prof 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('n$n two-stage', d['ms_per_step'], d['verifier_check'])"; BN_ARM_TWO_STAGE=0 python bench.py --n-vars $n --steps 20 --warmup 3 --no-cpu-baseline --no-prof 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('n$n one-stage', d['ms_per_step'])"; done; done
+timeout 900 python -m pytest tests/test_gpu_layer.py tests/test_gpu_at_size.py tests/test_gpu_fri.py tests/test_gpu_cpp_conformance.py -x -q -k "fri or conformance" 2>&1 | tail -2
+python tools/bench_ops.py 2>&1 | grep -i "fri"
+BN_FRI_SIX=0 python tools/bench_ops.py 2>&1 | grep -i "fri"
+tools/trace_cmd.sh r3f/trace_fri python tools/run_fri_only.py; tail -3 gpurun_out/r3f/trace_fri/per_launch.jsonl
+python tools/bench_fri_commit.py 2>&1 | tail -1 | cut -c1-300
