@@ -182,20 +182,31 @@ __global__ __launch_bounds__(TH) void k_fold_tab(const uint64_t *mat, const uint
 					uint4 t[KG * P];
 #pragma unroll
 					for (int kk = 0; kk < KG; kk++) {
-						const bool on = g0 + k + kk < jn; // (beyond the chunk: entry 0 of table 0, masked below)
+						const bool on = g0 + k + kk < jn; // (beyond the chunk: mm = 0 -> entry 0 of table 0 = vec * 0 = 0)
 						const char *tb = reinterpret_cast<const char *>(T + (on ? (g0 + k + kk) : 0) * P * 16);
+						// nibble * 16 of every nibble in one instruction each (ctable.hpp: a rotate by four puts the even nibbles
+						// where the odd ones are, an SDWA byte-select masks the high nibble of a byte in place)
+						const uint32_t hi = mm[k + kk], lo = __builtin_amdgcn_alignbit(hi, hi, 28);
+						uint32_t off[8];
+						off[0] = byte_and<0>(lo, 0xF0u);
+						off[1] = byte_and<0>(hi, 0xF0u);
+						off[2] = byte_and<1>(lo, 0xF0u);
+						off[3] = byte_and<1>(hi, 0xF0u);
+						off[4] = byte_and<2>(lo, 0xF0u);
+						off[5] = byte_and<2>(hi, 0xF0u);
+						off[6] = byte_and<3>(lo, 0xF0u);
+						off[7] = byte_and<3>(hi, 0xF0u);
 #pragma unroll
-						for (int p = 0; p < P; p++) {
-							const uint32_t off = ((mm[k + kk] >> (4 * p)) & 15u) << 4;
-							t[kk * P + p] = *reinterpret_cast<const uint4 *>(tb + p * 256 + off);
-						}
+						for (int p = 0; p < P; p++) t[kk * P + p] = *reinterpret_cast<const uint4 *>(tb + p * 256 + off[p]);
 					}
 					__builtin_amdgcn_sched_barrier(0);
+					// (KG * P = 16 lookups, folded two at a time with the three-input XOR)
 #pragma unroll
-					for (int kk = 0; kk < KG; kk++) {
-						if (g0 + k + kk >= jn) break; // (mm = 0 there anyway, but table 0's entry 0 is vec * 0 = 0 too)
-#pragma unroll
-						for (int p = 0; p < P; p++) acc[r] = xor4(acc[r], t[kk * P + p]);
+					for (int q = 0; q < KG * P; q += 2) {
+						acc[r].x = ct_xor3(acc[r].x, t[q].x, t[q + 1].x);
+						acc[r].y = ct_xor3(acc[r].y, t[q].y, t[q + 1].y);
+						acc[r].z = ct_xor3(acc[r].z, t[q].z, t[q + 1].z);
+						acc[r].w = ct_xor3(acc[r].w, t[q].w, t[q + 1].w);
 					}
 				}
 			}
