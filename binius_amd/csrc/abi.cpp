@@ -441,6 +441,7 @@ int bn_ctx_create(int device, uint64_t arena_elems, bn_ctx **out)
 	if (const char *a = getenv("BN_MLECHECK_SHADOW")) ctx->shadow_enabled = atoi(a) != 0;
 	BN_HIP(hipMalloc((void **)&ctx->d_flag, sizeof(unsigned)));
 	BN_HIP(hipMemset(ctx->d_flag, 0, sizeof(unsigned)));
+	BN_HIP(hipMalloc((void **)&ctx->d_s_evals, sizeof(uint64_t) * BN_NTT_MAX_DIM * BN_NTT_MAX_DIM));
 	BN_HIP(hipMalloc((void **)&ctx->d_mul8, 65536));
 	BN_HIP(bn::launch_build_mul8(ctx->stream, ctx->d_mul8));
 	if (arena_elems) {
@@ -592,6 +593,7 @@ int bn_ctx_destroy(bn_ctx *ctx)
 	if (ctx->scratch) hipFree(ctx->scratch);
 	if (ctx->d_result) hipFree(ctx->d_result);
 	if (ctx->d_mul8) hipFree(ctx->d_mul8);
+	if (ctx->d_s_evals) hipFree(ctx->d_s_evals);
 	if (ctx->d_ticket) hipFree(ctx->d_ticket);
 	if (ctx->h_result) hipHostFree(ctx->h_result);
 	if (ctx->h_mail) hipHostFree(ctx->h_mail);

@@ -78,16 +78,25 @@ int bn_fold_right(bn_ctx *ctx, const void *d_mat, uint64_t mat_len, uint32_t tow
 	return fold_common(ctx, false, d_mat, mat_len, tower_level, d_vec, vec_len, d_out, out_len);
 }
 
+// The twiddle basis of the caller's NTT instance on the device (d_out) + `extra_bytes` of scratch (extra).  The basis is
+// caller-owned pageable memory that does not change between the calls of one instance: it is compared with the copy of the
+// last call (8 KiB) and uploaded -- one synchronisation -- only when it differs.
 static int upload_s_evals(bn_ctx *ctx, const uint64_t *h_s_evals, uint64_t **d_out, size_t extra_bytes, void **extra)
 {
-	const size_t sb = sizeof(uint64_t) * BN_NTT_MAX_DIM * BN_NTT_MAX_DIM;
-	char *scr = (char *)bn::ctx_scratch(ctx, sb + extra_bytes);
-	if (!scr)
-		return bn::fail(BN_ERR_ALLOC, "allocation error: allocator is out of memory (scratch)");
-	BN_HIP(hipMemcpyAsync(scr, h_s_evals, sb, hipMemcpyHostToDevice, ctx->stream));
-	BN_HIP(hipStreamSynchronize(ctx->stream)); // h_s_evals is caller-owned pageable memory
-	*d_out = (uint64_t *)scr;
-	if (extra) *extra = scr + sb;
+	constexpr size_t words = (size_t)BN_NTT_MAX_DIM * BN_NTT_MAX_DIM;
+	if (ctx->h_s_evals.size() != words || memcmp(ctx->h_s_evals.data(), h_s_evals, words * sizeof(uint64_t)) != 0) {
+		// (kernels of earlier calls that still read the old basis are ahead of the copy on the same stream)
+		ctx->h_s_evals.assign(h_s_evals, h_s_evals + words);
+		BN_HIP(hipMemcpyAsync(ctx->d_s_evals, ctx->h_s_evals.data(), words * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+		BN_HIP(hipStreamSynchronize(ctx->stream)); // (the source is pageable: the runtime may still be reading it)
+	}
+	*d_out = ctx->d_s_evals;
+	if (extra) {
+		char *scr = (char *)bn::ctx_scratch(ctx, extra_bytes);
+		if (!scr)
+			return bn::fail(BN_ERR_ALLOC, "allocation error: allocator is out of memory (scratch)");
+		*extra = scr;
+	}
 	return BN_OK;
 }
 

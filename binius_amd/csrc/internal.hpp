@@ -44,6 +44,8 @@ struct bn_ctx {
 	uint64_t mail_seq = 0;
 	bool s_clean = false;              // accumulator slots d_result[0..64) known to be zero
 	uint8_t *d_mul8 = nullptr;         // 64 KiB GF(2^8) product table (tiled NTT)
+	uint64_t *d_s_evals = nullptr;     // the twiddle basis last handed to bn_ntt_* / bn_fri_fold (BN_NTT_MAX_DIM^2 words) ...
+	std::vector<uint64_t> h_s_evals;   // ... and its host copy: an NTT instance's basis is uploaded once, not per call
 	unsigned *d_ticket = nullptr;      // device-scope ticket counter for the fused finalize
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	int n_cu = 256;
