@@ -226,8 +226,8 @@ static hipError_t run_fold_tab(hipStream_t s, const void *mat, const void *vec, 
 	constexpr int NB = 1 << IOTA, P = NB / 4, J = 256 / P;
 	const size_t lds = 65536 + (size_t)J * NB * 16;
 	const uint64_t blocks = (out_len + TH * R - 1) / (TH * R);
-	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fold_tab<IOTA, LEFT, R, TH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-	if (e != hipSuccess) return e;
+	static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fold_tab<IOTA, LEFT, R, TH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); // (once per instantiation)
+	if (attr != hipSuccess) return attr;
 	hipLaunchKernelGGL((k_fold_tab<IOTA, LEFT, R, TH>), dim3((unsigned)blocks), dim3(TH), lds, s, (const uint64_t *)mat, (const uint4 *)vec, vec_len,
 	                   (uint4 *)out, out_len);
 	return hipGetLastError();
