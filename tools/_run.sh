@@ -1,6 +1,6 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_layer.py tests/test_gpu_at_size.py tests/test_gpu_fri.py tests/test_gpu_ntt.py tests/test_gpu_cpp_conformance.py -x -q -k "fri or conformance or ntt" 2>&1 | tail -2
-for n in 0 1 2 3; do echo "L1 lookups $n: $(BN_FRI_L1_LOOKUPS=$n python tools/bench_ops.py 2>&1 | grep -i 'fri' | cut -c1-120)"; done
-tools/trace_cmd.sh r3f/trace_fri python tools/run_fri_only.py; tail -3 gpurun_out/r3f/trace_fri/per_launch.jsonl
-python tools/bench_fri_commit.py 2>&1 | tail -1 | cut -c1-300
-python tools/bench_ops.py 2>&1 | grep -i "ntt"
+mkdir -p gpurun_out
+timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -3 > gpurun_out/pytest_gpu.log
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1 >> gpurun_out/pytest_gpu.log
+bash tools/final_measure.sh > gpurun_out/final_measure.log 2>&1
+cat gpurun_out/pytest_gpu.log
