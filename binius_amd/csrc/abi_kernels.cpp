@@ -259,6 +259,18 @@ int two_round_launch(bn_ctx *ctx, const two_round_req &rq, const bn::fin_fuse &f
 	vals[fz.args.terms[0].value] ^= E[0] ^ E[2];
 	vals[fz.args.terms[1].value] ^= E[1] ^ E[3];
 	for (uint32_t r = 0; r < n_ret; r++) h_out[r] = bn_f128{vals[ret_values[r]].lo, vals[ret_values[r]].hi};
+	ctx->fin_y.valid = false;
+	if (rq.m == 4 && f8.peer.world <= 1) {
+		// the last launch of this sumcheck: the kernel left Y's four elements per array in the mailbox (slots 32 .. 39)
+		for (int j = 0; j < 2; j++) {
+			ctx->fin_y.lo[j] = rq.lo[j];
+			for (int q = 0; q < 4; q++) {
+				ctx->fin_y.y[j][q].lo = __atomic_load_n(&ctx->h_mail[32 + 4 * j + q].lo, __ATOMIC_RELAXED);
+				ctx->fin_y.y[j][q].hi = __atomic_load_n(&ctx->h_mail[32 + 4 * j + q].hi, __ATOMIC_RELAXED);
+			}
+		}
+		ctx->fin_y.valid = true;
+	}
 	bn_ctx::precomp_state &pre = ctx->pre;
 	pre.valid = true;
 	pre.consumed = false;

@@ -136,10 +136,20 @@ struct bn_ctx {
 	// device memory; mailbox slot = off + i for element i of [ptr, ptr + n)
 	struct mirror_state {
 		bool valid = false;
+		bool host = false; // the values were computed on the host (host_vals): nothing to wait for
 		uint64_t seq = 0;
 		uint32_t count = 0, n = 0;
 		const void *ptr[8] = {};
+		bn::f128 host_vals[8] = {};
 	} mirror;
+	// The four elements per array that the LAST two-round launch of a sumcheck leaves (kernels_foldeval8.hip publishes them
+	// beside its sums): the two folds that remain are six host products, so the caller's read of the final evaluations does
+	// not wait for the kernel that performs them on the device (it is launched all the same: memory ends up as always).
+	struct final_y_state {
+		bool valid = false;
+		const void *lo[2] = {};
+		bn::f128 y[2][4] = {};
+	} fin_y;
 	void *ntt_cache = nullptr; // bn::ntt_bs_cache (allocated on first use)
 	// all-ones | all-zeros tables of the old HAL's routed round evaluation (abi_hal.cpp): filled once per size, kept
 	void *hal_const = nullptr;

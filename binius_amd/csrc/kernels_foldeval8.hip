@@ -241,6 +241,14 @@ __global__ __launch_bounds__(512, 1) void k_foldeval8(foldeval8_args fa, f128 z1
 		if constexpr (NF >= 1) ((uint4 *)fa.out[arr])[i] = y;
 		if constexpr (NF == 2) ((uint4 *)fa.out[arr])[i + m] = u_hi; // memory ends up exactly as after two separate in-place folds
 		stage[(arr * 4 + qt) * kRowsPad + lane] = y;
+		if (m == 4 && fz.mail) {
+			// the last launch of a sumcheck: Y is four elements per array -- the host folds them itself (six products) when the
+			// caller reads the final evaluations; published before the sequence number (drained below, a barrier follows)
+			f128 *slot = fz.mail + 32 + arr * 4 + qt;
+			__hip_atomic_store(&slot->lo, (uint64_t)y.x | ((uint64_t)y.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			__hip_atomic_store(&slot->hi, (uint64_t)y.z | ((uint64_t)y.w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		}
 	}
 	fin_commit(fz, fpre, fcache);
 	__syncthreads();
