@@ -1,4 +1,6 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_layer.py tests/test_gpu_at_size.py tests/test_gpu_cpp_conformance.py -x -q -k "fold or conformance" 2>&1 | tail -2
-python tools/bench_ops.py 2>&1 | grep -i "fold_r"
-BN_LINMAP=0 python tools/bench_ops.py 2>&1 | grep -i "fold_r"
+mkdir -p gpurun_out
+timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -3 > gpurun_out/pytest_gpu.log
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1 >> gpurun_out/pytest_gpu.log
+bash tools/final_measure.sh > gpurun_out/final_measure.log 2>&1
+cat gpurun_out/pytest_gpu.log
