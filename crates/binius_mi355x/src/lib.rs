@@ -115,6 +115,16 @@ impl Mi355xLayer {
 	pub fn sync(&self) -> Result<(), Error> {
 		check(unsafe { ffi::bn_sync(self.ctx) })
 	}
+
+	/// NUMA node of the host that `device` hangs off, if the platform says.  The thread that drives a context should run
+	/// there: a small sumcheck round is a host -> device -> host round trip through pinned memory, and from the other
+	/// socket of a 2-socket host every one of them also crosses the socket interconnect.  The
+	/// library does not touch affinities; bind the prover thread with `sched_setaffinity` / `hwloc` before creating the layer.
+	pub fn device_numa_node(device: i32) -> Result<Option<u32>, Error> {
+		let mut node: std::os::raw::c_int = -1;
+		check(unsafe { ffi::bn_device_numa_node(device, &mut node) })?;
+		Ok(if node >= 0 { Some(node as u32) } else { None })
+	}
 }
 
 impl Default for Mi355xLayer {

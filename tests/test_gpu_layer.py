@@ -551,3 +551,23 @@ def test_fresh_thread_allocating_entry_points(oracle):
     assert out == {"ntt": True, "ip": True}, out
 
 
+
+
+def test_device_numa_node_and_thread_binding(hal):
+    """bn_device_numa_node reads the device's PCI function from sysfs; the helper only ever narrows the affinity."""
+    import os
+
+    import binius_amd
+
+    node = binius_amd.device_numa_node(0)
+    assert node is None or (isinstance(node, int) and node >= 0)
+    before = os.sched_getaffinity(0)
+    try:
+        what = binius_amd.bind_host_thread_to_device(0)
+        after = os.sched_getaffinity(0)
+        assert after <= before and len(after) >= 1
+        if node is not None and what.startswith("NUMA node"):
+            cpus = open("/sys/devices/system/node/node%d/cpulist" % node).read().strip()
+            assert what == "NUMA node %d (%d CPUs)" % (node, len(after)) and cpus
+    finally:
+        os.sched_setaffinity(0, before)
