@@ -215,7 +215,10 @@ def bind_host_thread_to_device(device=0):
     done; never widens the current affinity, does nothing when the node or its CPU list is unknown."""
     import os
 
-    node = device_numa_node(device)
+    try:
+        node = device_numa_node(device)
+    except Exception as ex:  # (a measurement convenience must never be the reason a run fails)
+        return "unchanged (%s)" % type(ex).__name__
     if node is None or not hasattr(os, "sched_setaffinity"):
         return "unchanged (no NUMA information for the device)"
     try:
@@ -223,16 +226,22 @@ def bind_host_thread_to_device(device=0):
     except OSError:
         return "unchanged (node %d has no cpulist)" % node
     cpus = set()
-    for part in txt.split(","):
-        if "-" in part:
-            a, b = part.split("-")
-            cpus.update(range(int(a), int(b) + 1))
-        elif part:
-            cpus.add(int(part))
-    want = cpus & os.sched_getaffinity(0)
-    if not want:
-        return "unchanged (none of node %d's CPUs are allowed to this process)" % node
-    os.sched_setaffinity(0, want)
+    try:
+        for part in txt.split(","):
+            if "-" in part:
+                a, b = part.split("-")
+                cpus.update(range(int(a), int(b) + 1))
+            elif part:
+                cpus.add(int(part))
+    except ValueError:
+        return "unchanged (unreadable cpulist of node %d)" % node
+    try:
+        want = cpus & os.sched_getaffinity(0)
+        if not want:
+            return "unchanged (none of node %d's CPUs are allowed to this process)" % node
+        os.sched_setaffinity(0, want)
+    except OSError as ex:
+        return "unchanged (sched_setaffinity: %s)" % ex
     return "NUMA node %d (%d CPUs)" % (node, len(want))
 
 
