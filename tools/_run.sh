@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
-tools/trace_cmd.sh r3f/trace_fold python tools/run_fold_only.py; tail -4 gpurun_out/r3f/trace_fold/per_launch.jsonl
-tools/pmc_cmd.sh r3f/pmc_fold python tools/run_fold_only.py 2>&1 | tail -12
+timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
