@@ -422,8 +422,25 @@ __global__ __launch_bounds__(NW * 64, NTT ? 1 : 2) void k_fri_pass_multi(const u
 	__shared__ uint64_t s_basis[C][64];
 	__shared__ uint4 stage[NW * 64 * ROW];
 	extern __shared__ __attribute__((aligned(16))) uint8_t m8[]; // NTT: 65536 bytes
+	{
+		// the challenges' nibble tables side by side: groups of 128 threads build one table each (a build is a dependent chain
+		// of ~400 instructions whatever the number of threads: one after the other they cost 1 us each at the head of a pass)
+		constexpr int NGRP = NW * 64 / 128;
+		const unsigned grp = threadIdx.x >> 7, ltid = threadIdx.x & 127;
 #pragma unroll
-	for (int c = 0; c < C; c++) ctable_build(tab[c], lv.l[c].r);
+		for (int c0 = 0; c0 < C; c0 += NGRP) {
+			f128 r = lv.l[c0].r;
+			unsigned mine = 0; // (compile-time indices only: a run-time index into the by-value argument makes every thread copy it to scratch)
+#pragma unroll
+			for (int g = 1; g < NGRP; g++)
+				if (c0 + g < C && grp == (unsigned)g) {
+					r = lv.l[c0 + g < C ? c0 + g : 0].r;
+					mine = g;
+				}
+			const bool has = c0 + (int)grp < C;
+			ctable_build_group(tab[has ? c0 + mine : c0], r, has ? ltid : 128u, 128u);
+		}
+	}
 	if (threadIdx.x < 64) {
 #pragma unroll
 		for (int c = 0; c < C; c++)
