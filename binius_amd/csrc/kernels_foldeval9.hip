@@ -221,10 +221,13 @@ __global__ __launch_bounds__(256, WAVES) void k_foldeval9(foldeval_args fa, uint
 	}
 	const ctable_smem *hs = nullptr;
 	if constexpr (SCALED) {
-		ctable_build(tab_hs.get(), fa.hi_scale);
+		// both tables side by side (two halves of the workgroup): a build is one dependent chain whatever the number of threads
+		const unsigned half = blockDim.x >> 1, grp = threadIdx.x >= half ? 1u : 0u;
+		ctable_build_group(grp ? tab_hs.get() : tab, grp ? fa.hi_scale : z, threadIdx.x - grp * half, half);
 		hs = &tab_hs.get();
+	} else {
+		ctable_build(tab, z);
 	}
-	ctable_build(tab, z);
 	fin_commit(fz, fpre, fcache);
 	const unsigned lane = threadIdx.x & 63;
 	const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -276,9 +279,13 @@ __global__ __launch_bounds__(256, 2) void k_foldeval9_small(foldeval_args fa, ui
 		if (!arm_wait(arm, z, hs_in)) return;
 		fa.hi_scale = hs_in;
 	}
-	if constexpr (SCALED) ctable_build(tab_hs.get(), fa.hi_scale);
 	BN_TS(1);
-	ctable_build(tab, z); // the loads above are in flight meanwhile
+	if constexpr (SCALED) { // (both tables side by side, see above; the loads above are in flight meanwhile)
+		const unsigned half = blockDim.x >> 1, grp = threadIdx.x >= half ? 1u : 0u;
+		ctable_build_group(grp ? tab_hs.get() : tab, grp ? fa.hi_scale : z, threadIdx.x - grp * half, half);
+	} else {
+		ctable_build(tab, z); // the loads above are in flight meanwhile
+	}
 	BN_TS(2);
 	const bool scaled_quadrant = SCALED && (wave & 1) && ((fa.scale_mask >> (wave >> 1)) & 1); // (wave-uniform)
 	if (threadIdx.x < kBlkQ)

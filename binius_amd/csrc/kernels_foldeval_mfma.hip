@@ -88,8 +88,12 @@ __global__ __launch_bounds__(256, 2) void k_foldeval_mfma(foldeval_args fa, uint
 			if (!arm_wait(arm, z, hs_in)) return;
 			fa.hi_scale = hs_in;
 		}
-		if constexpr (SC != 0) ctable_build(tab_hs.get(), fa.hi_scale);
-		ctable_build(tab, z); // the loads above are in flight meanwhile; ends with a barrier
+		if constexpr (SC != 0) { // both tables side by side (two halves of the workgroup): a build is one dependent chain
+			const unsigned grp = threadIdx.x >> 7;
+			ctable_build_group(grp ? tab_hs.get() : tab, grp ? fa.hi_scale : z, threadIdx.x & 127, 128);
+		} else {
+			ctable_build(tab, z); // the loads above are in flight meanwhile; ends with a barrier
+		}
 		fin_commit(fz, fpre, fcache);
 	}
 
