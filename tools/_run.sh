@@ -1,7 +1,6 @@
 cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests/test_gpu_sumcheck.py tests/test_gpu_mlecheck_shadow.py tests/test_gpu_two_round.py tests/test_gpu_lazy_vs_eager.py -x -q 2>&1 | tail -2
-for i in 1 2; do tools/bench_mlecheck_quick.sh 2>&1 | python -c "
-import sys,json
-for l in sys.stdin:
-    if l.startswith('{'):
-        d=json.loads(l); print(d['op'][-20:], d['prover'], d['ms'])"; done
+mkdir -p gpurun_out
+timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -3 > gpurun_out/pytest_gpu.log
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1 >> gpurun_out/pytest_gpu.log
+bash tools/final_measure.sh > gpurun_out/final_measure.log 2>&1
+cat gpurun_out/pytest_gpu.log
