@@ -44,7 +44,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
-PMC_FILE = os.path.join("profiles", "r03", "bench_pmc.json")  # tools/pmc_bench.sh: FETCH_SIZE / WRITE_SIZE passes of this command
+PMC_FILE = os.path.join("profiles", "r04", "bench_pmc.json")  # tools/pmc_bench.sh: FETCH_SIZE / WRITE_SIZE passes of this command
 
 
 def csrc_sha16():
@@ -166,6 +166,10 @@ def main():
     shm, rccl, reducer, peer = None, None, None, None
     d_partial, d_gathered = 0, 0
     available = []
+    # what happened to every exchange on this node, whatever the default ends up being: the first run on a
+    # real multi-GPU node must be diagnostic even if it falls back
+    ex_rec = {k: {"set_up": False, "tried": False, "ok": None, "error": None, "trial_ms_per_step": None, "ms_per_step": None,
+                  "same_transcript": None, "exchange_us_per_round": None} for k in ("peer", "shm", "rccl")}
     if dist is not None:
         from binius_amd.distributed import ShardedRoundReducer
 
@@ -183,6 +187,7 @@ def main():
                 shm = ShmExchange(dist, rank, world)
             except Exception as ex:  # noqa: BLE001
                 print("[bench] rank %d: shared-memory exchange unavailable (%s)" % (rank, ex), file=sys.stderr)
+                ex_rec["shm"]["error"] = "set-up failed on rank %d: %s" % (rank, ex)
                 shm = None
             if not everybody(shm is not None):
                 if shm is not None:
@@ -195,6 +200,7 @@ def main():
                 available.insert(0, "peer")
             except Exception as ex:  # noqa: BLE001
                 print("[bench] rank %d: peer exchange unavailable (%s)" % (rank, ex), file=sys.stderr)
+                ex_rec["peer"]["error"] = "set-up failed on rank %d: %s" % (rank, ex)
                 peer = None
         if rccl_possible:
             # the per-round collective is issued from the compiled host loop: ncclAllGather of the 32-byte
@@ -203,6 +209,7 @@ def main():
                 rccl = RcclComm(dist, rank, world)
             except Exception as ex:  # noqa: BLE001
                 print("[bench] rank %d: RCCL communicator unavailable (%s)" % (rank, ex), file=sys.stderr)
+                ex_rec["rccl"]["error"] = "set-up failed on rank %d: %s" % (rank, ex)
                 rccl = None
             if not everybody(rccl is not None):
                 if rccl is not None:
@@ -212,8 +219,14 @@ def main():
                 d_partial = reducer.local.data_ptr()
                 d_gathered = reducer.gathered.data_ptr()
                 available.append("rccl")
+        for k in available:
+            ex_rec[k]["set_up"] = True
+        if not rccl_possible:
+            ex_rec["rccl"]["error"] = "process group backend is %s, not nccl" % dist.get_backend()
+        if local_world != world:
+            ex_rec["shm"]["error"] = ex_rec["peer"]["error"] = "ranks span several nodes"
         if not available:
-            raise SystemExit("no exchange is available on this node (shared memory, peer mailboxes and RCCL all failed)")
+            raise SystemExit("no exchange is available on this node (shared memory, peer mailboxes and RCCL all failed): " + json.dumps(ex_rec))
         if exchange != "auto" and exchange not in available:
             exchange = "%s (fallback: %s is not available on this node)" % (available[0], exchange)
 
@@ -263,16 +276,23 @@ def main():
         for cand in list(available):
             pl = make_plan(cand)
             ok = True
+            ex_rec[cand]["tried"] = True
             try:
                 pl.run()
             except Exception as ex:  # noqa: BLE001
                 print("[bench] rank %d: exchange %s failed (%s)" % (rank, cand, ex), file=sys.stderr)
+                ex_rec[cand]["error"] = "first run raised on rank %d: %s" % (rank, ex)
                 ok = False
             if not everybody(ok):
                 available.remove(cand)
                 trials[cand] = None
+                ex_rec[cand]["ok"] = False
+                if ex_rec[cand]["error"] is None:
+                    ex_rec[cand]["error"] = "first run raised on another rank"
                 continue
             trials[cand] = timed(pl, 2) * 1e3 / 2
+            ex_rec[cand]["ok"] = True
+            ex_rec[cand]["trial_ms_per_step"] = round(trials[cand], 4)
         if not available:
             raise SystemExit("every exchange failed on this node")
         exchange = min(available, key=lambda c: trials[c])
@@ -283,14 +303,20 @@ def main():
     if dist is not None:
         while True:
             ok = True
+            ex_rec[exchange.split(" ")[0]]["tried"] = True
             try:
                 plan.run()
             except Exception as ex:  # noqa: BLE001
                 print("[bench] rank %d: exchange %s failed (%s)" % (rank, exchange.split(" ")[0], ex), file=sys.stderr)
+                ex_rec[exchange.split(" ")[0]]["error"] = "run raised on rank %d: %s" % (rank, ex)
                 ok = False
             if everybody(ok):
+                ex_rec[exchange.split(" ")[0]]["ok"] = True
                 break
             failed = exchange.split(" ")[0]
+            ex_rec[failed]["ok"] = False
+            if ex_rec[failed]["error"] is None:
+                ex_rec[failed]["error"] = "run raised on another rank"
             available.remove(failed)
             if not available:
                 raise SystemExit("every exchange failed on this node")
@@ -331,19 +357,26 @@ def main():
                 continue
             plan_alt = make_plan(other)
             ok_alt = True
+            ex_rec[other]["tried"] = True
             try:
                 plan_alt.run()
             except Exception as ex:  # noqa: BLE001
                 print("[bench] rank %d: exchange %s failed (%s)" % (rank, other, ex), file=sys.stderr)
+                ex_rec[other]["error"] = "run raised on rank %d: %s" % (rank, ex)
                 ok_alt = False
             if not everybody(ok_alt):
                 alt.append({"exchange": other, "error": "failed on this node"})
+                ex_rec[other]["ok"] = False
                 continue
             dt_alt = timed(plan_alt, args.steps)
             same = plan_alt.round_coeffs() == get_coeffs() and plan_alt.final_evals() == get_finals()
+            ex_rec[other].update(ok=True, ms_per_step=round(dt_alt * 1e3 / args.steps, 4), same_transcript=bool(same),
+                                 exchange_us_per_round=round((dt_alt - dt_solo) * 1e6 / args.steps / n_rounds, 2))
             alt.append({"exchange": other, "ms_per_step": dt_alt * 1e3 / args.steps, "value": m * (1 << n_global) * args.steps / dt_alt,
                         "same_transcript_as_default": bool(same),
                         "exchange_us_per_round": round((dt_alt - dt_solo) * 1e6 / args.steps / n_rounds, 2)})
+        ex_rec[main_kind].update(ms_per_step=round(elapsed * 1e3 / args.steps, 4), same_transcript=True,
+                                 exchange_us_per_round=round((elapsed - dt_solo) * 1e6 / args.steps / n_rounds, 2))
         alt.append({"exchange": "none (the local shard alone, no residual rounds: diagnostic)", "ms_per_step": dt_solo * 1e3 / args.steps})
         alt.append({"exchange": main_kind + " (the default: `value`)", "exchange_us_per_round": round((elapsed - dt_solo) * 1e6 / args.steps / n_rounds, 2),
                     "chosen_by": "measurement before the warm-up: ms per step " + json.dumps(trials) if trials is not None else "BN_EXCHANGE"})
@@ -515,6 +548,9 @@ def main():
                          + (" -- " + exchange if " (" in exchange else "")) if dist is not None else "none",
         },
         "alt_exchange": alt,
+        # every exchange on this node: was it set up, tried, did it run on all ranks (error text if not), its ms per step and
+        # whether it produced the default's transcript -- filled in even when the default is a fallback
+        "exchanges": ex_rec if dist is not None else None,
         # the sumcheck verifier's equations on the device-produced transcript (claim from the device inner product):
         # P_r(0) + P_r(1) == running sum every round, product of the final evaluations == last sum.  Bit-exact parity of
         # this very instance against the CPU oracle is tests/test_gpu_north_star.py (n = 24, n = 28, 8 shards).

@@ -160,11 +160,20 @@ int shadow_check_table(bn_ctx *ctx, bool *ok)
 hipStream_t side_stream(bn_ctx *ctx)
 {
 	if (!ctx->side) {
-		if (hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->side_ev, hipEventDisableTiming) != hipSuccess ||
-		    hipEventCreateWithFlags(&ctx->main_ev, hipEventDisableTiming) != hipSuccess) {
+		hipStream_t st = nullptr;
+		hipEvent_t e_side = nullptr, e_main = nullptr;
+		if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e_side, hipEventDisableTiming) != hipSuccess ||
+		    hipEventCreateWithFlags(&e_main, hipEventDisableTiming) != hipSuccess) {
+			// all or nothing: a stream without its two events would run unordered against the main stream
 			(void)hipGetLastError();
+			if (e_main) (void)hipEventDestroy(e_main);
+			if (e_side) (void)hipEventDestroy(e_side);
+			if (st) (void)hipStreamDestroy(st);
 			return ctx->stream; // (no side stream: the work simply stays in line)
 		}
+		ctx->side = st;
+		ctx->side_ev = e_side;
+		ctx->main_ev = e_main;
 	}
 	if (!ctx->side_busy) {
 		(void)hipEventRecord(ctx->main_ev, ctx->stream);
@@ -223,11 +232,96 @@ bool independent_of_pending(bn_ctx *ctx, const void *p, uint64_t n)
 	return true;
 }
 
+// [p, p + n) overlaps an array the MLE-check shadow describes: the halves of the caller's a and b the next evaluation will
+// pass, the indicator table (and the noted copy of its lower half, which the caller's next add turns into the table), S
+bool shadow_touched_by_write(bn_ctx *ctx, const void *p, uint64_t n)
+{
+	const bn_ctx::shadow_state &sh = ctx->shadow;
+	if (!sh.valid) return false;
+	for (const void *q : {sh.a_lo, sh.a_hi, sh.b_lo, sh.b_hi})
+		if (q && ranges_overlap(p, n, q, sh.half)) return true;
+	if (sh.eq && ranges_overlap(p, n, sh.eq, sh.eq_len)) return true;
+	if (sh.eq_copy_dst && ranges_overlap(p, n, sh.eq_copy_dst, sh.eq_len / 2)) return true;
+	if (sh.S && ranges_overlap(p, n, sh.S, sh.S_cap)) return true;
+	return false;
+}
+
 bool pre_matches(const bn_ctx::precomp_state &pre, const bn_ctx::pending_fold &pf)
 {
 	if (!pre.valid || pre.consumed || pf.count != 2 || pf.scale_mask || 2 * pf.n != pre.m) return false;
 	auto is = [&](uint32_t i, int j) { return pf.src0[i] == pre.lo[j] && pf.x1[i] == pre.hi[j]; };
 	return (is(0, 0) && is(1, 1)) || (is(0, 1) && is(1, 0));
+}
+
+// ---- host tail (abi_kernels.cpp): the device catches up with the folds the host performed on its own copy
+// publish: the caller is a host read -- when the arrays are down to one element each, the answer is already here
+int host_tail_flush(bn_ctx *ctx, bool publish)
+{
+	bn_ctx::host_tail_state &ht = ctx->ht;
+	if (!ht.active) return BN_OK;
+	ht.active = false;
+	if (ht.n_levels) {
+		ht.chain.k = ht.n_levels;
+		prof_scope ps(ctx, BN_PROF_FOLD);
+		BN_HIP(bn::launch_fold_chain(ctx->stream, ht.chain));
+		ctx->ht_flushed++;
+	}
+	if (publish && ht.cur_m == 1 && !ht.evaluated && ht.n_levels) {
+		ctx->mirror.valid = true;
+		ctx->mirror.host = true;
+		ctx->mirror.seq = 0;
+		ctx->mirror.count = 2;
+		ctx->mirror.n = 1;
+		for (int j = 0; j < 2; j++) {
+			ctx->mirror.ptr[j] = ht.cur_lo[j];
+			ctx->mirror.host_vals[j] = bn::hostpoly_to_tower(bn::hp128{ht.y[j][0], ht.y[j][1]});
+		}
+	}
+	ht.n_levels = 0;
+	return BN_OK;
+}
+
+// The fold batch (src0 | x1 -> x0, n elements each) is the fold of the host tail's current arrays: performed on the host
+// copy, recorded for the device (true), or not the expected call (false: the caller flushes).
+bool host_tail_fold(bn_ctx *ctx, void *const *x0, const void *const *src0, const void *const *x1, uint32_t count, uint64_t n, uint32_t scale_mask, f128 z)
+{
+	bn_ctx::host_tail_state &ht = ctx->ht;
+	if (!ht.active || !ht.evaluated || ctx->pend.active || count != 2 || scale_mask || 2 * n != ht.cur_m || ht.n_levels >= 8) return false;
+	auto is = [&](uint32_t i, int j) { return src0[i] == ht.cur_lo[j] && x1[i] == ht.cur_hi[j]; };
+	int perm = -1;
+	if (is(0, 0) && is(1, 1)) perm = 0;
+	else if (is(0, 1) && is(1, 0)) perm = 1;
+	if (perm < 0 || x0[0] == x0[1]) return false;
+	// later levels chain in place on the first level's output (fold_chain_args)
+	if (ht.n_levels > 0)
+		for (uint32_t i = 0; i < 2; i++)
+			if (x0[i] != src0[i]) return false;
+	for (uint32_t i = 0; i < 2; i++) { // the output must not overlap what the batch reads of the OTHER array, nor x1 of its own
+		const uint32_t o = 1 - i;
+		if (ranges_overlap(x0[i], n, src0[o], n) || ranges_overlap(x0[i], n, x1[o], n) || ranges_overlap(x0[i], n, x1[i], n)) return false;
+		if (x0[i] != src0[i] && ranges_overlap(x0[i], n, src0[i], n)) return false;
+	}
+	if (ht.n_levels == 0) {
+		if (n > 128) return false;
+		for (uint32_t i = 0; i < 2; i++) {
+			const int j = perm ? 1 - (int)i : (int)i;
+			ht.chain.src0[j] = src0[i];
+			ht.chain.x1[j] = x1[i];
+			ht.chain.out[j] = x0[i];
+		}
+		ht.chain.n0 = (uint32_t)n;
+	}
+	ht.chain.z[ht.n_levels++] = z;
+	const bn::hp128 pz = bn::hostpoly_from_tower(z);
+	for (int j = 0; j < 2; j++) bn::hostpoly_fold(reinterpret_cast<bn::hp128 *>(ht.y[j].data()), n, pz);
+	for (uint32_t i = 0; i < 2; i++) {
+		const int j = perm ? 1 - (int)i : (int)i;
+		ht.cur_lo[j] = x0[i];
+		ht.cur_hi[j] = (const char *)x0[i] + (n / 2) * sizeof(f128);
+	}
+	ht.cur_m = n;
+	ht.evaluated = false;
+	return true;
 }
 
 int flush_first_fold(bn_ctx *ctx)
@@ -280,6 +374,10 @@ int flush_copies(bn_ctx *ctx)
 
 int flush_pending(bn_ctx *ctx, bool keep_tail, bool publish_tiny, bool keep_shadow)
 {
+	if (ctx->ht.active) {
+		int rc = host_tail_flush(ctx, publish_tiny);
+		if (rc) return rc;
+	}
 	if (!(keep_shadow && !ctx->pend.active)) side_join(ctx); // whatever follows may read what the side stream writes
 	if (ctx->tail.active && !keep_tail) {
 		int rc = tail_cancel(ctx);
@@ -473,6 +571,23 @@ int bn_ctx_create(int device, uint64_t arena_elems, bn_ctx **out)
 		ctx->arena_elems = arena_elems;
 	}
 	ctx->lazy_fold = getenv("BN_NO_LAZY_FOLD") == nullptr;
+	{
+		// host tail: pinned staging for Y (2 x 256 elements) and the nibble table of the host's basis change on the device
+		const char *e = getenv("BN_HOST_TAIL");
+		if (!(e && e[0] == '0') && bn::hostpoly_available()) {
+			std::vector<uint64_t> phi(1024);
+			bn::hostpoly_phi_nibble_table(phi.data());
+			BN_HIP(hipHostMalloc(&ctx->h_tail, 512 * sizeof(f128), hipHostMallocMapped | hipHostMallocCoherent));
+			BN_HIP(hipHostGetDevicePointer(&ctx->d_tail, ctx->h_tail, 0));
+			BN_HIP(hipMalloc(&ctx->d_phi, 512 * sizeof(f128)));
+			BN_HIP(hipMemcpy(ctx->d_phi, phi.data(), 512 * sizeof(f128), hipMemcpyHostToDevice));
+			ctx->ht_enabled = true;
+			if (const char *l = getenv("BN_HOST_TAIL_MAX_LOG2")) {
+				const int v = atoi(l);
+				ctx->ht_max = (uint64_t)1 << (v < 2 ? 2 : (v > 8 ? 8 : v));
+			}
+		}
+	}
 	if (const char *t = getenv("BN_TAIL_MAX_LOG2")) {
 		const int l = atoi(t);
 		ctx->tail_max_n_in = (l >= 3 && l <= 12) ? (1ull << l) : 0; // one workgroup: at most 2^12 elements per array
@@ -523,6 +638,7 @@ int bn_peer_create(bn_ctx *ctx, uint32_t world, uint32_t rank, uint8_t *handle_o
 	std::memcpy(handle_out, &h, sizeof(h));
 	ctx->peer.world = world;
 	ctx->peer.rank = rank;
+	if (const char *st = getenv("BN_PEER_STRESS")) ctx->peer.stress = (uint32_t)atoi(st);
 	ctx->peer.own = p;
 	ctx->peer.box[rank] = p;
 	return BN_OK;
@@ -603,6 +719,8 @@ int bn_ctx_destroy(bn_ctx *ctx)
 		if (ctx->main_ev) hipEventDestroy(ctx->main_ev);
 	}
 	if (ctx->d_flag) hipFree(ctx->d_flag);
+	if (ctx->d_phi) hipFree(ctx->d_phi);
+	if (ctx->h_tail) hipHostFree(ctx->h_tail);
 	if (ctx->shadow.S) hipFree(ctx->shadow.S);
 	if (ctx->ntt_cache) {
 		bn::ntt_bs_cache *nc = (bn::ntt_bs_cache *)ctx->ntt_cache;
@@ -818,6 +936,23 @@ int bn_copy_d2d(bn_ctx *ctx, const void *d_src, uint64_t src_len, void *d_dst, u
 			for (const void *b : {ctx->pre.lo[j], ctx->pre.hi[j]})
 				if (d0 < (const char *)b + half && (const char *)b < d1) ctx->pre.valid = false;
 	}
+	if (ctx->ht.active) {
+		// a host tail: with folds outstanding the device arrays are stale (the chain runs first); with none, the host only holds
+		// a copy -- which a write into the arrays ends
+		const bn_ctx::host_tail_state &ht = ctx->ht;
+		bool hit = ht.n_levels > 0;
+		for (int j = 0; j < 2 && !hit; j++)
+			hit = ranges_overlap(d_dst, dst_len, ht.cur_lo[j], ht.cur_m / 2) || ranges_overlap(d_dst, dst_len, ht.cur_hi[j], ht.cur_m / 2);
+		if (hit) BN_FLUSH(ctx);
+	}
+	if (shadow_touched_by_write(ctx, d_dst, dst_len)) {
+		// a write into an array the MLE-check shadow describes (the caller's a / b, the table or the noted copy of its lower
+		// half, S itself): everything deferred runs first, in issue order, the side stream is joined and the shadow ends --
+		// the literal kernels answer from here on (a deferred or side-queued copy must not leave S stale)
+		BN_FLUSH(ctx);
+		BN_HIP(hipMemcpyAsync(d_dst, d_src, src_len * sizeof(f128), hipMemcpyDeviceToDevice, ctx->stream));
+		return BN_OK;
+	}
 	if (ctx->lazy_fold && !ctx->pend.active && ctx->pend_copies.size() < 8) {
 		// deferred: a fold into d_dst may absorb it (see bn_ctx::pending_copy)
 		ctx->pend_copies.push_back({d_src, d_dst, src_len});
@@ -829,16 +964,11 @@ int bn_copy_d2d(bn_ctx *ctx, const void *d_src, uint64_t src_len, void *d_dst, u
 		// deferred (the MLE-check prover copies the lower half of its indicator table between a fold and the next round
 		// evaluation, v3/bivariate_mlecheck.rs:195-254).
 		bn_ctx::shadow_state &sh = ctx->shadow;
-		if (sh.valid) {
-			if (d_src == sh.eq && 2 * src_len == sh.eq_len) {
-				BN_SHDBG("copy of the table's lower half noted");
-				sh.eq_copy_src = d_src;
-				sh.eq_copy_dst = d_dst;
-			} else if (ranges_overlap(d_dst, dst_len, sh.eq, sh.eq_len)) {
-				sh.valid = false;
-				sh.fold_pending = false;
-				ctx->shadow_dropped++;
-			}
+		if (sh.valid && d_src == sh.eq && 2 * src_len == sh.eq_len) {
+			// (writes INTO the shadow's arrays never get here: shadow_touched_by_write above)
+			BN_SHDBG("copy of the table's lower half noted");
+			sh.eq_copy_src = d_src;
+			sh.eq_copy_dst = d_dst;
 		}
 		if (sh.valid)
 			ctx->side_queue.push_back({bn_ctx::side_op::COPY, d_dst, d_src, nullptr, src_len, f128{0, 0}}); // (launched behind the next round's kernel)
@@ -1015,6 +1145,8 @@ int bn_extrapolate_line_batch_scaled(bn_ctx *ctx, void *const *d_evals_0, const 
 			for (uint32_t i = 0; i < count; i++) src0[i] = d_evals_0[i];
 		}
 	}
+	if (ctx->ht.active && host_tail_fold(ctx, d_evals_0, src0, d_evals_1, count, n, scale_mask, to_f(z)))
+		return BN_OK; // (performed on the host's copy; the device catches up in one launch, host_tail_flush)
 	{
 		// a resident tail kernel survives this call only if the batch is the fold it is parked for
 		bool keep_tail = false;
@@ -1057,6 +1189,9 @@ int bn_extrapolate_line_batch_scaled(bn_ctx *ctx, void *const *d_evals_0, const 
 			if (is(0, sh.a_lo, sh.a_hi) && is(1, sh.b_lo, sh.b_hi)) sh_ia = 0;
 			else if (is(1, sh.a_lo, sh.a_hi) && is(0, sh.b_lo, sh.b_hi)) sh_ia = 1;
 		}
+		// (deferred copies that the batch did not absorb run inside flush_pending, on the main stream and in issue order: they
+		// may write what the shadow describes or race the side stream's fold of b -- the shadow does not survive them)
+		if (sh_ia >= 0 && !ctx->pend_copies.empty()) sh_ia = -1;
 		if (sh_ia >= 0 && !sh.checked && n >= 2) {
 			// the caller goes on with this instance: is its table a tensor expansion (what the later rounds rely on)?
 			bool ok = false;
@@ -1131,6 +1266,9 @@ int bn_arm_counters(bn_ctx *ctx, uint64_t *counters)
 	counters[BN_ARM_SHADOW_CREATED] = ctx->shadow_created;
 	counters[BN_ARM_SHADOW_ROUNDS] = ctx->shadow_rounds;
 	counters[BN_ARM_SHADOW_DROPPED] = ctx->shadow_dropped;
+	counters[BN_ARM_HT_STARTED] = ctx->ht_started;
+	counters[BN_ARM_HT_ROUNDS] = ctx->ht_rounds;
+	counters[BN_ARM_HT_FLUSHED] = ctx->ht_flushed;
 	return BN_OK;
 }
 

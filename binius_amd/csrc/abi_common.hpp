@@ -90,6 +90,8 @@ bool independent_of_pending(bn_ctx *ctx, const void *p, uint64_t n);
 // the MLE-check shadow's table: read eq[0], eq[2^k] to the host, derive the ratios rho_k, check the whole table against them
 // (one gather + one pass + two stream synchronisations); false: not a tensor expansion (or a coordinate 0 / 1)
 int shadow_check_table(bn_ctx *ctx, bool *ok);
+// host tail (abi_kernels.cpp): launch the chain of folds the host performed on its own copy; the tail ends
+int host_tail_flush(bn_ctx *ctx, bool publish);
 // two deferred folds (two-round launches): run the first one now, the second becomes the deferred one
 int flush_first_fold(bn_ctx *ctx);
 // the deferred fold `pf` folds exactly the arrays the precomputed next-round sums describe

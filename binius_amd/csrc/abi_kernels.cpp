@@ -100,8 +100,14 @@ uint64_t two_round_max_m()
 bool two_round_size_ok(uint64_t m) { return m >= 4 && (m & 3) == 0 && m <= two_round_max_m(); }
 // the caller's request must be the plain pair (y_1, y_inf) with ONE batch coefficient (the precomputed sums of the next
 // round mix slots of both) -- what calculate_round_evals records for one bivariate product claim
-bool two_round_recipe_ok(const bn::fin_args &a)
+// (under a peer exchange the kernel reduces the RAW sums across the ranks and the host adds the values' initial contents
+// once, where the one-round finalize adds them once per rank: only zero initial values mean the same thing on both paths)
+bool two_round_recipe_ok(const bn::fin_fuse &f)
 {
+	const bn::fin_args &a = f.args;
+	if (f.peer.world > 1)
+		for (uint32_t v = 0; v < a.n_values; v++)
+			if (!(a.init[v] == f128{0, 0})) return false;
 	return a.n_terms == 2 && a.n_ret >= 1 && a.n_ret <= 2 && a.terms[0].coeff == a.terms[1].coeff;
 }
 bn::fin_fuse two_round_recipe(const bn::fin_fuse &fz)
@@ -116,6 +122,19 @@ bn::fin_fuse two_round_recipe(const bn::fin_fuse &fz)
 	}
 	return f8;
 }
+// ---- host tail ---------------------------------------------------------------------------------------------------------
+// A two-round launch whose Y is at most ht_max (<= 256) elements per array -- one workgroup -- also hands Y to the host,
+// mapped into the power basis of hostmul_clmul.cpp by one more nibble-table product per element.  From then on the sumcheck
+// is host arithmetic: a fold of 2 x 128 elements is 0.9 us, a round evaluation over 128 points 0.8 us (the 256-bit
+// carry-less products are XORed unreduced, one reduction per sum), against ~10 us per round through the device.  The calls
+// must be the expected ones (the fold of exactly these arrays, the evaluation of exactly their halves); anything else
+// launches the chain of outstanding folds (launch_fold_chain: the caller's memory ends up as eager execution leaves it)
+// and the device path takes over again.  Not under a peer exchange (the ranks' partial sums meet on the devices there).
+bool host_tail_applies(const bn_ctx *ctx, uint64_t m, uint32_t peer_world)
+{
+	return ctx->ht_enabled && ctx->lazy_fold && peer_world <= 1 && m >= 4 && m <= ctx->ht_max;
+}
+
 struct two_round_req {
 	bn::foldeval8_args fa;
 	f128 z1{0, 0}, z2{0, 0};
@@ -127,6 +146,7 @@ struct two_round_req {
 void arm_two_round_next(bn_ctx *ctx, const two_round_req &rq, const bn::fin_fuse &f8, f128 *d_S)
 {
 	if (!ctx->arm_enabled || ctx->prof_on || ctx->tail_max_n_in || !two_round_size_ok(rq.m >> 2)) return;
+	if (host_tail_applies(ctx, rq.m, f8.peer.world)) return; // (the host has the arrays: nothing more is launched for this instance)
 	bn::foldeval8_args fn{};
 	for (int j = 0; j < 2; j++) {
 		fn.x0[j] = rq.lo[j];
@@ -135,6 +155,10 @@ void arm_two_round_next(bn_ctx *ctx, const two_round_req &rq, const bn::fin_fuse
 	}
 	fn.n_in = rq.m;
 	fn.n_folds = 2;
+	if (host_tail_applies(ctx, rq.m >> 2, f8.peer.world)) {
+		fn.mirror = (f128 *)ctx->d_tail;
+		fn.phi_tab = (const uint4 *)ctx->d_phi;
+	}
 	bn::fin_fuse fzn = f8;
 	fzn.args.seq = f8.args.seq + 1;
 	fzn.peer.round = f8.peer.round + 1;
@@ -260,6 +284,28 @@ int two_round_launch(bn_ctx *ctx, const two_round_req &rq, const bn::fin_fuse &f
 	vals[fz.args.terms[1].value] ^= E[1] ^ E[3];
 	for (uint32_t r = 0; r < n_ret; r++) h_out[r] = bn_f128{vals[ret_values[r]].lo, vals[ret_values[r]].hi};
 	ctx->fin_y.valid = false;
+	if (rq.fa.mirror) {
+		// ---- host tail: Y is in the pinned staging, in the power basis (written before the sequence number was)
+		bn_ctx::host_tail_state &ht = ctx->ht;
+		const uint64_t *src = (const uint64_t *)ctx->h_tail;
+		for (int j = 0; j < 2; j++) {
+			ht.y[j].resize(2 * rq.m);
+			for (uint64_t w = 0; w < 2 * rq.m; w++) ht.y[j][w] = __atomic_load_n(&src[2 * rq.m * j + w], __ATOMIC_RELAXED);
+			ht.cur_lo[j] = rq.lo[j];
+			ht.cur_hi[j] = rq.hi[j];
+		}
+		ht.cur_m = rq.m;
+		ht.n_levels = 0;
+		ht.evaluated = true;
+		ht.active = true;
+		ctx->ht_started++;
+		ctx->pre.valid = false;
+		ctx->pend.active = false;
+		ctx->pend2.active = false;
+		ctx->s_clean = true;
+		ctx->two_round_launches++;
+		return BN_OK;
+	}
 	if (rq.m == 4 && f8.peer.world <= 1) {
 		// the last launch of this sumcheck: the kernel left Y's four elements per array in the mailbox (slots 32 .. 39)
 		for (int j = 0; j < 2; j++) {
@@ -437,7 +483,26 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 	// A deferred fold survives into this launch only if the kernel has the calculate_round_evals
 	// shape (two bivariate-product sums, Local "lo + hi" operands, nothing written to memory); the
 	// launch site below then checks that it reads exactly the folded arrays.
-	if (!ctx->pend.active) BN_FLUSH(ctx); // (deferred copies; a parked tail kernel without a fold to run)
+	// A host tail survives into this launch only if it has the same shape and wants a host result; the launch site below then
+	// checks that it reads exactly the halves of the host's arrays.
+	bool ht_keep = false;
+	if (ctx->ht.active) {
+		uint32_t n_sum = 0;
+		bool pure = n_ret > 0 && h_out && !d_out && !ctx->ht.evaluated && !ctx->pend.active;
+		for (uint32_t o = 0; o < n_ops && pure; o++) {
+			const bn_kop &op = ops[o];
+			if (op.kind == BN_KOP_SUM_COMPOSITION) {
+				n_sum++;
+				if (!op.expr || op.expr->shape != bn_expr::PRODUCT || op.expr->product_vars.size() != 2) pure = false;
+			} else if (op.kind == BN_KOP_ADD) {
+				if (op.dst.buf >= n_maps || maps[op.dst.buf].kind != BN_MAP_LOCAL) pure = false;
+			} else if (op.kind != BN_KOP_DECL_VALUE) {
+				pure = false;
+			}
+		}
+		ht_keep = pure && n_sum == 2;
+	}
+	if (!ctx->pend.active && !ht_keep) BN_FLUSH(ctx); // (deferred copies; a parked tail kernel without a fold to run; a host tail)
 	if (ctx->pend.active) {
 		uint32_t n_sum = 0;
 		bool pure = n_ret > 0 && ctx->pend.count == 2;
@@ -713,8 +778,37 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 									fz.peer.rank = ctx->peer.rank;
 									for (uint32_t w = 0; w < ctx->peer.world; w++) fz.peer.box[w] = (uint64_t *)ctx->peer.box[w];
 									fz.peer.round = ++ctx->peer.round;
+									fz.peer.stress = ctx->peer.stress;
 								}
 								hipError_t fe = hipErrorNotSupported;
+								// ---- host tail: the halves of exactly the arrays the host holds -- answered here, no launch
+								if (ctx->ht.active) {
+									bn_ctx::host_tail_state &ht = ctx->ht;
+									auto is = [&](int f, int j) { return lo[f] == ht.cur_lo[j] && hi[f] == ht.cur_hi[j]; };
+									const bool match = k == 2 && !ht.evaluated && !peer_on && h_out && !d_out && 2 * row_len == ht.cur_m && lo[0] && lo[1] &&
+									                   ((is(0, 0) && is(1, 1)) || (is(0, 1) && is(1, 0))) && two_round_recipe_ok(fz);
+									if (match) {
+										bn::hp128 p1, pi;
+										bn::hostpoly_round_sums(reinterpret_cast<const bn::hp128 *>(ht.y[0].data()), reinterpret_cast<const bn::hp128 *>(ht.y[1].data()), row_len, &p1, &pi);
+										f128 s1 = bn::hostpoly_to_tower(p1), si = bn::hostpoly_to_tower(pi);
+										const f128 cf = fz.args.terms[0].coeff;
+										if (!(cf == f128{1, 0})) {
+											s1 = bn::mul_host(cf, s1);
+											si = bn::mul_host(cf, si);
+										}
+										f128 vals[bn::kFinMaxValues];
+										for (uint32_t v = 0; v < n_values; v++) vals[v] = h_values[v];
+										vals[fz.args.terms[0].value] ^= s1;
+										vals[fz.args.terms[1].value] ^= si;
+										for (uint32_t r = 0; r < n_ret; r++) h_out[r] = bn_f128{vals[ret_values[r]].lo, vals[ret_values[r]].hi};
+										ht.evaluated = true;
+										--ctx->mail_seq; // (no launch, no mailbox traffic)
+										ctx->s_clean = was_clean_or_zeroed;
+										ctx->ht_rounds++;
+										return BN_OK;
+									}
+									BN_FLUSH(ctx); // not the expected evaluation: the device catches up first
+								}
 								// ---- MLE-check shape a * b * eq (one factor the same at both points): the weighted shadow
 								if (k == 3 && ctx->shadow_enabled && h_out && !d_out && !peer_on && ctx->lazy_fold) {
 									int same = -1, n_same = 0;
@@ -808,10 +902,10 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 										fa.hi_scale = pf.hi_scale;
 										const uint64_t n_in = 2 * pf.n;
 										const bool two_ok = ctx->two_round && h_out && !d_out && !fa.scale_mask && !ctx->tail_max_n_in && !ctx->tail.active &&
-										                    two_round_recipe_ok(fz.args) && two_round_size_ok(pf.n);
+										                    two_round_recipe_ok(fz) && two_round_size_ok(pf.n);
 										// (h) the next-round quadratics of the previous two-round launch describe exactly the arrays this fold
 										// folds: the host answers -- y(z) = c0 + z c1 + z^2 c2 at the fold's challenge -- and the fold stays deferred
-										if (!two && h_out && !d_out && pre_matches(ctx->pre, pf) && two_round_recipe_ok(fz.args) && recipe_bytes(fz.args) == ctx->pre.recipe) {
+										if (!two && h_out && !d_out && pre_matches(ctx->pre, pf) && two_round_recipe_ok(fz) && recipe_bytes(fz.args) == ctx->pre.recipe) {
 											const bn_ctx::precomp_state &pre = ctx->pre;
 											const f128 z = pf.z, zz = bn::mul_host(z, z);
 											const f128 y1 = pre.P0 ^ bn::mul_host(z, pre.P0 ^ pre.P1v ^ pre.P2) ^ bn::mul_host(zz, pre.P2);
@@ -845,6 +939,10 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 											rq.z1 = p1.z;
 											rq.z2 = two ? pf.z : f128{0, 0};
 											rq.m = pf.n;
+											if (host_tail_applies(ctx, rq.m, fz.peer.world)) {
+												rq.fa.mirror = (f128 *)ctx->d_tail;
+												rq.fa.phi_tab = (const uint4 *)ctx->d_phi;
+											}
 											return two_round_launch(ctx, rq, fz, h_values.data(), n_values, ret_values, n_ret, h_out, d_S + slot, t_enter);
 										}
 										if (two) { // (two_round_size_ok was checked at entry; something else rules the two-round kernel out)
@@ -863,7 +961,7 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 											// host waits for long kernels with a stream synchronisation, which an armed kernel would hold up
 											const bool mfma_next = bn::mfma_applies(ctx->n_cu, n_next >> 2);
 											if (ctx->arm_enabled && !ctx->prof_on && h_out && !d_out && ctx->two_round && !fa_.scale_mask && !ctx->tail_max_n_in &&
-											    two_round_recipe_ok(fz_.args) && two_round_size_ok(n_next >> 1)) {
+											    two_round_recipe_ok(fz_) && two_round_size_ok(n_next >> 1)) {
 												// the next round will be a two-round launch with ONE fold (its arrays: the halves written now)
 												bn::foldeval8_args f8a{};
 												for (uint32_t j = 0; j < 2; j++) {
@@ -873,6 +971,10 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 												}
 												f8a.n_in = n_next;
 												f8a.n_folds = 1;
+												if (host_tail_applies(ctx, n_next >> 1, fz_.peer.world)) {
+													f8a.mirror = (f128 *)ctx->d_tail;
+													f8a.phi_tab = (const uint4 *)ctx->d_phi;
+												}
 												bn::fin_fuse fzn = two_round_recipe(fz_);
 												fzn.args.seq = fz_.args.seq + 1;
 												fzn.peer.round = fz_.peer.round + 1;
@@ -1100,7 +1202,7 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 								// number of variables is even, so that the chain of two-round launches ends on four elements (with an
 								// odd number this round runs alone and the chain starts with the first fold)
 								if (fe == hipErrorNotSupported && !out_scaled && !ctx->pend.active && k == 2 && lo[0] && lo[1] && lo[0] != lo[1] && ctx->two_round && ctx->lazy_fold && h_out && !d_out &&
-								    !ctx->tail_max_n_in && two_round_recipe_ok(fz.args) && two_round_size_ok(2 * row_len) && (ilog2(2 * row_len) & 1) == 0) {
+								    !ctx->tail_max_n_in && two_round_recipe_ok(fz) && two_round_size_ok(2 * row_len) && (ilog2(2 * row_len) & 1) == 0) {
 									two_round_req rq{};
 									for (uint32_t j = 0; j < 2; j++) {
 										rq.fa.x0[j] = lo[j];
@@ -1112,6 +1214,10 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 									rq.fa.n_in = 2 * row_len;
 									rq.fa.n_folds = 0;
 									rq.m = 2 * row_len;
+									if (host_tail_applies(ctx, rq.m, fz.peer.world)) {
+										rq.fa.mirror = (f128 *)ctx->d_tail;
+										rq.fa.phi_tab = (const uint4 *)ctx->d_phi;
+									}
 									return two_round_launch(ctx, rq, fz, h_values.data(), n_values, ret_values, n_ret, h_out, d_S + slot, t_enter);
 								}
 								if (fe == hipErrorNotSupported) {
@@ -1231,6 +1337,7 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 			pr.rank = ctx->peer.rank;
 			for (uint32_t w = 0; w < ctx->peer.world; w++) pr.box[w] = (uint64_t *)ctx->peer.box[w];
 			pr.round = ++ctx->peer.round;
+			pr.stress = ctx->peer.stress;
 			peer_standalone = true;
 		}
 		BN_HIP(bn::launch_finalize(s, fa, d_S, rets, ctx->d_mail, &pr));

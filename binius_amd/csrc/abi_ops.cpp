@@ -86,9 +86,11 @@ static int upload_s_evals(bn_ctx *ctx, const uint64_t *h_s_evals, uint64_t **d_o
 	constexpr size_t words = (size_t)BN_NTT_MAX_DIM * BN_NTT_MAX_DIM;
 	if (ctx->h_s_evals.size() != words || memcmp(ctx->h_s_evals.data(), h_s_evals, words * sizeof(uint64_t)) != 0) {
 		// (kernels of earlier calls that still read the old basis are ahead of the copy on the same stream)
-		ctx->h_s_evals.assign(h_s_evals, h_s_evals + words);
-		BN_HIP(hipMemcpyAsync(ctx->d_s_evals, ctx->h_s_evals.data(), words * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+		// (the host copy only names what IS on the device: forgotten first, so that a failed upload is retried by the next call)
+		ctx->h_s_evals.clear();
+		BN_HIP(hipMemcpyAsync(ctx->d_s_evals, h_s_evals, words * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
 		BN_HIP(hipStreamSynchronize(ctx->stream)); // (the source is pageable: the runtime may still be reading it)
+		ctx->h_s_evals.assign(h_s_evals, h_s_evals + words);
 	}
 	*d_out = ctx->d_s_evals;
 	if (extra) {

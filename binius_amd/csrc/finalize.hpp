@@ -37,32 +37,83 @@ __device__ __forceinline__ uint32_t fin_wave_xor(uint32_t v)
 // ---- cross-rank reduction (fin_peer, internal.hpp) -------------------------------------------------------------------
 // Wave 0 of the finalizing workgroup; vals[0 .. n_ret) in LDS hold this rank's returned values on entry and the XOR over
 // all ranks on exit.  Lane p < world talks to rank p: it stores the values into slot `rank` of p's mailbox (system-scope
-// stores into fine-grained memory, the round number last with release semantics), then waits for slot p of its OWN
-// mailbox to show this round's number and reads rank p's values.  Two parities: a rank can be at most one round ahead
-// of the slowest reader (it needs everybody's round r + 1 values, which they send after reading round r).  The wait
-// is bounded (a rank that died cannot park the device): on a timeout the function returns false and the caller
-// reports it through mail[65].
-__device__ __forceinline__ bool peer_exchange(f128 *vals, uint32_t n_ret, uint64_t *const *box, uint32_t world, uint32_t rank, uint64_t round)
+// stores into fine-grained memory), then the slot's TAG word, and waits for slot p of its OWN mailbox to become valid for
+// this round before it takes rank p's values.
+//
+// Slots validate themselves (the ordering of the value words and the flag must not be an argument about the
+// fabric): tag = peer_tag(round, value words), a 64-bit mix of the round number and every value word.  The reader loads
+// the tag AND the values in one look and accepts them only if the tag it read is the tag OF the values it read for THIS
+// round; a tag that overtook a value word over xGMI, a torn slot or a stale one (same parity, round - 2) does not
+// validate and the lane looks again.  So a stale partial can never be XORed into a round polynomial silently, whatever
+// order the words arrive in; the writer still drains its value stores (vmcnt(0)) before the tag so that the first look
+// after the tag lands normally succeeds.  Two parities: a rank can be at most one round ahead of the slowest reader (it
+// needs everybody's round r + 1 values, which they send after reading round r).  The wait is bounded (a rank that
+// died cannot park the device): on a timeout the function returns false and the caller reports it through mail[65].
+//
+// stress (BN_PEER_STRESS, test only): bit 0 = the tag is stored FIRST and the values follow after a pause -- the order a
+// reordering fabric could produce; bit 1 = a pause between the value words as well (torn slots).
+__device__ __forceinline__ uint64_t peer_mix(uint64_t h, uint64_t w)
+{
+	h = (h ^ w) * 0xBF58476D1CE4E5B9ull;
+	return h ^ (h >> 29);
+}
+__device__ __forceinline__ uint64_t peer_tag(uint64_t round, const uint64_t *w, uint32_t n_words)
+{
+	uint64_t h = peer_mix(0x9E3779B97F4A7C15ull, round);
+	for (uint32_t i = 0; i < n_words; i++) h = peer_mix(h, w[i]);
+	return h | 1ull; // (never the zero a fresh mailbox holds)
+}
+
+__device__ __forceinline__ bool peer_exchange(f128 *vals, uint32_t n_ret, uint64_t *const *box, uint32_t world, uint32_t rank, uint64_t round,
+                                              uint32_t stress = 0)
 {
 	const unsigned p = threadIdx.x; // < 64
 	const unsigned par = (unsigned)(round & 1);
 	bool ok = true;
-	const uint64_t *src = nullptr;
+	uint64_t got[2 * kFinMaxRets];
+#pragma unroll
+	for (int i = 0; i < 2 * kFinMaxRets; i++) got[i] = 0;
 	if (p < world) {
-		uint64_t *dst = box[p] + (size_t)(par * kPeerMaxWorld + rank) * kPeerSlotWords;
-		for (uint32_t r = 0; r < n_ret; r++) {
-			__hip_atomic_store(dst + 2 * r, vals[r].lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-			__hip_atomic_store(dst + 2 * r + 1, vals[r].hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		uint64_t mine[2 * kFinMaxRets];
+#pragma unroll
+		for (int r = 0; r < kFinMaxRets; r++) {
+			mine[2 * r] = (uint32_t)r < n_ret ? vals[r].lo : 0;
+			mine[2 * r + 1] = (uint32_t)r < n_ret ? vals[r].hi : 0;
 		}
+		const uint64_t tag = peer_tag(round, mine, 2 * n_ret);
+		uint64_t *dst = box[p] + (size_t)(par * kPeerMaxWorld + rank) * kPeerSlotWords;
+		if (stress & 1) { // the flag overtakes the values
+			__hip_atomic_store(dst + 16, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			for (int k = 0; k < 64; k++) __builtin_amdgcn_s_sleep(127);
+		}
+#pragma unroll
+		for (int r = 0; r < kFinMaxRets; r++)
+			if ((uint32_t)r < n_ret) {
+				__hip_atomic_store(dst + 2 * r, mine[2 * r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+				if (stress & 2) {
+					asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+					for (int k = 0; k < 8; k++) __builtin_amdgcn_s_sleep(127);
+				}
+				__hip_atomic_store(dst + 2 * r + 1, mine[2 * r + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			}
 		// No release / acquire FENCES: a system-scope release writes the whole L2 back and an acquire invalidates it (measured:
 		// +6 us per round on one device).  Every word of the mailbox is only ever touched by system-scope atomics on
-		// fine-grained memory, which are performed at the memory itself, in program order per lane once the lane has drained its
-		// stores (vmcnt(0)) -- the same argument as for the relay of arm.hpp and the ticket of re9.hpp.
+		// fine-grained memory, performed at the memory itself; the drain below makes the common case cheap (the tag lands after
+		// the values), the tag's content makes every other case safe.
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-		__hip_atomic_store(dst + 16, round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-		src = box[rank] + (size_t)(par * kPeerMaxWorld + p) * kPeerSlotWords;
+		if (!(stress & 1)) __hip_atomic_store(dst + 16, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		const uint64_t *src = box[rank] + (size_t)(par * kPeerMaxWorld + p) * kPeerSlotWords;
 		uint32_t spins = 0;
-		while (__hip_atomic_load(src + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != round) {
+		for (;;) {
+			const uint64_t t = __hip_atomic_load(src + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#pragma unroll
+			for (int r = 0; r < kFinMaxRets; r++)
+				if ((uint32_t)r < n_ret) {
+					got[2 * r] = __hip_atomic_load(src + 2 * r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+					got[2 * r + 1] = __hip_atomic_load(src + 2 * r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+				}
+			if (t == peer_tag(round, got, 2 * n_ret)) break; // this round's values, all of them
 			if (++spins > (1u << 21)) { // ~1 us per look: gives up after a couple of seconds
 				ok = false;
 				break;
@@ -71,12 +122,10 @@ __device__ __forceinline__ bool peer_exchange(f128 *vals, uint32_t n_ret, uint64
 		}
 	}
 	ok = __all(ok);
-	for (uint32_t r = 0; r < n_ret; r++) {
-		uint64_t lo = 0, hi = 0;
-		if (p < world && ok) {
-			lo = __hip_atomic_load(src + 2 * r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-			hi = __hip_atomic_load(src + 2 * r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-		}
+#pragma unroll
+	for (int r = 0; r < kFinMaxRets; r++) {
+		if ((uint32_t)r >= n_ret) break;
+		uint64_t lo = (p < world && ok) ? got[2 * r] : 0, hi = (p < world && ok) ? got[2 * r + 1] : 0;
 #pragma unroll
 		for (int m = 8; m >= 1; m >>= 1) { // world <= 16
 			lo ^= __shfl_xor(lo, m, 64);
@@ -158,7 +207,7 @@ __device__ __forceinline__ void finalize_body(const fin_args &a, f128 *S, f128 *
 		if (tid < a.n_ret) fin_pv[tid] = fin_values[a.ret_ids[tid]];
 		__syncthreads();
 		if (tid < 64) {
-			const bool ok = peer_exchange(fin_pv, a.n_ret, peer->box, peer->world, peer->rank, peer->round);
+			const bool ok = peer_exchange(fin_pv, a.n_ret, peer->box, peer->world, peer->rank, peer->round, peer->stress);
 			if (!ok && tid == 0 && seq) __hip_atomic_store(&mail[65].lo, peer->round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 		}
 		__syncthreads();
@@ -206,7 +255,7 @@ struct fin_cache {
 	f128 *S, *rets, *mail;
 	unsigned *counter;
 	uint64_t *peer_box[kPeerMaxWorld];
-	uint32_t peer_world, peer_rank;
+	uint32_t peer_world, peer_rank, peer_stress;
 	uint64_t peer_round;
 };
 struct fin_pref {
@@ -250,6 +299,7 @@ __device__ __forceinline__ void fin_commit(const fin_fuse &fz, const fin_pref &r
 		if (tid == 0) {
 			c.peer_world = fz.peer.world;
 			c.peer_rank = fz.peer.rank;
+			c.peer_stress = fz.peer.stress;
 			c.peer_round = fz.peer.round;
 			c.n_terms = n_terms;
 			c.n_values = fz.args.n_values;
@@ -337,7 +387,7 @@ __device__ __forceinline__ void finalize_cached(const fin_cache &c, uint64_t seq
 		if (tid < n_ret) fc_pv[tid] = fc_values[c.ret_ids[tid]];
 		__syncthreads();
 		if (tid < 64) {
-			const bool ok = peer_exchange(fc_pv, n_ret, c.peer_box, c.peer_world, c.peer_rank, c.peer_round);
+			const bool ok = peer_exchange(fc_pv, n_ret, c.peer_box, c.peer_world, c.peer_rank, c.peer_round, c.peer_stress);
 			if (!ok && tid == 0 && seq) __hip_atomic_store(&mail[65].lo, c.peer_round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 		}
 		__syncthreads();

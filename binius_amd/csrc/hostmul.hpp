@@ -5,6 +5,7 @@
 // ~0.2 us instead of ~0.9 us (mul_host_table); on hosts with PCLMULQDQ mul_host takes the route of hostmul_clmul.cpp instead.  A small round of the sumcheck costs the caller three of these (evaluate_univariate,
 // powers of the batching coefficient), which is a tenth of the round once the launch is off the critical path (arm.hpp).
 #pragma once
+#include <cstddef>
 #include <cstdint>
 #include <cstdlib>
 #include <memory>
@@ -64,6 +65,21 @@ inline f128 mul_host_table(f128 a, f128 b)
 // self-check against mul_host_table on a host that has the instruction.  BN_HOSTMUL=table keeps the table form.
 bool hostmul_clmul_available();
 f128 mul_host_clmul(f128 a, f128 b);
+
+// ---- the same field in the power basis of hostmul_clmul.cpp (coordinates Phi(v)): products are four PCLMULQDQ plus a
+// Barrett reduction, sums of products reduce once.  Used by the host tail of a sumcheck (abi_kernels.cpp); only meaningful
+// when hostpoly_available().
+struct hp128 {
+	uint64_t lo, hi;
+};
+bool hostpoly_available();
+hp128 hostpoly_from_tower(f128 v);
+f128 hostpoly_to_tower(hp128 v);
+hp128 hostpoly_mul(hp128 a, hp128 b);
+void hostpoly_fold(hp128 *x, size_t half, hp128 z); // x[i] += z (x[i] + x[i + half]), i < half
+// y1 = sum a[half + i] b[half + i], yinf = sum (a[i] + a[half + i]) (b[i] + b[half + i]), i < half
+void hostpoly_round_sums(const hp128 *a, const hp128 *b, size_t half, hp128 *y1, hp128 *yinf);
+void hostpoly_phi_nibble_table(uint64_t *out); // [1024]: Phi(e << 4 p) at entry 16 p + e (the layout of ctable.hpp's T)
 
 inline f128 mul_host(f128 a, f128 b)
 {

@@ -12,13 +12,22 @@
 // exist, and the finished multiplier is compared with the table product on fixed and pseudo-random operands before it is
 // used; on a host without PCLMULQDQ (or if any check fails) hostmul.hpp keeps the table form.
 //
-// Host-only translation unit (compiled with -mpclmul -msse4.1, entered only after the cpuid check).
-#include <immintrin.h>
+// The same state serves the HOST TAIL of a sumcheck (abi_kernels.cpp): the last rounds, on arrays of a few hundred elements,
+// run on the host in the power basis (the device hands the arrays over already mapped through Phi: hostpoly_phi_nibble_table)
+// -- sums of products accumulate the unreduced 256-bit carry-less products and are reduced once (hostpoly_round_sums).
+//
+// Host-only translation unit.  Built without any -m flag: only the functions that use the intrinsics carry the target
+// attribute, and they are entered only after the cpuid check; on a host that is not x86-64 the unit compiles to stubs that
+// report "not available" (hostmul.hpp then keeps the table form and the host tail stays off).
 #include <stdint.h>
 
 #include <cstring>
 
 #include "hostmul.hpp"
+
+#if defined(__x86_64__)
+#include <immintrin.h>
+#define BN_CLMUL_FN __attribute__((target("pclmul,sse4.1")))
 
 namespace bn {
 
@@ -48,7 +57,7 @@ inline u128 apply(const u128 (*tab)[256], u128 v)
 }
 
 // 128 x 128 -> 256 bit carry-less product
-inline void clmul256(u128 a, u128 b, u128 &lo, u128 &hi)
+BN_CLMUL_FN inline void clmul256(u128 a, u128 b, u128 &lo, u128 &hi)
 {
 	const __m128i va = _mm_set_epi64x((long long)a.hi, (long long)a.lo), vb = _mm_set_epi64x((long long)b.hi, (long long)b.lo);
 	const __m128i p00 = _mm_clmulepi64_si128(va, vb, 0x00), p11 = _mm_clmulepi64_si128(va, vb, 0x11);
@@ -58,14 +67,21 @@ inline void clmul256(u128 a, u128 b, u128 &lo, u128 &hi)
 	hi = u128{(uint64_t)_mm_cvtsi128_si64(h), (uint64_t)_mm_extract_epi64(h, 1)};
 }
 
-inline u128 mul_poly(const clmul_state &st, u128 a, u128 b)
+// (L + x^128 H) mod m, Barrett: q = H + floor(H mu0 / x^128), r = L + low128(q m0)
+BN_CLMUL_FN inline u128 reduce256(const clmul_state &st, u128 L, u128 H)
 {
-	u128 L, H, t_lo, t_hi;
-	clmul256(a, b, L, H);
+	u128 t_lo, t_hi;
 	clmul256(H, st.mu0, t_lo, t_hi);
 	const u128 q = x128(H, t_hi); // floor(H mu / x^128)
 	clmul256(q, st.m0, t_lo, t_hi);
 	return x128(L, t_lo);
+}
+
+BN_CLMUL_FN inline u128 mul_poly(const clmul_state &st, u128 a, u128 b)
+{
+	u128 L, H;
+	clmul256(a, b, L, H);
+	return reduce256(st, L, H);
 }
 
 // bit i of the 128-bit row vector
@@ -78,9 +94,14 @@ inline void flip(u128 &v, int i)
 		v.hi ^= 1ull << (i - 64);
 }
 
+BN_CLMUL_FN bool build_checked(clmul_state &st);
 bool build(clmul_state &st)
 {
 	if (!__builtin_cpu_supports("pclmul") || !__builtin_cpu_supports("sse4.1")) return false;
+	return build_checked(st);
+}
+BN_CLMUL_FN bool build_checked(clmul_state &st)
+{
 	for (uint64_t attempt = 1; attempt <= 8; attempt++) {
 		// candidate generator: fixed odd constants, no structure needed -- almost every element has a minimal polynomial of degree 128
 		const f128 beta{0x9E3779B97F4A7C15ull * attempt ^ 0x2545F4914F6CDD1Dull, 0xD1B54A32D192ED03ull * attempt ^ 0x8CB92BA72F3D8DD7ull};
@@ -187,11 +208,89 @@ const clmul_state &state()
 
 bool hostmul_clmul_available() { return state().ok; }
 
-f128 mul_host_clmul(f128 a, f128 b)
+namespace {
+BN_CLMUL_FN f128 mul_host_clmul_impl(const clmul_state &st, f128 a, f128 b)
 {
-	const clmul_state &st = state();
 	const u128 p = apply(st.inv, mul_poly(st, apply(st.fwd, u128{a.lo, a.hi}), apply(st.fwd, u128{b.lo, b.hi})));
 	return f128{p.lo, p.hi};
 }
+BN_CLMUL_FN void fold_impl(const clmul_state &st, hp128 *x, size_t half, hp128 z)
+{
+	const u128 zz{z.lo, z.hi};
+	for (size_t i = 0; i < half; i++) {
+		const u128 d = mul_poly(st, zz, u128{x[i].lo ^ x[i + half].lo, x[i].hi ^ x[i + half].hi});
+		x[i].lo ^= d.lo;
+		x[i].hi ^= d.hi;
+	}
+}
+BN_CLMUL_FN void round_sums_impl(const clmul_state &st, const hp128 *a, const hp128 *b, size_t half, hp128 *y1, hp128 *yinf)
+{
+	// reduction modulo m is linear: the 256-bit carry-less products are XORed unreduced and reduced once per sum
+	u128 L1{0, 0}, H1{0, 0}, Li{0, 0}, Hi{0, 0};
+	for (size_t i = 0; i < half; i++) {
+		u128 l, h;
+		const u128 ah{a[half + i].lo, a[half + i].hi}, bh{b[half + i].lo, b[half + i].hi};
+		clmul256(ah, bh, l, h);
+		L1 = x128(L1, l);
+		H1 = x128(H1, h);
+		clmul256(u128{a[i].lo ^ ah.lo, a[i].hi ^ ah.hi}, u128{b[i].lo ^ bh.lo, b[i].hi ^ bh.hi}, l, h);
+		Li = x128(Li, l);
+		Hi = x128(Hi, h);
+	}
+	const u128 r1 = reduce256(st, L1, H1), ri = reduce256(st, Li, Hi);
+	*y1 = hp128{r1.lo, r1.hi};
+	*yinf = hp128{ri.lo, ri.hi};
+}
+BN_CLMUL_FN hp128 mul_impl(const clmul_state &st, hp128 a, hp128 b)
+{
+	const u128 p = mul_poly(st, u128{a.lo, a.hi}, u128{b.lo, b.hi});
+	return hp128{p.lo, p.hi};
+}
+} // namespace
+
+f128 mul_host_clmul(f128 a, f128 b) { return mul_host_clmul_impl(state(), a, b); }
+
+// ---- arithmetic in the power basis (the host tail of a sumcheck)
+bool hostpoly_available() { return state().ok; }
+hp128 hostpoly_from_tower(f128 v)
+{
+	const u128 p = apply(state().fwd, u128{v.lo, v.hi});
+	return hp128{p.lo, p.hi};
+}
+f128 hostpoly_to_tower(hp128 v)
+{
+	const u128 p = apply(state().inv, u128{v.lo, v.hi});
+	return f128{p.lo, p.hi};
+}
+hp128 hostpoly_mul(hp128 a, hp128 b) { return mul_impl(state(), a, b); }
+void hostpoly_fold(hp128 *x, size_t half, hp128 z) { fold_impl(state(), x, half, z); }
+void hostpoly_round_sums(const hp128 *a, const hp128 *b, size_t half, hp128 *y1, hp128 *yinf) { round_sums_impl(state(), a, b, half, y1, yinf); }
+void hostpoly_phi_nibble_table(uint64_t *out)
+{
+	// out[(16 p + e) * 2 ..] = Phi(e << 4 p): the layout of ctable.hpp's T (nibble position p, entry e)
+	const clmul_state &st = state();
+	for (int p = 0; p < 32; p++)
+		for (int e = 0; e < 16; e++) {
+			const u128 v = st.fwd[p >> 1][(p & 1) ? (e << 4) : e];
+			out[2 * (16 * p + e)] = v.lo;
+			out[2 * (16 * p + e) + 1] = v.hi;
+		}
+}
 
 } // namespace bn
+
+#else // not x86-64: no carry-less multiply route
+
+namespace bn {
+bool hostmul_clmul_available() { return false; }
+f128 mul_host_clmul(f128 a, f128 b) { return mul_host_table(a, b); }
+bool hostpoly_available() { return false; }
+hp128 hostpoly_from_tower(f128 v) { return hp128{v.lo, v.hi}; }
+f128 hostpoly_to_tower(hp128 v) { return f128{v.lo, v.hi}; }
+hp128 hostpoly_mul(hp128 a, hp128) { return a; }
+void hostpoly_fold(hp128 *, size_t, hp128) {}
+void hostpoly_round_sums(const hp128 *, const hp128 *, size_t, hp128 *, hp128 *) {}
+void hostpoly_phi_nibble_table(uint64_t *) {}
+} // namespace bn
+
+#endif

@@ -23,6 +23,16 @@ struct bn_expr {
 
 namespace bn {
 constexpr int kPeerMaxWorld = 16; // ranks of one node that can share a peer exchange (finalize.hpp)
+// Up to 8 chained folds of two small arrays in ONE launch (the device catching up with a host tail, abi_kernels.cpp):
+// level 0 reads src0[j][i], x1[j][i] (i < n0 <= 128) and writes out[j][i]; level l >= 1 folds out[j][0 .. n0 >> (l - 1))
+// in place with z[l].  Memory ends up exactly as after `k` separate folds.
+struct fold_chain_args {
+	const void *src0[2];
+	const void *x1[2];
+	void *out[2];
+	uint32_t n0, k;
+	f128 z[8];
+};
 }
 
 struct bn_ctx {
@@ -150,6 +160,25 @@ struct bn_ctx {
 		const void *lo[2] = {};
 		bn::f128 y[2][4] = {};
 	} fin_y;
+	// Host tail of a sumcheck (abi_kernels.cpp "host tail"): once the arrays are down to a few hundred elements the
+	// two-round kernel hands them to the host (already mapped into the power basis of hostmul_clmul.cpp) and the remaining
+	// rounds -- evaluations and folds -- are host arithmetic: no launch, no round trip.  The device catches up with ONE
+	// launch that performs all the folds (launch_fold_chain) when the caller reads the final evaluations or does anything
+	// else; the caller's memory ends up exactly as eager execution leaves it.
+	struct host_tail_state {
+		bool active = false;
+		bool evaluated = false;        // the evaluation of the current arrays has been answered: the next expected call is their fold
+		uint32_t n_levels = 0;         // folds performed on the host and not yet on the device
+		bn::fold_chain_args chain{};   // ... and what they are
+		uint64_t cur_m = 0;            // elements per array of the current (host) arrays
+		const void *cur_lo[2] = {}, *cur_hi[2] = {}; // device addresses of their halves: what the next calls must name
+		std::vector<uint64_t> y[2];    // the arrays in the power basis, 2 words per element
+	} ht;
+	void *h_tail = nullptr, *d_tail = nullptr; // pinned staging the kernel mirrors Y into (host / device view), 2 x 256 elements
+	void *d_phi = nullptr;                     // nibble table of the basis change (8 KiB of device memory)
+	bool ht_enabled = false;                   // BN_HOST_TAIL=0 turns it off; needs PCLMULQDQ on the host
+	uint64_t ht_max = 256;                     // largest Y (elements per array) the host takes over (BN_HOST_TAIL_MAX_LOG2, <= 8)
+	uint64_t ht_started = 0, ht_rounds = 0, ht_flushed = 0; // instances taken over, evaluations answered, chains launched
 	void *ntt_cache = nullptr; // bn::ntt_bs_cache (allocated on first use)
 	// all-ones | all-zeros tables of the old HAL's routed round evaluation (abi_hal.cpp): filled once per size, kept
 	void *hal_const = nullptr;
@@ -197,6 +226,7 @@ struct bn_ctx {
 		void *own = nullptr;                       // this rank's mailbox (fine-grained device memory)
 		void *box[bn::kPeerMaxWorld] = {};         // every rank's mailbox as mapped here (box[rank] == own)
 		bool connected = false, active = false;    // active: reduce the round evaluations launched from now on
+		uint32_t stress = 0;                       // BN_PEER_STRESS, read when the mailbox is created
 		uint64_t round = 0;                        // rounds executed so far (monotonic for the life of the attachment)
 	} peer;
 };
@@ -265,13 +295,15 @@ hipError_t launch_xor_publish(hipStream_t s, const f128 *d_vals, uint32_t n_grou
 // (hipIpc; over xGMI between devices).  The finalizing workgroup stores this rank's returned values into its slot of
 // EVERY rank's mailbox, waits until all `world` slots of its own mailbox carry this round's number, and publishes
 // the XOR.  Mailbox = [2 (round parity)][kPeerMaxWorld (writer rank)][kPeerSlotWords] 64-bit words; slot words
-// 0 .. 2 n_ret - 1 = values, word 16 = round number (written last, release).
+// 0 .. 2 n_ret - 1 = values, word 16 = the slot's tag = a 64-bit mix of the round number and the value words: a reader accepts
+// a slot only when the tag it read is the tag of the values it read (finalize.hpp peer_exchange).
 constexpr int kPeerSlotWords = 24;
 constexpr size_t kPeerMailboxBytes = 2 * kPeerMaxWorld * kPeerSlotWords * sizeof(uint64_t);
 struct fin_peer {
 	uint64_t *box[kPeerMaxWorld]; // device-visible mailbox of every rank (box[rank] = this rank's own)
 	uint32_t world, rank;         // world <= 1: no exchange
 	uint64_t round;               // >= 1, the same on every rank, +1 per reduced launch
+	uint32_t stress;              // BN_PEER_STRESS (test only): bit 0 = tag before the values, bit 1 = pauses between the value words
 };
 // fused form: the last workgroup to finish (device-scope ticket counter) runs the finalize body
 struct fin_fuse {
@@ -318,11 +350,17 @@ struct foldeval8_args {
 	void *out[2];      // n_folds >= 1: where Y (n_in >> n_folds elements) is written (may be x0)
 	uint64_t n_in;
 	uint32_t n_folds;
+	// host tail (abi_kernels.cpp): non-null -> Y is also handed to the host, mapped into the host's power basis on the way
+	// (mirror[arr * M + i] = Phi(Y_arr[i]), pinned host memory; phi_tab = the 512-entry nibble table of Phi in device
+	// memory, ctable.hpp layout).  Single-workgroup launches only (M <= 256).
+	f128 *mirror;
+	const uint4 *phi_tab;
 };
 hipError_t launch_foldeval8(hipStream_t s, const foldeval8_args &fa, f128 z1, f128 z2, f128 *d_out8, const fin_fuse *fuse,
                             const arm_args *armed = nullptr);
 // the last two folds of a sumcheck in one launch (4 n_out -> n_out elements per array, count * n_out <= 64), mirrored into
 // the mailbox like launch_fold_publish
+hipError_t launch_fold_chain(hipStream_t s, const fold_chain_args &a);
 hipError_t launch_fold2_publish(hipStream_t s, void *const *out, const void *const *src0, const void *const *x1, uint32_t count, uint32_t n_out,
                                 f128 z1, f128 z2, f128 *d_mail, uint64_t seq);
 hipError_t launch_roundeval9_eq(hipStream_t s, int n_cu, const void *a_hi, const void *a_lo, const void *b_hi, const void *b_lo,

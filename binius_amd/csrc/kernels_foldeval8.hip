@@ -156,6 +156,7 @@ __device__ __forceinline__ void tail8(const uint32_t (&acc)[32], const lay8 &lay
 		wsum[wave][2 * lane] = S.lo;
 		wsum[wave][2 * lane + 1] = S.hi;
 	}
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (a host-tail launch: every wave's stores into the host mirror are out before the barrier)
 	__syncthreads();
 	BN_TS(7);
 	unsigned *const counter = fc.counter;
@@ -192,6 +193,7 @@ __global__ __launch_bounds__(512, 1) void k_foldeval8(foldeval8_args fa, f128 z1
 	__shared__ uint4 stage[8 * kRowsPad];
 	__shared__ uint4 tile[4][kTile8];
 	__shared__ ctable_smem tab[NF == 2 ? 2 : 1];
+	__shared__ uint4 phi_T[512]; // host tail: the nibble table of the host's basis change (ctable.hpp layout of T)
 	__shared__ fin_cache fcache;
 	BN_TS(0);
 	const uint64_t seq = fz.args.seq;
@@ -220,11 +222,18 @@ __global__ __launch_bounds__(512, 1) void k_foldeval8(foldeval8_args fa, f128 z1
 		}
 	}
 	const fin_pref fpre = fin_prefetch(fz);
+	const bool to_host = fa.mirror != nullptr; // (uniform) host tail: Y also goes to the host, in the host's basis
+	uint4 phi_v{0, 0, 0, 0};
+	if (to_host) phi_v = fa.phi_tab[tid];
 	BN_TS(1);
 	if (arm.h_cmd) { // (uniform) armed launch: the data is on its way, the challenges are what is missing (arm.hpp)
 		f128 z2_in;
 		if (!arm_wait(arm, z1, z2_in)) return;
 		z2 = z2_in;
+	}
+	if (to_host) {
+		phi_T[tid] = phi_v;
+		if constexpr (NF == 0) __syncthreads(); // (the table builds below contain the barrier otherwise)
 	}
 	if constexpr (NF == 2)
 		ctable_build_group(tab[tid >> 8], (tid >> 8) ? z2 : z1, tid & 255, 256); // both tables at once
@@ -241,7 +250,14 @@ __global__ __launch_bounds__(512, 1) void k_foldeval8(foldeval8_args fa, f128 z1
 		if constexpr (NF >= 1) ((uint4 *)fa.out[arr])[i] = y;
 		if constexpr (NF == 2) ((uint4 *)fa.out[arr])[i + m] = u_hi; // memory ends up exactly as after two separate in-place folds
 		stage[(arr * 4 + qt) * kRowsPad + lane] = y;
-		if (m == 4 && fz.mail) {
+		if (to_host) {
+			// Phi is GF(2)-linear: one more nibble-table product.  Stored with system-scope atomics into pinned host memory;
+			// every wave drains its stores in tail8, ahead of the barrier that precedes the sequence word.
+			const uint4 py = ctable_mul(*reinterpret_cast<const ctable_smem *>(phi_T), y);
+			f128 *slot = fa.mirror + (uint64_t)arr * m + i;
+			__hip_atomic_store(&slot->lo, (uint64_t)py.x | ((uint64_t)py.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			__hip_atomic_store(&slot->hi, (uint64_t)py.z | ((uint64_t)py.w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		} else if (m == 4 && fz.mail) {
 			// the last launch of a sumcheck: Y is four elements per array -- the host folds them itself (six products) when the
 			// caller reads the final evaluations; published before the sequence number (drained below, a barrier follows)
 			f128 *slot = fz.mail + 32 + arr * 4 + qt;
@@ -279,6 +295,7 @@ hipError_t launch_foldeval8(hipStream_t s, const foldeval8_args &fa, f128 z1, f1
 	if (m < 4 || (m & 3) || (m << fa.n_folds) != fa.n_in) return hipErrorNotSupported;
 	const uint64_t q = m >> 2, blocks = (q + kPts - 1) / kPts;
 	if (blocks > 4096) return hipErrorNotSupported;
+	if (fa.mirror && (blocks != 1 || !fa.phi_tab)) return hipErrorNotSupported; // (the mirror's ordering argument is a single workgroup's)
 	arm_args arm{};
 	if (armed) arm = *armed;
 	fin_fuse fz{};

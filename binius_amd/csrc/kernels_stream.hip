@@ -272,6 +272,53 @@ hipError_t launch_fold2_publish(hipStream_t s, void *const *out, const void *con
 	return hipGetLastError();
 }
 
+// Up to eight chained folds of two small arrays in one launch (fold_chain_args, internal.hpp): the device catching up with
+// the folds a host tail performed on its own copy (abi_kernels.cpp).  One workgroup of 512 threads; the nibble tables of four
+// levels are built side by side by its four quarters, thread (array = t >> 7, i = t & 127) carries element i of its array
+// through the levels (values in LDS between them), and every level's output is stored where a separate in-place fold
+// would have left it -- later levels overwrite the lower part, by the same thread, in program order.
+__global__ __launch_bounds__(512) void k_fold_chain(fold_chain_args a)
+{
+	__shared__ ctable_smem tab[4];
+	__shared__ uint4 buf[2][128];
+	const unsigned tid = threadIdx.x, grp = tid >> 7, arr = (tid >> 7) & 1, i = tid & 127;
+	const bool mine = tid < 256;
+	for (uint32_t l0 = 0; l0 < a.k; l0 += 4) {
+		const bool build = l0 + grp < a.k; // (every thread takes part in the barriers of the build)
+		ctable_build_group(tab[grp], build ? a.z[l0 + grp] : f128{0, 0}, build ? i : 128u, 128);
+		for (uint32_t l = l0; l < l0 + 4 && l < a.k; l++) {
+			const uint32_t n = a.n0 >> l; // elements this level writes
+			uint4 v{0, 0, 0, 0};
+			const bool act = mine && i < n;
+			if (act) {
+				uint4 x0, x1;
+				if (l == 0) {
+					x0 = ((const uint4 *)a.src0[arr])[i];
+					x1 = ((const uint4 *)a.x1[arr])[i];
+				} else {
+					x0 = buf[arr][i];
+					x1 = buf[arr][i + n];
+				}
+				v = xor4(x0, ctable_mul(tab[l - l0], xor4(x0, x1)));
+			}
+			__syncthreads(); // (everybody has read the previous level)
+			if (act) {
+				buf[arr][i] = v;
+				((uint4 *)a.out[arr])[i] = v;
+			}
+			__syncthreads();
+		}
+	}
+}
+
+hipError_t launch_fold_chain(hipStream_t s, const fold_chain_args &a)
+{
+	if (a.k == 0) return hipSuccess;
+	if (a.k > 8 || a.n0 == 0 || a.n0 > 128 || (a.n0 & (a.n0 - 1)) || (a.n0 >> (a.k - 1)) == 0) return hipErrorNotSupported;
+	hipLaunchKernelGGL(k_fold_chain, dim3(1), dim3(512), 0, s, a);
+	return hipGetLastError();
+}
+
 // x[i] *= c in place (the stand-alone form of the upper-half scaling of bn_extrapolate_line_batch_scaled; the fused
 // fold + evaluation kernels do it on the folded registers)
 __global__ __launch_bounds__(256) void k_scale(uint4 *__restrict__ x, uint64_t n, f128 c)

@@ -318,8 +318,12 @@ int bn_prof_end(bn_ctx *ctx, double *ms_by_class /*[BN_PROF_N]*/, uint64_t *laun
  * turns it off).  Counters since context creation: rounds served by an armed kernel, armed kernels that were cancelled
  * because the next call was something else, armed kernels that gave up waiting; host nanoseconds between handing over
  * a challenge and seeing the round's result, the part of that spent enqueueing the next armed kernel, and the time from
- * the entry of bn_kernel_launch to handing the challenge over (validation + recognising the round). */
-enum { BN_ARM_HITS = 0, BN_ARM_CANCELS = 1, BN_ARM_EXPIRED = 2, BN_ARM_NS_WAIT = 3, BN_ARM_NS_LAUNCH = 4, BN_ARM_NS_PARSE = 5, BN_ARM_HOSTED = 6, BN_ARM_TWO_ROUND = 7, BN_ARM_SHADOW_CREATED = 8, BN_ARM_SHADOW_ROUNDS = 9, BN_ARM_SHADOW_DROPPED = 10, BN_ARM_N = 11 };
+ * the entry of bn_kernel_launch to handing the challenge over (validation + recognising the round).
+ * BN_ARM_HT_*: the host tail -- once the arrays of a bivariate sumcheck are down to <= 256 elements the two-round kernel
+ * hands them to the host and the remaining evaluations and folds are host arithmetic (PCLMULQDQ in an isomorphic power
+ * basis), the device catching up with one launch; instances taken over, evaluations answered, catch-up launches.
+ * BN_HOST_TAIL=0 turns it off.  Like arming, an execution detail of the unchanged call sequence. */
+enum { BN_ARM_HITS = 0, BN_ARM_CANCELS = 1, BN_ARM_EXPIRED = 2, BN_ARM_NS_WAIT = 3, BN_ARM_NS_LAUNCH = 4, BN_ARM_NS_PARSE = 5, BN_ARM_HOSTED = 6, BN_ARM_TWO_ROUND = 7, BN_ARM_SHADOW_CREATED = 8, BN_ARM_SHADOW_ROUNDS = 9, BN_ARM_SHADOW_DROPPED = 10, BN_ARM_HT_STARTED = 11, BN_ARM_HT_ROUNDS = 12, BN_ARM_HT_FLUSHED = 13, BN_ARM_N = 14 };
 int bn_arm_counters(bn_ctx *ctx, uint64_t *counters /*[BN_ARM_N]*/);
 
 #ifdef __cplusplus

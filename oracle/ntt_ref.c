@@ -102,9 +102,14 @@ int ref_ntt_forward(void *data, int elem_level, int tw_level, const uint64_t *s_
 	for (size_t x = 0; x < ((size_t)1 << log_x); x++)
 		for (size_t z = 0; z < ((size_t)1 << log_z); z++) {
 			size_t batch = x | z << (log_x + log_y);
-			for (int i = log_n - skip_rounds - 1; i >= 0; i--)
+			for (int i = log_n - skip_rounds - 1; i >= 0; i--) {
+				/* (the butterflies of one layer are independent: blocks j across the host threads when there are many of them,
+				 * otherwise the butterflies k inside a block -- the arithmetic and its order per element are unchanged) */
+				const int many = (log_n - 1 - i) >= 6;
+#pragma omp parallel for schedule(static) if (many && log_n >= 16)
 				for (size_t j = 0; j < ((size_t)1 << (log_n - 1 - i)); j++) {
 					uint64_t tw = ref_ntt_twiddle(s_evals, log_domain, base + i, coset << (log_n - 1 - i) | j);
+#pragma omp parallel for schedule(static) if (!many && log_n >= 16)
 					for (size_t k = 0; k < ((size_t)1 << i); k++) {
 						size_t idx0 = j << (i + 1) | k;
 						size_t idx1 = idx0 | (size_t)1 << i;
@@ -117,6 +122,7 @@ int ref_ntt_forward(void *data, int elem_level, int tw_level, const uint64_t *s_
 						store_elem(data, elem_level, p1, v);
 					}
 				}
+			}
 		}
 	return 0;
 }
@@ -132,9 +138,12 @@ int ref_ntt_inverse(void *data, int elem_level, int tw_level, const uint64_t *s_
 	for (size_t x = 0; x < ((size_t)1 << log_x); x++)
 		for (size_t z = 0; z < ((size_t)1 << log_z); z++) {
 			size_t batch = x | z << (log_x + log_y);
-			for (int i = 0; i < log_n - skip_rounds; i++)
+			for (int i = 0; i < log_n - skip_rounds; i++) {
+				const int many = (log_n - 1 - i) >= 6;
+#pragma omp parallel for schedule(static) if (many && log_n >= 16)
 				for (size_t j = 0; j < ((size_t)1 << (log_n - 1 - i)); j++) {
 					uint64_t tw = ref_ntt_twiddle(s_evals, log_domain, base + i, coset << (log_n - 1 - i) | j);
+#pragma omp parallel for schedule(static) if (!many && log_n >= 16)
 					for (size_t k = 0; k < ((size_t)1 << i); k++) {
 						size_t idx0 = j << (i + 1) | k;
 						size_t idx1 = idx0 | (size_t)1 << i;
@@ -147,6 +156,7 @@ int ref_ntt_inverse(void *data, int elem_level, int tw_level, const uint64_t *s_
 						store_elem(data, elem_level, p1, v);
 					}
 				}
+			}
 		}
 	return 0;
 }

@@ -1,6 +1,8 @@
 """Differential test of the ABI's deferred execution (pending folds and copies, fold + evaluation
 fusion, host mirror of tiny folds, resident tail) against eager execution (BN_NO_LAZY_FOLD=1): random
 sequences of ComputeLayer calls must leave identical device memory and return identical values."""
+import os
+
 import numpy as np
 import pytest
 
@@ -97,6 +99,186 @@ def test_random_call_sequences(monkeypatch, oracle, seed, tail):
             assert len(outs) in (0, 2) and (not outs or outs[0] == outs[1]), (step, op)
         for j in range(n_bufs):
             assert np.array_equal(ctxs[0][0].copy_d2h(ctxs[0][1][j]), ctxs[1][0].copy_d2h(ctxs[1][1][j])), j
+    finally:
+        eager.close()
+        lazy.close()
+
+
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_random_call_sequences_at_dispatch_sizes(monkeypatch, oracle, seed):
+    """VERDICT r3 item 6 iii: the same differential fuzz where the dispatcher actually switches kernels -- arrays of 2^16 ..
+    2^21 elements (k_foldeval_mfma / k_roundeval_fp4 from 2^17 points, the armed mid-size launches up to 2^21, the hand-over
+    to the two-round kernels at 2^17 -> 2^16, and with long enough chains the host tail) -- with prover-shaped chains of
+    rounds, three-factor (MLE-check) evaluations and table folds (the weighted shadow), scaled folds and foreign calls in the
+    mix.  Three-way: deferred execution == eager execution (BN_NO_LAZY_FOLD=1) == a host model driven by the oracle, for
+    every returned value and, at the end, for every byte of every buffer."""
+    import binius_amd
+    from binius_amd.sumcheck import bivariate_product_eq_expr, bivariate_product_expr, calculate_round_evals
+
+    rng = np.random.RandomState(0xD15 + 977 * seed)
+    log_n = int(rng.randint(16, 22))
+    n = 1 << log_n
+    n_bufs = 4
+    monkeypatch.setenv("BN_NO_LAZY_FOLD", "1")
+    eager = binius_amd.Context(0, (n_bufs + 1) * n + 4096)
+    monkeypatch.delenv("BN_NO_LAZY_FOLD")
+    lazy = binius_amd.Context(0, (n_bufs + 1) * n + 4096)
+    threads = min(8, os.cpu_count() or 1)
+    try:
+        model = [oracle.random_b128(0xFA330000 + 16 * seed + j, n) for j in range(n_bufs)]
+        eq_model = oracle.random_b128(0xFA330000 + 16 * seed + 9, n // 2)
+        ctxs = []
+        for hal in (eager, lazy):
+            alloc = hal.dev_alloc()
+            bufs = [alloc.alloc(n) for _ in range(n_bufs)]
+            for b, h in zip(bufs, model):
+                hal.copy_h2d(h, b)
+            eq = alloc.alloc(n // 2)
+            hal.copy_h2d(eq_model, eq)
+            ctxs.append((hal, bufs, eq, bivariate_product_expr(hal, 0, 1), bivariate_product_eq_expr(hal, 0, 1, 2)))
+        zs = oracle.random_scalars(0xFA33 + seed, 256)
+        zi = iter(zs)
+        cur = n        # live length of the arrays a, b (they shrink when folded)
+        eq_len = n // 2  # live length of the table
+        a, b = 0, 1
+
+        def fold_model(idx, z, scale_mask=0, hi_scale=0):
+            for pos, j in enumerate(idx):
+                f = model[j][: cur // 2].copy()
+                assert oracle.extrapolate_line(f, model[j][cur // 2 : cur].copy(), z) == 0
+                if (scale_mask >> pos) & 1:
+                    q = cur // 4
+                    c = oracle.arr(q)
+                    c[:] = (hi_scale & ((1 << 64) - 1), hi_scale >> 64)
+                    f[q:] = oracle.mul_vec(f[q:].copy(), c)
+                model[j][: cur // 2] = f
+
+        def check(outs, want, what):
+            assert len(outs) == 2 and outs[0] == outs[1], ("lazy != eager", what)
+            if want is not None:
+                assert outs[1] == want, ("device != oracle", what)
+
+        def eval2(what):
+            outs = [calculate_round_evals(hal, int(np.log2(cur)), [1], [bufs[a].slice(0, cur), bufs[b].slice(0, cur)], [e2]) for hal, bufs, eq, e2, e3 in ctxs]
+            rc, want = oracle.round_evals([model[a][:cur], model[b][:cur]], int(np.log2(cur)), [(0, 1)], 1, threads=threads)
+            assert rc == 0
+            check(outs, want, what)
+
+        def eval3(what):
+            if eq_len != cur // 2:
+                return
+            outs = [calculate_round_evals(hal, int(np.log2(cur)), [1], [bufs[a].slice(0, cur), bufs[b].slice(0, cur)], [e3], eq_ind=eq.slice(0, eq_len))
+                    for hal, bufs, eq, e2, e3 in ctxs]
+            want = None
+            if cur <= 1 << 19:  # (the scalar three-factor oracle: ~1 us per point)
+                rc, want = oracle.round_evals_eq([model[a][:cur].copy(), model[b][:cur].copy()], int(np.log2(cur)), eq_model[:eq_len].copy(), [(0, 1)], 1)
+                assert rc == 0
+            check(outs, want, what)
+
+        def fold_ab(z, scaled=False):
+            nonlocal cur
+            half = cur // 2
+            mask, hs = (int(rng.randint(1, 4)), next(zi)) if scaled else (0, 0)
+            for hal, bufs, eq, e2, e3 in ctxs:
+                e0 = [bufs[a].slice(0, half), bufs[b].slice(0, half)]
+                e1 = [bufs[a].slice(half, cur), bufs[b].slice(half, cur)]
+                if scaled:
+                    hal.extrapolate_line_batch_scaled(e0, e1, z, mask, hs)
+                else:
+                    hal.extrapolate_line_batch(e0, e1, z)
+            fold_model([a, b], z, mask, hs)
+            cur = half
+
+        def fold_table():
+            nonlocal eq_len
+            h = eq_len // 2
+            for hal, bufs, eq, e2, e3 in ctxs:
+                def k(local_exec, log_chunks, buffers, h=h):
+                    local_exec.add_assign(int(np.log2(h)) - log_chunks, buffers[1].to_ref(), buffers[0])
+                    return []
+                hal.map_kernels(k, [("chunked_mut", eq.slice(0, h), 0), ("chunked", eq.slice(h, eq_len), 0)])
+            eq_model[:h] ^= eq_model[h:eq_len]
+            eq_len = h
+
+        def foreign(kind):
+            c = int(rng.choice([2, 3]))
+            if kind == "read":
+                j = int(rng.choice([a, b, c]))
+                outs = [hal.copy_d2h(bufs[j].slice(0, 4)).tolist() for hal, bufs, *_ in ctxs]
+                check(outs, model[j][:4].tolist(), "read")
+            elif kind == "copy_out":
+                for hal, bufs, *_ in ctxs:
+                    hal.copy_d2d(bufs[a].slice(0, cur // 2), bufs[c].slice(0, cur // 2))
+                model[c][: cur // 2] = model[a][: cur // 2]
+            elif kind == "copy_in":
+                for hal, bufs, *_ in ctxs:
+                    hal.copy_d2d(bufs[c].slice(0, 64), bufs[b].slice(cur // 2, cur // 2 + 64))
+                model[b][cur // 2 : cur // 2 + 64] = model[c][:64]
+            elif kind == "copy_table":
+                for hal, bufs, eq, *_ in ctxs:
+                    hal.copy_d2d(bufs[c].slice(0, 16), eq.slice(0, 16))
+                eq_model[:16] = model[c][:16]
+            elif kind == "fill":
+                z = next(zi)
+                for hal, bufs, *_ in ctxs:
+                    hal.fill(bufs[c].slice(0, 1024), z)
+                model[c][:1024] = (z & ((1 << 64) - 1), z >> 64)
+            elif kind == "sync":
+                for hal, *_ in ctxs:
+                    hal.sync()
+
+        kinds = ["read", "copy_out", "copy_in", "copy_table", "fill", "sync"]
+        for step in range(14):
+            if cur < (1 << 13) or eq_len < 8:
+                # start over on the full buffers (whatever they hold by now) with a fresh table
+                cur, eq_len = n, n // 2
+                eq_model[:] = oracle.random_b128(0xFA340000 + 64 * seed + step, n // 2)
+                for hal, bufs, eq, *_ in ctxs:
+                    hal.copy_h2d(eq_model, eq)
+                if rng.rand() < 0.5:
+                    a, b = b, a
+            op = rng.choice(["rounds", "rounds", "rounds", "mle_rounds", "mle_rounds", "eval3", "scaled", "foreign"])
+            if op == "rounds":
+                # the v3 prover's chain: evaluate, fold, evaluate ... with the occasional foreign call in between
+                eval2((step, "rounds: first evaluation"))
+                for r in range(int(rng.randint(1, 9))):
+                    if cur < 8:
+                        break
+                    if rng.rand() < 0.15:
+                        foreign(str(rng.choice(kinds)))
+                    fold_ab(next(zi))
+                    if rng.rand() < 0.15:
+                        foreign(str(rng.choice(kinds)))
+                    eval2((step, "rounds", r))
+            elif op == "mle_rounds":
+                # the literal MLE-check sequence: a * b * eq, fold of (a, b), fold of the table (v3/bivariate_mlecheck.rs:145-254)
+                if eq_len != cur // 2:
+                    continue
+                eval3((step, "mle_rounds: first evaluation"))
+                for r in range(int(rng.randint(1, 6))):
+                    if cur < 16:
+                        break
+                    fold_ab(next(zi))
+                    if rng.rand() < 0.2:
+                        foreign(str(rng.choice(kinds)))
+                    fold_table()
+                    if rng.rand() < 0.1:
+                        foreign(str(rng.choice(kinds)))
+                    eval3((step, "mle_rounds", r))
+            elif op == "eval3":
+                eval3((step, "lone three-factor evaluation"))
+            elif op == "scaled":
+                if cur >= 16:
+                    fold_ab(next(zi), scaled=True)
+                    eval2((step, "after a scaled fold"))
+            else:
+                foreign(str(rng.choice(kinds)))
+        for j in range(n_bufs):
+            got = [hal.copy_d2h(bufs[j]) for hal, bufs, *_ in ctxs]
+            assert np.array_equal(got[0], got[1]), ("lazy != eager", j)
+            assert np.array_equal(got[1], model[j]), ("device != model", j)
+        got = [hal.copy_d2h(eq) for hal, bufs, eq, *_ in ctxs]
+        assert np.array_equal(got[0], got[1]) and np.array_equal(got[1], eq_model)
     finally:
         eager.close()
         lazy.close()

@@ -104,6 +104,33 @@ def test_transcript_equals_oracle_at_benchmark_size(oracle, n_vars):
     assert oracle.mul(want_finals[0], want_finals[1]) == running
 
 
+@pytest.mark.parametrize("n_vars", [24, 28])
+def test_bench_transcript_digest_is_the_oracles(oracle, n_vars):
+    """VERDICT r3 item 6 ii: the `transcript_digest` a `bench.py` line carries is the digest of the ORACLE's transcript of
+    the same instance -- so that BENCH_r*.json itself carries oracle parity, not only verifier_check.  bench.py runs in a
+    subprocess exactly as the driver runs it (one step is enough: every step proves the same instance)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+
+    inst = _instance(oracle, n_vars)
+    _, want_coeffs, want_finals = inst["want"]
+    want = bench.transcript_digest(want_coeffs, want_finals)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--n-vars", str(n_vars), "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-prof"],
+                       capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["verifier_check"] is True
+    assert line["transcript_digest"] == want, "bench.py's transcript digest is not the oracle's"
+    # ... and the in-process HIP transcript of the same instance has that digest too
+    _, got_coeffs, got_finals = inst["got"]
+    assert bench.transcript_digest(got_coeffs, got_finals) == want
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

@@ -98,8 +98,8 @@ def test_ntt_validation(hal):
 
 def test_ntt_config3_full_size(oracle):
     """BASELINE config 3: 2^24 BinaryField32b coefficients, shape {log_x 0, log_y 24, log_z 0}, coset 0.
-    A quarter-size transform is compared with the scalar oracle outright; at full size the checks are
-    size-independent: forward then inverse is the identity, the transform is GF(2)-linear, and (the
+    The full-size transform AND a quarter-size one (over coset 1) are compared with the scalar oracle outright; on top of
+    that the size-independent properties: forward then inverse is the identity, the transform is GF(2)-linear, and (the
     recursive structure of the novel-basis evaluation, additive_ntt.rs:23-56) the full transform with
     skip_rounds = 2 equals four quarter-size transforms over the cosets 0..3 of the same domain."""
     import binius_amd
@@ -128,6 +128,13 @@ def test_ntt_config3_full_size(oracle):
         fx = hal.copy_bytes_d2h(dx.ptr, np.zeros_like(x))
         fy = hal.copy_bytes_d2h(dy.ptr, np.zeros_like(x))
         fz = hal.copy_bytes_d2h(dz.ptr, np.zeros_like(x))
+        # the benchmarked transform itself against the scalar oracle, every one of the 2^24 outputs (VERDICT r3 item 6 i: a
+        # wrong twiddle in the two top layers, which forward and inverse share, would pass every property below; the
+        # oracle's layers run across the host threads, ~10 s)
+        want = x.copy()
+        assert oracle.ntt_forward(want, 5, 5, s, L, 0, L, 0, 0, 0, 0) == 0
+        assert np.array_equal(fx, want), "config 3 (2^24 x B32 forward) differs from the scalar oracle"
+        del want
         assert np.array_equal(fx ^ fy, fz)
         assert not np.array_equal(fx, x)
         hal.ntt_inverse(dx.ptr, 5, 5, s, L, 0, L, 0)

@@ -127,3 +127,40 @@ def test_sharded_hip_prover_matches_unsharded_oracle(world, n_global, m, comps, 
         assert [list(c) for c in coeffs] == [list(c) for c in want_coeffs], "rank %d: round polynomials differ from the unsharded oracle" % rank
         assert list(finals) == list(want_finals), "rank %d: final evaluations differ" % rank
         assert rerun_same, "rank %d: a second run from the same inputs gave a different transcript" % rank
+
+
+@pytest.mark.parametrize("world,n_global", [(2, 10), (4, 13), (8, 12), (2, 20)])
+@pytest.mark.parametrize("stress", [1, 2, 3])
+def test_peer_exchange_validates_its_slots_under_reordering(monkeypatch, world, n_global, stress):
+    """the peer exchange must not depend on the order in which a slot's words arrive.  BN_PEER_STRESS makes
+    the writer produce the orders a reordering fabric could (bit 0: the slot's tag is stored FIRST and the values follow a
+    quarter of a millisecond later; bit 1: pauses between the value words, so that readers see torn slots); a reader accepts a
+    slot only when the tag it read is the tag of the values it read for this round (csrc/finalize.hpp peer_exchange), so every
+    rank must still produce the unsharded oracle's transcript -- a stale partial XORed into a round polynomial cannot pass."""
+    import torch.multiprocessing as mp
+
+    import oracle
+
+    oracle.build()
+    monkeypatch.setenv("BN_PEER_STRESS", str(stress))  # (read by bn_peer_create in the spawned ranks)
+    m, comps = 2, [(0, 1)]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_global, m, comps, q, "peer")) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    full = [oracle.random_b128(0xB1A50000 + j, 1 << n_global) for j in range(m)]
+    stream = oracle.random_scalars(0xC4A1, n_global + 1)
+    batch_coeff, challenges = stream[0], stream[1:]
+    want_sums = [oracle.inner_product(full[i], 7, full[j])[1] for i, j in comps]
+    want_coeffs, want_finals = oracle.bivariate_sumcheck_prove([x.copy() for x in full], n_global, comps, want_sums, batch_coeff, challenges,
+                                                               threads=min(8, os.cpu_count() or 1))
+    for rank, sums, coeffs, finals, rerun_same in sorted(results):
+        assert [list(c) for c in coeffs] == [list(c) for c in want_coeffs], "rank %d, stress %d: round polynomials differ from the unsharded oracle" % (rank, stress)
+        assert list(finals) == list(want_finals), "rank %d: final evaluations differ" % rank
+        assert rerun_same, "rank %d: a second run from the same inputs gave a different transcript" % rank

@@ -65,22 +65,65 @@ def _drive(hal, oracle, n_vars, seed, after_eval=None, after_fold=None, model=No
     return full
 
 
+@pytest.fixture(scope="module")
+def hal_no_host_tail():
+    """BN_HOST_TAIL=0 (read at context creation): the chain of two-round launches runs down to four elements."""
+    import os
+
+    import binius_amd
+
+    old = os.environ.get("BN_HOST_TAIL")
+    os.environ["BN_HOST_TAIL"] = "0"
+    try:
+        ctx = binius_amd.Context(0, 1 << 21)
+    finally:
+        if old is None:
+            os.environ.pop("BN_HOST_TAIL", None)
+        else:
+            os.environ["BN_HOST_TAIL"] = old
+    yield ctx
+    ctx.close()
+
+
 @pytest.mark.parametrize("n_vars", [2, 3, 4, 5, 6, 7, 8, 11, 12, 15, 16, 17])
-def test_two_round_launches_answer_two_rounds_each(hal, oracle, n_vars):
+def test_two_round_launches_answer_two_rounds_each(hal_no_host_tail, oracle, n_vars):
     """Counted, not timed: with an even number of variables round 0 is itself a two-round launch (no fold), with an odd
     number it runs alone; from then on every launch covers two rounds and the chain ends on four elements."""
+    hal = hal_no_host_tail
     c0 = hal.arm_counters()
     _drive(hal, oracle, n_vars, 0x2B2B0000 + 64 * n_vars)
     c1 = hal.arm_counters()
     launches, hosted = c1["two_round"] - c0["two_round"], c1["hosted"] - c0["hosted"]
     small = min(n_vars - n_vars % 2, 16)  # rounds inside the two-round regime: Y of at most 2^16 elements, an even exponent
     assert launches == small // 2 and hosted == small // 2, (launches, hosted)
+    assert c1["ht_started"] == c0["ht_started"] and c1["ht_rounds"] == c0["ht_rounds"]
 
 
-def test_two_round_path_leaves_memory_as_two_separate_folds_would(hal, oracle):
+@pytest.mark.parametrize("n_vars", [2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 15, 16, 17])
+def test_host_tail_takes_the_last_rounds(hal, oracle, n_vars):
+    """The default: the first two-round launch whose Y has at most 2^8 elements per array hands Y to the host (in the host's
+    power basis), and every later evaluation and fold of the instance is host arithmetic -- no launch until the caller reads
+    the final evaluations, when ONE launch performs all the outstanding folds on the device (csrc/abi_kernels.cpp "host
+    tail").  Counted; every round's values against the oracle inside _drive, the final read included."""
+    c0 = hal.arm_counters()
+    _drive(hal, oracle, n_vars, 0x2B3B0000 + 64 * n_vars)
+    c1 = hal.arm_counters()
+    d = {k: c1[k] - c0[k] for k in c1}
+    small = min(n_vars - n_vars % 2, 16)          # exponent of the first Y of the chain (even)
+    take = min(small, 8)                          # exponent of the Y the host takes over
+    launches = (small - take) // 2 + 1            # two-round launches: Y of 2^small, 2^(small-2), ..., 2^take
+    assert d["two_round"] == launches and d["hosted"] == launches - 1, d
+    assert d["ht_started"] == 1 and d["ht_flushed"] == 1, d
+    assert d["ht_rounds"] == take - 1, d          # the rounds on 2^(take-1), ..., 2^1 elements
+
+
+@pytest.mark.parametrize("which", ["default", "no_host_tail"])
+def test_two_round_path_leaves_memory_as_two_separate_folds_would(hal, hal_no_host_tail, oracle, which):
     """After the second fold of a pair the caller's buffers hold what two in-place folds leave: Y in the first quarter,
     the upper half of the once-folded array behind it, the rest untouched.  Reading the whole buffer back at different
-    points of the pair (which flushes whatever is deferred) must always show exactly that."""
+    points of the pair (which flushes whatever is deferred) must always show exactly that.  With the host tail (the default)
+    the same holds for the folds the host performed on its own copy: a read launches the chain of outstanding folds."""
+    hal = hal if which == "default" else hal_no_host_tail
     for read_at in ("after_every_fold", "after_even_folds", "after_odd_folds", "after_eval"):
         model = []
 
@@ -98,10 +141,13 @@ def test_two_round_path_leaves_memory_as_two_separate_folds_would(hal, oracle):
             _drive(hal, oracle, 10, 0x2B2C0100, after_fold=check, model=model)
 
 
-def test_two_round_path_survives_foreign_calls(hal, oracle):
+@pytest.mark.parametrize("which", ["default", "no_host_tail"])
+def test_two_round_path_survives_foreign_calls(hal, hal_no_host_tail, oracle, which):
     """A call that is not the predicted one -- between the evaluation and its fold, between the host-answered round and the
     second fold, or after it -- flushes what is deferred and drops the precomputed sums; the rounds go on with the right
     answers (the one-round kernels take over until the next two-round launch)."""
+    hal = hal if which == "default" else hal_no_host_tail
+
     def after_eval(r, d, full):
         if r in (1, 2, 6, 9):
             hal.copy_d2h(d[0].slice(0, 1))
@@ -164,8 +210,9 @@ def test_compiled_prover_same_transcript_with_and_without_two_round_launches(ora
     batch_coeff, challenges = stream[0], stream[1:]
     want = oracle.bivariate_sumcheck_prove([x.copy() for x in mls], n_vars, comps, sums, batch_coeff, challenges, threads=4)
     seen = {}
-    for mode in ("0", "1"):
-        monkeypatch.setenv("BN_TWO_ROUND", mode)
+    for mode in ("0", "1", "1-no-host-tail"):
+        monkeypatch.setenv("BN_TWO_ROUND", mode[0])
+        monkeypatch.setenv("BN_HOST_TAIL", "0" if mode.endswith("no-host-tail") else "1")
         with binius_amd.Context(0, 4 * m << n_vars) as ctx:
             alloc = ctx.dev_alloc()
             d = [upload(ctx, alloc, x) for x in mls]
@@ -179,5 +226,10 @@ def test_compiled_prover_same_transcript_with_and_without_two_round_launches(ora
             for j in range(m):
                 assert np.array_equal(ctx.copy_d2h(d[j]), mls[j])  # PreFold inputs are never modified
     assert seen["0"]["two_round"] == 0 and seen["0"]["hosted"] == 0
+    assert seen["0"]["ht_started"] == 0 and seen["1-no-host-tail"]["ht_started"] == 0
     if len(comps) == 1 and comps[0][0] != comps[0][1] and n_vars >= 2:
-        assert seen["1"]["two_round"] > 0 and seen["1"]["hosted"] == seen["1"]["two_round"]
+        assert seen["1-no-host-tail"]["two_round"] > 0 and seen["1-no-host-tail"]["hosted"] == seen["1-no-host-tail"]["two_round"]
+        # the default: both runs of the plan were taken over by the host once, each caught up with one launch
+        assert seen["1"]["ht_started"] == 2 and seen["1"]["ht_flushed"] == 2 and seen["1"]["two_round"] > 0
+    else:
+        assert seen["1"]["ht_started"] == 0
