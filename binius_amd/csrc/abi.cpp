@@ -557,6 +557,7 @@ int bn_ctx_create(int device, uint64_t arena_elems, bn_ctx **out)
 	if (const char *a = getenv("BN_ARM")) ctx->arm_enabled = atoi(a) != 0;
 	if (const char *a = getenv("BN_TWO_ROUND")) ctx->two_round = atoi(a) != 0;
 	if (const char *a = getenv("BN_MLECHECK_SHADOW")) ctx->shadow_enabled = atoi(a) != 0;
+	if (const char *a = getenv("BN_CIRCUIT_MULTIPASS")) ctx->circuit_multipass = atoi(a) != 0;
 	BN_HIP(hipMalloc((void **)&ctx->d_flag, sizeof(unsigned)));
 	BN_HIP(hipMemset(ctx->d_flag, 0, sizeof(unsigned)));
 	BN_HIP(hipMalloc((void **)&ctx->d_s_evals, sizeof(uint64_t) * BN_NTT_MAX_DIM * BN_NTT_MAX_DIM));

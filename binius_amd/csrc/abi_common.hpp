@@ -96,6 +96,15 @@ int host_tail_flush(bn_ctx *ctx, bool publish);
 int flush_first_fold(bn_ctx *ctx);
 // the deferred fold `pf` folds exactly the arrays the precomputed next-round sums describe
 bool pre_matches(const bn_ctx::precomp_state &pre, const bn_ctx::pending_fold &pf);
+// ---- arbitrary ArithCircuits on the throughput kernels (abi_circuit.cpp)
+bool circuit_multipass_applies(const bn_ctx *ctx, const bn_expr *e, uint64_t row_len);
+constexpr int kCircuitDeclined = -1000; // (internal: the planner declines this circuit -- run the interpreter)
+// out[i] = expr(rows[.][i])
+int circuit_multipass_map(bn_ctx *ctx, const bn_expr *e, const void *const *rows, uint64_t row_len, void *out, size_t scratch_off);
+// temporaries of row_len elements circuit_multipass_sum will need (-1: declined)
+int circuit_multipass_sum_temps(const bn_expr *e, bool has_eq);
+// d_slots[0] ^ d_slots[1] ^= sum_i expr(rows[.][i]) * (eq ? eq[i] : 1)
+int circuit_multipass_sum(bn_ctx *ctx, const bn_expr *e, const void *const *rows, uint64_t row_len, const void *eq, bn::f128 *d_slots, size_t scratch_off);
 // ---- small helpers shared by the op entry points (abi.cpp)
 int publish_result(bn_ctx *ctx, uint32_t n_groups, bn_f128 *h_out);
 int upload_ptrs(bn_ctx *ctx, const void *const *ptrs, uint32_t n, const void ***d_ptrs);

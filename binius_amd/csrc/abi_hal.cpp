@@ -145,12 +145,38 @@ int bn_hal_round_evals(bn_ctx *ctx, uint32_t order, uint32_t n_vars, const void 
 		BN_REQUIRE(mls[k].d_evals || mls[k].len == 0, "multilinear without evaluations");
 		if (mls[k].kind == BN_HAL_ML_TRANSPARENT) n_tr++;
 	}
+	// ---- the general path's plan (below: "rows + compiled circuits"), made before anything is launched so that the context
+	// scratch is laid out once: [partial evaluations of the Transparent multilinears | 1 | rows | circuit temporaries]
+	bool general_ok = circuit_multipass_applies(ctx, evs[0].composition, half) && total <= 32;
+	uint32_t used_mls = 0; // bit k: multilinear k is read by some composition
+	int max_temps = 0;
+	for (uint32_t e = 0; e < n_evs && general_ok; e++)
+		for (const bn_expr *c : {(const bn_expr *)evs[e].composition, (const bn_expr *)evs[e].composition_at_infinity}) {
+			for (const bn_step &st : c->steps)
+				if (st.kind == BN_STEP_VAR) used_mls |= 1u << st.a;
+			const int t = circuit_multipass_sum_temps(c, evs[e].d_eq_ind != nullptr);
+			if (t < 0) general_ok = false;
+			if (t > max_temps) max_temps = t;
+		}
+	uint32_t n_used = 0;
+	for (uint32_t k = 0; k < n_mls; k++) n_used += (used_mls >> k) & 1;
+	const size_t tr_elems = n_tr ? (size_t)n_tr * full + 1 : 0;
+	const size_t row_elems = general_ok ? (size_t)(pt_hi - pt_lo) * n_used * half : 0;
+	const size_t temp_elems = general_ok ? (size_t)max_temps * half : 0;
 	char *scr = nullptr;
-	if (n_tr) {
-		scr = (char *)bn::ctx_scratch(ctx, ((size_t)n_tr * full + 1) * sizeof(f128));
-		if (!scr) return bn::fail(BN_ERR_ALLOC, "allocation error: allocator is out of memory (scratch)");
-		BN_HIP(bn::launch_fill(ctx->stream, scr + (size_t)n_tr * full * sizeof(f128), 1, bn::f128_one()));
+	if (tr_elems + row_elems + temp_elems) {
+		scr = (char *)bn::ctx_scratch(ctx, (tr_elems + row_elems + temp_elems) * sizeof(f128));
+		if (!scr) {
+			if (!n_tr) {
+				general_ok = false; // (no room for the rows: the interpreter kernel needs none)
+			} else {
+				scr = (char *)bn::ctx_scratch(ctx, tr_elems * sizeof(f128));
+				general_ok = false;
+				if (!scr) return bn::fail(BN_ERR_ALLOC, "allocation error: allocator is out of memory (scratch)");
+			}
+		}
 	}
+	if (n_tr) BN_HIP(bn::launch_fill(ctx->stream, scr + (size_t)n_tr * full * sizeof(f128), 1, bn::f128_one()));
 	bn::hal_round_args a{};
 	a.n_ml = n_mls;
 	a.n_ev = n_evs;
@@ -192,7 +218,10 @@ int bn_hal_round_evals(bn_ctx *ctx, uint32_t order, uint32_t n_vars, const void 
 	std::vector<term_job> jobs;
 	std::vector<std::vector<monomial>> p1(n_evs), pinf(n_evs);
 	char *ones = nullptr, *zeros = nullptr;
-	bool fast = order == BN_ORDER_HIGH_TO_LOW && all_full && pt_lo >= 1 && pt_hi <= 3 && n_vars >= 2;
+	// (Low-to-High order: the pairs are interleaved -- the matrix-core kernel reads them with an element stride of two, so the
+	// two-factor jobs take the same path from 2^17 points on)
+	const bool l2h = order == BN_ORDER_LOW_TO_HIGH;
+	bool fast = (!l2h || bn::mfma_applies(ctx->n_cu, half)) && all_full && pt_lo >= 1 && pt_hi <= 3 && n_vars >= 2;
 	auto job_of = [&](const std::vector<uint32_t> &vars, const void *eq) -> int {
 		for (size_t j = 0; j < jobs.size(); j++)
 			if (jobs[j].vars == vars && jobs[j].eq == eq) return (int)j;
@@ -203,7 +232,7 @@ int bn_hal_round_evals(bn_ctx *ctx, uint32_t order, uint32_t n_vars, const void 
 		fast = expand_poly(evs[e].composition, p1[e]) && expand_poly(evs[e].composition_at_infinity, pinf[e]);
 		for (const auto *pl : {&p1[e], &pinf[e]})
 			for (const auto &t : *pl) {
-				if (t.vars.size() + (evs[e].d_eq_ind ? 1 : 0) > 3) fast = false; // (one slot is kept for the all-ones factor)
+				if (t.vars.size() + (evs[e].d_eq_ind ? 1 : 0) > (l2h ? 2u : 3u)) fast = false; // (one slot is kept for the all-ones factor)
 				if (fast) job_of(t.vars, evs[e].d_eq_ind);
 			}
 		if (jobs.size() > 15) fast = false;
@@ -245,11 +274,12 @@ int bn_hal_round_evals(bn_ctx *ctx, uint32_t order, uint32_t n_vars, const void 
 		for (size_t j = 0; j < jobs.size(); j++) {
 			if (jobs[j].vars.empty() && !jobs[j].eq) continue; // constant monomial: both sums are zero (the slots are)
 			const void *hi[4] = {nullptr, nullptr, nullptr, nullptr}, *lo[4] = {nullptr, nullptr, nullptr, nullptr};
-			uint32_t k = 0;
+			uint32_t k = 0, shift[4] = {0, 0, 0, 0};
 			for (uint32_t v : jobs[j].vars) {
 				const char *p = (const char *)a.ml[v].evals;
-				hi[k] = p + half * 16;
+				hi[k] = l2h ? p + 16 : p + half * 16;
 				lo[k] = p;
+				shift[k] = l2h ? 1 : 0;
 				k++;
 			}
 			if (jobs[j].eq) hi[k++] = jobs[j].eq; // (lo = NULL: the same factor at both evaluation points)
@@ -257,7 +287,10 @@ int bn_hal_round_evals(bn_ctx *ctx, uint32_t order, uint32_t n_vars, const void 
 			if (k == 2)
 				for (uint32_t f = 0; f < 2; f++)
 					if (!lo[f]) lo[f] = zeros;
-			BN_HIP(bn::launch_roundeval_product(ctx->stream, ctx->n_cu, hi, lo, k, half, d_acc + 32 + 2 * j, nullptr));
+			if (l2h)
+				BN_HIP(bn::launch_roundeval_mfma_pair_strided(ctx->stream, ctx->n_cu, hi[0], lo[0], shift[0], hi[1], lo[1], shift[1], half, d_acc + 32 + 2 * j));
+			else
+				BN_HIP(bn::launch_roundeval_product(ctx->stream, ctx->n_cu, hi, lo, k, half, d_acc + 32 + 2 * j, nullptr));
 		}
 		std::vector<f128> sums(2 * jobs.size());
 		BN_HIP(hipMemcpyAsync(sums.data(), d_acc + 32, sums.size() * sizeof(f128), hipMemcpyDeviceToHost, ctx->stream));
@@ -271,6 +304,53 @@ int bn_hal_round_evals(bn_ctx *ctx, uint32_t order, uint32_t n_vars, const void 
 				h_out[off + (p - evs[e].eval_point_start)] = bn_f128{v.lo, v.hi};
 			}
 			off += evs[e].eval_point_end - evs[e].eval_point_start;
+		}
+		BN_HIP(hipMemsetAsync(d_acc, 0, 64 * sizeof(f128), ctx->stream));
+		ctx->s_clean = true;
+		return BN_OK;
+	} else if (general_ok) {
+		// ---- everything else at throughput sizes: "rows + compiled circuits".  Every multilinear a composition reads is brought
+		// to its value at every evaluation point asked for -- e0 / e1 by a gather (nothing at all for a full multilinear in
+		// High-to-Low order), e0 + e1 for infinity, e0 + z (e0 + e1) through the nibble-table kernel for a domain point; pairs
+		// as the order says, the constant suffix filled in -- as a plain row of 2^(n_vars - 1) elements, ONCE, whatever the
+		// number of evaluators.  The composition (at infinity: its leading form) is then compiled into passes of the throughput
+		// kernels over those rows (abi_circuit.cpp): products on the bit-sliced element-wise kernel, the outermost sum of
+		// products on the matrix cores.  (The interpreter kernel below walked the cube once per point with a scalar tower
+		// product per Mul: 170 x slower per point, profiles/r03/hal.jsonl.)
+		char *rows_base = scr + tr_elems * sizeof(f128);
+		const size_t temps_off = (tr_elems + row_elems) * sizeof(f128);
+		std::vector<std::vector<const void *>> row(pt_hi, std::vector<const void *>(n_mls, nullptr));
+		size_t next_row = 0;
+		for (uint32_t p = pt_lo; p < pt_hi; p++) {
+			bool wanted = false;
+			for (uint32_t e = 0; e < n_evs; e++) wanted = wanted || (p >= evs[e].eval_point_start && p < evs[e].eval_point_end);
+			for (uint32_t k = 0; k < n_mls; k++) {
+				if (!((used_mls >> k) & 1)) continue;
+				char *dst = rows_base + next_row++ * half * sizeof(f128);
+				if (!wanted) continue;
+				if (!l2h && a.ml[k].len == full && p <= 1) {
+					row[p][k] = (const char *)a.ml[k].evals + (p ? half * 16 : 0); // the half itself
+					continue;
+				}
+				BN_HIP(bn::launch_hal_row(ctx->stream, ctx->n_cu, a.ml[k].evals, a.ml[k].len, a.ml[k].suffix, order, half, p, p >= 3 ? a.pts[p - 3] : f128{0, 0}, dst,
+				                          half));
+				row[p][k] = dst;
+			}
+		}
+		uint32_t idx = 0;
+		for (uint32_t e = 0; e < n_evs; e++)
+			for (uint32_t p = evs[e].eval_point_start; p < evs[e].eval_point_end; p++, idx++) {
+				const bn_expr *c = p == 2 ? evs[e].composition_at_infinity : evs[e].composition;
+				int rc = circuit_multipass_sum(ctx, c, row[p].data(), half, evs[e].d_eq_ind, d_acc + 2 * idx, temps_off);
+				if (rc == kCircuitDeclined) return bn::fail(BN_ERR_CORE_LIB, "internal: a planned circuit was declined");
+				if (rc) return rc;
+			}
+		std::vector<f128> sums(2 * total);
+		BN_HIP(hipMemcpyAsync(sums.data(), d_acc, sums.size() * sizeof(f128), hipMemcpyDeviceToHost, ctx->stream));
+		BN_HIP(hipStreamSynchronize(ctx->stream));
+		for (uint32_t i = 0; i < total; i++) {
+			const f128 v = sums[2 * i] ^ sums[2 * i + 1];
+			h_out[i] = bn_f128{v.lo, v.hi};
 		}
 		BN_HIP(hipMemsetAsync(d_acc, 0, 64 * sizeof(f128), ctx->stream));
 		ctx->s_clean = true;

@@ -285,12 +285,32 @@ int two_round_launch(bn_ctx *ctx, const two_round_req &rq, const bn::fin_fuse &f
 	for (uint32_t r = 0; r < n_ret; r++) h_out[r] = bn_f128{vals[ret_values[r]].lo, vals[ret_values[r]].hi};
 	ctx->fin_y.valid = false;
 	if (rq.fa.mirror) {
-		// ---- host tail: Y is in the pinned staging, in the power basis (written before the sequence number was)
+		// ---- host tail: Y is in the pinned staging, in the power basis.  The kernel wrote it with plain posted stores and
+		// nothing is assumed about their order against the sequence word: the tag in mailbox word 66 is the tag OF the data (a
+		// mix of every element and its index, XOR the sequence number), and the staging is accepted only when what is read
+		// matches it -- normally at the first look.
 		bn_ctx::host_tail_state &ht = ctx->ht;
 		const uint64_t *src = (const uint64_t *)ctx->h_tail;
+		for (int j = 0; j < 2; j++) ht.y[j].resize(2 * rq.m);
+		bool valid = false;
+		for (int tries = 0; tries < 4096 && !valid; tries++) {
+			if (tries == 2048) BN_HIP(hipStreamSynchronize(s)); // (a finished kernel's stores are visible: the last word on the matter)
+			const uint64_t want = __atomic_load_n(&ctx->h_mail[66].lo, __ATOMIC_ACQUIRE);
+			uint64_t t = f8.args.seq;
+			for (int j = 0; j < 2; j++)
+				for (uint64_t i = 0; i < rq.m; i++) {
+					const uint64_t lo = __atomic_load_n(&src[2 * (rq.m * j + i)], __ATOMIC_RELAXED), hi = __atomic_load_n(&src[2 * (rq.m * j + i) + 1], __ATOMIC_RELAXED);
+					ht.y[j][2 * i] = lo;
+					ht.y[j][2 * i + 1] = hi;
+					uint64_t h = (lo ^ ((rq.m * j + i + 1) * 0x9E3779B97F4A7C15ull)) * 0xBF58476D1CE4E5B9ull;
+					h ^= h >> 31;
+					h = (h ^ hi) * 0x94D049BB133111EBull;
+					t ^= h ^ (h >> 29);
+				}
+			valid = t == want;
+		}
+		if (!valid) return bn::fail(BN_ERR_DEVICE, "device error: the host tail's staging never became consistent");
 		for (int j = 0; j < 2; j++) {
-			ht.y[j].resize(2 * rq.m);
-			for (uint64_t w = 0; w < 2 * rq.m; w++) ht.y[j][w] = __atomic_load_n(&src[2 * rq.m * j + w], __ATOMIC_RELAXED);
 			ht.cur_lo[j] = rq.lo[j];
 			ht.cur_hi[j] = rq.hi[j];
 		}
@@ -1284,6 +1304,18 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 					slice_view v = view(op.rows[r]);
 					BN_REQUIRE(!v.q && !v.zero, "generic composition over an unmaterialised Local buffer");
 					rows[r] = v.p;
+				}
+				if (circuit_multipass_applies(ctx, op.expr, row_len)) {
+					// compiled into passes of the throughput kernels (abi_circuit.cpp): the sums arrive in both slots of the pair
+					BN_FLUSH(ctx);
+					rc = circuit_multipass_sum(ctx, op.expr, rows.data(), row_len, nullptr, d_S + slot, need_materialise ? local_bytes : 0);
+					if (rc != kCircuitDeclined) {
+						if (rc) return rc;
+						terms.push_back(bn::fin_term{op.value, slot, f128{op.scalar.lo, op.scalar.hi}});
+						terms.push_back(bn::fin_term{op.value, slot + 1, f128{op.scalar.lo, op.scalar.hi}});
+						n_slots += 2;
+						break;
+					}
 				}
 				const void **d_ptrs = nullptr;
 				rc = upload_ptrs(ctx, rows.data(), op.n_rows, &d_ptrs);

@@ -145,8 +145,14 @@ int bn_compute_composite(bn_ctx *ctx, const void *const *d_rows, uint32_t n_rows
 		                       row_len));
 		return BN_OK;
 	}
+	int rc;
+	if (circuit_multipass_applies(ctx, expr, row_len)) {
+		// any other circuit: compiled into passes of the throughput kernels (abi_circuit.cpp)
+		rc = circuit_multipass_map(ctx, expr, d_rows, row_len, d_out, 0);
+		if (rc != kCircuitDeclined) return rc;
+	}
 	const void **d_ptrs = nullptr;
-	int rc = upload_ptrs(ctx, d_rows, n_rows, &d_ptrs);
+	rc = upload_ptrs(ctx, d_rows, n_rows, &d_ptrs);
 	if (rc) return rc;
 	rc = ensure_d_steps(expr);
 	if (rc) return rc;

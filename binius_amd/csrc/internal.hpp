@@ -179,6 +179,7 @@ struct bn_ctx {
 	bool ht_enabled = false;                   // BN_HOST_TAIL=0 turns it off; needs PCLMULQDQ on the host
 	uint64_t ht_max = 256;                     // largest Y (elements per array) the host takes over (BN_HOST_TAIL_MAX_LOG2, <= 8)
 	uint64_t ht_started = 0, ht_rounds = 0, ht_flushed = 0; // instances taken over, evaluations answered, chains launched
+	bool circuit_multipass = true; // BN_CIRCUIT_MULTIPASS=0: generic circuits stay on the scalar interpreter kernels (abi_circuit.cpp)
 	void *ntt_cache = nullptr; // bn::ntt_bs_cache (allocated on first use)
 	// all-ones | all-zeros tables of the old HAL's routed round evaluation (abi_hal.cpp): filled once per size, kept
 	void *hal_const = nullptr;
@@ -262,6 +263,7 @@ hipError_t launch_extrapolate_line_batch(hipStream_t s, int n_cu, const fold_bat
 hipError_t launch_fold_publish(hipStream_t s, void *const *x0, const void *const *src0, const void *const *x1, uint32_t count, uint32_t n,
                                f128 z, f128 *d_mail, uint64_t seq, uint32_t scale_mask = 0, f128 hi_scale = f128{0, 0});
 hipError_t launch_scale(hipStream_t s, int n_cu, void *x, uint64_t n, f128 c); // x[i] *= c
+hipError_t launch_scale_to(hipStream_t s, int n_cu, void *out, const void *x, uint64_t n, f128 c); // out[i] = c * x[i]
 hipError_t launch_tensor_expand(hipStream_t s, int n_cu, void *data, uint32_t log_n, const f128 *coords, uint32_t k);
 
 // ---- kernels_roundeval.hip
@@ -374,6 +376,10 @@ hipError_t launch_roundeval9_split(hipStream_t s, int n_cu, const void *a, const
 bool mfma_applies(int n_cu, uint64_t n_points);
 hipError_t launch_roundeval_mfma_pair(hipStream_t s, int n_cu, const void *a_hi, const void *a_lo, const void *b_hi, const void *b_lo,
                                       uint64_t n, f128 *d_out, const fin_fuse *fuse);
+// the same sums with operands whose pairs are INTERLEAVED (Low-to-High evaluation order of the old HAL: e0 = x[2 i],
+// e1 = x[2 i + 1]): log2 of the element stride per operand (0: unit stride as above, 1: every other element)
+hipError_t launch_roundeval_mfma_pair_strided(hipStream_t s, int n_cu, const void *a_hi, const void *a_lo, uint32_t a_shift, const void *b_hi,
+                                              const void *b_lo, uint32_t b_shift, uint64_t n, f128 *d_out);
 // the same sums on the FP4 matrix path (kernels_roundeval_fp4.hip): round 0 of a sumcheck
 hipError_t launch_roundeval_fp4_pair(hipStream_t s, int n_cu, const void *a_hi, const void *a_lo, const void *b_hi, const void *b_lo,
                                      uint64_t n, f128 *d_out, const fin_fuse *fuse);
@@ -403,6 +409,10 @@ struct hal_round_args {
 hipError_t launch_hal_round_evals(hipStream_t s, int n_cu, const hal_round_args &a, f128 *d_out);
 hipError_t launch_hal_fold_lerp(hipStream_t s, int n_cu, const void *evals, uint64_t len, f128 suffix, uint32_t order, uint64_t half, f128 z,
                                 void *out, uint64_t n_out);
+// rows of the general round calculation (abi_hal.cpp): out[i] = the multilinear's value at evaluation point `point` of pair i
+// -- 0: e0, 1: e1, 2 (infinity): e0 + e1, otherwise e0 + z (e0 + e1) --, pairs taken as in launch_hal_fold_lerp
+hipError_t launch_hal_row(hipStream_t s, int n_cu, const void *evals, uint64_t len, f128 suffix, uint32_t order, uint64_t half, uint32_t point, f128 z,
+                          void *out, uint64_t n_out);
 
 // ---- kernels_misc.hip
 hipError_t launch_inner_product(hipStream_t s, int n_cu, const void *a, uint32_t tower_level, const void *b,

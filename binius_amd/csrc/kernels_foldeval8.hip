@@ -40,6 +40,15 @@ constexpr int kBlk = re9::kBlkQ;         // 9 uint4 per (limb, group) block of t
 constexpr int kZero8 = 8 * kG8;          // zero block index
 constexpr int kTile8 = (kZero8 + 1) * kBlk;
 
+// 64-bit mix of one mirrored element and its index (host tail; the host computes the same: abi_kernels.cpp mirror_mix)
+__device__ __forceinline__ uint64_t mirror_mix(uint64_t lo, uint64_t hi, uint64_t idx)
+{
+	uint64_t h = (lo ^ ((idx + 1) * 0x9E3779B97F4A7C15ull)) * 0xBF58476D1CE4E5B9ull;
+	h ^= h >> 31;
+	h = (h ^ hi) * 0x94D049BB133111EBull;
+	return h ^ (h >> 29);
+}
+
 struct lay8 {
 	unsigned off_a[4], off_b[4];
 	unsigned off_w;
@@ -156,7 +165,7 @@ __device__ __forceinline__ void tail8(const uint32_t (&acc)[32], const lay8 &lay
 		wsum[wave][2 * lane] = S.lo;
 		wsum[wave][2 * lane + 1] = S.hi;
 	}
-	asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (a host-tail launch: every wave's stores into the host mirror are out before the barrier)
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (a host-tail launch: every wave's stores into the host staging have left before the barrier)
 	__syncthreads();
 	BN_TS(7);
 	unsigned *const counter = fc.counter;
@@ -194,6 +203,7 @@ __global__ __launch_bounds__(512, 1) void k_foldeval8(foldeval8_args fa, f128 z1
 	__shared__ uint4 tile[4][kTile8];
 	__shared__ ctable_smem tab[NF == 2 ? 2 : 1];
 	__shared__ uint4 phi_T[512]; // host tail: the nibble table of the host's basis change (ctable.hpp layout of T)
+	__shared__ uint64_t mir_tag[8];
 	__shared__ fin_cache fcache;
 	BN_TS(0);
 	const uint64_t seq = fz.args.seq;
@@ -241,6 +251,7 @@ __global__ __launch_bounds__(512, 1) void k_foldeval8(foldeval8_args fa, f128 z1
 		ctable_build(tab[0], z1);
 	BN_TS(2);
 	uint4 y = v[0], u_hi{0, 0, 0, 0};
+	uint64_t tag = 0;
 	if constexpr (NF >= 1) y = xor4(v[0], ctable_mul(tab[0], xor4(v[0], v[1])));
 	if constexpr (NF == 2) {
 		u_hi = xor4(v[2], ctable_mul(tab[0], xor4(v[2], v[3]))); // X'[i + m]
@@ -251,12 +262,13 @@ __global__ __launch_bounds__(512, 1) void k_foldeval8(foldeval8_args fa, f128 z1
 		if constexpr (NF == 2) ((uint4 *)fa.out[arr])[i + m] = u_hi; // memory ends up exactly as after two separate in-place folds
 		stage[(arr * 4 + qt) * kRowsPad + lane] = y;
 		if (to_host) {
-			// Phi is GF(2)-linear: one more nibble-table product.  Stored with system-scope atomics into pinned host memory;
-			// every wave drains its stores in tail8, ahead of the barrier that precedes the sequence word.
+			// Phi is GF(2)-linear: one more nibble-table product.  PLAIN 16-byte stores into the pinned staging -- posted writes,
+			// a wave's 64 of them one coalesced burst (system-scope atomic stores of the 1024 words were measured at ~120 ns
+			// each, one PCIe round trip after the other: 125 us per hand-over) --, and nothing is assumed about the order in
+			// which they and the sequence word reach host memory: the staging validates itself (mirror_tag below).
 			const uint4 py = ctable_mul(*reinterpret_cast<const ctable_smem *>(phi_T), y);
-			f128 *slot = fa.mirror + (uint64_t)arr * m + i;
-			__hip_atomic_store(&slot->lo, (uint64_t)py.x | ((uint64_t)py.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-			__hip_atomic_store(&slot->hi, (uint64_t)py.z | ((uint64_t)py.w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			reinterpret_cast<uint4 *>(fa.mirror)[(uint64_t)arr * m + i] = py;
+			tag = mirror_mix((uint64_t)py.x | ((uint64_t)py.y << 32), (uint64_t)py.z | ((uint64_t)py.w << 32), (uint64_t)arr * m + i);
 		} else if (m == 4 && fz.mail) {
 			// the last launch of a sumcheck: Y is four elements per array -- the host folds them itself (six products) when the
 			// caller reads the final evaluations; published before the sequence number (drained below, a barrier follows)
@@ -266,8 +278,22 @@ __global__ __launch_bounds__(512, 1) void k_foldeval8(foldeval8_args fa, f128 z1
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		}
 	}
+	if (to_host) {
+		// the staging's tag: XOR over the elements of a 64-bit mix of (index, value), published in mailbox word 66 by the lane that
+		// publishes the sequence word later (same lane: the tag is out first); the host accepts the staging only when the tag it
+		// reads is the tag of the data it reads (abi_kernels.cpp)
+#pragma unroll
+		for (int sh = 32; sh >= 1; sh >>= 1) tag ^= __shfl_xor(tag, sh, 64);
+		if (lane == 0) mir_tag[wave] = tag;
+	}
 	fin_commit(fz, fpre, fcache);
 	__syncthreads();
+	if (to_host && tid == 0) {
+		uint64_t t = 0;
+#pragma unroll
+		for (int w = 0; w < 8; w++) t ^= mir_tag[w];
+		__hip_atomic_store(&fz.mail[66].lo, t ^ seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+	}
 	BN_TS(3);
 	uint32_t acc[32];
 #pragma unroll

@@ -125,6 +125,41 @@ __global__ __launch_bounds__(256) void k_hal_fold_lerp(const uint4 *evals, uint6
 	}
 }
 
+// One row of the general round calculation: the multilinear at evaluation point 0 / 1 / infinity (no multiplication: a
+// gather, or one XOR) -- what brings Low-to-High pairs and truncated multilinears into the layout the throughput kernels read.
+__global__ __launch_bounds__(256) void k_hal_row(const uint4 *evals, uint64_t len, f128 suffix, uint32_t order, uint64_t half, uint32_t point, uint4 *out,
+                                                  uint64_t n_out)
+{
+	const uint4 sfx = to_u4(suffix);
+	for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n_out; i += (uint64_t)gridDim.x * 256) {
+		const uint64_t i0 = order == BN_ORDER_LOW_TO_HIGH ? 2 * i : i;
+		const uint64_t i1 = order == BN_ORDER_LOW_TO_HIGH ? 2 * i + 1 : i + half;
+		uint4 r;
+		if (point == 0) {
+			r = i0 < len ? evals[i0] : sfx;
+		} else if (point == 1) {
+			r = i1 < len ? evals[i1] : sfx;
+		} else {
+			const uint4 x0 = i0 < len ? evals[i0] : sfx;
+			const uint4 x1 = i1 < len ? evals[i1] : sfx;
+			r = xor4(x0, x1);
+		}
+		out[i] = r;
+	}
+}
+
+hipError_t launch_hal_row(hipStream_t s, int n_cu, const void *evals, uint64_t len, f128 suffix, uint32_t order, uint64_t half, uint32_t point, f128 z,
+                          void *out, uint64_t n_out)
+{
+	if (n_out == 0) return hipSuccess;
+	if (point > 2) return launch_hal_fold_lerp(s, n_cu, evals, len, suffix, order, half, z, out, n_out);
+	uint64_t blocks = (n_out + 255) / 256;
+	const uint64_t cap = (uint64_t)n_cu * 8;
+	hipLaunchKernelGGL(k_hal_row, dim3((unsigned)(blocks < cap ? blocks : cap)), dim3(256), 0, s, (const uint4 *)evals, len, suffix, order, half, point,
+	                   (uint4 *)out, n_out);
+	return hipGetLastError();
+}
+
 hipError_t launch_hal_fold_lerp(hipStream_t s, int n_cu, const void *evals, uint64_t len, f128 suffix, uint32_t order, uint64_t half, f128 z,
                                 void *out, uint64_t n_out)
 {

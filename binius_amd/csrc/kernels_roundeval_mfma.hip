@@ -20,7 +20,8 @@ namespace bn {
 
 using namespace gram;
 
-template <bool SPLIT>
+// SA, SB: log2 of the element stride of the a / b operands (1: the pairs of the old HAL's Low-to-High order, interleaved)
+template <bool SPLIT, int SA = 0, int SB = 0>
 __global__ __launch_bounds__(256, 2) void k_roundeval_mfma(const uint4 *__restrict__ a_hi, const uint4 *__restrict__ a_lo,
                                                            const uint4 *__restrict__ b_hi, const uint4 *__restrict__ b_lo, uint64_t n,
                                                            f128 *out, fin_fuse fz, uint32_t xcd_tiles)
@@ -55,10 +56,10 @@ __global__ __launch_bounds__(256, 2) void k_roundeval_mfma(const uint4 *__restri
 		for (int i = 0; i < kTiles; i++) {
 			const uint64_t pt = ((gbase + g) * kTiles + i) * kTP + threadIdx.x;
 			const uint64_t e = pt < n ? pt : 0;
-			x[i][0] = a_hi[e];
-			x[i][1] = a_lo[e];
-			x[i][2] = b_hi[e];
-			x[i][3] = b_lo[e];
+			x[i][0] = a_hi[e << SA];
+			x[i][1] = a_lo[e << SA];
+			x[i][2] = b_hi[e << SB];
+			x[i][3] = b_lo[e << SB];
 		}
 	};
 	auto stage = [&](uint64_t g, uint32_t (*Tb)[kTileW]) {
@@ -158,6 +159,24 @@ hipError_t launch_roundeval_mfma_pair(hipStream_t s, int n_cu, const void *a_hi,
 		if (e != hipErrorNotSupported) return e;
 	}
 	return launch_mfma<false>(s, n_cu, a_hi, a_lo, b_hi, b_lo, n, d_out, fuse);
+}
+
+hipError_t launch_roundeval_mfma_pair_strided(hipStream_t s, int n_cu, const void *a_hi, const void *a_lo, uint32_t a_shift, const void *b_hi,
+                                              const void *b_lo, uint32_t b_shift, uint64_t n, f128 *d_out)
+{
+	if (n == 0) return hipSuccess;
+	if (a_shift > 1 || b_shift > 1) return hipErrorNotSupported;
+	const fin_fuse fz{};
+	const dim3 grid(grid_mfma(n, n_cu)), block(256);
+#define BN_LAUNCH_STRIDED(SA_, SB_)                                                                                                              \
+	hipLaunchKernelGGL((k_roundeval_mfma<false, SA_, SB_>), grid, block, 0, s, (const uint4 *)a_hi, (const uint4 *)a_lo, (const uint4 *)b_hi, \
+	                   (const uint4 *)b_lo, n, d_out, fz, 1u)
+	if (a_shift == 1 && b_shift == 1) BN_LAUNCH_STRIDED(1, 1);
+	else if (a_shift == 1) BN_LAUNCH_STRIDED(1, 0);
+	else if (b_shift == 1) BN_LAUNCH_STRIDED(0, 1);
+	else BN_LAUNCH_STRIDED(0, 0);
+#undef BN_LAUNCH_STRIDED
+	return hipGetLastError();
 }
 
 // d_out[0] ^= sum_{i<n} a[i]*b[i] ; d_out[1] ^= sum_{i<n} a[i+split]*b[i+split]

@@ -336,6 +336,22 @@ hipError_t launch_scale(hipStream_t s, int n_cu, void *x, uint64_t n, f128 c)
 	return hipGetLastError();
 }
 
+// out[i] = c * x[i] (a Mul(const, x) step of a compiled circuit, abi_circuit.cpp; out may be x)
+__global__ __launch_bounds__(256) void k_scale_to(uint4 *out, const uint4 *x, uint64_t n, f128 c)
+{
+	__shared__ ctable_smem tab;
+	ctable_build(tab, c);
+	for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256)
+		out[i] = ctable_mul(tab, x[i]);
+}
+
+hipError_t launch_scale_to(hipStream_t s, int n_cu, void *out, const void *x, uint64_t n, f128 c)
+{
+	if (n == 0) return hipSuccess;
+	hipLaunchKernelGGL(k_scale_to, dim3(grid_for(n, 256, n_cu, 8)), dim3(256), 0, s, (uint4 *)out, (const uint4 *)x, n, c);
+	return hipGetLastError();
+}
+
 // ---- tensor_expand, fused ---------------------------------------------------------------------
 // (1) head: while the expansion fits in LDS (<= 2^12 elements) ALL passes run inside one workgroup.
 struct expand_coords {
