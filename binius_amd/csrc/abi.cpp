@@ -496,6 +496,28 @@ int publish_result(bn_ctx *ctx, uint32_t n_groups, bn_f128 *h_out)
 	return BN_OK;
 }
 
+// h_out[i] = XOR_g d_vals[g * g_stride + i * i_stride], i < group_len <= 64, through the zero-copy mailbox: one tiny kernel and a
+// spin on the sequence word instead of a device-to-host copy plus a stream synchronisation (~20 us less per call)
+int publish_vals(bn_ctx *ctx, const f128 *d_vals, uint32_t n_groups, uint32_t group_len, uint32_t g_stride, uint32_t i_stride, f128 *h_out)
+{
+	const uint64_t seq = ++ctx->mail_seq;
+	BN_HIP(bn::launch_xor_publish(ctx->stream, d_vals, n_groups, group_len, ctx->d_result + 64, ctx->d_mail, seq, g_stride, i_stride));
+	volatile uint64_t *seqw = &ctx->h_mail[64].lo;
+	uint64_t spins = 0;
+	while (__atomic_load_n(seqw, __ATOMIC_ACQUIRE) != seq) {
+		if (++spins > (1ull << 22)) {
+			BN_HIP(hipStreamSynchronize(ctx->stream));
+			if (__atomic_load_n(seqw, __ATOMIC_ACQUIRE) != seq) return bn::fail(BN_ERR_DEVICE, "device error: result mailbox was not published");
+			break;
+		}
+	}
+	for (uint32_t r = 0; r < group_len; r++) {
+		h_out[r].lo = __atomic_load_n(&ctx->h_mail[r].lo, __ATOMIC_RELAXED);
+		h_out[r].hi = __atomic_load_n(&ctx->h_mail[r].hi, __ATOMIC_RELAXED);
+	}
+	return BN_OK;
+}
+
 int upload_ptrs(bn_ctx *ctx, const void *const *ptrs, uint32_t n, const void ***d_ptrs)
 {
 	// use slots [128, 256) of the mailbox: 128 * 16 B = 2 KiB = 256 pointers

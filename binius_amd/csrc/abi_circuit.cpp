@@ -388,7 +388,8 @@ int circuit_multipass_sum_temps(const bn_expr *e, bool has_eq)
 
 // d_slots[0] ^ d_slots[1] ^= sum_i expr(rows[.][i]) * (eq ? eq[i] : 1).  The slots are raw accumulators of the product-sum
 // kernels (both must be XORed by the reader).
-int circuit_multipass_sum(bn_ctx *ctx, const bn_expr *e, const void *const *rows, uint64_t row_len, const void *eq, f128 *d_slots, size_t scratch_off)
+int circuit_multipass_sum(bn_ctx *ctx, const bn_expr *e, const void *const *rows, uint64_t row_len, const void *eq, f128 *d_slots, size_t scratch_off,
+                          const void *ones_table)
 {
 	planner p{ctx, e, rows, row_len};
 	std::vector<sum_job> jobs;
@@ -398,9 +399,10 @@ int circuit_multipass_sum(bn_ctx *ctx, const bn_expr *e, const void *const *rows
 	char *base = (char *)bn::ctx_scratch(ctx, scratch_off + (size_t)n_t * row_len * sizeof(f128));
 	if (!base) return bn::fail(BN_ERR_ALLOC, "allocation error: allocator is out of memory (circuit temporaries)");
 	p.scr = base + scratch_off;
-	char *ones = need_ones ? p.scr + (size_t)p.n_temps * row_len * sizeof(f128) : nullptr;
+	// (ones_table: the caller keeps an all-ones table of row_len elements around -- no fill per call)
+	const char *ones = need_ones ? (ones_table ? (const char *)ones_table : p.scr + (size_t)p.n_temps * row_len * sizeof(f128)) : nullptr;
 	char *spare = p.scr + (size_t)(n_t - 1) * row_len * sizeof(f128);
-	if (ones) BN_HIP(bn::launch_fill(ctx->stream, ones, row_len, bn::f128_one()));
+	if (ones && !ones_table) BN_HIP(bn::launch_fill(ctx->stream, const_cast<char *>(ones), row_len, bn::f128_one()));
 	p.dry = false;
 	int rc = p.run_steps(false);
 	if (rc) return rc;

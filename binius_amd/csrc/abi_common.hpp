@@ -104,9 +104,11 @@ int circuit_multipass_map(bn_ctx *ctx, const bn_expr *e, const void *const *rows
 // temporaries of row_len elements circuit_multipass_sum will need (-1: declined)
 int circuit_multipass_sum_temps(const bn_expr *e, bool has_eq);
 // d_slots[0] ^ d_slots[1] ^= sum_i expr(rows[.][i]) * (eq ? eq[i] : 1)
-int circuit_multipass_sum(bn_ctx *ctx, const bn_expr *e, const void *const *rows, uint64_t row_len, const void *eq, bn::f128 *d_slots, size_t scratch_off);
+int circuit_multipass_sum(bn_ctx *ctx, const bn_expr *e, const void *const *rows, uint64_t row_len, const void *eq, bn::f128 *d_slots, size_t scratch_off,
+                          const void *ones_table = nullptr);
 // ---- small helpers shared by the op entry points (abi.cpp)
 int publish_result(bn_ctx *ctx, uint32_t n_groups, bn_f128 *h_out);
+int publish_vals(bn_ctx *ctx, const bn::f128 *d_vals, uint32_t n_groups, uint32_t group_len, uint32_t g_stride, uint32_t i_stride, bn::f128 *h_out);
 int upload_ptrs(bn_ctx *ctx, const void *const *ptrs, uint32_t n, const void ***d_ptrs);
 int ensure_d_steps(const bn_expr *e);
 } // namespace bnabi

@@ -249,7 +249,7 @@ int bn_hal_round_evals(bn_ctx *ctx, uint32_t order, uint32_t n_vars, const void 
 		for (const auto &j : jobs)
 			if (!(j.vars.empty() && !j.eq) && j.vars.size() + (j.eq ? 1 : 0) <= 2 && (j.eq || j.vars.size() < 2)) need_tables = true;
 		if (need_tables) {
-			if (ctx->hal_const_half != half) {
+			if (ctx->hal_const_half != half) { // (the same tables serve the general path below: ensure_const_tables)
 				if (ctx->hal_const) {
 					BN_HIP(hipStreamSynchronize(ctx->stream));
 					BN_HIP(hipFree(ctx->hal_const));
@@ -293,8 +293,10 @@ int bn_hal_round_evals(bn_ctx *ctx, uint32_t order, uint32_t n_vars, const void 
 				BN_HIP(bn::launch_roundeval_product(ctx->stream, ctx->n_cu, hi, lo, k, half, d_acc + 32 + 2 * j, nullptr));
 		}
 		std::vector<f128> sums(2 * jobs.size());
-		BN_HIP(hipMemcpyAsync(sums.data(), d_acc + 32, sums.size() * sizeof(f128), hipMemcpyDeviceToHost, ctx->stream));
-		BN_HIP(hipStreamSynchronize(ctx->stream));
+		{
+			int rc = publish_vals(ctx, d_acc + 32, 1, (uint32_t)sums.size(), 0, 0, sums.data()); // (through the mailbox: no copy, no synchronisation)
+			if (rc) return rc;
+		}
 		uint32_t off = 0;
 		for (uint32_t e = 0; e < n_evs; e++) {
 			for (uint32_t p = evs[e].eval_point_start; p < evs[e].eval_point_end; p++) {
@@ -317,6 +319,23 @@ int bn_hal_round_evals(bn_ctx *ctx, uint32_t order, uint32_t n_vars, const void 
 		// kernels over those rows (abi_circuit.cpp): products on the bit-sliced element-wise kernel, the outermost sum of
 		// products on the matrix cores.  (The interpreter kernel below walked the cube once per point with a scalar tower
 		// product per Mul: 170 x slower per point, profiles/r03/hal.jsonl.)
+		// the all-ones table of the sums of lone factors: filled once per size and kept in the context
+		if (ctx->hal_const_half != half) {
+			if (ctx->hal_const) {
+				BN_HIP(hipStreamSynchronize(ctx->stream));
+				BN_HIP(hipFree(ctx->hal_const));
+				ctx->hal_const = nullptr;
+				ctx->hal_const_half = 0;
+			}
+			if (hipMalloc(&ctx->hal_const, 2 * half * sizeof(f128)) == hipSuccess) {
+				BN_HIP(bn::launch_fill(ctx->stream, ctx->hal_const, half, bn::f128_one()));
+				BN_HIP(hipMemsetAsync((char *)ctx->hal_const + half * sizeof(f128), 0, half * sizeof(f128), ctx->stream));
+				ctx->hal_const_half = half;
+			} else {
+				(void)hipGetLastError();
+				ctx->hal_const = nullptr; // (the circuits fill their own)
+			}
+		}
 		char *rows_base = scr + tr_elems * sizeof(f128);
 		const size_t temps_off = (tr_elems + row_elems) * sizeof(f128);
 		std::vector<std::vector<const void *>> row(pt_hi, std::vector<const void *>(n_mls, nullptr));
@@ -341,17 +360,16 @@ int bn_hal_round_evals(bn_ctx *ctx, uint32_t order, uint32_t n_vars, const void 
 		for (uint32_t e = 0; e < n_evs; e++)
 			for (uint32_t p = evs[e].eval_point_start; p < evs[e].eval_point_end; p++, idx++) {
 				const bn_expr *c = p == 2 ? evs[e].composition_at_infinity : evs[e].composition;
-				int rc = circuit_multipass_sum(ctx, c, row[p].data(), half, evs[e].d_eq_ind, d_acc + 2 * idx, temps_off);
+				int rc = circuit_multipass_sum(ctx, c, row[p].data(), half, evs[e].d_eq_ind, d_acc + 2 * idx, temps_off, ctx->hal_const);
 				if (rc == kCircuitDeclined) return bn::fail(BN_ERR_CORE_LIB, "internal: a planned circuit was declined");
 				if (rc) return rc;
 			}
-		std::vector<f128> sums(2 * total);
-		BN_HIP(hipMemcpyAsync(sums.data(), d_acc, sums.size() * sizeof(f128), hipMemcpyDeviceToHost, ctx->stream));
-		BN_HIP(hipStreamSynchronize(ctx->stream));
-		for (uint32_t i = 0; i < total; i++) {
-			const f128 v = sums[2 * i] ^ sums[2 * i + 1];
-			h_out[i] = bn_f128{v.lo, v.hi};
+		std::vector<f128> vals(total);
+		{
+			int rc = publish_vals(ctx, d_acc, 2, total, 1, 2, vals.data()); // value i = slot 2 i + slot 2 i + 1, through the mailbox
+			if (rc) return rc;
 		}
+		for (uint32_t i = 0; i < total; i++) h_out[i] = bn_f128{vals[i].lo, vals[i].hi};
 		BN_HIP(hipMemsetAsync(d_acc, 0, 64 * sizeof(f128), ctx->stream));
 		ctx->s_clean = true;
 		return BN_OK;

@@ -192,6 +192,64 @@ __device__ __forceinline__ uint4 ctable_mul_pinned(const ctable_smem &s, uint4 x
 	return acc;
 }
 
+// Variant of ctable_mul_pinned for measurements (tools/gram_bench.hip, FE_VARIANT): returns init ^ x * z -- the fold's
+// "x0 +" rides in the first three-input XOR instead of costing four more --, and with LAZY the table offsets of a group are
+// formed right before its reads are issued (4 live offset registers instead of 32).
+template <int G, bool LAZY>
+__device__ __forceinline__ uint4 ctable_mul_acc(const ctable_smem &s, uint4 x, uint4 init)
+{
+	static_assert(G == 4 || G == 8, "half a word or one word of lookups per group");
+	const char *base = reinterpret_cast<const char *>(s.T);
+	const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+	const uint32_t m = 0xF0u;
+	uint32_t off[32];
+	uint32_t rot[4];
+	auto offset = [&](int j) -> uint32_t { // j = 8 * word + r: r even -> low nibble of byte r / 2 (from the rotated word), odd -> its high nibble
+		const int wq = j >> 3, r = j & 7;
+		const uint32_t src = (r & 1) ? w[wq] : rot[wq];
+		switch (r >> 1) {
+		case 0: return byte_and<0>(src, m);
+		case 1: return byte_and<1>(src, m);
+		case 2: return byte_and<2>(src, m);
+		default: return byte_and<3>(src, m);
+		}
+	};
+#pragma unroll
+	for (int wq = 0; wq < 4; wq++)
+		rot[wq] = __builtin_amdgcn_alignbit(w[wq], w[wq], 28); // rotl(w, 4)
+	if constexpr (!LAZY) {
+#pragma unroll
+		for (int j = 0; j < 32; j++)
+			off[j] = offset(j);
+	}
+	uint4 acc = init;
+	uint4 cur[G], nxt[G];
+#pragma unroll
+	for (int j = 0; j < G; j++)
+		cur[j] = *reinterpret_cast<const uint4 *>(base + j * 256 + (LAZY ? offset(j) : off[j]));
+#pragma unroll
+	for (int g0 = 0; g0 < 32; g0 += G) {
+		if (g0 + G < 32) {
+#pragma unroll
+			for (int j = 0; j < G; j++)
+				nxt[j] = *reinterpret_cast<const uint4 *>(base + (g0 + G + j) * 256 + (LAZY ? offset(g0 + G + j) : off[g0 + G + j]));
+		}
+		asm volatile("" ::: "memory");
+#pragma unroll
+		for (int j = 0; j < G; j += 2) {
+			acc.x = ct_xor3(acc.x, cur[j].x, cur[j + 1].x);
+			acc.y = ct_xor3(acc.y, cur[j].y, cur[j + 1].y);
+			acc.z = ct_xor3(acc.z, cur[j].z, cur[j + 1].z);
+			acc.w = ct_xor3(acc.w, cur[j].w, cur[j + 1].w);
+		}
+		asm volatile("" : "+v"(acc.x), "+v"(acc.y), "+v"(acc.z), "+v"(acc.w)::"memory");
+#pragma unroll
+		for (int j = 0; j < G; j++)
+			cur[j] = nxt[j];
+	}
+	return acc;
+}
+
 // A second nibble table that exists only in the kernel variants that need one (no LDS in the others)
 template <bool ON>
 struct ctable_opt {

@@ -291,7 +291,7 @@ struct fin_args {
 struct fin_peer; // below: cross-rank reduction of the returned values (nullptr / world <= 1: none)
 hipError_t launch_finalize(hipStream_t s, const fin_args &args, f128 *d_S, f128 *d_rets, f128 *d_mail, const fin_peer *peer = nullptr);
 hipError_t launch_xor_publish(hipStream_t s, const f128 *d_vals, uint32_t n_groups, uint32_t group_len, f128 *d_rets, f128 *d_mail,
-                              uint64_t seq);
+                              uint64_t seq, uint32_t g_stride = 0, uint32_t i_stride = 0); // (strides 0: g_stride = group_len, i_stride = 1)
 // Cross-rank reduction of the returned values inside the finalize step (sharded sumcheck, SURVEY.md section 8e;
 // bn_peer_*): every rank owns a mailbox in fine-grained device memory that all ranks of the node have mapped
 // (hipIpc; over xGMI between devices).  The finalizing workgroup stores this rank's returned values into its slot of

@@ -109,26 +109,34 @@ __global__ __launch_bounds__(256, 2) void k_foldeval_mfma(foldeval_args fa, uint
 		gram_pipe gp;
 		uint4 f[4];
 		if (GRAM) gram_begin(Tp, gr, gp);
-		f[0] = xor4(x0[0], ctable_mul_pinned<4>(tab, xor4(x0[0], x1[0])));
+#ifndef FE_VARIANT
+#define FE_VARIANT 0
+#endif
+#if FE_VARIANT == 0
+#define FE_FOLD(k) xor4(x0[k], ctable_mul_pinned<4>(tab, xor4(x0[k], x1[k])))
+#else
+#define FE_FOLD(k) ctable_mul_acc<(FE_VARIANT & 4) ? 8 : 4, (FE_VARIANT & 2) != 0>(tab, xor4(x0[k], x1[k]), x0[k])
+#endif
+		f[0] = FE_FOLD(0);
 		load1(tn, 0); // this quadrant of the next tile flies from here on
 		if (GRAM) {
 			gram_step<0>(Tp, gr, gp, acc);
 			gram_step<1>(Tp, gr, gp, acc);
 		}
-		f[1] = xor4(x0[1], ctable_mul_pinned<4>(tab, xor4(x0[1], x1[1])));
+		f[1] = FE_FOLD(1);
 		load1(tn, 1); // this quadrant of the next tile flies from here on
 		if constexpr (SC == 1) f[1] = ctable_mul_pinned<4>(tab_hs.get(), f[1]);
 		if (GRAM) {
 			gram_step<2>(Tp, gr, gp, acc);
 			gram_step<3>(Tp, gr, gp, acc);
 		}
-		f[2] = xor4(x0[2], ctable_mul_pinned<4>(tab, xor4(x0[2], x1[2])));
+		f[2] = FE_FOLD(2);
 		load1(tn, 2); // this quadrant of the next tile flies from here on
 		if (GRAM) {
 			gram_step<4>(Tp, gr, gp, acc);
 			gram_step<5>(Tp, gr, gp, acc);
 		}
-		f[3] = xor4(x0[3], ctable_mul_pinned<4>(tab, xor4(x0[3], x1[3])));
+		f[3] = FE_FOLD(3);
 		load1(tn, 3); // this quadrant of the next tile flies from here on
 		if constexpr (SC == 2) f[3] = ctable_mul_pinned<4>(tab_hs.get(), f[3]);
 		if (GRAM) {

@@ -345,16 +345,17 @@ hipError_t launch_finalize(hipStream_t s, const fin_args &args, f128 *d_S, f128 
 	return hipGetLastError();
 }
 
-// out[i] = XOR_g vals[g * group_len + i], straight into the host mailbox (the combine step of the
-// sharded prover after the per-round all_gather; RCCL has no XOR reduction)
-__global__ __launch_bounds__(64) void k_xor_publish(const f128 *vals, uint32_t n_groups, uint32_t group_len, f128 *rets, f128 *mail,
-                                                    uint64_t seq)
+// out[i] = XOR_g vals[g * g_stride + i * i_stride], straight into the host mailbox (the combine step of the
+// sharded prover after the per-round all_gather -- RCCL has no XOR reduction --, g_stride = group_len, i_stride = 1; the raw
+// slot pairs of the old HAL's round evaluations, g_stride = 1, i_stride = 2)
+__global__ __launch_bounds__(64) void k_xor_publish(const f128 *vals, uint32_t n_groups, uint32_t group_len, uint32_t g_stride, uint32_t i_stride, f128 *rets,
+                                                    f128 *mail, uint64_t seq)
 {
 	const unsigned i = threadIdx.x;
 	if (i < group_len) {
 		f128 v = f128_zero();
 		for (uint32_t g = 0; g < n_groups; g++)
-			v ^= vals[(size_t)g * group_len + i];
+			v ^= vals[(size_t)g * g_stride + (size_t)i * i_stride];
 		rets[i] = v;
 		__hip_atomic_store(&mail[i].lo, v.lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 		__hip_atomic_store(&mail[i].hi, v.hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -366,9 +367,10 @@ __global__ __launch_bounds__(64) void k_xor_publish(const f128 *vals, uint32_t n
 }
 
 hipError_t launch_xor_publish(hipStream_t s, const f128 *d_vals, uint32_t n_groups, uint32_t group_len, f128 *d_rets, f128 *d_mail,
-                              uint64_t seq)
+                              uint64_t seq, uint32_t g_stride, uint32_t i_stride)
 {
-	hipLaunchKernelGGL(k_xor_publish, dim3(1), dim3(64), 0, s, d_vals, n_groups, group_len, d_rets, d_mail, seq);
+	hipLaunchKernelGGL(k_xor_publish, dim3(1), dim3(64), 0, s, d_vals, n_groups, group_len, g_stride ? g_stride : group_len, i_stride ? i_stride : 1u, d_rets,
+	                   d_mail, seq);
 	return hipGetLastError();
 }
 
