@@ -171,6 +171,8 @@ def lib():
         "bn_peer_connect": [vp, C.c_char_p],
         "bn_peer_set_active": [vp, C.c_int],
         "bn_peer_stats": [vp, C.POINTER(u64)],
+        "bn_host_tail_allow_peer": [vp, C.c_int],
+        "bn_host_tail_active": [vp, C.POINTER(C.c_int)],
         "bn_peer_destroy": [vp],
     }
     for name, args in sig.items():
@@ -192,7 +194,7 @@ ABI_SYMBOLS = [
     "bn_timer_begin", "bn_timer_end_ms", "bn_prof_begin", "bn_prof_end", "bn_arm_counters", "bn_xor_reduce", "bn_host_scratch", "bn_device_numa_node",
     "bn_merkle_build", "bn_groestl256_leaves", "bn_groestl256_compress_layer", "bn_gather_d2h",
     "bn_hal_round_evals", "bn_hal_fold_multilinear", "bn_extrapolate_line_batch_scaled",
-    "bn_peer_create", "bn_peer_connect", "bn_peer_set_active", "bn_peer_stats", "bn_peer_destroy",
+    "bn_peer_create", "bn_peer_connect", "bn_peer_set_active", "bn_peer_stats", "bn_peer_destroy", "bn_host_tail_allow_peer", "bn_host_tail_active",
 ]
 
 

@@ -693,10 +693,32 @@ int bn_peer_connect(bn_ctx *ctx, const uint8_t *handles)
 	return BN_OK;
 }
 
+int bn_host_tail_allow_peer(bn_ctx *ctx, int on)
+{
+	BN_REQUIRE(ctx, "null argument");
+	BN_ENTER(ctx);
+	ctx->ht_peer_ok = on != 0;
+	return BN_OK;
+}
+
+int bn_host_tail_active(bn_ctx *ctx, int *active)
+{
+	BN_REQUIRE(ctx && active, "null argument");
+	BN_ENTER(ctx);
+	*active = ctx->ht.active ? 1 : 0;
+	return BN_OK;
+}
+
 int bn_peer_set_active(bn_ctx *ctx, int on)
 {
 	BN_REQUIRE(ctx, "null argument");
 	BN_ENTER(ctx);
+	if (ctx->ht.active && !on) {
+		// a host tail is running: nothing is deferred on the device and nothing armed -- the caller takes over the exchange of
+		// the host rounds' partial sums (bn_host_tail_allow_peer); no flush, the tail goes on
+		ctx->peer.active = false;
+		return BN_OK;
+	}
 	BN_FLUSH(ctx);
 	BN_REQUIRE(!on || ctx->peer.connected, "peer exchange: not connected");
 	if (ctx->peer.active != (on != 0)) arm_cancel(ctx); // (a kernel armed under the other setting would publish the wrong thing)

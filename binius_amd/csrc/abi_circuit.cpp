@@ -363,12 +363,7 @@ bool sum_plan(planner &p, bool has_eq, std::vector<sum_job> &jobs, bool &need_on
 	}
 	p.dry = true;
 	if (p.run_steps(false) != BN_OK) return false;
-	// a job with fewer than two non-constant factors is summed against the all-ones table
-	need_ones = false;
-	for (const auto &j : jobs) {
-		int nf = (p.val[j.x].kind != node::CONST) + (j.y >= 0 ? (p.val[j.y].kind != node::CONST) : (has_eq ? 1 : 0));
-		if (nf == 1) need_ones = true;
-	}
+	need_ones = false; // (a lone factor is summed by the streaming XOR kernel: no all-ones table)
 	n_temps = p.n_temps + (need_ones ? 1 : 0) + 1; // + one spare for a summand with a constant coefficient
 	return true;
 }
@@ -435,7 +430,10 @@ int circuit_multipass_sum(bn_ctx *ctx, const bn_expr *e, const void *const *rows
 			BN_HIP(bn::launch_scale_to(ctx->stream, ctx->n_cu, spare, f[0], row_len, c));
 			f[0] = spare;
 		}
-		if (nf == 1) f[1] = ones;
+		if (nf == 1) {
+			BN_HIP(bn::launch_xor_sum(ctx->stream, ctx->n_cu, f[0], row_len, d_slots));
+			continue;
+		}
 		BN_HIP(bn::launch_sum_product(ctx->stream, ctx->n_cu, f, 2, row_len, d_slots));
 	}
 	return BN_OK;

@@ -249,7 +249,7 @@ int bn_hal_round_evals(bn_ctx *ctx, uint32_t order, uint32_t n_vars, const void 
 		for (const auto &j : jobs)
 			if (!(j.vars.empty() && !j.eq) && j.vars.size() + (j.eq ? 1 : 0) <= 2 && (j.eq || j.vars.size() < 2)) need_tables = true;
 		if (need_tables) {
-			if (ctx->hal_const_half != half) { // (the same tables serve the general path below: ensure_const_tables)
+			if (ctx->hal_const_half != half) {
 				if (ctx->hal_const) {
 					BN_HIP(hipStreamSynchronize(ctx->stream));
 					BN_HIP(hipFree(ctx->hal_const));
@@ -319,23 +319,6 @@ int bn_hal_round_evals(bn_ctx *ctx, uint32_t order, uint32_t n_vars, const void 
 		// kernels over those rows (abi_circuit.cpp): products on the bit-sliced element-wise kernel, the outermost sum of
 		// products on the matrix cores.  (The interpreter kernel below walked the cube once per point with a scalar tower
 		// product per Mul: 170 x slower per point, profiles/r03/hal.jsonl.)
-		// the all-ones table of the sums of lone factors: filled once per size and kept in the context
-		if (ctx->hal_const_half != half) {
-			if (ctx->hal_const) {
-				BN_HIP(hipStreamSynchronize(ctx->stream));
-				BN_HIP(hipFree(ctx->hal_const));
-				ctx->hal_const = nullptr;
-				ctx->hal_const_half = 0;
-			}
-			if (hipMalloc(&ctx->hal_const, 2 * half * sizeof(f128)) == hipSuccess) {
-				BN_HIP(bn::launch_fill(ctx->stream, ctx->hal_const, half, bn::f128_one()));
-				BN_HIP(hipMemsetAsync((char *)ctx->hal_const + half * sizeof(f128), 0, half * sizeof(f128), ctx->stream));
-				ctx->hal_const_half = half;
-			} else {
-				(void)hipGetLastError();
-				ctx->hal_const = nullptr; // (the circuits fill their own)
-			}
-		}
 		char *rows_base = scr + tr_elems * sizeof(f128);
 		const size_t temps_off = (tr_elems + row_elems) * sizeof(f128);
 		std::vector<std::vector<const void *>> row(pt_hi, std::vector<const void *>(n_mls, nullptr));
@@ -360,7 +343,7 @@ int bn_hal_round_evals(bn_ctx *ctx, uint32_t order, uint32_t n_vars, const void 
 		for (uint32_t e = 0; e < n_evs; e++)
 			for (uint32_t p = evs[e].eval_point_start; p < evs[e].eval_point_end; p++, idx++) {
 				const bn_expr *c = p == 2 ? evs[e].composition_at_infinity : evs[e].composition;
-				int rc = circuit_multipass_sum(ctx, c, row[p].data(), half, evs[e].d_eq_ind, d_acc + 2 * idx, temps_off, ctx->hal_const);
+				int rc = circuit_multipass_sum(ctx, c, row[p].data(), half, evs[e].d_eq_ind, d_acc + 2 * idx, temps_off);
 				if (rc == kCircuitDeclined) return bn::fail(BN_ERR_CORE_LIB, "internal: a planned circuit was declined");
 				if (rc) return rc;
 			}

@@ -84,7 +84,19 @@ hipError_t roundeval_product_routed(bn_ctx *ctx, bool scratch_free, const void *
 }
 
 constexpr uint64_t kArmMaxIn = 1ull << 19;     // largest round (elements per array before the fold) that is armed ...
-constexpr uint64_t kArmMaxInMfma = 1ull << 21; // ... when it runs on the matrix-core kernel (60 us at 2^21: a launch is 10 % of that)
+// ... when it runs on the matrix-core kernel.  Round 3 stopped at 2^21 (a launch is a tenth of a 60 us kernel); a launch is still
+// ~7 us of dead time against a ~3 us signal however long the kernel is, and a shard of an eight-way split has five such rounds
+// (r = 22 ... 25 + the first fused one), so every fused round is armed now (BN_ARM_MAX_LOG2 brings a limit back).  The host's
+// waits cancel the armed kernel before they ever fall back to a stream synchronisation, so a long kernel in front is harmless.
+uint64_t arm_max_in_mfma()
+{
+	static const uint64_t v = [] {
+		const char *e = getenv("BN_ARM_MAX_LOG2");
+		const int l = e ? atoi(e) : 40;
+		return (uint64_t)1 << (l < 4 ? 4 : (l > 40 ? 40 : l));
+	}();
+	return v;
+}
 // ---- two rounds per launch (kernels_foldeval8.hip) ------------------------------------------------------------------
 // largest Y (elements per array after the folds of the launch): one 64-point workgroup per CU, 256 CUs
 // (BN_TWO_ROUND_MAX_LOG2, 2 .. 20, moves the limit: measurement knob)
@@ -132,7 +144,8 @@ bn::fin_fuse two_round_recipe(const bn::fin_fuse &fz)
 // and the device path takes over again.  Not under a peer exchange (the ranks' partial sums meet on the devices there).
 bool host_tail_applies(const bn_ctx *ctx, uint64_t m, uint32_t peer_world)
 {
-	return ctx->ht_enabled && ctx->lazy_fold && peer_world <= 1 && m >= 4 && m <= ctx->ht_max;
+	// (under a peer exchange only for a caller that exchanges the host rounds' partial sums itself: bn_host_tail_allow_peer)
+	return ctx->ht_enabled && ctx->lazy_fold && (peer_world <= 1 || ctx->ht_peer_ok) && m >= 4 && m <= ctx->ht_max;
 }
 
 struct two_round_req {
@@ -1025,7 +1038,7 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 												return;
 											}
 											if (!ctx->arm_enabled || ctx->prof_on || !h_out || d_out || n_next < 4 || (n_next & 3) ||
-											    n_next > (mfma_next ? kArmMaxInMfma : kArmMaxIn) || (mfma_next && fa_.scale_mask == 3) || ctx->tail_max_n_in)
+											    n_next > (mfma_next ? arm_max_in_mfma() : kArmMaxIn) || (mfma_next && fa_.scale_mask == 3) || ctx->tail_max_n_in)
 												return;
 											bn_ctx::arm_state &am = ctx->arm;
 											bn::foldeval_args fn{};

@@ -177,6 +177,7 @@ struct bn_ctx {
 	void *h_tail = nullptr, *d_tail = nullptr; // pinned staging the kernel mirrors Y into (host / device view), 2 x 256 elements
 	void *d_phi = nullptr;                     // nibble table of the basis change (8 KiB of device memory)
 	bool ht_enabled = false;                   // BN_HOST_TAIL=0 turns it off; needs PCLMULQDQ on the host
+	bool ht_peer_ok = false;                   // bn_host_tail_allow_peer: the caller exchanges the host rounds' partials itself
 	uint64_t ht_max = 256;                     // largest Y (elements per array) the host takes over (BN_HOST_TAIL_MAX_LOG2, <= 8)
 	uint64_t ht_started = 0, ht_rounds = 0, ht_flushed = 0; // instances taken over, evaluations answered, chains launched
 	bool circuit_multipass = true; // BN_CIRCUIT_MULTIPASS=0: generic circuits stay on the scalar interpreter kernels (abi_circuit.cpp)
@@ -263,6 +264,7 @@ hipError_t launch_extrapolate_line_batch(hipStream_t s, int n_cu, const fold_bat
 hipError_t launch_fold_publish(hipStream_t s, void *const *x0, const void *const *src0, const void *const *x1, uint32_t count, uint32_t n,
                                f128 z, f128 *d_mail, uint64_t seq, uint32_t scale_mask = 0, f128 hi_scale = f128{0, 0});
 hipError_t launch_scale(hipStream_t s, int n_cu, void *x, uint64_t n, f128 c); // x[i] *= c
+hipError_t launch_xor_sum(hipStream_t s, int n_cu, const void *x, uint64_t n, f128 *d_out); // d_out[0] ^= XOR_i x[i]
 hipError_t launch_scale_to(hipStream_t s, int n_cu, void *out, const void *x, uint64_t n, f128 c); // out[i] = c * x[i]
 hipError_t launch_tensor_expand(hipStream_t s, int n_cu, void *data, uint32_t log_n, const f128 *coords, uint32_t k);
 

@@ -109,8 +109,13 @@ __global__ __launch_bounds__(256, 2) void k_foldeval_mfma(foldeval_args fa, uint
 		gram_pipe gp;
 		uint4 f[4];
 		if (GRAM) gram_begin(Tp, gr, gp);
+		// FE_VARIANT (measurement knob, tools/r04_fe_variants.sh): 0 = round 3's form (x0 ^ ctable_mul_pinned<4>); bit 0 = the
+		// "x0 +" of the fold rides in the product's first three-input XOR, bit 1 = table offsets formed per group of lookups
+		// (4 live offset registers instead of 32), bit 2 = groups of 8 lookups in flight.  7: 813 instead of 841 VALU per tile
+		// and wave, 252 registers, no scratch; 0.7523 -> 0.7415 ms at 2^26, 1.4832 -> 1.4653 ms at 2^27 elements per array
+		// (sustained launches, two alternating runs, profiles/r04/fe_variants.txt).
 #ifndef FE_VARIANT
-#define FE_VARIANT 0
+#define FE_VARIANT 7
 #endif
 #if FE_VARIANT == 0
 #define FE_FOLD(k) xor4(x0[k], ctable_mul_pinned<4>(tab, xor4(x0[k], x1[k])))

@@ -336,6 +336,38 @@ hipError_t launch_scale(hipStream_t s, int n_cu, void *x, uint64_t n, f128 c)
 	return hipGetLastError();
 }
 
+// d_out[0] ^= XOR_i x[i]: the sum of a lone row (a degree-1 term of a compiled circuit's sum, abi_circuit.cpp) at streaming
+// speed -- the product-sum kernels would multiply it by an all-ones table
+__global__ __launch_bounds__(256) void k_xor_sum(const uint4 *__restrict__ x, uint64_t n, f128 *out)
+{
+	__shared__ uint4 red[4];
+	uint4 acc{0, 0, 0, 0};
+	for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256)
+		acc = xor4(acc, x[i]);
+#pragma unroll
+	for (int m = 32; m >= 1; m >>= 1) {
+		acc.x ^= __shfl_xor(acc.x, m, 64);
+		acc.y ^= __shfl_xor(acc.y, m, 64);
+		acc.z ^= __shfl_xor(acc.z, m, 64);
+		acc.w ^= __shfl_xor(acc.w, m, 64);
+	}
+	if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+	__syncthreads();
+	if (threadIdx.x < 2) {
+		const uint4 a = red[0], b = red[1], c = red[2], d = red[3];
+		const uint64_t v = threadIdx.x == 0 ? ((uint64_t)(a.x ^ b.x ^ c.x ^ d.x) | ((uint64_t)(a.y ^ b.y ^ c.y ^ d.y) << 32))
+		                                    : ((uint64_t)(a.z ^ b.z ^ c.z ^ d.z) | ((uint64_t)(a.w ^ b.w ^ c.w ^ d.w) << 32));
+		if (v) atomicXor(reinterpret_cast<unsigned long long *>(out) + threadIdx.x, (unsigned long long)v);
+	}
+}
+
+hipError_t launch_xor_sum(hipStream_t s, int n_cu, const void *x, uint64_t n, f128 *d_out)
+{
+	if (n == 0) return hipSuccess;
+	hipLaunchKernelGGL(k_xor_sum, dim3(grid_for(n, 256 * 8, n_cu, 4)), dim3(256), 0, s, (const uint4 *)x, n, d_out);
+	return hipGetLastError();
+}
+
 // out[i] = c * x[i] (a Mul(const, x) step of a compiled circuit, abi_circuit.cpp; out may be x)
 __global__ __launch_bounds__(256) void k_scale_to(uint4 *out, const uint4 *x, uint64_t n, f128 c)
 {

@@ -217,6 +217,7 @@ int bnh_bivariate_sumcheck_prove(bn_ctx *ctx, uint32_t n_vars, uint32_t m, const
 		~peer_scope()
 		{
 			if (on) (void)bn_peer_set_active(c, 0);
+			(void)bn_host_tail_allow_peer(c, 0);
 		}
 	} peer_guard{ctx};
 	try {
@@ -263,6 +264,9 @@ int bnh_bivariate_sumcheck_prove(bn_ctx *ctx, uint32_t n_vars, uint32_t m, const
 		const std::vector<B128> coeffs = powers(bc, n_comps);
 		// `n_rounds` rounds on the arrays in `cur` (2^n_rounds elements each); exchange: combine the
 		// ranks' partial round evaluations (local rounds) or not (residual rounds, identical everywhere)
+		// peer exchange + host tail: from the launch after which the library holds the arrays on the host (bn_host_tail_active)
+		// the rounds' LOCAL partial sums come back from host arithmetic and meet in the shared-memory segment instead
+		bool host_rounds = false;
 		auto do_rounds = [&](uint32_t n_rounds, bool exchange, const bn_f128 *ch, bn_f128 *coeffs_out) {
 		for (uint32_t r = 0; r < n_rounds; r++) {
 			const size_t rem = n_rounds - r, split = rem - 1;
@@ -282,11 +286,20 @@ int bnh_bivariate_sumcheck_prove(bn_ctx *ctx, uint32_t n_vars, uint32_t m, const
 				const std::vector<B128> part = calculate_round_evals(hal, rem, bc, cmls, evaluators);
 				const uint64_t mine[4] = {part[0].raw().lo, part[0].raw().hi, part[1].raw().lo, part[1].raw().hi};
 				std::vector<uint64_t> all((size_t)4 * world);
-				const int n_src = (exchange && !peer) ? world : 1;
-				if (exchange && !peer) {
+				const bool via_shm = exchange && (!peer || host_rounds);
+				const int n_src = via_shm ? world : 1;
+				if (via_shm) {
 					if (bnh_shm_allgather(shm, mine, 4, all.data())) throw Error(Error::DeviceError, g_err);
 				} else {
 					for (int i = 0; i < 4; i++) all[i] = mine[i];
+				}
+				if (exchange && peer && !host_rounds) {
+					int active = 0;
+					check(bn_host_tail_active(ctx, &active));
+					if (active) { // (every rank sees this after the same launch: the shards have the same size)
+						host_rounds = true;
+						peer_guard.set(false);
+					}
 				}
 				ev[0] = bn_f128{0, 0};
 				ev[1] = bn_f128{0, 0};
@@ -363,6 +376,7 @@ int bnh_bivariate_sumcheck_prove(bn_ctx *ctx, uint32_t n_vars, uint32_t m, const
 		};
 		if (peer) {
 			if (!shm) throw Error(Error::InputValidation, "the peer exchange needs the shared-memory segment for the residual instance");
+			check(bn_host_tail_allow_peer(ctx, 1)); // (the host rounds' partials are exchanged here, through the segment)
 			peer_guard.set(true);
 		}
 		do_rounds(n_vars, true, challenges, round_coeffs_out);

@@ -312,5 +312,7 @@ unsafe extern "C" {
 	pub fn bn_peer_connect(ctx: *mut bn_ctx, handles: *const u8) -> c_int;
 	pub fn bn_peer_set_active(ctx: *mut bn_ctx, on: c_int) -> c_int;
 	pub fn bn_peer_stats(ctx: *mut bn_ctx, stats: *mut u64) -> c_int;
+	pub fn bn_host_tail_allow_peer(ctx: *mut bn_ctx, on: c_int) -> c_int;
+	pub fn bn_host_tail_active(ctx: *mut bn_ctx, active: *mut c_int) -> c_int;
 	pub fn bn_peer_destroy(ctx: *mut bn_ctx) -> c_int;
 }

@@ -277,6 +277,15 @@ int bn_peer_create(bn_ctx *ctx, uint32_t world, uint32_t rank, uint8_t *handle_o
 int bn_peer_connect(bn_ctx *ctx, const uint8_t *handles /*[world][BN_PEER_HANDLE_BYTES]*/);
 int bn_peer_set_active(bn_ctx *ctx, int on);
 int bn_peer_stats(bn_ctx *ctx, uint64_t *stats /*[2]*/);
+/* The host tail under a peer exchange (sharded sumcheck): once the arrays of a shard are down to <= 256 elements the library
+ * takes the remaining rounds onto the host (BN_ARM_HT_*), where the ranks' partial sums cannot meet on the devices any more.
+ * A caller that exchanges the partials of those rounds ITSELF (host shared memory: binius_amd/host/host_capi.cpp) says so with
+ * bn_host_tail_allow_peer(ctx, 1); after every reduced launch it asks bn_host_tail_active, and from the launch that answers 1 on
+ * it switches the peer exchange off (bn_peer_set_active(ctx, 0): no flush while the tail is active) and combines what
+ * bn_kernel_launch returns -- this rank's LOCAL sums -- across the ranks.  Without the permission a context with an active peer
+ * exchange never starts a host tail. */
+int bn_host_tail_allow_peer(bn_ctx *ctx, int on);
+int bn_host_tail_active(bn_ctx *ctx, int *active);
 int bn_peer_destroy(bn_ctx *ctx);
 
 /* ---- Merkle commitment of a BinaryField128b vector with Groestl-256.

@@ -26,3 +26,8 @@ BN_HOST_TAIL=0 python tools/small_rounds.py > $O/small_rounds_BN_HOST_TAIL_0.jso
 cat $O/step_times.txt
 tail -3 $O/bnh_prof_n24.txt
 tail -4 $O/small_rounds.jsonl
+# the exchanges with several ranks on this one device (diagnostic): the transcript must be the single-GPU one
+for W in 2 8; do
+  BN_ALL_ON_GPU0=1 BN_PG_BACKEND=gloo timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node $W --master-addr 127.0.0.1 --master-port 2972$W bench.py --gpus $W --n-vars 13 --steps 50 --warmup 5 --no-cpu-baseline --no-prof 2>/dev/null | grep '^{' > $O/bench_${W}_ranks_on_one_gpu_n13.json
+  python -c "import json; d=json.load(open('$O/bench_${W}_ranks_on_one_gpu_n13.json')); print('$W ranks n=13:', round(d['ms_per_step'],4), d['verifier_check'], d['transcript_digest'], json.dumps(d['exchanges']))"
+done
