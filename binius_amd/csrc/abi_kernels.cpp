@@ -85,14 +85,16 @@ hipError_t roundeval_product_routed(bn_ctx *ctx, bool scratch_free, const void *
 
 constexpr uint64_t kArmMaxIn = 1ull << 19;     // largest round (elements per array before the fold) that is armed ...
 // ... when it runs on the matrix-core kernel.  Round 3 stopped at 2^21 (a launch is a tenth of a 60 us kernel); a launch is still
-// ~7 us of dead time against a ~3 us signal however long the kernel is, and a shard of an eight-way split has five such rounds
-// (r = 22 ... 25 + the first fused one), so every fused round is armed now (BN_ARM_MAX_LOG2 brings a limit back).  The host's
-// waits cancel the armed kernel before they ever fall back to a stream synchronisation, so a long kernel in front is harmless.
+// ~7 us of dead time against a ~3 us signal however long the kernel is, and a shard of an eight-way split has three more such
+// rounds (r = 22 ... 24), so the limit is 2^24 now.  Above that a launch is < 2 % of the kernel, and an armed kernel's wait for
+// its challenge would be booked to the kernel by every profiler (rocprofv3 durations of the launches that carry the roofline
+// figure).  BN_ARM_MAX_LOG2 moves the limit.  The host's waits cancel an armed kernel before they ever fall back to a stream
+// synchronisation, so a long kernel in front is harmless.
 uint64_t arm_max_in_mfma()
 {
 	static const uint64_t v = [] {
 		const char *e = getenv("BN_ARM_MAX_LOG2");
-		const int l = e ? atoi(e) : 40;
+		const int l = e ? atoi(e) : 24;
 		return (uint64_t)1 << (l < 4 ? 4 : (l > 40 ? 40 : l));
 	}();
 	return v;

@@ -145,3 +145,81 @@ def test_round_by_round_with_foreign_calls(oracle, monkeypatch):
         c = hal.arm_counters()
         assert c["shadow_dropped"] >= 3 and c["shadow_created"] >= 2
         prover.close()
+
+
+@pytest.mark.parametrize("where", ["b_hi", "b_lo", "table", "table_copy", "a_lo"])
+@pytest.mark.parametrize("n_vars", [11, 18])
+def test_a_copy_into_the_shadows_arrays_ends_the_shadow(oracle, monkeypatch, where, n_vars):
+    """between an evaluation and the caller's fold, a copy_d2d INTO an array the shadow describes -- a
+    half of b, a half of a, the indicator table, or the buffer the table's lower half has just been copied to -- must not leave
+    S = lambda * b (.) eq stale: everything deferred runs in issue order, the side stream is joined, the shadow ends and the
+    literal kernels answer.  Two rounds of the literal call sequence with the foreign copy in the first, every returned value
+    and, at the end, the caller's arrays against a host model driven by the oracle."""
+    import binius_amd
+    from binius_amd.sumcheck import bivariate_product_eq_expr, calculate_round_evals
+
+    n = 1 << n_vars
+    a, b = oracle.random_b128(0x5AD70000 + n_vars, n), oracle.random_b128(0x5AD70100 + n_vars, n)
+    eq = oracle.random_b128(0x5AD70200 + n_vars, n // 2)
+    junk = oracle.random_b128(0x5AD70300 + n_vars, 64)
+    zs = oracle.random_scalars(0x5AD7, 4)
+    with binius_amd.Context(0, 6 * n) as hal:
+        alloc = hal.dev_alloc()
+        da, db, deq, dj = (upload(hal, alloc, x) for x in (a, b, eq, junk))
+        dcopy = alloc.alloc(n // 4)
+        e3 = bivariate_product_eq_expr(hal, 0, 1, 2)
+        cur, eq_len = n, n // 2
+        c0 = hal.arm_counters()
+        for r in range(3):
+            got = calculate_round_evals(hal, int(np.log2(cur)), [1], [da.slice(0, cur), db.slice(0, cur)], [e3], eq_ind=deq.slice(0, eq_len))
+            rc, want = oracle.round_evals_eq([a[:cur].copy(), b[:cur].copy()], int(np.log2(cur)), eq[:eq_len].copy(), [(0, 1)], 1)
+            assert rc == 0 and got == want, (where, r)
+            half = cur // 2
+            if r == 0:
+                # the foreign write, between execute and fold
+                if where == "b_hi":
+                    hal.copy_d2d(dj, db.slice(half + 8, half + 72))
+                    b[half + 8 : half + 72] = junk
+                elif where == "b_lo":
+                    hal.copy_d2d(dj, db.slice(3, 67))
+                    b[3:67] = junk
+                elif where == "a_lo":
+                    hal.copy_d2d(dj, da.slice(5, 69))
+                    a[5:69] = junk
+                elif where == "table":
+                    hal.copy_d2d(dj, deq.slice(1, 65))
+                    eq[1:65] = junk
+            hal.extrapolate_line_batch([da.slice(0, half), db.slice(0, half)], [da.slice(half, cur), db.slice(half, cur)], zs[r])
+            for x in (a, b):
+                f = x[:half].copy()
+                assert oracle.extrapolate_line(f, x[half:cur].copy(), zs[r]) == 0
+                x[:half] = f
+            h = eq_len // 2
+            if r == 0 and where == "table_copy":
+                # the prover's "copy the lower half, add the upper half onto the copy" -- with a foreign write into the copy in between
+                hal.copy_d2d(deq.slice(0, h), dcopy.slice(0, h))
+                hal.copy_d2d(dj, dcopy.slice(2, 66))
+                model_copy = eq[:h].copy()
+                model_copy[2:66] = junk
+
+                def k(ke, log_chunks, bufs, h=h):
+                    ke.add_assign(int(np.log2(h)) - log_chunks, bufs[1].to_ref(), bufs[0])
+
+                hal.map_kernels(k, [("chunked_mut", dcopy.slice(0, h), 0), ("chunked", deq.slice(h, eq_len), 0)])
+                model_copy ^= eq[h:eq_len]
+                # the caller goes on with the copy as its table
+                eq = model_copy
+                deq = dcopy
+            else:
+                def k(ke, log_chunks, bufs, h=h):
+                    ke.add_assign(int(np.log2(h)) - log_chunks, bufs[1].to_ref(), bufs[0])
+
+                hal.map_kernels(k, [("chunked_mut", deq.slice(0, h), 0), ("chunked", deq.slice(h, eq_len), 0)])
+                eq[:h] ^= eq[h:eq_len]
+            cur, eq_len = half, h
+        assert np.array_equal(hal.copy_d2h(da.slice(0, n if da.len >= n else da.len)), a[: da.len])
+        assert np.array_equal(hal.copy_d2h(db), b)
+        assert np.array_equal(hal.copy_d2h(deq.slice(0, eq_len)), eq[:eq_len])
+        c1 = hal.arm_counters()
+        if n_vars >= 11:
+            assert c1["shadow_dropped"] - c0["shadow_dropped"] >= 1, "the foreign write did not end the shadow"
