@@ -479,7 +479,7 @@ def main():
     }
     # HBM traffic of the dominant kernel: PMC counters cannot be collected inside this process, so the
     # value comes from the committed counters-only rocprofv3 passes OF THIS COMMAND (tools/pmc_bench.sh ->
-    # profiles/r02/bench_pmc.json: FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, average bytes per launch
+    # profiles/r04/bench_pmc.json: FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, average bytes per launch
     # of the kernel symbol, with the commit of the build it was taken on); null for a workload it does not hold
     try:
         pmc = json.load(open(os.path.join(ROOT, PMC_FILE)))

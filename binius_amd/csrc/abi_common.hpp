@@ -96,6 +96,9 @@ int host_tail_flush(bn_ctx *ctx, bool publish);
 int flush_first_fold(bn_ctx *ctx);
 // the deferred fold `pf` folds exactly the arrays the precomputed next-round sums describe
 bool pre_matches(const bn_ctx::precomp_state &pre, const bn_ctx::pending_fold &pf);
+// the product-sum kernels with the three-factor a * b * eq shape routed through two element-wise passes + the matrix-core
+// kernel from 2^20 points (abi_kernels.cpp roundeval_product_routed); scratch_free: the context scratch is not in use
+hipError_t roundeval_product_routed_pub(bn_ctx *ctx, bool scratch_free, const void *const *hi, const void *const *lo, uint32_t k, uint64_t n, bn::f128 *d_out);
 // ---- arbitrary ArithCircuits on the throughput kernels (abi_circuit.cpp)
 bool circuit_multipass_applies(const bn_ctx *ctx, const bn_expr *e, uint64_t row_len);
 constexpr int kCircuitDeclined = -1000; // (internal: the planner declines this circuit -- run the interpreter)

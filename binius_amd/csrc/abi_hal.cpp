@@ -290,7 +290,7 @@ int bn_hal_round_evals(bn_ctx *ctx, uint32_t order, uint32_t n_vars, const void 
 			if (l2h)
 				BN_HIP(bn::launch_roundeval_mfma_pair_strided(ctx->stream, ctx->n_cu, hi[0], lo[0], shift[0], hi[1], lo[1], shift[1], half, d_acc + 32 + 2 * j));
 			else
-				BN_HIP(bn::launch_roundeval_product(ctx->stream, ctx->n_cu, hi, lo, k, half, d_acc + 32 + 2 * j, nullptr));
+				BN_HIP(roundeval_product_routed_pub(ctx, /*scratch_free=*/n_tr == 0, hi, lo, k, half, d_acc + 32 + 2 * j)); // (a * b * eq: routed from 2^20 points)
 		}
 		std::vector<f128> sums(2 * jobs.size());
 		{

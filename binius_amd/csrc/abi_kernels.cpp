@@ -447,6 +447,15 @@ struct slice_view {
 };
 } // namespace
 
+} // extern "C"
+namespace bnabi {
+hipError_t roundeval_product_routed_pub(bn_ctx *ctx, bool scratch_free, const void *const *hi, const void *const *lo, uint32_t k, uint64_t n, f128 *d_out)
+{
+	return roundeval_product_routed(ctx, scratch_free, hi, lo, k, n, d_out, nullptr);
+}
+} // namespace bnabi
+extern "C" {
+
 int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const bn_kop *ops, uint32_t n_ops,
                      const uint32_t *ret_values, uint32_t n_ret, uint32_t log_chunks, bn_f128 *h_out, void *d_out)
 {

@@ -313,9 +313,11 @@ __device__ __forceinline__ void tail_finish(gram_parity &Gc, unsigned wave, unsi
 		if (lane == 0) z3[pr][s] = z;
 	}
 	__syncthreads();
+	BN_TS(6);
 	if (tid < 2)
 		s_loc[tid] = kara64(z3[tid][0], z3[tid][1], z3[tid][2]);
 	__syncthreads();
+	BN_TS(7);
 	// fc: the finalize arguments were staged in LDS at kernel entry (finalize.hpp)
 	unsigned *const counter = fc ? fc->counter : fz.counter;
 	f128 *const S = fc ? fc->S : fz.S;
@@ -341,6 +343,7 @@ __device__ __forceinline__ void tail_finish(gram_parity &Gc, unsigned wave, unsi
 			is_last = (t == gridDim.x - 1) ? 1u : 0u;
 		}
 		__syncthreads();
+		BN_TS(8);
 		if (is_last) {
 			if (fc)
 				finalize_cached(*fc, seq);

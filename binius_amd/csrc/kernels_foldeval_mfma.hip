@@ -49,6 +49,7 @@ __global__ __launch_bounds__(256, 2) void k_foldeval_mfma(foldeval_args fa, uint
 
 	v16i acc[kAccTiles];
 	acc_zero(acc);
+	BN_TS(0);
 
 	// quadrant k = 2 * array + half: element index half * n + point
 	uint4 x0[4], x1[4];
@@ -80,6 +81,7 @@ __global__ __launch_bounds__(256, 2) void k_foldeval_mfma(foldeval_args fa, uint
 	};
 	uint64_t t = t0;
 	if (t < tlimit) load(t);
+	BN_TS(1);
 	{
 		// the finalize arguments travel with the first tile and wait in LDS for the tail (finalize.hpp)
 		const fin_pref fpre = fin_prefetch(fz);
@@ -96,6 +98,7 @@ __global__ __launch_bounds__(256, 2) void k_foldeval_mfma(foldeval_args fa, uint
 		}
 		fin_commit(fz, fpre, fcache);
 	}
+	BN_TS(2);
 
 	// One iteration: fold tile tt (VALU + LDS lookups) with, when GRAM, the Gram k-steps of the previous
 	// tile (in Tp) between the four constant multiplications (matrix pipe); the folded registers go to HBM
@@ -166,13 +169,17 @@ __global__ __launch_bounds__(256, 2) void k_foldeval_mfma(foldeval_args fa, uint
 	if (t < tlimit) {
 		unsigned buf = 0;
 		iteration(t, T[1], T[0], std::false_type{});
+		BN_TS(3);
 		for (t += tstride; t < tlimit; t += tstride) {
 			iteration(t, T[buf], T[buf ^ 1], std::true_type{});
 			buf ^= 1;
 		}
+		BN_TS(4);
 		gram_tile(T[buf], gr, acc);
 	}
+	BN_TS(5);
 	gram::tail(acc, wave, lane, out, fz, seq, &fcache);
+	BN_TS(12);
 }
 
 // For both arrays j: out_j[i] = x0_j[i] + z * (x1_j[i] - x0_j[i]), i < n_in/2 (out_j may be x0_j), and

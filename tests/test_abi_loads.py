@@ -174,7 +174,7 @@ def test_host_library_exports_every_declared_symbol(ffi):
 
 
 def test_design_tables_are_generated_from_the_committed_profiles():
-    """DESIGN.md section 5 is generated (tools/gen_design_tables.py) from profiles/r03: hand edits or stale numbers fail here."""
+    """DESIGN.md section 5 is generated (tools/gen_design_tables.py) from profiles/r04: hand edits or stale numbers fail here."""
     import subprocess
     import sys
 

@@ -15,7 +15,7 @@ ap.add_argument("--n-vars-general", type=int, default=20)
 ap.add_argument("--reps", type=int, default=4)
 a = ap.parse_args()
 n = 1 << a.n_vars
-hal = binius_amd.Context(0, 5 * n + (1 << 16))
+hal = binius_amd.Context(0, 5 * n + (1 << 16))  # (the general path's rows and temporaries live in context scratch)
 alloc = hal.dev_alloc()
 d = []
 for j in range(3):
@@ -51,9 +51,13 @@ timed("hal_round_evals a*b + c at X = 1, inf, n_vars=%d (routed)" % nv,
       lambda: hal.hal_round_evals(1, nv, None, full(3, nv), [{"composition": AB_C, "composition_at_infinity": AB, "start": 1, "end": 3, "eq_ind": None}], []), 48 * n)
 ng = a.n_vars_general
 pts = synthetic.random_scalars(5, 1)
-timed("hal_round_evals a*b*c + a at X = 1, inf, z (general interpreter kernel), n_vars=%d" % ng,
+timed("hal_round_evals a*b*c + a at X = 1, inf, z (round 3: interpreter kernel; now rows + compiled circuits), n_vars=%d" % ng,
       lambda: hal.hal_round_evals(1, ng, None, full(3, ng), [{"composition": ABC_A, "composition_at_infinity": ABC, "start": 1, "end": 4, "eq_ind": None}], pts), 48 << ng)
-timed("hal_round_evals a*b, Low-to-High (general kernel), n_vars=%d" % ng,
+timed("hal_round_evals a*b*c + a at X = 1, inf, z (rows + compiled circuits), n_vars=%d" % nv,
+      lambda: hal.hal_round_evals(1, nv, None, full(3, nv), [{"composition": ABC_A, "composition_at_infinity": ABC, "start": 1, "end": 4, "eq_ind": None}], pts), 48 << nv)
+timed("hal_round_evals a*b at X = 1, inf, High-to-Low, n_vars=%d (routed)" % ng,
+      lambda: hal.hal_round_evals(1, ng, None, full(2, ng), [{"composition": AB, "composition_at_infinity": AB, "start": 1, "end": 3, "eq_ind": None}], []), 32 << ng)
+timed("hal_round_evals a*b, Low-to-High (round 3: interpreter kernel; now the strided matrix-core kernel), n_vars=%d" % ng,
       lambda: hal.hal_round_evals(0, ng, None, full(2, ng), [{"composition": AB, "composition_at_infinity": AB, "start": 1, "end": 3, "eq_ind": None}], []), 32 << ng)
 z = synthetic.random_scalars(6, 1)[0]
 timed("hal_fold_multilinear High-to-Low out of place, 2^%d" % nv, lambda: hal.hal_fold_multilinear(1, nv, ("folded", d[0], 0), z, None, out), 24 * n)

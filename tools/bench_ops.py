@@ -61,6 +61,17 @@ timed("fri_fold log_len=%d log_batch=4, 3 fold rounds" % (a.log_n - lb), lambda:
 small = 1 << 20
 timed("compute_composite a*b, 2^20", lambda: hal.compute_composite([A.slice(0, small), B.slice(0, small)], Cc.slice(0, small), expr), 48 * small)
 timed("compute_composite a*b, 2^%d" % (a.log_n - 1), lambda: hal.compute_composite([A.slice(0, half), B.slice(0, half)], Cc.slice(0, half), expr), 48 * half)
+# generic circuits (csrc/abi_circuit.cpp: compiled into passes of the throughput kernels)
+gen = hal.compile_expr([("var", 0), ("var", 1), ("mul", 0, 1), ("var", 2), ("mul", 2, 3), ("add", 4, 0)])  # a*b*c + a
+q = n // 4
+timed("compute_composite a*b*c + a (generic circuit), 2^%d" % (a.log_n - 2), lambda: hal.compute_composite([A.slice(0, q), B.slice(0, q), D.slice(0, q)], Cc.slice(0, q), gen), 64 * q)
+def gk(ke, lc_, b):
+    acc = ke.decl_value(0)
+    ke.sum_composition_evals([x.to_ref() for x in b], gen, 1, acc)
+    return [acc]
+gm = [("chunked", A.slice(0, q), 0), ("chunked", B.slice(0, q), 0), ("chunked", D.slice(0, q), 0)]
+gops, grets, glc = hal.record(gk, gm)
+timed("accumulate_kernels sum of a*b*c + a (generic circuit), 2^%d rows" % (a.log_n - 2), lambda: hal.kernel_launch(gm, gops, grets, glc), 48 * q)
 outs = [alloc.alloc(small >> (r + 1)) for r in range(20)] if alloc.capacity() > small else None
 if outs:
     timed("pairwise_product_reduce 2^20", lambda: hal.pairwise_product_reduce(A.slice(0, small), outs), 16 * small * 2)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# the round's measurement batch (run through gpurun from the repo root); results in gpurun_out/final/, copied to profiles/r03/
+# the round's measurement batch (run through gpurun from the repo root); results in gpurun_out/final/, copied to profiles/r04/
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/final
 rm -rf $O; mkdir -p $O
@@ -10,11 +10,14 @@ cd $R
 BUILD=$(cat $R/tools/.build_id 2>/dev/null || python -c "import bench; print(bench.csrc_sha16())")
 tools/pmc_bench.sh $BUILD 28 24 > $O/pmc_bench.log 2>&1
 cp $R/gpurun_out/bench_pmc.json $O/bench_pmc.json
-cp $R/gpurun_out/bench_pmc.json $R/profiles/r03/bench_pmc.json
+mkdir -p $R/profiles/r04; cp $R/gpurun_out/bench_pmc.json $R/profiles/r04/bench_pmc.json
 python bench.py > $O/bench_n28.json 2> $O/bench_n28.stderr
 python bench.py --n-vars 24 --steps 5 --warmup 2 > $O/bench_n24.json 2> $O/bench_n24.stderr
 python bench.py --n-vars 25 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_n25_one_shard_of_eight.json 2>/dev/null
 python bench.py --n-vars 20 --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_n20.json 2>/dev/null
+BN_HOST_TAIL=0 python bench.py --n-vars 24 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_n24_BN_HOST_TAIL_0.json 2>/dev/null
+BN_HOST_TAIL=0 python bench.py --n-vars 25 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_n25_BN_HOST_TAIL_0.json 2>/dev/null
+BN_HOST_TAIL=0 python bench.py --n-vars 20 --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_n20_BN_HOST_TAIL_0.json 2>/dev/null
 BN_TWO_ROUND=0 python bench.py --n-vars 24 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_n24_BN_TWO_ROUND_0.json 2>/dev/null
 BN_TWO_ROUND=0 python bench.py --n-vars 25 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_n25_BN_TWO_ROUND_0.json 2>/dev/null
 python tools/bench_ops.py > $O/ops.jsonl 2>&1
@@ -24,12 +27,15 @@ python tools/profile_ntt.py --reps 3 > $O/ntt_2p24_b32.txt 2>&1
 python tools/bench_fri_commit.py > $O/fri_commit.jsonl 2>&1
 python tools/small_rounds.py > $O/small_rounds.jsonl 2>&1
 BN_TWO_ROUND=0 python tools/small_rounds.py > $O/small_rounds_BN_TWO_ROUND_0.jsonl 2>&1
-BN_TWO_ROUND_MAX_LOG2=18 python tools/small_rounds.py > $O/small_rounds_BN_TWO_ROUND_MAX_LOG2_18.jsonl 2>&1
+BN_HOST_TAIL=0 python tools/small_rounds.py > $O/small_rounds_BN_HOST_TAIL_0.jsonl 2>&1
+tools/mfma_round_phases > $O/mfma_round_phases.txt 2>&1
+tools/r04_fe_variants.sh > /dev/null 2>&1; cp $R/gpurun_out/fe_variants/times.txt $O/fe_variants.txt
 python tools/bench_pairwise.py > $O/pairwise.jsonl 2>&1
 BN_PAIRTREE_MAX_LOG2=0 python tools/bench_pairwise.py 20 > $O/pairwise_BN_PAIRTREE_MAX_LOG2_0.jsonl 2>&1
 tools/trace_cmd.sh final/trace_pair python tools/bench_pairwise.py 20 > /dev/null 2>&1; tail -8 $O/trace_pair/per_launch.jsonl > $O/pairwise_per_launch.jsonl; rm -rf $O/trace_pair
 tools/trace_cmd.sh final/trace_fri python tools/run_fri_only.py > /dev/null 2>&1; tail -3 $O/trace_fri/per_launch.jsonl > $O/fri_fold_per_launch.jsonl; rm -rf $O/trace_fri
-{ for L in 16 17 18; do echo "== BN_TWO_ROUND_MAX_LOG2=$L"; for n in 20 24 25; do BN_TWO_ROUND_MAX_LOG2=$L python bench.py --n-vars $n --steps 20 --warmup 3 --no-cpu-baseline --no-prof 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('n=$n L=$L ms_per_step', d['ms_per_step'], d['verifier_check'], d['transcript_digest'])"; done; done
+{ for rep in 1 2 3; do for n in 20 24 25; do for HT in 1 0; do BN_HOST_TAIL=$HT python bench.py --n-vars $n --steps 20 --warmup 3 --no-cpu-baseline --no-prof 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('n=$n BN_HOST_TAIL=$HT ms_per_step', round(d['ms_per_step'],4), d['verifier_check'], d['transcript_digest'])"; done; done; done
+  echo "== BN_ARM_MAX_LOG2=21 (round 3's arming limit)"; for n in 24 25; do BN_ARM_MAX_LOG2=21 python bench.py --n-vars $n --steps 20 --warmup 3 --no-cpu-baseline --no-prof 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('n=$n ms_per_step', round(d['ms_per_step'],4), d['verifier_check'], d['transcript_digest'])"; done
   echo "== BN_TWO_ROUND=0"; for n in 20 24 25; do BN_TWO_ROUND=0 python bench.py --n-vars $n --steps 20 --warmup 3 --no-cpu-baseline --no-prof 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('n=$n off ms_per_step', d['ms_per_step'], d['verifier_check'], d['transcript_digest'])"; done; } > $O/two_round_step_times.txt 2>&1
 tools/two_round_phases > $O/two_round_phases.txt 2>&1
 tools/small_round_phases > $O/small_round_phases.txt 2>&1
