@@ -5,6 +5,8 @@
 //
 // No arithmetic fallback lives here: every op is a HIP kernel launch.  Host-side field arithmetic
 // is used only for O(log n) metadata (twiddle basis = OnTheFlyTwiddleAccess::generate).
+#include <atomic>
+
 #include "abi_common.hpp"
 #include "hostmul.hpp"
 
@@ -261,9 +263,14 @@ int host_tail_flush(bn_ctx *ctx, bool publish)
 	if (!ht.active) return BN_OK;
 	ht.active = false;
 	if (ht.n_levels) {
-		ht.chain.k = ht.n_levels;
+		// the host copy's first n0 elements per array ARE the caller's buffers after the folds (the host folds in place exactly as
+		// the device would): into the pinned staging, then one launch maps them back to the tower basis and stores them
+		uint64_t *stg = (uint64_t *)ctx->h_tail + 2 * 512;
+		const uint32_t n0 = ht.chain.n0;
+		for (int j = 0; j < 2; j++) std::memcpy(stg + 2 * (size_t)n0 * j, ht.y[j].data(), (size_t)n0 * 16);
+		std::atomic_thread_fence(std::memory_order_seq_cst);
 		prof_scope ps(ctx, BN_PROF_FOLD);
-		BN_HIP(bn::launch_fold_chain(ctx->stream, ht.chain));
+		BN_HIP(bn::launch_tail_writeback(ctx->stream, ht.chain, (const char *)ctx->d_tail + 512 * sizeof(f128), (const char *)ctx->d_phi + 512 * sizeof(f128)));
 		ctx->ht_flushed++;
 	}
 	if (publish && ht.cur_m == 1 && !ht.evaluated && ht.n_levels) {
@@ -286,13 +293,13 @@ int host_tail_flush(bn_ctx *ctx, bool publish)
 bool host_tail_fold(bn_ctx *ctx, void *const *x0, const void *const *src0, const void *const *x1, uint32_t count, uint64_t n, uint32_t scale_mask, f128 z)
 {
 	bn_ctx::host_tail_state &ht = ctx->ht;
-	if (!ht.active || !ht.evaluated || ctx->pend.active || count != 2 || scale_mask || 2 * n != ht.cur_m || ht.n_levels >= 8) return false;
+	if (!ht.active || !ht.evaluated || ctx->pend.active || count != 2 || scale_mask || 2 * n != ht.cur_m) return false;
 	auto is = [&](uint32_t i, int j) { return src0[i] == ht.cur_lo[j] && x1[i] == ht.cur_hi[j]; };
 	int perm = -1;
 	if (is(0, 0) && is(1, 1)) perm = 0;
 	else if (is(0, 1) && is(1, 0)) perm = 1;
 	if (perm < 0 || x0[0] == x0[1]) return false;
-	// later levels chain in place on the first level's output (fold_chain_args)
+	// later folds are in place on the first fold's output (what the write-back of the host copy assumes)
 	if (ht.n_levels > 0)
 		for (uint32_t i = 0; i < 2; i++)
 			if (x0[i] != src0[i]) return false;
@@ -303,15 +310,10 @@ bool host_tail_fold(bn_ctx *ctx, void *const *x0, const void *const *src0, const
 	}
 	if (ht.n_levels == 0) {
 		if (n > 128) return false;
-		for (uint32_t i = 0; i < 2; i++) {
-			const int j = perm ? 1 - (int)i : (int)i;
-			ht.chain.src0[j] = src0[i];
-			ht.chain.x1[j] = x1[i];
-			ht.chain.out[j] = x0[i];
-		}
+		for (uint32_t i = 0; i < 2; i++) ht.chain.out[perm ? 1 - (int)i : (int)i] = x0[i];
 		ht.chain.n0 = (uint32_t)n;
 	}
-	ht.chain.z[ht.n_levels++] = z;
+	ht.n_levels++;
 	const bn::hp128 pz = bn::hostpoly_from_tower(z);
 	for (int j = 0; j < 2; j++) bn::hostpoly_fold(reinterpret_cast<bn::hp128 *>(ht.y[j].data()), n, pz);
 	for (uint32_t i = 0; i < 2; i++) {
@@ -598,12 +600,13 @@ int bn_ctx_create(int device, uint64_t arena_elems, bn_ctx **out)
 		// host tail: pinned staging for Y (2 x 256 elements) and the nibble table of the host's basis change on the device
 		const char *e = getenv("BN_HOST_TAIL");
 		if (!(e && e[0] == '0') && bn::hostpoly_available()) {
-			std::vector<uint64_t> phi(1024);
+			std::vector<uint64_t> phi(2048);
 			bn::hostpoly_phi_nibble_table(phi.data());
-			BN_HIP(hipHostMalloc(&ctx->h_tail, 512 * sizeof(f128), hipHostMallocMapped | hipHostMallocCoherent));
+			bn::hostpoly_phi_inv_nibble_table(phi.data() + 1024);
+			BN_HIP(hipHostMalloc(&ctx->h_tail, 768 * sizeof(f128), hipHostMallocMapped | hipHostMallocCoherent));
 			BN_HIP(hipHostGetDevicePointer(&ctx->d_tail, ctx->h_tail, 0));
-			BN_HIP(hipMalloc(&ctx->d_phi, 512 * sizeof(f128)));
-			BN_HIP(hipMemcpy(ctx->d_phi, phi.data(), 512 * sizeof(f128), hipMemcpyHostToDevice));
+			BN_HIP(hipMalloc(&ctx->d_phi, 1024 * sizeof(f128)));
+			BN_HIP(hipMemcpy(ctx->d_phi, phi.data(), 1024 * sizeof(f128), hipMemcpyHostToDevice));
 			ctx->ht_enabled = true;
 			if (const char *l = getenv("BN_HOST_TAIL_MAX_LOG2")) {
 				const int v = atoi(l);

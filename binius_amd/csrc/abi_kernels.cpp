@@ -142,7 +142,7 @@ bn::fin_fuse two_round_recipe(const bn::fin_fuse &fz)
 // is host arithmetic: a fold of 2 x 128 elements is 0.9 us, a round evaluation over 128 points 0.8 us (the 256-bit
 // carry-less products are XORed unreduced, one reduction per sum), against ~10 us per round through the device.  The calls
 // must be the expected ones (the fold of exactly these arrays, the evaluation of exactly their halves); anything else
-// launches the chain of outstanding folds (launch_fold_chain: the caller's memory ends up as eager execution leaves it)
+// writes the host's folded copy back (launch_tail_writeback: the caller's memory ends up as eager execution leaves it)
 // and the device path takes over again.  Not under a peer exchange (the ranks' partial sums meet on the devices there).
 bool host_tail_applies(const bn_ctx *ctx, uint64_t m, uint32_t peer_world)
 {

@@ -80,6 +80,7 @@ void hostpoly_fold(hp128 *x, size_t half, hp128 z); // x[i] += z (x[i] + x[i + h
 // y1 = sum a[half + i] b[half + i], yinf = sum (a[i] + a[half + i]) (b[i] + b[half + i]), i < half
 void hostpoly_round_sums(const hp128 *a, const hp128 *b, size_t half, hp128 *y1, hp128 *yinf);
 void hostpoly_phi_nibble_table(uint64_t *out); // [1024]: Phi(e << 4 p) at entry 16 p + e (the layout of ctable.hpp's T)
+void hostpoly_phi_inv_nibble_table(uint64_t *out); // the same for the inverse map (power basis -> tower basis)
 
 inline f128 mul_host(f128 a, f128 b)
 {

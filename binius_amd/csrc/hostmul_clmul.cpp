@@ -277,6 +277,17 @@ void hostpoly_phi_nibble_table(uint64_t *out)
 		}
 }
 
+void hostpoly_phi_inv_nibble_table(uint64_t *out)
+{
+	const clmul_state &st = state();
+	for (int p = 0; p < 32; p++)
+		for (int e = 0; e < 16; e++) {
+			const u128 v = st.inv[p >> 1][(p & 1) ? (e << 4) : e];
+			out[2 * (16 * p + e)] = v.lo;
+			out[2 * (16 * p + e) + 1] = v.hi;
+		}
+}
+
 } // namespace bn
 
 #else // not x86-64: no carry-less multiply route
@@ -291,6 +302,7 @@ hp128 hostpoly_mul(hp128 a, hp128) { return a; }
 void hostpoly_fold(hp128 *, size_t, hp128) {}
 void hostpoly_round_sums(const hp128 *, const hp128 *, size_t, hp128 *, hp128 *) {}
 void hostpoly_phi_nibble_table(uint64_t *) {}
+void hostpoly_phi_inv_nibble_table(uint64_t *) {}
 } // namespace bn
 
 #endif

@@ -23,15 +23,11 @@ struct bn_expr {
 
 namespace bn {
 constexpr int kPeerMaxWorld = 16; // ranks of one node that can share a peer exchange (finalize.hpp)
-// Up to 8 chained folds of two small arrays in ONE launch (the device catching up with a host tail, abi_kernels.cpp):
-// level 0 reads src0[j][i], x1[j][i] (i < n0 <= 128) and writes out[j][i]; level l >= 1 folds out[j][0 .. n0 >> (l - 1))
-// in place with z[l].  Memory ends up exactly as after `k` separate folds.
-struct fold_chain_args {
-	const void *src0[2];
-	const void *x1[2];
+// What a host tail (abi_kernels.cpp) leaves for the device to catch up with: the host folded its copy of two small arrays in place
+// `levels` times; out[j][0 .. n0) -- where the FIRST of those folds wrote -- must end up holding what the host copy holds there.
+struct tail_writeback_args {
 	void *out[2];
-	uint32_t n0, k;
-	f128 z[8];
+	uint32_t n0;
 };
 }
 
@@ -163,19 +159,19 @@ struct bn_ctx {
 	// Host tail of a sumcheck (abi_kernels.cpp "host tail"): once the arrays are down to a few hundred elements the
 	// two-round kernel hands them to the host (already mapped into the power basis of hostmul_clmul.cpp) and the remaining
 	// rounds -- evaluations and folds -- are host arithmetic: no launch, no round trip.  The device catches up with ONE
-	// launch that performs all the folds (launch_fold_chain) when the caller reads the final evaluations or does anything
+	// launch that writes the host's folded copy back (launch_tail_writeback) when the caller reads the final evaluations or does anything
 	// else; the caller's memory ends up exactly as eager execution leaves it.
 	struct host_tail_state {
 		bool active = false;
 		bool evaluated = false;        // the evaluation of the current arrays has been answered: the next expected call is their fold
 		uint32_t n_levels = 0;         // folds performed on the host and not yet on the device
-		bn::fold_chain_args chain{};   // ... and what they are
+		bn::tail_writeback_args chain{}; // ... and where their results belong
 		uint64_t cur_m = 0;            // elements per array of the current (host) arrays
 		const void *cur_lo[2] = {}, *cur_hi[2] = {}; // device addresses of their halves: what the next calls must name
 		std::vector<uint64_t> y[2];    // the arrays in the power basis, 2 words per element
 	} ht;
-	void *h_tail = nullptr, *d_tail = nullptr; // pinned staging the kernel mirrors Y into (host / device view), 2 x 256 elements
-	void *d_phi = nullptr;                     // nibble table of the basis change (8 KiB of device memory)
+	void *h_tail = nullptr, *d_tail = nullptr; // pinned staging (host / device view): [0, 512) the kernel mirrors Y into, [512, 768) the host's folded copy for the write-back
+	void *d_phi = nullptr;                     // nibble tables of the basis change and of its inverse (2 x 8 KiB of device memory)
 	bool ht_enabled = false;                   // BN_HOST_TAIL=0 turns it off; needs PCLMULQDQ on the host
 	bool ht_peer_ok = false;                   // bn_host_tail_allow_peer: the caller exchanges the host rounds' partials itself
 	uint64_t ht_max = 256;                     // largest Y (elements per array) the host takes over (BN_HOST_TAIL_MAX_LOG2, <= 8)
@@ -364,7 +360,9 @@ hipError_t launch_foldeval8(hipStream_t s, const foldeval8_args &fa, f128 z1, f1
                             const arm_args *armed = nullptr);
 // the last two folds of a sumcheck in one launch (4 n_out -> n_out elements per array, count * n_out <= 64), mirrored into
 // the mailbox like launch_fold_publish
-hipError_t launch_fold_chain(hipStream_t s, const fold_chain_args &a);
+// the device catching up with a host tail: out[j][i] = PhiInv(staging[j * n0 + i]), i < n0 <= 128 -- the host's folded copy (power
+// basis, pinned host memory) mapped back to the tower basis through the nibble table of the inverse basis change
+hipError_t launch_tail_writeback(hipStream_t s, const tail_writeback_args &a, const void *d_staging, const void *d_phi_inv);
 hipError_t launch_fold2_publish(hipStream_t s, void *const *out, const void *const *src0, const void *const *x1, uint32_t count, uint32_t n_out,
                                 f128 z1, f128 z2, f128 *d_mail, uint64_t seq);
 hipError_t launch_roundeval9_eq(hipStream_t s, int n_cu, const void *a_hi, const void *a_lo, const void *b_hi, const void *b_lo,

@@ -272,50 +272,27 @@ hipError_t launch_fold2_publish(hipStream_t s, void *const *out, const void *con
 	return hipGetLastError();
 }
 
-// Up to eight chained folds of two small arrays in one launch (fold_chain_args, internal.hpp): the device catching up with
-// the folds a host tail performed on its own copy (abi_kernels.cpp).  One workgroup of 512 threads; the nibble tables of four
-// levels are built side by side by its four quarters, thread (array = t >> 7, i = t & 127) carries element i of its array
-// through the levels (values in LDS between them), and every level's output is stored where a separate in-place fold
-// would have left it -- later levels overwrite the lower part, by the same thread, in program order.
-__global__ __launch_bounds__(512) void k_fold_chain(fold_chain_args a)
+// The device catching up with a host tail (abi_kernels.cpp): the host has folded its copy of the two arrays -- in the power basis of
+// hostmul_clmul.cpp -- and left it in pinned memory; out[j][i] = PhiInv(staging[j * n0 + i]) puts into the caller's buffers exactly what
+// the folds it asked for would have (field arithmetic is exact: the same element whichever basis the products were taken in).  One
+// workgroup, one element per thread, the inverse basis change as one nibble-table product; nobody waits for it.
+__global__ __launch_bounds__(256) void k_tail_writeback(tail_writeback_args a, const uint4 *__restrict__ staging, const uint4 *__restrict__ phi_inv)
 {
-	__shared__ ctable_smem tab[4];
-	__shared__ uint4 buf[2][128];
-	const unsigned tid = threadIdx.x, grp = tid >> 7, arr = (tid >> 7) & 1, i = tid & 127;
-	const bool mine = tid < 256;
-	for (uint32_t l0 = 0; l0 < a.k; l0 += 4) {
-		const bool build = l0 + grp < a.k; // (every thread takes part in the barriers of the build)
-		ctable_build_group(tab[grp], build ? a.z[l0 + grp] : f128{0, 0}, build ? i : 128u, 128);
-		for (uint32_t l = l0; l < l0 + 4 && l < a.k; l++) {
-			const uint32_t n = a.n0 >> l; // elements this level writes
-			uint4 v{0, 0, 0, 0};
-			const bool act = mine && i < n;
-			if (act) {
-				uint4 x0, x1;
-				if (l == 0) {
-					x0 = ((const uint4 *)a.src0[arr])[i];
-					x1 = ((const uint4 *)a.x1[arr])[i];
-				} else {
-					x0 = buf[arr][i];
-					x1 = buf[arr][i + n];
-				}
-				v = xor4(x0, ctable_mul(tab[l - l0], xor4(x0, x1)));
-			}
-			__syncthreads(); // (everybody has read the previous level)
-			if (act) {
-				buf[arr][i] = v;
-				((uint4 *)a.out[arr])[i] = v;
-			}
-			__syncthreads();
-		}
-	}
+	__shared__ uint4 T[512];
+	const unsigned tid = threadIdx.x, arr = tid >> 7, i = tid & 127;
+	const bool act = i < a.n0;
+	uint4 v{0, 0, 0, 0};
+	if (act) v = staging[arr * a.n0 + i];
+	T[tid] = phi_inv[tid];
+	T[tid + 256] = phi_inv[tid + 256];
+	__syncthreads();
+	if (act) ((uint4 *)a.out[arr])[i] = ctable_mul(*reinterpret_cast<const ctable_smem *>(T), v);
 }
 
-hipError_t launch_fold_chain(hipStream_t s, const fold_chain_args &a)
+hipError_t launch_tail_writeback(hipStream_t s, const tail_writeback_args &a, const void *d_staging, const void *d_phi_inv)
 {
-	if (a.k == 0) return hipSuccess;
-	if (a.k > 8 || a.n0 == 0 || a.n0 > 128 || (a.n0 & (a.n0 - 1)) || (a.n0 >> (a.k - 1)) == 0) return hipErrorNotSupported;
-	hipLaunchKernelGGL(k_fold_chain, dim3(1), dim3(512), 0, s, a);
+	if (a.n0 == 0 || a.n0 > 128) return hipErrorNotSupported;
+	hipLaunchKernelGGL(k_tail_writeback, dim3(1), dim3(256), 0, s, a, (const uint4 *)d_staging, (const uint4 *)d_phi_inv);
 	return hipGetLastError();
 }
 
