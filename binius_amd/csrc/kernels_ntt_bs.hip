@@ -95,12 +95,31 @@ __host__ __device__ constexpr int top_slot(int b, int blk) { return (16 >> b) - 
 
 // v * tw through the twiddle's nibble tables (LDS): 8 lookups, all lanes of a wave use the same
 // twiddle, so a lookup touches one 64-byte table row (conflict-free)
+// (byte offsets of the eight entries with one SDWA byte-select-and-mask each: bits 2..5 of byte k of v << 2 are the low nibble
+// of byte k of v times four, of v >> 2 the high nibble times four -- 10 instead of 16 address instructions per product)
+template <int B>
+__device__ __forceinline__ uint32_t ntt_byte_and(uint32_t w, uint32_t m)
+{
+	uint32_t r;
+	if constexpr (B == 0)
+		asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(r) : "v"(w), "v"(m));
+	else if constexpr (B == 1)
+		asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(r) : "v"(w), "v"(m));
+	else if constexpr (B == 2)
+		asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(r) : "v"(w), "v"(m));
+	else
+		asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(r) : "v"(w), "v"(m));
+	return r;
+}
 __device__ __forceinline__ uint32_t top_mul(const uint32_t *tab /*[8][16]*/, uint32_t v)
 {
-	uint32_t r = 0;
-#pragma unroll
-	for (int p = 0; p < 8; p++)
-		r ^= tab[16 * p + ((v >> (4 * p)) & 15u)];
+	const char *base = reinterpret_cast<const char *>(tab);
+	const uint32_t lo = v << 2, hi = v >> 2, m = 0x3Cu;
+	auto at = [&](int p, uint32_t off) { return *reinterpret_cast<const uint32_t *>(base + 64 * p + off); };
+	uint32_t r = at(0, ntt_byte_and<0>(lo, m)) ^ at(1, ntt_byte_and<0>(hi, m));
+	r ^= at(2, ntt_byte_and<1>(lo, m)) ^ at(3, ntt_byte_and<1>(hi, m));
+	r ^= at(4, ntt_byte_and<2>(lo, m)) ^ at(5, ntt_byte_and<2>(hi, m));
+	r ^= at(6, ntt_byte_and<3>(lo, m)) ^ at(7, ntt_byte_and<3>(hi, m));
 	return r;
 }
 
@@ -301,7 +320,20 @@ __global__ __launch_bounds__(256, 2) void k_ntt_bs_pass(uint4 *__restrict__ bs, 
 			tile3[s_u * kSetQ + k] = u4v{U[4 * k], U[4 * k + 1], U[4 * k + 2], U[4 * k + 3]};
 			tile3[s_v * kSetQ + k] = u4v{V[4 * k], V[4 * k + 1], V[4 * k + 2], V[4 * k + 3]};
 		}
-		__syncthreads();
+		// Who reads what this layer wrote?  The thread that handles set s at butterfly bit `pos` is s with that bit removed,
+		// so for pos <= 6 its wave is s >> 7 whatever pos is: between two layers whose butterfly bits are both <= 6 every set
+		// stays inside one wave, and the wave's own LDS operations are performed in order -- no workgroup barrier (the waves of
+		// a tile drift apart instead of waiting for the slowest after every layer).  BN_NTT_WG_BARRIERS (build flag): round 3's form.
+		const int tn = tt + 1 < (int)R ? (INV ? tt + 1 : (int)R - 2 - tt) : -1;
+		const unsigned pos_next = tn >= 0 ? n_lo + (unsigned)tn : 99u;
+#ifndef BN_NTT_WG_BARRIERS
+		if (pos <= 6 && pos_next <= 6) {
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		} else
+#endif
+			__syncthreads();
 	}
 	if (CONV && !INV) {
 		// plane sets -> elements
