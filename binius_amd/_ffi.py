@@ -516,12 +516,12 @@ class Context:
     def arm_counters(self):
         """Armed rounds (csrc/arm.hpp): {hits, cancels, expired} since the context was created; two-round launches
         (csrc/kernels_foldeval8.hip): their number and the rounds the host answered from their precomputed sums."""
-        c = (C.c_uint64 * 14)()
+        c = (C.c_uint64 * 15)()
         _check(lib().bn_arm_counters(self._h, c))
         return {"hits": int(c[0]), "cancels": int(c[1]), "expired": int(c[2]), "ns_wait": int(c[3]), "ns_launch": int(c[4]), "ns_parse": int(c[5]),
                 "hosted": int(c[6]), "two_round": int(c[7]), "shadow_created": int(c[8]), "shadow_rounds": int(c[9]), "shadow_dropped": int(c[10]),
                 # host tail (abi_kernels.cpp): instances the host took over, round evaluations it answered, fold chains launched
-                "ht_started": int(c[11]), "ht_rounds": int(c[12]), "ht_flushed": int(c[13])}
+                "ht_started": int(c[11]), "ht_rounds": int(c[12]), "ht_flushed": int(c[13]), "ht_max": int(c[14])}
 
     # ---- ComputeLayer
     def copy_h2d(self, src, dst):

@@ -265,12 +265,12 @@ int host_tail_flush(bn_ctx *ctx, bool publish)
 	if (ht.n_levels) {
 		// the host copy's first n0 elements per array ARE the caller's buffers after the folds (the host folds in place exactly as
 		// the device would): into the pinned staging, then one launch maps them back to the tower basis and stores them
-		uint64_t *stg = (uint64_t *)ctx->h_tail + 2 * 512;
+		uint64_t *stg = (uint64_t *)ctx->h_tail + 2 * (2 * bn::kHtMaxM);
 		const uint32_t n0 = ht.chain.n0;
 		for (int j = 0; j < 2; j++) std::memcpy(stg + 2 * (size_t)n0 * j, ht.y[j].data(), (size_t)n0 * 16);
 		std::atomic_thread_fence(std::memory_order_seq_cst);
 		prof_scope ps(ctx, BN_PROF_FOLD);
-		BN_HIP(bn::launch_tail_writeback(ctx->stream, ht.chain, (const char *)ctx->d_tail + 512 * sizeof(f128), (const char *)ctx->d_phi + 512 * sizeof(f128)));
+		BN_HIP(bn::launch_tail_writeback(ctx->stream, ht.chain, (const char *)ctx->d_tail + 2 * bn::kHtMaxM * sizeof(f128), (const char *)ctx->d_phi + 512 * sizeof(f128)));
 		ctx->ht_flushed++;
 	}
 	if (publish && ht.cur_m == 1 && !ht.evaluated && ht.n_levels) {
@@ -309,7 +309,7 @@ bool host_tail_fold(bn_ctx *ctx, void *const *x0, const void *const *src0, const
 		if (x0[i] != src0[i] && ranges_overlap(x0[i], n, src0[i], n)) return false;
 	}
 	if (ht.n_levels == 0) {
-		if (n > 128) return false;
+		if (n > bn::kHtMaxM / 2) return false;
 		for (uint32_t i = 0; i < 2; i++) ht.chain.out[perm ? 1 - (int)i : (int)i] = x0[i];
 		ht.chain.n0 = (uint32_t)n;
 	}
@@ -603,14 +603,18 @@ int bn_ctx_create(int device, uint64_t arena_elems, bn_ctx **out)
 			std::vector<uint64_t> phi(2048);
 			bn::hostpoly_phi_nibble_table(phi.data());
 			bn::hostpoly_phi_inv_nibble_table(phi.data() + 1024);
-			BN_HIP(hipHostMalloc(&ctx->h_tail, 768 * sizeof(f128), hipHostMallocMapped | hipHostMallocCoherent));
+			BN_HIP(hipHostMalloc(&ctx->h_tail, 3 * bn::kHtMaxM * sizeof(f128), hipHostMallocMapped | hipHostMallocCoherent));
+			BN_HIP(hipMalloc((void **)&ctx->d_ht_tag, sizeof(uint64_t)));
+			BN_HIP(hipMemset(ctx->d_ht_tag, 0, sizeof(uint64_t)));
 			BN_HIP(hipHostGetDevicePointer(&ctx->d_tail, ctx->h_tail, 0));
 			BN_HIP(hipMalloc(&ctx->d_phi, 1024 * sizeof(f128)));
 			BN_HIP(hipMemcpy(ctx->d_phi, phi.data(), 1024 * sizeof(f128), hipMemcpyHostToDevice));
 			ctx->ht_enabled = true;
+			// (with the host's folds on VPCLMULQDQ, four products per instruction, 2^10 elements are taken over; else 2^8)
+			ctx->ht_max = bn::hostpoly_vectorized() ? 1024 : 256;
 			if (const char *l = getenv("BN_HOST_TAIL_MAX_LOG2")) {
 				const int v = atoi(l);
-				ctx->ht_max = (uint64_t)1 << (v < 2 ? 2 : (v > 8 ? 8 : v));
+				ctx->ht_max = (uint64_t)1 << (v < 2 ? 2 : (v > 12 ? 12 : v));
 			}
 		}
 	}
@@ -768,6 +772,7 @@ int bn_ctx_destroy(bn_ctx *ctx)
 	}
 	if (ctx->d_flag) hipFree(ctx->d_flag);
 	if (ctx->d_phi) hipFree(ctx->d_phi);
+	if (ctx->d_ht_tag) hipFree(ctx->d_ht_tag);
 	if (ctx->h_tail) hipHostFree(ctx->h_tail);
 	if (ctx->shadow.S) hipFree(ctx->shadow.S);
 	if (ctx->ntt_cache) {
@@ -1317,6 +1322,7 @@ int bn_arm_counters(bn_ctx *ctx, uint64_t *counters)
 	counters[BN_ARM_HT_STARTED] = ctx->ht_started;
 	counters[BN_ARM_HT_ROUNDS] = ctx->ht_rounds;
 	counters[BN_ARM_HT_FLUSHED] = ctx->ht_flushed;
+	counters[BN_ARM_HT_MAX] = ctx->ht_enabled ? ctx->ht_max : 0;
 	return BN_OK;
 }
 

@@ -137,7 +137,7 @@ bn::fin_fuse two_round_recipe(const bn::fin_fuse &fz)
 	return f8;
 }
 // ---- host tail ---------------------------------------------------------------------------------------------------------
-// A two-round launch whose Y is at most ht_max (<= 256) elements per array -- one workgroup -- also hands Y to the host,
+// A two-round launch whose Y is at most ht_max elements per array (2^10 when the host folds on VPCLMULQDQ, else 2^8) also hands Y to the host,
 // mapped into the power basis of hostmul_clmul.cpp by one more nibble-table product per element.  From then on the sumcheck
 // is host arithmetic: a fold of 2 x 128 elements is 0.9 us, a round evaluation over 128 points 0.8 us (the 256-bit
 // carry-less products are XORed unreduced, one reduction per sum), against ~10 us per round through the device.  The calls
@@ -173,6 +173,7 @@ void arm_two_round_next(bn_ctx *ctx, const two_round_req &rq, const bn::fin_fuse
 	if (host_tail_applies(ctx, rq.m >> 2, f8.peer.world)) {
 		fn.mirror = (f128 *)ctx->d_tail;
 		fn.phi_tab = (const uint4 *)ctx->d_phi;
+		fn.tag_acc = ctx->d_ht_tag;
 	}
 	bn::fin_fuse fzn = f8;
 	fzn.args.seq = f8.args.seq + 1;
@@ -317,10 +318,9 @@ int two_round_launch(bn_ctx *ctx, const two_round_req &rq, const bn::fin_fuse &f
 					const uint64_t lo = __atomic_load_n(&src[2 * (rq.m * j + i)], __ATOMIC_RELAXED), hi = __atomic_load_n(&src[2 * (rq.m * j + i) + 1], __ATOMIC_RELAXED);
 					ht.y[j][2 * i] = lo;
 					ht.y[j][2 * i + 1] = hi;
-					uint64_t h = (lo ^ ((rq.m * j + i + 1) * 0x9E3779B97F4A7C15ull)) * 0xBF58476D1CE4E5B9ull;
-					h ^= h >> 31;
-					h = (h ^ hi) * 0x94D049BB133111EBull;
-					t ^= h ^ (h >> 29);
+					const uint64_t idx = rq.m * j + i; // (the device's mirror_mix, kernels_foldeval8.hip)
+					const unsigned r1 = (unsigned)(idx & 63), r2 = (unsigned)((idx * 7 + 17) & 63);
+					t ^= ((lo << r1) | (r1 ? lo >> (64 - r1) : 0)) ^ ((hi << r2) | (r2 ? hi >> (64 - r2) : 0)) ^ (idx + 1) * 0x9E3779B97F4A7C15ull;
 				}
 			valid = t == want;
 		}
@@ -986,6 +986,7 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 											if (host_tail_applies(ctx, rq.m, fz.peer.world)) {
 												rq.fa.mirror = (f128 *)ctx->d_tail;
 												rq.fa.phi_tab = (const uint4 *)ctx->d_phi;
+													rq.fa.tag_acc = ctx->d_ht_tag;
 											}
 											return two_round_launch(ctx, rq, fz, h_values.data(), n_values, ret_values, n_ret, h_out, d_S + slot, t_enter);
 										}
@@ -1018,6 +1019,7 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 												if (host_tail_applies(ctx, n_next >> 1, fz_.peer.world)) {
 													f8a.mirror = (f128 *)ctx->d_tail;
 													f8a.phi_tab = (const uint4 *)ctx->d_phi;
+														f8a.tag_acc = ctx->d_ht_tag;
 												}
 												bn::fin_fuse fzn = two_round_recipe(fz_);
 												fzn.args.seq = fz_.args.seq + 1;
@@ -1261,6 +1263,7 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 									if (host_tail_applies(ctx, rq.m, fz.peer.world)) {
 										rq.fa.mirror = (f128 *)ctx->d_tail;
 										rq.fa.phi_tab = (const uint4 *)ctx->d_phi;
+													rq.fa.tag_acc = ctx->d_ht_tag;
 									}
 									return two_round_launch(ctx, rq, fz, h_values.data(), n_values, ret_values, n_ret, h_out, d_S + slot, t_enter);
 								}

@@ -73,6 +73,7 @@ struct hp128 {
 	uint64_t lo, hi;
 };
 bool hostpoly_available();
+bool hostpoly_vectorized(); // the folds and sums below run four elements per instruction (AVX-512 VPCLMULQDQ); BN_HOSTMUL_VECTOR=0: never
 hp128 hostpoly_from_tower(f128 v);
 f128 hostpoly_to_tower(hp128 v);
 hp128 hostpoly_mul(hp128 a, hp128 b);

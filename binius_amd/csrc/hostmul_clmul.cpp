@@ -21,6 +21,7 @@
 // report "not available" (hostmul.hpp then keeps the table form and the host tail stays off).
 #include <stdint.h>
 
+#include <cstdlib>
 #include <cstring>
 
 #include "hostmul.hpp"
@@ -241,6 +242,91 @@ BN_CLMUL_FN void round_sums_impl(const clmul_state &st, const hp128 *a, const hp
 	*y1 = hp128{r1.lo, r1.hi};
 	*yinf = hp128{ri.lo, ri.hi};
 }
+// ---- the same two loops four elements at a time on VPCLMULQDQ (AVX-512): per 128-bit lane exactly the arithmetic above
+#define BN_VCLMUL_FN __attribute__((target("avx512f,avx512bw,vpclmulqdq,pclmul,sse4.1")))
+BN_VCLMUL_FN inline void vclmul256(__m512i a, __m512i b, __m512i &lo, __m512i &hi)
+{
+	const __m512i p00 = _mm512_clmulepi64_epi128(a, b, 0x00), p11 = _mm512_clmulepi64_epi128(a, b, 0x11);
+	const __m512i mid = _mm512_xor_si512(_mm512_clmulepi64_epi128(a, b, 0x10), _mm512_clmulepi64_epi128(a, b, 0x01));
+	lo = _mm512_xor_si512(p00, _mm512_bslli_epi128(mid, 8));
+	hi = _mm512_xor_si512(p11, _mm512_bsrli_epi128(mid, 8));
+}
+BN_VCLMUL_FN inline __m512i vreduce256(__m512i L, __m512i H, __m512i mu0, __m512i m0)
+{
+	__m512i t_lo, t_hi;
+	vclmul256(H, mu0, t_lo, t_hi);
+	const __m512i q = _mm512_xor_si512(H, t_hi);
+	vclmul256(q, m0, t_lo, t_hi);
+	return _mm512_xor_si512(L, t_lo);
+}
+BN_VCLMUL_FN void fold_impl_v(const clmul_state &st, hp128 *x, size_t half, hp128 z)
+{
+	const __m512i zz = _mm512_broadcast_i32x4(_mm_set_epi64x((long long)z.hi, (long long)z.lo));
+	const __m512i mu0 = _mm512_broadcast_i32x4(_mm_set_epi64x((long long)st.mu0.hi, (long long)st.mu0.lo));
+	const __m512i m0 = _mm512_broadcast_i32x4(_mm_set_epi64x((long long)st.m0.hi, (long long)st.m0.lo));
+	size_t i = 0;
+	for (; i + 4 <= half; i += 4) {
+		const __m512i a = _mm512_loadu_si512((const void *)(x + i)), b = _mm512_loadu_si512((const void *)(x + i + half));
+		__m512i L, H;
+		vclmul256(zz, _mm512_xor_si512(a, b), L, H);
+		_mm512_storeu_si512((void *)(x + i), _mm512_xor_si512(a, vreduce256(L, H, mu0, m0)));
+	}
+	if (i < half) { // (half < 4, or a ragged end: the scalar form on what is left -- x[i + half] is addressed from the same base)
+		const u128 zs{z.lo, z.hi};
+		for (; i < half; i++) {
+			const u128 d = mul_poly(st, zs, u128{x[i].lo ^ x[i + half].lo, x[i].hi ^ x[i + half].hi});
+			x[i].lo ^= d.lo;
+			x[i].hi ^= d.hi;
+		}
+	}
+}
+BN_VCLMUL_FN inline u128 fold4(__m512i v) // XOR of the four 128-bit lanes
+{
+	alignas(64) uint64_t w[8];
+	_mm512_store_si512((void *)w, v);
+	return u128{w[0] ^ w[2] ^ w[4] ^ w[6], w[1] ^ w[3] ^ w[5] ^ w[7]};
+}
+BN_VCLMUL_FN void round_sums_impl_v(const clmul_state &st, const hp128 *a, const hp128 *b, size_t half, hp128 *y1, hp128 *yinf)
+{
+	__m512i L1 = _mm512_setzero_si512(), H1 = L1, Li = L1, Hi = L1;
+	size_t i = 0;
+	for (; i + 4 <= half; i += 4) {
+		const __m512i al = _mm512_loadu_si512((const void *)(a + i)), ah = _mm512_loadu_si512((const void *)(a + half + i));
+		const __m512i bl = _mm512_loadu_si512((const void *)(b + i)), bh = _mm512_loadu_si512((const void *)(b + half + i));
+		__m512i l, h;
+		vclmul256(ah, bh, l, h);
+		L1 = _mm512_xor_si512(L1, l);
+		H1 = _mm512_xor_si512(H1, h);
+		vclmul256(_mm512_xor_si512(al, ah), _mm512_xor_si512(bl, bh), l, h);
+		Li = _mm512_xor_si512(Li, l);
+		Hi = _mm512_xor_si512(Hi, h);
+	}
+	// the four lanes of every accumulator, then whatever is left of the range, then ONE reduction per sum
+	u128 l1 = fold4(L1), h1 = fold4(H1), li = fold4(Li), hi = fold4(Hi);
+	for (; i < half; i++) {
+		u128 l, h;
+		const u128 ahs{a[half + i].lo, a[half + i].hi}, bhs{b[half + i].lo, b[half + i].hi};
+		clmul256(ahs, bhs, l, h);
+		l1 = x128(l1, l);
+		h1 = x128(h1, h);
+		clmul256(u128{a[i].lo ^ ahs.lo, a[i].hi ^ ahs.hi}, u128{b[i].lo ^ bhs.lo, b[i].hi ^ bhs.hi}, l, h);
+		li = x128(li, l);
+		hi = x128(hi, h);
+	}
+	const u128 r1 = reduce256(st, l1, h1), ri = reduce256(st, li, hi);
+	*y1 = hp128{r1.lo, r1.hi};
+	*yinf = hp128{ri.lo, ri.hi};
+}
+bool have_vclmul()
+{
+	static const bool v = [] {
+		const char *e = getenv("BN_HOSTMUL_VECTOR");
+		if (e && e[0] == '0') return false;
+		return __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("vpclmulqdq");
+	}();
+	return v;
+}
+
 BN_CLMUL_FN hp128 mul_impl(const clmul_state &st, hp128 a, hp128 b)
 {
 	const u128 p = mul_poly(st, u128{a.lo, a.hi}, u128{b.lo, b.hi});
@@ -263,8 +349,21 @@ f128 hostpoly_to_tower(hp128 v)
 	return f128{p.lo, p.hi};
 }
 hp128 hostpoly_mul(hp128 a, hp128 b) { return mul_impl(state(), a, b); }
-void hostpoly_fold(hp128 *x, size_t half, hp128 z) { fold_impl(state(), x, half, z); }
-void hostpoly_round_sums(const hp128 *a, const hp128 *b, size_t half, hp128 *y1, hp128 *yinf) { round_sums_impl(state(), a, b, half, y1, yinf); }
+bool hostpoly_vectorized() { return state().ok && have_vclmul(); }
+void hostpoly_fold(hp128 *x, size_t half, hp128 z)
+{
+	if (half >= 4 && have_vclmul())
+		fold_impl_v(state(), x, half, z);
+	else
+		fold_impl(state(), x, half, z);
+}
+void hostpoly_round_sums(const hp128 *a, const hp128 *b, size_t half, hp128 *y1, hp128 *yinf)
+{
+	if (half >= 4 && have_vclmul())
+		round_sums_impl_v(state(), a, b, half, y1, yinf);
+	else
+		round_sums_impl(state(), a, b, half, y1, yinf);
+}
 void hostpoly_phi_nibble_table(uint64_t *out)
 {
 	// out[(16 p + e) * 2 ..] = Phi(e << 4 p): the layout of ctable.hpp's T (nibble position p, entry e)
@@ -296,6 +395,7 @@ namespace bn {
 bool hostmul_clmul_available() { return false; }
 f128 mul_host_clmul(f128 a, f128 b) { return mul_host_table(a, b); }
 bool hostpoly_available() { return false; }
+bool hostpoly_vectorized() { return false; }
 hp128 hostpoly_from_tower(f128 v) { return hp128{v.lo, v.hi}; }
 f128 hostpoly_to_tower(hp128 v) { return f128{v.lo, v.hi}; }
 hp128 hostpoly_mul(hp128 a, hp128) { return a; }

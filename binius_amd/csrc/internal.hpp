@@ -23,6 +23,7 @@ struct bn_expr {
 
 namespace bn {
 constexpr int kPeerMaxWorld = 16; // ranks of one node that can share a peer exchange (finalize.hpp)
+constexpr uint64_t kHtMaxM = 4096; // largest array (elements) a host tail can take over (abi_kernels.cpp)
 // What a host tail (abi_kernels.cpp) leaves for the device to catch up with: the host folded its copy of two small arrays in place
 // `levels` times; out[j][0 .. n0) -- where the FIRST of those folds wrote -- must end up holding what the host copy holds there.
 struct tail_writeback_args {
@@ -170,11 +171,12 @@ struct bn_ctx {
 		const void *cur_lo[2] = {}, *cur_hi[2] = {}; // device addresses of their halves: what the next calls must name
 		std::vector<uint64_t> y[2];    // the arrays in the power basis, 2 words per element
 	} ht;
-	void *h_tail = nullptr, *d_tail = nullptr; // pinned staging (host / device view): [0, 512) the kernel mirrors Y into, [512, 768) the host's folded copy for the write-back
+	void *h_tail = nullptr, *d_tail = nullptr; // pinned staging (host / device view): [0, 2 * kHtMaxM) the kernel mirrors Y into, then kHtMaxM elements of the host's folded copy for the write-back
+	uint64_t *d_ht_tag = nullptr;              // the tag accumulator of host-tail launches of several workgroups (zero between launches)
 	void *d_phi = nullptr;                     // nibble tables of the basis change and of its inverse (2 x 8 KiB of device memory)
 	bool ht_enabled = false;                   // BN_HOST_TAIL=0 turns it off; needs PCLMULQDQ on the host
 	bool ht_peer_ok = false;                   // bn_host_tail_allow_peer: the caller exchanges the host rounds' partials itself
-	uint64_t ht_max = 256;                     // largest Y (elements per array) the host takes over (BN_HOST_TAIL_MAX_LOG2, <= 8)
+	uint64_t ht_max = 256;                     // largest Y (elements per array) the host takes over (BN_HOST_TAIL_MAX_LOG2 <= 12; default 2^10 when the host folds on VPCLMULQDQ, else 2^8)
 	uint64_t ht_started = 0, ht_rounds = 0, ht_flushed = 0; // instances taken over, evaluations answered, chains launched
 	bool circuit_multipass = true; // BN_CIRCUIT_MULTIPASS=0: generic circuits stay on the scalar interpreter kernels (abi_circuit.cpp)
 	void *ntt_cache = nullptr; // bn::ntt_bs_cache (allocated on first use)
@@ -352,15 +354,17 @@ struct foldeval8_args {
 	uint32_t n_folds;
 	// host tail (abi_kernels.cpp): non-null -> Y is also handed to the host, mapped into the host's power basis on the way
 	// (mirror[arr * M + i] = Phi(Y_arr[i]), pinned host memory; phi_tab = the 512-entry nibble table of Phi in device
-	// memory, ctable.hpp layout).  Single-workgroup launches only (M <= 256).
+	// memory, ctable.hpp layout).  tag_acc: a zeroed 64-bit word of device memory in which the workgroups of a launch of several
+	// accumulate the staging's tag (the last one publishes and re-zeroes it); may be null for a single workgroup.
 	f128 *mirror;
 	const uint4 *phi_tab;
+	uint64_t *tag_acc;
 };
 hipError_t launch_foldeval8(hipStream_t s, const foldeval8_args &fa, f128 z1, f128 z2, f128 *d_out8, const fin_fuse *fuse,
                             const arm_args *armed = nullptr);
 // the last two folds of a sumcheck in one launch (4 n_out -> n_out elements per array, count * n_out <= 64), mirrored into
 // the mailbox like launch_fold_publish
-// the device catching up with a host tail: out[j][i] = PhiInv(staging[j * n0 + i]), i < n0 <= 128 -- the host's folded copy (power
+// the device catching up with a host tail: out[j][i] = PhiInv(staging[j * n0 + i]), i < n0 <= 2048 -- the host's folded copy (power
 // basis, pinned host memory) mapped back to the tower basis through the nibble table of the inverse basis change
 hipError_t launch_tail_writeback(hipStream_t s, const tail_writeback_args &a, const void *d_staging, const void *d_phi_inv);
 hipError_t launch_fold2_publish(hipStream_t s, void *const *out, const void *const *src0, const void *const *x1, uint32_t count, uint32_t n_out,

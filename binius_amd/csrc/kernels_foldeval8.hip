@@ -40,13 +40,12 @@ constexpr int kBlk = re9::kBlkQ;         // 9 uint4 per (limb, group) block of t
 constexpr int kZero8 = 8 * kG8;          // zero block index
 constexpr int kTile8 = (kZero8 + 1) * kBlk;
 
-// 64-bit mix of one mirrored element and its index (host tail; the host computes the same: abi_kernels.cpp mirror_mix)
+// tag contribution of one mirrored element (host tail; the host computes the same: abi_kernels.cpp): the two words rotated by
+// amounts that depend on the element's index, so that neither a stale element nor two swapped ones leave the XOR unchanged
 __device__ __forceinline__ uint64_t mirror_mix(uint64_t lo, uint64_t hi, uint64_t idx)
 {
-	uint64_t h = (lo ^ ((idx + 1) * 0x9E3779B97F4A7C15ull)) * 0xBF58476D1CE4E5B9ull;
-	h ^= h >> 31;
-	h = (h ^ hi) * 0x94D049BB133111EBull;
-	return h ^ (h >> 29);
+	const unsigned r1 = (unsigned)(idx & 63), r2 = (unsigned)((idx * 7 + 17) & 63);
+	return ((lo << r1) | (r1 ? lo >> (64 - r1) : 0)) ^ ((hi << r2) | (r2 ? hi >> (64 - r2) : 0)) ^ (idx + 1) * 0x9E3779B97F4A7C15ull;
 }
 
 struct lay8 {
@@ -131,7 +130,7 @@ __device__ __forceinline__ void eval_pair(const uint4 *stage, uint4 *wt, const l
 // Collapse, recombine the nine limb products per slot, XOR into out[0..8) (or keep them in LDS when the launch is a
 // single workgroup) and run the fused finalize in the last workgroup.  All 512 threads.
 __device__ __forceinline__ void tail8(const uint32_t (&acc)[32], const lay8 &lay, unsigned wave, unsigned lane, f128 *out, const fin_fuse &fz, uint64_t seq,
-                                      const fin_cache &fc)
+                                      const fin_cache &fc, uint64_t *tag_acc = nullptr)
 {
 	__shared__ uint32_t red[4][2][9][kG8];
 	__shared__ uint64_t wsum[4][4];
@@ -189,6 +188,13 @@ __device__ __forceinline__ void tail8(const uint32_t (&acc)[32], const lay8 &lay
 		}
 		__syncthreads();
 		if (is_last) {
+			if (tag_acc && threadIdx.x == 0) {
+				// a host-tail launch of several workgroups: every one of them XORed the tag of its part of the staging into
+				// tag_acc before it took its ticket; published here, by the lane that publishes the sequence word afterwards
+				const uint64_t t = __hip_atomic_load(tag_acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				__hip_atomic_store(&fc.mail[66].lo, t ^ seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+				__hip_atomic_store(tag_acc, (uint64_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
 			finalize_cached(fc, seq);
 			if (threadIdx.x == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
@@ -292,7 +298,10 @@ __global__ __launch_bounds__(512, 1) void k_foldeval8(foldeval8_args fa, f128 z1
 		uint64_t t = 0;
 #pragma unroll
 		for (int w = 0; w < 8; w++) t ^= mir_tag[w];
-		__hip_atomic_store(&fz.mail[66].lo, t ^ seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		if (gridDim.x == 1)
+			__hip_atomic_store(&fz.mail[66].lo, t ^ seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		else if (t)
+			atomicXor(reinterpret_cast<unsigned long long *>(fa.tag_acc), (unsigned long long)t); // (the last workgroup publishes: tail8)
 	}
 	BN_TS(3);
 	uint32_t acc[32];
@@ -306,7 +315,7 @@ __global__ __launch_bounds__(512, 1) void k_foldeval8(foldeval8_args fa, f128 z1
 		const unsigned l0 = wave == 1 ? 1u : 0u;
 		eval_pair(stage, tile[wave], lay, h0, wave == 3 ? 3 : -1, l0, wave == 3 ? 1 : -1, n_valid, acc);
 	}
-	tail8(acc, lay, wave, lane, out, fz, seq, fcache);
+	tail8(acc, lay, wave, lane, out, fz, seq, fcache, to_host && gridDim.x > 1 ? fa.tag_acc : nullptr);
 	BN_TS(8);
 }
 
@@ -321,7 +330,7 @@ hipError_t launch_foldeval8(hipStream_t s, const foldeval8_args &fa, f128 z1, f1
 	if (m < 4 || (m & 3) || (m << fa.n_folds) != fa.n_in) return hipErrorNotSupported;
 	const uint64_t q = m >> 2, blocks = (q + kPts - 1) / kPts;
 	if (blocks > 4096) return hipErrorNotSupported;
-	if (fa.mirror && (blocks != 1 || !fa.phi_tab)) return hipErrorNotSupported; // (the mirror's ordering argument is a single workgroup's)
+	if (fa.mirror && (!fa.phi_tab || (blocks > 1 && !fa.tag_acc))) return hipErrorNotSupported; // (several workgroups accumulate the staging's tag on the device)
 	arm_args arm{};
 	if (armed) arm = *armed;
 	fin_fuse fz{};

@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void k_ntt_bs_tail(const uint4 *__restrict__ b
 template <bool INV, bool CONV>
 __global__ __launch_bounds__(256, 2) void k_ntt_bs_pass(uint4 *__restrict__ bs, uint64_t S, uint32_t l_lo, uint32_t R, uint32_t n_lo,
                                                         const ntt_bs_tables *__restrict__ tb, uint32_t *__restrict__ data, uint32_t lx,
-                                                        uint32_t log_y)
+                                                        uint32_t log_y, uint32_t wg_bar)
 {
 	extern __shared__ __attribute__((aligned(16))) uint4 tile[]; // [512][kSetQ]
 	lds_vu4 *tile3 = (lds_vu4 *)(__attribute__((address_space(3))) void *)tile;
@@ -323,17 +323,16 @@ __global__ __launch_bounds__(256, 2) void k_ntt_bs_pass(uint4 *__restrict__ bs, 
 		// Who reads what this layer wrote?  The thread that handles set s at butterfly bit `pos` is s with that bit removed,
 		// so for pos <= 6 its wave is s >> 7 whatever pos is: between two layers whose butterfly bits are both <= 6 every set
 		// stays inside one wave, and the wave's own LDS operations are performed in order -- no workgroup barrier (the waves of
-		// a tile drift apart instead of waiting for the slowest after every layer).  BN_NTT_WG_BARRIERS (build flag): round 3's form.
+		// a tile drift apart instead of waiting for the slowest after every layer).  BN_NTT_WG_BARRIERS=1: round 3's form.
 		const int tn = tt + 1 < (int)R ? (INV ? tt + 1 : (int)R - 2 - tt) : -1;
 		const unsigned pos_next = tn >= 0 ? n_lo + (unsigned)tn : 99u;
-#ifndef BN_NTT_WG_BARRIERS
-		if (pos <= 6 && pos_next <= 6) {
+		if (!wg_bar && pos <= 6 && pos_next <= 6) {
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 			__builtin_amdgcn_wave_barrier();
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-		} else
-#endif
+		} else {
 			__syncthreads();
+		}
 	}
 	if (CONV && !INV) {
 		// plane sets -> elements
@@ -476,6 +475,8 @@ static hipError_t run_ntt_bs(hipStream_t s, void *data, const uint64_t *h_s_eval
 		return v ? (uint32_t)atoi(v) : 1u;
 	}();
 	const bool merged = !plan.empty() && lx <= merge_max_lx;
+	const char *wb = getenv("BN_NTT_WG_BARRIERS"); // (read per call: a measurement knob)
+	const uint32_t wg_bar = wb && wb[0] == '1' ? 1u : 0u;
 	const dim3 ht_grid((unsigned)(((S << lx) + 255) / 256), 1u << log_z);
 	if (!(INV && merged))
 		hipLaunchKernelGGL(k_ntt_bs_head<INV>, ht_grid, dim3(256), 0, s, (const uint32_t *)data, bs, S, lx, log_y, d_tb, n_top);
@@ -485,9 +486,9 @@ static hipError_t run_ntt_bs(hipStream_t s, void *data, const uint64_t *h_s_eval
 		const uint32_t n_lo = Q < l_lo ? Q : l_lo;
 		const dim3 grid((unsigned)(S >> kTileLog), n_batch);
 		if (l_lo == 0 && merged)
-			hipLaunchKernelGGL((k_ntt_bs_pass<INV, true>), grid, dim3(256), lds, s, bs, S, l_lo, R, n_lo, d_tb, (uint32_t *)data, lx, log_y);
+			hipLaunchKernelGGL((k_ntt_bs_pass<INV, true>), grid, dim3(256), lds, s, bs, S, l_lo, R, n_lo, d_tb, (uint32_t *)data, lx, log_y, wg_bar);
 		else
-			hipLaunchKernelGGL((k_ntt_bs_pass<INV, false>), grid, dim3(256), lds, s, bs, S, l_lo, R, n_lo, d_tb, (uint32_t *)data, lx, log_y);
+			hipLaunchKernelGGL((k_ntt_bs_pass<INV, false>), grid, dim3(256), lds, s, bs, S, l_lo, R, n_lo, d_tb, (uint32_t *)data, lx, log_y, wg_bar);
 	}
 	if (INV || !merged)
 		hipLaunchKernelGGL(k_ntt_bs_tail<INV>, ht_grid, dim3(256), 0, s, bs, (uint32_t *)data, S, lx, log_y, d_tb, n_top);

@@ -275,14 +275,15 @@ hipError_t launch_fold2_publish(hipStream_t s, void *const *out, const void *con
 // The device catching up with a host tail (abi_kernels.cpp): the host has folded its copy of the two arrays -- in the power basis of
 // hostmul_clmul.cpp -- and left it in pinned memory; out[j][i] = PhiInv(staging[j * n0 + i]) puts into the caller's buffers exactly what
 // the folds it asked for would have (field arithmetic is exact: the same element whichever basis the products were taken in).  One
-// workgroup, one element per thread, the inverse basis change as one nibble-table product; nobody waits for it.
+// element per thread, the inverse basis change as one nibble-table product; nobody waits for it.
 __global__ __launch_bounds__(256) void k_tail_writeback(tail_writeback_args a, const uint4 *__restrict__ staging, const uint4 *__restrict__ phi_inv)
 {
 	__shared__ uint4 T[512];
-	const unsigned tid = threadIdx.x, arr = tid >> 7, i = tid & 127;
-	const bool act = i < a.n0;
+	const unsigned tid = threadIdx.x, g = blockIdx.x * 256 + tid;
+	const bool act = g < 2 * a.n0;
+	const unsigned arr = g >= a.n0 ? 1 : 0, i = g - arr * a.n0;
 	uint4 v{0, 0, 0, 0};
-	if (act) v = staging[arr * a.n0 + i];
+	if (act) v = staging[g];
 	T[tid] = phi_inv[tid];
 	T[tid + 256] = phi_inv[tid + 256];
 	__syncthreads();
@@ -291,8 +292,8 @@ __global__ __launch_bounds__(256) void k_tail_writeback(tail_writeback_args a, c
 
 hipError_t launch_tail_writeback(hipStream_t s, const tail_writeback_args &a, const void *d_staging, const void *d_phi_inv)
 {
-	if (a.n0 == 0 || a.n0 > 128) return hipErrorNotSupported;
-	hipLaunchKernelGGL(k_tail_writeback, dim3(1), dim3(256), 0, s, a, (const uint4 *)d_staging, (const uint4 *)d_phi_inv);
+	if (a.n0 == 0 || a.n0 > kHtMaxM / 2) return hipErrorNotSupported;
+	hipLaunchKernelGGL(k_tail_writeback, dim3((2 * a.n0 + 255) / 256), dim3(256), 0, s, a, (const uint4 *)d_staging, (const uint4 *)d_phi_inv);
 	return hipGetLastError();
 }
 

@@ -89,7 +89,7 @@ pub struct bn_kop {
 }
 
 pub const BN_PROF_N: usize = 11;
-pub const BN_ARM_N: usize = 14;
+pub const BN_ARM_N: usize = 15;
 
 // ---- the old HAL (binius_hal::ComputationBackend) on device-resident multilinears
 pub const BN_ORDER_LOW_TO_HIGH: u32 = 0;

@@ -101,7 +101,7 @@ def test_two_round_launches_answer_two_rounds_each(hal_no_host_tail, oracle, n_v
 
 @pytest.mark.parametrize("n_vars", [2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 15, 16, 17])
 def test_host_tail_takes_the_last_rounds(hal, oracle, n_vars):
-    """The default: the first two-round launch whose Y has at most 2^8 elements per array hands Y to the host (in the host's
+    """The default: the first two-round launch whose Y has at most 2^10 (without VPCLMULQDQ on the host: 2^8) elements per array hands Y to the host (in the host's
     power basis), and every later evaluation and fold of the instance is host arithmetic -- no launch until the caller reads
     the final evaluations, when ONE launch performs all the outstanding folds on the device (csrc/abi_kernels.cpp "host
     tail").  Counted; every round's values against the oracle inside _drive, the final read included."""
@@ -109,8 +109,10 @@ def test_host_tail_takes_the_last_rounds(hal, oracle, n_vars):
     _drive(hal, oracle, n_vars, 0x2B3B0000 + 64 * n_vars)
     c1 = hal.arm_counters()
     d = {k: c1[k] - c0[k] for k in c1}
+    ht_log = c1["ht_max"].bit_length() - 1        # 10 when the host folds on VPCLMULQDQ, else 8 (BN_HOST_TAIL_MAX_LOG2 moves it)
+    assert ht_log >= 2 and ht_log % 2 == 0
     small = min(n_vars - n_vars % 2, 16)          # exponent of the first Y of the chain (even)
-    take = min(small, 8)                          # exponent of the Y the host takes over
+    take = min(small, ht_log)                     # exponent of the Y the host takes over
     launches = (small - take) // 2 + 1            # two-round launches: Y of 2^small, 2^(small-2), ..., 2^take
     assert d["two_round"] == launches and d["hosted"] == launches - 1, d
     assert d["ht_started"] == 1 and d["ht_flushed"] == 1, d
@@ -233,3 +235,28 @@ def test_compiled_prover_same_transcript_with_and_without_two_round_launches(ora
         assert seen["1"]["ht_started"] == 2 and seen["1"]["ht_flushed"] == 2 and seen["1"]["two_round"] > 0
     else:
         assert seen["1"]["ht_started"] == 0
+
+
+@pytest.mark.parametrize("ht_log,vector", [(4, "1"), (6, "1"), (8, "0"), (10, "1"), (10, "0"), (12, "1")])
+def test_host_tail_at_other_hand_over_sizes(oracle, monkeypatch, ht_log, vector):
+    """The hand-over size is a knob (BN_HOST_TAIL_MAX_LOG2): 2^10 and 2^12 elements are handed over by 4 and 16 workgroups (the
+    staging's tag is accumulated on the device and published by the last one), 2^4 by a nearly empty one; the host folds and sums
+    on VPCLMULQDQ when it has it (BN_HOSTMUL_VECTOR=0: the scalar PCLMULQDQ loops).  Same values, same memory, whatever the setting."""
+    import binius_amd
+
+    monkeypatch.setenv("BN_HOST_TAIL_MAX_LOG2", str(ht_log))
+    monkeypatch.setenv("BN_HOSTMUL_VECTOR", vector)
+    with binius_amd.Context(0, 1 << 21) as ctx:
+        assert ctx.arm_counters()["ht_max"] == 1 << ht_log
+        for n_vars in (5, 10, 13, 14, 17):
+            model = []
+
+            def check(r, d, full, model=model):
+                if r in (n_vars - 3, n_vars - 6):  # a read in the middle of the host rounds: the write-back must leave eager memory
+                    for j, buf in enumerate(full):
+                        assert np.array_equal(ctx.copy_d2h(buf), model[j]), (ht_log, n_vars, r, j)
+
+            c0 = ctx.arm_counters()
+            _drive(ctx, oracle, n_vars, 0x2B4B0000 + 1024 * ht_log + n_vars, after_fold=check, model=model)
+            c1 = ctx.arm_counters()
+            assert c1["ht_started"] > c0["ht_started"], (ht_log, n_vars)

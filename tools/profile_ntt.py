@@ -32,6 +32,17 @@ else:
 hal.copy_bytes_h2d(data, d.ptr)
 hal.ntt_forward(d.ptr, a.elem_level, 5, s, a.log_n, 0, a.log_n, 0)
 hal.sync()
+if os.environ.get("BN_NTT_AB"):
+    # A/B of the barrier forms on this box, alternating (BN_NTT_WG_BARRIERS is read per call)
+    for rep in range(6):
+        for mode in ("1", "0"):
+            os.environ["BN_NTT_WG_BARRIERS"] = mode
+            hal.copy_bytes_h2d(data, d.ptr)
+            hal.sync()
+            hal.prof_begin()
+            hal.ntt_forward(d.ptr, a.elem_level, 5, s, a.log_n, 0, a.log_n, 0)
+            print("BN_NTT_WG_BARRIERS=%s: %.4f ms" % (mode, hal.prof_end()["ntt"][0]))
+    os.environ.pop("BN_NTT_WG_BARRIERS", None)
 for _ in range(a.reps):
     hal.copy_bytes_h2d(data, d.ptr)
     hal.sync()
