@@ -137,7 +137,7 @@ bn::fin_fuse two_round_recipe(const bn::fin_fuse &fz)
 	return f8;
 }
 // ---- host tail ---------------------------------------------------------------------------------------------------------
-// A two-round launch whose Y is at most ht_max elements per array (2^10 when the host folds on VPCLMULQDQ, else 2^8) also hands Y to the host,
+// A two-round launch whose Y is at most ht_max elements per array (2^12 when the host folds on VPCLMULQDQ, else 2^8) also hands Y to the host,
 // mapped into the power basis of hostmul_clmul.cpp by one more nibble-table product per element.  From then on the sumcheck
 // is host arithmetic: a fold of 2 x 128 elements is 0.9 us, a round evaluation over 128 points 0.8 us (the 256-bit
 // carry-less products are XORed unreduced, one reduction per sum), against ~10 us per round through the device.  The calls

@@ -176,7 +176,7 @@ struct bn_ctx {
 	void *d_phi = nullptr;                     // nibble tables of the basis change and of its inverse (2 x 8 KiB of device memory)
 	bool ht_enabled = false;                   // BN_HOST_TAIL=0 turns it off; needs PCLMULQDQ on the host
 	bool ht_peer_ok = false;                   // bn_host_tail_allow_peer: the caller exchanges the host rounds' partials itself
-	uint64_t ht_max = 256;                     // largest Y (elements per array) the host takes over (BN_HOST_TAIL_MAX_LOG2 <= 12; default 2^10 when the host folds on VPCLMULQDQ, else 2^8)
+	uint64_t ht_max = 256;                     // largest Y (elements per array) the host takes over (BN_HOST_TAIL_MAX_LOG2 <= 12; default 2^12 when the host folds on VPCLMULQDQ, else 2^8)
 	uint64_t ht_started = 0, ht_rounds = 0, ht_flushed = 0; // instances taken over, evaluations answered, chains launched
 	bool circuit_multipass = true; // BN_CIRCUIT_MULTIPASS=0: generic circuits stay on the scalar interpreter kernels (abi_circuit.cpp)
 	void *ntt_cache = nullptr; // bn::ntt_bs_cache (allocated on first use)

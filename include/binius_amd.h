@@ -277,7 +277,7 @@ int bn_peer_create(bn_ctx *ctx, uint32_t world, uint32_t rank, uint8_t *handle_o
 int bn_peer_connect(bn_ctx *ctx, const uint8_t *handles /*[world][BN_PEER_HANDLE_BYTES]*/);
 int bn_peer_set_active(bn_ctx *ctx, int on);
 int bn_peer_stats(bn_ctx *ctx, uint64_t *stats /*[2]*/);
-/* The host tail under a peer exchange (sharded sumcheck): once the arrays of a shard are down to <= 2^10 (2^8) elements the library
+/* The host tail under a peer exchange (sharded sumcheck): once the arrays of a shard are down to <= 2^12 (2^8) elements the library
  * takes the remaining rounds onto the host (BN_ARM_HT_*), where the ranks' partial sums cannot meet on the devices any more.
  * A caller that exchanges the partials of those rounds ITSELF (host shared memory: binius_amd/host/host_capi.cpp) says so with
  * bn_host_tail_allow_peer(ctx, 1); after every reduced launch it asks bn_host_tail_active, and from the launch that answers 1 on
@@ -328,10 +328,10 @@ int bn_prof_end(bn_ctx *ctx, double *ms_by_class /*[BN_PROF_N]*/, uint64_t *laun
  * because the next call was something else, armed kernels that gave up waiting; host nanoseconds between handing over
  * a challenge and seeing the round's result, the part of that spent enqueueing the next armed kernel, and the time from
  * the entry of bn_kernel_launch to handing the challenge over (validation + recognising the round).
- * BN_ARM_HT_*: the host tail -- once the arrays of a bivariate sumcheck are down to <= 2^10 (2^8) elements the two-round kernel
+ * BN_ARM_HT_*: the host tail -- once the arrays of a bivariate sumcheck are down to <= 2^12 (2^8) elements the two-round kernel
  * hands them to the host and the remaining evaluations and folds are host arithmetic (PCLMULQDQ in an isomorphic power
  * basis), the device catching up with one launch; instances taken over, evaluations answered, catch-up launches, and (not a
- * counter) the largest array the host takes over: 2^10 elements when the host has VPCLMULQDQ (four products per instruction),
+ * counter) the largest array the host takes over: 2^12 elements when the host has VPCLMULQDQ (four products per instruction),
  * else 2^8; 0 when the host tail is off.  BN_HOST_TAIL=0 turns it off.  Like arming, an execution detail of the unchanged call
  * sequence. */
 enum { BN_ARM_HITS = 0, BN_ARM_CANCELS = 1, BN_ARM_EXPIRED = 2, BN_ARM_NS_WAIT = 3, BN_ARM_NS_LAUNCH = 4, BN_ARM_NS_PARSE = 5, BN_ARM_HOSTED = 6, BN_ARM_TWO_ROUND = 7, BN_ARM_SHADOW_CREATED = 8, BN_ARM_SHADOW_ROUNDS = 9, BN_ARM_SHADOW_DROPPED = 10, BN_ARM_HT_STARTED = 11, BN_ARM_HT_ROUNDS = 12, BN_ARM_HT_FLUSHED = 13, BN_ARM_HT_MAX = 14, BN_ARM_N = 15 };

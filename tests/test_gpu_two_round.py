@@ -101,7 +101,7 @@ def test_two_round_launches_answer_two_rounds_each(hal_no_host_tail, oracle, n_v
 
 @pytest.mark.parametrize("n_vars", [2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 15, 16, 17])
 def test_host_tail_takes_the_last_rounds(hal, oracle, n_vars):
-    """The default: the first two-round launch whose Y has at most 2^10 (without VPCLMULQDQ on the host: 2^8) elements per array hands Y to the host (in the host's
+    """The default: the first two-round launch whose Y has at most 2^12 (without VPCLMULQDQ on the host: 2^8) elements per array hands Y to the host (in the host's
     power basis), and every later evaluation and fold of the instance is host arithmetic -- no launch until the caller reads
     the final evaluations, when ONE launch performs all the outstanding folds on the device (csrc/abi_kernels.cpp "host
     tail").  Counted; every round's values against the oracle inside _drive, the final read included."""
@@ -109,7 +109,7 @@ def test_host_tail_takes_the_last_rounds(hal, oracle, n_vars):
     _drive(hal, oracle, n_vars, 0x2B3B0000 + 64 * n_vars)
     c1 = hal.arm_counters()
     d = {k: c1[k] - c0[k] for k in c1}
-    ht_log = c1["ht_max"].bit_length() - 1        # 10 when the host folds on VPCLMULQDQ, else 8 (BN_HOST_TAIL_MAX_LOG2 moves it)
+    ht_log = c1["ht_max"].bit_length() - 1        # 12 when the host folds on VPCLMULQDQ, else 8 (BN_HOST_TAIL_MAX_LOG2 moves it)
     assert ht_log >= 2 and ht_log % 2 == 0
     small = min(n_vars - n_vars % 2, 16)          # exponent of the first Y of the chain (even)
     take = min(small, ht_log)                     # exponent of the Y the host takes over
