@@ -825,6 +825,35 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 									fz.peer.stress = ctx->peer.stress;
 								}
 								hipError_t fe = hipErrorNotSupported;
+								// ---- a host tail can also START here, without a kernel: the arrays of this evaluation lie in the context's own pinned
+								// scratch (bn_host_scratch: host memory the device reads through a mapping -- the residual instance of the sharded
+								// prover, a handful of elements the ranks have just exchanged on the host), the library reads them where they are
+								if (!ctx->ht.active && host_tail_applies(ctx, 2 * row_len, peer_on ? ctx->peer.world : 1) && k == 2 && !peer_on && h_out && !d_out && !ctx->pend.active &&
+								    lo[0] && lo[1] && lo[0] != lo[1] && !out_scaled && two_round_recipe_ok(fz) && ctx->pend_copies.empty()) {
+									const char *d0 = (const char *)(ctx->d_mail + 96), *d1 = d0 + 32 * sizeof(f128);
+									auto inside = [&](const void *p) { return (const char *)p >= d0 && (const char *)p + row_len * sizeof(f128) <= d1; };
+									if (inside(lo[0]) && inside(hi[0]) && inside(lo[1]) && inside(hi[1]) && hipStreamSynchronize(s) == hipSuccess) { // (nothing enqueued is still writing there: microseconds, against three device round trips)
+										bn_ctx::host_tail_state &ht = ctx->ht;
+										auto host_view = [&](const void *p) { return (const f128 *)((const char *)(ctx->h_mail + 96) + ((const char *)p - d0)); };
+										for (int j = 0; j < 2; j++) {
+											ht.y[j].resize(4 * row_len);
+											for (uint64_t i = 0; i < row_len; i++) {
+												const bn::hp128 a = bn::hostpoly_from_tower(host_view(lo[j])[i]), b = bn::hostpoly_from_tower(host_view(hi[j])[i]);
+												ht.y[j][2 * i] = a.lo;
+												ht.y[j][2 * i + 1] = a.hi;
+												ht.y[j][2 * (row_len + i)] = b.lo;
+												ht.y[j][2 * (row_len + i) + 1] = b.hi;
+											}
+											ht.cur_lo[j] = lo[j];
+											ht.cur_hi[j] = hi[j];
+										}
+										ht.cur_m = 2 * row_len;
+										ht.n_levels = 0;
+										ht.evaluated = false;
+										ht.active = true;
+										ctx->ht_started++;
+									}
+								}
 								// ---- host tail: the halves of exactly the arrays the host holds -- answered here, no launch
 								if (ctx->ht.active) {
 									bn_ctx::host_tail_state &ht = ctx->ht;
