@@ -86,7 +86,7 @@ def _worker(rank, world, port, n_global, m, comps, q, exchange="shm"):
         plan.run()  # a second run from the same inputs: the prover must not have modified them
         q.put((rank, sums, first[0], first[1], (plan.round_coeffs(), plan.final_evals()) == first))
         c = hal.arm_counters()
-        if c["ht_max"] and n_local >= 2:
+        if c["ht_max"] and n_local >= 2 and len(comps) == 1 and m == 2:
             # the host tail took the last local rounds of both runs -- under the peer exchange too, the host rounds'
             # partials going through the shared-memory segment -- and, from four ranks on, the residual rounds as well (their
             # instance lies in the context's pinned scratch: no kernel at all)
