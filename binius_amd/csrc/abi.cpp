@@ -1200,8 +1200,16 @@ int bn_extrapolate_line_batch_scaled(bn_ctx *ctx, void *const *d_evals_0, const 
 			for (uint32_t i = 0; i < count; i++) src0[i] = d_evals_0[i];
 		}
 	}
-	if (ctx->ht.active && host_tail_fold(ctx, d_evals_0, src0, d_evals_1, count, n, scale_mask, to_f(z)))
-		return BN_OK; // (performed on the host's copy; the device catches up in one launch, host_tail_flush)
+	if (ctx->ht.active) {
+		// (deferred copies the batch did not absorb -- possible only while the device is still in step with the host copy --
+		// were issued BEFORE this fold and may read what its write-back will overwrite: they run now, in issue order)
+		if (!ctx->pend_copies.empty()) {
+			int rc_c = flush_copies(ctx);
+			if (rc_c) return rc_c;
+		}
+		if (host_tail_fold(ctx, d_evals_0, src0, d_evals_1, count, n, scale_mask, to_f(z)))
+			return BN_OK; // (performed on the host's copy; the device catches up in one launch, host_tail_flush)
+	}
 	{
 		// a resident tail kernel survives this call only if the batch is the fold it is parked for
 		bool keep_tail = false;

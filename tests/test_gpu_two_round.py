@@ -260,3 +260,31 @@ def test_host_tail_at_other_hand_over_sizes(oracle, monkeypatch, ht_log, vector)
             _drive(ctx, oracle, n_vars, 0x2B4B0000 + 1024 * ht_log + n_vars, after_fold=check, model=model)
             c1 = ctx.arm_counters()
             assert c1["ht_started"] > c0["ht_started"], (ht_log, n_vars)
+
+
+@pytest.mark.parametrize("n_vars", [9, 12, 14])
+def test_deferred_copies_and_the_host_tail_keep_their_order(hal, oracle, n_vars):
+    """A copy_d2d OUT of the arrays between an evaluation and their fold is deferred (it may be the "copy evals_0 into a fresh
+    buffer" of a first fold); when the fold that follows is performed on the host copy, the copy must still read what the arrays
+    held BEFORE the fold -- not what the host tail's write-back leaves there later (found by the differential fuzz at the 2^12
+    hand-over: the write-back used to be enqueued ahead of the unabsorbed copies)."""
+    alloc_spare = hal.dev_alloc()
+    alloc_spare.alloc(4 << n_vars)  # (every dev_alloc() starts at the arena's base: stay clear of the arrays _drive allocates)
+    spare = alloc_spare.alloc(1 << n_vars)
+    expect = {}
+
+    def after_eval(r, d, full):
+        if r >= 1 and r % 2 == 1 and d[0].len >= 4:
+            half = d[0].len // 2
+            hal.copy_d2d(d[0].slice(0, half), spare.slice(0, half))
+            expect["n"] = half
+            expect["want"] = hal_model[0][:half].copy()
+
+    def after_fold(r, d, full):
+        if "want" in expect:
+            got = hal.copy_d2h(spare.slice(0, expect["n"]))
+            assert np.array_equal(got, expect.pop("want")), r
+
+    hal_model = []
+    # (_drive folds `model` in place like the device: model[0][:len] is array 0 before the fold when after_eval runs)
+    _drive(hal, oracle, n_vars, 0x2B5B0000 + n_vars, after_eval=after_eval, after_fold=after_fold, model=hal_model)
