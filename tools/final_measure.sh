@@ -12,14 +12,14 @@ tools/pmc_bench.sh $BUILD 28 24 > $O/pmc_bench.log 2>&1
 cp $R/gpurun_out/bench_pmc.json $O/bench_pmc.json
 mkdir -p $R/profiles/r04; cp $R/gpurun_out/bench_pmc.json $R/profiles/r04/bench_pmc.json
 python bench.py > $O/bench_n28.json 2> $O/bench_n28.stderr
-python bench.py --n-vars 24 --steps 5 --warmup 2 > $O/bench_n24.json 2> $O/bench_n24.stderr
-python bench.py --n-vars 25 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_n25_one_shard_of_eight.json 2>/dev/null
+python bench.py --n-vars 24 --steps 20 --warmup 3 > $O/bench_n24.json 2> $O/bench_n24.stderr
+python bench.py --n-vars 25 --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_n25_one_shard_of_eight.json 2>/dev/null
 python bench.py --n-vars 20 --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_n20.json 2>/dev/null
-BN_HOST_TAIL=0 python bench.py --n-vars 24 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_n24_BN_HOST_TAIL_0.json 2>/dev/null
-BN_HOST_TAIL=0 python bench.py --n-vars 25 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_n25_BN_HOST_TAIL_0.json 2>/dev/null
+BN_HOST_TAIL=0 python bench.py --n-vars 24 --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_n24_BN_HOST_TAIL_0.json 2>/dev/null
+BN_HOST_TAIL=0 python bench.py --n-vars 25 --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_n25_BN_HOST_TAIL_0.json 2>/dev/null
 BN_HOST_TAIL=0 python bench.py --n-vars 20 --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_n20_BN_HOST_TAIL_0.json 2>/dev/null
-BN_TWO_ROUND=0 python bench.py --n-vars 24 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_n24_BN_TWO_ROUND_0.json 2>/dev/null
-BN_TWO_ROUND=0 python bench.py --n-vars 25 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_n25_BN_TWO_ROUND_0.json 2>/dev/null
+BN_TWO_ROUND=0 python bench.py --n-vars 24 --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_n24_BN_TWO_ROUND_0.json 2>/dev/null
+BN_TWO_ROUND=0 python bench.py --n-vars 25 --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_n25_BN_TWO_ROUND_0.json 2>/dev/null
 python tools/bench_ops.py > $O/ops.jsonl 2>&1
 tools/bench_mlecheck_quick.sh > $O/mlecheck_prover.jsonl 2>&1
 BN_MLECHECK_SHADOW=0 tools/bench_mlecheck_quick.sh > $O/mlecheck_prover_BN_MLECHECK_SHADOW_0.jsonl 2>&1
