@@ -251,9 +251,15 @@ int two_round_launch(bn_ctx *ctx, const two_round_req &rq, const bn::fin_fuse &f
 					}
 				}
 				if (spins > (1ull << 26)) {
-					arm_cancel(ctx);
+					// slow rather than dead (ranks that share one device under a stress mode, a profiler): let the stream drain --
+					// the kernel queued behind this one leaves by its own bounded spin -- and look once more before giving up
 					BN_HIP(hipStreamSynchronize(s));
-					return bn::fail(BN_ERR_DEVICE, "device error: armed round kernel stopped answering");
+					got = __atomic_load_n(seqw, __ATOMIC_ACQUIRE) == f8.args.seq;
+					if (!got && __atomic_load_n(arm_status(ctx), __ATOMIC_ACQUIRE) != id) {
+						arm_cancel(ctx);
+						return bn::fail(BN_ERR_DEVICE, "device error: armed round kernel stopped answering");
+					}
+					break;
 				}
 			}
 			if (got) {
@@ -1160,9 +1166,16 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 														}
 													}
 													if (spins > (1ull << 26)) {
-														arm_cancel(ctx);
+														// slow rather than dead (ranks that share one device under a stress mode, a profiler): let the
+														// stream drain -- the kernel queued behind this one leaves by its own bounded spin -- and look
+														// once more before giving up
 														BN_HIP(hipStreamSynchronize(s));
-														return bn::fail(BN_ERR_DEVICE, "device error: armed round kernel stopped answering");
+														got = __atomic_load_n(seqw, __ATOMIC_ACQUIRE) == fz.args.seq;
+														if (!got && __atomic_load_n(arm_status(ctx), __ATOMIC_ACQUIRE) != id) {
+															arm_cancel(ctx);
+															return bn::fail(BN_ERR_DEVICE, "device error: armed round kernel stopped answering");
+														}
+														break;
 													}
 												}
 												if (got) {

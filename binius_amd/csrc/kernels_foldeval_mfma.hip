@@ -30,9 +30,46 @@ namespace bn {
 
 using namespace gram;
 
+// FE_ABL (measurement builds of tools/gram_bench.hip only; the library is built with 0): bit 0 = no Gram k-steps, bit 1 = the fold
+// without its constant multiplication, bit 2 / 3 = non-temporal loads / stores, bit 4 = no staging of the folded registers,
+// bit 5 = no workgroup barrier per tile (only with bits 0 and 4).  What the memory system gives the kernel's access pattern
+// with the arithmetic taken out piece by piece (tools/r04_fe_ablation.sh).
+#ifndef FE_ABL
+#define FE_ABL 0
+#endif
+typedef unsigned int fe_v4u __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ uint4 fe_load(const uint4 *p)
+{
+	if constexpr (NT || (FE_ABL & 4) != 0) {
+		const fe_v4u v = __builtin_nontemporal_load(reinterpret_cast<const fe_v4u *>(p));
+		return uint4{v.x, v.y, v.z, v.w};
+	} else {
+		return *p;
+	}
+}
+template <bool NT>
+__device__ __forceinline__ void fe_store(uint4 *p, uint4 r)
+{
+	if constexpr (NT || (FE_ABL & 8) != 0) {
+		const fe_v4u v = {r.x, r.y, r.z, r.w};
+		__builtin_nontemporal_store(v, reinterpret_cast<fe_v4u *>(p));
+	} else {
+		*p = r;
+	}
+}
+
 // SC: 0 = plain fold; 1 / 2 = the upper half of folded array 0 / 1 is multiplied by fa.hi_scale (a fifth constant
 // multiplication per point, through a second nibble table) before it is stored and staged.
-template <int SC>
+// FULL: the number of evaluation points is a multiple of the tile (every size a prover reaches this kernel with): no lane is ever
+// past the end, so the stores are unconditional.  This is not cosmetic: behind a conditional block of stores the compiler's wait
+// for a quadrant's loads has to hold on the path that skipped the stores as well -- `s_waitcnt vmcnt(6)` where the path with the
+// stores allows vmcnt(10) --, and a wave then waits for the loads of the next TWO quadrants too, issued half an iteration ago
+// instead of a whole one.
+// NT: non-temporal loads and stores -- the arrays of an HBM-resident round are touched once per launch, and marking the accesses
+// as streaming is worth 2 % there (profiles/r04/fe_full_nt.txt); the cache-resident rounds keep the plain accesses (the folded
+// halves ARE the next round's input).
+template <int SC, bool FULL, bool NT>
 __global__ __launch_bounds__(256, 2) void k_foldeval_mfma(foldeval_args fa, uint64_t n_in, f128 z, f128 *out, fin_fuse fz, arm_args arm)
 {
 	__shared__ __attribute__((aligned(16))) uint32_t T[2][kTileW];
@@ -70,9 +107,9 @@ __global__ __launch_bounds__(256, 2) void k_foldeval_mfma(foldeval_args fa, uint
 	}
 	auto load1 = [&](uint64_t t, int k) {
 		const uint64_t pt = (tbase + t) * kTP + threadIdx.x;
-		const uint64_t e = (k & 1 ? n : 0) + (pt < n ? pt : 0);
-		x0[k] = ((const uint4 *)fa.x0[k >> 1])[e];
-		x1[k] = ((const uint4 *)fa.x1[k >> 1])[e];
+		const uint64_t e = (k & 1 ? n : 0) + (FULL || pt < n ? pt : 0);
+		x0[k] = fe_load<NT>((const uint4 *)fa.x0[k >> 1] + e);
+		x1[k] = fe_load<NT>((const uint4 *)fa.x1[k >> 1] + e);
 	};
 	auto load = [&](uint64_t t) {
 #pragma unroll
@@ -104,9 +141,9 @@ __global__ __launch_bounds__(256, 2) void k_foldeval_mfma(foldeval_args fa, uint
 	// tile (in Tp) between the four constant multiplications (matrix pipe); the folded registers go to HBM
 	// and, byte-transposed, into the Gram tile Tn.
 	auto iteration = [&](uint64_t tt, const uint32_t *Tp, uint32_t *Tn, auto with_gram) {
-		constexpr bool GRAM = decltype(with_gram)::value;
+		constexpr bool GRAM = decltype(with_gram)::value && !(FE_ABL & 1);
 		const uint64_t pt = (tbase + tt) * kTP + threadIdx.x;
-		const bool ok = pt < n;
+		const bool ok = FULL || pt < n;
 		// the last iteration re-requests its own tile (cache hits) instead of branching around the loads
 		const uint64_t tn = tt + tstride < tlimit ? tt + tstride : tt;
 		gram_pipe gp;
@@ -120,7 +157,9 @@ __global__ __launch_bounds__(256, 2) void k_foldeval_mfma(foldeval_args fa, uint
 #ifndef FE_VARIANT
 #define FE_VARIANT 7
 #endif
-#if FE_VARIANT == 0
+#if FE_ABL & 2
+#define FE_FOLD(k) xor4(x0[k], x1[k])
+#elif FE_VARIANT == 0
 #define FE_FOLD(k) xor4(x0[k], ctable_mul_pinned<4>(tab, xor4(x0[k], x1[k])))
 #else
 #define FE_FOLD(k) ctable_mul_acc<(FE_VARIANT & 4) ? 8 : 4, (FE_VARIANT & 2) != 0>(tab, xor4(x0[k], x1[k]), x0[k])
@@ -154,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void k_foldeval_mfma(foldeval_args fa, uint
 		if (ok) {
 #pragma unroll
 			for (int k = 0; k < 4; k++)
-				((uint4 *)fa.out[k >> 1])[(k & 1 ? n : 0) + pt] = f[k];
+				fe_store<NT>((uint4 *)fa.out[k >> 1] + ((k & 1 ? n : 0) + pt), f[k]);
 		} else {
 #pragma unroll
 			for (int k = 0; k < 4; k++)
@@ -162,9 +201,11 @@ __global__ __launch_bounds__(256, 2) void k_foldeval_mfma(foldeval_args fa, uint
 		}
 		// quadrant 2 * array + half: half 1 is the evaluation at 1, half 0 its partner; points past the
 		// end carry zeros
-		stage_T<true>(Tn, sr, 0, f[1], f[0]);
-		stage_T<true>(Tn, sr, 1, f[3], f[2]);
-		__syncthreads();
+		if constexpr (!(FE_ABL & 16)) {
+			stage_T<true>(Tn, sr, 0, f[1], f[0]);
+			stage_T<true>(Tn, sr, 1, f[3], f[2]);
+		}
+		if constexpr (!(FE_ABL & 32)) __syncthreads();
 	};
 	if (t < tlimit) {
 		unsigned buf = 0;
@@ -175,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void k_foldeval_mfma(foldeval_args fa, uint
 			buf ^= 1;
 		}
 		BN_TS(4);
-		gram_tile(T[buf], gr, acc);
+		if constexpr (!(FE_ABL & 1)) gram_tile(T[buf], gr, acc);
 	}
 	BN_TS(5);
 	gram::tail(acc, wave, lane, out, fz, seq, &fcache);
@@ -201,12 +242,27 @@ hipError_t launch_foldeval_mfma(hipStream_t s, int n_cu, const foldeval_args &fa
 	}();
 	foldeval_args fx = fa;
 	fx.xcd_tiles = xcd_tiles;
+	const bool full = ((n_in >> 2) % kTP) == 0;
+	// BN_FE_NT_MIN_LOG2: elements per array from which the accesses are non-temporal (measurement knob; 64 = never)
+	static const int nt_min_log2 = [] {
+		const char *e = getenv("BN_FE_NT_MIN_LOG2");
+		return e ? atoi(e) : 25;
+	}();
+	const bool nt = full && nt_min_log2 < 64 && n_in >= (1ull << nt_min_log2);
+#define BN_FE_LAUNCH(SC)                                                                                                       \
+	if (nt)                                                                                                                    \
+		hipLaunchKernelGGL((k_foldeval_mfma<SC, true, true>), grid, dim3(256), 0, s, fx, n_in, z, d_out, fz, arm);             \
+	else if (full)                                                                                                             \
+		hipLaunchKernelGGL((k_foldeval_mfma<SC, true, false>), grid, dim3(256), 0, s, fx, n_in, z, d_out, fz, arm);            \
+	else                                                                                                                       \
+		hipLaunchKernelGGL((k_foldeval_mfma<SC, false, false>), grid, dim3(256), 0, s, fx, n_in, z, d_out, fz, arm);
 	switch (fa.scale_mask) {
-	case 0: hipLaunchKernelGGL(k_foldeval_mfma<0>, grid, dim3(256), 0, s, fx, n_in, z, d_out, fz, arm); break;
-	case 1: hipLaunchKernelGGL(k_foldeval_mfma<1>, grid, dim3(256), 0, s, fx, n_in, z, d_out, fz, arm); break;
-	case 2: hipLaunchKernelGGL(k_foldeval_mfma<2>, grid, dim3(256), 0, s, fx, n_in, z, d_out, fz, arm); break;
+	case 0: BN_FE_LAUNCH(0) break;
+	case 1: BN_FE_LAUNCH(1) break;
+	case 2: BN_FE_LAUNCH(2) break;
 	default: return hipErrorNotSupported; // both arrays scaled: the caller runs fold, scale and evaluation separately
 	}
+#undef BN_FE_LAUNCH
 	return hipGetLastError();
 }
 

@@ -16,6 +16,8 @@
 // A register carries 32 elements (no [1|inf] packing); a wave-batch is 7 x 32 = 224 elements.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "bitslice.hpp"
 #include "internal.hpp"
 
@@ -222,6 +224,164 @@ struct mul9_wave {
 	}
 }
 
+	// ---- two wave-batches per rebuild (round 4) -------------------------------------------------------------------
+	// In `batch` the rebuild of the result limbs, the transpose back and the stores are work for the four builder lanes of a
+	// group -- 28 lanes of 64 -- that the whole wave executes: ~800 of the ~2450 instructions of a batch at 44 % use.  Here a
+	// wave takes TWO batches (448 elements) per step: the load / transpose / limb exchange / product phases run once per
+	// batch and publish their partial products into the batch's own LDS region (wt, wt + kWaveQ4), and ONE rebuild serves
+	// both -- lanes c < 4 of a group rebuild limb c of the first batch, lanes 4 <= c < 8 limb c - 4 of the second --, reads
+	// exactly the partial products a limb needs and folds them with three-input XORs: ~1700 instead of ~2450 instructions
+	// per batch.  LDS: 18 KiB per wave, two workgroups per CU = 147 KiB (dynamic shared memory).
+	// (Textually a variant of `batch` on purpose: the same statements in the same scopes.  Splitting `batch` into two
+	// functions took the kernel from 192 registers to 256 + 44 spilled -- the schedule of the product is that close to the edge.)
+	__device__ __forceinline__ void batch2(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b, uint32_t *__restrict__ out, uint64_t e0,
+	                                      uint64_t limit)
+	{
+		constexpr uint64_t stride_w = (uint64_t)STRIDE << 2; // in 32-bit words
+		uint4 *const wt0 = this->wt;
+#pragma unroll 1
+		for (unsigned reg = 0; reg < 2; reg++) {
+		uint4 *wt = wt0 + reg * kWaveQ4;
+		const uint64_t e0r = e0 + (uint64_t)reg * kWB;
+		const uint32_t *src = ((c & 4) ? b : a) + w;
+		const bool full = e0r + kWB <= limit;
+		{
+		const uint64_t base = e0r + gg; // element of row j: base + 7*j
+		uint32_t r[32];
+		if (full) {
+			const uint32_t *p = src + base * stride_w;
+#pragma unroll
+			for (int j = 0; j < 32; j++)
+				r[j] = p[(uint64_t)j * 7 * stride_w];
+		} else {
+			// ragged last batch: 8 rows at a time so only a few guarded addresses are live at once
+#pragma unroll
+			for (int j0 = 0; j0 < 32; j0 += 8) {
+#pragma unroll
+				for (int j = j0; j < j0 + 8; j++) {
+					const uint64_t e = base + 7 * (uint64_t)j;
+					const bool ok = e < limit;
+					const uint32_t v = src[ok ? e * stride_w : 0];
+					r[j] = ok ? v : 0u;
+				}
+				__builtin_amdgcn_sched_barrier(0);
+			}
+		}
+		transpose32(r);
+		if (loader) {
+#pragma unroll
+			for (int q = 0; q < 8; q++)
+				wt[off_w + q] = uint4{r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]};
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		uint32_t A[32], B[32];
+#pragma unroll
+		for (int q = 0; q < 8; q++) {
+			const uint4 x0 = wt[off_a[0] + q], x1 = wt[off_a[1] + q], x2 = wt[off_a[2] + q], x3 = wt[off_a[3] + q];
+			const uint4 y0 = wt[off_b[0] + q], y1 = wt[off_b[1] + q], y2 = wt[off_b[2] + q], y3 = wt[off_b[3] + q];
+			A[4 * q] = xor3(x0.x, x1.x, x2.x) ^ x3.x;
+			A[4 * q + 1] = xor3(x0.y, x1.y, x2.y) ^ x3.y;
+			A[4 * q + 2] = xor3(x0.z, x1.z, x2.z) ^ x3.z;
+			A[4 * q + 3] = xor3(x0.w, x1.w, x2.w) ^ x3.w;
+			B[4 * q] = xor3(y0.x, y1.x, y2.x) ^ y3.x;
+			B[4 * q + 1] = xor3(y0.y, y1.y, y2.y) ^ y3.y;
+			B[4 * q + 2] = xor3(y0.z, y1.z, y2.z) ^ y3.z;
+			B[4 * q + 3] = xor3(y0.w, y1.w, y2.w) ^ y3.w;
+			if (q & 1)
+				__builtin_amdgcn_sched_barrier(0);
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		uint32_t P[32];
+		bs_mul<5>(A, B, P);
+		// publish the partial product (the limb tile is dead now: same LDS region)
+#pragma unroll
+		for (int q = 0; q < 8; q++)
+			wt[off_pp + q] = uint4{P[4 * q], P[4 * q + 1], P[4 * q + 2], P[4 * q + 3]};
+		}
+		} // (both batches' partial products are in LDS)
+		{
+		uint32_t r[32];
+		uint4 *wt = wt0;
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		// rebuild: lane c < 8 of a group builds limb c & 3 of batch c >> 2 -- R = X ^ alpha(Y ^ alpha(W)) with exactly the partial
+		// products the limb needs (7 + 4 + 1 blocks per four planes, padded with the zero block).  The lists are packed four bits
+		// per entry (9 = zero block) and unpacked into twelve offsets HERE, behind the product, from an opaque copy of g.
+		{
+			unsigned gl = g;
+			asm volatile("" : "+v"(gl));
+			uint32_t xl, yl, wl;
+			switch ((live && c < 8) ? (c & 3) : 4u) {
+			case 0: xl = 0x9994310u; yl = 0x9999u; wl = 9; break; // p0 p1 p3 p4
+			case 1: xl = 0x9543210u; yl = 0x9941u; wl = 9; break; // p0..p5 ; alpha(p1 p4)
+			case 2: xl = 0x9976510u; yl = 0x9994u; wl = 9; break; // p0 p1 p5 p6 p7 ; alpha(p4)
+			case 3: xl = 0x8765210u; yl = 0x7531u; wl = 4; break; // p0 p1 p2 p5 p6 p7 p8 ; alpha(p1 p3 p5 p7) ; alpha^2(p4)
+			default: xl = 0x9999999u; yl = 0x9999u; wl = 9; break;
+			}
+			const unsigned reg_q = (c & 4) ? (unsigned)kWaveQ4 : 0u;
+			auto off_of = [&](uint32_t idx) -> unsigned { return (idx == 9 ? (unsigned)kZero : idx * kG + gl) * kQ + reg_q; };
+			unsigned ox[7], oy[4], ow;
+#pragma unroll
+			for (int k = 0; k < 7; k++) ox[k] = off_of((xl >> (4 * k)) & 15u);
+#pragma unroll
+			for (int k = 0; k < 4; k++) oy[k] = off_of((yl >> (4 * k)) & 15u);
+			ow = off_of(wl);
+			uint32_t t0[32], t1[32];
+#pragma unroll
+			for (int q = 0; q < 8; q++) {
+				const uint4 ww = wt[ow + q];
+				t0[4 * q] = ww.x; t0[4 * q + 1] = ww.y; t0[4 * q + 2] = ww.z; t0[4 * q + 3] = ww.w;
+			}
+			bs_mul_alpha<5>(t0, t1); // t1 = alpha(W)
+			asm volatile("" : "+v"(oy[0]), "+v"(oy[1]), "+v"(oy[2]), "+v"(oy[3]) : "v"(t1[31]));
+#pragma unroll
+			for (int q = 0; q < 8; q++) {
+				const uint4 y0 = wt[oy[0] + q], y1 = wt[oy[1] + q], y2 = wt[oy[2] + q], y3 = wt[oy[3] + q];
+				t1[4 * q] = xor3(xor3(y0.x, y1.x, y2.x), y3.x, t1[4 * q]);
+				t1[4 * q + 1] = xor3(xor3(y0.y, y1.y, y2.y), y3.y, t1[4 * q + 1]);
+				t1[4 * q + 2] = xor3(xor3(y0.z, y1.z, y2.z), y3.z, t1[4 * q + 2]);
+				t1[4 * q + 3] = xor3(xor3(y0.w, y1.w, y2.w), y3.w, t1[4 * q + 3]); // Y + alpha(W)
+				// (the next quad's reads wait for this quad's result: left alone the compiler hoists every read of the phase)
+				asm volatile("" : "+v"(oy[0]), "+v"(oy[1]), "+v"(oy[2]), "+v"(oy[3]) : "v"(t1[4 * q]), "v"(t1[4 * q + 1]), "v"(t1[4 * q + 2]), "v"(t1[4 * q + 3]));
+			}
+			bs_mul_alpha<5>(t1, t0); // t0 = alpha(Y) + alpha^2(W)
+			asm volatile("" : "+v"(ox[0]), "+v"(ox[1]), "+v"(ox[2]), "+v"(ox[3]), "+v"(ox[4]), "+v"(ox[5]), "+v"(ox[6]) : "v"(t0[31]));
+#pragma unroll
+			for (int q = 0; q < 8; q++) {
+				const uint4 x0 = wt[ox[0] + q], x1 = wt[ox[1] + q], x2 = wt[ox[2] + q], x3 = wt[ox[3] + q];
+				const uint4 x4 = wt[ox[4] + q], x5 = wt[ox[5] + q], x6 = wt[ox[6] + q];
+				r[4 * q] = xor3(xor3(x0.x, x1.x, x2.x), xor3(x3.x, x4.x, x5.x), x6.x ^ t0[4 * q]);
+				r[4 * q + 1] = xor3(xor3(x0.y, x1.y, x2.y), xor3(x3.y, x4.y, x5.y), x6.y ^ t0[4 * q + 1]);
+				r[4 * q + 2] = xor3(xor3(x0.z, x1.z, x2.z), xor3(x3.z, x4.z, x5.z), x6.z ^ t0[4 * q + 2]);
+				r[4 * q + 3] = xor3(xor3(x0.w, x1.w, x2.w), xor3(x3.w, x4.w, x5.w), x6.w ^ t0[4 * q + 3]);
+				asm volatile("" : "+v"(ox[0]), "+v"(ox[1]), "+v"(ox[2]), "+v"(ox[3]), "+v"(ox[4]), "+v"(ox[5]), "+v"(ox[6])
+				             : "v"(r[4 * q]), "v"(r[4 * q + 1]), "v"(r[4 * q + 2]), "v"(r[4 * q + 3]));
+			}
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		transpose32(r); // planes -> word c & 3 of the 32 elements of this group in batch c >> 2
+		if (live && c < 8) {
+			const uint64_t base = e0 + (uint64_t)(c >> 2) * kWB + gg;
+			uint32_t *dst = out + (c & 3) + (base << 2);
+			if (e0 + 2 * kWB <= limit) {
+#pragma unroll
+				for (int j = 0; j < 32; j++)
+					dst[28 * j] = r[j];
+			} else {
+#pragma unroll
+				for (int j = 0; j < 32; j++)
+					if (base + 7 * (uint64_t)j < limit)
+						dst[28 * j] = r[j];
+			}
+		}
+		}
+	}
+
 };
 
 // The wave-batches wave_global, wave_global + n_waves, ... of one element-wise product; wt = this wave's LDS tile.
@@ -234,6 +394,22 @@ __device__ __forceinline__ void mul9_batches(const uint32_t *__restrict__ a, con
 	const uint64_t n_batches = (n + kWB - 1) / kWB;
 	for (uint64_t bt = wave_global; bt < n_batches; bt += n_waves)
 		mw.batch(a, b, out, bt * kWB, n);
+}
+
+template <int STRIDE>
+__global__ __launch_bounds__(256, 2) void k_mul9_dual(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b,
+                                                     uint32_t *__restrict__ out, uint64_t n)
+{
+	extern __shared__ uint4 tile2[];
+	const unsigned wave = threadIdx.x >> 6;
+	mul9_wave<STRIDE> mw;
+	mw.init(tile2 + wave * 2 * kWaveQ4);
+	if ((threadIdx.x & 63) < kQ)
+		tile2[wave * 2 * kWaveQ4 + kWaveQ4 + kZero * kQ + (threadIdx.x & 63)] = uint4{0, 0, 0, 0}; // the second region's zero block
+	const uint64_t n_steps = (n + 2 * kWB - 1) / (2 * kWB);
+	const uint64_t n_waves = (uint64_t)gridDim.x * 4;
+	for (uint64_t st = (uint64_t)blockIdx.x * 4 + wave; st < n_steps; st += n_waves)
+		mw.batch2(a, b, out, st * 2 * kWB, n);
 }
 
 template <int STRIDE>
@@ -284,6 +460,26 @@ hipError_t launch_mul9(hipStream_t s, int n_cu, const void *a, uint64_t a_stride
 	const uint64_t cap = (uint64_t)n_cu * 2; // two workgroups per CU = two waves per SIMD
 	if (blocks > cap) blocks = cap;
 	const uint32_t *pb = (const uint32_t *)b + b_off * 4;
+	// more batches than wave slots: two batches per rebuild (k_mul9_dual); BN_MUL9_DUAL=0 keeps the one-batch kernel
+	static const bool dual_on = [] {
+		const char *e = getenv("BN_MUL9_DUAL");
+		return !(e && e[0] == '0');
+	}();
+	if (dual_on && n_batches > cap * 4 && ((a_stride == 1 && b_stride == 1) || (a_stride == 2 && b_stride == 2))) {
+		constexpr size_t lds = (size_t)4 * 2 * kWaveQ4 * sizeof(uint4);
+		static const hipError_t attr1 = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mul9_dual<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		static const hipError_t attr2 = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mul9_dual<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		if (attr1 != hipSuccess) return attr1;
+		if (attr2 != hipSuccess) return attr2;
+		const uint64_t n_steps = (n_batches + 1) / 2;
+		uint64_t blk = (n_steps + 3) / 4;
+		if (blk > cap) blk = cap;
+		if (a_stride == 1)
+			hipLaunchKernelGGL(k_mul9_dual<1>, dim3((unsigned)blk), dim3(256), lds, s, (const uint32_t *)a, pb, (uint32_t *)out, n);
+		else
+			hipLaunchKernelGGL(k_mul9_dual<2>, dim3((unsigned)blk), dim3(256), lds, s, (const uint32_t *)a, pb, (uint32_t *)out, n);
+		return hipGetLastError();
+	}
 	if (a_stride == 1 && b_stride == 1)
 		hipLaunchKernelGGL(k_mul9<1>, dim3((unsigned)blocks), dim3(256), 0, s, (const uint32_t *)a, pb, (uint32_t *)out, n);
 	else if (a_stride == 2 && b_stride == 2)

@@ -363,6 +363,190 @@ __global__ __launch_bounds__(256, 2) void k_ntt_bs_pass(uint4 *__restrict__ bs, 
 	}
 }
 
+// ---- the same R <= 7 lower layers with the plane sets held in REGISTERS (round 4) ----------------------------------------
+// k_ntt_bs_pass above moves every plane set through LDS once per layer (16 + 16 ds_*_b128 per thread and layer, all four
+// waves of a tile in their LDS phase at the same time, then all in their product phase): VALU issue 59 % busy.  Here a WAVE
+// owns 128 plane sets for the whole pass, two per lane (X0, X1: 64 registers), and a layer is the in-lane butterfly (X0, X1):
+// no LDS, no barrier, nothing shared between waves.  Between two layers ONE plane set per lane changes hands:
+// local index bits live either in the slot (X0 / X1) or in one of six lane bits; the layer about to run needs its bit in the
+// slot, so the lanes that differ in that lane bit swap X1 (side 0) against X0 (side 1) -- side 0 then holds (its X0, the
+// partner's X0), side 1 (the partner's X1, its X1): both are butterfly pairs of the new bit, and the bit that was in the slot
+// now lives in the lane bit.  Every bit is a butterfly bit at most once, so the permutation is never undone; it is tracked in
+// a packed scalar (phys) and resolved when the sets are stored.  The six lane bits are chosen so that each swap is one or two
+// instructions per register: lane ^ 32 and lane ^ 16 are v_permlane32_swap / v_permlane16_swap (gfx950), row_mirror and
+// row_half_mirror are DPP moves whose two sides are whole banks (bank_mask), lane ^ 2 and lane ^ 1 DPP moves + selects.
+// Encoded lane bits (each operation flips exactly one of them): e5 = j5, e4 = j4, e3 = j3, e2 = j2 ^ j3, e1 = j1 ^ j2,
+// e0 = j0 ^ j2 for lane j.
+constexpr int kRegLog = 7; // plane sets per wave = 128
+
+template <int B>
+__device__ __forceinline__ void reg_swap(uint32_t (&X0)[32], uint32_t (&X1)[32], unsigned side)
+{
+#pragma unroll
+	for (int j = 0; j < 32; j++) {
+		if constexpr (B == 5) {
+			const auto r = __builtin_amdgcn_permlane32_swap(X0[j], X1[j], false, false); // X0[upper half] <-> X1[lower half]
+			X0[j] = r[0];
+			X1[j] = r[1];
+		} else if constexpr (B == 4) {
+			const auto r = __builtin_amdgcn_permlane16_swap(X0[j], X1[j], false, false); // X0[odd rows] <-> X1[even rows]
+			X0[j] = r[0];
+			X1[j] = r[1];
+		} else if constexpr (B == 3) {
+			// row_mirror (lane ^ 15 inside a row of 16): side = j3 = banks 2, 3
+			const uint32_t n1 = (uint32_t)__builtin_amdgcn_update_dpp((int)X1[j], (int)X0[j], 0x140, 0xF, 0x3, false);
+			const uint32_t n0 = (uint32_t)__builtin_amdgcn_update_dpp((int)X0[j], (int)X1[j], 0x140, 0xF, 0xC, false);
+			X0[j] = n0;
+			X1[j] = n1;
+		} else if constexpr (B == 2) {
+			// row_half_mirror (lane ^ 7 inside a group of 8): side = j2 ^ j3 = banks 1, 2
+			const uint32_t n1 = (uint32_t)__builtin_amdgcn_update_dpp((int)X1[j], (int)X0[j], 0x141, 0xF, 0x9, false);
+			const uint32_t n0 = (uint32_t)__builtin_amdgcn_update_dpp((int)X0[j], (int)X1[j], 0x141, 0xF, 0x6, false);
+			X0[j] = n0;
+			X1[j] = n1;
+		} else {
+			// inside a quad: lane ^ 2 (B == 1) or lane ^ 1 (B == 0); the sides are not banks -- select
+			constexpr int ctrl = B == 1 ? 0x4E : 0xB1;
+			const uint32_t r0 = (uint32_t)__builtin_amdgcn_mov_dpp((int)X0[j], ctrl, 0xF, 0xF, true);
+			const uint32_t r1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)X1[j], ctrl, 0xF, 0xF, true);
+			X0[j] = side ? r1 : X0[j];
+			X1[j] = side ? X1[j] : r0;
+		}
+	}
+}
+
+template <bool INV, bool CONV>
+__global__ __launch_bounds__(256, 2) void k_ntt_bs_pass_reg(uint4 *__restrict__ bs, uint64_t S, uint32_t l_lo, uint32_t R, uint32_t n_lo,
+                                                            const ntt_bs_tables *__restrict__ tb, uint32_t *__restrict__ data, uint32_t lx,
+                                                            uint32_t log_y)
+{
+	const unsigned lane = threadIdx.x & 63;
+	const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	bs += (uint64_t)blockIdx.y * S * 8; // batch
+	if (CONV) {
+		const uint64_t beta = blockIdx.y;
+		data += ((beta >> lx) << (log_y + lx)) + (beta & (((uint64_t)1 << lx) - 1));
+	}
+	const uint32_t gap = l_lo - n_lo; // block bits between the two local runs
+	const uint64_t b = (uint64_t)blockIdx.x * 4 + wave;
+	const uint64_t i_tile = ((b & (((uint64_t)1 << gap) - 1)) << n_lo) | ((b >> gap) << (l_lo + kRegLog - n_lo));
+	auto index_of = [&](unsigned s) -> uint64_t { return i_tile | (s & ((1u << n_lo) - 1)) | ((uint64_t)(s >> n_lo) << l_lo); };
+	// encoded lane bits
+	const unsigned j2 = (lane >> 2) & 1, j3 = (lane >> 3) & 1;
+	const unsigned E = (lane & 0x30) | (j3 << 3) | ((j2 ^ j3) << 2) | ((((lane >> 1) & 1) ^ j2) << 1) | ((lane & 1) ^ j2);
+	// phys: 4 bits per local index bit k = the lane bit that holds it (15: the slot).  The first butterfly bit starts in the
+	// slot, the other six local bits take the lane bits in increasing order.
+	const unsigned k_first = INV ? n_lo : n_lo + R - 1;
+	uint32_t phys = 0;
+	{
+		unsigned nb = 0;
+		for (unsigned k = 0; k < (unsigned)kRegLog; k++)
+			phys |= (k == k_first ? 15u : nb++) << (4 * k);
+	}
+	auto local_index = [&](uint32_t ph, unsigned slot) -> unsigned { // local set number of this lane's X_slot
+		unsigned s = 0;
+#pragma unroll
+		for (unsigned k = 0; k < (unsigned)kRegLog; k++) {
+			const unsigned pb = (ph >> (4 * k)) & 15u;
+			s |= (pb == 15u ? slot : ((E >> pb) & 1u)) << k;
+		}
+		return s;
+	};
+	uint32_t X0[32], X1[32];
+	if (CONV && INV) {
+		// elements -> plane sets (the words of one set are S elements apart; the lanes of a wave cover 128 consecutive i)
+#pragma unroll 1
+		for (unsigned h = 0; h < 2; h++) {
+			const uint64_t i = index_of(local_index(phys, h));
+			uint32_t W[32];
+#pragma unroll
+			for (int c = 0; c < 32; c++)
+				W[c] = data[((uint64_t)c * S + i) << lx];
+			transpose32(W);
+#pragma unroll
+			for (int c = 0; c < 32; c++) {
+				if (h == 0) X0[c] = W[c];
+				else X1[c] = W[c];
+			}
+		}
+	} else {
+		const uint4 *p0 = bs + index_of(local_index(phys, 0)) * 8, *p1 = bs + index_of(local_index(phys, 1)) * 8;
+#pragma unroll
+		for (int k = 0; k < 8; k++) {
+			const uint4 a = p0[k], c = p1[k];
+			X0[4 * k] = a.x; X0[4 * k + 1] = a.y; X0[4 * k + 2] = a.z; X0[4 * k + 3] = a.w;
+			X1[4 * k] = c.x; X1[4 * k + 1] = c.y; X1[4 * k + 2] = c.z; X1[4 * k + 3] = c.w;
+		}
+	}
+	unsigned k_prev = k_first;
+#pragma unroll 1
+	for (unsigned tt = 0; tt < R; tt++) {
+		const unsigned k = INV ? n_lo + tt : n_lo + R - 1 - tt; // local index bit of this layer (forward: high layer first)
+		const uint32_t l = l_lo + (k - n_lo);
+		if (tt) {
+			const unsigned pb = __builtin_amdgcn_readfirstlane((phys >> (4 * k)) & 15u);
+			const unsigned side = (E >> pb) & 1u;
+			switch (pb) { // (uniform)
+			case 0: reg_swap<0>(X0, X1, side); break;
+			case 1: reg_swap<1>(X0, X1, side); break;
+			case 2: reg_swap<2>(X0, X1, side); break;
+			case 3: reg_swap<3>(X0, X1, side); break;
+			case 4: reg_swap<4>(X0, X1, side); break;
+			default: reg_swap<5>(X0, X1, side); break;
+			}
+			phys = (phys & ~((15u << (4 * k)) | (15u << (4 * k_prev)))) | (15u << (4 * k)) | (pb << (4 * k_prev));
+			k_prev = k;
+		}
+		// twiddle of bit position c: pat (c part) ^ tbase (i part + coset part), all XOR-linear; this lane's u set is X0, whose
+		// index has bit l clear; the bits above l come from the block (uniform: scalar loop) and from the lane bits
+		uint32_t tbase = tb->tconst[l];
+		{
+			uint64_t qt = i_tile >> (l + 1);
+			for (unsigned bit = 0; qt; bit++, qt >>= 1)
+				if (qt & 1) tbase ^= tb->rows[l][bit];
+#pragma unroll
+			for (unsigned kk = 0; kk < (unsigned)kRegLog; kk++) {
+				const unsigned gp = kk < n_lo ? kk : l_lo + kk - n_lo; // index bit of local bit kk
+				if (gp > l) { // (uniform; never the slot bit, which is bit l itself)
+					const uint32_t rv = tb->rows[l][gp - (l + 1)];
+					const unsigned pb = (phys >> (4 * kk)) & 15u;
+					tbase ^= ((E >> pb) & 1u) ? rv : 0u;
+				}
+			}
+		}
+		uint32_t T[32];
+#pragma unroll
+		for (int j = 0; j < 32; j++)
+			T[j] = tb->pat[l][j] ^ (uint32_t)__builtin_amdgcn_sbfe((int)tbase, j, 1);
+		if (tb->sub8[l]) // (uniform)
+			butterfly_planes_sub8<INV>(X0, X1, T);
+		else
+			butterfly_planes<INV>(X0, X1, T);
+	}
+	if (CONV && !INV) {
+		// plane sets -> elements
+#pragma unroll 1
+		for (unsigned h = 0; h < 2; h++) {
+			const uint64_t i = index_of(local_index(phys, h));
+			uint32_t W[32];
+#pragma unroll
+			for (int c = 0; c < 32; c++)
+				W[c] = h == 0 ? X0[c] : X1[c];
+			transpose32(W);
+#pragma unroll
+			for (int c = 0; c < 32; c++)
+				data[((uint64_t)c * S + i) << lx] = W[c];
+		}
+		return;
+	}
+	uint4 *q0 = bs + index_of(local_index(phys, 0)) * 8, *q1 = bs + index_of(local_index(phys, 1)) * 8;
+#pragma unroll
+	for (int k = 0; k < 8; k++) {
+		q0[k] = uint4{X0[4 * k], X0[4 * k + 1], X0[4 * k + 2], X0[4 * k + 3]};
+		q1[k] = uint4{X1[4 * k], X1[4 * k + 1], X1[4 * k + 2], X1[4 * k + 3]};
+	}
+}
+
 // OnTheFlyTwiddleAccess::get (twiddle.rs:141-168): XOR of the layer's basis values over the index bits
 uint32_t host_twiddle(const uint64_t *s_evals, uint32_t log_domain, uint32_t layer, uint64_t index)
 {
@@ -480,9 +664,26 @@ static hipError_t run_ntt_bs(hipStream_t s, void *data, const uint64_t *h_s_eval
 	const dim3 ht_grid((unsigned)(((S << lx) + 255) / 256), 1u << log_z);
 	if (!(INV && merged))
 		hipLaunchKernelGGL(k_ntt_bs_head<INV>, ht_grid, dim3(256), 0, s, (const uint32_t *)data, bs, S, lx, log_y, d_tb, n_top);
+	static const bool reg_pass = [] {
+		const char *v = getenv("BN_NTT_REG_PASS"); // 0: the LDS-tile passes of rounds 1 - 3
+		return !(v && v[0] == '0');
+	}();
 	for (size_t k = 0; k < plan.size(); k++) {
 		const auto &pr = INV ? plan[plan.size() - 1 - k] : plan[k];
-		const uint32_t l_lo = pr.first, R = pr.second, Q = kTileLog - R;
+		const uint32_t l_lo = pr.first, R = pr.second;
+		if (reg_pass) {
+			// a wave owns 128 plane sets (kRegLog local bits), four waves per workgroup: the same grid as the LDS tiles
+			const uint32_t Qr = kRegLog - R, n_lo_r = Qr < l_lo ? Qr : l_lo;
+			// (one block per wave, 162 registers: three waves per SIMD.  A persistent grid of two waves per SIMD walking two blocks
+			// each -- no fourth wave running alone at the end -- was measured slower: 0.274 - 0.286 against 0.252 - 0.264 ms)
+			const dim3 grid_r((unsigned)(S >> (kRegLog + 2)), n_batch);
+			if (l_lo == 0 && merged)
+				hipLaunchKernelGGL((k_ntt_bs_pass_reg<INV, true>), grid_r, dim3(256), 0, s, bs, S, l_lo, R, n_lo_r, d_tb, (uint32_t *)data, lx, log_y);
+			else
+				hipLaunchKernelGGL((k_ntt_bs_pass_reg<INV, false>), grid_r, dim3(256), 0, s, bs, S, l_lo, R, n_lo_r, d_tb, (uint32_t *)data, lx, log_y);
+			continue;
+		}
+		const uint32_t Q = kTileLog - R;
 		const uint32_t n_lo = Q < l_lo ? Q : l_lo;
 		const dim3 grid((unsigned)(S >> kTileLog), n_batch);
 		if (l_lo == 0 && merged)

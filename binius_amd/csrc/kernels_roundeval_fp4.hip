@@ -54,7 +54,8 @@ __device__ unsigned long long fp4_phase_cycles[8];
 #endif
 // MIX: the second pair of sets holds hi ^ lo (evaluation at infinity); otherwise lo itself (two independent products: the
 // two halves of an inner product).
-template <bool MIX>
+// NT: the LDS-DMA loads carry the non-temporal hint (HBM-resident sizes: every element is read once per launch).
+template <bool MIX, bool NT>
 __global__ __launch_bounds__(256, 3) void k_roundeval_fp4(const uint4 *__restrict__ a_hi, const uint4 *__restrict__ a_lo,
                                                           const uint4 *__restrict__ b_hi, const uint4 *__restrict__ b_lo, uint64_t n, f128 *out,
                                                           fin_fuse fz, uint32_t xcd_tiles)
@@ -88,10 +89,17 @@ __global__ __launch_bounds__(256, 3) void k_roundeval_fp4(const uint4 *__restric
 		const uint64_t pt = (tbase + t) * kTP + threadIdx.x;
 		const uint64_t e = pt < n ? pt : 0;
 		const uint32_t l0 = __builtin_amdgcn_readfirstlane(raw_base + slot * (4 * kTP * 16));
-		asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(a_hi + e), "s"(l0) : "memory", "m0");
-		asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(a_lo + e), "s"(l0 + 1 * kTP * 16) : "memory", "m0");
-		asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(b_hi + e), "s"(l0 + 2 * kTP * 16) : "memory", "m0");
-		asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(b_lo + e), "s"(l0 + 3 * kTP * 16) : "memory", "m0");
+		if constexpr (NT) {
+			asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off nt" ::"v"(a_hi + e), "s"(l0) : "memory", "m0");
+			asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off nt" ::"v"(a_lo + e), "s"(l0 + 1 * kTP * 16) : "memory", "m0");
+			asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off nt" ::"v"(b_hi + e), "s"(l0 + 2 * kTP * 16) : "memory", "m0");
+			asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off nt" ::"v"(b_lo + e), "s"(l0 + 3 * kTP * 16) : "memory", "m0");
+		} else {
+			asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(a_hi + e), "s"(l0) : "memory", "m0");
+			asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(a_lo + e), "s"(l0 + 1 * kTP * 16) : "memory", "m0");
+			asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(b_hi + e), "s"(l0 + 2 * kTP * 16) : "memory", "m0");
+			asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(b_lo + e), "s"(l0 + 3 * kTP * 16) : "memory", "m0");
+		}
 	};
 	// workgroup barrier that waits for this wave's LDS traffic only (not for the LDS-DMA loads in flight)
 	auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
@@ -151,8 +159,17 @@ static hipError_t launch_fp4(hipStream_t s, int n_cu, const void *a_hi, const vo
 		const char *e = getenv("BN_XCD_TILES");
 		return (uint32_t)!(e && e[0] == '0');
 	}();
-	hipLaunchKernelGGL(k_roundeval_fp4<MIX>, dim3(grid), dim3(256), 0, s, (const uint4 *)a_hi, (const uint4 *)a_lo, (const uint4 *)b_hi,
-	                   (const uint4 *)b_lo, n, d_out, fz, xcd_tiles);
+	// BN_FP4_NT_MIN_LOG2: points from which the loads are non-temporal (measurement knob; 64 = never)
+	static const int nt_min_log2 = [] {
+		const char *e = getenv("BN_FP4_NT_MIN_LOG2");
+		return e ? atoi(e) : 24;
+	}();
+	if (nt_min_log2 < 64 && n >= (1ull << nt_min_log2))
+		hipLaunchKernelGGL((k_roundeval_fp4<MIX, true>), dim3(grid), dim3(256), 0, s, (const uint4 *)a_hi, (const uint4 *)a_lo, (const uint4 *)b_hi,
+		                   (const uint4 *)b_lo, n, d_out, fz, xcd_tiles);
+	else
+		hipLaunchKernelGGL((k_roundeval_fp4<MIX, false>), dim3(grid), dim3(256), 0, s, (const uint4 *)a_hi, (const uint4 *)a_lo, (const uint4 *)b_hi,
+		                   (const uint4 *)b_lo, n, d_out, fz, xcd_tiles);
 	return hipGetLastError();
 }
 

@@ -109,7 +109,9 @@ bool mfma_applies(int n_cu, uint64_t n_points)
 	}();
 	if (min_tiles < 0) return false;
 	const uint64_t n_tiles = (n_points + kTP - 1) / kTP;
-	return n_tiles >= (min_tiles ? (uint64_t)min_tiles : (uint64_t)n_cu * 2);
+	// one tile per CU is enough (round 4, tools/r04_min_tiles.sh: r = 18 of a sumcheck on the matrix cores instead of the 9-lane
+	// kernel: n = 24 0.755 - 0.79 -> 0.734 - 0.749 ms, n = 20 0.228 -> 0.2255; half a tile per CU gains nothing more)
+	return n_tiles >= (min_tiles ? (uint64_t)min_tiles : (uint64_t)n_cu);
 }
 
 static unsigned grid_mfma(uint64_t n, int n_cu)

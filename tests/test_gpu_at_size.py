@@ -101,6 +101,22 @@ def test_compute_composite_product_2p20(hal, oracle):
     assert np.array_equal(hal.copy_d2h(do), oracle.mul_vec(a, b))
 
 
+@pytest.mark.parametrize("n", [458752 + 1, 458752 + 224, 458752 + 225, 458752 + 447, 458752 + 448, 500001, (1 << 20) - 3])
+def test_compute_composite_product_ragged_sizes_on_the_two_batch_kernel(hal, oracle, n):
+    """More products than wave slots (2048 x 224): kernels_mul9.hip takes two wave-batches per rebuild (k_mul9_dual).  Lengths
+    that end inside the first batch of a step, on its boundary, inside the second batch and on a step boundary."""
+    alloc = hal.dev_alloc()
+    a, b = rnd(oracle, 0x4B0 + (n & 7), n), rnd(oracle, 0x4B8 + (n & 7), n)
+    da, db, do = upload(hal, alloc, a), upload(hal, alloc, b), alloc.alloc(n)
+    guard = alloc.alloc(64)  # right behind the output: must stay untouched
+    hal.fill(guard, 0x5A)
+    expr = hal.compile_expr([("var", 0), ("var", 1), ("mul", 0, 1)])
+    hal.compute_composite([da, db], do, expr)
+    assert np.array_equal(hal.copy_d2h(do), oracle.mul_vec(a, b))
+    g = hal.copy_d2h(guard)
+    assert (g[:, 0] == 0x5A).all() and (g[:, 1] == 0).all()
+
+
 def test_pairwise_product_reduce_2p20(hal, oracle):
     alloc = hal.dev_alloc()
     n = 1 << LOG
