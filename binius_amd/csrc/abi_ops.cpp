@@ -59,10 +59,21 @@ static int fold_common(bn_ctx *ctx, bool left, const void *d_mat, uint64_t mat_l
 	const uint32_t log_q = ilog2(vec_len);
 	BN_REQUIRE(log_q <= log_evals, "query larger than evals");
 	BN_REQUIRE(out_len == ((uint64_t)1 << (log_evals - log_q)), "output has the wrong number of elements");
-	if (left)
+	if (left) {
 		BN_HIP(bn::launch_fold_left(ctx->stream, ctx->n_cu, d_mat, tower_level, d_vec, vec_len, d_out, out_len));
-	else
-		BN_HIP(bn::launch_fold_right(ctx->stream, ctx->n_cu, d_mat, tower_level, d_vec, vec_len, d_out, out_len));
+		return BN_OK;
+	}
+	// rows of 512 .. 2048 bits: the linear map on the matrix cores (kernels_linmap.hip); every other shape: nibble tables
+	const uint64_t row_bits = vec_len << tower_level;
+	if (out_len >= 4096 && (row_bits == 512 || row_bits == 1024 || row_bits == 2048)) {
+		void *tab = bn::ctx_scratch(ctx, bn::linmap_table_bytes(row_bits));
+		if (tab) {
+			const hipError_t e = bn::launch_fold_right_mfma(ctx->stream, ctx->n_cu, d_mat, tower_level, d_vec, vec_len, d_out, out_len, tab);
+			if (e == hipSuccess) return BN_OK;
+			if (e != hipErrorNotSupported) BN_HIP(e);
+		}
+	}
+	BN_HIP(bn::launch_fold_right(ctx->stream, ctx->n_cu, d_mat, tower_level, d_vec, vec_len, d_out, out_len));
 	return BN_OK;
 }
 

@@ -423,6 +423,11 @@ hipError_t launch_inner_product(hipStream_t s, int n_cu, const void *a, uint32_t
                                 uint64_t b_len, f128 *d_out);
 hipError_t launch_fold_left(hipStream_t s, int n_cu, const void *mat, uint32_t tower_level, const void *vec,
                             uint64_t vec_len, void *out, uint64_t out_len);
+// fold_right as a GF(2)-linear map on the matrix cores (kernels_linmap.hip): rows of 512 / 1024 / 2048 bits; hipErrorNotSupported
+// for every other shape.  d_table: linmap_table_bytes(row_bits) bytes of scratch.
+size_t linmap_table_bytes(uint64_t row_bits);
+hipError_t launch_fold_right_mfma(hipStream_t s, int n_cu, const void *mat, uint32_t tower_level, const void *vec, uint64_t vec_len, void *out,
+                                  uint64_t out_len, void *d_table);
 hipError_t launch_fold_right(hipStream_t s, int n_cu, const void *mat, uint32_t tower_level, const void *vec,
                              uint64_t vec_len, void *out, uint64_t out_len);
 hipError_t launch_compute_composite_generic(hipStream_t s, const void *const *d_rows_dev, uint32_t n_rows,

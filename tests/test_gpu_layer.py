@@ -254,6 +254,28 @@ def test_fold_left_right_table_path(hal, oracle, level, log_q, left):
     assert np.array_equal(hal.copy_d2h(do), exp)
 
 
+@pytest.mark.parametrize("level,log_q", [(0, 9), (0, 10), (0, 11), (3, 6), (3, 7), (3, 8), (4, 5), (4, 6), (4, 7), (5, 4), (5, 5), (5, 6),
+                                          (6, 3), (6, 4), (6, 5), (7, 2), (7, 3), (7, 4)])
+@pytest.mark.parametrize("log_out", [12, 14])
+def test_fold_right_on_the_matrix_cores(hal, oracle, level, log_q, log_out):
+    """Rows of 512, 1024 and 2048 bits (vec_len << level) with at least 4096 outputs: fold_right as a GF(2)-linear map on the FP4
+    matrix path (csrc/kernels_linmap.hip), every tower level, against the oracle."""
+    alloc = hal.dev_alloc()
+    assert (1 << log_q) << level in (512, 1024, 2048)
+    log_evals = log_out + log_q
+    mat = rnd(oracle, 260 + 8 * level + log_q, (1 << log_evals) >> (7 - level))
+    vec = rnd(oracle, 261 + level, 1 << log_q)
+    out_len = 1 << log_out
+    dm, dv, do = upload(hal, alloc, mat), upload(hal, alloc, vec), alloc.alloc(out_len)
+    guard = alloc.alloc(8)
+    hal.fill(guard, 0x77)
+    exp = oracle.arr(out_len)
+    hal.fold_right(dm, level, dv, do)
+    assert oracle.fold_right(mat, level, vec, exp) == 0
+    assert np.array_equal(hal.copy_d2h(do), exp)
+    assert (hal.copy_d2h(guard)[:, 0] == 0x77).all()
+
+
 def test_fold_validation(hal):
     import binius_amd
 
