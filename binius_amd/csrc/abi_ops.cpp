@@ -60,6 +60,14 @@ static int fold_common(bn_ctx *ctx, bool left, const void *d_mat, uint64_t mat_l
 	BN_REQUIRE(log_q <= log_evals, "query larger than evals");
 	BN_REQUIRE(out_len == ((uint64_t)1 << (log_evals - log_q)), "output has the wrong number of elements");
 	if (left) {
+		if (tower_level == 5 && out_len >= 4096 && (vec_len == 16 || vec_len == 32 || vec_len == 64)) {
+			void *tab = bn::ctx_scratch(ctx, bn::linmap_table_bytes(vec_len * 32));
+			if (tab) {
+				const hipError_t e = bn::launch_fold_left_mfma(ctx->stream, ctx->n_cu, d_mat, tower_level, d_vec, vec_len, d_out, out_len, tab);
+				if (e == hipSuccess) return BN_OK;
+				if (e != hipErrorNotSupported) BN_HIP(e);
+			}
+		}
 		BN_HIP(bn::launch_fold_left(ctx->stream, ctx->n_cu, d_mat, tower_level, d_vec, vec_len, d_out, out_len));
 		return BN_OK;
 	}

@@ -428,6 +428,8 @@ hipError_t launch_fold_left(hipStream_t s, int n_cu, const void *mat, uint32_t t
 size_t linmap_table_bytes(uint64_t row_bits);
 hipError_t launch_fold_right_mfma(hipStream_t s, int n_cu, const void *mat, uint32_t tower_level, const void *vec, uint64_t vec_len, void *out,
                                   uint64_t out_len, void *d_table);
+hipError_t launch_fold_left_mfma(hipStream_t s, int n_cu, const void *mat, uint32_t tower_level, const void *vec, uint64_t vec_len, void *out,
+                                 uint64_t out_len, void *d_table); // B32 entries, vec_len 16 / 32 / 64
 hipError_t launch_fold_right(hipStream_t s, int n_cu, const void *mat, uint32_t tower_level, const void *vec,
                              uint64_t vec_len, void *out, uint64_t out_len);
 hipError_t launch_compute_composite_generic(hipStream_t s, const void *const *d_rows_dev, uint32_t n_rows,

@@ -283,6 +283,117 @@ __global__ __launch_bounds__(256, 2) void k_linmap_ring(const char *__restrict__
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// fold_left (layer.rs:321): out[j] = sum_i mat[i * n_out + j] * vec[i] -- the same map with the "row" of output j gathered from
+// the vec_len matrix rows.  B32 entries only (one dword per (i, j)): a load instruction brings the 64 entries (i, 64 p .. 64 p + 63)
+// of a step -- 256 contiguous bytes, one dword per lane -- into LDS row i of the slot, and the B operand of (t, kh) is the four
+// dwords of rows 8 t + 4 kh .. + 3 at the lane's column (four ds_read_b32: their bank pattern is the lane index, conflict-free).
+// Bit k of the gathered row = bit k % 32 of entry i = k / 32: the K order of fold_right's rows, so the table is the same.
+template <int T>
+__global__ __launch_bounds__(256, 2) void k_linmap_ring_left(const uint32_t *__restrict__ mat, const uint4 *__restrict__ A, uint32_t *__restrict__ out,
+                                                             uint64_t n_out)
+{
+	constexpr int STEPS = 4 * T;
+	constexpr int L = 8 * T;       // matrix rows (= vec_len)
+	constexpr int D = 4;           // ring slots (steps of 64 outputs)
+	constexpr int IPW = L / 4;     // load instructions per step and wave
+	constexpr int SLOT_BYTES = L * 256;
+	extern __shared__ __attribute__((aligned(16))) unsigned char lm_ring[];
+	const unsigned lane = threadIdx.x & 63;
+	const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const unsigned n = lane & 31, kh = lane >> 5;
+	uint4 a[STEPS];
+#pragma unroll
+	for (int st = 0; st < STEPS; st++)
+		a[st] = A[((size_t)wave * STEPS + st) * 64 + lane];
+	const uint64_t n_pairs = n_out / 64;
+	const uint64_t my_pairs = blockIdx.x < n_pairs ? (n_pairs - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+	if (my_pairs == 0) return;
+	const uint32_t ring_base = (uint32_t)(uintptr_t)lm_ring;
+	auto fetch = [&](uint64_t j) {
+		const uint64_t jj = j < my_pairs ? j : my_pairs - 1;
+		const uint64_t pr = blockIdx.x + jj * gridDim.x;
+		const uint32_t *g0 = mat + pr * 64 + lane;
+		const uint32_t slot = ring_base + (uint32_t)(j % D) * SLOT_BYTES;
+#pragma unroll
+		for (int u = 0; u < IPW; u++) {
+			const unsigned i = wave + 4 * u; // matrix row
+			const uint32_t *g = g0 + (uint64_t)i * n_out;
+			const uint32_t l0 = __builtin_amdgcn_readfirstlane(slot + i * 256);
+			asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dword %0, off" ::"v"(g), "s"(l0) : "memory", "m0");
+		}
+	};
+	for (uint64_t j = 0; j + 1 < (uint64_t)D; j++) fetch(j);
+	const unsigned rd0 = (4 * kh) * 256 + n * 4, rd1 = rd0 + 128;
+	auto chunk = [&](const unsigned char *base, int t) -> uint4 {
+		const unsigned char *q = base + t * 8 * 256;
+		return uint4{*reinterpret_cast<const uint32_t *>(q), *reinterpret_cast<const uint32_t *>(q + 256), *reinterpret_cast<const uint32_t *>(q + 512),
+		             *reinterpret_cast<const uint32_t *>(q + 768)};
+	};
+	for (uint64_t j = 0; j < my_pairs; j++) {
+		static_assert((D - 2) * IPW <= 63, "vmcnt range");
+		if constexpr ((D - 2) * IPW == 32) asm volatile("s_waitcnt vmcnt(32)\n\ts_barrier" ::: "memory");
+		else if constexpr ((D - 2) * IPW == 16) asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+		else if constexpr ((D - 2) * IPW == 8) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+		else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+		fetch(j + D - 1);
+		const unsigned char *slot = lm_ring + (j % D) * SLOT_BYTES;
+		lm_v16f acc0, acc1;
+#pragma unroll
+		for (int r = 0; r < 16; r++) {
+			acc0[r] = 0.0f;
+			acc1[r] = 0.0f;
+		}
+		uint4 x0 = chunk(slot + rd0, 0), x1 = chunk(slot + rd1, 0);
+		uint4 m[2][4];
+		m[0][0] = lm_bit(x0, 0);
+		m[0][1] = lm_bit(x1, 0);
+		m[0][2] = lm_bit(x0, 1);
+		m[0][3] = lm_bit(x1, 1);
+#pragma unroll
+		for (int k = 0; k < 2 * T; k++) {
+			const int t = k >> 1, h = k & 1, cur = k & 1, nxt = cur ^ 1;
+			uint4 nx0 = x0, nx1 = x1;
+			if (h == 1 && t + 1 < T) {
+				nx0 = chunk(slot + rd0, t + 1);
+				nx1 = chunk(slot + rd1, t + 1);
+			}
+			BN_LM_MFMA(acc0, a[4 * t + 2 * h], m[cur][0]);
+			BN_LM_MFMA(acc1, a[4 * t + 2 * h], m[cur][1]);
+			BN_LM_MFMA(acc0, a[4 * t + 2 * h + 1], m[cur][2]);
+			BN_LM_MFMA(acc1, a[4 * t + 2 * h + 1], m[cur][3]);
+			if (k + 1 < 2 * T) {
+				const int hn = h ^ 1;
+				const uint4 &s0 = h == 1 ? nx0 : x0, &s1 = h == 1 ? nx1 : x1;
+				m[nxt][0] = lm_bit(s0, 2 * hn);
+				m[nxt][1] = lm_bit(s1, 2 * hn);
+				m[nxt][2] = lm_bit(s0, 2 * hn + 1);
+				m[nxt][3] = lm_bit(s1, 2 * hn + 1);
+			}
+#pragma unroll
+			for (int g = 0; g < 4; g++) {
+				__builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+				__builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+			}
+			x0 = nx0;
+			x1 = nx1;
+		}
+		uint32_t p0 = 0, p1 = 0;
+#pragma unroll
+		for (int r = 0; r < 16; r++) {
+			p0 |= ((uint32_t)(int)acc0[r] & 1u) << ((r & 3) + 8 * (r >> 2));
+			p1 |= ((uint32_t)(int)acc1[r] & 1u) << ((r & 3) + 8 * (r >> 2));
+		}
+		p0 <<= 4 * kh;
+		p1 <<= 4 * kh;
+		const uint32_t give = kh ? p0 : p1, keep = kh ? p1 : p0;
+		const uint32_t word = keep | (uint32_t)__shfl_xor((int)give, 32, 64);
+		const uint64_t col = (blockIdx.x + j * gridDim.x) * 64 + lane;
+		out[col * 4 + wave] = word;
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+	}
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 template <int IOTA>
 hipError_t linmap_prep(hipStream_t s, const void *vec, uint32_t steps, void *A)
 {
@@ -345,6 +456,35 @@ hipError_t launch_fold_right_mfma(hipStream_t s, int n_cu, const void *mat, uint
 	case 512: hipLaunchKernelGGL(k_linmap<2>, grid, dim3(256), 0, s, (const char *)mat, (const uint4 *)d_table, (uint32_t *)out, out_len); break;
 	case 1024: hipLaunchKernelGGL(k_linmap<4>, grid, dim3(256), 0, s, (const char *)mat, (const uint4 *)d_table, (uint32_t *)out, out_len); break;
 	default: hipLaunchKernelGGL(k_linmap<8>, grid, dim3(256), 0, s, (const char *)mat, (const uint4 *)d_table, (uint32_t *)out, out_len); break;
+	}
+	return hipGetLastError();
+}
+
+// fold_left on the matrix cores: B32 entries, vec_len = 16, 32 or 64 (gathered rows of 512 / 1024 / 2048 bits)
+hipError_t launch_fold_left_mfma(hipStream_t s, int n_cu, const void *mat, uint32_t tower_level, const void *vec, uint64_t vec_len, void *out,
+                                 uint64_t out_len, void *d_table)
+{
+	static const bool on = [] {
+		const char *e = getenv("BN_FOLD_MFMA");
+		return !(e && e[0] == '0');
+	}();
+	if (!on || !d_table || tower_level != 5 || out_len < 4096 || (out_len & 63) || (vec_len != 16 && vec_len != 32 && vec_len != 64)) return hipErrorNotSupported;
+	const uint32_t steps = (uint32_t)(vec_len * 32 / 64);
+	hipError_t e = linmap_prep<5>(s, vec, steps, d_table);
+	if (e != hipSuccess) return e;
+	const uint64_t n_pairs = out_len / 64, cap = (uint64_t)n_cu * 2;
+	const dim3 grid((unsigned)(n_pairs < cap ? n_pairs : cap));
+	const size_t lds = (size_t)4 * vec_len * 256;
+	static const hipError_t a2 = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_linmap_ring_left<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 16 * 256);
+	static const hipError_t a4 = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_linmap_ring_left<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32 * 256);
+	static const hipError_t a8 = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_linmap_ring_left<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 256);
+	if (a2 != hipSuccess) return a2;
+	if (a4 != hipSuccess) return a4;
+	if (a8 != hipSuccess) return a8;
+	switch (vec_len) {
+	case 16: hipLaunchKernelGGL(k_linmap_ring_left<2>, grid, dim3(256), lds, s, (const uint32_t *)mat, (const uint4 *)d_table, (uint32_t *)out, out_len); break;
+	case 32: hipLaunchKernelGGL(k_linmap_ring_left<4>, grid, dim3(256), lds, s, (const uint32_t *)mat, (const uint4 *)d_table, (uint32_t *)out, out_len); break;
+	default: hipLaunchKernelGGL(k_linmap_ring_left<8>, grid, dim3(256), lds, s, (const uint32_t *)mat, (const uint4 *)d_table, (uint32_t *)out, out_len); break;
 	}
 	return hipGetLastError();
 }

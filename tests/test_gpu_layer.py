@@ -276,6 +276,26 @@ def test_fold_right_on_the_matrix_cores(hal, oracle, level, log_q, log_out):
     assert (hal.copy_d2h(guard)[:, 0] == 0x77).all()
 
 
+@pytest.mark.parametrize("log_q", [4, 5, 6])
+@pytest.mark.parametrize("log_out", [12, 15])
+def test_fold_left_on_the_matrix_cores(hal, oracle, log_q, log_out):
+    """fold_left with B32 entries and 16, 32 or 64 vector elements: the gathered rows through csrc/kernels_linmap.hip."""
+    alloc = hal.dev_alloc()
+    level = 5
+    log_evals = log_out + log_q
+    mat = rnd(oracle, 360 + log_q, (1 << log_evals) >> (7 - level))
+    vec = rnd(oracle, 361 + log_q, 1 << log_q)
+    out_len = 1 << log_out
+    dm, dv, do = upload(hal, alloc, mat), upload(hal, alloc, vec), alloc.alloc(out_len)
+    guard = alloc.alloc(8)
+    hal.fill(guard, 0x66)
+    exp = oracle.arr(out_len)
+    hal.fold_left(dm, level, dv, do)
+    assert oracle.fold_left(mat, level, vec, exp) == 0
+    assert np.array_equal(hal.copy_d2h(do), exp)
+    assert (hal.copy_d2h(guard)[:, 0] == 0x66).all()
+
+
 def test_fold_validation(hal):
     import binius_amd
 
