@@ -15,7 +15,7 @@ for f in glob.glob(out + "/raw/**/*kernel_stats.csv", recursive=True):
 rows = []
 for f in glob.glob(out + "/raw/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void ", ""), r.get("Grid_Size_X", r.get("Grid_Size", ""))))
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", ""), r.get("Grid_Size_X", r.get("Grid_Size", ""))))
 rows.sort()
 with open(out + "/per_launch.jsonl", "w") as g:
     for s, d, k, grid in rows[-200:]:
