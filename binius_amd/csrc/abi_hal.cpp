@@ -323,6 +323,15 @@ int bn_hal_round_evals(bn_ctx *ctx, uint32_t order, uint32_t n_vars, const void 
 		const size_t temps_off = (tr_elems + row_elems) * sizeof(f128);
 		std::vector<std::vector<const void *>> row(pt_hi, std::vector<const void *>(n_mls, nullptr));
 		size_t next_row = 0;
+		bn::hal_rows_args ra{};
+		ra.order = order;
+		ra.half = half;
+		ra.n_out = half;
+		auto flush_rows = [&]() -> int {
+			if (ra.n_jobs) BN_HIP(bn::launch_hal_rows(ctx->stream, ctx->n_cu, ra));
+			ra.n_jobs = 0;
+			return BN_OK;
+		};
 		for (uint32_t p = pt_lo; p < pt_hi; p++) {
 			bool wanted = false;
 			for (uint32_t e = 0; e < n_evs; e++) wanted = wanted || (p >= evs[e].eval_point_start && p < evs[e].eval_point_end);
@@ -334,10 +343,24 @@ int bn_hal_round_evals(bn_ctx *ctx, uint32_t order, uint32_t n_vars, const void 
 					row[p][k] = (const char *)a.ml[k].evals + (p ? half * 16 : 0); // the half itself
 					continue;
 				}
-				BN_HIP(bn::launch_hal_row(ctx->stream, ctx->n_cu, a.ml[k].evals, a.ml[k].len, a.ml[k].suffix, order, half, p, p >= 3 ? a.pts[p - 3] : f128{0, 0}, dst,
-				                          half));
+				// (all the rows of the request in one launch, kernels_hal.hip k_hal_rows)
+				auto &jb = ra.jobs[ra.n_jobs++];
+				jb.evals = a.ml[k].evals;
+				jb.out = (uint4 *)dst;
+				jb.len = a.ml[k].len;
+				jb.suffix = a.ml[k].suffix;
+				jb.z = p >= 3 ? a.pts[p - 3] : f128{0, 0};
+				jb.point = p;
 				row[p][k] = dst;
+				if (ra.n_jobs == (uint32_t)bn::kHalMaxRows) {
+					int rc = flush_rows();
+					if (rc) return rc;
+				}
 			}
+		}
+		{
+			int rc = flush_rows();
+			if (rc) return rc;
 		}
 		uint32_t idx = 0;
 		for (uint32_t e = 0; e < n_evs; e++)

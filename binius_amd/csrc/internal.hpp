@@ -415,6 +415,20 @@ hipError_t launch_hal_fold_lerp(hipStream_t s, int n_cu, const void *evals, uint
                                 void *out, uint64_t n_out);
 // rows of the general round calculation (abi_hal.cpp): out[i] = the multilinear's value at evaluation point `point` of pair i
 // -- 0: e0, 1: e1, 2 (infinity): e0 + e1, otherwise e0 + z (e0 + e1) --, pairs taken as in launch_hal_fold_lerp
+// the same for up to kHalMaxRows (multilinear, point) pairs in one launch
+constexpr int kHalMaxRows = 24;
+struct hal_rows_args {
+	struct job {
+		const uint4 *evals;
+		uint4 *out;
+		uint64_t len;
+		f128 suffix, z;
+		uint32_t point;
+	} jobs[kHalMaxRows];
+	uint32_t n_jobs, order;
+	uint64_t half, n_out;
+};
+hipError_t launch_hal_rows(hipStream_t s, int n_cu, const hal_rows_args &a);
 hipError_t launch_hal_row(hipStream_t s, int n_cu, const void *evals, uint64_t len, f128 suffix, uint32_t order, uint64_t half, uint32_t point, f128 z,
                           void *out, uint64_t n_out);
 

@@ -148,6 +148,42 @@ __global__ __launch_bounds__(256) void k_hal_row(const uint4 *evals, uint64_t le
 	}
 }
 
+// All the rows of a general round calculation in ONE launch (blockIdx.y = job): at 2^19 points a row is a few microseconds
+// of kernel behind as many of launch, and a request with three multilinears and three points has six of them.
+__global__ __launch_bounds__(256) void k_hal_rows(hal_rows_args a)
+{
+	__shared__ ctable_smem tab;
+	const hal_rows_args::job j = a.jobs[blockIdx.y];
+	if (j.point > 2) ctable_build(tab, j.z); // (uniform per workgroup)
+	const uint4 sfx = to_u4(j.suffix);
+	for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < a.n_out; i += (uint64_t)gridDim.x * 256) {
+		const uint64_t i0 = a.order == BN_ORDER_LOW_TO_HIGH ? 2 * i : i;
+		const uint64_t i1 = a.order == BN_ORDER_LOW_TO_HIGH ? 2 * i + 1 : i + a.half;
+		uint4 r;
+		if (j.point == 0) {
+			r = i0 < j.len ? j.evals[i0] : sfx;
+		} else if (j.point == 1) {
+			r = i1 < j.len ? j.evals[i1] : sfx;
+		} else {
+			const uint4 x0 = i0 < j.len ? j.evals[i0] : sfx;
+			const uint4 x1 = i1 < j.len ? j.evals[i1] : sfx;
+			r = xor4(x0, x1);
+			if (j.point > 2) r = xor4(x0, ctable_mul_pinned<8>(tab, r));
+		}
+		j.out[i] = r;
+	}
+}
+
+hipError_t launch_hal_rows(hipStream_t s, int n_cu, const hal_rows_args &a)
+{
+	if (a.n_jobs == 0 || a.n_out == 0) return hipSuccess;
+	uint64_t blocks = (a.n_out + 255) / 256;
+	const uint64_t cap = ((uint64_t)n_cu * 8 + a.n_jobs - 1) / a.n_jobs;
+	if (blocks > cap) blocks = cap ? cap : 1;
+	hipLaunchKernelGGL(k_hal_rows, dim3((unsigned)blocks, a.n_jobs), dim3(256), 0, s, a);
+	return hipGetLastError();
+}
+
 hipError_t launch_hal_row(hipStream_t s, int n_cu, const void *evals, uint64_t len, f128 suffix, uint32_t order, uint64_t half, uint32_t point, f128 z,
                           void *out, uint64_t n_out)
 {
