@@ -35,10 +35,13 @@ def _worker(rank, world, port, n_global, m, comps, q, exchange="shm"):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    if world >= 8:
+    if world >= 4:
         # Ranks that SHARE a device must not arm rounds (csrc/arm.hpp): an armed kernel waits on the device for its
-        # challenge, and eight processes' worth of waiting workgroups leave no compute units for the kernels whose results
-        # those challenges depend on (on a node every rank has its own device and the question does not arise).
+        # challenge, and several processes' worth of waiting workgroups leave no compute units for the kernels whose results
+        # those challenges depend on (on a node every rank has its own device and the question does not arise).  Eight ranks
+        # time out outright; four ranks with matrix-core rounds armed (512 waiting workgroups each on 512 slots) get through on
+        # the kernels' bounded spins, and on a slow box not always inside the exchange's own bound (seen once in a full run of
+        # the suite): they run unarmed as well, as `bench.py` does for ranks that share a device.  Two ranks keep the armed rounds.
         os.environ["BN_ARM"] = "0"
     import torch
     import torch.distributed as dist
