@@ -21,8 +21,10 @@
 //  * Parity of the counts = the output bits; the two lane halves of a row are merged with one DPP-free shuffle and every wave
 //    stores its limb of the 32 rows.
 //
-// 2^20 rows x 2048 bits: 4.2 M MFMAs = 60 us of matrix pipe; measured 104 us + 5 us for the table (k_linmap_ring) against 134 us
-// for the nibble-table kernel, which is bound by the LDS bandwidth of its 8 lookups per 32-bit entry.
+// 2^20 rows x 2048 bits: 4.2 M MFMAs = 4096 per SIMD.  tools/mfma_issue_fp4.hip puts this instruction at 18 - 20 ns back to back on
+// random operands (two waves per SIMD) and at 21.7 ns with eight bitwise VALU instructions per MFMA, this kernel's mix: 74 and 89 us.
+// Measured: 104 us + 5 us for the table (k_linmap_ring) against 134 us for the nibble-table kernel, which is bound by the LDS
+// bandwidth of its 8 lookups per 32-bit entry.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -161,8 +163,8 @@ __global__ __launch_bounds__(256, 2) void k_linmap(const char *__restrict__ mat,
 // per block and wave) operations outstanding, output stores included -- which leaves about four blocks in flight.
 // ABL (measurement builds only): bit 0 = no MFMAs, bit 1 = no loads (the ring keeps whatever it holds), bit 2 = no barrier.
 // At 2^20 rows x 2048 bits (profiles/r04/experiments/linmap_ablation.txt): 104 us as shipped; 49 without the MFMAs; 101 without the
-// loads; 39 without both; 97 without loads and barrier -- the matrix pipe's 60 us and the VALU's 39 us ADD UP: operand masks and
-// MFMAs of the two waves of a SIMD do not overlap here the way ten VALU instructions hide under an int8 MFMA in the Gram kernels.
+// loads; 39 without both; 97 without loads and barrier: neither the memory system nor the barrier holds the kernel, the matrix
+// pipe with its ~8 VALU instructions per MFMA does (89 us by tools/mfma_issue_fp4.hip, profiles/r04/experiments/mfma_issue_fp4.txt).
 template <int T, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void k_linmap_ring(const char *__restrict__ mat, const uint4 *__restrict__ A, uint32_t *__restrict__ out,
                                                         uint64_t n_rows)

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256, WAVES) void k(uint32_t *out, int iters)
 	for (int i = 0; i < 9; i++)
 #pragma unroll
 		for (int r = 0; r < 16; r++)
-			s ^= __builtin_bit_cast(uint32_t, acc[i][r]);
+			s += (uint32_t)(int)acc[i][r];
 	out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
