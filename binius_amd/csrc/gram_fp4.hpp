@@ -24,9 +24,10 @@ struct stage4_role {
 	unsigned st_off;  // word offset of this lane's word inside a (set, limb) group: k-step, nibble index, point group
 	unsigned st_off3; // the same inside a (set, limb pair) group of bit-3 words (rotated by half a block, see make_gram4_role)
 };
-__device__ __forceinline__ stage4_role make_stage4_role()
+// tid: index of the lane among the 256 staging lanes of the tile (the workgroup's threads in kernels_roundeval_fp4.hip; the
+// fold waves' lanes in kernels_foldeval_fp4.hip)
+__device__ __forceinline__ stage4_role make_stage4_role(unsigned tid)
 {
-	const unsigned tid = threadIdx.x;
 	const unsigned j = tid & 7, jj = j < 4 ? j : 7 - j;
 	stage4_role r;
 	r.sel1 = j < 4 ? 0x05040100u : 0x03020706u;
@@ -43,6 +44,8 @@ __device__ __forceinline__ stage4_role make_stage4_role()
 	r.st_off3 = (g >> 3) * 64 + (((cidx + 4) & 7) + 8 * (gq >> 2)) * 4 + (gq & 3);
 	return r;
 }
+
+__device__ __forceinline__ stage4_role make_stage4_role() { return make_stage4_role(threadIdx.x); }
 
 // word x of this lane's point -> the word whose nibble i is nibble c(j) of x in the i-th lane (fixed order) of the
 // group of eight; c(j) = [0, 2, 1, 3, 7, 5, 6, 4][j]
@@ -153,10 +156,8 @@ __device__ __forceinline__ void gram4_tile(const uint32_t *T, const gram4_role &
 
 // parity bits out of the f32 accumulators, then the common tail.  Register r of a tile is row (r & 3) + 8 (r >> 2) +
 // 4 (lane >> 5): its bit position inside the nibble is r & 3; tile t = 2 s + i has rows from an even (i = 0) or odd limb.
-__device__ __forceinline__ void tail4(const v16f (&acc)[kAccTiles], const gram4_role &g, unsigned wave, unsigned lane, f128 *out,
-                                      const fin_fuse &fz, uint64_t seq, const fin_cache *fc = nullptr)
+__device__ __forceinline__ void parity4(const v16f (&acc)[kAccTiles], const gram4_role &g, unsigned wave, unsigned lane, gram_parity &Gc)
 {
-	__shared__ gram_parity Gc;
 #pragma unroll
 	for (int t = 0; t < kAccTiles; t++) {
 		uint32_t v = 0;
@@ -169,6 +170,12 @@ __device__ __forceinline__ void tail4(const v16f (&acc)[kAccTiles], const gram4_
 		}
 		Gc[wave][t][lane] = v;
 	}
+}
+__device__ __forceinline__ void tail4(const v16f (&acc)[kAccTiles], const gram4_role &g, unsigned wave, unsigned lane, f128 *out,
+                                      const fin_fuse &fz, uint64_t seq, const fin_cache *fc = nullptr)
+{
+	__shared__ gram_parity Gc;
+	parity4(acc, g, wave, lane, Gc);
 	tail_finish(Gc, wave, lane, out, fz, seq, fc);
 }
 

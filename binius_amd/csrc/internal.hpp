@@ -340,6 +340,11 @@ struct foldeval_args {
 };
 bool foldeval9_is_small(int n_cu, uint64_t n_in);
 struct arm_args; // arm.hpp: non-null = an armed launch (z and hi_scale arrive through the command block)
+// kernels_foldeval_fp4.hip: the fused fold + evaluation with fold waves and FP4 Gram waves (plain fold, whole tiles)
+struct fin_fuse;
+bool foldeval_fp4_applies(int n_cu, const foldeval_args &fa, uint64_t n_in);
+hipError_t launch_foldeval_fp4(hipStream_t s, int n_cu, const foldeval_args &fa, uint64_t n_in, f128 z, f128 *d_out, const fin_fuse &fz,
+                               const arm_args &arm, bool nt);
 hipError_t launch_foldeval9(hipStream_t s, int n_cu, const foldeval_args &fa, uint64_t n_in, f128 z, f128 *d_out, const fin_fuse *fuse,
                             const arm_args *armed = nullptr);
 hipError_t launch_foldeval_tail(hipStream_t s, const foldeval_args &fa, uint64_t n_in, f128 z, f128 *d_out, const fin_fuse &fz,

@@ -249,6 +249,8 @@ hipError_t launch_foldeval_mfma(hipStream_t s, int n_cu, const foldeval_args &fa
 		return e ? atoi(e) : 25;
 	}();
 	const bool nt = full && nt_min_log2 < 64 && n_in >= (1ull << nt_min_log2);
+	// whole tiles, plain fold, at least a tile per CU: the wave-specialised FP4 form (kernels_foldeval_fp4.hip)
+	if (foldeval_fp4_applies(n_cu, fx, n_in)) return launch_foldeval_fp4(s, n_cu, fx, n_in, z, d_out, fz, arm, nt);
 #define BN_FE_LAUNCH(SC)                                                                                                       \
 	if (nt)                                                                                                                    \
 		hipLaunchKernelGGL((k_foldeval_mfma<SC, true, true>), grid, dim3(256), 0, s, fx, n_in, z, d_out, fz, arm);             \
