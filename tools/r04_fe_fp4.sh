@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-.}
 O=$R/gpurun_out/fe_fp4
 mkdir -p $O
 cd $R
-timeout 900 python -m pytest tests/test_gpu_north_star.py tests/test_gpu_sumcheck.py tests/test_gpu_lazy_vs_eager.py tests/test_gpu_at_size.py -m gpu -x -q > $O/tests.txt 2>&1
+timeout 900 python -m pytest tests/test_gpu_north_star.py tests/test_gpu_sumcheck.py tests/test_gpu_lazy_vs_eager.py tests/test_gpu_at_size.py tests/test_gpu_layer.py -m gpu -x -q > $O/tests.txt 2>&1
 tail -3 $O/tests.txt
 one() { # name, env..., -- bench args
   local name=$1; shift
@@ -18,14 +18,14 @@ print('$name', 'ms_per_step', round(d['ms_per_step'],4), 'roofline', round(d['ro
 }
 {
 for rep in 1 2; do
-  one "n=28 fp4" X=1 -- --n-vars 28 --steps 10 --warmup 3
-  one "n=28 int8" BN_FE_FP4=0 -- --n-vars 28 --steps 10 --warmup 3
-  one "n=28 fp4>=25" BN_FE_FP4_MIN_LOG2=25 -- --n-vars 28 --steps 10 --warmup 3
-  for n in 20 24 25; do
-    one "n=$n fp4" X=1 -- --n-vars $n --steps 20 --warmup 3
-    one "n=$n int8" BN_FE_FP4=0 -- --n-vars $n --steps 20 --warmup 3
-    one "n=$n fp4>=22" BN_FE_FP4_MIN_LOG2=22 -- --n-vars $n --steps 20 --warmup 3
+  one "n=28 ws" X=1 -- --n-vars 28 --steps 10 --warmup 3
+  one "n=28 r0 old" BN_FP4_WS=0 -- --n-vars 28 --steps 10 --warmup 3
+  one "n=28 both old" BN_FP4_WS=0 BN_FE_FP4=0 -- --n-vars 28 --steps 10 --warmup 3
+  for n in 22 24 25; do
+    one "n=$n ws" X=1 -- --n-vars $n --steps 20 --warmup 3
+    one "n=$n r0 old" BN_FP4_WS=0 -- --n-vars $n --steps 20 --warmup 3
+    one "n=$n both old" BN_FP4_WS=0 BN_FE_FP4=0 -- --n-vars $n --steps 20 --warmup 3
   done
 done
 } > $O/step_times.txt 2>&1
-cat $O/step_times.txt
+cut -c1-330 $O/step_times.txt
