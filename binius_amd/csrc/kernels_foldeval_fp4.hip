@@ -17,7 +17,7 @@
 // T[(i - 1) & 1] -- each kind of wave has 168 registers for its own job alone, a SIMD's issue slots go to two VALU
 // streams and one MFMA stream, and one workgroup barrier per pair hands the tiles over.
 //
-// Only the plain fold (no hi_scale) on whole tiles; everything else stays with kernels_foldeval_mfma.hip.
+// Whole tiles, at least two per CU; everything else stays with kernels_foldeval_mfma.hip.
 // Algorithmic bytes: read 16*m*N + write 8*m*N = 24*m*N per launch.
 #include <hip/hip_runtime.h>
 
@@ -66,11 +66,14 @@ constexpr unsigned kThreads = 64 * kGramWaves * (1 + kFoldGroups);
 // threads, a tile per iteration -- was built first and is latency-bound: a single wave issues a dependent VALU instruction every
 // ~4.7 cycles and waits out every group of table reads alone; 0.546 of the HBM peak against 0.556 for kernels_foldeval_mfma.hip
 // on the same box, profiles/r04/experiments/fe_fp4_v1.txt.)
-template <bool NT>
+// SC: 0 = plain fold; 1 / 2 = the upper half of folded array 0 / 1 is multiplied by fa.hi_scale (a fifth constant multiplication
+// per point, through a second nibble table) before it is stored and staged (bn_extrapolate_line_batch_scaled).
+template <int SC, bool NT>
 __global__ __launch_bounds__(kThreads, 1) void k_foldeval_mfma_fp4(foldeval_args fa, uint64_t n_in, f128 z, f128 *out, fin_fuse fz, arm_args arm)
 {
 	extern __shared__ __attribute__((aligned(16))) uint32_t T_dyn[]; // 2 buffers x 2 tiles of FP4 operands
 	__shared__ ctable_smem tab;
+	__shared__ ctable_opt<SC != 0> tab_hs;
 	__shared__ fin_cache fcache;
 	__shared__ gram_parity Gc;
 	const uint64_t seq = fz.args.seq;
@@ -111,8 +114,14 @@ __global__ __launch_bounds__(kThreads, 1) void k_foldeval_mfma_fp4(foldeval_args
 		if (arm.h_cmd) { // (uniform) armed launch of a mid-size round: the challenge arrives through the command block (arm.hpp)
 			f128 hs_in;
 			if (!arm_wait(arm, z, hs_in)) return;
+			fa.hi_scale = hs_in;
 		}
-		ctable_build(tab, z); // the loads above are in flight meanwhile; ends with a barrier
+		if constexpr (SC != 0) { // both tables side by side (two groups of 128 threads): a build is one dependent chain
+			const unsigned g2 = threadIdx.x >> 7;
+			ctable_build_group(g2 == 1 ? tab_hs.get() : tab, g2 == 1 ? fa.hi_scale : z, g2 < 2 ? (threadIdx.x & 127) : 512u, 128);
+		} else {
+			ctable_build(tab, z); // the loads above are in flight meanwhile; ends with a barrier
+		}
 		fin_commit(fz, fpre, fcache);
 	}
 
@@ -131,6 +140,9 @@ __global__ __launch_bounds__(kThreads, 1) void k_foldeval_mfma_fp4(foldeval_args
 				for (int k = 0; k < 4; k++) {
 					f[k] = ctable_mul_acc<8, true>(tab, xor4(x0[k], x1[k]), x0[k]);
 					load1(tn, k); // this quadrant of the group's next tile flies from here on
+					if constexpr (SC != 0) {
+						if (k == 2 * SC - 1) f[k] = ctable_mul_pinned<8>(tab_hs.get(), f[k]);
+					}
 				}
 #pragma unroll
 				for (int k = 0; k < 4; k++)
@@ -169,9 +181,9 @@ bool foldeval_fp4_applies(int n_cu, const foldeval_args &fa, uint64_t n_in)
 		const char *e = getenv("BN_FE_FP4");
 		if (e && e[0] == '0') return 64;
 		const char *m = getenv("BN_FE_FP4_MIN_LOG2");
-		return m ? atoi(m) : 22;
+		return m ? atoi(m) : 0;
 	}();
-	if (min_log2 >= 64 || fa.scale_mask != 0 || n_in < 4 || (n_in & 3)) return false;
+	if (min_log2 >= 64 || fa.scale_mask > 2 || n_in < 4 || (n_in & 3)) return false;
 	const uint64_t n = n_in >> 2;
 	if (n % kTP) return false;
 	const uint64_t n_tiles = n / kTP;
@@ -187,15 +199,27 @@ hipError_t launch_foldeval_fp4(hipStream_t s, int n_cu, const foldeval_args &fa,
 	const unsigned grid = (unsigned)(n_tiles < (uint64_t)n_cu ? n_tiles : (uint64_t)n_cu);
 	constexpr unsigned lds = 2 * kFoldGroups * kTile4W * 4;
 	static const hipError_t attr = [] {
-		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_foldeval_mfma_fp4<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-		if (e != hipSuccess) return e;
-		return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_foldeval_mfma_fp4<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+		const void *fn[6] = {reinterpret_cast<const void *>(&k_foldeval_mfma_fp4<0, false>), reinterpret_cast<const void *>(&k_foldeval_mfma_fp4<0, true>),
+		                     reinterpret_cast<const void *>(&k_foldeval_mfma_fp4<1, false>), reinterpret_cast<const void *>(&k_foldeval_mfma_fp4<1, true>),
+		                     reinterpret_cast<const void *>(&k_foldeval_mfma_fp4<2, false>), reinterpret_cast<const void *>(&k_foldeval_mfma_fp4<2, true>)};
+		for (const void *f : fn) {
+			const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+			if (e != hipSuccess) return e;
+		}
+		return hipSuccess;
 	}();
 	if (attr != hipSuccess) return attr;
-	if (nt)
-		hipLaunchKernelGGL((k_foldeval_mfma_fp4<true>), dim3(grid), dim3(kThreads), lds, s, fa, n_in, z, d_out, fz, arm);
-	else
-		hipLaunchKernelGGL((k_foldeval_mfma_fp4<false>), dim3(grid), dim3(kThreads), lds, s, fa, n_in, z, d_out, fz, arm);
+#define BN_FQ_LAUNCH(SC)                                                                                                       \
+	if (nt)                                                                                                                    \
+		hipLaunchKernelGGL((k_foldeval_mfma_fp4<SC, true>), dim3(grid), dim3(kThreads), lds, s, fa, n_in, z, d_out, fz, arm);  \
+	else                                                                                                                       \
+		hipLaunchKernelGGL((k_foldeval_mfma_fp4<SC, false>), dim3(grid), dim3(kThreads), lds, s, fa, n_in, z, d_out, fz, arm);
+	switch (fa.scale_mask) {
+	case 0: BN_FQ_LAUNCH(0) break;
+	case 1: BN_FQ_LAUNCH(1) break;
+	default: BN_FQ_LAUNCH(2) break;
+	}
+#undef BN_FQ_LAUNCH
 	return hipGetLastError();
 }
 

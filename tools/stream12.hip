@@ -121,6 +121,31 @@ __global__ __launch_bounds__(256, WGS) void k_s6(sargs a)
 		}
 	}
 }
+// the round-0 pattern: every element of both arrays read once, as four streams x[k][p], x[k][p + N/2] (no stores)
+template <int W, bool NT, int WGS>
+__global__ __launch_bounds__(256, WGS) void k_r4(sargs a)
+{
+	const uint64_t h = 2 * a.n, n_tiles = h / (256 * W);
+	uint64_t tbase = 0, tstride = gridDim.x, tlimit = n_tiles, t0 = blockIdx.x;
+	if (a.order == 1) {
+		const uint64_t chunk = (n_tiles + 7) >> 3;
+		tbase = (blockIdx.x & 7) * chunk;
+		tstride = gridDim.x >> 3;
+		t0 = blockIdx.x >> 3;
+		tlimit = tbase >= n_tiles ? 0 : (n_tiles - tbase < chunk ? n_tiles - tbase : chunk);
+	}
+	v4u acc = {0, 0, 0, 0};
+	for (uint64_t t = t0; t < tlimit; t += tstride) {
+#pragma unroll
+		for (int w = 0; w < W; w++) {
+			const uint64_t p = ((tbase + t) * W + w) * 256 + threadIdx.x;
+#pragma unroll
+			for (int k = 0; k < 2; k++)
+				acc ^= ld<NT>(&a.x[k][p]) ^ ld<NT>(&a.x[k][p + h]);
+		}
+	}
+	if (acc.x == 0x12345 && acc.y == 0x777) a.out[0][0] = acc;
+}
 __global__ void k_copy(v4u *__restrict__ d, const v4u *__restrict__ s, uint64_t n)
 {
 	for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) d[i] = s[i];
@@ -171,6 +196,22 @@ int main(int argc, char **argv)
 	const double B = 48.0 * N; // 24 * m * N
 	timeit("copy 2 GiB-class (x1 <- x0), 2048 wgs", [&] { hipLaunchKernelGGL(k_copy, dim3(2048), dim3(256), 0, 0, x[1], x[0], N); }, 32.0 * N);
 	timeit("read only, 2048 wgs", [&] { hipLaunchKernelGGL(k_read, dim3(2048), dim3(256), 0, 0, o[0], x[0], N); }, 16.0 * N);
+	if (argc > 2) { // round-0 pattern only
+		sargs a{};
+		a.x[0] = x[0];
+		a.x[1] = x[1];
+		a.out[0] = o[0];
+		a.out[1] = o[1];
+		a.n = N / 4;
+		char nm[128];
+#define RUNR4(W, NT, WGS, ORD)                                                                                                 \
+	a.order = ORD;                                                                                                             \
+	snprintf(nm, 128, "r4  W=%d NT=%d wgs/CU=%d order=%d", W, NT, WGS, ORD);                                                  \
+	timeit(nm, [&] { hipLaunchKernelGGL((k_r4<W, NT, WGS>), dim3(n_cu * WGS), dim3(256), 0, 0, a); }, 32.0 * N);
+		RUNR4(1, false, 2, 0) RUNR4(1, true, 2, 0) RUNR4(1, true, 2, 1) RUNR4(1, true, 4, 1) RUNR4(1, true, 8, 1) RUNR4(2, true, 4, 1) RUNR4(2, true, 8, 1)
+		RUNR4(4, true, 4, 1) RUNR4(4, true, 2, 1) RUNR4(4, true, 1, 1) RUNR4(2, true, 4, 0) RUNR4(1, false, 8, 1)
+		return 0;
+	}
 	for (int inplace = 0; inplace < 2; inplace++) {
 		sargs a{};
 		a.x[0] = x[0];
