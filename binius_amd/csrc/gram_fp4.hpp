@@ -70,8 +70,10 @@ __device__ __forceinline__ void stage4_elem(uint32_t *T, const stage4_role &sr, 
 	dst[2 * 256] = y2;
 	dst[3 * 256] = y3;
 	uint32_t *dw = T + kT4W + set * 512 + sr.st_off3;
-	dw[0] = ((y0 >> 1) & 0x44444444u) | ((y1 >> 2) & 0x22222222u);
-	dw[256] = ((y2 >> 1) & 0x44444444u) | ((y3 >> 2) & 0x22222222u);
+	// bit 3 of the even limb's nibbles at bit 2, of the odd limb's at bit 1 -- the only two bits the k-steps' masks keep of a bit-3
+	// word (make_gram4_role: 0x44444444 / 0x22222222), so whatever else the select drags along is never read: three instructions
+	dw[0] = __builtin_amdgcn_bitop3_b32(y0, y1 >> 1, 0x88888888u, 0xE4) >> 1; // ((y0 & m) | ((y1 >> 1) & ~m)) >> 1
+	dw[256] = __builtin_amdgcn_bitop3_b32(y2, y3 >> 1, 0x88888888u, 0xE4) >> 1;
 }
 
 struct gram4_role {
