@@ -45,6 +45,8 @@ tools/r04_ab2.sh > /dev/null 2>&1; cp $R/gpurun_out/ab2/times.txt $O/ab_ntt_regp
 { for v in 1 0 1 0; do echo "BN_FOLD_MFMA=$v"; BN_FOLD_MFMA=$v python tools/bench_ops.py 2>&1 | grep -E "fold_"; done; } > $O/ab_fold_mfma.txt 2>&1
 tools/trace_cmd.sh final/trace_fold python tools/run_fold_only.py > /dev/null 2>&1; tail -12 $O/trace_fold/per_launch.jsonl > $O/fold_per_launch.jsonl; rm -rf $O/trace_fold
 tools/r04_nt.sh > /dev/null 2>&1; cp $R/gpurun_out/nt/step_times.txt $O/ab_nt_step_times.txt
+# round 4, last step: the fused kernel's two forms
+tools/r04_fe_fp4.sh > /dev/null 2>&1; cp $R/gpurun_out/fe_fp4/step_times.txt $O/ab_fe_fp4.txt
 tools/trace_bench.sh final/trace_n28 --n-vars 28 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 tools/trace_bench.sh final/trace_n24 --n-vars 24 --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
 for t in trace_n28 trace_n24; do cp $O/$t/kernel_stats.csv $O/bench_${t#trace_}_kernel_stats.csv; cp $O/$t/per_launch.jsonl $O/per_launch_${t#trace_}.jsonl; cp $O/$t/bench_line.json $O/bench_${t#trace_}_under_rocprof.json; done

@@ -24,6 +24,10 @@ for rep in 1 2; do
     one "n=$n int8" BN_FE_FP4=0 -- --n-vars $n --steps 20 --warmup 3
   done
 done
-for v in 1 0 1 0; do echo "BN_FE_FP4=$v"; BN_FE_FP4=$v tools/bench_mlecheck_quick.sh 2>&1 | cut -c1-300; done
+for v in 1 0 1 0; do BN_FE_FP4=$v tools/bench_mlecheck_quick.sh 2>&1 | python -c "
+import sys, re
+for l in sys.stdin:
+    m = re.search(r'n_vars=(\d+).*\"prover\": \"(\w+)\", \"ms\": ([\d.]+)', l)
+    if m: print('MLE-check prove n_vars=%s m=2 %-8s BN_FE_FP4=$v: %s ms' % (m.group(1), m.group(2), m.group(3)))"; done
 } > $O/step_times.txt 2>&1
 cat $O/step_times.txt
