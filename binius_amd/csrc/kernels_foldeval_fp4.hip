@@ -87,7 +87,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_foldeval_mfma_fp4(foldeval_args
 
 	// tile order: see kernels_foldeval_mfma.hip (XCD x = blockIdx.x & 7 takes the x-th contiguous eighth of the tiles)
 	uint64_t tbase = 0, tstride = gridDim.x, tlimit = n_tiles, t0 = blockIdx.x;
-	if (fa.xcd_tiles && (gridDim.x & 7) == 0) {
+	if ((fa.xcd_tiles & 1) && (gridDim.x & 7) == 0) {
 		const uint64_t chunk = (n_tiles + 7) >> 3;
 		tbase = (blockIdx.x & 7) * chunk;
 		tstride = gridDim.x >> 3;
@@ -125,6 +125,16 @@ __global__ __launch_bounds__(kThreads, 1) void k_foldeval_mfma_fp4(foldeval_args
 		fin_commit(fz, fpre, fcache);
 	}
 
+	// The fold waves are the critical path of a pair (588 VALU instructions per tile against the Gram wave's 151 + 24 MFMAs): they issue
+	// ahead of the Gram wave of their SIMD (fa.xcd_tiles bits 1 .. 2 = their priority; 1.5 - 2.5 % on the n = 24 ... 28 steps, any level above the Gram waves' does it: experiments/fe_fp4_prio.txt).
+	if (folds) {
+		switch ((fa.xcd_tiles >> 1) & 3) {
+		case 1: __builtin_amdgcn_s_setprio(1); break;
+		case 2: __builtin_amdgcn_s_setprio(2); break;
+		case 3: __builtin_amdgcn_s_setprio(3); break;
+		default: break;
+		}
+	}
 	if (folds) {
 		const stage4_role sr = make_stage4_role(ftid);
 		uint32_t *Tn = T_dyn + grp * kTile4W;
@@ -192,9 +202,16 @@ bool foldeval_fp4_applies(int n_cu, const foldeval_args &fa, uint64_t n_in)
 	return (n_tiles + n_cu - 1) / n_cu <= (1ull << 14); // 2^22 points per workgroup: the f32 counts stay exact
 }
 
-hipError_t launch_foldeval_fp4(hipStream_t s, int n_cu, const foldeval_args &fa, uint64_t n_in, f128 z, f128 *d_out, const fin_fuse &fz,
+hipError_t launch_foldeval_fp4(hipStream_t s, int n_cu, const foldeval_args &fa_in, uint64_t n_in, f128 z, f128 *d_out, const fin_fuse &fz,
                                const arm_args &arm, bool nt)
 {
+	// BN_FE_FP4_PRIO=0 .. 3: issue priority of the fold waves (default 3; the Gram waves stay at 0)
+	static const uint32_t prio = [] {
+		const char *e = getenv("BN_FE_FP4_PRIO");
+		return e ? (uint32_t)atoi(e) & 3u : 3u;
+	}();
+	foldeval_args fa = fa_in;
+	fa.xcd_tiles = (fa.xcd_tiles & 1u) | (prio << 1);
 	const uint64_t n_tiles = (n_in >> 2) / kTP;
 	const unsigned grid = (unsigned)(n_tiles < (uint64_t)n_cu ? n_tiles : (uint64_t)n_cu);
 	constexpr unsigned lds = 2 * kFoldGroups * kTile4W * 4;

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256, 3) void k_roundeval_fp4(const uint4 *__restric
 	const uint64_t n_tiles_all = (n + kTP - 1) / kTP;
 	// tile order: XCD x = blockIdx.x & 7 takes the x-th contiguous eighth of the tiles (see kernels_foldeval_mfma.hip)
 	uint64_t tbase = 0, tstride = gridDim.x, n_tiles = n_tiles_all, t0 = blockIdx.x;
-	if (xcd_tiles && (gridDim.x & 7) == 0) {
+	if ((xcd_tiles & 1) && (gridDim.x & 7) == 0) {
 		const uint64_t chunk = (n_tiles_all + 7) >> 3;
 		tbase = (blockIdx.x & 7) * chunk;
 		tstride = gridDim.x >> 3;
@@ -131,10 +131,19 @@ __global__ __launch_bounds__(256, 3) void k_roundeval_fp4(const uint4 *__restric
 	}
 	for (; t < n_tiles; t += tstride) {
 		lds_barrier(); // the previous tile's k-steps are done with T
+		// the staging phase (VALU) issues ahead of the other workgroups' k-steps (matrix pipe): xcd_tiles bits 1 .. 2 = its priority
+		// (BN_FP4_PRIO; round 0 at n = 28 0.500 - 0.504 -> 0.529 - 0.532 of the roofline, experiments/fp4_prio.txt)
+		switch ((xcd_tiles >> 1) & 3) {
+		case 1: __builtin_amdgcn_s_setprio(1); break;
+		case 2: __builtin_amdgcn_s_setprio(2); break;
+		case 3: __builtin_amdgcn_s_setprio(3); break;
+		default: break;
+		}
 		stage4_elem(T, sr, 0, x[0]);
 		stage4_elem(T, sr, 2, MIX ? uint4{x[0].x ^ x[1].x, x[0].y ^ x[1].y, x[0].z ^ x[1].z, x[0].w ^ x[1].w} : x[1]);
 		stage4_elem(T, sr, 1, x[2]);
 		stage4_elem(T, sr, 3, MIX ? uint4{x[2].x ^ x[3].x, x[2].y ^ x[3].y, x[2].z ^ x[3].z, x[2].w ^ x[3].w} : x[3]);
+		if (xcd_tiles & 6) __builtin_amdgcn_s_setprio(0);
 		lds_barrier(); // T staged
 		gram4_tile(T, gr, acc);
 		take(t + tstride);
@@ -157,7 +166,8 @@ static hipError_t launch_fp4(hipStream_t s, int n_cu, const void *a_hi, const vo
 	if ((n_tiles + grid - 1) / grid > (1ull << 14)) return hipErrorNotSupported; // 2^22 points per workgroup: the f32 counts stay exact
 	static const uint32_t xcd_tiles = [] {
 		const char *e = getenv("BN_XCD_TILES");
-		return (uint32_t)!(e && e[0] == '0');
+		const char *p = getenv("BN_FP4_PRIO");
+		return (uint32_t)!(e && e[0] == '0') | (((p ? (uint32_t)atoi(p) : 2u) & 3u) << 1); // BN_FP4_PRIO=0 .. 3 (default 2)
 	}();
 	// BN_FP4_NT_MIN_LOG2: points from which the loads are non-temporal (measurement knob; 64 = never)
 	static const int nt_min_log2 = [] {
