@@ -1,8 +1,9 @@
 // binius_amd/csrc/gram_fp4.hpp -- the GF(2) Gram products of gram.hpp on the FP4 matrix path: operand encoding, staging
-// (nibble transpose), Gram k-steps and the parity read-out used by kernels_roundeval_fp4.hip (round evaluation alone).
-// The fused fold + evaluation kernel (kernels_foldeval_mfma.hip) runs its Gram part in int8 (gram.hpp): an FP4 form of it
-// was built and measured slower (61 - 85 spilled registers next to the constant multiplication) and is not
-// in the tree.  The design notes are at the top of kernels_roundeval_fp4.hip.
+// (nibble transpose), Gram k-steps and the parity read-out.  Used by kernels_roundeval_fp4.hip (round evaluation alone: every wave
+// stages and runs k-steps) and by kernels_foldeval_fp4.hip (fused fold + evaluation: fold waves stage, Gram waves run the k-steps).
+// The single-kind-of-wave fused kernel (kernels_foldeval_mfma.hip) runs its Gram part in int8 (gram.hpp): FP4 k-steps next to the
+// constant multiplication in ONE wave did not fit the register file.  The design notes are at the top of
+// kernels_roundeval_fp4.hip.
 #pragma once
 #include <hip/hip_runtime.h>
 

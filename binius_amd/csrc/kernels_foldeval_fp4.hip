@@ -213,7 +213,14 @@ hipError_t launch_foldeval_fp4(hipStream_t s, int n_cu, const foldeval_args &fa_
 	foldeval_args fa = fa_in;
 	fa.xcd_tiles = (fa.xcd_tiles & 1u) | (prio << 1);
 	const uint64_t n_tiles = (n_in >> 2) / kTP;
-	const unsigned grid = (unsigned)(n_tiles < (uint64_t)n_cu ? n_tiles : (uint64_t)n_cu);
+	// BN_FE_FP4_GRID=g (tests): g workgroups instead of one per CU -- on 256 CUs every size the prover reaches gives every workgroup
+	// an even number of tiles and the XCD-aware order; other grids exercise the odd last pair and the plain striding
+	static const unsigned grid_override = [] {
+		const char *e = getenv("BN_FE_FP4_GRID");
+		return e ? (unsigned)atoi(e) : 0u;
+	}();
+	unsigned grid = (unsigned)(n_tiles < (uint64_t)n_cu ? n_tiles : (uint64_t)n_cu);
+	if (grid_override && grid_override <= grid && (n_tiles + grid_override - 1) / grid_override <= (1ull << 14)) grid = grid_override;
 	constexpr unsigned lds = 2 * kFoldGroups * kTile4W * 4;
 	static const hipError_t attr = [] {
 		const void *fn[6] = {reinterpret_cast<const void *>(&k_foldeval_mfma_fp4<0, false>), reinterpret_cast<const void *>(&k_foldeval_mfma_fp4<0, true>),
