@@ -88,21 +88,33 @@ __global__ __launch_bounds__(kThreads, 1) void k_foldeval_mfma_fp4(foldeval_args
 	// tile order: see kernels_foldeval_mfma.hip (XCD x = blockIdx.x & 7 takes the x-th contiguous eighth of the tiles)
 	uint64_t tbase = 0, tstride = gridDim.x, tlimit = n_tiles, t0 = blockIdx.x;
 	if ((fa.xcd_tiles & 1) && (gridDim.x & 7) == 0) {
-		const uint64_t chunk = (n_tiles + 7) >> 3;
+		const uint32_t chunk = (uint32_t)((n_tiles + 7) >> 3);
 		tbase = (blockIdx.x & 7) * chunk;
 		tstride = gridDim.x >> 3;
 		t0 = blockIdx.x >> 3;
-		tlimit = tbase >= n_tiles ? 0 : (n_tiles - tbase < chunk ? n_tiles - tbase : chunk);
+		tlimit = tbase >= (uint32_t)n_tiles ? 0 : ((uint32_t)n_tiles - tbase < chunk ? (uint32_t)n_tiles - tbase : chunk);
 	}
 
 	// quadrant k = 2 * array + half: element index half * n + point
 	uint4 x0[4], x1[4];
-	auto load1 = [&](uint64_t t, int k) {
-		const uint64_t e = (k & 1 ? n : 0) + (tbase + t) * kTP + ftid;
-		x0[k] = fq_load<NT>((const uint4 *)fa.x0[k >> 1] + e);
-		x1[k] = fq_load<NT>((const uint4 *)fa.x1[k >> 1] + e);
+	// addresses = a uniform 64-bit base (array, half, tile: scalar registers and scalar arithmetic) + the lane's constant 32-bit byte
+	// offset: the loads and stores take the scalar-base form and the loop has no 64-bit vector address arithmetic (13 v_lshl_add_u64
+	// per tile and fold wave otherwise)
+	const uint32_t voff = ftid * 16u;
+	// (the empty asm keeps the compiler from folding the lane offset into a loop-invariant 64-bit vector base, which would bring the
+	// vector additions back)
+	auto lane_off = [&]() {
+		uint32_t v = voff;
+		asm volatile("" : "+v"(v));
+		return v;
 	};
-	const uint64_t tm0 = t0 + grp * tstride; // this fold group's first tile
+	uint32_t vo = lane_off();
+	auto load1 = [&](uint32_t t, int k) {
+		const uint64_t e = ((k & 1 ? n : 0) + (uint64_t)(tbase + t) * kTP) * 16; // (uniform)
+		x0[k] = fq_load<NT>(reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(fa.x0[k >> 1]) + e + vo));
+		x1[k] = fq_load<NT>(reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(fa.x1[k >> 1]) + e + vo));
+	};
+	const uint32_t tm0 = t0 + grp * tstride; // this fold group's first tile
 	if (folds && tm0 < tlimit) {
 #pragma unroll
 		for (int k = 0; k < 4; k++)
@@ -139,12 +151,13 @@ __global__ __launch_bounds__(kThreads, 1) void k_foldeval_mfma_fp4(foldeval_args
 		const stage4_role sr = make_stage4_role(ftid);
 		uint32_t *Tn = T_dyn + grp * kTile4W;
 		unsigned buf = 0;
-		for (uint64_t t = t0; t < tlimit; t += 2 * tstride) {
-			const uint64_t tm = t + grp * tstride;
+		for (uint32_t t = t0; t < tlimit; t += 2 * tstride) {
+			const uint32_t tm = t + grp * tstride;
 			if (tm < tlimit) { // (uniform; false only for group 1 on an odd last pair)
 				// the last iteration re-requests its own tile (cache hits) instead of branching around the loads
-				const uint64_t tn = tm + 2 * tstride < tlimit ? tm + 2 * tstride : tm;
-				const uint64_t pt = (tbase + tm) * kTP + ftid;
+				const uint32_t tn = tm + 2 * tstride < tlimit ? tm + 2 * tstride : tm;
+				vo = lane_off();
+				const uint64_t pt16 = (uint64_t)(tbase + tm) * kTP * 16; // (uniform)
 				uint4 f[4];
 #pragma unroll
 				for (int k = 0; k < 4; k++) {
@@ -156,7 +169,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_foldeval_mfma_fp4(foldeval_args
 				}
 #pragma unroll
 				for (int k = 0; k < 4; k++)
-					fq_store<NT>((uint4 *)fa.out[k >> 1] + ((k & 1 ? n : 0) + pt), f[k]);
+					fq_store<NT>(reinterpret_cast<uint4 *>(reinterpret_cast<char *>(fa.out[k >> 1]) + (k & 1 ? n * 16 : 0) + pt16 + vo), f[k]);
 				// half 1 is the evaluation at 1, half 0 its partner: sets 0 / 1 = u, v at 1; sets 2 / 3 = u, v at infinity
 				stage4_elem(Tn, sr, 0, f[1]);
 				stage4_elem(Tn, sr, 2, xor4(f[1], f[0]));
@@ -172,7 +185,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_foldeval_mfma_fp4(foldeval_args
 		v16f acc[kAccTiles];
 		acc4_zero(acc);
 		unsigned buf = 0;
-		for (uint64_t t = t0; t < tlimit; t += 2 * tstride) {
+		for (uint32_t t = t0; t < tlimit; t += 2 * tstride) {
 			__syncthreads();
 			const uint32_t *Tp = T_dyn + buf * kFoldGroups * kTile4W;
 			gram4_tile(Tp, gr, acc);
