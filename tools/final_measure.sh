@@ -47,6 +47,9 @@ tools/trace_cmd.sh final/trace_fold python tools/run_fold_only.py > /dev/null 2>
 tools/r04_nt.sh > /dev/null 2>&1; cp $R/gpurun_out/nt/step_times.txt $O/ab_nt_step_times.txt
 # round 4, last step: the fused kernel's two forms
 tools/r04_fe_fp4.sh > /dev/null 2>&1; cp $R/gpurun_out/fe_fp4/step_times.txt $O/ab_fe_fp4.txt
+# counters of the two large kernels at one size each (instruction mix, pipe-busy cycles)
+tools/pmc_fused.sh 27 > /dev/null 2>&1; cp $R/gpurun_out/pmc_fused/summary.json $O/fused_fp4_pmc_2p27.json; cp $R/gpurun_out/pmc_fused/kernel_stats.csv $O/fused_fp4_2p27_kernel_stats.csv
+tools/pmc_round0.sh 27 > /dev/null 2>&1; cp $R/gpurun_out/pmc_round0/summary.json $O/round0_fp4_pmc_2p27.json; cp $R/gpurun_out/pmc_round0/kernel_stats.csv $O/round0_fp4_2p27_kernel_stats.csv
 tools/trace_bench.sh final/trace_n28 --n-vars 28 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 tools/trace_bench.sh final/trace_n24 --n-vars 24 --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
 for t in trace_n28 trace_n24; do cp $O/$t/kernel_stats.csv $O/bench_${t#trace_}_kernel_stats.csv; cp $O/$t/per_launch.jsonl $O/per_launch_${t#trace_}.jsonl; cp $O/$t/bench_line.json $O/bench_${t#trace_}_under_rocprof.json; done
