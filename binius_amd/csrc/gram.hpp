@@ -290,13 +290,13 @@ __device__ __forceinline__ void tail(const v16i (&acc)[kAccTiles], unsigned wave
 	tail_finish(Gc, wave, lane, out, fz, seq, fc);
 }
 
+__device__ __forceinline__ void tail_publish(uint64_t (&z3)[2][3], f128 *out, const fin_fuse &fz, uint64_t seq, const fin_cache *fc);
+
 // everything after the parity bits: shared by the int8 form above and the FP4 form (kernels_roundeval_fp4.hip)
 __device__ __forceinline__ void tail_finish(gram_parity &Gc, unsigned wave, unsigned lane, f128 *out, const fin_fuse &fz, uint64_t seq,
                                             const fin_cache *fc)
 {
 	__shared__ uint64_t z3[2][3];
-	__shared__ f128 s_loc[2];
-	const unsigned tid = threadIdx.x;
 	__syncthreads();
 	// column n' = 32 h + n of matrix (pr, s) as a GF(2^64) element (bit p = G[p][n']); z = sum_n' col * e_n'
 	for (unsigned task = wave; task < 6; task += 4) {
@@ -312,6 +312,15 @@ __device__ __forceinline__ void tail_finish(gram_parity &Gc, unsigned wave, unsi
 			z ^= __shfl_xor(z, mm, 64);
 		if (lane == 0) z3[pr][s] = z;
 	}
+	tail_publish(z3, out, fz, seq, fc);
+}
+
+// from the six GF(2^64) sums z3[product][Karatsuba term] on: the two products, their way into the global accumulators, the ticket
+// and the fused finalize.  z3 is workgroup-shared and complete for the caller's own wave; the barrier in front is in here.
+__device__ __forceinline__ void tail_publish(uint64_t (&z3)[2][3], f128 *out, const fin_fuse &fz, uint64_t seq, const fin_cache *fc)
+{
+	__shared__ f128 s_loc[2];
+	const unsigned tid = threadIdx.x;
 	__syncthreads();
 	BN_TS(6);
 	if (tid < 2)

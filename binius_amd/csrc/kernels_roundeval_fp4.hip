@@ -24,6 +24,8 @@
 // taking their decisions from the mirrored index so that every lane ends up with the same point order.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "gram_fp4.hpp"
 
 namespace bn {
@@ -52,6 +54,8 @@ __device__ unsigned long long fp4_phase_cycles[8];
 #else
 #define FP4_CLK(i)
 #endif
+// (This is the three-workgroups-per-CU form: ragged sizes and launches below two tiles per CU.  Whole tiles from 2^20 points on run
+// k_roundeval_fp4_ws further down: stager waves and software-pipelined Gram waves.)
 // MIX: the second pair of sets holds hi ^ lo (evaluation at infinity); otherwise lo itself (two independent products: the
 // two halves of an inner product).
 // NT: the LDS-DMA loads carry the non-temporal hint (HBM-resident sizes: every element is read once per launch).
@@ -153,6 +157,113 @@ __global__ __launch_bounds__(256, 3) void k_roundeval_fp4(const uint4 *__restric
 	tail4(acc, gr, wave, lane, out, fz, fz.args.seq);
 }
 
+// ---- the same evaluation with the two halves of the work on different waves -----------------------------------------------
+// (the structure of kernels_foldeval_fp4.hip, without the fold).  A workgroup is 12 waves on one CU: waves 4 .. 11 load the four
+// elements of a point straight into registers (two tiles ahead), nibble-transpose them and stage a PAIR of tiles into T[i & 1]
+// while waves 0 .. 3 run the k-steps of the previous pair out of T[(i - 1) & 1] -- nine-block roles (gram4k_role: five or four
+// accumulator tiles, which leaves room for a second operand register set) with the k-steps software-pipelined, so that a Gram wave
+// keeps the matrix pipe of its SIMD busy by itself; one workgroup barrier per pair, no LDS round trip for the raw elements.  Whole
+// tiles only, at least two tiles per CU.
+namespace {
+constexpr unsigned kWsGramWaves = 4, kWsGroups = 2, kWsThreads = 64 * kWsGramWaves * (1 + kWsGroups);
+typedef unsigned int ws_v4u __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ uint4 ws_load(const uint4 *p)
+{
+	if constexpr (NT) {
+		const ws_v4u v = __builtin_nontemporal_load(reinterpret_cast<const ws_v4u *>(p));
+		return uint4{v.x, v.y, v.z, v.w};
+	} else {
+		return *p;
+	}
+}
+} // namespace
+
+template <bool MIX, bool NT>
+__global__ __launch_bounds__(kWsThreads, 1) void k_roundeval_fp4_ws(const uint4 *__restrict__ a_hi, const uint4 *__restrict__ a_lo,
+                                                                    const uint4 *__restrict__ b_hi, const uint4 *__restrict__ b_lo, uint64_t n,
+                                                                    f128 *out, fin_fuse fz, uint32_t xcd_tiles)
+{
+	extern __shared__ __attribute__((aligned(16))) uint32_t T_dyn[]; // 2 buffers x 2 tiles of FP4 operands
+	const unsigned lane = threadIdx.x & 63;
+	const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const bool stages = wave >= kWsGramWaves;
+	const unsigned grp = stages ? (wave - kWsGramWaves) >> 2 : 0;  // which tile of the pair
+	const unsigned stid = (threadIdx.x - 64 * kWsGramWaves) & 255; // the lane's point inside its tile
+	const uint64_t n_tiles_all = n / kTP;
+	uint64_t tbase = 0, tstride = gridDim.x, tlimit = n_tiles_all, t0 = blockIdx.x;
+	if ((xcd_tiles & 1) && (gridDim.x & 7) == 0) {
+		const uint64_t chunk = (n_tiles_all + 7) >> 3;
+		tbase = (blockIdx.x & 7) * chunk;
+		tstride = gridDim.x >> 3;
+		t0 = blockIdx.x >> 3;
+		tlimit = tbase >= n_tiles_all ? 0 : (n_tiles_all - tbase < chunk ? n_tiles_all - tbase : chunk);
+	}
+	// pairs of this workgroup: pair p = tiles t0 + (2 p + g) * tstride, g = 0, 1
+	const uint64_t n_seq = t0 < tlimit ? (tlimit - t0 + tstride - 1) / tstride : 0;
+	const uint64_t n_pairs = (n_seq + 1) >> 1;
+	if (stages) {
+		__builtin_amdgcn_s_setprio(3); // the stager waves issue ahead of their SIMD's Gram wave
+		const stage4_role sr = make_stage4_role(stid);
+		uint4 xa[4], xb[4]; // the group's tile of pair p (even p: xa, odd p: xb), loaded two pairs ahead
+		auto load = [&](uint4 (&x)[4], uint64_t p) {
+			const uint64_t seq = 2 * p + grp;
+			if (seq < n_seq) { // (uniform)
+				const uint64_t e = (tbase + t0 + seq * tstride) * kTP + stid;
+				x[0] = ws_load<NT>(a_hi + e);
+				x[1] = ws_load<NT>(a_lo + e);
+				x[2] = ws_load<NT>(b_hi + e);
+				x[3] = ws_load<NT>(b_lo + e);
+			}
+		};
+		auto half = [&](uint4 (&x)[4], uint64_t p) {
+			uint32_t *const Tn = T_dyn + ((p & 1) * kWsGroups + grp) * kTile4kW;
+			if (2 * p + grp < n_seq) { // (uniform; false only for group 1 on an odd last pair)
+				stage4k_elem(Tn, sr, 0, x[0]);
+				stage4k_elem(Tn, sr, 2, MIX ? uint4{x[0].x ^ x[1].x, x[0].y ^ x[1].y, x[0].z ^ x[1].z, x[0].w ^ x[1].w} : x[1]);
+				stage4k_elem(Tn, sr, 1, x[2]);
+				stage4k_elem(Tn, sr, 3, MIX ? uint4{x[2].x ^ x[3].x, x[2].y ^ x[3].y, x[2].z ^ x[3].z, x[2].w ^ x[3].w} : x[3]);
+			}
+			load(x, p + 2);
+			__syncthreads(); // the pair is staged; the Gram waves are done with the buffer this wave writes next
+		};
+		load(xa, 0);
+		load(xb, 1);
+		for (uint64_t p = 0; p < n_pairs; p += 2) {
+			half(xa, p);
+			if (p + 1 < n_pairs) half(xb, p + 1);
+		}
+	} else {
+		const gram4k_role gr = make_gram4k_role(wave >> 1, (wave ^ blockIdx.x) & 1, lane);
+		auto run = [&](auto qc) {
+			constexpr int Q = decltype(qc)::value;
+			v16f acc[Q == 0 ? 5 : 4];
+#pragma unroll
+			for (int i = 0; i < (Q == 0 ? 5 : 4); i++)
+#pragma unroll
+				for (int r = 0; r < 16; r++)
+					acc[i][r] = 0.0f;
+			for (uint64_t p = 0; p < n_pairs; p++) {
+				__syncthreads();
+				const uint32_t *Tp = T_dyn + (p & 1) * kWsGroups * kTile4kW;
+				const int n_t = 2 * p + 1 < n_seq ? 2 : 1; // (uniform) both tiles of the pair, or the odd last one
+				for (int i = 0; i < n_t; i++)
+					gram4k_steps<Q, 4>(Tp + i * kTile4kW, gr, acc);
+			}
+			__syncthreads(); // every wave is done with the operand tiles: the parity words take their place
+			parity4k<Q>(acc, gr, lane, *reinterpret_cast<gram4k_parity *>(T_dyn));
+		};
+		if (gr.q == 0) // (uniform per wave)
+			run(std::integral_constant<int, 0>{});
+		else
+			run(std::integral_constant<int, 1>{});
+	}
+	if (stages) __syncthreads(); // (the Gram waves' barrier in front of the parity words)
+	__shared__ uint64_t z3[2][3];
+	sums4k(*reinterpret_cast<gram4k_parity *>(T_dyn), wave, lane, z3);
+	tail_publish(z3, out, fz, fz.args.seq, nullptr);
+}
+
 template <bool MIX>
 static hipError_t launch_fp4(hipStream_t s, int n_cu, const void *a_hi, const void *a_lo, const void *b_hi, const void *b_lo, uint64_t n, f128 *d_out,
                              const fin_fuse *fuse)
@@ -174,7 +285,39 @@ static hipError_t launch_fp4(hipStream_t s, int n_cu, const void *a_hi, const vo
 		const char *e = getenv("BN_FP4_NT_MIN_LOG2");
 		return e ? atoi(e) : 24;
 	}();
-	if (nt_min_log2 < 64 && n >= (1ull << nt_min_log2))
+	const bool nt = nt_min_log2 < 64 && n >= (1ull << nt_min_log2);
+	// BN_FP4_WS=0: never the wave-specialised form; BN_FP4_WS_MIN_LOG2: points from which it takes the launch
+	static const int ws_min_log2 = [] {
+		const char *e = getenv("BN_FP4_WS");
+		if (e && e[0] == '0') return 64;
+		const char *m = getenv("BN_FP4_WS_MIN_LOG2");
+		return m ? atoi(m) : 20;
+	}();
+	if (ws_min_log2 < 64 && n >= (1ull << ws_min_log2) && n % kTP == 0 && n_tiles >= 2 * (uint64_t)n_cu && (n_tiles + n_cu - 1) / n_cu <= (1ull << 14)) {
+		constexpr unsigned lds = 2 * kWsGroups * kTile4kW * 4;
+		// BN_FP4_WS_GRID=g (tests): g workgroups instead of one per CU -- odd tile counts per workgroup and the plain tile order, which
+		// 256 CUs and power-of-two sizes never produce
+		static const unsigned grid_override = [] {
+			const char *e = getenv("BN_FP4_WS_GRID");
+			return e ? (unsigned)atoi(e) : 0u;
+		}();
+		unsigned ws_grid = (unsigned)n_cu;
+		if (grid_override && grid_override <= ws_grid && (n_tiles + grid_override - 1) / grid_override <= (1ull << 14)) ws_grid = grid_override;
+		static const hipError_t attr = [] {
+			hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_roundeval_fp4_ws<MIX, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+			if (e != hipSuccess) return e;
+			return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_roundeval_fp4_ws<MIX, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+		}();
+		if (attr != hipSuccess) return attr;
+		if (nt)
+			hipLaunchKernelGGL((k_roundeval_fp4_ws<MIX, true>), dim3(ws_grid), dim3(kWsThreads), lds, s, (const uint4 *)a_hi, (const uint4 *)a_lo,
+			                   (const uint4 *)b_hi, (const uint4 *)b_lo, n, d_out, fz, xcd_tiles & 1u);
+		else
+			hipLaunchKernelGGL((k_roundeval_fp4_ws<MIX, false>), dim3(ws_grid), dim3(kWsThreads), lds, s, (const uint4 *)a_hi, (const uint4 *)a_lo,
+			                   (const uint4 *)b_hi, (const uint4 *)b_lo, n, d_out, fz, xcd_tiles & 1u);
+		return hipGetLastError();
+	}
+	if (nt)
 		hipLaunchKernelGGL((k_roundeval_fp4<MIX, true>), dim3(grid), dim3(256), 0, s, (const uint4 *)a_hi, (const uint4 *)a_lo, (const uint4 *)b_hi,
 		                   (const uint4 *)b_lo, n, d_out, fz, xcd_tiles);
 	else

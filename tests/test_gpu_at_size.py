@@ -309,10 +309,10 @@ def test_weighted_and_literal_mlecheck_provers_agree_at_2p23(oracle, monkeypatch
 
 @pytest.mark.parametrize("grid", [100, 248])
 def test_fused_fp4_kernel_with_odd_tile_counts(grid):
-    """kernels_foldeval_fp4.hip hands PAIRS of tiles from its fold waves to its Gram waves.  On 256 CUs every size a prover
+    """kernels_foldeval_fp4.hip and the wave-specialised k_roundeval_fp4_ws hand PAIRS of tiles from their fold / stager waves to their Gram waves.  On 256 CUs every size a prover
     reaches gives every workgroup an even number of tiles and the XCD-aware tile order, so the odd last pair (fold group 1
-    idle, the Gram waves run four k-steps instead of eight) and the plain striding never run.  BN_FE_FP4_GRID launches the
-    kernel on another grid -- 100 workgroups: plain striding, 248 = 8 x 31: the XCD-aware order with uneven counts -- and the
+    idle, the Gram waves run four k-steps instead of eight) and the plain striding never run.  BN_FE_FP4_GRID / BN_FP4_WS_GRID launch the
+    kernels on another grid -- 100 workgroups: plain striding, 248 = 8 x 31: the XCD-aware order with uneven counts -- and the
     transcripts of the n = 20 / 22 plans, the 2^23 MLE-check provers (scaled folds) and the n = 20 round evaluations must still
     be the oracle's.  A fresh process, because the switch is read once."""
     import os
@@ -321,7 +321,7 @@ def test_fused_fp4_kernel_with_odd_tile_counts(grid):
 
     if os.environ.get("BN_FE_FP4_GRID"):
         pytest.skip("already the inner run")
-    env = dict(os.environ, BN_FE_FP4_GRID=str(grid))
+    env = dict(os.environ, BN_FE_FP4_GRID=str(grid), BN_FP4_WS_GRID=str(grid))
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     p = subprocess.run(
         [sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_at_size.py"), "-x", "-q", "-m", "gpu",
