@@ -404,7 +404,7 @@ def main():
     #   fold alone              24*m*2^r                                        (the last fold, r = 1)
     # The ABI decides per launch which kernel runs; the launch counts per class say what actually ran.
     # Classes (include/binius_amd.h BN_PROF_*), as rocprof lists the kernel symbols:
-    #   round_eval_mfma  k_roundeval_fp4 (>= 2^20 points: FP4 matrix path) / k_roundeval_mfma (int8; BN_FP4=0)   round 0 on the matrix cores
+    #   round_eval_mfma  k_roundeval_fp4_ws / k_roundeval_fp4 (>= 2^20 points: FP4 matrix path) / k_roundeval_mfma (int8; BN_FP4=0)   round 0 on the matrix cores
     #                                                                          fold_eval_mfma   k_foldeval_mfma_fp4 (whole tiles, >= 2 per CU) / k_foldeval_mfma (the rest down to 2 tiles per CU)
     #   round_eval       k_roundeval9       round 0, 9-lane VALU kernel        fold_eval        k_foldeval9<2>   (the next size down)
     #   fold             k_extrapolate_line / k_fold_publish (last fold)       fold_eval_small  k_foldeval9_small (one workgroup per batch: latency-shaped)

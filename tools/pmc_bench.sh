@@ -32,6 +32,8 @@ for nv in nvs:
                 k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("bn::", "").split("<")[0]
                 if k == "k_foldeval_mfma_fp4":  # the two forms of the fused kernel are one class (bench.py: fold_eval_mfma)
                     k = "k_foldeval_mfma"
+                if k == "k_roundeval_fp4_ws":  # likewise round 0's two forms (bench.py: round_eval_mfma)
+                    k = "k_roundeval_fp4"
                 acc[k][c][0] += float(r["Counter_Value"])
                 acc[k][c][1] += 1
     w = {}
