@@ -89,6 +89,26 @@ def main():
     ap.add_argument("--cpu-n-vars", type=int, default=0, help="size of the CPU baseline sample (0 = auto)")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` run bare (no launcher, WORLD_SIZE unset) must still be an N-rank run: the process replaces itself
+    # with the launcher the driver would have used (one rank per GPU, rendezvous on 127.0.0.1), so that a scaling run cannot
+    # degrade into an N = 1 line.  And a launcher whose world size disagrees with --gpus is refused rather than mislabelled.
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        import socket
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        print("[bench] --gpus %d without a launcher: re-executing as %s" % (args.gpus, " ".join(cmd)), file=sys.stderr)
+        sys.stderr.flush()
+        os.execv(sys.executable, cmd)
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus and os.environ.get("BN_FORCE_SHARDED") != "1":
+        sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks: refusing to print a line for the wrong number of GPUs"
+                 % (args.gpus, os.environ.get("WORLD_SIZE", "1")))
+
     import numpy as np
     import torch
 

@@ -158,6 +158,7 @@ def lib():
         "bn_prof_begin": [vp],
         "bn_prof_end": [vp, C.POINTER(C.c_double), C.POINTER(u64)],
         "bn_arm_counters": [vp, C.POINTER(u64)],
+        "bn_group_counters": [vp, C.POINTER(u64)],
         "bn_xor_reduce": [vp, vp, u32, u32, PF],
         "bn_host_scratch": [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)],
         "bn_device_numa_node": [C.c_int, C.POINTER(C.c_int)],
@@ -191,7 +192,7 @@ ABI_SYMBOLS = [
     "bn_extrapolate_line", "bn_extrapolate_line_batch", "bn_tensor_expand", "bn_inner_product", "bn_fold_left", "bn_fold_right", "bn_fri_fold",
     "bn_compute_composite", "bn_pairwise_product_reduce", "bn_log_chunks_range", "bn_pick_log_chunks",
     "bn_kernel_launch", "bn_ntt_forward", "bn_ntt_inverse", "bn_ntt_s_evals", "bn_scalar_mul", "bn_scalar_invert",
-    "bn_timer_begin", "bn_timer_end_ms", "bn_prof_begin", "bn_prof_end", "bn_arm_counters", "bn_xor_reduce", "bn_host_scratch", "bn_device_numa_node",
+    "bn_timer_begin", "bn_timer_end_ms", "bn_prof_begin", "bn_prof_end", "bn_arm_counters", "bn_group_counters", "bn_xor_reduce", "bn_host_scratch", "bn_device_numa_node",
     "bn_merkle_build", "bn_groestl256_leaves", "bn_groestl256_compress_layer", "bn_gather_d2h",
     "bn_hal_round_evals", "bn_hal_fold_multilinear", "bn_extrapolate_line_batch_scaled",
     "bn_peer_create", "bn_peer_connect", "bn_peer_set_active", "bn_peer_stats", "bn_peer_destroy", "bn_host_tail_allow_peer", "bn_host_tail_active",
@@ -522,6 +523,16 @@ class Context:
                 "hosted": int(c[6]), "two_round": int(c[7]), "shadow_created": int(c[8]), "shadow_rounds": int(c[9]), "shadow_dropped": int(c[10]),
                 # host tail (abi_kernels.cpp): instances the host took over, round evaluations it answered, fold chains launched
                 "ht_started": int(c[11]), "ht_rounds": int(c[12]), "ht_flushed": int(c[13]), "ht_max": int(c[14])}
+
+    def group_counters(self):
+        """Claim groups (csrc/abi_group.cpp): how the call shape of piop::prove -- k product claims over m multilinears per
+        prover, several provers front-loaded on one layer -- was run: launches of the group kernel, claims evaluated fused
+        with their folds / on pre-folded arrays, plain fold launches of a round, claims of other provers carried along,
+        execute() calls answered from sums computed ahead, execute() calls on this path, deferred folds forced out."""
+        c = (C.c_uint64 * 8)()
+        _check(lib().bn_group_counters(self._h, c))
+        keys = ("launches", "jobs_fused", "jobs_eval", "prefolds", "spec_jobs", "spec_hits", "evals", "flushed_folds")
+        return {k: int(c[i]) for i, k in enumerate(keys)}
 
     # ---- ComputeLayer
     def copy_h2d(self, src, dst):

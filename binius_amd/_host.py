@@ -51,6 +51,18 @@ def host_lib():
             C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
             C.c_uint64, C.POINTER(F128), C.c_void_p, C.c_void_p, C.POINTER(C.c_double),
         ]
+        L.bnh_batch_sumcheck_prove.restype = C.c_int
+        L.bnh_batch_sumcheck_prove.argtypes = [
+            C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.POINTER(F128), C.c_void_p, C.c_uint64,
+            C.POINTER(F128), C.POINTER(F128), C.POINTER(F128), C.POINTER(F128),
+        ]
+        L.bnh_piop_prove.restype = C.c_int
+        L.bnh_piop_prove.argtypes = [
+            C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_void_p),
+            C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(F128), C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32,
+            C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(F128), C.c_uint32, C.POINTER(F128), C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32,
+            C.POINTER(C.c_uint32), C.POINTER(F128), C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_double),
+        ]
         L.bnh_rccl_open.argtypes = [C.c_char_p]
         L.bnh_rccl_unique_id.argtypes = [C.c_void_p]
         L.bnh_rccl_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
@@ -224,6 +236,115 @@ class FriPlan:
         if rc != 0:
             raise BnError(rc, host_lib().bnh_last_error().decode())
         return self.phase_ms[0], self.phase_ms[1]
+
+
+class BatchSumcheckPlan:
+    """p BivariateSumcheckProvers front-loaded on ONE layer (bnh_batch_sumcheck_prove = SumcheckBatchProver::run,
+    protocols/sumcheck/prove/front_loaded.rs:33-203): per round execute() on every live prover, one challenge, fold() on
+    every live prover.  provers: list of (n_vars, multilins, comps, sums), ascending by n_vars."""
+
+    def __init__(self, hal, provers, scratch, batch_coeffs, challenges):
+        self.hal, self.scratch = hal, scratch
+        self.n = len(provers)
+        desc, ptrs, flat, sums = [], [], [], []
+        for n_vars, mls, comps, sm in provers:
+            desc += [n_vars, len(mls), len(comps)]
+            ptrs += [x.ptr for x in mls]
+            flat += [i for pair in comps for i in pair]
+            sums += list(sm)
+        self._keep = provers
+        self.desc = (C.c_uint32 * max(1, len(desc)))(*desc)
+        self.ptrs = (C.c_void_p * max(1, len(ptrs)))(*ptrs)
+        self.comps = (C.c_uint32 * max(1, len(flat)))(*flat)
+        self.sums = _f128_array(sums if sums else [0])
+        self.bcs = _f128_array(list(batch_coeffs))
+        self.rounds = max([pv[0] for pv in provers]) if provers else 0
+        assert len(challenges) >= self.rounds
+        self.ch = _f128_array(list(challenges) if challenges else [0])
+        self.proofs = (F128 * max(1, 2 * self.rounds))()
+        self.total_m = len(ptrs)
+        self.final = (F128 * max(1, self.total_m))()
+        self.m_by_prover = [len(pv[1]) for pv in provers]
+
+    def run(self):
+        rc = host_lib().bnh_batch_sumcheck_prove(self.hal._h, self.n, self.desc, self.ptrs, self.comps, self.sums, self.scratch.ptr, self.scratch.len,
+                                                 self.bcs, self.ch, self.proofs, self.final)
+        if rc != 0:
+            raise BnError(rc, host_lib().bnh_last_error().decode())
+
+    def round_proofs(self):
+        return [[from_f128(self.proofs[2 * r]), from_f128(self.proofs[2 * r + 1])] for r in range(self.rounds)]
+
+    def final_evals(self):
+        out, at = [], 0
+        for m in self.m_by_prover:
+            out.append([from_f128(self.final[at + j]) for j in range(m)])
+            at += m
+        return out
+
+
+class PiopPlan:
+    """piop::prove through the compiled C++ mirror (bnh_piop_prove, binius_amd/host/piop.hpp): commit_interleaved of the merged
+    message, one BivariateSumcheckProver per size, the front-loaded batch interleaved with the FRI folder
+    (crates/core/src/piop/prove.rs:148-395).  committed / transparents: lists of (n_vars, device slice), ascending by n_vars;
+    claims: list of (n_vars, committed index, transparent index, sum); params: FRIParams with log_dim + log_batch_size =
+    total_vars; message: device slice of 2^total_vars elements (merge_multilins of the committed multilinears)."""
+
+    KINDS = ("round_proof", "multilinear_evals", "fri_commitment", "fri_terminate")
+
+    def __init__(self, hal, committed, transparents, claims, params, message, scratch, batch_coeffs, challenges):
+        import numpy as np
+
+        self.hal, self.p, self.message, self.scratch = hal, params, message, scratch
+        self._keep = (committed, transparents)
+        self.nc, self.nt = len(committed), len(transparents)
+        self.c_nv = (C.c_uint32 * max(1, self.nc))(*[v for v, _ in committed])
+        self.c_ptr = (C.c_void_p * max(1, self.nc))(*[s.ptr for _, s in committed])
+        self.t_nv = (C.c_uint32 * max(1, self.nt))(*[v for v, _ in transparents])
+        self.t_ptr = (C.c_void_p * max(1, self.nt))(*[s.ptr for _, s in transparents])
+        flat = [x for c in claims for x in c[:3]]
+        self.n_claims = len(claims)
+        self.claims = (C.c_uint32 * max(1, len(flat)))(*flat)
+        self.sums = _f128_array([c[3] for c in claims] if claims else [0])
+        self.arities = (C.c_uint32 * max(1, len(params.fold_arities)))(*params.fold_arities)
+        self.bcs, self.n_bcs = _f128_array(list(batch_coeffs) if batch_coeffs else [0]), len(batch_coeffs)
+        self.ch, self.n_ch = _f128_array(list(challenges)), len(challenges)
+        rounds = params.n_fold_rounds()
+        self.max_items = 2 * rounds + self.nc + len(params.fold_arities) + 8
+        self.max_scalars = 2 * rounds + self.nc + self.nt + (1 << (params.log_inv_rate + params.n_final_challenges())) + 8
+        self.max_digests = len(params.fold_arities) + 1
+        self.items = (C.c_uint32 * (2 * self.max_items))()
+        self.scalars = (F128 * self.max_scalars)()
+        self.digests = np.zeros((self.max_digests, 32), dtype=np.uint8)
+        self.commitment = np.zeros(32, dtype=np.uint8)
+        self.n_items, self.n_scalars, self.n_digests = C.c_uint32(), C.c_uint64(), C.c_uint32()
+        self.phase_ms = (C.c_double * 2)()
+
+    def run(self):
+        p = self.p
+        rc = host_lib().bnh_piop_prove(
+            self.hal._h, self.nc, self.c_nv, self.c_ptr, self.nt, self.t_nv, self.t_ptr, self.n_claims, self.claims, self.sums,
+            p.log_dim, p.log_inv_rate, p.log_batch_size, self.arities, len(p.fold_arities), p.n_test_queries, self.message.ptr,
+            self.scratch.ptr, self.scratch.len, self.bcs, self.n_bcs, self.ch, self.n_ch, self.commitment.ctypes.data, self.items, self.max_items,
+            C.byref(self.n_items), self.scalars, self.max_scalars, C.byref(self.n_scalars), self.digests.ctypes.data, self.max_digests,
+            C.byref(self.n_digests), self.phase_ms,
+        )
+        if rc != 0:
+            raise BnError(rc, host_lib().bnh_last_error().decode())
+        return self.phase_ms[0], self.phase_ms[1]
+
+    def transcript(self):
+        """[(kind, payload)] in writing order: lists of ints for scalar items, 32 bytes for a FRI commitment."""
+        out, at_s, at_d = [], 0, 0
+        for i in range(self.n_items.value):
+            kind, cnt = self.KINDS[self.items[2 * i]], self.items[2 * i + 1]
+            if kind == "fri_commitment":
+                out.append((kind, bytes(self.digests[at_d])))
+                at_d += 1
+            else:
+                out.append((kind, [from_f128(self.scalars[at_s + j]) for j in range(cnt)]))
+                at_s += cnt
+        return out
 
 
 class ShmExchange:

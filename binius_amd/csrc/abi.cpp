@@ -261,7 +261,8 @@ int host_tail_flush(bn_ctx *ctx, bool publish)
 {
 	bn_ctx::host_tail_state &ht = ctx->ht;
 	if (!ht.active) return BN_OK;
-	ht.active = false;
+	// (ht.active is cleared only once the write-back is enqueued: if the launch fails the host's folded copy is still the only
+	// up-to-date one, and every later call comes back here and reports the error again instead of reading stale arrays)
 	if (ht.n_levels) {
 		// the host copy's first n0 elements per array ARE the caller's buffers after the folds (the host folds in place exactly as
 		// the device would): into the pinned staging, then one launch maps them back to the tower basis and stores them
@@ -273,6 +274,7 @@ int host_tail_flush(bn_ctx *ctx, bool publish)
 		BN_HIP(bn::launch_tail_writeback(ctx->stream, ht.chain, (const char *)ctx->d_tail + 2 * bn::kHtMaxM * sizeof(f128), (const char *)ctx->d_phi + 512 * sizeof(f128)));
 		ctx->ht_flushed++;
 	}
+	ht.active = false;
 	if (publish && ht.cur_m == 1 && !ht.evaluated && ht.n_levels) {
 		ctx->mirror.valid = true;
 		ctx->mirror.host = true;
@@ -374,7 +376,20 @@ int flush_copies(bn_ctx *ctx)
 	return BN_OK;
 }
 
+// everything deferred runs: the claim groups' folds (abi_group.cpp), then the single-claim state.  (The two sets of arrays are
+// disjoint -- a batch only joins either side while it is independent of everything waiting -- so the order is free.)
 int flush_pending(bn_ctx *ctx, bool keep_tail, bool publish_tiny, bool keep_shadow)
+{
+	if (ctx->grp.on || !ctx->grp.folds.empty()) {
+		const int rc = group_flush(ctx);
+		if (rc) return rc;
+	} else {
+		for (auto &s : ctx->grp.sessions) s.pre_valid = false;
+	}
+	return flush_legacy(ctx, keep_tail, publish_tiny, keep_shadow);
+}
+
+int flush_legacy(bn_ctx *ctx, bool keep_tail, bool publish_tiny, bool keep_shadow)
 {
 	if (ctx->ht.active) {
 		int rc = host_tail_flush(ctx, publish_tiny);
@@ -582,6 +597,8 @@ int bn_ctx_create(int device, uint64_t arena_elems, bn_ctx **out)
 	if (const char *a = getenv("BN_TWO_ROUND")) ctx->two_round = atoi(a) != 0;
 	if (const char *a = getenv("BN_MLECHECK_SHADOW")) ctx->shadow_enabled = atoi(a) != 0;
 	if (const char *a = getenv("BN_CIRCUIT_MULTIPASS")) ctx->circuit_multipass = atoi(a) != 0;
+	if (const char *a = getenv("BN_GROUP")) ctx->grp.enabled = atoi(a) != 0;
+	if (const char *a = getenv("BN_GROUP_SPEC")) ctx->grp.speculate = atoi(a) != 0;
 	BN_HIP(hipMalloc((void **)&ctx->d_flag, sizeof(unsigned)));
 	BN_HIP(hipMemset(ctx->d_flag, 0, sizeof(unsigned)));
 	BN_HIP(hipMalloc((void **)&ctx->d_s_evals, sizeof(uint64_t) * BN_NTT_MAX_DIM * BN_NTT_MAX_DIM));
@@ -935,8 +952,11 @@ int bn_copy_d2h(bn_ctx *ctx, const void *d_src, uint64_t src_len, bn_f128 *h_dst
 	BN_REQUIRE(ctx, "null ctx");
 	BN_ENTER(ctx);
 	{
-		// a read does not invalidate the host mirror of a tiny fold -- and may create it
-		int rc_ = flush_pending(ctx, false, /*publish_tiny=*/ctx->lazy_fold);
+		// a read does not invalidate the host mirror of a tiny fold -- and may create it.  Of the claim groups' deferred folds only
+		// those that touch what is read run (the final evaluations of a prover that finishes while the others go on,
+		// front_loaded.rs:100-112): the rest stays deferred for the next round's launch
+		int rc_ = flush_legacy(ctx, false, /*publish_tiny=*/ctx->lazy_fold);
+		if (!rc_) rc_ = group_flush_touching(ctx, d_src, src_len);
 		if (rc_) return rc_;
 	}
 	BN_REQUIRE(src_len == dst_len, "precondition: src and dst buffers must have the same length");
@@ -1008,7 +1028,9 @@ int bn_copy_d2d(bn_ctx *ctx, const void *d_src, uint64_t src_len, void *d_dst, u
 		BN_HIP(hipMemcpyAsync(d_dst, d_src, src_len * sizeof(f128), hipMemcpyDeviceToDevice, ctx->stream));
 		return BN_OK;
 	}
-	if (ctx->lazy_fold && !ctx->pend.active && ctx->pend_copies.size() < 8) {
+	if (!ctx->grp.folds.empty() && (!group_independent(ctx, d_src, src_len) || !group_independent(ctx, d_dst, dst_len))) BN_FLUSH(ctx); // (ordered behind the folds it touches)
+	group_note_write(ctx, d_dst, dst_len); // (sums computed ahead from what is overwritten are stale)
+	if (ctx->lazy_fold && !ctx->pend.active && ctx->pend_copies.size() < (size_t)bn::kFoldBatchMax) {
 		// deferred: a fold into d_dst may absorb it (see bn_ctx::pending_copy)
 		ctx->pend_copies.push_back({d_src, d_dst, src_len});
 		return BN_OK;
@@ -1142,7 +1164,7 @@ int bn_extrapolate_line_batch_scaled(bn_ctx *ctx, void *const *d_evals_0, const 
 	BN_REQUIRE(ctx && z && d_evals_0 && d_evals_1, "null argument");
 	BN_ENTER(ctx);
 	BN_REQUIRE(count <= (uint32_t)bn::kFoldBatchMax, "too many slices in one extrapolate_line batch");
-	BN_REQUIRE(scale_mask == 0 || (hi_scale && (n & 1) == 0 && (scale_mask >> count) == 0),
+	BN_REQUIRE(scale_mask == 0 || (hi_scale && (n & 1) == 0 && (count >= 32 || (scale_mask >> count) == 0)),
 	           "scaled fold: needs a scale, an even length and a mask within the batch");
 	if (count == 0) return BN_OK;
 	ctx->mirror.valid = false;
@@ -1198,6 +1220,26 @@ int bn_extrapolate_line_batch_scaled(bn_ctx *ctx, void *const *d_evals_0, const 
 			ctx->pend_copies.clear();
 		} else {
 			for (uint32_t i = 0; i < count; i++) src0[i] = d_evals_0[i];
+		}
+	}
+	// ---- claim groups (abi_group.cpp): a batch that is not the lone two-array shape of the single-claim machinery -- more than
+	// two arrays, other batches already waiting, or a second prover's batch arriving while the first one's is deferred -- waits
+	// beside the others; the next evaluations pick their folds up in one launch
+	{
+		bool to_group = group_fold_applies(ctx, count, scale_mask);
+		if (!to_group && ctx->grp.enabled && ctx->lazy_fold && !ctx->peer.active && !scale_mask && !ctx->tail_max_n_in && ctx->pend.active && !ctx->pend2.active &&
+		    !ctx->pend.scale_mask && !ctx->ht.active && !ctx->tail.active && !ctx->shadow.valid) {
+			bool indep = true;
+			for (uint32_t i = 0; i < count && indep; i++)
+				indep = independent_of_pending(ctx, d_evals_0[i], n) && independent_of_pending(ctx, d_evals_1[i], n) && independent_of_pending(ctx, src0[i], n);
+			to_group = indep;
+		}
+		if (to_group) {
+			if (!ctx->pend_copies.empty()) { // (copies the batch did not absorb: issued before it, they run before it)
+				int rc_c = flush_copies(ctx);
+				if (rc_c) return rc_c;
+			}
+			return group_defer_fold(ctx, d_evals_0, src0, d_evals_1, count, n, to_f(z));
 		}
 	}
 	if (ctx->ht.active) {
@@ -1333,6 +1375,22 @@ int bn_arm_counters(bn_ctx *ctx, uint64_t *counters)
 	counters[BN_ARM_HT_ROUNDS] = ctx->ht_rounds;
 	counters[BN_ARM_HT_FLUSHED] = ctx->ht_flushed;
 	counters[BN_ARM_HT_MAX] = ctx->ht_enabled ? ctx->ht_max : 0;
+	return BN_OK;
+}
+
+int bn_group_counters(bn_ctx *ctx, uint64_t *counters)
+{
+	BN_REQUIRE(ctx && counters, "null argument");
+	BN_ENTER(ctx);
+	const auto &g = ctx->grp;
+	counters[BN_GROUP_LAUNCHES] = g.launches;
+	counters[BN_GROUP_JOBS_FUSED] = g.jobs_fused;
+	counters[BN_GROUP_JOBS_EVAL] = g.jobs_eval;
+	counters[BN_GROUP_PREFOLDS] = g.prefolds;
+	counters[BN_GROUP_SPEC_JOBS] = g.spec_jobs;
+	counters[BN_GROUP_SPEC_HITS] = g.spec_hits;
+	counters[BN_GROUP_EVALS] = g.evals;
+	counters[BN_GROUP_FLUSHED_FOLDS] = g.flushed_folds;
 	return BN_OK;
 }
 

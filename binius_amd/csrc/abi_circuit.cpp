@@ -324,6 +324,8 @@ bool sum_plan(planner &p, bool has_eq, std::vector<sum_job> &jobs, bool &need_on
 			} else {
 				summands.push_back(i);
 			}
+			// (shared Add nodes expand exponentially -- t_{k+1} = t_k + t_k, forty deep --: the limit holds DURING the expansion)
+			if (summands.size() + stack.size() > 16) return false;
 		}
 	}
 	if (summands.size() > 16) return false;
@@ -391,6 +393,9 @@ int circuit_multipass_sum(bn_ctx *ctx, const bn_expr *e, const void *const *rows
 	bool need_ones = false;
 	uint32_t n_t = 0;
 	if (!sum_plan(p, eq != nullptr, jobs, need_ones, n_t)) return kCircuitDeclined;
+	// (a caller that already keeps data in the scratch below scratch_off sized it for the temporaries as well -- a growth here would
+	// free that data: declined, the interpreter answers)
+	if (scratch_off && scratch_off + (size_t)n_t * row_len * sizeof(f128) > ctx->scratch_bytes) return kCircuitDeclined;
 	char *base = (char *)bn::ctx_scratch(ctx, scratch_off + (size_t)n_t * row_len * sizeof(f128));
 	if (!base) return bn::fail(BN_ERR_ALLOC, "allocation error: allocator is out of memory (circuit temporaries)");
 	p.scr = base + scratch_off;

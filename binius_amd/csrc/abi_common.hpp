@@ -109,6 +109,27 @@ int circuit_multipass_sum_temps(const bn_expr *e, bool has_eq);
 // d_slots[0] ^ d_slots[1] ^= sum_i expr(rows[.][i]) * (eq ? eq[i] : 1)
 int circuit_multipass_sum(bn_ctx *ctx, const bn_expr *e, const void *const *rows, uint64_t row_len, const void *eq, bn::f128 *d_slots, size_t scratch_off,
                           const void *ones_table = nullptr);
+// ---- claim groups (abi_group.cpp)
+// the single-claim deferral state only (pending fold(s), armed / resident kernels, host tail, shadow, deferred copies)
+int flush_legacy(bn_ctx *ctx, bool keep_tail = false, bool publish_tiny = false, bool keep_shadow = false);
+// is any of that state alive?
+bool legacy_state_active(const bn_ctx *ctx);
+// a batch of folds can be deferred on the group path
+bool group_fold_applies(const bn_ctx *ctx, uint32_t count, uint32_t scale_mask);
+// [p, p + n) touches none of the arrays a deferred group fold reads or writes
+bool group_independent(const bn_ctx *ctx, const void *p, uint64_t n);
+// defer the batch (src0 | x1 -> x0, n elements each); deferred folds it overlaps run first
+int group_defer_fold(bn_ctx *ctx, void *const *x0, const void *const *src0, const void *const *x1, uint32_t count, uint64_t n, f128 z);
+// run every deferred group fold as a plain launch and forget every prediction
+int group_flush(bn_ctx *ctx);
+// run only the deferred folds that overlap [p, p + n); predictions that describe overlapping arrays are forgotten
+int group_flush_touching(bn_ctx *ctx, const void *p, uint64_t n);
+// a write into [p, p + n) that flushed nothing: predictions that describe overlapping arrays are forgotten
+void group_note_write(bn_ctx *ctx, const void *p, uint64_t n);
+// the round evaluation of a prover (k product claims over m arrays) on the group path; *handled = false: not that shape / not
+// wanted -- the caller goes on with the single-claim dispatcher
+int group_eval(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const bn_kop *ops, uint32_t n_ops, const uint32_t *ret_values, uint32_t n_ret,
+               bn_f128 *h_out, bool *handled);
 // ---- small helpers shared by the op entry points (abi.cpp)
 int publish_result(bn_ctx *ctx, uint32_t n_groups, bn_f128 *h_out);
 int publish_vals(bn_ctx *ctx, const bn::f128 *d_vals, uint32_t n_groups, uint32_t group_len, uint32_t g_stride, uint32_t i_stride, bn::f128 *h_out);

@@ -1,0 +1,662 @@
+// binius_amd/csrc/abi_group.cpp -- claim groups: the deferral and dispatch of the call shape the reference's PCS prover issues.
+//
+// piop::prove builds ONE BivariateSumcheckProver per size out of all committed multilinears of that size and their
+// ring-switch transparents (core/src/piop/prove.rs:271-287): k product claims over m multilinears, a multilinear possibly in
+// several claims or in none; the provers run front-loaded in one batch (protocols/sumcheck/prove/front_loaded.rs:122-155):
+//
+//     execute(P_1) .. execute(P_p)  |  challenge  |  fold(P_1) .. fold(P_p)  |  (FRI: nothing, or fri_fold + commit)  |  execute(P_1) ..
+//
+// and each execute records  SUM(c_0, at 1) .. SUM(c_{k-1}, at 1), ADD x m, SUM(c_0, at inf) .. SUM(c_{k-1}, at inf)
+// (protocols/sumcheck/v3/bivariate_product.rs:345-399).  The single-claim machinery of abi.cpp / abi_kernels.cpp (ONE deferred
+// fold per context, two arrays, one claim) drops every one of these to eager launches.  Here
+//
+//   * a fold batch is deferred PER PROVER: any number of batches wait side by side as long as their arrays are disjoint
+//     (bn_ctx::group_state::folds);
+//   * a round evaluation of that shape is parsed into arrays (lo, hi) and claims (a, b); every claim whose two arrays are
+//     folded by a deferred batch and are used by no other claim becomes a fold + evaluate job (kind 0), every other claim an
+//     evaluate job (kind 1) on arrays that a plain fold launch in front of it has brought up to date;
+//   * ONE launch (kernels_group.hip) carries the jobs of the calling prover AND of every other prover whose deferred fold
+//     is waiting and whose claims are known from its last evaluation (a session); the others' raw sums are kept and answer
+//     their execute() without a launch;
+//   * the batch coefficients are applied on the host (value = init + sum_c coeff_c * S_c, compute/src/cpu/layer.rs:512).
+//
+// One invalidation rule: a call that reads or writes device memory the deferred folds touch, or that the library cannot see
+// through, runs them first as plain fold launches (group_flush / group_flush_touching) -- the caller's memory is then exactly
+// what eager execution leaves -- and forgets the sums computed ahead.  A session is only a description (pointers and claim
+// indices); a stale one costs a wasted evaluation, never a wrong answer: sums computed ahead are used only for a request that
+// names exactly the arrays they were computed from, and die with any write into those arrays.
+#include "abi_common.hpp"
+#include "hostmul.hpp"
+
+namespace bnabi {
+
+namespace {
+constexpr uint32_t kMaxArrays = 32;
+constexpr size_t kMaxSessions = 16;
+
+inline const char *at(const void *p, uint64_t elems) { return (const char *)p + elems * sizeof(f128); }
+
+bool fold_touches(const bn_ctx::group_fold &f, const void *p, uint64_t n)
+{
+	for (uint32_t i = 0; i < f.count; i++)
+		if (ranges_overlap(p, n, f.x0[i], f.n) || ranges_overlap(p, n, f.x1[i], f.n) || ranges_overlap(p, n, f.src0[i], f.n)) return true;
+	return false;
+}
+
+int launch_fold(bn_ctx *ctx, const bn_ctx::group_fold &f)
+{
+	bn::fold_batch fb{};
+	for (uint32_t i = 0; i < f.count; i++) {
+		fb.x0[i] = f.x0[i];
+		fb.x1[i] = f.x1[i];
+		fb.src0[i] = f.src0[i] != f.x0[i] ? f.src0[i] : nullptr; // (absorbed copy: read there, write here)
+	}
+	prof_scope ps(ctx, BN_PROF_FOLD);
+	BN_HIP(bn::launch_extrapolate_line_batch(ctx->stream, ctx->n_cu, fb, f.count, f.n, f.z));
+	ctx->grp.flushed_folds++;
+	return BN_OK;
+}
+
+void drop_predictions_touching(bn_ctx *ctx, const void *p, uint64_t n)
+{
+	for (auto &s : ctx->grp.sessions) {
+		if (!s.pre_valid) continue;
+		for (uint32_t i = 0; i < s.m && s.pre_valid; i++)
+			if (ranges_overlap(p, n, s.pre_lo[i], s.pre_row_len) || ranges_overlap(p, n, s.pre_hi[i], s.pre_row_len)) s.pre_valid = false;
+	}
+}
+
+// what an evaluation request of the calculate_round_evals shape asks for
+struct request {
+	uint32_t m = 0, k = 0;
+	uint64_t row_len = 0;
+	const void *lo[kMaxArrays] = {}, *hi[kMaxArrays] = {};
+	uint8_t pa[kMaxArrays] = {}, pb[kMaxArrays] = {};
+	struct term {
+		uint32_t value, claim, at_inf;
+		f128 coeff;
+	};
+	std::vector<term> terms;
+	uint32_t n_values = 0;
+	f128 init[bn::kFinMaxValues] = {};
+};
+
+// Parses the op list.  false: not the shape (the single-claim dispatcher validates and answers it).
+bool parse(const bn_memmap *maps, uint32_t n_maps, const bn_kop *ops, uint32_t n_ops, const uint32_t *ret_values, uint32_t n_ret, request &rq)
+{
+	if (n_ret == 0 || n_ret > (uint32_t)bn::kFinMaxRets) return false;
+	std::vector<int> local_array(n_maps, -1); // Local buffer -> the array whose lo + hi it holds
+	auto plain = [&](const bn_kslice &sl, const char *&p) {
+		if (sl.buf >= n_maps || maps[sl.buf].kind == BN_MAP_LOCAL || !maps[sl.buf].d_data) return false;
+		if (sl.off + sl.len > maps[sl.buf].len) return false;
+		p = (const char *)maps[sl.buf].d_data + sl.off * sizeof(f128);
+		return true;
+	};
+	auto claim_of = [&](uint32_t a, uint32_t b) -> int {
+		for (uint32_t c = 0; c < rq.k; c++)
+			if (rq.pa[c] == a && rq.pb[c] == b) return (int)c;
+		if (rq.k >= kMaxArrays) return -1;
+		rq.pa[rq.k] = (uint8_t)a;
+		rq.pb[rq.k] = (uint8_t)b;
+		return (int)rq.k++;
+	};
+	// first pass: the arrays (every ADD of two mapped halves into a whole Local buffer) and the values
+	for (uint32_t o = 0; o < n_ops; o++) {
+		const bn_kop &op = ops[o];
+		if (op.kind == BN_KOP_DECL_VALUE) {
+			if (op.value >= (uint32_t)bn::kFinMaxValues) return false;
+			if (op.value + 1 > rq.n_values) rq.n_values = op.value + 1;
+			rq.init[op.value] = f128{op.scalar.lo, op.scalar.hi};
+		} else if (op.kind == BN_KOP_ADD) {
+			if (op.dst.buf >= n_maps || maps[op.dst.buf].kind != BN_MAP_LOCAL || maps[op.dst.buf].log_size > 40) return false;
+			const uint64_t len = (uint64_t)1 << maps[op.dst.buf].log_size;
+			if (op.dst.off != 0 || op.dst.len != len || op.src1.len != len || op.src2.len != len) return false;
+			const char *p = nullptr, *q = nullptr;
+			if (!plain(op.src1, p) || !plain(op.src2, q)) return false;
+			if (local_array[op.dst.buf] >= 0 || rq.m >= kMaxArrays) return false; // (defined twice: not this shape)
+			if (rq.m && len != rq.row_len) return false;
+			rq.row_len = len;
+			local_array[op.dst.buf] = (int)rq.m;
+			rq.lo[rq.m] = p;
+			rq.hi[rq.m] = q;
+			rq.m++;
+		} else if (op.kind != BN_KOP_SUM_COMPOSITION) {
+			return false;
+		}
+	}
+	if (rq.m == 0 || rq.row_len == 0) return false;
+	// second pass, in order: a sum over Locals must come after the ADDs that define them
+	std::vector<char> defined(n_maps, 0);
+	for (uint32_t o = 0; o < n_ops; o++) {
+		const bn_kop &op = ops[o];
+		if (op.kind == BN_KOP_ADD) {
+			defined[op.dst.buf] = 1;
+			continue;
+		}
+		if (op.kind != BN_KOP_SUM_COMPOSITION) continue;
+		if (!op.expr || op.expr->shape != bn_expr::PRODUCT || op.expr->product_vars.size() != 2 || op.value >= rq.n_values) return false;
+		int arr[2];
+		int n_local = 0;
+		for (int j = 0; j < 2; j++) {
+			const uint32_t v = op.expr->product_vars[j];
+			if (v >= op.n_rows) return false;
+			const bn_kslice &sl = op.rows[v];
+			if (sl.buf >= n_maps || sl.len != rq.row_len) return false;
+			if (maps[sl.buf].kind == BN_MAP_LOCAL) {
+				if (sl.off != 0 || !defined[sl.buf] || local_array[sl.buf] < 0) return false;
+				arr[j] = local_array[sl.buf];
+				n_local++;
+			} else {
+				const char *p = nullptr;
+				if (!plain(sl, p)) return false;
+				arr[j] = -1;
+				for (uint32_t i = 0; i < rq.m; i++)
+					if (rq.hi[i] == p) arr[j] = (int)i; // the evaluation at 1 is the array's upper half
+				if (arr[j] < 0) return false;
+			}
+		}
+		if (n_local == 1) return false;
+		const int c = claim_of((uint32_t)arr[0], (uint32_t)arr[1]);
+		if (c < 0) return false;
+		rq.terms.push_back(request::term{op.value, (uint32_t)c, n_local == 2 ? 1u : 0u, f128{op.scalar.lo, op.scalar.hi}});
+	}
+	for (uint32_t r = 0; r < n_ret; r++)
+		if (ret_values[r] >= rq.n_values) return false;
+	// two arrays may not alias each other (a fold writes one while a job reads the other)
+	for (uint32_t i = 0; i < rq.m; i++)
+		for (uint32_t j = 0; j < i; j++)
+			if (rq.lo[i] == rq.lo[j] || rq.hi[i] == rq.hi[j]) return false;
+	return rq.k > 0 && rq.k <= 16;
+}
+
+void answer(const request &rq, const f128 *raw, const uint32_t *ret_values, uint32_t n_ret, bn_f128 *h_out)
+{
+	f128 vals[bn::kFinMaxValues];
+	for (uint32_t v = 0; v < rq.n_values; v++) vals[v] = rq.init[v];
+	for (const auto &t : rq.terms) {
+		const f128 s = raw[2 * t.claim + t.at_inf];
+		vals[t.value] ^= (t.coeff == f128{1, 0}) ? s : bn::mul_host(t.coeff, s);
+	}
+	for (uint32_t r = 0; r < n_ret; r++) h_out[r] = bn_f128{vals[ret_values[r]].lo, vals[ret_values[r]].hi};
+}
+
+// where array (lo, hi, row_len) comes out of a deferred fold: the batch and the index inside it
+struct fold_ref {
+	int f = -1, j = -1;
+};
+fold_ref find_output(const bn_ctx *ctx, const void *lo, const void *hi, uint64_t row_len)
+{
+	for (size_t f = 0; f < ctx->grp.folds.size(); f++) {
+		const auto &g = ctx->grp.folds[f];
+		if (g.n != 2 * row_len) continue;
+		for (uint32_t j = 0; j < g.count; j++)
+			if (g.x0[j] == lo && (const void *)at(lo, row_len) == hi) return fold_ref{(int)f, (int)j};
+	}
+	return fold_ref{};
+}
+fold_ref find_input(const bn_ctx *ctx, const void *lo, const void *hi, uint64_t row_len)
+{
+	for (size_t f = 0; f < ctx->grp.folds.size(); f++) {
+		const auto &g = ctx->grp.folds[f];
+		if (g.n != row_len) continue;
+		for (uint32_t j = 0; j < g.count; j++)
+			if (g.src0[j] == lo && g.x1[j] == hi) return fold_ref{(int)f, (int)j};
+	}
+	return fold_ref{};
+}
+
+// the jobs of one prover's evaluation: arrays (lo, hi) of row_len points each, array i coming out of deferred fold ref[i]
+// (f < 0: it is up to date in memory); appends kind-0 / kind-1 jobs (slot = slot0 + 2 * claim) and marks the folds that must
+// run as plain launches first
+void plan(const bn_ctx *ctx, uint32_t m, uint32_t k, const uint8_t *pa, const uint8_t *pb, const void *const *lo, const void *const *hi, uint64_t row_len,
+          const fold_ref *ref, uint32_t slot0, std::vector<bn::group_job> &jobs, std::vector<char> &prefold /*[m]*/, uint64_t &n_fused)
+{
+	uint32_t deg[kMaxArrays] = {};
+	for (uint32_t c = 0; c < k; c++) {
+		deg[pa[c]]++;
+		deg[pb[c]]++;
+	}
+	std::vector<char> fused_arr(m, 0);
+	for (uint32_t c = 0; c < k; c++) {
+		const uint32_t a = pa[c], b = pb[c];
+		bn::group_job j{};
+		j.n = row_len;
+		j.slot = slot0 + 2 * c;
+		if (a != b && deg[a] == 1 && deg[b] == 1 && ref[a].f >= 0 && ref[b].f >= 0 && ctx->grp.folds[ref[a].f].z == ctx->grp.folds[ref[b].f].z) {
+			const auto &fa = ctx->grp.folds[ref[a].f], &fb = ctx->grp.folds[ref[b].f];
+			j.kind = 0;
+			j.z = fa.z;
+			j.x0[0] = fa.src0[ref[a].j];
+			j.x1[0] = fa.x1[ref[a].j];
+			j.out[0] = fa.x0[ref[a].j];
+			j.x0[1] = fb.src0[ref[b].j];
+			j.x1[1] = fb.x1[ref[b].j];
+			j.out[1] = fb.x0[ref[b].j];
+			fused_arr[a] = fused_arr[b] = 1;
+			n_fused++;
+		} else {
+			j.kind = 1;
+			j.x0[0] = lo[a];
+			j.x1[0] = hi[a];
+			j.x0[1] = lo[b];
+			j.x1[1] = hi[b];
+		}
+		jobs.push_back(j);
+	}
+	for (uint32_t i = 0; i < m; i++) prefold[i] = (ref[i].f >= 0 && !fused_arr[i]) ? 1 : 0;
+}
+
+bn_ctx::group_session *session_for(bn_ctx *ctx, const request &rq, const fold_ref *ref)
+{
+	auto &ss = ctx->grp.sessions;
+	auto same_claims = [&](const bn_ctx::group_session &s) {
+		if (s.m != rq.m || s.k != rq.k) return false;
+		for (uint32_t c = 0; c < rq.k; c++)
+			if (s.pa[c] != rq.pa[c] || s.pb[c] != rq.pb[c]) return false;
+		return true;
+	};
+	for (auto &s : ss) {
+		if (!same_claims(s)) continue;
+		bool cont = true, same = s.row_len == rq.row_len;
+		for (uint32_t i = 0; i < rq.m; i++) {
+			if (ref[i].f < 0) {
+				cont = false;
+			} else {
+				const auto &g = ctx->grp.folds[ref[i].f];
+				if (g.src0[ref[i].j] != s.lo[i] || g.x1[ref[i].j] != s.hi[i] || g.n != s.row_len) cont = false;
+			}
+			if (s.lo[i] != rq.lo[i] || s.hi[i] != rq.hi[i]) same = false;
+		}
+		if (cont || same) return &s;
+	}
+	if (ss.size() >= kMaxSessions) {
+		size_t old = 0;
+		for (size_t i = 1; i < ss.size(); i++)
+			if (ss[i].stamp < ss[old].stamp) old = i;
+		ss.erase(ss.begin() + (long)old);
+	}
+	ss.emplace_back();
+	return &ss.back();
+}
+
+void record(bn_ctx *ctx, bn_ctx::group_session &s, const request &rq)
+{
+	s.m = rq.m;
+	s.k = rq.k;
+	s.row_len = rq.row_len;
+	for (uint32_t i = 0; i < rq.m; i++) {
+		s.lo[i] = rq.lo[i];
+		s.hi[i] = rq.hi[i];
+	}
+	for (uint32_t c = 0; c < rq.k; c++) {
+		s.pa[c] = rq.pa[c];
+		s.pb[c] = rq.pb[c];
+	}
+	s.pre_valid = false;
+	s.stamp = ++ctx->grp.stamp;
+}
+
+int wait_mail(bn_ctx *ctx, uint64_t seq)
+{
+	volatile uint64_t *seqw = &ctx->h_mail[64].lo;
+	uint64_t spins = 0;
+	while (__atomic_load_n(seqw, __ATOMIC_ACQUIRE) != seq) {
+		if (++spins > (1ull << 22)) {
+			BN_HIP(hipStreamSynchronize(ctx->stream));
+			if (__atomic_load_n(seqw, __ATOMIC_ACQUIRE) != seq) return bn::fail(BN_ERR_DEVICE, "device error: result mailbox was not published");
+			break;
+		}
+	}
+	return BN_OK;
+}
+} // namespace
+
+bool legacy_state_active(const bn_ctx *ctx)
+{
+	return ctx->pend.active || ctx->pend2.active || ctx->arm.active || ctx->tail.active || ctx->ht.active || ctx->shadow.valid || ctx->pre.valid ||
+	       ctx->side_busy || !ctx->side_queue.empty();
+}
+
+bool group_fold_applies(const bn_ctx *ctx, uint32_t count, uint32_t scale_mask)
+{
+	const auto &g = ctx->grp;
+	if (!g.enabled || !ctx->lazy_fold || ctx->peer.active || scale_mask || ctx->tail_max_n_in || count == 0 || count > kMaxArrays) return false;
+	// (a lone batch of two arrays with nothing else waiting is the single-claim shape: the armed / two-round / host-tail machinery
+	// of abi.cpp keeps it)
+	return g.on || !g.folds.empty() || count != 2;
+}
+
+bool group_independent(const bn_ctx *ctx, const void *p, uint64_t n)
+{
+	for (const auto &f : ctx->grp.folds)
+		if (fold_touches(f, p, n)) return false;
+	return true;
+}
+
+// the single-claim state gives way: a plain deferred fold moves over as it is, everything else of it is flushed
+static int legacy_to_group(bn_ctx *ctx)
+{
+	if (!legacy_state_active(ctx)) return BN_OK;
+	bn_ctx::group_fold moved;
+	bool have = false;
+	if (ctx->pend.active && !ctx->pend2.active && !ctx->pend.scale_mask && !ctx->ht.active && !ctx->tail.active && !(ctx->shadow.valid && ctx->shadow.fold_pending) &&
+	    ctx->pend.count <= kMaxArrays) {
+		const auto &pf = ctx->pend;
+		moved.count = pf.count;
+		moved.n = pf.n;
+		moved.z = pf.z;
+		for (uint32_t i = 0; i < pf.count; i++) {
+			moved.x0[i] = pf.x0[i];
+			moved.x1[i] = pf.x1[i];
+			moved.src0[i] = pf.src0[i];
+		}
+		ctx->pend.active = false;
+		have = true;
+	}
+	const int rc = flush_legacy(ctx);
+	if (rc) return rc;
+	if (have) ctx->grp.folds.push_back(moved);
+	return BN_OK;
+}
+
+int group_defer_fold(bn_ctx *ctx, void *const *x0, const void *const *src0, const void *const *x1, uint32_t count, uint64_t n, f128 z)
+{
+	int rc = legacy_to_group(ctx);
+	if (rc) return rc;
+	auto &g = ctx->grp;
+	// a batch whose arrays overlap what a waiting batch reads or writes is ordered behind it: the waiting ones run first
+	bool clash = false;
+	for (uint32_t i = 0; i < count && !clash; i++)
+		clash = !group_independent(ctx, x0[i], n) || !group_independent(ctx, x1[i], n) || !group_independent(ctx, src0[i], n);
+	// ... and so is one that overlaps ITSELF across arrays (the jobs of a launch run concurrently)
+	for (uint32_t i = 0; i < count && !clash; i++)
+		for (uint32_t j = 0; j < count && !clash; j++) {
+			if (i == j) continue;
+			clash = ranges_overlap(x0[i], n, x0[j], n) || ranges_overlap(x0[i], n, x1[j], n) || ranges_overlap(x0[i], n, src0[j], n);
+		}
+	for (uint32_t i = 0; i < count && !clash; i++) // (an out-of-place fold whose output overlaps its own inputs)
+		clash = ranges_overlap(x0[i], n, x1[i], n) || (x0[i] != src0[i] && ranges_overlap(x0[i], n, src0[i], n));
+	if (clash) {
+		rc = group_flush(ctx);
+		if (rc) return rc;
+		bn_ctx::group_fold f;
+		f.count = count;
+		f.n = n;
+		f.z = z;
+		for (uint32_t i = 0; i < count; i++) {
+			f.x0[i] = x0[i];
+			f.x1[i] = x1[i];
+			f.src0[i] = src0[i];
+		}
+		return launch_fold(ctx, f);
+	}
+	// the sums computed ahead describe arrays BEFORE this fold: a prover that folds without having asked for them has moved on
+	for (uint32_t i = 0; i < count; i++) drop_predictions_touching(ctx, x0[i], n);
+	bn_ctx::group_fold f;
+	f.count = count;
+	f.n = n;
+	f.z = z;
+	for (uint32_t i = 0; i < count; i++) {
+		f.x0[i] = x0[i];
+		f.x1[i] = x1[i];
+		f.src0[i] = src0[i];
+	}
+	g.folds.push_back(f);
+	g.on = true;
+	return BN_OK;
+}
+
+int group_flush(bn_ctx *ctx)
+{
+	auto &g = ctx->grp;
+	g.on = false;
+	for (auto &s : g.sessions) s.pre_valid = false;
+	if (g.folds.empty()) return BN_OK;
+	std::vector<bn_ctx::group_fold> todo;
+	todo.swap(g.folds);
+	for (const auto &f : todo) {
+		const int rc = launch_fold(ctx, f);
+		if (rc) return rc;
+	}
+	return BN_OK;
+}
+
+int group_flush_touching(bn_ctx *ctx, const void *p, uint64_t n)
+{
+	auto &g = ctx->grp;
+	drop_predictions_touching(ctx, p, n);
+	for (size_t i = 0; i < g.folds.size();) {
+		if (fold_touches(g.folds[i], p, n)) {
+			const bn_ctx::group_fold f = g.folds[i];
+			g.folds.erase(g.folds.begin() + (long)i);
+			const int rc = launch_fold(ctx, f);
+			if (rc) return rc;
+		} else {
+			i++;
+		}
+	}
+	return BN_OK;
+}
+
+void group_note_write(bn_ctx *ctx, const void *p, uint64_t n) { drop_predictions_touching(ctx, p, n); }
+
+int group_eval(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const bn_kop *ops, uint32_t n_ops, const uint32_t *ret_values, uint32_t n_ret,
+               bn_f128 *h_out, bool *handled)
+{
+	*handled = false;
+	auto &g = ctx->grp;
+	if (!g.enabled || !ctx->lazy_fold || ctx->peer.active || ctx->tail_max_n_in || !h_out) return BN_OK;
+	request rq;
+	if (!parse(maps, n_maps, ops, n_ops, ret_values, n_ret, rq)) return BN_OK;
+	// ---- sums computed ahead for exactly this request?
+	for (auto &s : g.sessions) {
+		if (!s.pre_valid || s.m != rq.m || s.k != rq.k || s.pre_row_len != rq.row_len) continue;
+		bool same = true;
+		for (uint32_t i = 0; i < rq.m && same; i++) same = s.pre_lo[i] == rq.lo[i] && s.pre_hi[i] == rq.hi[i];
+		for (uint32_t c = 0; c < rq.k && same; c++) same = s.pa[c] == rq.pa[c] && s.pb[c] == rq.pb[c];
+		if (!same) continue;
+		answer(rq, s.pre_raw, ret_values, n_ret, h_out);
+		record(ctx, s, rq);
+		g.spec_hits++;
+		g.evals++;
+		*handled = true;
+		return BN_OK;
+	}
+	// ---- is this a request for the group path at all?  One claim with nothing waiting is the single-claim machinery's.
+	if (rq.k < 2 && g.folds.empty() && !g.on) return BN_OK;
+	int rc = legacy_to_group(ctx);
+	if (rc) return rc;
+	if (!ctx->pend_copies.empty()) {
+		rc = flush_copies(ctx); // (independent of every deferred fold, checked when they were deferred: any order)
+		if (rc) return rc;
+	}
+	// ---- the request's arrays against the deferred folds
+	fold_ref ref[kMaxArrays];
+	for (uint32_t i = 0; i < rq.m; i++) {
+		ref[i] = find_output(ctx, rq.lo[i], rq.hi[i], rq.row_len);
+		if (ref[i].f < 0 && (!group_independent(ctx, rq.lo[i], rq.row_len) || !group_independent(ctx, rq.hi[i], rq.row_len))) {
+			// reads what a deferred fold touches, but not as that fold's output: those folds run first
+			rc = group_flush_touching(ctx, rq.lo[i], rq.row_len);
+			if (!rc) rc = group_flush_touching(ctx, rq.hi[i], rq.row_len);
+			if (rc) return rc;
+			for (uint32_t q = 0; q <= i; q++) ref[q] = find_output(ctx, rq.lo[q], rq.hi[q], rq.row_len); // (indices moved)
+		}
+	}
+	bn_ctx::group_session *self = session_for(ctx, rq, ref);
+	std::vector<bn::group_job> jobs;
+	std::vector<std::vector<char>> prefold; // per participating prover, per array
+	uint64_t n_fused = 0;
+	prefold.emplace_back(rq.m, 0);
+	plan(ctx, rq.m, rq.k, rq.pa, rq.pb, rq.lo, rq.hi, rq.row_len, ref, 0, jobs, prefold.back(), n_fused);
+	// consumed[f][j]: array j of deferred fold f is brought up to date by this launch (fused or plain)
+	std::vector<std::vector<char>> consumed(g.folds.size());
+	for (size_t f = 0; f < g.folds.size(); f++) consumed[f].assign(g.folds[f].count, 0);
+	for (uint32_t i = 0; i < rq.m; i++)
+		if (ref[i].f >= 0) consumed[ref[i].f][ref[i].j] = 1;
+	// ---- the other provers whose fold is waiting and whose claims are known: their next evaluation rides along
+	struct rider {
+		bn_ctx::group_session *s;
+		uint32_t slot0;
+		fold_ref ref[kMaxArrays];
+		const void *lo[kMaxArrays], *hi[kMaxArrays];
+		uint64_t row_len;
+	};
+	std::vector<rider> riders;
+	uint32_t n_slots = 2 * rq.k;
+	if (g.speculate) {
+		for (auto &s : g.sessions) {
+			if (&s == self || s.k == 0 || s.row_len < 2) continue;
+			if (jobs.size() + s.k > (size_t)bn::kGroupMaxJobs || n_slots + 2 * s.k > 64) continue;
+			rider r{};
+			r.s = &s;
+			r.row_len = s.row_len / 2;
+			bool ok = true;
+			for (uint32_t i = 0; i < s.m && ok; i++) {
+				r.ref[i] = find_input(ctx, s.lo[i], s.hi[i], s.row_len);
+				ok = r.ref[i].f >= 0 && !consumed[r.ref[i].f][r.ref[i].j];
+				if (ok) {
+					r.lo[i] = g.folds[r.ref[i].f].x0[r.ref[i].j];
+					r.hi[i] = at(r.lo[i], r.row_len);
+				}
+			}
+			if (!ok) continue;
+			r.slot0 = n_slots;
+			n_slots += 2 * s.k;
+			prefold.emplace_back(s.m, 0);
+			uint64_t nf = 0;
+			plan(ctx, s.m, s.k, s.pa, s.pb, r.lo, r.hi, r.row_len, r.ref, r.slot0, jobs, prefold.back(), nf);
+			n_fused += nf;
+			g.spec_jobs += s.k;
+			for (uint32_t i = 0; i < s.m; i++) consumed[r.ref[i].f][r.ref[i].j] = 1;
+			riders.push_back(r);
+		}
+	}
+	if (jobs.size() > (size_t)bn::kGroupMaxJobs || (int)jobs.size() > ctx->n_cu) return BN_OK; // (k <= 16 per prover: cannot happen; the eager kernels answer)
+	// ---- plain folds first: every consumed array that no job folds (shared arrays, arrays in no claim)
+	{
+		std::vector<std::vector<char>> plain(g.folds.size());
+		for (size_t f = 0; f < g.folds.size(); f++) plain[f].assign(g.folds[f].count, 0);
+		for (uint32_t i = 0; i < rq.m; i++)
+			if (prefold[0][i]) plain[ref[i].f][ref[i].j] = 1;
+		for (size_t r = 0; r < riders.size(); r++)
+			for (uint32_t i = 0; i < riders[r].s->m; i++)
+				if (prefold[r + 1][i]) plain[riders[r].ref[i].f][riders[r].ref[i].j] = 1;
+		// arrays of the participating provers' batches that appear in no request (an unconstrained column) stay deferred unless the
+		// whole batch is consumed otherwise -- they are folded with it so that the batch can be retired
+		for (size_t f = 0; f < g.folds.size(); f++) {
+			bool any = false;
+			for (uint32_t j = 0; j < g.folds[f].count; j++) any = any || consumed[f][j];
+			if (!any) continue;
+			for (uint32_t j = 0; j < g.folds[f].count; j++)
+				if (!consumed[f][j]) {
+					consumed[f][j] = 1;
+					plain[f][j] = 1;
+				}
+		}
+		for (size_t f = 0; f < g.folds.size(); f++) {
+			bn_ctx::group_fold part;
+			part.n = g.folds[f].n;
+			part.z = g.folds[f].z;
+			for (uint32_t j = 0; j < g.folds[f].count; j++)
+				if (plain[f][j]) {
+					part.x0[part.count] = g.folds[f].x0[j];
+					part.x1[part.count] = g.folds[f].x1[j];
+					part.src0[part.count] = g.folds[f].src0[j];
+					part.count++;
+				}
+			if (part.count) {
+				rc = launch_fold(ctx, part);
+				ctx->grp.flushed_folds--; // (not a flush: part of the round)
+				if (rc) return rc;
+				g.prefolds++;
+			}
+		}
+	}
+	// ---- the launch
+	if (!ctx->s_clean) {
+		BN_HIP(hipMemsetAsync(ctx->d_result, 0, 64 * sizeof(f128), ctx->stream));
+		ctx->s_clean = true;
+	}
+	const uint64_t seq = ++ctx->mail_seq;
+	{
+		prof_scope ps(ctx, BN_PROF_FOLD_EVAL_MFMA);
+		const hipError_t e = bn::launch_group(ctx->stream, ctx->n_cu, jobs.data(), (uint32_t)jobs.size(), n_slots, ctx->d_result, ctx->d_mail, ctx->d_ticket, seq);
+		if (e != hipSuccess) {
+			// nothing was enqueued by the failed launch; the plain folds above are part of what the caller asked for anyway.  The
+			// folds the jobs would have performed are still deferred: retire only what did run.
+			--ctx->mail_seq;
+			(void)hipGetLastError();
+			for (size_t f = g.folds.size(); f-- > 0;) {
+				// (arrays folded by the plain launches above must not be folded again)
+				bn_ctx::group_fold rest;
+				rest.n = g.folds[f].n;
+				rest.z = g.folds[f].z;
+				// which arrays of this batch ran?  exactly the `plain` ones -- recomputed: consumed and not fused
+				for (uint32_t j = 0; j < g.folds[f].count; j++) {
+					bool fused = false;
+					for (const auto &jb : jobs)
+						if (jb.kind == 0 && (jb.out[0] == g.folds[f].x0[j] || jb.out[1] == g.folds[f].x0[j])) fused = true;
+					if (!consumed[f][j] || fused) {
+						rest.x0[rest.count] = g.folds[f].x0[j];
+						rest.x1[rest.count] = g.folds[f].x1[j];
+						rest.src0[rest.count] = g.folds[f].src0[j];
+						rest.count++;
+					}
+				}
+				if (rest.count)
+					g.folds[f] = rest;
+				else
+					g.folds.erase(g.folds.begin() + (long)f);
+			}
+			rc = group_flush(ctx);
+			if (rc) return rc;
+			if (e == hipErrorNotSupported) return BN_OK; // (the eager kernels answer from up-to-date memory)
+			return bn::hip_fail(e, "launch_group");
+		}
+	}
+	g.launches++;
+	g.jobs_fused += n_fused;
+	g.jobs_eval += jobs.size() - n_fused;
+	// retire the consumed arrays
+	for (size_t f = g.folds.size(); f-- > 0;) {
+		bn_ctx::group_fold rest;
+		rest.n = g.folds[f].n;
+		rest.z = g.folds[f].z;
+		for (uint32_t j = 0; j < g.folds[f].count; j++)
+			if (!consumed[f][j]) {
+				rest.x0[rest.count] = g.folds[f].x0[j];
+				rest.x1[rest.count] = g.folds[f].x1[j];
+				rest.src0[rest.count] = g.folds[f].src0[j];
+				rest.count++;
+			}
+		if (rest.count)
+			g.folds[f] = rest;
+		else
+			g.folds.erase(g.folds.begin() + (long)f);
+	}
+	g.on = true;
+	rc = wait_mail(ctx, seq);
+	if (rc) return rc;
+	f128 raw[64];
+	for (uint32_t i = 0; i < n_slots; i++) {
+		raw[i].lo = __atomic_load_n(&ctx->h_mail[i].lo, __ATOMIC_RELAXED);
+		raw[i].hi = __atomic_load_n(&ctx->h_mail[i].hi, __ATOMIC_RELAXED);
+	}
+	answer(rq, raw, ret_values, n_ret, h_out);
+	record(ctx, *self, rq);
+	for (const auto &r : riders) {
+		bn_ctx::group_session &s = *r.s;
+		s.pre_valid = true;
+		s.pre_row_len = r.row_len;
+		for (uint32_t i = 0; i < s.m; i++) {
+			s.pre_lo[i] = r.lo[i];
+			s.pre_hi[i] = r.hi[i];
+		}
+		for (uint32_t c = 0; c < 2 * s.k; c++) s.pre_raw[c] = raw[r.slot0 + c];
+	}
+	g.evals++;
+	*handled = true;
+	return BN_OK;
+}
+
+} // namespace bnabi

@@ -475,6 +475,14 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 	BN_REQUIRE(n_ret <= 64, "too many returned values");
 	hipStream_t s = ctx->stream;
 
+	// ---- claim groups (abi_group.cpp): k product claims over m arrays, several provers' folds waiting -- the shape piop::prove
+	// issues.  Declines (handled = false) everything else, and a lone single-claim prover, which the machinery below keeps.
+	if (h_out && !d_out && n_ret > 0 && ops && n_ops) {
+		bool handled = false;
+		rc = group_eval(ctx, maps, n_maps, ops, n_ops, ret_values, n_ret, h_out, &handled);
+		if (rc || handled) return rc;
+	}
+
 	// Element-wise adds on buffers that the deferred fold neither reads nor writes commute with it: they run now and the
 	// fold stays deferred (the MLE-check prover folds its indicator table -- add the upper half onto the lower -- between
 	// the fold of its multilinears and the next round evaluation, v3/bivariate_mlecheck.rs:195-254).
@@ -624,7 +632,18 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 		}
 	}
 	if (need_materialise && local_bytes) {
-		char *mem = (char *)bn::ctx_scratch(ctx, local_bytes);
+		// The materialised Locals live in the context's scratch, and so do the temporaries of a generic composition compiled into
+		// passes (circuit_multipass_sum asks for local_bytes + its temporaries): the block is sized for BOTH here, once -- a later
+		// growth would free the Locals under the ops that already wrote them.
+		size_t temp_bytes = 0;
+		for (uint32_t o = 0; o < n_ops; o++) {
+			const bn_kop &op = ops[o];
+			if (op.kind != BN_KOP_SUM_COMPOSITION || !op.expr || op.expr->shape == bn_expr::PRODUCT || !op.n_rows) continue;
+			if (!circuit_multipass_applies(ctx, op.expr, op.rows[0].len)) continue;
+			const int t = circuit_multipass_sum_temps(op.expr, false);
+			if (t > 0 && (size_t)t * op.rows[0].len * sizeof(f128) > temp_bytes) temp_bytes = (size_t)t * op.rows[0].len * sizeof(f128);
+		}
+		char *mem = (char *)bn::ctx_scratch(ctx, local_bytes + temp_bytes);
 		if (!mem)
 			return bn::fail(BN_ERR_ALLOC, "allocation error: allocator is out of memory (Local kernel buffers)");
 		BN_HIP(hipMemsetAsync(mem, 0, local_bytes, s)); // "initialized with zeros", layer.rs:154-156
@@ -864,8 +883,13 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 								if (ctx->ht.active) {
 									bn_ctx::host_tail_state &ht = ctx->ht;
 									auto is = [&](int f, int j) { return lo[f] == ht.cur_lo[j] && hi[f] == ht.cur_hi[j]; };
+									// (a caller that exchanges the host rounds' partial sums itself -- bn_host_tail_allow_peer -- XORs the ranks' RETURNED
+									// values: a non-zero initial value would be counted once per rank, so only zero initial values are answered here)
+									bool init_ok = true;
+									if (ctx->ht_peer_ok)
+										for (uint32_t v = 0; v < n_values; v++) init_ok = init_ok && h_values[v] == f128{0, 0};
 									const bool match = k == 2 && !ht.evaluated && !peer_on && h_out && !d_out && 2 * row_len == ht.cur_m && lo[0] && lo[1] &&
-									                   ((is(0, 0) && is(1, 1)) || (is(0, 1) && is(1, 0))) && two_round_recipe_ok(fz);
+									                   ((is(0, 0) && is(1, 1)) || (is(0, 1) && is(1, 0))) && two_round_recipe_ok(fz) && init_ok;
 									if (match) {
 										bn::hp128 p1, pi;
 										bn::hostpoly_round_sums(reinterpret_cast<const bn::hp128 *>(ht.y[0].data()), reinterpret_cast<const bn::hp128 *>(ht.y[1].data()), row_len, &p1, &pi);

@@ -73,9 +73,9 @@ struct bn_ctx {
 		bn::f128 z{0, 0};
 		uint32_t scale_mask = 0; // bit i: the upper half of folded array i is multiplied by hi_scale (bn_extrapolate_line_batch_scaled)
 		bn::f128 hi_scale{0, 0};
-		void *x0[8] = {};        // evals_0: written in place ...
-		const void *x1[8] = {};
-		const void *src0[8] = {}; // ... and read from here (== x0 unless a deferred copy_d2d fed it)
+		void *x0[32] = {};        // evals_0: written in place ...   (32 = bn::kFoldBatchMax, declared below)
+		const void *x1[32] = {};
+		const void *src0[32] = {}; // ... and read from here (== x0 unless a deferred copy_d2d fed it)
 	} pend;
 	// a SECOND deferred fold, chained in place on pend's output: exists only between the call that answered a round from
 	// the precomputed sums below and the next round evaluation, which then folds twice (kernels_foldeval8.hip)
@@ -146,8 +146,8 @@ struct bn_ctx {
 		bool host = false; // the values were computed on the host (host_vals): nothing to wait for
 		uint64_t seq = 0;
 		uint32_t count = 0, n = 0;
-		const void *ptr[8] = {};
-		bn::f128 host_vals[8] = {};
+		const void *ptr[32] = {};
+		bn::f128 host_vals[32] = {};
 	} mirror;
 	// The four elements per array that the LAST two-round launch of a sumcheck leaves (kernels_foldeval8.hip publishes them
 	// beside its sums): the two folds that remain are six host products, so the caller's read of the final evaluations does
@@ -220,6 +220,37 @@ struct bn_ctx {
 	uint64_t arm_hits = 0, arm_cancels = 0, arm_expired = 0;
 	uint64_t arm_ns_parse = 0; // entry of bn_kernel_launch -> challenge handed over
 	uint64_t arm_ns_wait = 0, arm_ns_launch = 0; // go -> mailbox seen; of which: enqueueing the next armed kernel
+	// ---- claim groups (abi_group.cpp, kernels_group.hip): any number of deferred folds, each a prover's batch, beside the legacy
+	// single slot `pend`; the product claims of every prover that is ready evaluated in ONE launch, the others' sums kept for
+	// their execute().  The unit is the PROVER (a session: its arrays and claims), not the context.
+	struct group_fold {
+		uint32_t count = 0;
+		uint64_t n = 0; // elements per half = elements of the folded array
+		bn::f128 z{0, 0};
+		void *x0[32] = {};
+		const void *x1[32] = {};
+		const void *src0[32] = {};
+	};
+	struct group_session {
+		uint32_t m = 0, k = 0;                      // arrays, product claims
+		uint64_t row_len = 0;                       // points of the last evaluation
+		const void *lo[32] = {}, *hi[32] = {};      // the arrays' halves at the last evaluation (what the prover's next fold reads)
+		uint8_t pa[32] = {}, pb[32] = {};           // the claims, as indices into the arrays
+		bool pre_valid = false;                     // the raw sums of the NEXT evaluation were computed ahead ...
+		uint64_t pre_row_len = 0;                   // ... of these halves
+		const void *pre_lo[32] = {}, *pre_hi[32] = {};
+		bn::f128 pre_raw[64] = {};                  // claim c: [2 c] at 1, [2 c + 1] at infinity
+		uint64_t stamp = 0;
+	};
+	struct group_state {
+		bool enabled = true;   // BN_GROUP=0: every call takes the single-claim machinery / the eager kernels
+		bool speculate = true; // BN_GROUP_SPEC=0: a launch only carries the calling prover's claims
+		bool on = false;       // a group fold or evaluation happened since the last full flush: single-claim requests join in
+		std::vector<group_fold> folds;
+		std::vector<group_session> sessions;
+		uint64_t stamp = 0;
+		uint64_t launches = 0, jobs_fused = 0, jobs_eval = 0, prefolds = 0, spec_jobs = 0, spec_hits = 0, evals = 0, flushed_folds = 0;
+	} grp;
 	// cross-rank reduction inside the finalize step (bn_peer_*, finalize.hpp peer_exchange)
 	struct peer_state {
 		uint32_t world = 0, rank = 0;
@@ -252,7 +283,7 @@ hipError_t launch_fill(hipStream_t s, void *dst, uint64_t n, f128 v);
 hipError_t launch_add_assign(hipStream_t s, void *dst, const void *src, uint64_t n);
 hipError_t launch_add(hipStream_t s, void *dst, const void *src1, const void *src2, uint64_t n);
 hipError_t launch_extrapolate_line(hipStream_t s, int n_cu, void *evals_0, const void *evals_1, uint64_t n, f128 z);
-constexpr int kFoldBatchMax = 8;
+constexpr int kFoldBatchMax = 32; // (bn_ctx::pending_fold, bn_ctx::mirror_state and the shims' FOLD_BATCH_MAX follow)
 struct fold_batch {
 	void *x0[kFoldBatchMax];
 	const void *x1[kFoldBatchMax];
@@ -396,6 +427,21 @@ hipError_t launch_roundeval_fp4_split(hipStream_t s, int n_cu, const void *a, co
 hipError_t launch_roundeval_mfma_split(hipStream_t s, int n_cu, const void *a, const void *b, uint64_t n, uint64_t split_off, f128 *d_out);
 hipError_t launch_foldeval_mfma(hipStream_t s, int n_cu, const foldeval_args &fa, uint64_t n_in, f128 z, f128 *d_out, const fin_fuse *fuse,
                                 const arm_args *armed = nullptr);
+
+// ---- kernels_group.hip: the product claims of a whole batch round of sumchecks as jobs of ONE launch; returns raw sums
+constexpr int kGroupMaxJobs = 32;
+struct group_job {
+	const void *x0[2], *x1[2]; // kind 0: lower / upper half of the two arrays BEFORE the fold (2 n elements each); kind 1: lower half (evaluations
+	                           // at 0) / upper half (evaluations at 1) of the two arrays as they are (n elements each)
+	void *out[2];              // kind 0: where the folded arrays (2 n elements each) are written (may be x0)
+	f128 z;                    // kind 0: the fold's challenge
+	uint64_t n;                // evaluation points of the job
+	uint32_t kind;             // 0 = fold + evaluate, 1 = evaluate
+	uint32_t slot;             // the job's sums are XORed into S[slot] (at 1) and S[slot + 1] (at infinity)
+	uint32_t wg_begin, wg_count; // (filled in by the launcher)
+};
+hipError_t launch_group(hipStream_t s, int n_cu, const group_job *jobs, uint32_t n_jobs, uint32_t n_slots, f128 *d_S, f128 *d_mail, unsigned *d_counter,
+                        uint64_t seq);
 
 // ---- kernels_hal.hip: general forms of the old HAL's round calculation and lerp fold (abi_hal.cpp)
 constexpr int kHalMaxMl = 16, kHalMaxEv = 8, kHalMaxPts = 13;

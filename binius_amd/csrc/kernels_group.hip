@@ -1,0 +1,397 @@
+// binius_amd/csrc/kernels_group.hip -- ONE launch for a whole batch round of bivariate sumchecks: every product claim of every
+// prover that is ready becomes a JOB of the launch -- the fold of the claim's two multilinears fused with the evaluation of the
+// next round polynomial (kind 0), or the evaluation alone (kind 1) -- and the launch returns the RAW sums of all jobs.
+//
+//   kind 0   a'[i] = a[i] + z (a[i + N/2] - a[i]), likewise b'          (extrapolate_line, compute/src/layer.rs:421)
+//            S_1   = sum_{j < N/4} a'[j + N/4] b'[j + N/4]
+//            S_inf = sum_{j < N/4} (a'[j] + a'[j + N/4]) (b'[j] + b'[j + N/4])
+//   kind 1   S_1 = sum_j a_1[j] b_1[j], S_inf = sum_j (a_0[j] + a_1[j]) (b_0[j] + b_1[j]) over the halves a_0 | a_1, b_0 | b_1 as they are
+//
+// Why.  The reference's PCS prover issues k product claims over m multilinears per prover and runs several provers front-loaded
+// on one ComputeLayer: per batch round  execute(P_1) .. execute(P_p), one challenge, fold(P_1) .. fold(P_p)
+// (core/src/piop/prove.rs:271-287, core/src/protocols/sumcheck/prove/front_loaded.rs:122-155,
+// v3/bivariate_product.rs:303-408).  kernels_foldeval_fp4.hip fuses exactly ONE claim over two arrays.  Here the workgroups of
+// one launch are dealt out to the jobs (job j owns workgroups [wg_begin, wg_begin + wg_count): its own tile order, its own
+// nibble table for its own challenge, its own pair of accumulator slots); inside its range a workgroup is the twelve-wave
+// workgroup of kernels_foldeval_fp4.hip -- waves 4 .. 11 fold / load and stage a pair of tiles, waves 0 .. 3 run the FP4 Gram
+// k-steps of the previous pair (gram_fp4.hpp).  The last workgroup of the LAUNCH (device-scope ticket) copies all accumulator
+// slots to the pinned mailbox and re-zeroes them; the batch coefficients (value = init + sum_c alpha^c S_c,
+// cpu/layer.rs:512) are applied by the host, which keeps the kernel independent of the caller's recipe -- so the sums of a
+// prover whose execute() has not been called yet can be computed in the same launch (abi_group.cpp).
+//
+// Algorithmic bytes per job: kind 0 read 16 * 2 * N + write 8 * 2 * N = 48 N (24 * m * N summed over a prover's disjoint claims);
+// kind 1 read 16 * 2 * (N / 2) = 16 N.
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdlib>
+
+#include "ctable.hpp"
+#include "gram_fp4.hpp"
+
+namespace bn {
+
+using namespace gram4;
+
+namespace {
+
+typedef unsigned int gq_v4u __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ uint4 gq_load(const uint4 *p)
+{
+	if constexpr (NT) {
+		const gq_v4u v = __builtin_nontemporal_load(reinterpret_cast<const gq_v4u *>(p));
+		return uint4{v.x, v.y, v.z, v.w};
+	} else {
+		return *p;
+	}
+}
+template <bool NT>
+__device__ __forceinline__ void gq_store(uint4 *p, uint4 r)
+{
+	if constexpr (NT) {
+		const gq_v4u v = {r.x, r.y, r.z, r.w};
+		__builtin_nontemporal_store(v, reinterpret_cast<gq_v4u *>(p));
+	} else {
+		*p = r;
+	}
+}
+
+constexpr unsigned kGramWaves = 4;  // waves 0 .. 3: the Gram k-steps (one per SIMD)
+constexpr unsigned kFoldGroups = 2; // waves 4 .. 11: two groups of four waves, a tile per group
+constexpr unsigned kThreads = 64 * kGramWaves * (1 + kFoldGroups);
+
+// everything but the job table; the table follows in the same kernel-argument block and is indexed through the
+// kernarg segment pointer (a by-value array indexed with a run-time job number would be copied to scratch)
+struct group_kargs {
+	group_job jobs[kGroupMaxJobs];
+	f128 *S;           // accumulator slots (zero before the launch, zero after it)
+	f128 *mail;        // pinned mailbox: [0, n_slots) the raw sums, word 64 the sequence number
+	unsigned *counter; // device-scope ticket (zero between launches)
+	uint64_t seq;
+	uint32_t n_jobs, n_slots, prio, pad;
+};
+
+// the job table as it lies in the kernel-argument segment (scalar loads with a run-time index; the host pass of the compiler
+// never executes this)
+__device__ __forceinline__ const group_job *job_table()
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	return (const group_job *)__builtin_amdgcn_kernarg_segment_ptr();
+#else
+	return nullptr;
+#endif
+}
+
+} // namespace
+
+template <bool FULL, bool NT>
+__global__ __launch_bounds__(kThreads, 1) void k_group_fp4(group_kargs ga)
+{
+	extern __shared__ __attribute__((aligned(16))) uint32_t T_dyn[]; // 2 buffers x 2 tiles of FP4 operands
+	__shared__ ctable_smem tab;
+	__shared__ gram_parity Gc;
+	const unsigned lane = threadIdx.x & 63;
+	const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const bool folds = wave >= kGramWaves;
+	const unsigned grp = folds ? (wave - kGramWaves) >> 2 : 0;   // fold group: which tile of the pair
+	const unsigned ftid = (threadIdx.x - 64 * kGramWaves) & 255; // the lane's point inside its tile (fold waves)
+
+	// ---- this workgroup's job (uniform): the table is sorted by wg_begin
+	static_assert(offsetof(group_kargs, jobs) == 0, "the job table leads the kernel-argument block");
+	const group_job *const jt = job_table();
+	unsigned ji = 0;
+	for (unsigned i = 1; i < ga.n_jobs; i++)
+		if (blockIdx.x >= jt[i].wg_begin) ji = i;
+	const group_job *const jb = jt + ji;
+	const uint32_t kind = jb->kind;
+	const uint64_t n = jb->n; // evaluation points of the job
+	const uint32_t n_tiles = (uint32_t)(FULL ? n / kTP : (n + kTP - 1) / kTP);
+	const uint32_t G = jb->wg_count, b = blockIdx.x - jb->wg_begin;
+	const char *const X0[2] = {reinterpret_cast<const char *>(jb->x0[0]), reinterpret_cast<const char *>(jb->x0[1])};
+	const char *const X1[2] = {reinterpret_cast<const char *>(jb->x1[0]), reinterpret_cast<const char *>(jb->x1[1])};
+	char *const OUT[2] = {reinterpret_cast<char *>(jb->out[0]), reinterpret_cast<char *>(jb->out[1])};
+
+	// tile order inside the job's range: as kernels_foldeval_mfma.hip (XCD x = blockIdx.x & 7 takes the x-th contiguous eighth of
+	// the job's tiles) when the range starts on a multiple of eight workgroups and is a multiple of eight long
+	uint32_t tbase = 0, tstride = G, tlimit = n_tiles, t0 = b;
+	if ((G & 7) == 0 && (jb->wg_begin & 7) == 0) {
+		const uint32_t chunk = (n_tiles + 7) >> 3;
+		tbase = (b & 7) * chunk;
+		tstride = G >> 3;
+		t0 = b >> 3;
+		tlimit = tbase >= n_tiles ? 0 : (n_tiles - tbase < chunk ? n_tiles - tbase : chunk);
+	}
+
+	// quadrant q = 2 * side + half.  kind 0: x0[q] / x1[q] = the two elements the fold of (side, half) reads; kind 1: x0[q] = the
+	// element of (side, half) itself.
+	uint4 x0[4], x1[4];
+	const uint32_t voff = ftid * 16u;
+	auto lane_off = [&]() { // (kernels_foldeval_fp4.hip: keeps the lane offset out of a loop-invariant 64-bit vector base)
+		uint32_t v = voff;
+		asm volatile("" : "+v"(v));
+		return v;
+	};
+	uint32_t vo = lane_off();
+	auto in_range = [&](uint32_t t) { return FULL || (uint64_t)(tbase + t) * kTP + ftid < n; };
+	auto load1 = [&](uint32_t t, int q) {
+		const uint64_t e = ((q & 1 ? n : 0) + (uint64_t)(tbase + t) * kTP) * 16; // (uniform)
+		const uint32_t o = in_range(t) ? vo : 0u; // (a lane past the end reads the tile's first element: in range, never used)
+		if (kind == 0) {
+			x0[q] = gq_load<NT>(reinterpret_cast<const uint4 *>(X0[q >> 1] + e + o));
+			x1[q] = gq_load<NT>(reinterpret_cast<const uint4 *>(X1[q >> 1] + e + o));
+		} else {
+			const uint64_t e1 = (uint64_t)(tbase + t) * kTP * 16;
+			x0[q] = gq_load<NT>(reinterpret_cast<const uint4 *>((q & 1 ? X1[q >> 1] : X0[q >> 1]) + e1 + o));
+		}
+	};
+	const uint32_t tm0 = t0 + grp * tstride; // this fold group's first tile
+	if (folds && tm0 < tlimit) {
+#pragma unroll
+		for (int q = 0; q < 4; q++)
+			load1(tm0, q);
+	}
+	if (kind == 0)
+		ctable_build(tab, jb->z); // (uniform per workgroup; the loads above are in flight meanwhile; ends with a barrier)
+	if (folds) {
+		switch (ga.prio & 3) { // the fold waves issue ahead of the Gram wave of their SIMD (kernels_foldeval_fp4.hip)
+		case 1: __builtin_amdgcn_s_setprio(1); break;
+		case 2: __builtin_amdgcn_s_setprio(2); break;
+		case 3: __builtin_amdgcn_s_setprio(3); break;
+		default: break;
+		}
+		const stage4_role sr = make_stage4_role(ftid);
+		uint32_t *Tn = T_dyn + grp * kTile4W;
+		unsigned buf = 0;
+		for (uint32_t t = t0; t < tlimit; t += 2 * tstride) {
+			const uint32_t tm = t + grp * tstride;
+			if (tm < tlimit) { // (uniform; false only for group 1 on an odd last pair)
+				// the last iteration re-requests its own tile (cache hits) instead of branching around the loads
+				const uint32_t tn = tm + 2 * tstride < tlimit ? tm + 2 * tstride : tm;
+				vo = lane_off();
+				const bool ok = in_range(tm);
+				uint4 f[4];
+				if (kind == 0) {
+					const uint64_t pt16 = (uint64_t)(tbase + tm) * kTP * 16; // (uniform)
+#pragma unroll
+					for (int q = 0; q < 4; q++) {
+						f[q] = ctable_mul_acc<8, true>(tab, xor4(x0[q], x1[q]), x0[q]);
+						load1(tn, q); // this quadrant of the group's next tile flies from here on
+					}
+					if (FULL || ok) {
+#pragma unroll
+						for (int q = 0; q < 4; q++)
+							gq_store<NT>(reinterpret_cast<uint4 *>(OUT[q >> 1] + (q & 1 ? n * 16 : 0) + pt16 + vo), f[q]);
+					}
+				} else {
+#pragma unroll
+					for (int q = 0; q < 4; q++) {
+						f[q] = x0[q];
+						load1(tn, q);
+					}
+				}
+				if (!FULL && !ok) {
+#pragma unroll
+					for (int q = 0; q < 4; q++)
+						f[q] = uint4{0, 0, 0, 0}; // points past the end carry zeros
+				}
+				// half 1 is the evaluation at 1, half 0 its partner: sets 0 / 1 = u, v at 1; sets 2 / 3 = u, v at infinity
+				stage4_elem(Tn, sr, 0, f[1]);
+				stage4_elem(Tn, sr, 2, xor4(f[1], f[0]));
+				stage4_elem(Tn, sr, 1, f[3]);
+				stage4_elem(Tn, sr, 3, xor4(f[3], f[2]));
+			}
+			__syncthreads(); // the pair is staged; the Gram waves are done with the buffer this wave writes next
+			buf ^= 1;
+			Tn = T_dyn + (buf * kFoldGroups + grp) * kTile4W;
+		}
+	} else {
+		const gram4_role gr = make_gram4_role(wave, lane);
+		v16f acc[kAccTiles];
+		acc4_zero(acc);
+		unsigned buf = 0;
+		for (uint32_t t = t0; t < tlimit; t += 2 * tstride) {
+			__syncthreads();
+			const uint32_t *Tp = T_dyn + buf * kFoldGroups * kTile4W;
+			gram4_tile(Tp, gr, acc);
+			if (t + tstride < tlimit) gram4_tile(Tp + kTile4W, gr, acc);
+			buf ^= 1;
+		}
+		parity4(acc, gr, wave, lane, Gc);
+	}
+
+	// ---- tail: parity words -> the job's two sums -> its accumulator slots; the last workgroup of the launch publishes ALL slots
+	__shared__ uint64_t z3[2][3];
+	__shared__ f128 s_loc[2];
+	__shared__ unsigned is_last;
+	const unsigned tid = threadIdx.x;
+	__syncthreads();
+	// column n' = 32 h + n of matrix (pr, s) as a GF(2^64) element (bit p = G[p][n']); z = sum_n' col * e_n'  (gram.hpp tail_finish)
+	for (unsigned task = wave; task < 6; task += kThreads / 64) {
+		const unsigned pr = task / 3, s = task - 3 * pr;
+		const unsigned h = lane >> 5, nn = lane & 31;
+		auto spread = [](uint32_t x) { return (x & 0xFu) | ((x & 0xF0u) << 4) | ((x & 0xF00u) << 8) | ((x & 0xF000u) << 12); };
+		const uint32_t *g0 = Gc[2 * pr + h][2 * s], *g1 = Gc[2 * pr + h][2 * s + 1];
+		const uint32_t lo = spread(g0[nn]) | (spread(g0[nn + 32]) << 4);
+		const uint32_t hi = spread(g1[nn]) | (spread(g1[nn + 32]) << 4);
+		uint64_t z = mul_basis64((uint64_t)lo | ((uint64_t)hi << 32), lane);
+#pragma unroll
+		for (int mm = 32; mm >= 1; mm >>= 1)
+			z ^= __shfl_xor(z, mm, 64);
+		if (lane == 0) z3[pr][s] = z;
+	}
+	__syncthreads();
+	if (tid < 2) s_loc[tid] = kara64(z3[tid][0], z3[tid][1], z3[tid][2]);
+	__syncthreads();
+	if (tid < 4) {
+		const uint64_t v = reinterpret_cast<const uint64_t *>(s_loc)[tid];
+		if (v) atomicXor(reinterpret_cast<unsigned long long *>(ga.S + jb->slot) + tid, (unsigned long long)v);
+	}
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	__syncthreads();
+	if (tid == 0) {
+		const unsigned tk = atomicAdd(ga.counter, 1u);
+		is_last = (tk == gridDim.x - 1) ? 1u : 0u;
+	}
+	__syncthreads();
+	if (is_last) {
+		// (n_slots <= 64: everything below happens in wave 0, whose drain orders the value stores before the sequence word --
+		// posted writes to one destination keep their order; finalize.hpp)
+		if (tid < ga.n_slots) {
+			f128 v;
+			v.lo = __hip_atomic_load(&ga.S[tid].lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			v.hi = __hip_atomic_load(&ga.S[tid].hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			__hip_atomic_store(&ga.mail[tid].lo, v.lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			__hip_atomic_store(&ga.mail[tid].hi, v.hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			__hip_atomic_store(&ga.S[tid].lo, (uint64_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			__hip_atomic_store(&ga.S[tid].hi, (uint64_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		if (tid < 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		if (tid == 0) {
+			__hip_atomic_store(&ga.mail[64].lo, ga.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			__hip_atomic_store(ga.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+	}
+}
+
+// Deals the workgroups of one launch out to the jobs (in proportion to their traffic, eight at a time where a job gets at
+// least eight so that its tiles keep the XCD-aware order), sorts the table by first workgroup and launches.  jobs[i].slot is
+// the caller's; wg_begin / wg_count are filled in here.  Every job: n >= 1; kind 0 jobs write out[] (2 n elements each).
+hipError_t launch_group(hipStream_t s, int n_cu, const group_job *jobs_in, uint32_t n_jobs, uint32_t n_slots, f128 *d_S, f128 *d_mail, unsigned *d_counter,
+                        uint64_t seq)
+{
+	if (n_jobs == 0 || n_jobs > (uint32_t)kGroupMaxJobs || n_slots > 64 || n_cu < (int)n_jobs) return hipErrorNotSupported;
+	static const uint32_t prio = [] {
+		const char *e = getenv("BN_FE_FP4_PRIO");
+		return e ? (uint32_t)atoi(e) & 3u : 3u;
+	}();
+	group_kargs ga{};
+	bool full = true;
+	uint64_t total_elems = 0;
+	double w[kGroupMaxJobs], W = 0;
+	uint32_t tiles[kGroupMaxJobs], cap[kGroupMaxJobs], cnt[kGroupMaxJobs];
+	for (uint32_t i = 0; i < n_jobs; i++) {
+		const group_job &j = jobs_in[i];
+		if (j.n == 0 || j.kind > 1 || j.slot + 2 > n_slots) return hipErrorInvalidValue;
+		if (j.n % kTP) full = false;
+		const uint64_t nt = (j.n + kTP - 1) / kTP;
+		if (nt > (1ull << 14) * (uint64_t)n_cu) return hipErrorNotSupported; // 2^22 points per workgroup: the f32 counts stay exact
+		tiles[i] = (uint32_t)nt;
+		cap[i] = (uint32_t)(nt >= 2 ? nt / 2 : 1); // a workgroup wants a pair of tiles
+		w[i] = (double)nt * (j.kind == 0 ? 3.0 : 1.0);
+		W += w[i];
+		total_elems += j.n * (j.kind == 0 ? 8 : 4);
+	}
+	// first pass: the proportional share, rounded down (to a multiple of eight from eight on), at least the workgroups the
+	// exactness bound asks for, at most one per pair of tiles
+	uint32_t used = 0;
+	for (uint32_t i = 0; i < n_jobs; i++) {
+		uint32_t c = (uint32_t)((double)n_cu * w[i] / W);
+		if (c >= 8) c &= ~7u;
+		const uint32_t need = (tiles[i] + (1u << 14) - 1) >> 14;
+		if (c < need) c = need;
+		if (c > cap[i]) c = cap[i];
+		if (c < 1) c = 1;
+		cnt[i] = c;
+		used += c;
+	}
+	// (minimums can overshoot only with very many very uneven jobs: take from the largest)
+	while (used > (uint32_t)n_cu) {
+		uint32_t big = 0;
+		for (uint32_t i = 1; i < n_jobs; i++)
+			if (cnt[i] > cnt[big]) big = i;
+		if (cnt[big] <= 1) return hipErrorNotSupported;
+		const uint32_t need = (tiles[big] + (1u << 14) - 1) >> 14;
+		if (cnt[big] - 1 < need) return hipErrorNotSupported;
+		cnt[big]--;
+		used--;
+	}
+	// the rest goes to whoever has the most work per workgroup, eight at a time for jobs in multiples of eight
+	for (;;) {
+		int best = -1;
+		double best_load = 0;
+		for (uint32_t i = 0; i < n_jobs; i++) {
+			const uint32_t step = (cnt[i] >= 8 && (cnt[i] & 7) == 0) ? 8 : 1;
+			if (cnt[i] + step > cap[i] || used + step > (uint32_t)n_cu) continue;
+			const double load = w[i] / cnt[i];
+			if (load > best_load) {
+				best_load = load;
+				best = (int)i;
+			}
+		}
+		if (best < 0) break;
+		const uint32_t step = (cnt[best] >= 8 && (cnt[best] & 7) == 0) ? 8 : 1;
+		cnt[best] += step;
+		used += step;
+	}
+	// table order: the jobs whose count is a multiple of eight first (their ranges then start on multiples of eight)
+	uint32_t order[kGroupMaxJobs], no = 0;
+	for (uint32_t i = 0; i < n_jobs; i++)
+		if ((cnt[i] & 7) == 0) order[no++] = i;
+	for (uint32_t i = 0; i < n_jobs; i++)
+		if ((cnt[i] & 7) != 0) order[no++] = i;
+	uint32_t at = 0;
+	for (uint32_t k = 0; k < n_jobs; k++) {
+		ga.jobs[k] = jobs_in[order[k]];
+		ga.jobs[k].wg_begin = at;
+		ga.jobs[k].wg_count = cnt[order[k]];
+		at += cnt[order[k]];
+	}
+	ga.S = d_S;
+	ga.mail = d_mail;
+	ga.counter = d_counter;
+	ga.seq = seq;
+	ga.n_jobs = n_jobs;
+	ga.n_slots = n_slots;
+	ga.prio = prio;
+	static const int nt_min_log2 = [] {
+		const char *e = getenv("BN_FE_NT_MIN_LOG2");
+		return e ? atoi(e) : 25;
+	}();
+	// streaming accesses once the launch's arrays cannot stay in the caches anyway (the single-claim kernels' threshold is 2^25
+	// elements per array = 2^27 elements touched)
+	const bool nt = full && nt_min_log2 < 62 && total_elems >= (4ull << nt_min_log2);
+	constexpr unsigned lds = 2 * kFoldGroups * kTile4W * 4;
+	// (hipFuncSetAttribute is per device: once per device and process)
+	static bool attr_done[64] = {};
+	int dev = 0;
+	(void)hipGetDevice(&dev);
+	if (dev < 0 || dev >= 64 || !attr_done[dev]) {
+		const void *fn[4] = {reinterpret_cast<const void *>(&k_group_fp4<false, false>), reinterpret_cast<const void *>(&k_group_fp4<true, false>),
+		                     reinterpret_cast<const void *>(&k_group_fp4<true, true>), nullptr};
+		for (int i = 0; fn[i]; i++) {
+			const hipError_t e = hipFuncSetAttribute(fn[i], hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+			if (e != hipSuccess) return e;
+		}
+		if (dev >= 0 && dev < 64) attr_done[dev] = true;
+	}
+	if (nt)
+		hipLaunchKernelGGL((k_group_fp4<true, true>), dim3(at), dim3(kThreads), lds, s, ga);
+	else if (full)
+		hipLaunchKernelGGL((k_group_fp4<true, false>), dim3(at), dim3(kThreads), lds, s, ga);
+	else
+		hipLaunchKernelGGL((k_group_fp4<false, false>), dim3(at), dim3(kThreads), lds, s, ga);
+	return hipGetLastError();
+}
+
+} // namespace bn

@@ -660,7 +660,7 @@ private:
 			size_t j = i;
 			uint32_t mask = 0;
 			B128 hs{};
-			while (j < todo.size() && e0.size() < 8 && todo[j].len == todo[i].len && todo[j].z == todo[i].z &&
+			while (j < todo.size() && e0.size() < 32 /* bn::kFoldBatchMax */ && todo[j].len == todo[i].len && todo[j].z == todo[i].z &&
 			       !(todo[j].scaled && mask && !(todo[j].hi_scale == hs))) {
 				if (todo[j].scaled) {
 					mask |= 1u << e0.size();

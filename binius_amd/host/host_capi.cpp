@@ -25,6 +25,7 @@
 #include <cstring>
 
 #include "fri.hpp"
+#include "piop.hpp"
 #include "sumcheck.hpp"
 
 using namespace binius_amd;
@@ -639,6 +640,155 @@ int bnh_fri_commit_fold(bn_ctx *ctx, uint32_t log_dim, uint32_t log_inv_rate, ui
 		if (phase_ms_out) {
 			phase_ms_out[0] = std::chrono::duration<double, std::milli>(t1 - t0).count();
 			phase_ms_out[1] = std::chrono::duration<double, std::milli>(t2 - t1).count();
+		}
+		return 0;
+	} catch (const Error &e) {
+		g_err = e.what();
+		return (int)e.kind();
+	} catch (const std::exception &e) {
+		g_err = e.what();
+		return BN_ERR_CORE_LIB;
+	}
+}
+
+// piop::prove (crates/core/src/piop/prove.rs:148-395) through the C++ mirror piop.hpp: commit_interleaved of the merged message,
+// one BivariateSumcheckProver per number of variables, the front-loaded batch prover interleaved with the FRI folder.
+// The transcript comes back as a list of items in writing order: items_out[2 i] = kind (0 round proof, 1 final evaluations of a
+// finished prover, 2 FRI round commitment, 3 FRI terminate codeword), items_out[2 i + 1] = number of scalars (kinds 0, 1, 3:
+// consumed from scalars_out in order) or 1 digest (kind 2: consumed from digests_out in order).
+int bnh_piop_prove(bn_ctx *ctx, uint32_t n_committed, const uint32_t *committed_n_vars, const void *const *d_committed, uint32_t n_transparent,
+                   const uint32_t *transparent_n_vars, const void *const *d_transparent, uint32_t n_claims, const uint32_t *claims, const bn_f128 *claim_sums,
+                   uint32_t log_dim, uint32_t log_inv_rate, uint32_t log_batch_size, const uint32_t *fold_arities, uint32_t n_arities, uint32_t n_test_queries,
+                   const void *d_message, void *d_scratch, uint64_t scratch_elems, const bn_f128 *batch_coeffs, uint32_t n_batch_coeffs,
+                   const bn_f128 *challenges, uint32_t n_challenges, uint8_t *commitment_out, uint32_t *items_out, uint32_t max_items, uint32_t *n_items_out,
+                   bn_f128 *scalars_out, uint64_t max_scalars, uint64_t *n_scalars_out, uint8_t *digests_out, uint32_t max_digests, uint32_t *n_digests_out,
+                   double *phase_ms_out)
+{
+	try {
+		if (!ctx || !commitment_out || !items_out || !n_items_out || !scalars_out || !n_scalars_out || !digests_out || !n_digests_out)
+			throw Error(Error::InputValidation, "null argument");
+		ComputeLayer hal(ctx);
+		DeviceBumpAllocator dev_alloc(FSliceMut{d_scratch, (size_t)scratch_elems});
+		std::vector<size_t> n_varss;
+		std::vector<FSlice> committed, transparents;
+		size_t host_elems = 8;
+		for (uint32_t i = 0; i < n_committed; i++) {
+			if (i && committed_n_vars[i] < committed_n_vars[i - 1]) throw PiopError("CommittedsNotSorted");
+			n_varss.push_back(committed_n_vars[i]);
+			committed.push_back(FSlice{d_committed[i], (size_t)1 << committed_n_vars[i]});
+			host_elems++;
+		}
+		for (uint32_t i = 0; i < n_transparent; i++) {
+			transparents.push_back(FSlice{d_transparent[i], (size_t)1 << transparent_n_vars[i]});
+			host_elems++;
+		}
+		std::vector<B128> host_mem(host_elems);
+		HostBumpAllocator host_alloc(HostSliceMut{host_mem.data(), host_mem.size()});
+		const CommitMeta commit_meta = CommitMeta::with_vars(n_varss);
+		if (commit_meta.total_vars() != (size_t)log_dim + log_batch_size) throw PiopError("FRI message length does not match the commit metadata's total_vars");
+		std::vector<PIOPSumcheckClaim> cl;
+		for (uint32_t i = 0; i < n_claims; i++)
+			cl.push_back(PIOPSumcheckClaim{claims[3 * i], claims[3 * i + 1], claims[3 * i + 2], B128(claim_sums[i].lo, claim_sums[i].hi)});
+		std::vector<B128> bcs, chs;
+		for (uint32_t i = 0; i < n_batch_coeffs; i++) bcs.emplace_back(batch_coeffs[i].lo, batch_coeffs[i].hi);
+		for (uint32_t i = 0; i < n_challenges; i++) chs.emplace_back(challenges[i].lo, challenges[i].hi);
+		FRIParams p(log_dim, log_inv_rate, log_batch_size, std::vector<size_t>(fold_arities, fold_arities + n_arities), n_test_queries);
+		AdditiveNTT ntt(hal, 5, p.rs_log_len());
+		BinaryMerkleTreeProver merkle(hal);
+		hal.sync();
+		const auto t0 = std::chrono::steady_clock::now();
+		CommitOutput co = commit_interleaved(hal, dev_alloc, p, ntt, merkle, FSlice{d_message, (size_t)1 << (log_dim + log_batch_size)});
+		hal.sync();
+		const auto t1 = std::chrono::steady_clock::now();
+		std::memcpy(commitment_out, co.commitment.data(), 32);
+		PiopProveOutput out = piop_prove(hal, dev_alloc, host_alloc, p, ntt, merkle, commit_meta, co.committed, ComputeMemory::as_const(co.codeword), committed,
+		                                 transparents, cl, bcs, chs);
+		hal.sync();
+		const auto t2 = std::chrono::steady_clock::now();
+		uint32_t ni = 0, nd = 0;
+		uint64_t ns = 0;
+		for (const auto &it : out.transcript.items) {
+			if (ni >= max_items) throw Error(Error::InputValidation, "transcript has more items than items_out holds");
+			items_out[2 * ni] = (uint32_t)it.kind;
+			if (it.kind == PiopTranscript::Item::FriCommitment) {
+				if (nd >= max_digests) throw Error(Error::InputValidation, "transcript has more digests than digests_out holds");
+				std::memcpy(digests_out + 32 * (size_t)nd++, it.digest.data(), 32);
+				items_out[2 * ni + 1] = 1;
+			} else {
+				if (ns + it.scalars.size() > max_scalars) throw Error(Error::InputValidation, "transcript has more scalars than scalars_out holds");
+				for (const B128 &v : it.scalars) scalars_out[ns++] = v.raw();
+				items_out[2 * ni + 1] = (uint32_t)it.scalars.size();
+			}
+			ni++;
+		}
+		*n_items_out = ni;
+		*n_scalars_out = ns;
+		*n_digests_out = nd;
+		if (phase_ms_out) {
+			phase_ms_out[0] = std::chrono::duration<double, std::milli>(t1 - t0).count();
+			phase_ms_out[1] = std::chrono::duration<double, std::milli>(t2 - t1).count();
+		}
+		return 0;
+	} catch (const Error &e) {
+		g_err = e.what();
+		return (int)e.kind();
+	} catch (const std::exception &e) {
+		g_err = e.what();
+		return BN_ERR_CORE_LIB;
+	}
+}
+
+// The front-loaded batch prover alone (protocols/sumcheck/prove/front_loaded.rs:33-203: BatchProver::run with the transcript's
+// samples handed in): p BivariateSumcheckProvers on ONE layer, ascending by number of variables.
+//   prover_desc[3 * i] = (n_vars, m, n_comps) of prover i; d_multilins: the m pointers of prover 0, then of prover 1, ...;
+//   comp_indices / sums: likewise concatenated; batch_coeffs[n_provers]; challenges[max n_vars]
+//   round_proofs_out[2 * total_rounds]: the truncated round polynomial of every round (missing coefficients zero);
+//   final_evals_out: the provers' final evaluations concatenated in finishing (= input) order
+int bnh_batch_sumcheck_prove(bn_ctx *ctx, uint32_t n_provers, const uint32_t *prover_desc, const void *const *d_multilins, const uint32_t *comp_indices,
+                             const bn_f128 *sums, void *d_scratch, uint64_t scratch_elems, const bn_f128 *batch_coeffs, const bn_f128 *challenges,
+                             bn_f128 *round_proofs_out, bn_f128 *final_evals_out)
+{
+	try {
+		ComputeLayer hal(ctx);
+		DeviceBumpAllocator dev_alloc(FSliceMut{d_scratch, (size_t)scratch_elems});
+		size_t total_m = 0;
+		for (uint32_t i = 0; i < n_provers; i++) total_m += prover_desc[3 * i + 1];
+		std::vector<B128> host_mem(total_m + 8);
+		HostBumpAllocator host_alloc(HostSliceMut{host_mem.data(), host_mem.size()});
+		std::vector<std::unique_ptr<BivariateSumcheckProver>> provers;
+		std::vector<B128> bcs;
+		size_t at_ml = 0, at_c = 0;
+		for (uint32_t i = 0; i < n_provers; i++) {
+			const uint32_t n_vars = prover_desc[3 * i], m = prover_desc[3 * i + 1], nc = prover_desc[3 * i + 2];
+			std::vector<FSlice> mls;
+			for (uint32_t j = 0; j < m; j++) mls.push_back(FSlice{d_multilins[at_ml + j], (size_t)1 << n_vars});
+			std::vector<IndexCompositionBivariate> comps;
+			std::vector<B128> sv;
+			for (uint32_t c = 0; c < nc; c++) {
+				comps.push_back(IndexCompositionBivariate{m, {comp_indices[2 * (at_c + c)], comp_indices[2 * (at_c + c) + 1]}});
+				sv.emplace_back(sums[at_c + c].lo, sums[at_c + c].hi);
+			}
+			at_ml += m;
+			at_c += nc;
+			provers.push_back(std::make_unique<BivariateSumcheckProver>(hal, dev_alloc, host_alloc, n_vars, comps, sv, mls));
+			bcs.emplace_back(batch_coeffs[i].lo, batch_coeffs[i].hi);
+		}
+		SumcheckBatchProver batch(std::move(provers), bcs);
+		const size_t rounds = batch.total_rounds();
+		PiopTranscript tr;
+		for (size_t r = 0; r < rounds; r++) {
+			batch.send_round_proof(tr);
+			batch.receive_challenge(B128(challenges[r].lo, challenges[r].hi));
+		}
+		batch.finish(tr);
+		size_t r = 0, fe = 0;
+		for (const auto &it : tr.items) {
+			if (it.kind == PiopTranscript::Item::RoundProof) {
+				for (size_t i = 0; i < 2; i++) round_proofs_out[2 * r + i] = i < it.scalars.size() ? it.scalars[i].raw() : bn_f128{0, 0};
+				r++;
+			} else if (it.kind == PiopTranscript::Item::MultilinearEvals) {
+				for (const B128 &v : it.scalars) final_evals_out[fe++] = v.raw();
+			}
 		}
 		return 0;
 	} catch (const Error &e) {

@@ -60,7 +60,7 @@ pub struct Mi355xExec<'a> {
 unsafe impl Send for Mi355xExec<'_> {}
 
 /// Largest batch `bn_extrapolate_line_batch` accepts (binius_amd/csrc/internal.hpp kFoldBatchMax).
-const FOLD_BATCH_MAX: usize = 8;
+const FOLD_BATCH_MAX: usize = 32;
 
 impl<'a> Mi355xExec<'a> {
 	pub(crate) fn new(ctx: *mut bn_ctx) -> Self {

@@ -307,6 +307,7 @@ unsafe extern "C" {
 	pub fn bn_prof_begin(ctx: *mut bn_ctx) -> c_int;
 	pub fn bn_prof_end(ctx: *mut bn_ctx, ms_by_class: *mut f64, launches_by_class: *mut u64) -> c_int;
 	pub fn bn_arm_counters(ctx: *mut bn_ctx, counters: *mut u64) -> c_int;
+	pub fn bn_group_counters(ctx: *mut bn_ctx, counters: *mut u64) -> c_int;
 	// cross-rank reduction of the round evaluations inside the kernels' finalize step (one process per GPU)
 	pub fn bn_peer_create(ctx: *mut bn_ctx, world: u32, rank: u32, handle_out: *mut u8) -> c_int;
 	pub fn bn_peer_connect(ctx: *mut bn_ctx, handles: *const u8) -> c_int;

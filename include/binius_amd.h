@@ -336,6 +336,16 @@ int bn_prof_end(bn_ctx *ctx, double *ms_by_class /*[BN_PROF_N]*/, uint64_t *laun
  * sequence. */
 enum { BN_ARM_HITS = 0, BN_ARM_CANCELS = 1, BN_ARM_EXPIRED = 2, BN_ARM_NS_WAIT = 3, BN_ARM_NS_LAUNCH = 4, BN_ARM_NS_PARSE = 5, BN_ARM_HOSTED = 6, BN_ARM_TWO_ROUND = 7, BN_ARM_SHADOW_CREATED = 8, BN_ARM_SHADOW_ROUNDS = 9, BN_ARM_SHADOW_DROPPED = 10, BN_ARM_HT_STARTED = 11, BN_ARM_HT_ROUNDS = 12, BN_ARM_HT_FLUSHED = 13, BN_ARM_HT_MAX = 14, BN_ARM_N = 15 };
 int bn_arm_counters(bn_ctx *ctx, uint64_t *counters /*[BN_ARM_N]*/);
+/* Claim groups (not part of the reference interface: counters of how the backend ran the call shape of piop::prove --
+ * k product claims over m multilinears per BivariateSumcheckProver, several provers front-loaded on one layer,
+ * core/src/piop/prove.rs:271-287, protocols/sumcheck/prove/front_loaded.rs:122-155).  LAUNCHES: launches of the group kernel
+ * (each answers one execute() and computes ahead for the other waiting provers); JOBS_FUSED / JOBS_EVAL: claims evaluated
+ * together with the fold of their two arrays / on arrays folded by a plain launch (shared arrays, round 0); PREFOLDS: those
+ * plain fold launches; SPEC_JOBS: claims of OTHER provers carried by a launch; SPEC_HITS: execute() calls answered from sums
+ * computed ahead, without a launch; EVALS: execute() calls answered on this path; FLUSHED_FOLDS: deferred fold batches that a
+ * foreign call forced out as plain launches. */
+enum { BN_GROUP_LAUNCHES = 0, BN_GROUP_JOBS_FUSED = 1, BN_GROUP_JOBS_EVAL = 2, BN_GROUP_PREFOLDS = 3, BN_GROUP_SPEC_JOBS = 4, BN_GROUP_SPEC_HITS = 5, BN_GROUP_EVALS = 6, BN_GROUP_FLUSHED_FOLDS = 7, BN_GROUP_N = 8 };
+int bn_group_counters(bn_ctx *ctx, uint64_t *counters /*[BN_GROUP_N]*/);
 
 #ifdef __cplusplus
 }

@@ -88,6 +88,38 @@ int bnh_fri_commit_fold(bn_ctx *ctx, uint32_t log_dim, uint32_t log_inv_rate, ui
                         uint32_t n_arities, uint32_t n_test_queries, const void *d_message, void *d_scratch, uint64_t scratch_elems,
                         const bn_f128 *challenges, uint8_t *roots_out, bn_f128 *terminate_out, double *phase_ms_out);
 
+/* The front-loaded batch prover (SumcheckBatchProver = protocols/sumcheck/prove/front_loaded.rs:33-203, BatchProver::run with the
+ * transcript's samples handed in) over p BivariateSumcheckProvers on ONE layer, ascending by number of variables: per round
+ * execute() on every live prover, one challenge, fold() on every live prover; a prover finishes in the round that equals its
+ * number of variables.  prover_desc[3 i ..] = (n_vars, m, n_comps); d_multilins / comp_indices / sums: the provers' lists
+ * concatenated; batch_coeffs[n_provers]; challenges[max n_vars]; d_scratch: sum over provers of m * 2^(n_vars - 1) elements.
+ * round_proofs_out[2 * rounds]: the truncated round polynomials (RoundCoeffs::truncate, common.rs:101-105; missing coefficients
+ * zero); final_evals_out[sum m]: the final evaluations in finishing order. */
+int bnh_batch_sumcheck_prove(bn_ctx *ctx, uint32_t n_provers, const uint32_t *prover_desc, const void *const *d_multilins, const uint32_t *comp_indices,
+                             const bn_f128 *sums, void *d_scratch, uint64_t scratch_elems, const bn_f128 *batch_coeffs, const bn_f128 *challenges,
+                             bn_f128 *round_proofs_out, bn_f128 *final_evals_out);
+
+/* piop::prove (crates/core/src/piop/prove.rs:148-395) through the C++ mirror binius_amd/host/piop.hpp: commit_interleaved of the
+ * merged message (fri.hpp), one BivariateSumcheckProver per number of variables that has a committed multilinear, the
+ * front-loaded batch prover interleaved with the FRI folder (prove_interleaved_fri_sumcheck, :306-395).
+ *   committed_n_vars[n_committed] ascending, d_committed[i]: 2^n_vars elements (the packed committed multilinears, on the device)
+ *   transparent_n_vars[n_transparent] ascending, d_transparent[i] likewise
+ *   claims[3 i ..] = (n_vars, committed index, transparent index), claim_sums[i]          (PIOPSumcheckClaim, piop/verify.rs)
+ *   d_message: 2^(log_dim + log_batch_size) elements = merge_multilins of the committed multilinears (piop/prove.rs:66-104);
+ *              log_dim + log_batch_size must equal CommitMeta::total_vars
+ *   d_scratch: codeword, folded codewords, Merkle trees and folded multilinears
+ *   batch_coeffs: one per prover (sizes with a committed multilinear, ascending); challenges[total_vars]
+ * The transcript comes back in writing order: items_out[2 i] = kind (0 round proof, 1 final evaluations of a finished prover,
+ * 2 FRI round commitment, 3 FRI terminate codeword), items_out[2 i + 1] = its scalars (kinds 0, 1, 3: taken from scalars_out
+ * in order) or 1 (kind 2: one 32-byte digest from digests_out).  phase_ms_out[2]: commit, prove (wall clock), or NULL. */
+int bnh_piop_prove(bn_ctx *ctx, uint32_t n_committed, const uint32_t *committed_n_vars, const void *const *d_committed, uint32_t n_transparent,
+                   const uint32_t *transparent_n_vars, const void *const *d_transparent, uint32_t n_claims, const uint32_t *claims, const bn_f128 *claim_sums,
+                   uint32_t log_dim, uint32_t log_inv_rate, uint32_t log_batch_size, const uint32_t *fold_arities, uint32_t n_arities, uint32_t n_test_queries,
+                   const void *d_message, void *d_scratch, uint64_t scratch_elems, const bn_f128 *batch_coeffs, uint32_t n_batch_coeffs,
+                   const bn_f128 *challenges, uint32_t n_challenges, uint8_t *commitment_out, uint32_t *items_out, uint32_t max_items, uint32_t *n_items_out,
+                   bn_f128 *scalars_out, uint64_t max_scalars, uint64_t *n_scalars_out, uint8_t *digests_out, uint32_t max_digests, uint32_t *n_digests_out,
+                   double *phase_ms_out);
+
 /* shared-memory exchange: rank 0 creates the segment `name` ("/..."), the others open it afterwards */
 int bnh_shm_open(const char *name, int world, int rank, int create, void **handle_out);
 int bnh_shm_close(void *handle);

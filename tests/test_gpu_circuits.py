@@ -200,3 +200,47 @@ def test_multipass_and_interpreter_agree(oracle, monkeypatch):
     exp = oracle.arr(n)
     assert oracle.compute_composite(rows, exp, steps, 3) == 0
     assert np.array_equal(outs[0], exp) and np.array_equal(outs[1], exp)
+
+
+@pytest.mark.parametrize("log_n", [10, 12, 14])
+def test_generic_composition_over_materialised_local_rows_on_a_fresh_context(oracle, log_n):
+    """Local buffers that must be materialised (a generic composition reads them) live in the context's
+    scratch, and so do the temporaries of the compiled passes -- on a FRESH context the second request used to reallocate the
+    block and free the Locals under the ops that had written them.  add(lo, hi -> local) for two inputs, then the generic
+    a * b * a + b over the Locals, against the oracle's CpuLayer restatement; twice (fresh scratch, then reused scratch)."""
+    import binius_amd
+
+    ctx = binius_amd.Context(0, 1 << 18)
+    try:
+        n = 1 << log_n
+        rows = [oracle.random_b128(0xC3C00000 + 7 * log_n + j, 2 * n) for j in range(2)]
+        alloc = ctx.dev_alloc()
+        d = [upload(ctx, alloc, r) for r in rows]
+        steps = [("var", 0), ("var", 1), ("mul", 0, 1), ("mul", 2, 0), ("add", 3, 1)]
+        expr = ctx.compile_expr(steps)
+        coeff, init = oracle.random_scalars(0xC3C1 + log_n, 2)
+
+        def kernel(ke, log_chunks, bufs):
+            acc = ke.decl_value(init)
+            for i in range(2):
+                ke.add(log_n - log_chunks, bufs[3 * i], bufs[3 * i + 1], bufs[3 * i + 2])
+            ke.sum_composition_evals([bufs[2].to_ref(), bufs[5].to_ref()], expr, coeff, acc)
+            return [acc]
+
+        maps = []
+        for x in d:
+            lo, hi = x.split_half()
+            maps += [("chunked", lo, 0), ("chunked", hi, 0), ("local", log_n)]
+        o_maps = []
+        for r in rows:
+            o_maps += [("chunked", r[:n], 0), ("chunked", r[n:], 0), ("local", log_n)]
+        ops, rets, lc = ctx.record(kernel, maps)
+        o_ops = [dict(o, steps=o["expr"].steps) if o["op"] == "sum" else o for o in ops]
+        rc, want = oracle.run_kernels(o_maps, o_ops, rets, lc)
+        assert rc == 0
+        for _ in range(2):
+            (got,) = ctx.accumulate_kernels(kernel, maps)
+            assert [got] == want
+        expr.free()
+    finally:
+        ctx.close()

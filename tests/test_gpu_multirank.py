@@ -68,6 +68,19 @@ def test_bench_transcript_is_independent_of_the_number_of_ranks():
     assert len(digests[0]) == 32 and digests[0] == digests[1] == digests[2], digests
 
 
+def test_bench_bare_gpus_2_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` WITHOUT a launcher (WORLD_SIZE unset) must be a two-rank run -- the
+    process re-executes itself under torch.distributed.run -- and print `n_gpus: 2`, never an N = 1 line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update({"BN_ALL_ON_GPU0": "1", "BN_PG_BACKEND": "gloo", "BN_EXCHANGE": "shm"})
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "1", "--n-vars", "17", "--no-cpu-baseline"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert out.returncode == 0 and lines, out.stdout[-2000:] + out.stderr[-2000:]
+    r = json.loads(lines[-1])
+    assert r["n_gpus"] == 2 and r["verifier_check"] is True and r["config"]["n_vars_local"] == 16
+
+
 @pytest.mark.parametrize("exchange", ["shm", "rccl", "peer"])
 def test_bench_sharded_code_path_world1(exchange):
     r = _run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--n-vars", "15", "--no-cpu-baseline"],
