@@ -463,7 +463,8 @@ int group_eval(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const bn_kop
 		return BN_OK;
 	}
 	// ---- is this a request for the group path at all?  One claim with nothing waiting is the single-claim machinery's.
-	if (rq.k < 2 && g.folds.empty() && !g.on) return BN_OK;
+	// (one claim asked for by more than one pair of sums -- duplicate compositions -- is not: its look-ahead pairs nothing)
+	if (rq.k < 2 && rq.terms.size() <= 2 && g.folds.empty() && !g.on) return BN_OK;
 	int rc = legacy_to_group(ctx);
 	if (rc) return rc;
 	if (!ctx->pend_copies.empty()) {
@@ -579,7 +580,7 @@ int group_eval(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const bn_kop
 	}
 	const uint64_t seq = ++ctx->mail_seq;
 	{
-		prof_scope ps(ctx, BN_PROF_FOLD_EVAL_MFMA);
+		prof_scope ps(ctx, n_fused ? BN_PROF_FOLD_EVAL_MFMA : BN_PROF_ROUND_EVAL_MFMA); // (a launch without a fold: round 0, shared arrays)
 		const hipError_t e = bn::launch_group(ctx->stream, ctx->n_cu, jobs.data(), (uint32_t)jobs.size(), n_slots, ctx->d_result, ctx->d_mail, ctx->d_ticket, seq);
 		if (e != hipSuccess) {
 			// nothing was enqueued by the failed launch; the plain folds above are part of what the caller asked for anyway.  The

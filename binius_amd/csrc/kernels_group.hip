@@ -85,47 +85,33 @@ __device__ __forceinline__ const group_job *job_table()
 
 } // namespace
 
-template <bool FULL, bool NT>
-__global__ __launch_bounds__(kThreads, 1) void k_group_fp4(group_kargs ga)
+// what a workgroup needs to know about its job and its share of the job's tiles (uniform)
+struct group_wg {
+	const char *X0[2], *X1[2];
+	char *OUT[2];
+	f128 z;
+	uint64_t n;
+	uint32_t tbase, tstride, tlimit, t0;
+};
+
+// The loops of one workgroup for a job of kind KIND (0: fold + evaluate, 1: evaluate).  A function template per kind -- and not
+// a run-time `kind` inside one loop -- because the loaded elements must live in registers: with both kinds' uses of x0 / x1 in
+// one body the compiler keeps the two arrays in scratch memory and every tile pays 128 bytes of scratch stores and loads per
+// lane (measured: the launch at half the rate of kernels_foldeval_fp4.hip).  Leaves the parity words of the Gram waves in Gc.
+template <int KIND, bool FULL, bool NT>
+__device__ __forceinline__ void group_loops(const group_wg &w, uint32_t *T_dyn, ctable_smem &tab, gram_parity &Gc, uint32_t prio)
 {
-	extern __shared__ __attribute__((aligned(16))) uint32_t T_dyn[]; // 2 buffers x 2 tiles of FP4 operands
-	__shared__ ctable_smem tab;
-	__shared__ gram_parity Gc;
 	const unsigned lane = threadIdx.x & 63;
 	const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const bool folds = wave >= kGramWaves;
 	const unsigned grp = folds ? (wave - kGramWaves) >> 2 : 0;   // fold group: which tile of the pair
 	const unsigned ftid = (threadIdx.x - 64 * kGramWaves) & 255; // the lane's point inside its tile (fold waves)
+	const uint64_t n = w.n;
+	const uint32_t tbase = w.tbase, tstride = w.tstride, tlimit = w.tlimit, t0 = w.t0;
 
-	// ---- this workgroup's job (uniform): the table is sorted by wg_begin
-	static_assert(offsetof(group_kargs, jobs) == 0, "the job table leads the kernel-argument block");
-	const group_job *const jt = job_table();
-	unsigned ji = 0;
-	for (unsigned i = 1; i < ga.n_jobs; i++)
-		if (blockIdx.x >= jt[i].wg_begin) ji = i;
-	const group_job *const jb = jt + ji;
-	const uint32_t kind = jb->kind;
-	const uint64_t n = jb->n; // evaluation points of the job
-	const uint32_t n_tiles = (uint32_t)(FULL ? n / kTP : (n + kTP - 1) / kTP);
-	const uint32_t G = jb->wg_count, b = blockIdx.x - jb->wg_begin;
-	const char *const X0[2] = {reinterpret_cast<const char *>(jb->x0[0]), reinterpret_cast<const char *>(jb->x0[1])};
-	const char *const X1[2] = {reinterpret_cast<const char *>(jb->x1[0]), reinterpret_cast<const char *>(jb->x1[1])};
-	char *const OUT[2] = {reinterpret_cast<char *>(jb->out[0]), reinterpret_cast<char *>(jb->out[1])};
-
-	// tile order inside the job's range: as kernels_foldeval_mfma.hip (XCD x = blockIdx.x & 7 takes the x-th contiguous eighth of
-	// the job's tiles) when the range starts on a multiple of eight workgroups and is a multiple of eight long
-	uint32_t tbase = 0, tstride = G, tlimit = n_tiles, t0 = b;
-	if ((G & 7) == 0 && (jb->wg_begin & 7) == 0) {
-		const uint32_t chunk = (n_tiles + 7) >> 3;
-		tbase = (b & 7) * chunk;
-		tstride = G >> 3;
-		t0 = b >> 3;
-		tlimit = tbase >= n_tiles ? 0 : (n_tiles - tbase < chunk ? n_tiles - tbase : chunk);
-	}
-
-	// quadrant q = 2 * side + half.  kind 0: x0[q] / x1[q] = the two elements the fold of (side, half) reads; kind 1: x0[q] = the
+	// quadrant q = 2 * side + half.  KIND 0: x0[q] / x1[q] = the two elements the fold of (side, half) reads; KIND 1: x0[q] = the
 	// element of (side, half) itself.
-	uint4 x0[4], x1[4];
+	uint4 x0[4], x1[KIND == 0 ? 4 : 1];
 	const uint32_t voff = ftid * 16u;
 	auto lane_off = [&]() { // (kernels_foldeval_fp4.hip: keeps the lane offset out of a loop-invariant 64-bit vector base)
 		uint32_t v = voff;
@@ -135,14 +121,14 @@ __global__ __launch_bounds__(kThreads, 1) void k_group_fp4(group_kargs ga)
 	uint32_t vo = lane_off();
 	auto in_range = [&](uint32_t t) { return FULL || (uint64_t)(tbase + t) * kTP + ftid < n; };
 	auto load1 = [&](uint32_t t, int q) {
-		const uint64_t e = ((q & 1 ? n : 0) + (uint64_t)(tbase + t) * kTP) * 16; // (uniform)
 		const uint32_t o = in_range(t) ? vo : 0u; // (a lane past the end reads the tile's first element: in range, never used)
-		if (kind == 0) {
-			x0[q] = gq_load<NT>(reinterpret_cast<const uint4 *>(X0[q >> 1] + e + o));
-			x1[q] = gq_load<NT>(reinterpret_cast<const uint4 *>(X1[q >> 1] + e + o));
+		if constexpr (KIND == 0) {
+			const uint64_t e = ((q & 1 ? n : 0) + (uint64_t)(tbase + t) * kTP) * 16; // (uniform)
+			x0[q] = gq_load<NT>(reinterpret_cast<const uint4 *>(w.X0[q >> 1] + e + o));
+			x1[q] = gq_load<NT>(reinterpret_cast<const uint4 *>(w.X1[q >> 1] + e + o));
 		} else {
 			const uint64_t e1 = (uint64_t)(tbase + t) * kTP * 16;
-			x0[q] = gq_load<NT>(reinterpret_cast<const uint4 *>((q & 1 ? X1[q >> 1] : X0[q >> 1]) + e1 + o));
+			x0[q] = gq_load<NT>(reinterpret_cast<const uint4 *>((q & 1 ? w.X1[q >> 1] : w.X0[q >> 1]) + e1 + o));
 		}
 	};
 	const uint32_t tm0 = t0 + grp * tstride; // this fold group's first tile
@@ -151,10 +137,9 @@ __global__ __launch_bounds__(kThreads, 1) void k_group_fp4(group_kargs ga)
 		for (int q = 0; q < 4; q++)
 			load1(tm0, q);
 	}
-	if (kind == 0)
-		ctable_build(tab, jb->z); // (uniform per workgroup; the loads above are in flight meanwhile; ends with a barrier)
+	if constexpr (KIND == 0) ctable_build(tab, w.z); // (the loads above are in flight meanwhile; ends with a barrier)
 	if (folds) {
-		switch (ga.prio & 3) { // the fold waves issue ahead of the Gram wave of their SIMD (kernels_foldeval_fp4.hip)
+		switch (prio & 3) { // the fold waves issue ahead of the Gram wave of their SIMD (kernels_foldeval_fp4.hip)
 		case 1: __builtin_amdgcn_s_setprio(1); break;
 		case 2: __builtin_amdgcn_s_setprio(2); break;
 		case 3: __builtin_amdgcn_s_setprio(3); break;
@@ -171,7 +156,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_group_fp4(group_kargs ga)
 				vo = lane_off();
 				const bool ok = in_range(tm);
 				uint4 f[4];
-				if (kind == 0) {
+				if constexpr (KIND == 0) {
 					const uint64_t pt16 = (uint64_t)(tbase + tm) * kTP * 16; // (uniform)
 #pragma unroll
 					for (int q = 0; q < 4; q++) {
@@ -181,7 +166,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_group_fp4(group_kargs ga)
 					if (FULL || ok) {
 #pragma unroll
 						for (int q = 0; q < 4; q++)
-							gq_store<NT>(reinterpret_cast<uint4 *>(OUT[q >> 1] + (q & 1 ? n * 16 : 0) + pt16 + vo), f[q]);
+							gq_store<NT>(reinterpret_cast<uint4 *>(w.OUT[q >> 1] + (q & 1 ? n * 16 : 0) + pt16 + vo), f[q]);
 					}
 				} else {
 #pragma unroll
@@ -205,6 +190,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_group_fp4(group_kargs ga)
 			buf ^= 1;
 			Tn = T_dyn + (buf * kFoldGroups + grp) * kTile4W;
 		}
+		__builtin_amdgcn_s_setprio(0);
 	} else {
 		const gram4_role gr = make_gram4_role(wave, lane);
 		v16f acc[kAccTiles];
@@ -219,6 +205,51 @@ __global__ __launch_bounds__(kThreads, 1) void k_group_fp4(group_kargs ga)
 		}
 		parity4(acc, gr, wave, lane, Gc);
 	}
+}
+
+template <bool FULL, bool NT>
+__global__ __launch_bounds__(kThreads, 1) void k_group_fp4(group_kargs ga)
+{
+	extern __shared__ __attribute__((aligned(16))) uint32_t T_dyn[]; // 2 buffers x 2 tiles of FP4 operands
+	__shared__ ctable_smem tab;
+	__shared__ gram_parity Gc;
+	const unsigned lane = threadIdx.x & 63;
+	const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+	// ---- this workgroup's job (uniform): the table is sorted by wg_begin
+	static_assert(offsetof(group_kargs, jobs) == 0, "the job table leads the kernel-argument block");
+	const group_job *const jt = job_table();
+	unsigned ji = 0;
+	for (unsigned i = 1; i < ga.n_jobs; i++)
+		if (blockIdx.x >= jt[i].wg_begin) ji = i;
+	const group_job *const jb = jt + ji;
+	group_wg w;
+	w.n = jb->n; // evaluation points of the job
+	w.z = jb->z;
+	for (int sd = 0; sd < 2; sd++) {
+		w.X0[sd] = reinterpret_cast<const char *>(jb->x0[sd]);
+		w.X1[sd] = reinterpret_cast<const char *>(jb->x1[sd]);
+		w.OUT[sd] = reinterpret_cast<char *>(jb->out[sd]);
+	}
+	const uint32_t n_tiles = (uint32_t)(FULL ? w.n / kTP : (w.n + kTP - 1) / kTP);
+	const uint32_t G = jb->wg_count, b = blockIdx.x - jb->wg_begin;
+	// tile order inside the job's range: as kernels_foldeval_mfma.hip (XCD x = blockIdx.x & 7 takes the x-th contiguous eighth of
+	// the job's tiles) when the range starts on a multiple of eight workgroups and is a multiple of eight long
+	w.tbase = 0;
+	w.tstride = G;
+	w.tlimit = n_tiles;
+	w.t0 = b;
+	if ((G & 7) == 0 && (jb->wg_begin & 7) == 0) {
+		const uint32_t chunk = (n_tiles + 7) >> 3;
+		w.tbase = (b & 7) * chunk;
+		w.tstride = G >> 3;
+		w.t0 = b >> 3;
+		w.tlimit = w.tbase >= n_tiles ? 0 : (n_tiles - w.tbase < chunk ? n_tiles - w.tbase : chunk);
+	}
+	if (jb->kind == 0) // (uniform)
+		group_loops<0, FULL, NT>(w, T_dyn, tab, Gc, ga.prio);
+	else
+		group_loops<1, FULL, NT>(w, T_dyn, tab, Gc, ga.prio);
 
 	// ---- tail: parity words -> the job's two sums -> its accumulator slots; the last workgroup of the launch publishes ALL slots
 	__shared__ uint64_t z3[2][3];
