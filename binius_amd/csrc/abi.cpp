@@ -637,6 +637,14 @@ int bn_ctx_create(int device, uint64_t arena_elems, bn_ctx **out)
 			}
 		}
 	}
+	// hosted sessions of the claim groups: same switch and same limit as the single-claim host tail (BN_GROUP_HT_MAX_LOG2 moves it; 0 = off)
+	if (ctx->ht_enabled) {
+		ctx->grp.ht_max = ctx->ht_max;
+		if (const char *l = getenv("BN_GROUP_HT_MAX_LOG2")) {
+			const int v = atoi(l);
+			ctx->grp.ht_max = v <= 0 ? 0 : (uint64_t)1 << (v > 12 ? 12 : v);
+		}
+	}
 	if (const char *t = getenv("BN_TAIL_MAX_LOG2")) {
 		const int l = atoi(t);
 		ctx->tail_max_n_in = (l >= 3 && l <= 12) ? (1ull << l) : 0; // one workgroup: at most 2^12 elements per array
@@ -793,6 +801,7 @@ int bn_ctx_destroy(bn_ctx *ctx)
 	if (ctx->d_phi) hipFree(ctx->d_phi);
 	if (ctx->d_ht_tag) hipFree(ctx->d_ht_tag);
 	if (ctx->h_tail) hipHostFree(ctx->h_tail);
+	if (ctx->grp.h_stage) hipHostFree(ctx->grp.h_stage);
 	if (ctx->shadow.S) hipFree(ctx->shadow.S);
 	if (ctx->ntt_cache) {
 		bn::ntt_bs_cache *nc = (bn::ntt_bs_cache *)ctx->ntt_cache;
@@ -956,7 +965,10 @@ int bn_copy_d2h(bn_ctx *ctx, const void *d_src, uint64_t src_len, bn_f128 *h_dst
 		// those that touch what is read run (the final evaluations of a prover that finishes while the others go on,
 		// front_loaded.rs:100-112): the rest stays deferred for the next round's launch
 		int rc_ = flush_legacy(ctx, false, /*publish_tiny=*/ctx->lazy_fold);
-		if (!rc_) rc_ = group_flush_touching(ctx, d_src, src_len);
+		if (rc_) return rc_;
+		// (a hosted prover's current arrays -- finish()'s reads of the final evaluations -- come from the host's copies)
+		if (src_len == dst_len && src_len && group_host_read(ctx, d_src, src_len, h_dst)) return BN_OK;
+		rc_ = group_flush_touching(ctx, d_src, src_len, /*publish_tiny=*/ctx->lazy_fold, /*write=*/false);
 		if (rc_) return rc_;
 	}
 	BN_REQUIRE(src_len == dst_len, "precondition: src and dst buffers must have the same length");
@@ -1028,7 +1040,7 @@ int bn_copy_d2d(bn_ctx *ctx, const void *d_src, uint64_t src_len, void *d_dst, u
 		BN_HIP(hipMemcpyAsync(d_dst, d_src, src_len * sizeof(f128), hipMemcpyDeviceToDevice, ctx->stream));
 		return BN_OK;
 	}
-	if (!ctx->grp.folds.empty() && (!group_independent(ctx, d_src, src_len) || !group_independent(ctx, d_dst, dst_len))) BN_FLUSH(ctx); // (ordered behind the folds it touches)
+	if (!group_independent(ctx, d_src, src_len, false) || !group_independent(ctx, d_dst, dst_len, true)) BN_FLUSH(ctx); // (ordered behind the deferred folds / hosted provers it touches)
 	group_note_write(ctx, d_dst, dst_len); // (sums computed ahead from what is overwritten are stale)
 	if (ctx->lazy_fold && !ctx->pend.active && ctx->pend_copies.size() < (size_t)bn::kFoldBatchMax) {
 		// deferred: a fold into d_dst may absorb it (see bn_ctx::pending_copy)
@@ -1391,6 +1403,10 @@ int bn_group_counters(bn_ctx *ctx, uint64_t *counters)
 	counters[BN_GROUP_SPEC_HITS] = g.spec_hits;
 	counters[BN_GROUP_EVALS] = g.evals;
 	counters[BN_GROUP_FLUSHED_FOLDS] = g.flushed_folds;
+	counters[BN_GROUP_HOSTED_STARTED] = g.hosted_started;
+	counters[BN_GROUP_HOSTED_EVALS] = g.hosted_evals;
+	counters[BN_GROUP_HOSTED_FOLDS] = g.hosted_folds;
+	counters[BN_GROUP_HOSTED_WRITEBACKS] = g.hosted_writebacks;
 	return BN_OK;
 }
 

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <initializer_list>
 #include <map>
 #include <mutex>
 #include <sstream>
@@ -117,13 +118,15 @@ bool legacy_state_active(const bn_ctx *ctx);
 // a batch of folds can be deferred on the group path
 bool group_fold_applies(const bn_ctx *ctx, uint32_t count, uint32_t scale_mask);
 // [p, p + n) touches none of the arrays a deferred group fold reads or writes
-bool group_independent(const bn_ctx *ctx, const void *p, uint64_t n);
+bool group_independent(const bn_ctx *ctx, const void *p, uint64_t n, bool write = true);
 // defer the batch (src0 | x1 -> x0, n elements each); deferred folds it overlaps run first
 int group_defer_fold(bn_ctx *ctx, void *const *x0, const void *const *src0, const void *const *x1, uint32_t count, uint64_t n, f128 z);
 // run every deferred group fold as a plain launch and forget every prediction
 int group_flush(bn_ctx *ctx);
 // run only the deferred folds that overlap [p, p + n); predictions that describe overlapping arrays are forgotten
-int group_flush_touching(bn_ctx *ctx, const void *p, uint64_t n);
+int group_flush_touching(bn_ctx *ctx, const void *p, uint64_t n, bool publish_tiny = false, bool write = true);
+// a host read of [p, p + n) inside one current array of a hosted prover (abi_group.cpp): answered from the host's copy (true)
+bool group_host_read(bn_ctx *ctx, const void *p, uint64_t n, bn_f128 *h_dst);
 // a write into [p, p + n) that flushed nothing: predictions that describe overlapping arrays are forgotten
 void group_note_write(bn_ctx *ctx, const void *p, uint64_t n);
 // the round evaluation of a prover (k product claims over m arrays) on the group path; *handled = false: not that shape / not
@@ -151,6 +154,28 @@ struct bn_enter_guard {
 		int rc_ = flush_pending(ctx);    \
 		(ctx)->mirror.valid = false;     \
 		if (rc_) return rc_;             \
+	} while (0)
+
+// A call that touches device memory only inside the given ranges (and the context's own scratch): the single-claim state is
+// flushed as by BN_FLUSH; of the claim groups' deferred folds only those that touch one of the ranges run, the others stay deferred
+// for the next round's launch (FRIFolder::execute_fold_round between the folds and the next evaluations of a batch round,
+// core/src/piop/prove.rs:372-384: fri_fold, the Merkle tree, its root).
+struct bn_range {
+	const void *p;
+	uint64_t n; // field elements
+};
+static inline int flush_for_ranges(bn_ctx *ctx, std::initializer_list<bn_range> ranges)
+{
+	int rc = flush_legacy(ctx);
+	ctx->mirror.valid = false;
+	for (const bn_range &r : ranges)
+		if (!rc && r.p && r.n) rc = group_flush_touching(ctx, r.p, r.n);
+	return rc;
+}
+#define BN_FLUSH_FOR(ctx, ...)                                  \
+	do {                                                        \
+		int rc_ = flush_for_ranges(ctx, {__VA_ARGS__});         \
+		if (rc_) return rc_;                                    \
 	} while (0)
 
 static inline bool is_pow2(uint64_t n) { return n && !(n & (n - 1)); }

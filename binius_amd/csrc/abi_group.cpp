@@ -296,6 +296,103 @@ void record(bn_ctx *ctx, bn_ctx::group_session &s, const request &rq)
 	s.stamp = ++ctx->grp.stamp;
 }
 
+// ---- hosted sessions: the last rounds of a prover as host arithmetic ------------------------------------------------------------
+// Once every array of a prover is at most grp.ht_max elements, ONE launch hands them to the host (k_group_mirror: the prover's
+// deferred fold on the way, the basis change to the power basis of hostmul_clmul.cpp) and from then on its execute() and fold()
+// calls are host arithmetic on the host's copies -- no launch, no round trip -- as long as they are the expected ones (the
+// evaluation of exactly the current halves, the fold of exactly the current arrays, in place after the first).  The host folds
+// in place exactly as the device would, so the first h_n0 elements of its copies ARE the caller's buffers after the folds:
+// whoever looks at that memory first (a read, a copy, a foreign kernel: group_flush / group_flush_touching) triggers one
+// write-back launch.  Reads of elements of the current arrays (finish()) are answered from the copies without it.
+// does an access to [p, p + n) conflict with hosted session s?  A write into its current arrays ends the hosting (the host's copy
+// is stale); any access to memory its pending write-back covers needs that write-back first; a READ of the current arrays while
+// nothing is pending (the device still holds what the host holds) conflicts with nothing.
+bool session_touches(const bn_ctx::group_session &s, const void *p, uint64_t n, bool write)
+{
+	if (!s.hosted) return false;
+	for (uint32_t j = 0; j < s.m; j++) {
+		const uint64_t half = s.h_len > 1 ? s.h_len / 2 : 1;
+		if (write && (ranges_overlap(p, n, s.h_lo[j], half) || (s.h_len > 1 && ranges_overlap(p, n, s.h_hi[j], half)))) return true;
+		if (s.h_levels && ranges_overlap(p, n, s.h_out[j], s.h_n0)) return true;
+	}
+	return false;
+}
+
+int stage_alloc(bn_ctx *ctx)
+{
+	auto &g = ctx->grp;
+	if (g.h_stage) return BN_OK;
+	if (hipHostMalloc(&g.h_stage, 2 * bn::kGroupTailMaxElems * sizeof(f128), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+		(void)hipGetLastError();
+		g.h_stage = nullptr;
+		return BN_ERR_ALLOC;
+	}
+	BN_HIP(hipHostGetDevicePointer(&g.d_stage, g.h_stage, 0));
+	return BN_OK;
+}
+
+// the device catches up with the folds the host performed for session s; the session is an ordinary one again
+int unhost(bn_ctx *ctx, bn_ctx::group_session &s)
+{
+	if (!s.hosted) return BN_OK;
+	if (s.h_levels) {
+		// (the staging's write-back half may still be read by the previous write-back's kernel: one launch at a time)
+		BN_HIP(hipStreamSynchronize(ctx->stream));
+		uint64_t *stg = (uint64_t *)ctx->grp.h_stage + 2 * bn::kGroupTailMaxElems;
+		bn::group_writeback_args a{};
+		a.count = s.m;
+		a.n0 = (uint32_t)s.h_n0;
+		for (uint32_t j = 0; j < s.m; j++) {
+			std::memcpy(stg + 2 * (size_t)s.h_n0 * j, s.hy[j].data(), (size_t)s.h_n0 * 16);
+			a.out[j] = s.h_out[j];
+		}
+		a.staging = (const f128 *)((const char *)ctx->grp.d_stage + bn::kGroupTailMaxElems * sizeof(f128));
+		a.phi_inv = (const uint4 *)((const char *)ctx->d_phi + 512 * sizeof(f128));
+		__atomic_thread_fence(__ATOMIC_SEQ_CST);
+		prof_scope ps(ctx, BN_PROF_FOLD);
+		BN_HIP(bn::launch_group_writeback(ctx->stream, a));
+		ctx->grp.hosted_writebacks++;
+	}
+	s.hosted = false;
+	s.h_levels = 0;
+	s.hy.clear();
+	return BN_OK;
+}
+
+int unhost_touching(bn_ctx *ctx, const void *p, uint64_t n, bool write)
+{
+	for (auto &s : ctx->grp.sessions)
+		if (session_touches(s, p, n, write)) {
+			const int rc = unhost(ctx, s);
+			if (rc) return rc;
+		}
+	return BN_OK;
+}
+
+int unhost_all(bn_ctx *ctx)
+{
+	for (auto &s : ctx->grp.sessions) {
+		const int rc = unhost(ctx, s);
+		if (rc) return rc;
+	}
+	return BN_OK;
+}
+
+void host_answer(bn_ctx *ctx, const bn_ctx::group_session &s, const request &rq, const uint32_t *ret_values, uint32_t n_ret, bn_f128 *h_out)
+{
+	f128 raw[64];
+	const size_t half = (size_t)(s.h_len / 2);
+	for (uint32_t c = 0; c < rq.k; c++) {
+		bn::hp128 y1, yi;
+		bn::hostpoly_round_sums(reinterpret_cast<const bn::hp128 *>(s.hy[rq.pa[c]].data()), reinterpret_cast<const bn::hp128 *>(s.hy[rq.pb[c]].data()), half, &y1, &yi);
+		raw[2 * c] = bn::hostpoly_to_tower(y1);
+		raw[2 * c + 1] = bn::hostpoly_to_tower(yi);
+	}
+	answer(rq, raw, ret_values, n_ret, h_out);
+	ctx->grp.hosted_evals++;
+	ctx->grp.evals++;
+}
+
 int wait_mail(bn_ctx *ctx, uint64_t seq)
 {
 	volatile uint64_t *seqw = &ctx->h_mail[64].lo;
@@ -326,11 +423,87 @@ bool group_fold_applies(const bn_ctx *ctx, uint32_t count, uint32_t scale_mask)
 	return g.on || !g.folds.empty() || count != 2;
 }
 
-bool group_independent(const bn_ctx *ctx, const void *p, uint64_t n)
+bool group_independent(const bn_ctx *ctx, const void *p, uint64_t n, bool write)
 {
 	for (const auto &f : ctx->grp.folds)
 		if (fold_touches(f, p, n)) return false;
+	for (const auto &s : ctx->grp.sessions)
+		if (session_touches(s, p, n, write)) return false;
 	return true;
+}
+
+// The fold batch is the fold of a hosted prover's current arrays: performed on the host's copies (true), or not the expected call.
+static bool host_fold(bn_ctx *ctx, void *const *x0, const void *const *src0, const void *const *x1, uint32_t count, uint64_t n, f128 z)
+{
+	for (auto &s : ctx->grp.sessions) {
+		if (!s.hosted || s.m != count || s.h_len != 2 * n) continue;
+		int of[kMaxArrays]; // batch index -> session array
+		bool ok = true;
+		uint32_t used = 0;
+		for (uint32_t i = 0; i < count && ok; i++) {
+			of[i] = -1;
+			for (uint32_t j = 0; j < s.m; j++)
+				if (!((used >> j) & 1) && src0[i] == s.h_lo[j] && x1[i] == s.h_hi[j]) {
+					of[i] = (int)j;
+					used |= 1u << j;
+					break;
+				}
+			ok = of[i] >= 0;
+		}
+		if (!ok) continue;
+		// later folds are in place on the previous output (what the write-back of the host copies assumes); no output may overlap
+		// what the batch reads of ANOTHER array or the upper half of its own
+		for (uint32_t i = 0; i < count && ok; i++) {
+			if (s.h_levels > 0 && x0[i] != src0[i]) ok = false;
+			if (ranges_overlap(x0[i], n, x1[i], n) || (x0[i] != src0[i] && ranges_overlap(x0[i], n, src0[i], n))) ok = false;
+			for (uint32_t q = 0; q < count && ok; q++)
+				if (q != i && (ranges_overlap(x0[i], n, x0[q], n) || ranges_overlap(x0[i], n, src0[q], n) || ranges_overlap(x0[i], n, x1[q], n))) ok = false;
+		}
+		if (!ok) return false; // (the caller's general path writes the copies back and folds on the device)
+		if (s.h_levels == 0) {
+			s.h_n0 = n;
+			for (uint32_t i = 0; i < count; i++) s.h_out[of[i]] = x0[i];
+		}
+		const bn::hp128 pz = bn::hostpoly_from_tower(z);
+		for (uint32_t i = 0; i < count; i++) {
+			const int j = of[i];
+			bn::hostpoly_fold(reinterpret_cast<bn::hp128 *>(s.hy[j].data()), (size_t)n, pz);
+			s.h_lo[j] = x0[i];
+			s.h_hi[j] = at(x0[i], n / 2);
+		}
+		s.h_len = n;
+		s.h_levels++;
+		// (the session's description follows the arrays: what a later evaluation will name)
+		s.row_len = n / 2;
+		for (uint32_t j = 0; j < s.m; j++) {
+			s.lo[j] = s.h_lo[j];
+			s.hi[j] = s.h_hi[j];
+		}
+		ctx->grp.hosted_folds++;
+		ctx->grp.on = true;
+		return true;
+	}
+	return false;
+}
+
+// A host read of [p, p + n) that lies inside ONE current array of a hosted prover: answered from the host's copy (true).
+bool group_host_read(bn_ctx *ctx, const void *p, uint64_t n, bn_f128 *h_dst)
+{
+	for (const auto &s : ctx->grp.sessions) {
+		if (!s.hosted || n == 0) continue;
+		for (uint32_t j = 0; j < s.m; j++) {
+			if (s.h_len > 1 && s.h_hi[j] != (const void *)at(s.h_lo[j], s.h_len / 2)) continue; // (halves not adjacent: no single range)
+			const char *b0 = (const char *)s.h_lo[j], *b1 = b0 + s.h_len * sizeof(f128);
+			if ((const char *)p < b0 || (const char *)p + n * sizeof(f128) > b1) continue;
+			const size_t off = (size_t)((const char *)p - b0) / sizeof(f128);
+			for (uint64_t e = 0; e < n; e++) {
+				const f128 v = bn::hostpoly_to_tower(bn::hp128{s.hy[j][2 * (off + e)], s.hy[j][2 * (off + e) + 1]});
+				h_dst[e] = bn_f128{v.lo, v.hi};
+			}
+			return true;
+		}
+	}
+	return false;
 }
 
 // the single-claim state gives way: a plain deferred fold moves over as it is, everything else of it is flushed
@@ -364,10 +537,11 @@ int group_defer_fold(bn_ctx *ctx, void *const *x0, const void *const *src0, cons
 	int rc = legacy_to_group(ctx);
 	if (rc) return rc;
 	auto &g = ctx->grp;
+	if (host_fold(ctx, x0, src0, x1, count, n, z)) return BN_OK; // (a hosted prover's fold: performed on the host's copies)
 	// a batch whose arrays overlap what a waiting batch reads or writes is ordered behind it: the waiting ones run first
 	bool clash = false;
 	for (uint32_t i = 0; i < count && !clash; i++)
-		clash = !group_independent(ctx, x0[i], n) || !group_independent(ctx, x1[i], n) || !group_independent(ctx, src0[i], n);
+		clash = !group_independent(ctx, x0[i], n, true) || !group_independent(ctx, x1[i], n, false) || !group_independent(ctx, src0[i], n, false);
 	// ... and so is one that overlaps ITSELF across arrays (the jobs of a launch run concurrently)
 	for (uint32_t i = 0; i < count && !clash; i++)
 		for (uint32_t j = 0; j < count && !clash; j++) {
@@ -411,6 +585,10 @@ int group_flush(bn_ctx *ctx)
 	auto &g = ctx->grp;
 	g.on = false;
 	for (auto &s : g.sessions) s.pre_valid = false;
+	{
+		const int rc = unhost_all(ctx);
+		if (rc) return rc;
+	}
 	if (g.folds.empty()) return BN_OK;
 	std::vector<bn_ctx::group_fold> todo;
 	todo.swap(g.folds);
@@ -421,14 +599,34 @@ int group_flush(bn_ctx *ctx)
 	return BN_OK;
 }
 
-int group_flush_touching(bn_ctx *ctx, const void *p, uint64_t n)
+int group_flush_touching(bn_ctx *ctx, const void *p, uint64_t n, bool publish_tiny, bool write)
 {
 	auto &g = ctx->grp;
-	drop_predictions_touching(ctx, p, n);
+	if (write) drop_predictions_touching(ctx, p, n);
+	{
+		const int rc = unhost_touching(ctx, p, n, write);
+		if (rc) return rc;
+	}
 	for (size_t i = 0; i < g.folds.size();) {
 		if (fold_touches(g.folds[i], p, n)) {
 			const bn_ctx::group_fold f = g.folds[i];
 			g.folds.erase(g.folds.begin() + (long)i);
+			if (publish_tiny && (uint64_t)f.count * f.n <= 64 && !ctx->mirror.valid) {
+				// the caller is a host read of a handful of elements (finish(): one copy_d2h per multilinear, each a stream
+				// synchronisation otherwise): fold and mirror the results into the mailbox in one launch; the reads that follow are
+				// served from there (bn_copy_d2h)
+				const uint64_t seq = ++ctx->mail_seq;
+				prof_scope ps(ctx, BN_PROF_FOLD);
+				BN_HIP(bn::launch_fold_publish(ctx->stream, f.x0, f.src0, f.x1, f.count, (uint32_t)f.n, f.z, ctx->d_mail, seq));
+				ctx->grp.flushed_folds++;
+				ctx->mirror.valid = true;
+				ctx->mirror.host = false;
+				ctx->mirror.seq = seq;
+				ctx->mirror.count = f.count;
+				ctx->mirror.n = (uint32_t)f.n;
+				for (uint32_t q = 0; q < f.count; q++) ctx->mirror.ptr[q] = f.x0[q];
+				continue;
+			}
 			const int rc = launch_fold(ctx, f);
 			if (rc) return rc;
 		} else {
@@ -448,6 +646,18 @@ int group_eval(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const bn_kop
 	if (!g.enabled || !ctx->lazy_fold || ctx->peer.active || ctx->tail_max_n_in || !h_out) return BN_OK;
 	request rq;
 	if (!parse(maps, n_maps, ops, n_ops, ret_values, n_ret, rq)) return BN_OK;
+	// ---- a hosted prover's evaluation of exactly its current halves: host arithmetic
+	for (auto &s : g.sessions) {
+		if (!s.hosted || s.m != rq.m || s.k != rq.k || s.h_len != 2 * rq.row_len) continue;
+		bool same = true;
+		for (uint32_t i = 0; i < rq.m && same; i++) same = s.h_lo[i] == rq.lo[i] && s.h_hi[i] == rq.hi[i];
+		for (uint32_t c = 0; c < rq.k && same; c++) same = s.pa[c] == rq.pa[c] && s.pb[c] == rq.pb[c];
+		if (!same) continue;
+		host_answer(ctx, s, rq, ret_values, n_ret, h_out);
+		s.stamp = ++g.stamp;
+		*handled = true;
+		return BN_OK;
+	}
 	// ---- sums computed ahead for exactly this request?
 	for (auto &s : g.sessions) {
 		if (!s.pre_valid || s.m != rq.m || s.k != rq.k || s.pre_row_len != rq.row_len) continue;
@@ -475,12 +685,125 @@ int group_eval(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const bn_kop
 	fold_ref ref[kMaxArrays];
 	for (uint32_t i = 0; i < rq.m; i++) {
 		ref[i] = find_output(ctx, rq.lo[i], rq.hi[i], rq.row_len);
-		if (ref[i].f < 0 && (!group_independent(ctx, rq.lo[i], rq.row_len) || !group_independent(ctx, rq.hi[i], rq.row_len))) {
+		if (ref[i].f < 0 && (!group_independent(ctx, rq.lo[i], rq.row_len, false) || !group_independent(ctx, rq.hi[i], rq.row_len, false))) {
 			// reads what a deferred fold touches, but not as that fold's output: those folds run first
-			rc = group_flush_touching(ctx, rq.lo[i], rq.row_len);
-			if (!rc) rc = group_flush_touching(ctx, rq.hi[i], rq.row_len);
+			rc = group_flush_touching(ctx, rq.lo[i], rq.row_len, false, /*write=*/false);
+			if (!rc) rc = group_flush_touching(ctx, rq.hi[i], rq.row_len, false, /*write=*/false);
 			if (rc) return rc;
 			for (uint32_t q = 0; q <= i; q++) ref[q] = find_output(ctx, rq.lo[q], rq.hi[q], rq.row_len); // (indices moved)
+		}
+	}
+	// a request that reads what a hosted prover's pending write-back covers (but is not that prover's expected call, answered above)
+	for (uint32_t i = 0; i < rq.m; i++) {
+		rc = unhost_touching(ctx, rq.lo[i], rq.row_len, false);
+		if (!rc) rc = unhost_touching(ctx, rq.hi[i], rq.row_len, false);
+		if (rc) return rc;
+	}
+	// ---- small enough to finish on the host?  (all arrays contiguous, their deferred folds -- if any -- with one challenge)
+	if (g.ht_max && 2 * rq.row_len <= g.ht_max && (uint64_t)rq.m * 2 * rq.row_len <= bn::kGroupTailMaxElems && stage_alloc(ctx) == BN_OK) {
+		bool ok = true, any_fold = false;
+		f128 z{0, 0};
+		for (uint32_t i = 0; i < rq.m && ok; i++) {
+			ok = rq.hi[i] == (const void *)at(rq.lo[i], rq.row_len);
+			if (ok && ref[i].f >= 0) {
+				const f128 zi = g.folds[ref[i].f].z;
+				if (any_fold && !(zi == z)) ok = false;
+				z = zi;
+				any_fold = true;
+			}
+		}
+		if (ok) {
+			bn::group_mirror_args ma{};
+			ma.count = rq.m;
+			ma.n = (uint32_t)(2 * rq.row_len);
+			ma.z = z;
+			for (uint32_t i = 0; i < rq.m; i++) {
+				if (ref[i].f >= 0) {
+					const auto &f = g.folds[ref[i].f];
+					ma.src0[i] = f.src0[ref[i].j];
+					ma.x1[i] = f.x1[ref[i].j];
+					ma.out[i] = f.x0[ref[i].j];
+				} else {
+					ma.src0[i] = rq.lo[i];
+				}
+			}
+			ma.staging = (f128 *)g.d_stage;
+			ma.phi_tab = (const uint4 *)ctx->d_phi;
+			ma.tag_acc = ctx->d_ht_tag;
+			ma.counter = ctx->d_ticket;
+			ma.mail = ctx->d_mail;
+			ctx->mirror.valid = false;
+			ma.seq = ++ctx->mail_seq;
+			{
+				prof_scope ps(ctx, BN_PROF_FOLD_EVAL8);
+				BN_HIP(bn::launch_group_mirror(ctx->stream, ma));
+			}
+			bn_ctx::group_session *hs = session_for(ctx, rq, ref); // (before the deferred folds it is matched against are retired)
+			// retire the folds the hand-over performed; arrays of those batches that the request does not name are folded plainly
+			std::vector<std::vector<char>> done(g.folds.size());
+			for (size_t f = 0; f < g.folds.size(); f++) done[f].assign(g.folds[f].count, 0);
+			for (uint32_t i = 0; i < rq.m; i++)
+				if (ref[i].f >= 0) done[ref[i].f][ref[i].j] = 1;
+			for (size_t f = g.folds.size(); f-- > 0;) {
+				bool any = false;
+				for (uint32_t j = 0; j < g.folds[f].count; j++) any = any || done[f][j];
+				if (!any) continue;
+				bn_ctx::group_fold rest;
+				rest.n = g.folds[f].n;
+				rest.z = g.folds[f].z;
+				for (uint32_t j = 0; j < g.folds[f].count; j++)
+					if (!done[f][j]) {
+						rest.x0[rest.count] = g.folds[f].x0[j];
+						rest.x1[rest.count] = g.folds[f].x1[j];
+						rest.src0[rest.count] = g.folds[f].src0[j];
+						rest.count++;
+					}
+				g.folds.erase(g.folds.begin() + (long)f);
+				if (rest.count) {
+					rc = launch_fold(ctx, rest);
+					ctx->grp.flushed_folds--;
+					if (rc) return rc;
+				}
+			}
+			g.on = true;
+			rc = wait_mail(ctx, ma.seq);
+			if (rc) return rc;
+			// the staging validates itself (kernels_group.hip k_group_mirror): accepted only when the tag computed from what is read is
+			// the tag the kernel published
+			record(ctx, *hs, rq);
+			hs->hy.assign(rq.m, std::vector<uint64_t>());
+			const uint64_t total = (uint64_t)rq.m * ma.n;
+			const uint64_t *src = (const uint64_t *)g.h_stage;
+			bool valid = false;
+			for (int tries = 0; tries < 4096 && !valid; tries++) {
+				if (tries == 2048) BN_HIP(hipStreamSynchronize(ctx->stream));
+				const uint64_t want = __atomic_load_n(&ctx->h_mail[66].lo, __ATOMIC_ACQUIRE);
+				uint64_t t = ma.seq;
+				for (uint32_t j = 0; j < rq.m; j++) hs->hy[j].resize(2 * (size_t)ma.n);
+				for (uint64_t idx = 0; idx < total; idx++) {
+					const uint64_t lo = __atomic_load_n(&src[2 * idx], __ATOMIC_RELAXED), hi = __atomic_load_n(&src[2 * idx + 1], __ATOMIC_RELAXED);
+					const uint32_t j = (uint32_t)(idx / ma.n);
+					const uint64_t i = idx - (uint64_t)j * ma.n;
+					hs->hy[j][2 * i] = lo;
+					hs->hy[j][2 * i + 1] = hi;
+					const unsigned r1 = (unsigned)(idx & 63), r2 = (unsigned)((idx * 7 + 17) & 63);
+					t ^= ((lo << r1) | (r1 ? lo >> (64 - r1) : 0)) ^ ((hi << r2) | (r2 ? hi >> (64 - r2) : 0)) ^ (idx + 1) * 0x9E3779B97F4A7C15ull;
+				}
+				valid = t == want;
+			}
+			if (!valid) return bn::fail(BN_ERR_DEVICE, "device error: a hosted prover's staging never became consistent");
+			hs->hosted = true;
+			hs->h_len = ma.n;
+			hs->h_levels = 0;
+			hs->h_n0 = 0;
+			for (uint32_t i = 0; i < rq.m; i++) {
+				hs->h_lo[i] = rq.lo[i];
+				hs->h_hi[i] = rq.hi[i];
+			}
+			g.hosted_started++;
+			host_answer(ctx, *hs, rq, ret_values, n_ret, h_out);
+			*handled = true;
+			return BN_OK;
 		}
 	}
 	bn_ctx::group_session *self = session_for(ctx, rq, ref);
@@ -506,7 +829,7 @@ int group_eval(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const bn_kop
 	uint32_t n_slots = 2 * rq.k;
 	if (g.speculate) {
 		for (auto &s : g.sessions) {
-			if (&s == self || s.k == 0 || s.row_len < 2) continue;
+			if (&s == self || s.hosted || s.k == 0 || s.row_len < 2) continue;
 			if (jobs.size() + s.k > (size_t)bn::kGroupMaxJobs || n_slots + 2 * s.k > 64) continue;
 			rider r{};
 			r.s = &s;
@@ -578,6 +901,7 @@ int group_eval(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const bn_kop
 		BN_HIP(hipMemsetAsync(ctx->d_result, 0, 64 * sizeof(f128), ctx->stream));
 		ctx->s_clean = true;
 	}
+	ctx->mirror.valid = false; // (the launch publishes into the mailbox slots a mirrored tiny fold lives in)
 	const uint64_t seq = ++ctx->mail_seq;
 	{
 		prof_scope ps(ctx, n_fused ? BN_PROF_FOLD_EVAL_MFMA : BN_PROF_ROUND_EVAL_MFMA); // (a launch without a fold: round 0, shared arrays)

@@ -127,7 +127,7 @@ int bn_fri_fold(bn_ctx *ctx, const uint64_t *h_s_evals, uint32_t tw_level, uint3
 {
 	BN_REQUIRE(ctx && h_s_evals, "null argument");
 	BN_ENTER(ctx);
-	BN_FLUSH(ctx);
+	BN_FLUSH_FOR(ctx, bn_range{d_in, in_len}, bn_range{d_out, out_len}); // (deferred folds of a batch's provers that touch neither stay deferred)
 	BN_REQUIRE(log_len + log_batch_size < 64 && in_len == ((uint64_t)1 << (log_len + log_batch_size)), "invalid data_in length");
 	BN_REQUIRE(n_challenges >= log_batch_size, "invalid challenges length");
 	BN_REQUIRE(n_challenges <= log_batch_size + log_len, "challenges length too big");
@@ -268,8 +268,8 @@ int bn_merkle_build(bn_ctx *ctx, const void *d_elems, uint64_t n_elems, uint64_t
 {
 	BN_REQUIRE(ctx && d_elems && d_nodes, "null argument");
 	BN_ENTER(ctx);
-	BN_FLUSH(ctx);
 	BN_REQUIRE(batch_size != 0 && n_elems % batch_size == 0, "IncorrectBatchSize");
+	BN_FLUSH_FOR(ctx, bn_range{d_elems, n_elems}, bn_range{d_nodes, 2 * (2 * (n_elems / batch_size) - 1)});
 	const uint64_t n_leaves = n_elems / batch_size;
 	BN_REQUIRE(n_leaves != 0 && (n_leaves & (n_leaves - 1)) == 0, "PowerOfTwoLengthRequired");
 	BN_HIP(bn::launch_groestl_leaves(ctx->stream, ctx->n_cu, d_elems, batch_size, n_leaves, d_nodes));
@@ -283,7 +283,12 @@ int bn_gather_d2h(bn_ctx *ctx, const void *d_src, const uint64_t *h_offsets, uin
 {
 	BN_REQUIRE(ctx && d_src && (n_items == 0 || (h_offsets && h_out)), "null argument");
 	BN_ENTER(ctx);
-	BN_FLUSH(ctx);
+	{
+		uint64_t hi = 0; // (the items lie inside [d_src, d_src + max offset + item_elems))
+		for (uint64_t i = 0; i < n_items; i++)
+			if (h_offsets[i] > hi) hi = h_offsets[i];
+		BN_FLUSH_FOR(ctx, bn_range{d_src, hi + item_elems});
+	}
 	if (n_items == 0 || item_elems == 0) return BN_OK;
 	BN_REQUIRE(n_items <= (1ull << 24) && item_elems <= (1ull << 24) && n_items * item_elems <= (1ull << 26), "gather: too many elements for one call");
 	const size_t off_bytes = ((size_t)n_items * 8 + 15) & ~(size_t)15;

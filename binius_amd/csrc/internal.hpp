@@ -241,6 +241,17 @@ struct bn_ctx {
 		const void *pre_lo[32] = {}, *pre_hi[32] = {};
 		bn::f128 pre_raw[64] = {};                  // claim c: [2 c] at 1, [2 c + 1] at infinity
 		uint64_t stamp = 0;
+		// hosted: the prover's arrays are small enough that its remaining rounds are host arithmetic (abi_group.cpp "hosted
+		// sessions"): hy[j] = array j in the power basis of hostmul_clmul.cpp (2 words per element), folded in place exactly as
+		// the device would; the device catches up with ONE launch (write-back of the first h_n0 elements per array to h_out[j],
+		// where the first host fold wrote) when anybody looks at the memory
+		bool hosted = false;
+		uint64_t h_len = 0;                         // elements per array now
+		const void *h_lo[32] = {}, *h_hi[32] = {};  // device addresses of the current arrays' halves: what the next calls must name
+		uint32_t h_levels = 0;                      // folds performed on the host and not yet on the device
+		uint64_t h_n0 = 0;
+		void *h_out[32] = {};
+		std::vector<std::vector<uint64_t>> hy;
 	};
 	struct group_state {
 		bool enabled = true;   // BN_GROUP=0: every call takes the single-claim machinery / the eager kernels
@@ -250,6 +261,9 @@ struct bn_ctx {
 		std::vector<group_session> sessions;
 		uint64_t stamp = 0;
 		uint64_t launches = 0, jobs_fused = 0, jobs_eval = 0, prefolds = 0, spec_jobs = 0, spec_hits = 0, evals = 0, flushed_folds = 0;
+		uint64_t ht_max = 0;   // largest array (elements) a hosted session starts with (0: off; BN_GROUP_HT_MAX_LOG2)
+		void *h_stage = nullptr, *d_stage = nullptr; // pinned staging, 2 x kGroupTailMaxElems elements: hand-over | write-back
+		uint64_t hosted_started = 0, hosted_evals = 0, hosted_folds = 0, hosted_writebacks = 0;
 	} grp;
 	// cross-rank reduction inside the finalize step (bn_peer_*, finalize.hpp peer_exchange)
 	struct peer_state {
@@ -440,6 +454,30 @@ struct group_job {
 	uint32_t slot;             // the job's sums are XORed into S[slot] (at 1) and S[slot + 1] (at infinity)
 	uint32_t wg_begin, wg_count; // (filled in by the launcher)
 };
+// hosted provers (abi_group.cpp): hand-over of a prover's arrays to the host (with its deferred fold performed on the way) and the
+// write-back of the host's folded copies
+constexpr uint64_t kGroupTailMaxElems = 32 * 4096; // elements of one hand-over / write-back: the pinned staging holds that many
+struct group_mirror_args {
+	const void *src0[kGroupMaxJobs]; // x1[j] != null: the fold's inputs (n elements each), its output goes to out[j]; x1[j] == null: the array itself
+	const void *x1[kGroupMaxJobs];
+	void *out[kGroupMaxJobs];
+	f128 z;
+	uint32_t count, n;   // arrays, elements per array handed over
+	f128 *staging;       // pinned host memory (device view): staging[j * n + i] = Phi(y_j[i])
+	const uint4 *phi_tab; // nibble table of Phi (device memory, ctable.hpp layout)
+	uint64_t *tag_acc;   // zeroed 64-bit word of device memory
+	unsigned *counter;   // zeroed ticket
+	f128 *mail;          // pinned mailbox: word 66 = tag, word 64 = seq
+	uint64_t seq;
+};
+hipError_t launch_group_mirror(hipStream_t s, const group_mirror_args &a);
+struct group_writeback_args {
+	void *out[kGroupMaxJobs];
+	uint32_t count, n0;
+	const f128 *staging;  // pinned host memory (device view): the host's copies, power basis
+	const uint4 *phi_inv; // nibble table of the inverse basis change
+};
+hipError_t launch_group_writeback(hipStream_t s, const group_writeback_args &a);
 hipError_t launch_group(hipStream_t s, int n_cu, const group_job *jobs, uint32_t n_jobs, uint32_t n_slots, f128 *d_S, f128 *d_mail, unsigned *d_counter,
                         uint64_t seq);
 

@@ -83,6 +83,18 @@ __device__ __forceinline__ const group_job *job_table()
 #endif
 }
 
+// element `idx` of a small by-value pointer array (a run-time index into a kernel argument: read through a volatile-free loop of
+// selects, so that the array is not copied to scratch)
+template <class P>
+__device__ __forceinline__ const void *job_ptr(P const (&arr)[kGroupMaxJobs], uint32_t idx)
+{
+	const void *r = nullptr;
+#pragma unroll
+	for (uint32_t q = 0; q < (uint32_t)kGroupMaxJobs; q++)
+		if (q == idx) r = (const void *)arr[q];
+	return r;
+}
+
 } // namespace
 
 // what a workgroup needs to know about its job and its share of the job's tiles (uniform)
@@ -422,6 +434,107 @@ hipError_t launch_group(hipStream_t s, int n_cu, const group_job *jobs_in, uint3
 		hipLaunchKernelGGL((k_group_fp4<true, false>), dim3(at), dim3(kThreads), lds, s, ga);
 	else
 		hipLaunchKernelGGL((k_group_fp4<false, false>), dim3(at), dim3(kThreads), lds, s, ga);
+	return hipGetLastError();
+}
+
+// ---- host tail of a claim group (abi_group.cpp "hosted sessions") ------------------------------------------------------------
+// Hand-over: every array of a prover (count arrays of n elements: at most kGroupTailMaxElems elements in all) goes to the host in the
+// power basis of hostmul_clmul.cpp -- after the prover's deferred fold, performed here on the way (fold[j]: y = src0 + z (src0 +
+// x1), stored to out[j] as the fold asked) or as it is (x1[j] == null: y = src0[j][i], nothing stored).  Phi is GF(2)-linear:
+// one nibble-table product per element (table in device memory, ctable.hpp layout).  The staging is written with plain posted
+// stores and validates itself: the last workgroup publishes the XOR over all elements of mirror_mix(value, index) XOR seq in
+// mailbox word 66, then the sequence word; the host accepts the staging only when the tag it computes from what it reads is
+// that tag (the protocol of kernels_foldeval8.hip's hand-over).
+namespace {
+__device__ __forceinline__ uint64_t gt_mix(uint64_t lo, uint64_t hi, uint64_t idx)
+{
+	const unsigned r1 = (unsigned)(idx & 63), r2 = (unsigned)((idx * 7 + 17) & 63);
+	return ((lo << r1) | (r1 ? lo >> (64 - r1) : 0)) ^ ((hi << r2) | (r2 ? hi >> (64 - r2) : 0)) ^ (idx + 1) * 0x9E3779B97F4A7C15ull;
+}
+} // namespace
+
+__global__ __launch_bounds__(256) void k_group_mirror(group_mirror_args a)
+{
+	__shared__ ctable_smem tab;
+	__shared__ uint4 phi_T[512];
+	__shared__ uint64_t wtag[4];
+	__shared__ unsigned is_last;
+	const unsigned tid = threadIdx.x;
+	const uint64_t g = (uint64_t)blockIdx.x * 256 + tid, total = (uint64_t)a.count * a.n;
+	const bool act = g < total;
+	const uint32_t arr = act ? (uint32_t)(g / a.n) : 0, i = act ? (uint32_t)(g - (uint64_t)arr * a.n) : 0;
+	const uint4 *src0 = reinterpret_cast<const uint4 *>(job_ptr(a.src0, arr)), *x1 = reinterpret_cast<const uint4 *>(job_ptr(a.x1, arr));
+	uint4 v0{0, 0, 0, 0}, v1{0, 0, 0, 0};
+	if (act) {
+		v0 = src0[i];
+		if (x1) v1 = x1[i];
+	}
+	phi_T[tid] = a.phi_tab[tid];
+	phi_T[tid + 256] = a.phi_tab[tid + 256];
+	ctable_build(tab, a.z); // (ends with a barrier: phi_T is complete too)
+	uint64_t tag = 0;
+	if (act) {
+		uint4 y = v0;
+		if (x1) {
+			y = xor4(v0, ctable_mul(tab, xor4(v0, v1)));
+			reinterpret_cast<uint4 *>(const_cast<void *>(job_ptr(a.out, arr)))[i] = y;
+		}
+		const uint4 py = ctable_mul(*reinterpret_cast<const ctable_smem *>(phi_T), y);
+		reinterpret_cast<uint4 *>(a.staging)[g] = py;
+		tag = gt_mix((uint64_t)py.x | ((uint64_t)py.y << 32), (uint64_t)py.z | ((uint64_t)py.w << 32), g);
+	}
+#pragma unroll
+	for (int sh = 32; sh >= 1; sh >>= 1) tag ^= __shfl_xor(tag, sh, 64);
+	if ((tid & 63) == 0) wtag[tid >> 6] = tag;
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	__syncthreads();
+	if (tid == 0) {
+		const uint64_t t = wtag[0] ^ wtag[1] ^ wtag[2] ^ wtag[3];
+		if (t) atomicXor(reinterpret_cast<unsigned long long *>(a.tag_acc), (unsigned long long)t);
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		const unsigned tk = atomicAdd(a.counter, 1u);
+		is_last = tk == gridDim.x - 1 ? 1u : 0u;
+		if (is_last) {
+			const uint64_t all = __hip_atomic_load(a.tag_acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			__hip_atomic_store(a.tag_acc, (uint64_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			__hip_atomic_store(a.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			__hip_atomic_store(&a.mail[66].lo, all ^ a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			__hip_atomic_store(&a.mail[64].lo, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		}
+	}
+}
+
+hipError_t launch_group_mirror(hipStream_t s, const group_mirror_args &a)
+{
+	if (a.count == 0 || a.count > (uint32_t)kGroupMaxJobs || a.n == 0 || (uint64_t)a.count * a.n > kGroupTailMaxElems || !a.staging || !a.phi_tab || !a.tag_acc || !a.counter || !a.mail)
+		return hipErrorNotSupported;
+	hipLaunchKernelGGL(k_group_mirror, dim3((unsigned)(((uint64_t)a.count * a.n + 255) / 256)), dim3(256), 0, s, a);
+	return hipGetLastError();
+}
+
+// The device catching up with a hosted prover: out[j][i] = PhiInv(staging[j * n0 + i]), i < n0 -- the first n0 elements of the
+// host's folded copies, which are exactly what the folds the caller asked for leave in its buffers (kernels_stream.hip
+// k_tail_writeback for any number of arrays).
+__global__ __launch_bounds__(256) void k_group_writeback(group_writeback_args a)
+{
+	__shared__ uint4 T[512];
+	const unsigned tid = threadIdx.x;
+	const uint64_t g = (uint64_t)blockIdx.x * 256 + tid, total = (uint64_t)a.count * a.n0;
+	const bool act = g < total;
+	const uint32_t arr = act ? (uint32_t)(g / a.n0) : 0, i = act ? (uint32_t)(g - (uint64_t)arr * a.n0) : 0;
+	uint4 v{0, 0, 0, 0};
+	if (act) v = reinterpret_cast<const uint4 *>(a.staging)[g];
+	T[tid] = a.phi_inv[tid];
+	T[tid + 256] = a.phi_inv[tid + 256];
+	__syncthreads();
+	if (act) reinterpret_cast<uint4 *>(const_cast<void *>(job_ptr(a.out, arr)))[i] = ctable_mul(*reinterpret_cast<const ctable_smem *>(T), v);
+}
+
+hipError_t launch_group_writeback(hipStream_t s, const group_writeback_args &a)
+{
+	if (a.count == 0 || a.count > (uint32_t)kGroupMaxJobs || a.n0 == 0 || (uint64_t)a.count * a.n0 > kGroupTailMaxElems || !a.staging || !a.phi_inv) return hipErrorNotSupported;
+	hipLaunchKernelGGL(k_group_writeback, dim3((unsigned)(((uint64_t)a.count * a.n0 + 255) / 256)), dim3(256), 0, s, a);
 	return hipGetLastError();
 }
 

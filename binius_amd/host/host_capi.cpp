@@ -701,10 +701,17 @@ int bnh_piop_prove(bn_ctx *ctx, uint32_t n_committed, const uint32_t *committed_
 		hal.sync();
 		const auto t1 = std::chrono::steady_clock::now();
 		std::memcpy(commitment_out, co.commitment.data(), 32);
+		if (AbiProf::on()) AbiProf::get() = AbiProf{};
 		PiopProveOutput out = piop_prove(hal, dev_alloc, host_alloc, p, ntt, merkle, commit_meta, co.committed, ComputeMemory::as_const(co.codeword), committed,
 		                                 transparents, cl, bcs, chs);
 		hal.sync();
 		const auto t2 = std::chrono::steady_clock::now();
+		if (AbiProf::on()) {
+			const AbiProf &pr = AbiProf::get();
+			fprintf(stderr, "[bnh prof] piop prove %.1f us: send_round_proof %.1f, receive_challenge %.1f, fri round %.1f | inside the ABI: kernel_launch %.1f (%llu calls), extrapolate_line %.1f (%llu), copies %.1f (%llu)\n",
+			        std::chrono::duration<double, std::micro>(t2 - t1).count(), out.phase_ns[0] / 1e3, out.phase_ns[1] / 1e3, out.phase_ns[2] / 1e3, pr.ns[0] / 1e3,
+			        (unsigned long long)pr.calls[0], pr.ns[1] / 1e3, (unsigned long long)pr.calls[1], pr.ns[2] / 1e3, (unsigned long long)pr.calls[2]);
+		}
 		uint32_t ni = 0, nd = 0;
 		uint64_t ns = 0;
 		for (const auto &it : out.transcript.items) {

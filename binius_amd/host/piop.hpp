@@ -15,6 +15,7 @@
 // convention as the other mirrors (compute_test_utils' tests sample from a transcript; ours take a seeded stream).
 // F = P = BinaryField128b (the device field; packed committed multilinears are already its elements).
 #pragma once
+#include <chrono>
 #include <deque>
 #include <memory>
 
@@ -209,6 +210,7 @@ struct PiopProveOutput {
 	std::vector<std::vector<B128>> multilinear_evals; // per prover, in finishing order
 	std::vector<B128> terminate_codeword;
 	size_t n_provers = 0;
+	uint64_t phase_ns[3] = {0, 0, 0}; // BNH_PROF=1: send_round_proof, receive_challenge, execute_fold_round over all rounds
 };
 
 // prove_interleaved_fri_sumcheck (piop/prove.rs:306-395); `challenges[round]` is what transcript.sample() would have returned
@@ -223,12 +225,25 @@ inline PiopProveOutput prove_interleaved_fri_sumcheck(ComputeLayer &hal, DeviceB
 	out.n_provers = sumcheck_provers.size();
 	FRIFolder fri_prover(hal, fri_params, ntt, merkle_prover, codeword, committed);
 	SumcheckBatchProver sumcheck_batch_prover(std::move(sumcheck_provers), batch_coeffs);
+	const bool prof = AbiProf::on(); // BNH_PROF=1: wall time of the three steps of a round, summed (diagnostic)
+	auto now = [] { return std::chrono::steady_clock::now(); };
+	auto ns = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+		return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count();
+	};
 	for (size_t round = 0; round < n_rounds; round++) {
+		const auto t0 = prof ? now() : std::chrono::steady_clock::time_point{};
 		sumcheck_batch_prover.send_round_proof(out.transcript);
+		const auto t1 = prof ? now() : t0;
 		const B128 challenge = challenges[round];
 		sumcheck_batch_prover.receive_challenge(challenge);
+		const auto t2 = prof ? now() : t0;
 		auto [has_commitment, round_commitment] = fri_prover.execute_fold_round(dev_alloc, challenge);
 		if (has_commitment) out.transcript.write_digest(round_commitment);
+		if (prof) {
+			out.phase_ns[0] += ns(t0, t1);
+			out.phase_ns[1] += ns(t1, t2);
+			out.phase_ns[2] += ns(t2, now());
+		}
 	}
 	out.multilinear_evals = sumcheck_batch_prover.finish(out.transcript);
 	// fri_prover.finish_proof (fri/prove.rs:484-520): the terminate codeword goes to the transcript; the query phase (index sampling,

@@ -20,14 +20,14 @@ def _threads():
     return max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
 
 
-@pytest.mark.parametrize("seed", list(range(16)))
+@pytest.mark.parametrize("seed", list(range(28)))
 def test_group_call_sequences_three_way(monkeypatch, oracle, seed):
     import binius_amd
     from binius_amd.sumcheck import bivariate_product_expr, calculate_round_evals
 
     rng = np.random.RandomState(0x6F0 + 7919 * seed)
     n_provers = int(rng.choice([1, 2, 2]))
-    log_top = int(rng.randint(16, 22))
+    log_top = int(rng.randint(16, 22)) if seed < 16 else int(rng.randint(6, 15))  # (the small ones: hosted sessions from early on)
     specs = []
     for p in range(n_provers):
         log_n = log_top - (int(rng.randint(0, 4)) if p + 1 < n_provers else 0)
@@ -135,8 +135,9 @@ def test_group_call_sequences_three_way(monkeypatch, oracle, seed):
             p = int(rng.choice(live))
             j = int(rng.randint(specs[p][1]))
             if kind == "read":
-                outs = [c["hal"].copy_d2h(cur_dev(c, p, j).slice(0, 4)).tolist() for c in ctxs]
-                same(outs, cur_model(p, j)[:4].tolist(), "read")
+                w = min(4, 1 << n_rem[p])
+                outs = [c["hal"].copy_d2h(cur_dev(c, p, j).slice(0, w)).tolist() for c in ctxs]
+                same(outs, cur_model(p, j)[:w].tolist(), "read")
             elif kind == "read_spare":
                 outs = [c["hal"].copy_d2h(c["spare"][0].slice(0, 8)).tolist() for c in ctxs]
                 same(outs, spare_model[0][:8].tolist(), "read_spare")
@@ -213,7 +214,7 @@ def test_group_call_sequences_three_way(monkeypatch, oracle, seed):
             a, b = (c["hal"].copy_d2h(c["spare"][q]) for c in ctxs)
             assert np.array_equal(a, b) and np.array_equal(b, spare_model[q]), ("spare", q)
         cnt = lazy.group_counters()
-        if n_provers > 1 or any(len(c) > 1 or m > 2 for _, m, c in specs):
+        if n_provers > 1 or any(len(set(c)) > 1 or m > 2 for _, m, c in specs):
             assert cnt["evals"] > 0, cnt
     finally:
         eager.close()
