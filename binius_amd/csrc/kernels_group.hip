@@ -132,22 +132,33 @@ __device__ __forceinline__ void group_loops(const group_wg &w, uint32_t *T_dyn, 
 	};
 	uint32_t vo = lane_off();
 	auto in_range = [&](uint32_t t) { return FULL || (uint64_t)(tbase + t) * kTP + ftid < n; };
-	auto load1 = [&](uint32_t t, int q) {
+	// KIND 1 keeps TWO tiles of loads in flight per fold group (x0: the tile after this one, xb: the one after that): with nothing to
+	// compute between a tile's loads and its staging, one tile in flight is 32 KiB per CU and the launch sits at the memory
+	// latency (2.1 TB/s measured at 2^25 points per claim); KIND 0 has 64 KiB of loads per CU in flight with one tile per group
+	uint4 xb[KIND == 1 ? 4 : 1];
+	auto load_into = [&](uint4 *dst0, uint32_t t, int q) {
 		const uint32_t o = in_range(t) ? vo : 0u; // (a lane past the end reads the tile's first element: in range, never used)
 		if constexpr (KIND == 0) {
 			const uint64_t e = ((q & 1 ? n : 0) + (uint64_t)(tbase + t) * kTP) * 16; // (uniform)
-			x0[q] = gq_load<NT>(reinterpret_cast<const uint4 *>(w.X0[q >> 1] + e + o));
+			dst0[q] = gq_load<NT>(reinterpret_cast<const uint4 *>(w.X0[q >> 1] + e + o));
 			x1[q] = gq_load<NT>(reinterpret_cast<const uint4 *>(w.X1[q >> 1] + e + o));
 		} else {
 			const uint64_t e1 = (uint64_t)(tbase + t) * kTP * 16;
-			x0[q] = gq_load<NT>(reinterpret_cast<const uint4 *>((q & 1 ? w.X1[q >> 1] : w.X0[q >> 1]) + e1 + o));
+			dst0[q] = gq_load<NT>(reinterpret_cast<const uint4 *>((q & 1 ? w.X1[q >> 1] : w.X0[q >> 1]) + e1 + o));
 		}
 	};
+	auto load1 = [&](uint32_t t, int q) { load_into(x0, t, q); };
 	const uint32_t tm0 = t0 + grp * tstride; // this fold group's first tile
 	if (folds && tm0 < tlimit) {
 #pragma unroll
 		for (int q = 0; q < 4; q++)
 			load1(tm0, q);
+		if constexpr (KIND == 1) {
+			const uint32_t tm1 = tm0 + 2 * tstride < tlimit ? tm0 + 2 * tstride : tm0;
+#pragma unroll
+			for (int q = 0; q < 4; q++)
+				load_into(xb, tm1, q);
+		}
 	}
 	if constexpr (KIND == 0) ctable_build(tab, w.z); // (the loads above are in flight meanwhile; ends with a barrier)
 	if (folds) {
@@ -160,11 +171,14 @@ __device__ __forceinline__ void group_loops(const group_wg &w, uint32_t *T_dyn, 
 		const stage4_role sr = make_stage4_role(ftid);
 		uint32_t *Tn = T_dyn + grp * kTile4W;
 		unsigned buf = 0;
-		for (uint32_t t = t0; t < tlimit; t += 2 * tstride) {
+		// one pair of tiles: `cur` holds this group's tile, loaded one (KIND 0) or two (KIND 1) iterations ago, and is refilled for
+		// the iteration that will use it next
+		auto pair_step = [&](uint32_t t, uint4 *cur) {
 			const uint32_t tm = t + grp * tstride;
 			if (tm < tlimit) { // (uniform; false only for group 1 on an odd last pair)
-				// the last iteration re-requests its own tile (cache hits) instead of branching around the loads
-				const uint32_t tn = tm + 2 * tstride < tlimit ? tm + 2 * tstride : tm;
+				// the last iteration(s) re-request their own tile (cache hits) instead of branching around the loads
+				constexpr uint32_t kAhead = KIND == 1 ? 4 : 2;
+				const uint32_t tn = tm + kAhead * tstride < tlimit ? tm + kAhead * tstride : tm;
 				vo = lane_off();
 				const bool ok = in_range(tm);
 				uint4 f[4];
@@ -183,8 +197,8 @@ __device__ __forceinline__ void group_loops(const group_wg &w, uint32_t *T_dyn, 
 				} else {
 #pragma unroll
 					for (int q = 0; q < 4; q++) {
-						f[q] = x0[q];
-						load1(tn, q);
+						f[q] = cur[q];
+						load_into(cur, tn, q);
 					}
 				}
 				if (!FULL && !ok) {
@@ -201,6 +215,17 @@ __device__ __forceinline__ void group_loops(const group_wg &w, uint32_t *T_dyn, 
 			__syncthreads(); // the pair is staged; the Gram waves are done with the buffer this wave writes next
 			buf ^= 1;
 			Tn = T_dyn + (buf * kFoldGroups + grp) * kTile4W;
+		};
+		if constexpr (KIND == 0) {
+			for (uint32_t t = t0; t < tlimit; t += 2 * tstride) pair_step(t, x0);
+		} else {
+			for (uint32_t t = t0; t < tlimit;) {
+				pair_step(t, x0);
+				t += 2 * tstride;
+				if (t >= tlimit) break;
+				pair_step(t, xb);
+				t += 2 * tstride;
+			}
 		}
 		__builtin_amdgcn_s_setprio(0);
 	} else {
