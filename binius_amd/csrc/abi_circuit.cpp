@@ -444,4 +444,120 @@ int circuit_multipass_sum(bn_ctx *ctx, const bn_expr *e, const void *const *rows
 	return BN_OK;
 }
 
+// ---- the same plan for SEVERAL evaluation points at once, its final sums collected instead of launched ------------------------
+// rows[v] is a super-row: n_b segments of `seg` elements, segment b = variable v at the b-th evaluation point (abi_hal.cpp lays the
+// rows of a request out that way).  The element-wise passes of the plan run ONCE over the super-rows (n_b * seg elements per
+// launch); every final sum -- a product of two rows, a lone row, a row times the indicator -- becomes one inner-product request per
+// point (segment b of each factor; the indicator is the same at every point), with the summand's constant coefficient left for
+// the host.  circuit_ip_run then computes ALL requests of a call -- every evaluator, every point -- in one launch of the group
+// kernel (kernels_group.hip, kind 2: two inner products per job).  An `a·b·c + a` at three points is rows + two product passes
+// + one launch instead of thirteen launches.
+int circuit_multipass_collect(bn_ctx *ctx, const bn_expr *e, const void *const *rows, uint64_t seg, uint32_t n_b, const void *eq, size_t scratch_off,
+                              const uint32_t *out_index, ip_collector &col)
+{
+	const uint64_t n = (uint64_t)n_b * seg;
+	planner p{ctx, e, rows, n};
+	std::vector<sum_job> jobs;
+	bool need_ones = false;
+	uint32_t n_t = 0;
+	if (!sum_plan(p, eq != nullptr, jobs, need_ones, n_t)) return kCircuitDeclined;
+	if (scratch_off + (size_t)n_t * n * sizeof(f128) > ctx->scratch_bytes) return kCircuitDeclined; // (the caller sized the scratch: never grown here)
+	p.scr = (char *)ctx->scratch + scratch_off;
+	p.dry = false;
+	int rc = p.run_steps(false);
+	if (rc) return rc;
+	for (const auto &j : jobs) {
+		f128 c = bn::f128_one();
+		const void *f[2] = {nullptr, nullptr};
+		bool is_eq[2] = {false, false};
+		int nf = 0;
+		auto take = [&](const node &v) {
+			if (v.kind == node::CONST)
+				c = bn::mul_host(c, v.c);
+			else
+				f[nf++] = p.src(v);
+		};
+		take(p.val[j.x]);
+		if (j.y >= 0) {
+			take(p.val[j.y]);
+		} else if (eq) {
+			is_eq[nf] = true;
+			f[nf++] = eq;
+		}
+		if (c == bn::f128_zero()) continue;
+		for (uint32_t b = 0; b < n_b; b++) {
+			if (nf == 0) {
+				if (seg & 1) col.consts.push_back({out_index[b], c}); // a constant summand: c times (number of rows mod 2)
+				continue;
+			}
+			ip_job q;
+			q.a = is_eq[0] ? f[0] : (const char *)f[0] + (size_t)b * seg * sizeof(f128);
+			q.b = nf == 2 ? (is_eq[1] ? f[1] : (const char *)f[1] + (size_t)b * seg * sizeof(f128)) : nullptr;
+			q.coeff = c;
+			q.out = out_index[b];
+			col.jobs.push_back(q);
+		}
+	}
+	return BN_OK;
+}
+
+// values[q.out] ^= q.coeff * sum_j q.a[j] q.b[j] (q.b == null: the all-ones row `ones`) for every collected request, n elements each;
+// as many launches of the group kernel as 32 jobs of two products each take (one, for every request seen so far)
+int circuit_ip_run(bn_ctx *ctx, const ip_collector &col, uint64_t n, const void *ones, f128 *values)
+{
+	for (const auto &c : col.consts) values[c.first] ^= c.second;
+	size_t at = 0;
+	while (at < col.jobs.size()) {
+		bn::group_job gj[bn::kGroupMaxJobs];
+		uint32_t nj = 0, n_ip = 0;
+		const size_t first = at;
+		while (at < col.jobs.size() && nj < (uint32_t)bn::kGroupMaxJobs) {
+			bn::group_job &g = gj[nj];
+			g = bn::group_job{};
+			g.kind = 2;
+			g.n = n;
+			g.slot = 2 * nj;
+			g.x0[0] = col.jobs[at].a;
+			g.x0[1] = col.jobs[at].b ? col.jobs[at].b : ones;
+			at++;
+			n_ip++;
+			if (at < col.jobs.size()) {
+				g.x1[0] = col.jobs[at].a;
+				g.x1[1] = col.jobs[at].b ? col.jobs[at].b : ones;
+				at++;
+				n_ip++;
+			}
+			nj++;
+		}
+		if (!ctx->s_clean) {
+			BN_HIP(hipMemsetAsync(ctx->d_result, 0, 64 * sizeof(f128), ctx->stream));
+			ctx->s_clean = true;
+		}
+		ctx->mirror.valid = false;
+		const uint64_t seq = ++ctx->mail_seq;
+		{
+			prof_scope ps(ctx, BN_PROF_ROUND_EVAL_MFMA);
+			const hipError_t e = bn::launch_group(ctx->stream, ctx->n_cu, gj, nj, 2 * nj, ctx->d_result, ctx->d_mail, ctx->d_ticket, seq);
+			if (e != hipSuccess) return bn::hip_fail(e, "launch_group (inner products of compiled circuits)");
+		}
+		volatile uint64_t *seqw = &ctx->h_mail[64].lo;
+		uint64_t spins = 0;
+		while (__atomic_load_n(seqw, __ATOMIC_ACQUIRE) != seq) {
+			if (++spins > (1ull << 22)) {
+				BN_HIP(hipStreamSynchronize(ctx->stream));
+				if (__atomic_load_n(seqw, __ATOMIC_ACQUIRE) != seq) return bn::fail(BN_ERR_DEVICE, "device error: result mailbox was not published");
+				break;
+			}
+		}
+		for (uint32_t i = 0; i < n_ip; i++) {
+			f128 v;
+			v.lo = __atomic_load_n(&ctx->h_mail[i].lo, __ATOMIC_RELAXED);
+			v.hi = __atomic_load_n(&ctx->h_mail[i].hi, __ATOMIC_RELAXED);
+			const ip_job &q = col.jobs[first + i];
+			values[q.out] ^= (q.coeff == bn::f128_one()) ? v : bn::mul_host(q.coeff, v);
+		}
+	}
+	return BN_OK;
+}
+
 } // namespace bnabi

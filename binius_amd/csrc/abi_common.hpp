@@ -133,6 +133,20 @@ void group_note_write(bn_ctx *ctx, const void *p, uint64_t n);
 // wanted -- the caller goes on with the single-claim dispatcher
 int group_eval(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const bn_kop *ops, uint32_t n_ops, const uint32_t *ret_values, uint32_t n_ret,
                bn_f128 *h_out, bool *handled);
+// the same plan over super-rows (n_b evaluation points side by side), its final sums collected as inner-product requests, and
+// all requests of a call in one launch of the group kernel (abi_circuit.cpp)
+struct ip_job {
+	const void *a, *b; // b == null: the sum of row a
+	bn::f128 coeff;
+	uint32_t out;
+};
+struct ip_collector {
+	std::vector<ip_job> jobs;
+	std::vector<std::pair<uint32_t, bn::f128>> consts;
+};
+int circuit_multipass_collect(bn_ctx *ctx, const bn_expr *e, const void *const *rows, uint64_t seg, uint32_t n_b, const void *eq, size_t scratch_off,
+                              const uint32_t *out_index, ip_collector &col);
+int circuit_ip_run(bn_ctx *ctx, const ip_collector &col, uint64_t n, const void *ones, bn::f128 *values);
 // ---- small helpers shared by the op entry points (abi.cpp)
 int publish_result(bn_ctx *ctx, uint32_t n_groups, bn_f128 *h_out);
 int publish_vals(bn_ctx *ctx, const bn::f128 *d_vals, uint32_t n_groups, uint32_t group_len, uint32_t g_stride, uint32_t i_stride, bn::f128 *h_out);

@@ -149,20 +149,31 @@ int bn_hal_round_evals(bn_ctx *ctx, uint32_t order, uint32_t n_vars, const void 
 	// scratch is laid out once: [partial evaluations of the Transparent multilinears | 1 | rows | circuit temporaries]
 	bool general_ok = circuit_multipass_applies(ctx, evs[0].composition, half) && total <= 32;
 	uint32_t used_mls = 0; // bit k: multilinear k is read by some composition
-	int max_temps = 0;
+	// In the launch-bound regime the rows of all evaluation points of a multilinear lie side by side and ONE set of product passes
+	// serves every point that shares a composition (all points but infinity); from 2^18 rows on the passes are traffic-bound, the
+	// copies that would put the X = 0 / 1 halves beside the other rows cost more than the launches they save, and every point runs
+	// its own passes.
+	// (measured, a·b·c + a at X = 1, infinity, z: n = 20 -- rows of 8 MiB -- is traffic-bound already: 0.140 ms with the copies, the
+	// three rows of X = 1 being 72 MB of the 370 MB the request moves)
+	const bool batch_points = half <= ((uint64_t)1 << 17);
+	size_t max_temp_elems = 0; // temporaries of the largest plan, in elements
 	for (uint32_t e = 0; e < n_evs && general_ok; e++)
 		for (const bn_expr *c : {(const bn_expr *)evs[e].composition, (const bn_expr *)evs[e].composition_at_infinity}) {
 			for (const bn_step &st : c->steps)
 				if (st.kind == BN_STEP_VAR) used_mls |= 1u << st.a;
 			const int t = circuit_multipass_sum_temps(c, evs[e].d_eq_ind != nullptr);
 			if (t < 0) general_ok = false;
-			if (t > max_temps) max_temps = t;
+			const uint32_t n_b = (batch_points && c == evs[e].composition) ? evs[e].eval_point_end - evs[e].eval_point_start : 1;
+			// (the final sums of all compositions run in ONE launch at the end, so in the launch-bound regime every composition keeps
+			// its own temporaries until then: the sum; at traffic-bound sizes the sums collected so far run before temporaries are
+			// reused: the maximum)
+			if (t > 0) max_temp_elems = batch_points ? max_temp_elems + (size_t)t * n_b * half : std::max(max_temp_elems, (size_t)t * n_b * half);
 		}
 	uint32_t n_used = 0;
 	for (uint32_t k = 0; k < n_mls; k++) n_used += (used_mls >> k) & 1;
 	const size_t tr_elems = n_tr ? (size_t)n_tr * full + 1 : 0;
 	const size_t row_elems = general_ok ? (size_t)(pt_hi - pt_lo) * n_used * half : 0;
-	const size_t temp_elems = general_ok ? (size_t)max_temps * half : 0;
+	const size_t temp_elems = general_ok ? max_temp_elems : 0;
 	char *scr = nullptr;
 	if (tr_elems + row_elems + temp_elems) {
 		scr = (char *)bn::ctx_scratch(ctx, (tr_elems + row_elems + temp_elems) * sizeof(f128));
@@ -211,6 +222,25 @@ int bn_hal_round_evals(bn_ctx *ctx, uint32_t order, uint32_t n_vars, const void 
 	// sum of monomials of at most three multilinears (two next to an equality indicator).  Every DISTINCT monomial
 	// (x indicator table) is ONE pass of the ComputeLayer's product-sum kernels, which return the sums at both points;
 	// the coefficients are applied to the 16-byte sums on the host.
+	// all-ones | all-zeros tables of `half` elements, filled once per size and kept in the context
+	auto const_tables = [&]() -> int {
+		if (ctx->hal_const_half == half) return BN_OK;
+		if (ctx->hal_const) {
+			BN_HIP(hipStreamSynchronize(ctx->stream));
+			BN_HIP(hipFree(ctx->hal_const));
+			ctx->hal_const = nullptr;
+			ctx->hal_const_half = 0;
+		}
+		if (hipMalloc(&ctx->hal_const, 2 * half * sizeof(f128)) != hipSuccess) {
+			(void)hipGetLastError();
+			ctx->hal_const = nullptr;
+			return bn::fail(BN_ERR_ALLOC, "allocation error: allocator is out of memory (constant tables of the round evaluation)");
+		}
+		BN_HIP(bn::launch_fill(ctx->stream, ctx->hal_const, half, bn::f128_one()));
+		BN_HIP(hipMemsetAsync((char *)ctx->hal_const + half * sizeof(f128), 0, half * sizeof(f128), ctx->stream));
+		ctx->hal_const_half = half;
+		return BN_OK;
+	};
 	struct term_job {
 		std::vector<uint32_t> vars;
 		const void *eq;
@@ -249,21 +279,9 @@ int bn_hal_round_evals(bn_ctx *ctx, uint32_t order, uint32_t n_vars, const void 
 		for (const auto &j : jobs)
 			if (!(j.vars.empty() && !j.eq) && j.vars.size() + (j.eq ? 1 : 0) <= 2 && (j.eq || j.vars.size() < 2)) need_tables = true;
 		if (need_tables) {
-			if (ctx->hal_const_half != half) {
-				if (ctx->hal_const) {
-					BN_HIP(hipStreamSynchronize(ctx->stream));
-					BN_HIP(hipFree(ctx->hal_const));
-					ctx->hal_const = nullptr;
-					ctx->hal_const_half = 0;
-				}
-				if (hipMalloc(&ctx->hal_const, 2 * half * sizeof(f128)) != hipSuccess) {
-					(void)hipGetLastError();
-					ctx->hal_const = nullptr;
-					return bn::fail(BN_ERR_ALLOC, "allocation error: allocator is out of memory (constant tables of the routed round evaluation)");
-				}
-				BN_HIP(bn::launch_fill(ctx->stream, ctx->hal_const, half, bn::f128_one()));
-				BN_HIP(hipMemsetAsync((char *)ctx->hal_const + half * sizeof(f128), 0, half * sizeof(f128), ctx->stream));
-				ctx->hal_const_half = half;
+			{
+				int rc = const_tables();
+				if (rc) return rc;
 			}
 			ones = (char *)ctx->hal_const;
 			zeros = ones + half * sizeof(f128);
@@ -321,8 +339,14 @@ int bn_hal_round_evals(bn_ctx *ctx, uint32_t order, uint32_t n_vars, const void 
 		// product per Mul: 170 x slower per point, profiles/r03/hal.jsonl.)
 		char *rows_base = scr + tr_elems * sizeof(f128);
 		const size_t temps_off = (tr_elems + row_elems) * sizeof(f128);
+		// row storage: multilinear by multilinear, inside a multilinear the evaluation points in the order "all but infinity,
+		// ascending; infinity last" -- the points of any evaluator that share its composition are then adjacent
+		const uint32_t n_pts = pt_hi - pt_lo;
+		auto pos_of = [&](uint32_t p) -> uint32_t {
+			if (p == 2) return n_pts - 1;
+			return p - pt_lo - ((pt_lo <= 2 && p > 2) ? 1u : 0u);
+		};
 		std::vector<std::vector<const void *>> row(pt_hi, std::vector<const void *>(n_mls, nullptr));
-		size_t next_row = 0;
 		bn::hal_rows_args ra{};
 		ra.order = order;
 		ra.half = half;
@@ -332,14 +356,15 @@ int bn_hal_round_evals(bn_ctx *ctx, uint32_t order, uint32_t n_vars, const void 
 			ra.n_jobs = 0;
 			return BN_OK;
 		};
-		for (uint32_t p = pt_lo; p < pt_hi; p++) {
-			bool wanted = false;
-			for (uint32_t e = 0; e < n_evs; e++) wanted = wanted || (p >= evs[e].eval_point_start && p < evs[e].eval_point_end);
-			for (uint32_t k = 0; k < n_mls; k++) {
-				if (!((used_mls >> k) & 1)) continue;
-				char *dst = rows_base + next_row++ * half * sizeof(f128);
+		uint32_t ku = 0;
+		for (uint32_t k = 0; k < n_mls; k++) {
+			if (!((used_mls >> k) & 1)) continue;
+			for (uint32_t p = pt_lo; p < pt_hi; p++) {
+				bool wanted = false;
+				for (uint32_t e = 0; e < n_evs; e++) wanted = wanted || (p >= evs[e].eval_point_start && p < evs[e].eval_point_end);
 				if (!wanted) continue;
-				if (!l2h && a.ml[k].len == full && p <= 1) {
+				char *dst = rows_base + ((size_t)ku * n_pts + pos_of(p)) * half * sizeof(f128);
+				if (!batch_points && !l2h && a.ml[k].len == full && p <= 1) {
 					row[p][k] = (const char *)a.ml[k].evals + (p ? half * 16 : 0); // the half itself
 					continue;
 				}
@@ -357,27 +382,74 @@ int bn_hal_round_evals(bn_ctx *ctx, uint32_t order, uint32_t n_vars, const void 
 					if (rc) return rc;
 				}
 			}
+			ku++;
 		}
 		{
 			int rc = flush_rows();
 			if (rc) return rc;
 		}
-		uint32_t idx = 0;
-		for (uint32_t e = 0; e < n_evs; e++)
-			for (uint32_t p = evs[e].eval_point_start; p < evs[e].eval_point_end; p++, idx++) {
-				const bn_expr *c = p == 2 ? evs[e].composition_at_infinity : evs[e].composition;
-				int rc = circuit_multipass_sum(ctx, c, row[p].data(), half, evs[e].d_eq_ind, d_acc + 2 * idx, temps_off);
+		{
+			int rc = const_tables(); // (the all-ones row: the sum of a lone row is its inner product with it)
+			if (rc) return rc;
+		}
+		// the element-wise passes of every composition (once for all the points that share it when the rows lie side by side), the
+		// final sums collected; then ALL sums of the request in one launch
+		ip_collector col;
+		std::vector<f128> vals(total, bn::f128_zero());
+		size_t temp_cursor = 0; // elements of the temporaries' region handed out to compositions whose sums have not run yet
+		ctx->s_clean = true;    // (the accumulator slots were zeroed above, nothing has touched them since)
+		std::vector<uint32_t> base_idx(n_evs);
+		{
+			uint32_t idx = 0;
+			for (uint32_t e = 0; e < n_evs; e++) {
+				base_idx[e] = idx;
+				idx += evs[e].eval_point_end - evs[e].eval_point_start;
+			}
+		}
+		for (uint32_t e = 0; e < n_evs; e++) {
+			const uint32_t s0 = evs[e].eval_point_start, s1 = evs[e].eval_point_end;
+			std::vector<uint32_t> pts; // the points that use evs[e].composition, in row order
+			for (uint32_t p = s0; p < s1; p++)
+				if (p != 2) pts.push_back(p);
+			auto run = [&](const bn_expr *c, const std::vector<uint32_t> &ps) -> int {
+				std::vector<uint32_t> out_index;
+				for (uint32_t p : ps) out_index.push_back(base_idx[e] + (p - s0));
+				const int t = circuit_multipass_sum_temps(c, evs[e].d_eq_ind != nullptr);
+				const size_t need = t > 0 ? (size_t)t * ps.size() * half : 0;
+				if (temp_cursor + need > temp_elems) {
+					// the temporaries of the compositions collected so far are about to be reused: their sums run now
+					int rc = circuit_ip_run(ctx, col, half, ctx->hal_const, vals.data());
+					if (rc) return rc;
+					col = ip_collector{};
+					temp_cursor = 0;
+				}
+				int rc = circuit_multipass_collect(ctx, c, row[ps[0]].data(), half, (uint32_t)ps.size(), evs[e].d_eq_ind, temps_off + temp_cursor * sizeof(f128),
+				                                   out_index.data(), col);
 				if (rc == kCircuitDeclined) return bn::fail(BN_ERR_CORE_LIB, "internal: a planned circuit was declined");
+				temp_cursor += need;
+				return rc;
+			};
+			if (batch_points) {
+				if (!pts.empty()) {
+					int rc = run(evs[e].composition, pts);
+					if (rc) return rc;
+				}
+			} else {
+				for (uint32_t p : pts) {
+					int rc = run(evs[e].composition, std::vector<uint32_t>{p});
+					if (rc) return rc;
+				}
+			}
+			if (s0 <= 2 && 2 < s1) {
+				int rc = run(evs[e].composition_at_infinity, std::vector<uint32_t>{2});
 				if (rc) return rc;
 			}
-		std::vector<f128> vals(total);
+		}
 		{
-			int rc = publish_vals(ctx, d_acc, 2, total, 1, 2, vals.data()); // value i = slot 2 i + slot 2 i + 1, through the mailbox
+			int rc = circuit_ip_run(ctx, col, half, ctx->hal_const, vals.data());
 			if (rc) return rc;
 		}
 		for (uint32_t i = 0; i < total; i++) h_out[i] = bn_f128{vals[i].lo, vals[i].hi};
-		BN_HIP(hipMemsetAsync(d_acc, 0, 64 * sizeof(f128), ctx->stream));
-		ctx->s_clean = true;
 		return BN_OK;
 	} else {
 		uint32_t off = 0;

@@ -450,7 +450,7 @@ struct group_job {
 	void *out[2];              // kind 0: where the folded arrays (2 n elements each) are written (may be x0)
 	f128 z;                    // kind 0: the fold's challenge
 	uint64_t n;                // evaluation points of the job
-	uint32_t kind;             // 0 = fold + evaluate, 1 = evaluate
+	uint32_t kind;             // 0 = fold + evaluate, 1 = evaluate, 2 = two plain inner products: rows x0[0] . x0[1] -> S[slot], x1[0] . x1[1] -> S[slot + 1] (x1 null: one)
 	uint32_t slot;             // the job's sums are XORed into S[slot] (at 1) and S[slot + 1] (at infinity)
 	uint32_t wg_begin, wg_count; // (filled in by the launcher)
 };

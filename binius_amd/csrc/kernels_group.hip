@@ -6,6 +6,8 @@
 //            S_1   = sum_{j < N/4} a'[j + N/4] b'[j + N/4]
 //            S_inf = sum_{j < N/4} (a'[j] + a'[j + N/4]) (b'[j] + b'[j + N/4])
 //   kind 1   S_1 = sum_j a_1[j] b_1[j], S_inf = sum_j (a_0[j] + a_1[j]) (b_0[j] + b_1[j]) over the halves a_0 | a_1, b_0 | b_1 as they are
+//   kind 2   two plain inner products of rows: S[slot] = sum_j A[j] B[j], S[slot + 1] = sum_j C[j] D[j]  (the final sums of compiled
+//            circuits for all evaluation points of an old-HAL request in one launch, abi_hal.cpp; C = D = null: one product)
 //
 // Why.  The reference's PCS prover issues k product claims over m multilinears per prover and runs several provers front-loaded
 // on one ComputeLayer: per batch round  execute(P_1) .. execute(P_p), one challenge, fold(P_1) .. fold(P_p)
@@ -135,16 +137,21 @@ __device__ __forceinline__ void group_loops(const group_wg &w, uint32_t *T_dyn, 
 	// KIND 1 keeps TWO tiles of loads in flight per fold group (x0: the tile after this one, xb: the one after that): with nothing to
 	// compute between a tile's loads and its staging, one tile in flight is 32 KiB per CU and the launch sits at the memory
 	// latency (2.1 TB/s measured at 2^25 points per claim); KIND 0 has 64 KiB of loads per CU in flight with one tile per group
-	uint4 xb[KIND == 1 ? 4 : 1];
+	uint4 xb[KIND != 0 ? 4 : 1];
 	auto load_into = [&](uint4 *dst0, uint32_t t, int q) {
 		const uint32_t o = in_range(t) ? vo : 0u; // (a lane past the end reads the tile's first element: in range, never used)
 		if constexpr (KIND == 0) {
 			const uint64_t e = ((q & 1 ? n : 0) + (uint64_t)(tbase + t) * kTP) * 16; // (uniform)
 			dst0[q] = gq_load<NT>(reinterpret_cast<const uint4 *>(w.X0[q >> 1] + e + o));
 			x1[q] = gq_load<NT>(reinterpret_cast<const uint4 *>(w.X1[q >> 1] + e + o));
-		} else {
+		} else if constexpr (KIND == 1) {
 			const uint64_t e1 = (uint64_t)(tbase + t) * kTP * 16;
 			dst0[q] = gq_load<NT>(reinterpret_cast<const uint4 *>((q & 1 ? w.X1[q >> 1] : w.X0[q >> 1]) + e1 + o));
+		} else {
+			// rows A, B, C, D = x0[0], x0[1], x1[0], x1[1]; an absent second product reads the first one's rows (its sum is never looked at)
+			const uint64_t e1 = (uint64_t)(tbase + t) * kTP * 16;
+			const char *row = q < 2 ? w.X0[q] : (w.X1[q - 2] ? w.X1[q - 2] : w.X0[q - 2]);
+			dst0[q] = gq_load<NT>(reinterpret_cast<const uint4 *>(row + e1 + o));
 		}
 	};
 	auto load1 = [&](uint32_t t, int q) { load_into(x0, t, q); };
@@ -153,7 +160,7 @@ __device__ __forceinline__ void group_loops(const group_wg &w, uint32_t *T_dyn, 
 #pragma unroll
 		for (int q = 0; q < 4; q++)
 			load1(tm0, q);
-		if constexpr (KIND == 1) {
+		if constexpr (KIND != 0) {
 			const uint32_t tm1 = tm0 + 2 * tstride < tlimit ? tm0 + 2 * tstride : tm0;
 #pragma unroll
 			for (int q = 0; q < 4; q++)
@@ -177,7 +184,7 @@ __device__ __forceinline__ void group_loops(const group_wg &w, uint32_t *T_dyn, 
 			const uint32_t tm = t + grp * tstride;
 			if (tm < tlimit) { // (uniform; false only for group 1 on an odd last pair)
 				// the last iteration(s) re-request their own tile (cache hits) instead of branching around the loads
-				constexpr uint32_t kAhead = KIND == 1 ? 4 : 2;
+				constexpr uint32_t kAhead = KIND != 0 ? 4 : 2;
 				const uint32_t tn = tm + kAhead * tstride < tlimit ? tm + kAhead * tstride : tm;
 				vo = lane_off();
 				const bool ok = in_range(tm);
@@ -206,11 +213,19 @@ __device__ __forceinline__ void group_loops(const group_wg &w, uint32_t *T_dyn, 
 					for (int q = 0; q < 4; q++)
 						f[q] = uint4{0, 0, 0, 0}; // points past the end carry zeros
 				}
-				// half 1 is the evaluation at 1, half 0 its partner: sets 0 / 1 = u, v at 1; sets 2 / 3 = u, v at infinity
-				stage4_elem(Tn, sr, 0, f[1]);
-				stage4_elem(Tn, sr, 2, xor4(f[1], f[0]));
-				stage4_elem(Tn, sr, 1, f[3]);
-				stage4_elem(Tn, sr, 3, xor4(f[3], f[2]));
+				if constexpr (KIND == 2) {
+					// sets 0 / 1 = the first product's rows, sets 2 / 3 = the second's
+					stage4_elem(Tn, sr, 0, f[0]);
+					stage4_elem(Tn, sr, 1, f[1]);
+					stage4_elem(Tn, sr, 2, f[2]);
+					stage4_elem(Tn, sr, 3, f[3]);
+				} else {
+					// half 1 is the evaluation at 1, half 0 its partner: sets 0 / 1 = u, v at 1; sets 2 / 3 = u, v at infinity
+					stage4_elem(Tn, sr, 0, f[1]);
+					stage4_elem(Tn, sr, 2, xor4(f[1], f[0]));
+					stage4_elem(Tn, sr, 1, f[3]);
+					stage4_elem(Tn, sr, 3, xor4(f[3], f[2]));
+				}
 			}
 			__syncthreads(); // the pair is staged; the Gram waves are done with the buffer this wave writes next
 			buf ^= 1;
@@ -218,7 +233,7 @@ __device__ __forceinline__ void group_loops(const group_wg &w, uint32_t *T_dyn, 
 		};
 		if constexpr (KIND == 0) {
 			for (uint32_t t = t0; t < tlimit; t += 2 * tstride) pair_step(t, x0);
-		} else {
+		} else { // (KIND 1, 2: two tiles in flight)
 			for (uint32_t t = t0; t < tlimit;) {
 				pair_step(t, x0);
 				t += 2 * tstride;
@@ -285,8 +300,10 @@ __global__ __launch_bounds__(kThreads, 1) void k_group_fp4(group_kargs ga)
 	}
 	if (jb->kind == 0) // (uniform)
 		group_loops<0, FULL, NT>(w, T_dyn, tab, Gc, ga.prio);
-	else
+	else if (jb->kind == 1)
 		group_loops<1, FULL, NT>(w, T_dyn, tab, Gc, ga.prio);
+	else
+		group_loops<2, FULL, NT>(w, T_dyn, tab, Gc, ga.prio);
 
 	// ---- tail: parity words -> the job's two sums -> its accumulator slots; the last workgroup of the launch publishes ALL slots
 	__shared__ uint64_t z3[2][3];
@@ -360,7 +377,7 @@ hipError_t launch_group(hipStream_t s, int n_cu, const group_job *jobs_in, uint3
 	uint32_t tiles[kGroupMaxJobs], cap[kGroupMaxJobs], cnt[kGroupMaxJobs];
 	for (uint32_t i = 0; i < n_jobs; i++) {
 		const group_job &j = jobs_in[i];
-		if (j.n == 0 || j.kind > 1 || j.slot + 2 > n_slots) return hipErrorInvalidValue;
+		if (j.n == 0 || j.kind > 2 || j.slot + 2 > n_slots) return hipErrorInvalidValue;
 		if (j.n % kTP) full = false;
 		const uint64_t nt = (j.n + kTP - 1) / kTP;
 		if (nt > (1ull << 14) * (uint64_t)n_cu) return hipErrorNotSupported; // 2^22 points per workgroup: the f32 counts stay exact
