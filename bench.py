@@ -44,7 +44,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
-PMC_FILE = os.path.join("profiles", "r04", "bench_pmc.json")  # tools/pmc_bench.sh: FETCH_SIZE / WRITE_SIZE passes of this command
+PMC_FILE = os.path.join("profiles", "r05", "bench_pmc.json")  # tools/pmc_bench.sh: FETCH_SIZE / WRITE_SIZE passes of this command
 
 
 def csrc_sha16():
@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--n-vars", type=int, default=28, help="variables of the GLOBAL instance (28: north star; 24: BASELINE configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-claim-groups", action="store_true", help="skip the k = 4, m = 8 claim-group leg reported beside the headline")
     ap.add_argument("--no-prof", action="store_true", help="diagnostic: no per-launch hipEvents in the timed region (no roofline block)")
     ap.add_argument("--no-alt-exchange", action="store_true", help="do not time the shared-memory exchange beside the RCCL one")
     ap.add_argument("--cpu-n-vars", type=int, default=0, help="size of the CPU baseline sample (0 = auto)")
@@ -499,7 +500,7 @@ def main():
     }
     # HBM traffic of the dominant kernel: PMC counters cannot be collected inside this process, so the
     # value comes from the committed counters-only rocprofv3 passes OF THIS COMMAND (tools/pmc_bench.sh ->
-    # profiles/r04/bench_pmc.json: FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, average bytes per launch
+    # profiles/r05/bench_pmc.json: FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, average bytes per launch
     # of the kernel symbol, with the commit of the build it was taken on); null for a workload it does not hold
     try:
         pmc = json.load(open(os.path.join(ROOT, PMC_FILE)))
@@ -580,6 +581,58 @@ def main():
         "roofline": roofline,
         "kernels": per_kernel,
     }
+
+    # ---- the reference's REAL call shape beside the headline: ONE BivariateSumcheckProver with k = 4 product
+    # claims over m = 8 multilinears of 2^24 elements (piop::prove builds one such prover per size, core/src/piop/prove.rs:271-287),
+    # through the same compiled prover loop -- the claim-group path (csrc/abi_group.cpp, kernels_group.hip).  Reported, not the metric.
+    if rank == 0 and world == 1 and dist is None and not args.no_claim_groups:
+        try:
+            gk, gn_vars = 4, min(24, n_global)
+            gm, gn = 2 * gk, 1 << gn_vars
+            with binius_amd.Context(local_rank, gm * gn + gm * (gn // 2) + 4096) as ghal:
+                galloc = ghal.dev_alloc()
+                gd = []
+                for j in range(gm):  # dense pseudo-random inputs generated on the device: tensor expansions of random points
+                    s = galloc.alloc(gn)
+                    ghal.fill(s.slice(0, 1), 1 + j)
+                    ghal.tensor_expand(0, synthetic.random_scalars(0xB1A5 + j, gn_vars), s)
+                    gd.append(s)
+                gcomps = [(i, gk + i) for i in range(gk)]
+                gsums = [ghal.inner_product(gd[i], 7, gd[j]) for i, j in gcomps]
+                gstream = synthetic.random_scalars(0xC4A1, gn_vars + 1)
+                gplan = SumcheckPlan(ghal, gn_vars, gd, galloc.alloc(gm * (gn // 2)), gcomps, gsums, gstream[0], gstream[1:])
+                gplan.run()
+                ghal.sync()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    gplan.run()
+                ghal.sync()
+                gms = (time.perf_counter() - t0) * 1e3 / 3
+                gc, gf = gplan.round_coeffs(), gplan.final_evals()
+                run_sum, p = 0, 1
+                for sm in gsums:
+                    run_sum ^= F.mul(p, sm)
+                    p = F.mul(p, gstream[0])
+                gok = True
+                for r in range(gn_vars):
+                    c0, c1, c2 = gc[r]
+                    gok = gok and (c0 ^ (c0 ^ c1 ^ c2)) == run_sum
+                    z = gstream[1 + r]
+                    run_sum = c0 ^ F.mul(z, c1 ^ F.mul(z, c2))
+                acc, p = 0, 1
+                for i, j in gcomps:
+                    acc ^= F.mul(p, F.mul(gf[i], gf[j]))
+                    p = F.mul(p, gstream[0])
+                gok = gok and acc == run_sum
+                cnt = ghal.group_counters()
+            out["claim_groups"] = {
+                "workload": "one BivariateSumcheckProver, k=%d product claims over m=%d multilinears of 2^%d elements" % (gk, gm, gn_vars),
+                "ms_per_prove": round(gms, 4), "elems_per_s": round(gm * gn / (gms * 1e-3), 1),
+                "frac_of_64mN_at_8TBps": round(64.0 * gm * gn / (gms * 1e-3) / (HBM_PEAK_GBS * 1e9), 4), "verifier_check": bool(gok),
+                "per_prove": {"group_launches": cnt["launches"] // 4, "claims_fused_with_their_folds": cnt["jobs_fused"] // 4, "rounds_on_the_host": cnt["hosted_evals"] // 4},
+            }
+        except Exception as ex:  # noqa: BLE001 -- a side measurement must not cost the headline line
+            out["claim_groups"] = {"error": repr(ex)}
 
     # ---- CPU baseline, rank 0 only: the same loop (round-eval + fold every round) on the host cores.
     # Reported value = the OPTIMIZED port (oracle/fastcpu_ref.c: arithmetic in the isomorphic POLYVAL field with

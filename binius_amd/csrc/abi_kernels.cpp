@@ -57,7 +57,7 @@ hipError_t roundeval_product_routed(bn_ctx *ctx, bool scratch_free, const void *
                                     f128 *d_out, const bn::fin_fuse *fuse)
 {
 	static const bool route = [] {
-		const char *e = getenv("BN_EQ_ROUTE");
+		const char *e = bn::settled_knob("BN_EQ_ROUTE");
 		return !(e && e[0] == '0');
 	}();
 	if (route && scratch_free && k == 3 && n >= (1ull << 20) && bn::mfma_applies(ctx->n_cu, n)) {
@@ -93,7 +93,7 @@ constexpr uint64_t kArmMaxIn = 1ull << 19;     // largest round (elements per ar
 uint64_t arm_max_in_mfma()
 {
 	static const uint64_t v = [] {
-		const char *e = getenv("BN_ARM_MAX_LOG2");
+		const char *e = bn::settled_knob("BN_ARM_MAX_LOG2");
 		const int l = e ? atoi(e) : 24;
 		return (uint64_t)1 << (l < 4 ? 4 : (l > 40 ? 40 : l));
 	}();
@@ -105,7 +105,7 @@ uint64_t arm_max_in_mfma()
 uint64_t two_round_max_m()
 {
 	static const uint64_t v = [] {
-		const char *e = getenv("BN_TWO_ROUND_MAX_LOG2");
+		const char *e = bn::settled_knob("BN_TWO_ROUND_MAX_LOG2");
 		const int l = e ? atoi(e) : 16;
 		return (uint64_t)1 << (l < 2 ? 2 : (l > 20 ? 20 : l));
 	}();

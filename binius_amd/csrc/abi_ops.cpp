@@ -198,19 +198,19 @@ int bn_pairwise_product_reduce(bn_ctx *ctx, const void *d_in, uint64_t n, void *
 	// (kernels_pairtree.hip): up to BN_PAIRTREE_LOG_S (6) levels per launch.  (Round 2 measured the bit-sliced product itself inside one
 	// workgroup for the last 12 levels: 233 vs 225 us -- its chain is the cost)
 	static const uint32_t tree_max_log2 = [] {
-		const char *e = getenv("BN_PAIRTREE_MAX_LOG2"); // measurement knob: 0 = off
+		const char *e = bn::settled_knob("BN_PAIRTREE_MAX_LOG2"); // measurement knob: 0 = off
 		const int v = e ? atoi(e) : 15;
 		return (uint32_t)(v < 0 ? 0 : (v > 24 ? 24 : v));
 	}();
 	static const uint32_t tree_log_s = [] {
-		const char *e = getenv("BN_PAIRTREE_LOG_S");
+		const char *e = bn::settled_knob("BN_PAIRTREE_LOG_S");
 		const int v = e ? atoi(e) : 6;
 		return (uint32_t)(v < 1 ? 1 : (v > 8 ? 8 : v));
 	}();
 	const void *src = d_in;
 	uint32_t r = 0;
 	static const uint32_t fuse = [] {
-		const char *e = getenv("BN_MUL9_FUSE"); // levels per launch of the element-wise kernel (1 .. 4)
+		const char *e = bn::settled_knob("BN_MUL9_FUSE"); // levels per launch of the element-wise kernel (1 .. 4)
 		const int v = e ? atoi(e) : 2;
 		return (uint32_t)(v < 1 ? 1 : (v > 4 ? 4 : v));
 	}();
@@ -328,7 +328,7 @@ static int ntt_common(bn_ctx *ctx, bool inverse, void *d_data, uint32_t elem_lev
 	BN_REQUIRE(skip_rounds <= log_y, "skip_rounds larger than log_y");
 	BN_REQUIRE(log_x + log_y + log_z < 48, "transform too large");
 	if (log_y == 0 || skip_rounds == log_y) return BN_OK;
-	if (elem_level >= 5 && tw_level == 5 && log_y >= 14 && !getenv("BN_NTT_NO_BITSLICE")) {
+	if (elem_level >= 5 && tw_level == 5 && log_y >= 14 && !bn::settled_knob("BN_NTT_NO_BITSLICE")) {
 		// large transforms with B32 twiddles: bit-sliced butterflies (kernels_ntt_bs.hip); B64 / B128
 		// data and log_x / log_z batches are interleaved B32 transforms
 		const uint32_t lx = log_x + (elem_level - 5);
@@ -352,7 +352,7 @@ static int ntt_common(bn_ctx *ctx, bool inverse, void *d_data, uint32_t elem_lev
 	int rc = upload_s_evals(ctx, h_s_evals, &d_s, 0, nullptr);
 	if (rc) return rc;
 	prof_scope ps(ctx, BN_PROF_NTT);
-	if (!getenv("BN_NTT_PER_LAYER")) {
+	if (!bn::settled_knob("BN_NTT_PER_LAYER")) {
 		hipError_t te = bn::launch_ntt_tiled(ctx->stream, ctx->n_cu, inverse, d_data, elem_level, tw_level, ctx->d_mul8, d_s, log_domain,
 		                                     log_x, log_y, log_z, coset, coset_bits, skip_rounds);
 		if (te == hipSuccess) return BN_OK;

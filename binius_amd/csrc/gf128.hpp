@@ -16,6 +16,7 @@
 // nibble tables (8 KiB of LDS, conflict-free by construction), and the generic product is a
 // bilinear walk over those basis products.
 #pragma once
+#include <cstdlib>
 #include <stdint.h>
 
 #if defined(__HIPCC__)
@@ -23,6 +24,20 @@
 #else
 #define BN_HD
 #endif
+
+namespace bn {
+// Measurement knobs of rounds 1 - 4 whose A/B is settled (profiles/DEAD_ENDS.md): the shipped library runs their
+// defaults and does not read them from the environment; a measurement build (tools/*.hip, -DBN_MEASUREMENT_KNOBS) still does.
+inline const char *settled_knob(const char *name)
+{
+#ifdef BN_MEASUREMENT_KNOBS
+	return std::getenv(name);
+#else
+	(void)name;
+	return nullptr;
+#endif
+}
+} // namespace bn
 
 namespace bn {
 

@@ -203,7 +203,7 @@ bool foldeval_fp4_applies(int n_cu, const foldeval_args &fa, uint64_t n_in)
 	static const int min_log2 = [] {
 		const char *e = getenv("BN_FE_FP4");
 		if (e && e[0] == '0') return 64;
-		const char *m = getenv("BN_FE_FP4_MIN_LOG2");
+		const char *m = bn::settled_knob("BN_FE_FP4_MIN_LOG2");
 		return m ? atoi(m) : 0;
 	}();
 	if (min_log2 >= 64 || fa.scale_mask > 2 || n_in < 4 || (n_in & 3)) return false;
@@ -220,7 +220,7 @@ hipError_t launch_foldeval_fp4(hipStream_t s, int n_cu, const foldeval_args &fa_
 {
 	// BN_FE_FP4_PRIO=0 .. 3: issue priority of the fold waves (default 3; the Gram waves stay at 0)
 	static const uint32_t prio = [] {
-		const char *e = getenv("BN_FE_FP4_PRIO");
+		const char *e = bn::settled_knob("BN_FE_FP4_PRIO");
 		return e ? (uint32_t)atoi(e) & 3u : 3u;
 	}();
 	foldeval_args fa = fa_in;

@@ -237,7 +237,7 @@ hipError_t launch_foldeval_mfma(hipStream_t s, int n_cu, const foldeval_args &fa
 	const uint64_t cap = (uint64_t)n_cu * 2;
 	const dim3 grid((unsigned)(n_tiles < cap ? n_tiles : cap));
 	static const uint32_t xcd_tiles = [] {
-		const char *e = getenv("BN_XCD_TILES");
+		const char *e = bn::settled_knob("BN_XCD_TILES");
 		return (uint32_t)!(e && e[0] == '0');
 	}();
 	foldeval_args fx = fa;
@@ -245,7 +245,7 @@ hipError_t launch_foldeval_mfma(hipStream_t s, int n_cu, const foldeval_args &fa
 	const bool full = ((n_in >> 2) % kTP) == 0;
 	// BN_FE_NT_MIN_LOG2: elements per array from which the accesses are non-temporal (measurement knob; 64 = never)
 	static const int nt_min_log2 = [] {
-		const char *e = getenv("BN_FE_NT_MIN_LOG2");
+		const char *e = bn::settled_knob("BN_FE_NT_MIN_LOG2");
 		return e ? atoi(e) : 25;
 	}();
 	const bool nt = full && nt_min_log2 < 64 && n_in >= (1ull << nt_min_log2);

@@ -367,7 +367,7 @@ hipError_t launch_group(hipStream_t s, int n_cu, const group_job *jobs_in, uint3
 {
 	if (n_jobs == 0 || n_jobs > (uint32_t)kGroupMaxJobs || n_slots > 64 || n_cu < (int)n_jobs) return hipErrorNotSupported;
 	static const uint32_t prio = [] {
-		const char *e = getenv("BN_FE_FP4_PRIO");
+		const char *e = bn::settled_knob("BN_FE_FP4_PRIO");
 		return e ? (uint32_t)atoi(e) & 3u : 3u;
 	}();
 	group_kargs ga{};
@@ -450,7 +450,7 @@ hipError_t launch_group(hipStream_t s, int n_cu, const group_job *jobs_in, uint3
 	ga.n_slots = n_slots;
 	ga.prio = prio;
 	static const int nt_min_log2 = [] {
-		const char *e = getenv("BN_FE_NT_MIN_LOG2");
+		const char *e = bn::settled_knob("BN_FE_NT_MIN_LOG2");
 		return e ? atoi(e) : 25;
 	}();
 	// streaming accesses once the launch's arrays cannot stay in the caches anyway (the single-claim kernels' threshold is 2^25

@@ -413,7 +413,7 @@ hipError_t launch_fold_right_mfma(hipStream_t s, int n_cu, const void *mat, uint
                                   uint64_t out_len, void *d_table)
 {
 	static const bool on = [] {
-		const char *e = getenv("BN_FOLD_MFMA"); // 0: the nibble-table kernel everywhere
+		const char *e = bn::settled_knob("BN_FOLD_MFMA"); // 0: the nibble-table kernel everywhere
 		return !(e && e[0] == '0');
 	}();
 	const uint64_t row_bits = vec_len << tower_level;
@@ -434,7 +434,7 @@ hipError_t launch_fold_right_mfma(hipStream_t s, int n_cu, const void *mat, uint
 	const uint64_t cap = (uint64_t)n_cu * 2;
 	const dim3 grid((unsigned)(n_blocks < cap ? n_blocks : cap));
 	static const bool ring = [] {
-		const char *e = getenv("BN_FOLD_MFMA_RING"); // 0: rows prefetched in registers, one block ahead (measurement knob)
+		const char *e = bn::settled_knob("BN_FOLD_MFMA_RING"); // 0: rows prefetched in registers, one block ahead (measurement knob)
 		return !(e && e[0] == '0');
 	}();
 	if (ring) {
@@ -467,7 +467,7 @@ hipError_t launch_fold_left_mfma(hipStream_t s, int n_cu, const void *mat, uint3
                                  uint64_t out_len, void *d_table)
 {
 	static const bool on = [] {
-		const char *e = getenv("BN_FOLD_MFMA");
+		const char *e = bn::settled_knob("BN_FOLD_MFMA");
 		return !(e && e[0] == '0');
 	}();
 	if (!on || !d_table || tower_level != 5 || out_len < 4096 || (out_len & 63) || (vec_len != 16 && vec_len != 32 && vec_len != 64)) return hipErrorNotSupported;

@@ -570,11 +570,11 @@ hipError_t launch_fri_fold(hipStream_t s, const uint64_t *d_s_evals, uint32_t tw
 	uint64_t cur = in_len;
 	uint32_t ll = log_len;
 	static const bool multi = [] {
-		const char *e = getenv("BN_FRI_MULTI");
+		const char *e = bn::settled_knob("BN_FRI_MULTI");
 		return !(e && e[0] == '0');
 	}();
 	static const bool ntt_c3 = [] {
-		const char *e = getenv("BN_FRI_NTT_C3"); // measurement knob: three levels per pass next to butterflies too
+		const char *e = bn::settled_knob("BN_FRI_NTT_C3"); // measurement knob: three levels per pass next to butterflies too
 		return e && e[0] == '1';
 	}();
 	uint32_t c = 0, pass = 0;

@@ -462,7 +462,7 @@ hipError_t launch_mul9(hipStream_t s, int n_cu, const void *a, uint64_t a_stride
 	const uint32_t *pb = (const uint32_t *)b + b_off * 4;
 	// more batches than wave slots: two batches per rebuild (k_mul9_dual); BN_MUL9_DUAL=0 keeps the one-batch kernel
 	static const bool dual_on = [] {
-		const char *e = getenv("BN_MUL9_DUAL");
+		const char *e = bn::settled_knob("BN_MUL9_DUAL");
 		return !(e && e[0] == '0');
 	}();
 	// (unit strides only: the strided form -- one level of pairwise_product_reduce by itself -- never has that many batches

@@ -617,7 +617,7 @@ static hipError_t run_ntt_bs(hipStream_t s, void *data, const uint64_t *h_s_eval
 		uint32_t any = tb.tconst[l];
 		for (uint32_t c = 0; c < 32; c++) any |= host_twiddle(h_s_evals, log_domain, base + l, (uint64_t)c << (NB - l - 1));
 		for (uint32_t bit = 0; bit < 32; bit++) any |= tb.rows[l][bit];
-		static const bool no_sub8 = getenv("BN_NTT_NO_SUB8") != nullptr;
+		static const bool no_sub8 = bn::settled_knob("BN_NTT_NO_SUB8") != nullptr;
 		tb.sub8[l] = (any < 256 && !no_sub8) ? 1u : 0u;
 	}
 	e = hipMemcpyAsync(d_tb, &tb, sizeof(tb), hipMemcpyHostToDevice, s);
@@ -655,17 +655,17 @@ static hipError_t run_ntt_bs(hipStream_t s, void *data, const uint64_t *h_s_eval
 	// -- unless the transforms are interleaved (lx > kMergeMaxLx): the merged conversion walks one transform,
 	// i.e. words 2^lx apart, and every 4-byte access costs a whole sector; head and tail put x across the lanes
 	static const uint32_t merge_max_lx = [] {
-		const char *v = getenv("BN_NTT_MERGE_MAX_LX");
+		const char *v = bn::settled_knob("BN_NTT_MERGE_MAX_LX");
 		return v ? (uint32_t)atoi(v) : 1u;
 	}();
 	const bool merged = !plan.empty() && lx <= merge_max_lx;
-	const char *wb = getenv("BN_NTT_WG_BARRIERS"); // (read per call: a measurement knob)
+	const char *wb = bn::settled_knob("BN_NTT_WG_BARRIERS"); // (read per call: a measurement knob)
 	const uint32_t wg_bar = wb && wb[0] == '1' ? 1u : 0u;
 	const dim3 ht_grid((unsigned)(((S << lx) + 255) / 256), 1u << log_z);
 	if (!(INV && merged))
 		hipLaunchKernelGGL(k_ntt_bs_head<INV>, ht_grid, dim3(256), 0, s, (const uint32_t *)data, bs, S, lx, log_y, d_tb, n_top);
 	static const bool reg_pass = [] {
-		const char *v = getenv("BN_NTT_REG_PASS"); // 0: the LDS-tile passes of rounds 1 - 3
+		const char *v = bn::settled_knob("BN_NTT_REG_PASS"); // 0: the LDS-tile passes of rounds 1 - 3
 		return !(v && v[0] == '0');
 	}();
 	for (size_t k = 0; k < plan.size(); k++) {

@@ -276,13 +276,13 @@ static hipError_t launch_fp4(hipStream_t s, int n_cu, const void *a_hi, const vo
 	const unsigned grid = (unsigned)(n_tiles < cap ? n_tiles : cap);
 	if ((n_tiles + grid - 1) / grid > (1ull << 14)) return hipErrorNotSupported; // 2^22 points per workgroup: the f32 counts stay exact
 	static const uint32_t xcd_tiles = [] {
-		const char *e = getenv("BN_XCD_TILES");
-		const char *p = getenv("BN_FP4_PRIO");
+		const char *e = bn::settled_knob("BN_XCD_TILES");
+		const char *p = bn::settled_knob("BN_FP4_PRIO");
 		return (uint32_t)!(e && e[0] == '0') | (((p ? (uint32_t)atoi(p) : 2u) & 3u) << 1); // BN_FP4_PRIO=0 .. 3 (default 2)
 	}();
 	// BN_FP4_NT_MIN_LOG2: points from which the loads are non-temporal (measurement knob; 64 = never)
 	static const int nt_min_log2 = [] {
-		const char *e = getenv("BN_FP4_NT_MIN_LOG2");
+		const char *e = bn::settled_knob("BN_FP4_NT_MIN_LOG2");
 		return e ? atoi(e) : 24;
 	}();
 	const bool nt = nt_min_log2 < 64 && n >= (1ull << nt_min_log2);
@@ -290,7 +290,7 @@ static hipError_t launch_fp4(hipStream_t s, int n_cu, const void *a_hi, const vo
 	static const int ws_min_log2 = [] {
 		const char *e = getenv("BN_FP4_WS");
 		if (e && e[0] == '0') return 64;
-		const char *m = getenv("BN_FP4_WS_MIN_LOG2");
+		const char *m = bn::settled_knob("BN_FP4_WS_MIN_LOG2");
 		return m ? atoi(m) : 20;
 	}();
 	if (ws_min_log2 < 64 && n >= (1ull << ws_min_log2) && n % kTP == 0 && n_tiles >= 2 * (uint64_t)n_cu && (n_tiles + n_cu - 1) / n_cu <= (1ull << 14)) {

@@ -104,7 +104,7 @@ bool mfma_applies(int n_cu, uint64_t n_points)
 	static const int64_t min_tiles = [] {
 		const char *m = getenv("BN_EVAL");
 		if (m && m[0] == 'v') return (int64_t)-1;
-		const char *e = getenv("BN_MFMA_MIN_TILES");
+		const char *e = bn::settled_knob("BN_MFMA_MIN_TILES");
 		return e ? (int64_t)atoll(e) : (int64_t)0;
 	}();
 	if (min_tiles < 0) return false;
@@ -130,7 +130,7 @@ static hipError_t launch_mfma(hipStream_t s, int n_cu, const void *a_hi, const v
 	if (n == 0 && fuse) return hipErrorNotSupported; // nothing to launch: the caller finalizes separately
 	if (n == 0) return hipSuccess;
 	static const uint32_t xcd_tiles = [] {
-		const char *e = getenv("BN_XCD_TILES");
+		const char *e = bn::settled_knob("BN_XCD_TILES");
 		return (uint32_t)!(e && e[0] == '0');
 	}();
 	hipLaunchKernelGGL((k_roundeval_mfma<SPLIT>), dim3(grid_mfma(n, n_cu)), dim3(256), 0, s, (const uint4 *)a_hi, (const uint4 *)a_lo,

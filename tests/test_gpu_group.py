@@ -85,6 +85,7 @@ def claim_sums(oracle, mls, comps):
     return out
 
 
+_ORACLE = {}
 CASES = [(12, 2, "piop"), (12, 4, "piop"), (12, 8, "piop"), (12, 4, "bipartite"), (18, 2, "piop"), (18, 4, "disjoint"), (18, 8, "piop"), (20, 2, "disjoint"),
          (20, 4, "piop"), (20, 4, "bipartite"), (20, 8, "disjoint"), (22, 2, "piop"), (22, 4, "disjoint"), (9, 3, "piop"), (5, 2, "disjoint"), (3, 2, "piop")]
 
@@ -103,10 +104,14 @@ def test_multi_claim_prover_vs_oracle(oracle, n_vars, k, kind, group):
     m, comps = claims_for(kind, k)
     n = 1 << n_vars
     mls = [oracle.random_b128(0x6A0B0000 + 97 * n_vars + j, n) for j in range(m)]
-    sums = claim_sums(oracle, mls, comps)
     stream = oracle.random_scalars(0x6A0C + n_vars + k, n_vars + 1)
     batch_coeff, challenges = stream[0], stream[1:]
     assert batch_coeff not in (0, 1)
+    key = ("claims", n_vars, k, kind)
+    if key not in _ORACLE:  # (the oracle's side of a case is computed once for the group-on and group-off runs)
+        sums = claim_sums(oracle, mls, comps)
+        _ORACLE[key] = (sums, oracle_single(oracle, mls, n_vars, comps, sums, batch_coeff, challenges))
+    sums, (want_coeffs, want_final) = _ORACLE[key]
     with env(BN_GROUP=group):
         with binius_amd.Context(0, m * n + m * (n // 2) + 4096) as hal:
             alloc = hal.dev_alloc()
@@ -120,7 +125,6 @@ def test_multi_claim_prover_vs_oracle(oracle, n_vars, k, kind, group):
             again = (plan.round_coeffs(), plan.final_evals())
             for j in (0, m - 1):
                 assert np.array_equal(hal.copy_d2h(d[j].slice(0, min(n, 4096))), mls[j][: min(n, 4096)])
-    want_coeffs, want_final = oracle_single(oracle, mls, n_vars, comps, sums, batch_coeff, challenges)
     for r in range(n_vars):
         assert list(got[0][r]) == list(want_coeffs[r]), "round %d differs from the oracle" % r
     assert list(got[1]) == list(want_final)
@@ -172,8 +176,11 @@ def test_front_loaded_batch_vs_oracle(oracle, sizes, ks, group, spec):
             cnt = hal.group_counters()
             plan.run()
             assert (plan.round_proofs(), plan.final_evals()) == got
-    ref = [dict(n_vars=v, multilins=[x.copy() for x in mls], comps=comps, sums=sums) for v, mls, comps, sums in provers]
-    items, evals = piop_ref.batch_sumcheck_prove(ref, batch_coeffs, challenges, threads=_threads(), fast=max(sizes) >= 16)
+    key = ("batch", tuple(sizes), tuple(ks))
+    if key not in _ORACLE:
+        ref = [dict(n_vars=v, multilins=[x.copy() for x in mls], comps=comps, sums=sums) for v, mls, comps, sums in provers]
+        _ORACLE[key] = piop_ref.batch_sumcheck_prove(ref, batch_coeffs, challenges, threads=_threads(), fast=max(sizes) >= 16)
+    items, evals = _ORACLE[key]
     want_proofs = [list(p) + [0] * (2 - len(p)) for k, p in items if k == "round_proof"]
     assert got[0] == want_proofs
     assert got[1] == evals
@@ -228,7 +235,10 @@ def test_piop_prove_vs_oracle(oracle, n, log_inv_rate, log_batch, arities, group
             plan.run()
             got_commitment, got = bytes(plan.commitment), plan.transcript()
             cnt = hal.group_counters()
-    commitment, items, evals, terminate = piop_ref.piop_prove(committed, transparents, claims, p, batch_coeffs, challenges, threads=_threads(), fast=n >= 16)
+    key = ("piop", n, log_inv_rate, log_batch, tuple(arities))
+    if key not in _ORACLE:
+        _ORACLE[key] = piop_ref.piop_prove(committed, transparents, claims, p, batch_coeffs, challenges, threads=_threads(), fast=n >= 16)
+    commitment, items, evals, terminate = _ORACLE[key]
     assert got_commitment == commitment
     assert [k for k, _ in got] == [k for k, _ in items]
     for idx, ((k, a), (_, b)) in enumerate(zip(got, items)):

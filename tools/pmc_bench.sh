@@ -12,7 +12,7 @@ rm -rf $OUT; mkdir -p $OUT
 for NV in "$@"; do
   for C in FETCH_SIZE WRITE_SIZE; do
     # (BN_ARM=0: under counter collection every dispatch is serialised; no kernel should sit waiting for the host)
-    BN_ARM=0 rocprofv3 --pmc $C --output-format csv -d $OUT/n${NV}_$C -- python $R/bench.py --n-vars $NV --steps 1 --warmup 1 --no-cpu-baseline --no-prof > $OUT/n${NV}_$C.log 2>&1
+    BN_ARM=0 rocprofv3 --pmc $C --output-format csv -d $OUT/n${NV}_$C -- python $R/bench.py --n-vars $NV --steps 1 --warmup 1 --no-cpu-baseline --no-claim-groups --no-prof > $OUT/n${NV}_$C.log 2>&1
   done
 done
 python3 - "$OUT" "$BUILD" "$@" <<'PY'
