@@ -505,25 +505,52 @@ int circuit_multipass_collect(bn_ctx *ctx, const bn_expr *e, const void *const *
 // as many launches of the group kernel as 32 jobs of two products each take (one, for every request seen so far)
 int circuit_ip_run(bn_ctx *ctx, const ip_collector &col, uint64_t n, const void *ones, f128 *values)
 {
+	(void)ones;
 	for (const auto &c : col.consts) values[c.first] ^= c.second;
+	// At traffic-bound sizes the sum of a LONE row is a streaming XOR (kernels_stream.hip k_xor_sum: 16 B per element at the copy
+	// rate); as a job of the group kernel it would run at the Gram products' rate for nothing (measured: a·b·c + a at n = 24
+	// 1.30 -> 1.41 ms with every final sum in the group launch).  Their results wait in accumulator slots 32 .. and come back
+	// through the mailbox in one publish.
+	std::vector<ip_job> jobs;
+	std::vector<ip_job> lone;
+	for (const auto &q : col.jobs) {
+		if (!q.b && n >= ((uint64_t)1 << 20) && lone.size() < 32)
+			lone.push_back(q);
+		else
+			jobs.push_back(q);
+	}
+	if (!lone.empty()) {
+		if (!ctx->s_clean) {
+			BN_HIP(hipMemsetAsync(ctx->d_result, 0, 64 * sizeof(f128), ctx->stream));
+			ctx->s_clean = true;
+		}
+		for (size_t i = 0; i < lone.size(); i++) BN_HIP(bn::launch_xor_sum(ctx->stream, ctx->n_cu, lone[i].a, n, ctx->d_result + 32 + i));
+		std::vector<f128> got(lone.size());
+		ctx->mirror.valid = false;
+		int rc = publish_vals(ctx, ctx->d_result + 32, 1, (uint32_t)lone.size(), 0, 1, got.data());
+		if (rc) return rc;
+		BN_HIP(hipMemsetAsync(ctx->d_result + 32, 0, lone.size() * sizeof(f128), ctx->stream));
+		for (size_t i = 0; i < lone.size(); i++)
+			values[lone[i].out] ^= (lone[i].coeff == bn::f128_one()) ? got[i] : bn::mul_host(lone[i].coeff, got[i]);
+	}
 	size_t at = 0;
-	while (at < col.jobs.size()) {
+	while (at < jobs.size()) {
 		bn::group_job gj[bn::kGroupMaxJobs];
 		uint32_t nj = 0, n_ip = 0;
 		const size_t first = at;
-		while (at < col.jobs.size() && nj < (uint32_t)bn::kGroupMaxJobs) {
+		while (at < jobs.size() && nj < (uint32_t)bn::kGroupMaxJobs) {
 			bn::group_job &g = gj[nj];
 			g = bn::group_job{};
 			g.kind = 2;
 			g.n = n;
 			g.slot = 2 * nj;
-			g.x0[0] = col.jobs[at].a;
-			g.x0[1] = col.jobs[at].b ? col.jobs[at].b : ones;
+			g.x0[0] = jobs[at].a;
+			g.x0[1] = jobs[at].b; // (null: the kernel stages the all-ones row itself)
 			at++;
 			n_ip++;
-			if (at < col.jobs.size()) {
-				g.x1[0] = col.jobs[at].a;
-				g.x1[1] = col.jobs[at].b ? col.jobs[at].b : ones;
+			if (at < jobs.size()) {
+				g.x1[0] = jobs[at].a;
+				g.x1[1] = jobs[at].b;
 				at++;
 				n_ip++;
 			}
@@ -553,7 +580,7 @@ int circuit_ip_run(bn_ctx *ctx, const ip_collector &col, uint64_t n, const void 
 			f128 v;
 			v.lo = __atomic_load_n(&ctx->h_mail[i].lo, __ATOMIC_RELAXED);
 			v.hi = __atomic_load_n(&ctx->h_mail[i].hi, __ATOMIC_RELAXED);
-			const ip_job &q = col.jobs[first + i];
+			const ip_job &q = jobs[first + i];
 			values[q.out] ^= (q.coeff == bn::f128_one()) ? v : bn::mul_host(q.coeff, v);
 		}
 	}

@@ -166,7 +166,7 @@ bool parse(const bn_memmap *maps, uint32_t n_maps, const bn_kop *ops, uint32_t n
 	for (uint32_t i = 0; i < rq.m; i++)
 		for (uint32_t j = 0; j < i; j++)
 			if (rq.lo[i] == rq.lo[j] || rq.hi[i] == rq.hi[j]) return false;
-	return rq.k > 0 && rq.k <= 16;
+	return rq.k > 0 && rq.k <= (uint32_t)bn::kGroupMaxJobs; // (a launch carries at most that many jobs: 64 accumulator slots)
 }
 
 void answer(const request &rq, const f128 *raw, const uint32_t *ret_values, uint32_t n_ret, bn_f128 *h_out)

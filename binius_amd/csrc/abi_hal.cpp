@@ -153,9 +153,9 @@ int bn_hal_round_evals(bn_ctx *ctx, uint32_t order, uint32_t n_vars, const void 
 	// serves every point that shares a composition (all points but infinity); from 2^18 rows on the passes are traffic-bound, the
 	// copies that would put the X = 0 / 1 halves beside the other rows cost more than the launches they save, and every point runs
 	// its own passes.
-	// (measured, a·b·c + a at X = 1, infinity, z: n = 20 -- rows of 8 MiB -- is traffic-bound already: 0.140 ms with the copies, the
-	// three rows of X = 1 being 72 MB of the 370 MB the request moves)
-	const bool batch_points = half <= ((uint64_t)1 << 17);
+	// (measured, a·b·c + a at X = 1, infinity, z at n = 20 -- rows of 8 MiB --: 0.140 ms with the points side by side, 0.187 ms with
+	// a product pass per point; at n = 24 the copies of the X = 1 rows cost more than the launches)
+	const bool batch_points = half <= ((uint64_t)1 << 19);
 	size_t max_temp_elems = 0; // temporaries of the largest plan, in elements
 	for (uint32_t e = 0; e < n_evs && general_ok; e++)
 		for (const bn_expr *c : {(const bn_expr *)evs[e].composition, (const bn_expr *)evs[e].composition_at_infinity}) {
@@ -392,8 +392,30 @@ int bn_hal_round_evals(bn_ctx *ctx, uint32_t order, uint32_t n_vars, const void 
 			int rc = const_tables(); // (the all-ones row: the sum of a lone row is its inner product with it)
 			if (rc) return rc;
 		}
-		// the element-wise passes of every composition (once for all the points that share it when the rows lie side by side), the
-		// final sums collected; then ALL sums of the request in one launch
+		if (!batch_points) {
+			// traffic-bound sizes: every point runs its own passes and product-sum kernels straight into its pair of accumulator
+			// slots, nothing waits for anything, ONE publish at the end (collecting the final sums for a group launch was measured
+			// here too: the temporaries then force a launch + wait per composition, 1.30 -> 1.41 - 1.49 ms at n = 24)
+			uint32_t idx = 0;
+			for (uint32_t e = 0; e < n_evs; e++)
+				for (uint32_t p = evs[e].eval_point_start; p < evs[e].eval_point_end; p++, idx++) {
+					const bn_expr *c = p == 2 ? evs[e].composition_at_infinity : evs[e].composition;
+					int rc = circuit_multipass_sum(ctx, c, row[p].data(), half, evs[e].d_eq_ind, d_acc + 2 * idx, temps_off);
+					if (rc == kCircuitDeclined) return bn::fail(BN_ERR_CORE_LIB, "internal: a planned circuit was declined");
+					if (rc) return rc;
+				}
+			std::vector<f128> direct(total);
+			{
+				int rc = publish_vals(ctx, d_acc, 2, total, 1, 2, direct.data()); // value i = slot 2 i + slot 2 i + 1, through the mailbox
+				if (rc) return rc;
+			}
+			for (uint32_t i = 0; i < total; i++) h_out[i] = bn_f128{direct[i].lo, direct[i].hi};
+			BN_HIP(hipMemsetAsync(d_acc, 0, 64 * sizeof(f128), ctx->stream));
+			ctx->s_clean = true;
+			return BN_OK;
+		}
+		// launch-bound sizes: the element-wise passes of every composition once for all the points that share it (the rows lie side
+		// by side), the final sums collected; then ALL sums of the request in one launch
 		ip_collector col;
 		std::vector<f128> vals(total, bn::f128_zero());
 		size_t temp_cursor = 0; // elements of the temporaries' region handed out to compositions whose sums have not run yet

@@ -7,7 +7,8 @@
 //            S_inf = sum_{j < N/4} (a'[j] + a'[j + N/4]) (b'[j] + b'[j + N/4])
 //   kind 1   S_1 = sum_j a_1[j] b_1[j], S_inf = sum_j (a_0[j] + a_1[j]) (b_0[j] + b_1[j]) over the halves a_0 | a_1, b_0 | b_1 as they are
 //   kind 2   two plain inner products of rows: S[slot] = sum_j A[j] B[j], S[slot + 1] = sum_j C[j] D[j]  (the final sums of compiled
-//            circuits for all evaluation points of an old-HAL request in one launch, abi_hal.cpp; C = D = null: one product)
+//            circuits for all evaluation points of an old-HAL request in one launch, abi_hal.cpp; C = null: one product;
+//            B or D = null: the all-ones row, i.e. the plain sum of A or C)
 //
 // Why.  The reference's PCS prover issues k product claims over m multilinears per prover and runs several provers front-loaded
 // on one ComputeLayer: per batch round  execute(P_1) .. execute(P_p), one challenge, fold(P_1) .. fold(P_p)
@@ -106,6 +107,7 @@ struct group_wg {
 	f128 z;
 	uint64_t n;
 	uint32_t tbase, tstride, tlimit, t0;
+	uint32_t adj; // 1: the two fold groups take ADJACENT tiles (2 p, 2 p + 1) of the workgroup's p-th pair instead of tiles a stride apart
 };
 
 // The loops of one workgroup for a job of kind KIND (0: fold + evaluate, 1: evaluate).  A function template per kind -- and not
@@ -122,6 +124,9 @@ __device__ __forceinline__ void group_loops(const group_wg &w, uint32_t *T_dyn, 
 	const unsigned ftid = (threadIdx.x - 64 * kGramWaves) & 255; // the lane's point inside its tile (fold waves)
 	const uint64_t n = w.n;
 	const uint32_t tbase = w.tbase, tstride = w.tstride, tlimit = w.tlimit, t0 = w.t0;
+	// iteration variable `it` = t0, t0 + step, ... < limit; tile of fold group g in iteration it
+	const uint32_t adj = w.adj, step = adj ? tstride : 2 * tstride, limit = adj ? (tlimit + 1) >> 1 : tlimit;
+	auto tile_of = [&](uint32_t it, uint32_t g) { return adj ? 2 * it + g : it + g * tstride; };
 
 	// quadrant q = 2 * side + half.  KIND 0: x0[q] / x1[q] = the two elements the fold of (side, half) reads; KIND 1: x0[q] = the
 	// element of (side, half) itself.
@@ -150,18 +155,22 @@ __device__ __forceinline__ void group_loops(const group_wg &w, uint32_t *T_dyn, 
 		} else {
 			// rows A, B, C, D = x0[0], x0[1], x1[0], x1[1]; an absent second product reads the first one's rows (its sum is never looked at)
 			const uint64_t e1 = (uint64_t)(tbase + t) * kTP * 16;
-			const char *row = q < 2 ? w.X0[q] : (w.X1[q - 2] ? w.X1[q - 2] : w.X0[q - 2]);
-			dst0[q] = gq_load<NT>(reinterpret_cast<const uint4 *>(row + e1 + o));
+			const bool second = q >= 2 && w.X1[0] != nullptr; // (uniform)
+			const char *row = q < 2 ? w.X0[q] : (second ? w.X1[q - 2] : w.X0[q - 2]);
+			if (row) // (uniform) a null second factor is the all-ones row: the sum of the first factor, with nothing loaded for it
+				dst0[q] = gq_load<NT>(reinterpret_cast<const uint4 *>(row + e1 + o));
+			else
+				dst0[q] = uint4{1, 0, 0, 0};
 		}
 	};
 	auto load1 = [&](uint32_t t, int q) { load_into(x0, t, q); };
-	const uint32_t tm0 = t0 + grp * tstride; // this fold group's first tile
-	if (folds && tm0 < tlimit) {
+	const uint32_t tm0 = tile_of(t0, grp); // this fold group's first tile
+	if (folds && t0 < limit && tm0 < tlimit) {
 #pragma unroll
 		for (int q = 0; q < 4; q++)
 			load1(tm0, q);
 		if constexpr (KIND != 0) {
-			const uint32_t tm1 = tm0 + 2 * tstride < tlimit ? tm0 + 2 * tstride : tm0;
+			const uint32_t tm1 = (t0 + step < limit && tile_of(t0 + step, grp) < tlimit) ? tile_of(t0 + step, grp) : tm0;
 #pragma unroll
 			for (int q = 0; q < 4; q++)
 				load_into(xb, tm1, q);
@@ -181,11 +190,12 @@ __device__ __forceinline__ void group_loops(const group_wg &w, uint32_t *T_dyn, 
 		// one pair of tiles: `cur` holds this group's tile, loaded one (KIND 0) or two (KIND 1) iterations ago, and is refilled for
 		// the iteration that will use it next
 		auto pair_step = [&](uint32_t t, uint4 *cur) {
-			const uint32_t tm = t + grp * tstride;
+			const uint32_t tm = tile_of(t, grp);
 			if (tm < tlimit) { // (uniform; false only for group 1 on an odd last pair)
 				// the last iteration(s) re-request their own tile (cache hits) instead of branching around the loads
-				constexpr uint32_t kAhead = KIND != 0 ? 4 : 2;
-				const uint32_t tn = tm + kAhead * tstride < tlimit ? tm + kAhead * tstride : tm;
+				constexpr uint32_t kAhead = KIND != 0 ? 2 : 1; // iterations ahead
+				const uint32_t ta = t + kAhead * step;
+				const uint32_t tn = (ta < limit && tile_of(ta, grp) < tlimit) ? tile_of(ta, grp) : tm;
 				vo = lane_off();
 				const bool ok = in_range(tm);
 				uint4 f[4];
@@ -232,14 +242,14 @@ __device__ __forceinline__ void group_loops(const group_wg &w, uint32_t *T_dyn, 
 			Tn = T_dyn + (buf * kFoldGroups + grp) * kTile4W;
 		};
 		if constexpr (KIND == 0) {
-			for (uint32_t t = t0; t < tlimit; t += 2 * tstride) pair_step(t, x0);
+			for (uint32_t t = t0; t < limit; t += step) pair_step(t, x0);
 		} else { // (KIND 1, 2: two tiles in flight)
-			for (uint32_t t = t0; t < tlimit;) {
+			for (uint32_t t = t0; t < limit;) {
 				pair_step(t, x0);
-				t += 2 * tstride;
-				if (t >= tlimit) break;
+				t += step;
+				if (t >= limit) break;
 				pair_step(t, xb);
-				t += 2 * tstride;
+				t += step;
 			}
 		}
 		__builtin_amdgcn_s_setprio(0);
@@ -248,11 +258,11 @@ __device__ __forceinline__ void group_loops(const group_wg &w, uint32_t *T_dyn, 
 		v16f acc[kAccTiles];
 		acc4_zero(acc);
 		unsigned buf = 0;
-		for (uint32_t t = t0; t < tlimit; t += 2 * tstride) {
+		for (uint32_t t = t0; t < limit; t += step) {
 			__syncthreads();
 			const uint32_t *Tp = T_dyn + buf * kFoldGroups * kTile4W;
 			gram4_tile(Tp, gr, acc);
-			if (t + tstride < tlimit) gram4_tile(Tp + kTile4W, gr, acc);
+			if (tile_of(t, 1) < tlimit) gram4_tile(Tp + kTile4W, gr, acc);
 			buf ^= 1;
 		}
 		parity4(acc, gr, wave, lane, Gc);
@@ -298,6 +308,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_group_fp4(group_kargs ga)
 		w.t0 = b >> 3;
 		w.tlimit = w.tbase >= n_tiles ? 0 : (n_tiles - w.tbase < chunk ? n_tiles - w.tbase : chunk);
 	}
+	w.adj = (ga.prio >> 2) & 1;
 	if (jb->kind == 0) // (uniform)
 		group_loops<0, FULL, NT>(w, T_dyn, tab, Gc, ga.prio);
 	else if (jb->kind == 1)
@@ -448,7 +459,11 @@ hipError_t launch_group(hipStream_t s, int n_cu, const group_job *jobs_in, uint3
 	ga.seq = seq;
 	ga.n_jobs = n_jobs;
 	ga.n_slots = n_slots;
-	ga.prio = prio;
+	static const uint32_t adj_tiles = [] {
+		const char *e = settled_knob("BN_GROUP_ADJ"); // (round-5 A/B, profiles/DEAD_ENDS.md: adjacent tiles per pair of fold groups -- no difference)
+		return e ? (uint32_t)(atoi(e) != 0) : 0u;
+	}();
+	ga.prio = prio | (adj_tiles << 2);
 	static const int nt_min_log2 = [] {
 		const char *e = bn::settled_knob("BN_FE_NT_MIN_LOG2");
 		return e ? atoi(e) : 25;

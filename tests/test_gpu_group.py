@@ -291,3 +291,44 @@ def test_hosted_sessions_any_threshold(oracle, ht_log2):
             arm = hal.arm_counters()
         assert arm["ht_max"] == 0, "hosted sessions never started although the host tail is available"
     assert dumps[1][3]["hosted_started"] == 0
+
+
+@pytest.mark.parametrize("group", [1, 0])
+@pytest.mark.parametrize("n_varss,n_transparents,log_inv_rate", __import__("piop_verify").REFERENCE_SUITE)
+def test_reference_piop_suite(oracle, n_varss, n_transparents, log_inv_rate, group):
+    """Port of the reference's PIOP tests (crates/core/tests/piop.rs:10-112 -> compute_test_utils/src/piop.rs:101
+    commit_prove_verify): commit, prove through the backend (bnh_piop_prove: the C++ mirror of piop::prove over the C ABI), then
+    VERIFY -- piop::verify's equations on the device's own transcript (tests/piop_verify.py) -- for one polynomial, no opening
+    claims at all (provers without a composition), one size, an extreme rate (log_inv_rate 8), the small and the standard mix;
+    FRI parameters chosen as make_commit_params_with_optimal_arity chooses them.  And the transcript equals the oracle's."""
+    import binius_amd
+    from binius_amd._host import FRIParams, PiopPlan
+    from oracle import piop_ref
+    from piop_verify import make_instance, optimal_params, verify_transcript
+
+    meta = piop_ref.CommitMeta.with_vars(n_varss)
+    op = optimal_params(meta.total_vars, log_inv_rate)
+    p = FRIParams(op.log_dim, op.log_inv_rate, op.log_batch_size, op.fold_arities, n_test_queries=op.n_test_queries)
+    committed, transparents, claims = make_instance(oracle, n_varss, n_transparents, 0x51ED + sum(n_varss))
+    t_sizes = [t.shape[0].bit_length() - 1 for t in transparents]
+    n_sizes = len(set(n_varss))
+    stream = oracle.random_scalars(0x7A0 + len(n_varss), n_sizes + meta.total_vars)
+    batch_coeffs, challenges = stream[:n_sizes], stream[n_sizes:]
+    message = piop_ref.merge_multilins(committed, meta.total_vars)
+    code_elems = 1 << (meta.total_vars + log_inv_rate)
+    ml_elems = sum(x.shape[0] for x in committed) + sum(x.shape[0] for x in transparents)
+    with env(BN_GROUP=group):
+        with binius_amd.Context(0, message.shape[0] + 4 * code_elems + 2 * ml_elems + (1 << 16)) as hal:
+            alloc = hal.dev_alloc()
+            d_c = [(v, upload(hal, alloc, x)) for v, x in zip(n_varss, committed)]
+            d_t = [(v, upload(hal, alloc, x)) for v, x in zip(t_sizes, transparents)]
+            d_msg = upload(hal, alloc, message)
+            scratch = alloc.alloc(4 * code_elems + ml_elems + (1 << 14))
+            plan = PiopPlan(hal, d_c, d_t, claims, p, d_msg, scratch, batch_coeffs, challenges)
+            plan.run()
+            got_commitment, got = bytes(plan.commitment), plan.transcript()
+            for (v, d), x in zip(d_c + d_t, committed + transparents):
+                assert np.array_equal(hal.copy_d2h(d), x), "an input multilinear was modified"
+    verify_transcript(oracle, piop_ref, n_varss, committed, transparents, claims, op, batch_coeffs, challenges, got)
+    commitment, items, evals, terminate = piop_ref.piop_prove(committed, transparents, claims, op, batch_coeffs, challenges)
+    assert got_commitment == commitment and got == items
