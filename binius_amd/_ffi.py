@@ -529,10 +529,10 @@ class Context:
         prover, several provers front-loaded on one layer -- was run: launches of the group kernel, claims evaluated fused
         with their folds / on pre-folded arrays, plain fold launches of a round, claims of other provers carried along,
         execute() calls answered from sums computed ahead, execute() calls on this path, deferred folds forced out."""
-        c = (C.c_uint64 * 12)()
+        c = (C.c_uint64 * 14)()
         _check(lib().bn_group_counters(self._h, c))
         keys = ("launches", "jobs_fused", "jobs_eval", "prefolds", "spec_jobs", "spec_hits", "evals", "flushed_folds", "hosted_started", "hosted_evals",
-                "hosted_folds", "hosted_writebacks")
+                "hosted_folds", "hosted_writebacks", "jobs_fold", "chains")
         return {k: int(c[i]) for i, k in enumerate(keys)}
 
     # ---- ComputeLayer

@@ -599,6 +599,7 @@ int bn_ctx_create(int device, uint64_t arena_elems, bn_ctx **out)
 	if (const char *a = getenv("BN_CIRCUIT_MULTIPASS")) ctx->circuit_multipass = atoi(a) != 0;
 	if (const char *a = getenv("BN_GROUP")) ctx->grp.enabled = atoi(a) != 0;
 	if (const char *a = getenv("BN_GROUP_SPEC")) ctx->grp.speculate = atoi(a) != 0;
+	if (const char *a = getenv("BN_GROUP_CHAINS")) ctx->grp.chains = atoi(a) != 0;
 	BN_HIP(hipMalloc((void **)&ctx->d_flag, sizeof(unsigned)));
 	BN_HIP(hipMemset(ctx->d_flag, 0, sizeof(unsigned)));
 	BN_HIP(hipMalloc((void **)&ctx->d_s_evals, sizeof(uint64_t) * BN_NTT_MAX_DIM * BN_NTT_MAX_DIM));
@@ -1407,6 +1408,8 @@ int bn_group_counters(bn_ctx *ctx, uint64_t *counters)
 	counters[BN_GROUP_HOSTED_EVALS] = g.hosted_evals;
 	counters[BN_GROUP_HOSTED_FOLDS] = g.hosted_folds;
 	counters[BN_GROUP_HOSTED_WRITEBACKS] = g.hosted_writebacks;
+	counters[BN_GROUP_JOBS_FOLD] = g.jobs_fold;
+	counters[BN_GROUP_CHAINS] = g.chain_count;
 	return BN_OK;
 }
 

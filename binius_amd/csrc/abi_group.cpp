@@ -12,9 +12,9 @@
 //
 //   * a fold batch is deferred PER PROVER: any number of batches wait side by side as long as their arrays are disjoint
 //     (bn_ctx::group_state::folds);
-//   * a round evaluation of that shape is parsed into arrays (lo, hi) and claims (a, b); every claim whose two arrays are
-//     folded by a deferred batch and are used by no other claim becomes a fold + evaluate job (kind 0), every other claim an
-//     evaluate job (kind 1) on arrays that a plain fold launch in front of it has brought up to date;
+//   * a round evaluation of that shape is parsed into arrays (lo, hi) and claims (a, b); a matching of the claim graph becomes
+//     fold + evaluate jobs (kind 0: each folds its two arrays), the arrays left over fold-only jobs (kind 3), every other claim
+//     an evaluate job (kind 1) -- chained behind the jobs that fold what it reads, inside the same launch (plan_chained);
 //   * ONE launch (kernels_group.hip) carries the jobs of the calling prover AND of every other prover whose deferred fold
 //     is waiting and whose claims are known from its last evaluation (a session); the others' raw sums are kept and answer
 //     their execute() without a launch;
@@ -206,10 +206,121 @@ fold_ref find_input(const bn_ctx *ctx, const void *lo, const void *hi, uint64_t 
 }
 
 // the jobs of one prover's evaluation: arrays (lo, hi) of row_len points each, array i coming out of deferred fold ref[i]
-// (f < 0: it is up to date in memory); appends kind-0 / kind-1 jobs (slot = slot0 + 2 * claim) and marks the folds that must
-// run as plain launches first
-void plan(const bn_ctx *ctx, uint32_t m, uint32_t k, const uint8_t *pa, const uint8_t *pb, const void *const *lo, const void *const *hi, uint64_t row_len,
-          const fold_ref *ref, uint32_t slot0, std::vector<bn::group_job> &jobs, std::vector<char> &prefold /*[m]*/, uint64_t &n_fused)
+// (f < 0: it is up to date in memory); appends the jobs (slot = slot0 + 2 * claim).
+//
+//   * a claim whose two arrays both wait for their fold (one challenge) and are not yet folded by another job: fold + evaluate
+//     (kind 0) -- a matching of the claim graph, the claims over arrays of degree one first (a prover with disjoint claims: all);
+//   * the arrays still waiting after that: fold only (kind 3), two per job;
+//   * every other claim: evaluate (kind 1) -- and where it reads an array that a job of THIS launch folds, the jobs concerned form
+//     a CHAIN: the same workgroups run the folding jobs and then the evaluating ones on the same tiles, so that a workgroup only
+//     ever reads back what it has written itself (kernels_group.hip).  Everything else stays a job of its own.
+//
+// false (nothing appended): more than `room` jobs -- the caller falls back to plan_prefold.
+bool plan_chained(const bn_ctx *ctx, uint32_t m, uint32_t k, const uint8_t *pa, const uint8_t *pb, const void *const *lo, const void *const *hi, uint64_t row_len,
+                  const fold_ref *ref, uint32_t slot0, size_t room, std::vector<bn::group_job> &jobs, uint64_t &n_fused, uint64_t &n_fold_only, uint64_t &n_chains)
+{
+	const auto &folds = ctx->grp.folds;
+	uint32_t deg[kMaxArrays] = {};
+	for (uint32_t c = 0; c < k; c++) {
+		deg[pa[c]]++;
+		deg[pb[c]]++;
+	}
+	std::vector<char> matched(m, 0), fused_claim(k, 0);
+	auto fusable = [&](uint32_t c) {
+		const uint32_t a = pa[c], b = pb[c];
+		return a != b && !matched[a] && !matched[b] && ref[a].f >= 0 && ref[b].f >= 0 && folds[ref[a].f].z == folds[ref[b].f].z;
+	};
+	for (int pass = 0; pass < 2; pass++)
+		for (uint32_t c = 0; c < k; c++) {
+			if (fused_claim[c] || !fusable(c)) continue;
+			if (pass == 0 && (deg[pa[c]] != 1 || deg[pb[c]] != 1)) continue;
+			fused_claim[c] = 1;
+			matched[pa[c]] = matched[pb[c]] = 1;
+		}
+	// read_back[i]: array i is folded by this launch and read by an evaluate job of it
+	std::vector<char> read_back(m, 0);
+	for (uint32_t c = 0; c < k; c++)
+		if (!fused_claim[c])
+			for (uint32_t i : {(uint32_t)pa[c], (uint32_t)pb[c]})
+				if (ref[i].f >= 0) read_back[i] = 1;
+	std::vector<uint32_t> left[2]; // arrays to fold only: [1] = read back (chain), [0] = not
+	for (uint32_t i = 0; i < m; i++)
+		if (ref[i].f >= 0 && !matched[i]) left[read_back[i] ? 1 : 0].push_back(i);
+	auto fold_only_jobs = [&](const std::vector<uint32_t> &v) {
+		// (two arrays per job where they share the challenge)
+		size_t n = 0;
+		for (size_t q = 0; q < v.size();) {
+			const bool two = q + 1 < v.size() && folds[ref[v[q]].f].z == folds[ref[v[q + 1]].f].z;
+			q += two ? 2 : 1;
+			n++;
+		}
+		return n;
+	};
+	if ((size_t)k + fold_only_jobs(left[0]) + fold_only_jobs(left[1]) > room) return false;
+	auto fold_side = [&](bn::group_job &j, int sd, uint32_t i) {
+		const auto &f = folds[ref[i].f];
+		j.x0[sd] = f.src0[ref[i].j];
+		j.x1[sd] = f.x1[ref[i].j];
+		j.out[sd] = f.x0[ref[i].j];
+		j.z = f.z;
+	};
+	std::vector<bn::group_job> chain, alone;
+	for (uint32_t c = 0; c < k; c++) {
+		if (!fused_claim[c]) continue;
+		bn::group_job j{};
+		j.kind = 0;
+		j.n = row_len;
+		j.slot = slot0 + 2 * c;
+		fold_side(j, 0, pa[c]);
+		fold_side(j, 1, pb[c]);
+		(read_back[pa[c]] || read_back[pb[c]] ? chain : alone).push_back(j);
+		n_fused++;
+	}
+	for (int rb = 0; rb < 2; rb++)
+		for (size_t q = 0; q < left[rb].size();) {
+			bn::group_job j{};
+			j.kind = 3;
+			j.n = row_len;
+			fold_side(j, 0, left[rb][q]);
+			const bool two = q + 1 < left[rb].size() && folds[ref[left[rb][q]].f].z == folds[ref[left[rb][q + 1]].f].z;
+			if (two) fold_side(j, 1, left[rb][q + 1]);
+			q += two ? 2 : 1;
+			(rb ? chain : alone).push_back(j);
+			n_fold_only++;
+		}
+	bool first_reader = true;
+	for (uint32_t c = 0; c < k; c++) {
+		if (fused_claim[c]) continue;
+		const uint32_t a = pa[c], b = pb[c];
+		bn::group_job j{};
+		j.kind = 1;
+		j.n = row_len;
+		j.slot = slot0 + 2 * c;
+		j.x0[0] = lo[a];
+		j.x1[0] = hi[a];
+		j.x0[1] = lo[b];
+		j.x1[1] = hi[b];
+		if (ref[a].f >= 0 || ref[b].f >= 0) {
+			j.acquire = first_reader ? 1 : 0;
+			first_reader = false;
+			chain.push_back(j);
+		} else {
+			alone.push_back(j);
+		}
+	}
+	if (!chain.empty()) {
+		chain[0].chain = (uint32_t)chain.size() - 1;
+		jobs.insert(jobs.end(), chain.begin(), chain.end());
+		n_chains++;
+	}
+	jobs.insert(jobs.end(), alone.begin(), alone.end());
+	return true;
+}
+
+// the fallback (more jobs than a launch carries): only claims over arrays of degree one are fused; every other waiting array is
+// folded by a plain launch in front (prefold)
+void plan_prefold(const bn_ctx *ctx, uint32_t m, uint32_t k, const uint8_t *pa, const uint8_t *pb, const void *const *lo, const void *const *hi, uint64_t row_len,
+                  const fold_ref *ref, uint32_t slot0, std::vector<bn::group_job> &jobs, std::vector<char> &prefold /*[m]*/, uint64_t &n_fused)
 {
 	uint32_t deg[kMaxArrays] = {};
 	for (uint32_t c = 0; c < k; c++) {
@@ -807,12 +918,7 @@ int group_eval(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const bn_kop
 		}
 	}
 	bn_ctx::group_session *self = session_for(ctx, rq, ref);
-	std::vector<bn::group_job> jobs;
-	std::vector<std::vector<char>> prefold; // per participating prover, per array
-	uint64_t n_fused = 0;
-	prefold.emplace_back(rq.m, 0);
-	plan(ctx, rq.m, rq.k, rq.pa, rq.pb, rq.lo, rq.hi, rq.row_len, ref, 0, jobs, prefold.back(), n_fused);
-	// consumed[f][j]: array j of deferred fold f is brought up to date by this launch (fused or plain)
+	// consumed[f][j]: array j of deferred fold f is brought up to date by this launch (a job of it, or a plain launch in front)
 	std::vector<std::vector<char>> consumed(g.folds.size());
 	for (size_t f = 0; f < g.folds.size(); f++) consumed[f].assign(g.folds[f].count, 0);
 	for (uint32_t i = 0; i < rq.m; i++)
@@ -826,11 +932,11 @@ int group_eval(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const bn_kop
 		uint64_t row_len;
 	};
 	std::vector<rider> riders;
-	uint32_t n_slots = 2 * rq.k;
+	uint32_t n_slots = 2 * rq.k, n_claims = rq.k;
 	if (g.speculate) {
 		for (auto &s : g.sessions) {
 			if (&s == self || s.hosted || s.k == 0 || s.row_len < 2) continue;
-			if (jobs.size() + s.k > (size_t)bn::kGroupMaxJobs || n_slots + 2 * s.k > 64) continue;
+			if (n_claims + s.k > (uint32_t)bn::kGroupMaxJobs || n_slots + 2 * s.k > 64) continue;
 			rider r{};
 			r.s = &s;
 			r.row_len = s.row_len / 2;
@@ -846,18 +952,70 @@ int group_eval(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const bn_kop
 			if (!ok) continue;
 			r.slot0 = n_slots;
 			n_slots += 2 * s.k;
-			prefold.emplace_back(s.m, 0);
-			uint64_t nf = 0;
-			plan(ctx, s.m, s.k, s.pa, s.pb, r.lo, r.hi, r.row_len, r.ref, r.slot0, jobs, prefold.back(), nf);
-			n_fused += nf;
-			g.spec_jobs += s.k;
+			n_claims += s.k;
 			for (uint32_t i = 0; i < s.m; i++) consumed[r.ref[i].f][r.ref[i].j] = 1;
 			riders.push_back(r);
 		}
 	}
-	if (jobs.size() > (size_t)bn::kGroupMaxJobs || (int)jobs.size() > ctx->n_cu) return BN_OK; // (k <= 16 per prover: cannot happen; the eager kernels answer)
-	// ---- plain folds first: every consumed array that no job folds (shared arrays, arrays in no claim)
-	{
+	// arrays of the participating provers' batches that appear in no request (an unconstrained column) are folded with them, so
+	// that the batch can be retired
+	std::vector<std::pair<int, int>> loose;
+	for (size_t f = 0; f < g.folds.size(); f++) {
+		bool any = false;
+		for (uint32_t j = 0; j < g.folds[f].count; j++) any = any || consumed[f][j];
+		if (!any) continue;
+		for (uint32_t j = 0; j < g.folds[f].count; j++)
+			if (!consumed[f][j]) {
+				consumed[f][j] = 1;
+				loose.push_back({(int)f, (int)j});
+			}
+	}
+	// ---- the jobs.  Chained planning: every waiting fold is a job of the launch; where it does not fit (more than
+	// kGroupMaxJobs jobs), the fallback: plain fold launches in front for everything a fused job does not fold
+	std::vector<bn::group_job> jobs;
+	uint64_t n_fused = 0, n_fold_only = 0, n_chains = 0;
+	std::vector<std::vector<char>> ran(g.folds.size()); // (fallback only) folded by a plain launch that has been enqueued
+	for (size_t f = 0; f < g.folds.size(); f++) ran[f].assign(g.folds[f].count, 0);
+	auto plan_all_chained = [&]() {
+		const size_t cap = (size_t)bn::kGroupMaxJobs;
+		if (!g.chains) return false;
+		if (!plan_chained(ctx, rq.m, rq.k, rq.pa, rq.pb, rq.lo, rq.hi, rq.row_len, ref, 0, cap, jobs, n_fused, n_fold_only, n_chains)) return false;
+		for (const auto &r : riders)
+			if (jobs.size() > cap ||
+			    !plan_chained(ctx, r.s->m, r.s->k, r.s->pa, r.s->pb, r.lo, r.hi, r.row_len, r.ref, r.slot0, cap - jobs.size(), jobs, n_fused, n_fold_only, n_chains))
+				return false;
+		for (size_t q = 0; q < loose.size();) {
+			const auto &f = g.folds[loose[q].first];
+			if (f.n < 2 || (f.n & 1)) return false;
+			bn::group_job j{};
+			j.kind = 3;
+			j.n = f.n / 2;
+			j.z = f.z;
+			const bool two = q + 1 < loose.size() && loose[q + 1].first == loose[q].first;
+			for (int sd = 0; sd < (two ? 2 : 1); sd++) {
+				const int jj = loose[q + sd].second;
+				j.x0[sd] = f.src0[jj];
+				j.x1[sd] = f.x1[jj];
+				j.out[sd] = f.x0[jj];
+			}
+			jobs.push_back(j);
+			n_fold_only++;
+			q += two ? 2 : 1;
+		}
+		return jobs.size() <= cap;
+	};
+	const bool chained = plan_all_chained();
+	if (!chained) {
+		jobs.clear();
+		n_fused = n_fold_only = n_chains = 0;
+		std::vector<std::vector<char>> prefold; // per participating prover, per array
+		prefold.emplace_back(rq.m, 0);
+		plan_prefold(ctx, rq.m, rq.k, rq.pa, rq.pb, rq.lo, rq.hi, rq.row_len, ref, 0, jobs, prefold.back(), n_fused);
+		for (const auto &r : riders) {
+			prefold.emplace_back(r.s->m, 0);
+			plan_prefold(ctx, r.s->m, r.s->k, r.s->pa, r.s->pb, r.lo, r.hi, r.row_len, r.ref, r.slot0, jobs, prefold.back(), n_fused);
+		}
+		if (jobs.size() > (size_t)bn::kGroupMaxJobs || (int)jobs.size() > ctx->n_cu) return BN_OK; // (cannot happen: claims <= kGroupMaxJobs; the eager kernels answer)
 		std::vector<std::vector<char>> plain(g.folds.size());
 		for (size_t f = 0; f < g.folds.size(); f++) plain[f].assign(g.folds[f].count, 0);
 		for (uint32_t i = 0; i < rq.m; i++)
@@ -865,18 +1023,7 @@ int group_eval(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const bn_kop
 		for (size_t r = 0; r < riders.size(); r++)
 			for (uint32_t i = 0; i < riders[r].s->m; i++)
 				if (prefold[r + 1][i]) plain[riders[r].ref[i].f][riders[r].ref[i].j] = 1;
-		// arrays of the participating provers' batches that appear in no request (an unconstrained column) stay deferred unless the
-		// whole batch is consumed otherwise -- they are folded with it so that the batch can be retired
-		for (size_t f = 0; f < g.folds.size(); f++) {
-			bool any = false;
-			for (uint32_t j = 0; j < g.folds[f].count; j++) any = any || consumed[f][j];
-			if (!any) continue;
-			for (uint32_t j = 0; j < g.folds[f].count; j++)
-				if (!consumed[f][j]) {
-					consumed[f][j] = 1;
-					plain[f][j] = 1;
-				}
-		}
+		for (const auto &l : loose) plain[l.first][l.second] = 1;
 		for (size_t f = 0; f < g.folds.size(); f++) {
 			bn_ctx::group_fold part;
 			part.n = g.folds[f].n;
@@ -892,10 +1039,15 @@ int group_eval(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const bn_kop
 				rc = launch_fold(ctx, part);
 				ctx->grp.flushed_folds--; // (not a flush: part of the round)
 				if (rc) return rc;
+				for (uint32_t j = 0; j < g.folds[f].count; j++)
+					if (plain[f][j]) ran[f][j] = 1;
 				g.prefolds++;
 			}
 		}
+	} else if ((int)jobs.size() > ctx->n_cu) {
+		return BN_OK; // (fewer compute units than jobs: the eager kernels answer; nothing has been enqueued)
 	}
+	for (const auto &r : riders) g.spec_jobs += r.s->k;
 	// ---- the launch
 	if (!ctx->s_clean) {
 		BN_HIP(hipMemsetAsync(ctx->d_result, 0, 64 * sizeof(f128), ctx->stream));
@@ -904,30 +1056,24 @@ int group_eval(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const bn_kop
 	ctx->mirror.valid = false; // (the launch publishes into the mailbox slots a mirrored tiny fold lives in)
 	const uint64_t seq = ++ctx->mail_seq;
 	{
-		prof_scope ps(ctx, n_fused ? BN_PROF_FOLD_EVAL_MFMA : BN_PROF_ROUND_EVAL_MFMA); // (a launch without a fold: round 0, shared arrays)
+		prof_scope ps(ctx, (n_fused || n_fold_only) ? BN_PROF_FOLD_EVAL_MFMA : BN_PROF_ROUND_EVAL_MFMA); // (a launch without a fold: round 0)
 		const hipError_t e = bn::launch_group(ctx->stream, ctx->n_cu, jobs.data(), (uint32_t)jobs.size(), n_slots, ctx->d_result, ctx->d_mail, ctx->d_ticket, seq);
 		if (e != hipSuccess) {
-			// nothing was enqueued by the failed launch; the plain folds above are part of what the caller asked for anyway.  The
-			// folds the jobs would have performed are still deferred: retire only what did run.
+			// nothing was enqueued by the failed launch: the folds its jobs would have performed are still deferred; those a plain
+			// launch in front has performed (the fallback) are retired.  Then everything runs eagerly.
 			--ctx->mail_seq;
 			(void)hipGetLastError();
 			for (size_t f = g.folds.size(); f-- > 0;) {
-				// (arrays folded by the plain launches above must not be folded again)
 				bn_ctx::group_fold rest;
 				rest.n = g.folds[f].n;
 				rest.z = g.folds[f].z;
-				// which arrays of this batch ran?  exactly the `plain` ones -- recomputed: consumed and not fused
-				for (uint32_t j = 0; j < g.folds[f].count; j++) {
-					bool fused = false;
-					for (const auto &jb : jobs)
-						if (jb.kind == 0 && (jb.out[0] == g.folds[f].x0[j] || jb.out[1] == g.folds[f].x0[j])) fused = true;
-					if (!consumed[f][j] || fused) {
+				for (uint32_t j = 0; j < g.folds[f].count; j++)
+					if (!ran[f][j]) {
 						rest.x0[rest.count] = g.folds[f].x0[j];
 						rest.x1[rest.count] = g.folds[f].x1[j];
 						rest.src0[rest.count] = g.folds[f].src0[j];
 						rest.count++;
 					}
-				}
 				if (rest.count)
 					g.folds[f] = rest;
 				else
@@ -941,7 +1087,9 @@ int group_eval(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const bn_kop
 	}
 	g.launches++;
 	g.jobs_fused += n_fused;
-	g.jobs_eval += jobs.size() - n_fused;
+	g.jobs_fold += n_fold_only;
+	g.chain_count += n_chains;
+	g.jobs_eval += jobs.size() - n_fused - n_fold_only;
 	// retire the consumed arrays
 	for (size_t f = g.folds.size(); f-- > 0;) {
 		bn_ctx::group_fold rest;

@@ -256,11 +256,12 @@ struct bn_ctx {
 	struct group_state {
 		bool enabled = true;   // BN_GROUP=0: every call takes the single-claim machinery / the eager kernels
 		bool speculate = true; // BN_GROUP_SPEC=0: a launch only carries the calling prover's claims
+		bool chains = true;    // BN_GROUP_CHAINS=0: shared arrays are folded by a plain launch in front of the group launch (round 5's first form)
 		bool on = false;       // a group fold or evaluation happened since the last full flush: single-claim requests join in
 		std::vector<group_fold> folds;
 		std::vector<group_session> sessions;
 		uint64_t stamp = 0;
-		uint64_t launches = 0, jobs_fused = 0, jobs_eval = 0, prefolds = 0, spec_jobs = 0, spec_hits = 0, evals = 0, flushed_folds = 0;
+		uint64_t launches = 0, jobs_fused = 0, jobs_eval = 0, prefolds = 0, spec_jobs = 0, spec_hits = 0, evals = 0, flushed_folds = 0, jobs_fold = 0, chain_count = 0;
 		uint64_t ht_max = 0;   // largest array (elements) a hosted session starts with (0: off; BN_GROUP_HT_MAX_LOG2)
 		void *h_stage = nullptr, *d_stage = nullptr; // pinned staging, 2 x kGroupTailMaxElems elements: hand-over | write-back
 		uint64_t hosted_started = 0, hosted_evals = 0, hosted_folds = 0, hosted_writebacks = 0;
@@ -450,9 +451,14 @@ struct group_job {
 	void *out[2];              // kind 0: where the folded arrays (2 n elements each) are written (may be x0)
 	f128 z;                    // kind 0: the fold's challenge
 	uint64_t n;                // evaluation points of the job
-	uint32_t kind;             // 0 = fold + evaluate, 1 = evaluate, 2 = two plain inner products: rows x0[0] . x0[1] -> S[slot], x1[0] . x1[1] -> S[slot + 1] (x1 null: one)
+	uint32_t kind;             // 0 = fold + evaluate, 1 = evaluate, 2 = two plain inner products: rows x0[0] . x0[1] -> S[slot], x1[0] . x1[1] -> S[slot + 1] (x1 null: one),
+	                           // 3 = fold only: arrays x0[sd] / x1[sd] -> out[sd] as kind 0, no sums (x0[1] null: one array)
 	uint32_t slot;             // the job's sums are XORed into S[slot] (at 1) and S[slot + 1] (at infinity)
-	uint32_t wg_begin, wg_count; // (filled in by the launcher)
+	uint32_t wg_begin, wg_count; // (filled in by the launcher; wg_count = 0: a follower of the chain in front of it)
+	uint32_t chain;            // the `chain` jobs that follow this one in the table are run by THIS job's workgroups, one after the other, each on
+	                           // the tiles the workgroup had in this job (all jobs of a chain: the same n)
+	uint32_t acquire;          // 1: the job reads what earlier jobs of its chain wrote (a workgroup reads back only its own tiles: its stores are
+	                           // awaited and its vector cache invalidated first)
 };
 // hosted provers (abi_group.cpp): hand-over of a prover's arrays to the host (with its deferred fold performed on the way) and the
 // write-back of the host's folded copies

@@ -9,6 +9,15 @@
 //   kind 2   two plain inner products of rows: S[slot] = sum_j A[j] B[j], S[slot + 1] = sum_j C[j] D[j]  (the final sums of compiled
 //            circuits for all evaluation points of an old-HAL request in one launch, abi_hal.cpp; C = null: one product;
 //            B or D = null: the all-ones row, i.e. the plain sum of A or C)
+//   kind 3   the fold of kind 0 for one or two arrays and nothing else (an array that several claims share is folded ONCE, by a
+//            kind-0 job of one of its claims or by a kind-3 job; the other claims over it are kind-1 jobs)
+//
+// Chains.  A kind-1 job may read what a kind-0 / kind-3 job of the SAME launch writes -- the folds are in place, so a workgroup
+// that evaluated such a claim while another one folded the array would read half-folded memory.  Jobs that depend on each other
+// therefore form a chain: ONE set of workgroups runs them one after the other, each workgroup on the same tiles in every job,
+// the folding jobs first.  A workgroup then only ever reads back what it wrote itself: it waits for its stores (vmcnt), meets
+// its own waves at a barrier and invalidates its vector cache (the `acquire` flag of the first reading job) -- no grid-wide
+// synchronisation, no second launch, and the shared arrays' folds cost no pass of their own.
 //
 // Why.  The reference's PCS prover issues k product claims over m multilinears per prover and runs several provers front-loaded
 // on one ComputeLayer: per batch round  execute(P_1) .. execute(P_p), one challenge, fold(P_1) .. fold(P_p)
@@ -23,7 +32,7 @@
 // prover whose execute() has not been called yet can be computed in the same launch (abi_group.cpp).
 //
 // Algorithmic bytes per job: kind 0 read 16 * 2 * N + write 8 * 2 * N = 48 N (24 * m * N summed over a prover's disjoint claims);
-// kind 1 read 16 * 2 * (N / 2) = 16 N.
+// kind 1 read 16 * 2 * (N / 2) = 16 N; kind 3 24 N per array.
 #include <hip/hip_runtime.h>
 
 #include <cstddef>
@@ -115,13 +124,19 @@ struct group_wg {
 // one body the compiler keeps the two arrays in scratch memory and every tile pays 128 bytes of scratch stores and loads per
 // lane (measured: the launch at half the rate of kernels_foldeval_fp4.hip).  Leaves the parity words of the Gram waves in Gc.
 template <int KIND, bool FULL, bool NT>
-__device__ __forceinline__ void group_loops(const group_wg &w, uint32_t *T_dyn, ctable_smem &tab, gram_parity &Gc, uint32_t prio)
+__device__ __forceinline__ void group_loops(const group_wg &w, uint32_t *T_dyn, ctable_smem &tab, gram_parity &Gc, uint32_t prio, bool build)
 {
-	const unsigned lane = threadIdx.x & 63;
-	const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	constexpr bool kFolds = KIND == 0 || KIND == 3; // the job folds its arrays (KIND 3: and nothing else -- no staging, no Gram work, no sums)
+	constexpr bool kTwoAhead = KIND == 1 || KIND == 2;
+	// (the thread index behind an opaque move: everything derived from it -- roles, lane offsets -- is recomputed per job of a chain
+	// instead of being hoisted out of the kernel's job loop and kept in registers across all four loop bodies)
+	unsigned tx = threadIdx.x;
+	asm volatile("" : "+v"(tx));
+	const unsigned lane = tx & 63;
+	const unsigned wave = __builtin_amdgcn_readfirstlane(tx >> 6);
 	const bool folds = wave >= kGramWaves;
 	const unsigned grp = folds ? (wave - kGramWaves) >> 2 : 0;   // fold group: which tile of the pair
-	const unsigned ftid = (threadIdx.x - 64 * kGramWaves) & 255; // the lane's point inside its tile (fold waves)
+	const unsigned ftid = (tx - 64 * kGramWaves) & 255; // the lane's point inside its tile (fold waves)
 	const uint64_t n = w.n;
 	const uint32_t tbase = w.tbase, tstride = w.tstride, tlimit = w.tlimit, t0 = w.t0;
 	// iteration variable `it` = t0, t0 + step, ... < limit; tile of fold group g in iteration it
@@ -130,7 +145,7 @@ __device__ __forceinline__ void group_loops(const group_wg &w, uint32_t *T_dyn, 
 
 	// quadrant q = 2 * side + half.  KIND 0: x0[q] / x1[q] = the two elements the fold of (side, half) reads; KIND 1: x0[q] = the
 	// element of (side, half) itself.
-	uint4 x0[4], x1[KIND == 0 ? 4 : 1];
+	uint4 x0[4], x1[kFolds ? 4 : 1];
 	const uint32_t voff = ftid * 16u;
 	auto lane_off = [&]() { // (kernels_foldeval_fp4.hip: keeps the lane offset out of a loop-invariant 64-bit vector base)
 		uint32_t v = voff;
@@ -142,10 +157,11 @@ __device__ __forceinline__ void group_loops(const group_wg &w, uint32_t *T_dyn, 
 	// KIND 1 keeps TWO tiles of loads in flight per fold group (x0: the tile after this one, xb: the one after that): with nothing to
 	// compute between a tile's loads and its staging, one tile in flight is 32 KiB per CU and the launch sits at the memory
 	// latency (2.1 TB/s measured at 2^25 points per claim); KIND 0 has 64 KiB of loads per CU in flight with one tile per group
-	uint4 xb[KIND != 0 ? 4 : 1];
+	uint4 xb[kTwoAhead ? 4 : 1];
 	auto load_into = [&](uint4 *dst0, uint32_t t, int q) {
 		const uint32_t o = in_range(t) ? vo : 0u; // (a lane past the end reads the tile's first element: in range, never used)
-		if constexpr (KIND == 0) {
+		if constexpr (kFolds) {
+			if (KIND == 3 && q >= 2 && w.X0[1] == nullptr) return; // (uniform) a fold-only job of ONE array
 			const uint64_t e = ((q & 1 ? n : 0) + (uint64_t)(tbase + t) * kTP) * 16; // (uniform)
 			dst0[q] = gq_load<NT>(reinterpret_cast<const uint4 *>(w.X0[q >> 1] + e + o));
 			x1[q] = gq_load<NT>(reinterpret_cast<const uint4 *>(w.X1[q >> 1] + e + o));
@@ -169,14 +185,16 @@ __device__ __forceinline__ void group_loops(const group_wg &w, uint32_t *T_dyn, 
 #pragma unroll
 		for (int q = 0; q < 4; q++)
 			load1(tm0, q);
-		if constexpr (KIND != 0) {
+		if constexpr (kTwoAhead) {
 			const uint32_t tm1 = (t0 + step < limit && tile_of(t0 + step, grp) < tlimit) ? tile_of(t0 + step, grp) : tm0;
 #pragma unroll
 			for (int q = 0; q < 4; q++)
 				load_into(xb, tm1, q);
 		}
 	}
-	if constexpr (KIND == 0) ctable_build(tab, w.z); // (the loads above are in flight meanwhile; ends with a barrier)
+	if constexpr (kFolds) {
+		if (build) ctable_build(tab, w.z); // (uniform; the loads above are in flight meanwhile; ends with a barrier)
+	}
 	if (folds) {
 		switch (prio & 3) { // the fold waves issue ahead of the Gram wave of their SIMD (kernels_foldeval_fp4.hip)
 		case 1: __builtin_amdgcn_s_setprio(1); break;
@@ -193,23 +211,27 @@ __device__ __forceinline__ void group_loops(const group_wg &w, uint32_t *T_dyn, 
 			const uint32_t tm = tile_of(t, grp);
 			if (tm < tlimit) { // (uniform; false only for group 1 on an odd last pair)
 				// the last iteration(s) re-request their own tile (cache hits) instead of branching around the loads
-				constexpr uint32_t kAhead = KIND != 0 ? 2 : 1; // iterations ahead
+				constexpr uint32_t kAhead = kTwoAhead ? 2 : 1; // iterations ahead
 				const uint32_t ta = t + kAhead * step;
 				const uint32_t tn = (ta < limit && tile_of(ta, grp) < tlimit) ? tile_of(ta, grp) : tm;
 				vo = lane_off();
 				const bool ok = in_range(tm);
 				uint4 f[4];
-				if constexpr (KIND == 0) {
+				if constexpr (kFolds) {
 					const uint64_t pt16 = (uint64_t)(tbase + tm) * kTP * 16; // (uniform)
+					const int nq = (KIND == 3 && w.X0[1] == nullptr) ? 2 : 4; // (uniform)
 #pragma unroll
 					for (int q = 0; q < 4; q++) {
+						if (q >= nq) break;
 						f[q] = ctable_mul_acc<8, true>(tab, xor4(x0[q], x1[q]), x0[q]);
 						load1(tn, q); // this quadrant of the group's next tile flies from here on
 					}
 					if (FULL || ok) {
 #pragma unroll
-						for (int q = 0; q < 4; q++)
+						for (int q = 0; q < 4; q++) {
+							if (q >= nq) break;
 							gq_store<NT>(reinterpret_cast<uint4 *>(w.OUT[q >> 1] + (q & 1 ? n * 16 : 0) + pt16 + vo), f[q]);
+						}
 					}
 				} else {
 #pragma unroll
@@ -218,12 +240,16 @@ __device__ __forceinline__ void group_loops(const group_wg &w, uint32_t *T_dyn, 
 						load_into(cur, tn, q);
 					}
 				}
-				if (!FULL && !ok) {
+				if constexpr (KIND != 3) {
+					if (!FULL && !ok) {
 #pragma unroll
-					for (int q = 0; q < 4; q++)
-						f[q] = uint4{0, 0, 0, 0}; // points past the end carry zeros
+						for (int q = 0; q < 4; q++)
+							f[q] = uint4{0, 0, 0, 0}; // points past the end carry zeros
+					}
 				}
-				if constexpr (KIND == 2) {
+				if constexpr (KIND == 3) {
+					// (nothing is staged)
+				} else if constexpr (KIND == 2) {
 					// sets 0 / 1 = the first product's rows, sets 2 / 3 = the second's
 					stage4_elem(Tn, sr, 0, f[0]);
 					stage4_elem(Tn, sr, 1, f[1]);
@@ -237,11 +263,11 @@ __device__ __forceinline__ void group_loops(const group_wg &w, uint32_t *T_dyn, 
 					stage4_elem(Tn, sr, 3, xor4(f[3], f[2]));
 				}
 			}
-			__syncthreads(); // the pair is staged; the Gram waves are done with the buffer this wave writes next
+			if constexpr (KIND != 3) __syncthreads(); // the pair is staged; the Gram waves are done with the buffer this wave writes next
 			buf ^= 1;
 			Tn = T_dyn + (buf * kFoldGroups + grp) * kTile4W;
 		};
-		if constexpr (KIND == 0) {
+		if constexpr (kFolds) {
 			for (uint32_t t = t0; t < limit; t += step) pair_step(t, x0);
 		} else { // (KIND 1, 2: two tiles in flight)
 			for (uint32_t t = t0; t < limit;) {
@@ -253,7 +279,7 @@ __device__ __forceinline__ void group_loops(const group_wg &w, uint32_t *T_dyn, 
 			}
 		}
 		__builtin_amdgcn_s_setprio(0);
-	} else {
+	} else if constexpr (KIND != 3) {
 		const gram4_role gr = make_gram4_role(wave, lane);
 		v16f acc[kAccTiles];
 		acc4_zero(acc);
@@ -278,71 +304,99 @@ __global__ __launch_bounds__(kThreads, 1) void k_group_fp4(group_kargs ga)
 	const unsigned lane = threadIdx.x & 63;
 	const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
-	// ---- this workgroup's job (uniform): the table is sorted by wg_begin
+	// ---- this workgroup's job (uniform): the table is sorted by wg_begin; followers of a chain (wg_count = 0) belong to the job in
+	// front of them
 	static_assert(offsetof(group_kargs, jobs) == 0, "the job table leads the kernel-argument block");
 	const group_job *const jt = job_table();
 	unsigned ji = 0;
 	for (unsigned i = 1; i < ga.n_jobs; i++)
-		if (blockIdx.x >= jt[i].wg_begin) ji = i;
-	const group_job *const jb = jt + ji;
-	group_wg w;
-	w.n = jb->n; // evaluation points of the job
-	w.z = jb->z;
-	for (int sd = 0; sd < 2; sd++) {
-		w.X0[sd] = reinterpret_cast<const char *>(jb->x0[sd]);
-		w.X1[sd] = reinterpret_cast<const char *>(jb->x1[sd]);
-		w.OUT[sd] = reinterpret_cast<char *>(jb->out[sd]);
-	}
-	const uint32_t n_tiles = (uint32_t)(FULL ? w.n / kTP : (w.n + kTP - 1) / kTP);
-	const uint32_t G = jb->wg_count, b = blockIdx.x - jb->wg_begin;
-	// tile order inside the job's range: as kernels_foldeval_mfma.hip (XCD x = blockIdx.x & 7 takes the x-th contiguous eighth of
-	// the job's tiles) when the range starts on a multiple of eight workgroups and is a multiple of eight long
-	w.tbase = 0;
-	w.tstride = G;
-	w.tlimit = n_tiles;
-	w.t0 = b;
-	if ((G & 7) == 0 && (jb->wg_begin & 7) == 0) {
-		const uint32_t chunk = (n_tiles + 7) >> 3;
-		w.tbase = (b & 7) * chunk;
-		w.tstride = G >> 3;
-		w.t0 = b >> 3;
-		w.tlimit = w.tbase >= n_tiles ? 0 : (n_tiles - w.tbase < chunk ? n_tiles - w.tbase : chunk);
-	}
-	w.adj = (ga.prio >> 2) & 1;
-	if (jb->kind == 0) // (uniform)
-		group_loops<0, FULL, NT>(w, T_dyn, tab, Gc, ga.prio);
-	else if (jb->kind == 1)
-		group_loops<1, FULL, NT>(w, T_dyn, tab, Gc, ga.prio);
-	else
-		group_loops<2, FULL, NT>(w, T_dyn, tab, Gc, ga.prio);
-
-	// ---- tail: parity words -> the job's two sums -> its accumulator slots; the last workgroup of the launch publishes ALL slots
+		if (jt[i].wg_count != 0 && blockIdx.x >= jt[i].wg_begin) ji = i;
+	const group_job *const head = jt + ji;
+	const uint32_t G = head->wg_count, b = blockIdx.x - head->wg_begin;
+	const bool xcd_order = (G & 7) == 0 && (head->wg_begin & 7) == 0;
+	const unsigned n_sub = 1 + head->chain;
 	__shared__ uint64_t z3[2][3];
 	__shared__ f128 s_loc[2];
 	__shared__ unsigned is_last;
 	const unsigned tid = threadIdx.x;
-	__syncthreads();
-	// column n' = 32 h + n of matrix (pr, s) as a GF(2^64) element (bit p = G[p][n']); z = sum_n' col * e_n'  (gram.hpp tail_finish)
-	for (unsigned task = wave; task < 6; task += kThreads / 64) {
-		const unsigned pr = task / 3, s = task - 3 * pr;
-		const unsigned h = lane >> 5, nn = lane & 31;
-		auto spread = [](uint32_t x) { return (x & 0xFu) | ((x & 0xF0u) << 4) | ((x & 0xF00u) << 8) | ((x & 0xF000u) << 12); };
-		const uint32_t *g0 = Gc[2 * pr + h][2 * s], *g1 = Gc[2 * pr + h][2 * s + 1];
-		const uint32_t lo = spread(g0[nn]) | (spread(g0[nn + 32]) << 4);
-		const uint32_t hi = spread(g1[nn]) | (spread(g1[nn + 32]) << 4);
-		uint64_t z = mul_basis64((uint64_t)lo | ((uint64_t)hi << 32), lane);
+	f128 z_built{0, 0};
+	bool have_table = false;
+	for (unsigned sub = 0; sub < n_sub; sub++) {
+		const group_job *const jb = head + sub;
+		if (jb->acquire) {
+			// this workgroup's own stores of the chain's earlier jobs (folded arrays, in place) are read back by this job: all of
+			// them have reached the L2 (vmcnt), and the vector cache forgets the lines it loaded before they were written
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			__syncthreads();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+		}
+		group_wg w;
+		w.n = jb->n; // evaluation points of the job
+		w.z = jb->z;
+		for (int sd = 0; sd < 2; sd++) {
+			w.X0[sd] = reinterpret_cast<const char *>(jb->x0[sd]);
+			w.X1[sd] = reinterpret_cast<const char *>(jb->x1[sd]);
+			w.OUT[sd] = reinterpret_cast<char *>(jb->out[sd]);
+		}
+		const uint32_t n_tiles = (uint32_t)(FULL ? w.n / kTP : (w.n + kTP - 1) / kTP);
+		// tile order inside the job's range: as kernels_foldeval_mfma.hip (XCD x = blockIdx.x & 7 takes the x-th contiguous eighth of
+		// the job's tiles) when the range starts on a multiple of eight workgroups and is a multiple of eight long
+		w.tbase = 0;
+		w.tstride = G;
+		w.tlimit = n_tiles;
+		w.t0 = b;
+		if (xcd_order) {
+			const uint32_t chunk = (n_tiles + 7) >> 3;
+			w.tbase = (b & 7) * chunk;
+			w.tstride = G >> 3;
+			w.t0 = b >> 3;
+			w.tlimit = w.tbase >= n_tiles ? 0 : (n_tiles - w.tbase < chunk ? n_tiles - w.tbase : chunk);
+		}
+		w.adj = (ga.prio >> 2) & 1;
+		const uint32_t kind = jb->kind; // (uniform)
+		const bool build = !have_table || !(z_built == w.z);
+		if (kind == 0 || kind == 3) {
+			z_built = w.z;
+			have_table = true;
+		}
+		if (kind == 0)
+			group_loops<0, FULL, NT>(w, T_dyn, tab, Gc, ga.prio, build);
+		else if (kind == 1)
+			group_loops<1, FULL, NT>(w, T_dyn, tab, Gc, ga.prio, false);
+		else if (kind == 2)
+			group_loops<2, FULL, NT>(w, T_dyn, tab, Gc, ga.prio, false);
+		else
+			group_loops<3, FULL, NT>(w, T_dyn, tab, Gc, ga.prio, build);
+		if (kind == 3) { // (no sums; the waves that had nothing to do must not rebuild the table under the folding ones)
+			__syncthreads();
+			continue;
+		}
+
+		// ---- parity words -> the job's two sums -> its accumulator slots
+		__syncthreads();
+		// column n' = 32 h + n of matrix (pr, s) as a GF(2^64) element (bit p = G[p][n']); z = sum_n' col * e_n'  (gram.hpp tail_finish)
+		for (unsigned task = wave; task < 6; task += kThreads / 64) {
+			const unsigned pr = task / 3, s = task - 3 * pr;
+			const unsigned h = lane >> 5, nn = lane & 31;
+			auto spread = [](uint32_t x) { return (x & 0xFu) | ((x & 0xF0u) << 4) | ((x & 0xF00u) << 8) | ((x & 0xF000u) << 12); };
+			const uint32_t *g0 = Gc[2 * pr + h][2 * s], *g1 = Gc[2 * pr + h][2 * s + 1];
+			const uint32_t lo = spread(g0[nn]) | (spread(g0[nn + 32]) << 4);
+			const uint32_t hi = spread(g1[nn]) | (spread(g1[nn + 32]) << 4);
+			uint64_t z = mul_basis64((uint64_t)lo | ((uint64_t)hi << 32), lane);
 #pragma unroll
-		for (int mm = 32; mm >= 1; mm >>= 1)
-			z ^= __shfl_xor(z, mm, 64);
-		if (lane == 0) z3[pr][s] = z;
+			for (int mm = 32; mm >= 1; mm >>= 1)
+				z ^= __shfl_xor(z, mm, 64);
+			if (lane == 0) z3[pr][s] = z;
+		}
+		__syncthreads();
+		if (tid < 2) s_loc[tid] = kara64(z3[tid][0], z3[tid][1], z3[tid][2]);
+		__syncthreads();
+		if (tid < 4) {
+			const uint64_t v = reinterpret_cast<const uint64_t *>(s_loc)[tid];
+			if (v) atomicXor(reinterpret_cast<unsigned long long *>(ga.S + jb->slot) + tid, (unsigned long long)v);
+		}
 	}
-	__syncthreads();
-	if (tid < 2) s_loc[tid] = kara64(z3[tid][0], z3[tid][1], z3[tid][2]);
-	__syncthreads();
-	if (tid < 4) {
-		const uint64_t v = reinterpret_cast<const uint64_t *>(s_loc)[tid];
-		if (v) atomicXor(reinterpret_cast<unsigned long long *>(ga.S + jb->slot) + tid, (unsigned long long)v);
-	}
+	// ---- the last workgroup of the launch publishes ALL slots
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	__syncthreads();
 	if (tid == 0) {
@@ -370,13 +424,14 @@ __global__ __launch_bounds__(kThreads, 1) void k_group_fp4(group_kargs ga)
 	}
 }
 
-// Deals the workgroups of one launch out to the jobs (in proportion to their traffic, eight at a time where a job gets at
-// least eight so that its tiles keep the XCD-aware order), sorts the table by first workgroup and launches.  jobs[i].slot is
-// the caller's; wg_begin / wg_count are filled in here.  Every job: n >= 1; kind 0 jobs write out[] (2 n elements each).
+// Deals the workgroups of one launch out to the UNITS of the job list -- a job with its chain (jobs_in[i].chain followers directly
+// behind it), or a lone job -- in proportion to their traffic, eight at a time where a unit gets at least eight so that its tiles
+// keep the XCD-aware order; sorts the table by first workgroup and launches.  jobs[i].slot is the caller's; wg_begin / wg_count are
+// filled in here.  Every job: n >= 1; all jobs of a chain: the same n; kind 0 / 3 jobs write out[] (2 n elements each).
 hipError_t launch_group(hipStream_t s, int n_cu, const group_job *jobs_in, uint32_t n_jobs, uint32_t n_slots, f128 *d_S, f128 *d_mail, unsigned *d_counter,
                         uint64_t seq)
 {
-	if (n_jobs == 0 || n_jobs > (uint32_t)kGroupMaxJobs || n_slots > 64 || n_cu < (int)n_jobs) return hipErrorNotSupported;
+	if (n_jobs == 0 || n_jobs > (uint32_t)kGroupMaxJobs || n_slots > 64) return hipErrorNotSupported;
 	static const uint32_t prio = [] {
 		const char *e = bn::settled_knob("BN_FE_FP4_PRIO");
 		return e ? (uint32_t)atoi(e) & 3u : 3u;
@@ -385,23 +440,36 @@ hipError_t launch_group(hipStream_t s, int n_cu, const group_job *jobs_in, uint3
 	bool full = true;
 	uint64_t total_elems = 0;
 	double w[kGroupMaxJobs], W = 0;
-	uint32_t tiles[kGroupMaxJobs], cap[kGroupMaxJobs], cnt[kGroupMaxJobs];
-	for (uint32_t i = 0; i < n_jobs; i++) {
-		const group_job &j = jobs_in[i];
-		if (j.n == 0 || j.kind > 2 || j.slot + 2 > n_slots) return hipErrorInvalidValue;
-		if (j.n % kTP) full = false;
-		const uint64_t nt = (j.n + kTP - 1) / kTP;
-		if (nt > (1ull << 14) * (uint64_t)n_cu) return hipErrorNotSupported; // 2^22 points per workgroup: the f32 counts stay exact
-		tiles[i] = (uint32_t)nt;
-		cap[i] = (uint32_t)(nt >= 2 ? nt / 2 : 1); // a workgroup wants a pair of tiles
-		w[i] = (double)nt * (j.kind == 0 ? 3.0 : 1.0);
-		W += w[i];
-		total_elems += j.n * (j.kind == 0 ? 8 : 4);
+	uint32_t tiles[kGroupMaxJobs], cap[kGroupMaxJobs], cnt[kGroupMaxJobs], first[kGroupMaxJobs], len[kGroupMaxJobs];
+	uint32_t n_units = 0;
+	for (uint32_t i = 0; i < n_jobs;) {
+		const uint32_t l = 1 + jobs_in[i].chain;
+		if (i + l > n_jobs) return hipErrorInvalidValue;
+		const uint32_t u = n_units++;
+		first[u] = i;
+		len[u] = l;
+		w[u] = 0;
+		const uint64_t nt = (jobs_in[i].n + kTP - 1) / kTP;
+		for (uint32_t q = i; q < i + l; q++) {
+			const group_job &j = jobs_in[q];
+			if (j.n == 0 || j.kind > 3 || (j.kind != 3 && j.slot + 2 > n_slots) || j.n != jobs_in[i].n || (q > i && j.chain)) return hipErrorInvalidValue;
+			if (q == i && j.acquire) return hipErrorInvalidValue; // (nothing in front of it to read back)
+			if (j.n % kTP) full = false;
+			const bool one = j.kind == 3 && !j.x0[1];
+			w[u] += (double)nt * (j.kind == 0 ? 3.0 : j.kind == 3 ? (one ? 1.5 : 3.0) : 1.0);
+			total_elems += j.n * (j.kind == 0 ? 8 : j.kind == 3 ? (one ? 3 : 6) : 4);
+		}
+		if (nt > (1ull << 14) * (uint64_t)n_cu) return hipErrorNotSupported; // 2^22 points per workgroup and job: the f32 counts stay exact
+		tiles[u] = (uint32_t)nt;
+		cap[u] = (uint32_t)(nt >= 2 ? nt / 2 : 1); // a workgroup wants a pair of tiles
+		W += w[u];
+		i += l;
 	}
+	if (n_cu < (int)n_units) return hipErrorNotSupported;
 	// first pass: the proportional share, rounded down (to a multiple of eight from eight on), at least the workgroups the
 	// exactness bound asks for, at most one per pair of tiles
 	uint32_t used = 0;
-	for (uint32_t i = 0; i < n_jobs; i++) {
+	for (uint32_t i = 0; i < n_units; i++) {
 		uint32_t c = (uint32_t)((double)n_cu * w[i] / W);
 		if (c >= 8) c &= ~7u;
 		const uint32_t need = (tiles[i] + (1u << 14) - 1) >> 14;
@@ -411,10 +479,10 @@ hipError_t launch_group(hipStream_t s, int n_cu, const group_job *jobs_in, uint3
 		cnt[i] = c;
 		used += c;
 	}
-	// (minimums can overshoot only with very many very uneven jobs: take from the largest)
+	// (minimums can overshoot only with very many very uneven units: take from the largest)
 	while (used > (uint32_t)n_cu) {
 		uint32_t big = 0;
-		for (uint32_t i = 1; i < n_jobs; i++)
+		for (uint32_t i = 1; i < n_units; i++)
 			if (cnt[i] > cnt[big]) big = i;
 		if (cnt[big] <= 1) return hipErrorNotSupported;
 		const uint32_t need = (tiles[big] + (1u << 14) - 1) >> 14;
@@ -422,11 +490,11 @@ hipError_t launch_group(hipStream_t s, int n_cu, const group_job *jobs_in, uint3
 		cnt[big]--;
 		used--;
 	}
-	// the rest goes to whoever has the most work per workgroup, eight at a time for jobs in multiples of eight
+	// the rest goes to whoever has the most work per workgroup, eight at a time for units in multiples of eight
 	for (;;) {
 		int best = -1;
 		double best_load = 0;
-		for (uint32_t i = 0; i < n_jobs; i++) {
+		for (uint32_t i = 0; i < n_units; i++) {
 			const uint32_t step = (cnt[i] >= 8 && (cnt[i] & 7) == 0) ? 8 : 1;
 			if (cnt[i] + step > cap[i] || used + step > (uint32_t)n_cu) continue;
 			const double load = w[i] / cnt[i];
@@ -440,18 +508,21 @@ hipError_t launch_group(hipStream_t s, int n_cu, const group_job *jobs_in, uint3
 		cnt[best] += step;
 		used += step;
 	}
-	// table order: the jobs whose count is a multiple of eight first (their ranges then start on multiples of eight)
+	// table order: the units whose count is a multiple of eight first (their ranges then start on multiples of eight)
 	uint32_t order[kGroupMaxJobs], no = 0;
-	for (uint32_t i = 0; i < n_jobs; i++)
+	for (uint32_t i = 0; i < n_units; i++)
 		if ((cnt[i] & 7) == 0) order[no++] = i;
-	for (uint32_t i = 0; i < n_jobs; i++)
+	for (uint32_t i = 0; i < n_units; i++)
 		if ((cnt[i] & 7) != 0) order[no++] = i;
-	uint32_t at = 0;
-	for (uint32_t k = 0; k < n_jobs; k++) {
-		ga.jobs[k] = jobs_in[order[k]];
-		ga.jobs[k].wg_begin = at;
-		ga.jobs[k].wg_count = cnt[order[k]];
-		at += cnt[order[k]];
+	uint32_t at = 0, k = 0;
+	for (uint32_t o = 0; o < n_units; o++) {
+		const uint32_t u = order[o];
+		for (uint32_t q = 0; q < len[u]; q++, k++) {
+			ga.jobs[k] = jobs_in[first[u] + q];
+			ga.jobs[k].wg_begin = at;
+			ga.jobs[k].wg_count = q == 0 ? cnt[u] : 0;
+		}
+		at += cnt[u];
 	}
 	ga.S = d_S;
 	ga.mail = d_mail;

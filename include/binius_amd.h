@@ -345,8 +345,10 @@ int bn_arm_counters(bn_ctx *ctx, uint64_t *counters /*[BN_ARM_N]*/);
  * computed ahead, without a launch; EVALS: execute() calls answered on this path; FLUSHED_FOLDS: deferred fold batches that a
  * foreign call forced out as plain launches. */
 /* HOSTED_*: provers whose arrays were small enough to finish on the host (started), execute() / fold() calls performed
- * there, write-backs of the host's folded copies launched. */
-enum { BN_GROUP_LAUNCHES = 0, BN_GROUP_JOBS_FUSED = 1, BN_GROUP_JOBS_EVAL = 2, BN_GROUP_PREFOLDS = 3, BN_GROUP_SPEC_JOBS = 4, BN_GROUP_SPEC_HITS = 5, BN_GROUP_EVALS = 6, BN_GROUP_FLUSHED_FOLDS = 7, BN_GROUP_HOSTED_STARTED = 8, BN_GROUP_HOSTED_EVALS = 9, BN_GROUP_HOSTED_FOLDS = 10, BN_GROUP_HOSTED_WRITEBACKS = 11, BN_GROUP_N = 12 };
+ * there, write-backs of the host's folded copies launched.  JOBS_FOLD: fold-only jobs of the group launches (arrays shared by
+ * several claims or in none, folded inside the launch); CHAINS: groups of jobs run by one set of workgroups one after the other
+ * (folds first, then the evaluations that read them back). */
+enum { BN_GROUP_LAUNCHES = 0, BN_GROUP_JOBS_FUSED = 1, BN_GROUP_JOBS_EVAL = 2, BN_GROUP_PREFOLDS = 3, BN_GROUP_SPEC_JOBS = 4, BN_GROUP_SPEC_HITS = 5, BN_GROUP_EVALS = 6, BN_GROUP_FLUSHED_FOLDS = 7, BN_GROUP_HOSTED_STARTED = 8, BN_GROUP_HOSTED_EVALS = 9, BN_GROUP_HOSTED_FOLDS = 10, BN_GROUP_HOSTED_WRITEBACKS = 11, BN_GROUP_JOBS_FOLD = 12, BN_GROUP_CHAINS = 13, BN_GROUP_N = 14 };
 int bn_group_counters(bn_ctx *ctx, uint64_t *counters /*[BN_GROUP_N]*/);
 
 #ifdef __cplusplus

@@ -133,8 +133,13 @@ def test_multi_claim_prover_vs_oracle(oracle, n_vars, k, kind, group):
         # every execute() was answered on the group path: by a launch of the group kernel while the arrays are large, on the host
         # once they are small (hosted sessions: at most 2^12 elements per array, 2^8 on a host without VPCLMULQDQ)
         assert cnt["evals"] == n_vars and cnt["launches"] + cnt["hosted_evals"] == n_vars, cnt
+        # ... and every fold is a job of a group launch, none a launch of its own: claims over arrays of their own fused with the folds,
+        # shared arrays folded by the workgroups that then evaluate the claims over them (chains)
+        assert cnt["prefolds"] == 0, cnt
         if kind == "disjoint":
-            assert cnt["jobs_fused"] == k * max(0, cnt["launches"] - 1) and cnt["prefolds"] == 0, cnt
+            assert cnt["jobs_fused"] == k * max(0, cnt["launches"] - 1) and cnt["chains"] == 0, cnt
+        elif cnt["launches"] > 1:
+            assert cnt["chains"] >= cnt["launches"] - 1 and cnt["jobs_fused"] > 0, cnt
         assert cnt["flushed_folds"] <= 1, cnt  # (at most the last fold, forced out by finish()'s reads)
     else:
         assert cnt["launches"] == 0

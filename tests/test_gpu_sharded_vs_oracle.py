@@ -32,16 +32,45 @@ def _free_port():
 
 
 def _worker(rank, world, port, n_global, m, comps, q, exchange="shm"):
+    try:
+        _worker_body(rank, world, port, n_global, m, comps, q, exchange)
+    except BaseException as e:  # (a rank that dies must fail the test now, not after the queue's timeout)
+        import traceback
+
+        q.put((rank, "ERROR", "%r\n%s" % (e, traceback.format_exc())))
+        raise
+
+
+def _collect(q, world, timeout, procs):
+    results = []
+    try:
+        for _ in range(world):
+            item = q.get(timeout=timeout)
+            assert not (len(item) == 3 and item[1] == "ERROR"), "rank %d failed: %s" % (item[0], item[2])
+            results.append(item)
+    except BaseException:
+        for p in procs:  # (the other ranks wait for the one that died)
+            if p.is_alive():
+                p.terminate()
+        for p in procs:
+            p.join(30)
+        raise
+    return results
+
+
+def _worker_body(rank, world, port, n_global, m, comps, q, exchange="shm"):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    if world >= 4:
+    if world >= 4 or os.environ.get("BN_PEER_STRESS"):
         # Ranks that SHARE a device must not arm rounds (csrc/arm.hpp): an armed kernel waits on the device for its
         # challenge, and several processes' worth of waiting workgroups leave no compute units for the kernels whose results
         # those challenges depend on (on a node every rank has its own device and the question does not arise).  Eight ranks
         # time out outright; four ranks with matrix-core rounds armed (512 waiting workgroups each on 512 slots) get through on
         # the kernels' bounded spins, and on a slow box not always inside the exchange's own bound (seen once in a full run of
-        # the suite): they run unarmed as well, as `bench.py` does for ranks that share a device.  Two ranks keep the armed rounds.
+        # the suite): they run unarmed as well, as `bench.py` does for ranks that share a device.  Two ranks keep the armed rounds
+        # -- except under the exchange's stress modes, whose pauses (a quarter of a millisecond per slot) stretch a round past the
+        # armed kernels' bounded spins when both ranks' waiting workgroups sit on the one device (seen once, world 2, n = 20).
         os.environ["BN_ARM"] = "0"
     import torch
     import torch.distributed as dist
@@ -121,7 +150,7 @@ def test_sharded_hip_prover_matches_unsharded_oracle(world, n_global, m, comps, 
     procs = [ctx.Process(target=_worker, args=(r, world, port, n_global, m, comps, q, exchange)) for r in range(world)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=300) for _ in range(world)]
+    results = _collect(q, world, 300, procs)
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
@@ -159,7 +188,7 @@ def test_peer_exchange_validates_its_slots_under_reordering(monkeypatch, world, 
     procs = [ctx.Process(target=_worker, args=(r, world, port, n_global, m, comps, q, "peer")) for r in range(world)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=600) for _ in range(world)]
+    results = _collect(q, world, 600, procs)
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
