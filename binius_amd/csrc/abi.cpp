@@ -599,7 +599,7 @@ int bn_ctx_create(int device, uint64_t arena_elems, bn_ctx **out)
 	if (const char *a = getenv("BN_CIRCUIT_MULTIPASS")) ctx->circuit_multipass = atoi(a) != 0;
 	if (const char *a = getenv("BN_GROUP")) ctx->grp.enabled = atoi(a) != 0;
 	if (const char *a = getenv("BN_GROUP_SPEC")) ctx->grp.speculate = atoi(a) != 0;
-	if (const char *a = getenv("BN_GROUP_CHAINS")) ctx->grp.chains = atoi(a) != 0;
+	if (const char *a = getenv("BN_GROUP_CHAIN_MIN_LOG2")) ctx->grp.chain_min_rows = atoi(a) >= 63 ? ~(uint64_t)0 : (uint64_t)1 << (atoi(a) < 0 ? 0 : atoi(a));
 	BN_HIP(hipMalloc((void **)&ctx->d_flag, sizeof(unsigned)));
 	BN_HIP(hipMemset(ctx->d_flag, 0, sizeof(unsigned)));
 	BN_HIP(hipMalloc((void **)&ctx->d_s_evals, sizeof(uint64_t) * BN_NTT_MAX_DIM * BN_NTT_MAX_DIM));

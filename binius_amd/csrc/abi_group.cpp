@@ -970,23 +970,42 @@ int group_eval(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const bn_kop
 				loose.push_back({(int)f, (int)j});
 			}
 	}
-	// ---- the jobs.  Chained planning: every waiting fold is a job of the launch; where it does not fit (more than
-	// kGroupMaxJobs jobs), the fallback: plain fold launches in front for everything a fused job does not fold
+	// ---- the jobs.  Chained planning (large arrays): every waiting fold is a job of the launch; otherwise, and where that does not
+	// fit (more than kGroupMaxJobs jobs): plain fold launches in front for everything a fused job does not fold
 	std::vector<bn::group_job> jobs;
 	uint64_t n_fused = 0, n_fold_only = 0, n_chains = 0;
-	std::vector<std::vector<char>> ran(g.folds.size()); // (fallback only) folded by a plain launch that has been enqueued
+	std::vector<std::vector<char>> ran(g.folds.size()); // folded by a plain launch that has been enqueued
 	for (size_t f = 0; f < g.folds.size(); f++) ran[f].assign(g.folds[f].count, 0);
-	auto plan_all_chained = [&]() {
+	std::vector<std::vector<char>> plain(g.folds.size()); // folded by a plain launch in front of the group launch
+	// Chains pay where the arrays are large -- the shared arrays' folds cost no pass of their own -- and lose where a launch is
+	// latency-bound: the jobs of a chain run one after the other on one set of workgroups (measured, 2 x 2 claims: 474 against
+	// 537 us at 2^24 elements per array, 152 against 143 at 2^22, 39 against 17 at 2^14; profiles/r05).  Per prover by size.
+	auto plan_all = [&](bool allow_chains) {
 		const size_t cap = (size_t)bn::kGroupMaxJobs;
-		if (!g.chains) return false;
-		if (!plan_chained(ctx, rq.m, rq.k, rq.pa, rq.pb, rq.lo, rq.hi, rq.row_len, ref, 0, cap, jobs, n_fused, n_fold_only, n_chains)) return false;
+		jobs.clear();
+		n_fused = n_fold_only = n_chains = 0;
+		for (size_t f = 0; f < g.folds.size(); f++) plain[f].assign(g.folds[f].count, 0);
+		auto one = [&](uint32_t m, uint32_t k, const uint8_t *pa, const uint8_t *pb, const void *const *lo, const void *const *hi, uint64_t row_len, const fold_ref *rf,
+		               uint32_t slot0) {
+			if (jobs.size() > cap) return false;
+			if (allow_chains && row_len >= g.chain_min_rows)
+				return plan_chained(ctx, m, k, pa, pb, lo, hi, row_len, rf, slot0, cap - jobs.size(), jobs, n_fused, n_fold_only, n_chains);
+			std::vector<char> pf(m, 0);
+			plan_prefold(ctx, m, k, pa, pb, lo, hi, row_len, rf, slot0, jobs, pf, n_fused);
+			for (uint32_t i = 0; i < m; i++)
+				if (pf[i]) plain[rf[i].f][rf[i].j] = 1;
+			return jobs.size() <= cap;
+		};
+		if (!one(rq.m, rq.k, rq.pa, rq.pb, rq.lo, rq.hi, rq.row_len, ref, 0)) return false;
 		for (const auto &r : riders)
-			if (jobs.size() > cap ||
-			    !plan_chained(ctx, r.s->m, r.s->k, r.s->pa, r.s->pb, r.lo, r.hi, r.row_len, r.ref, r.slot0, cap - jobs.size(), jobs, n_fused, n_fold_only, n_chains))
-				return false;
+			if (!one(r.s->m, r.s->k, r.s->pa, r.s->pb, r.lo, r.hi, r.row_len, r.ref, r.slot0)) return false;
 		for (size_t q = 0; q < loose.size();) {
 			const auto &f = g.folds[loose[q].first];
-			if (f.n < 2 || (f.n & 1)) return false;
+			if (!allow_chains || f.n / 2 < g.chain_min_rows || f.n < 2 || (f.n & 1)) {
+				plain[loose[q].first][loose[q].second] = 1;
+				q++;
+				continue;
+			}
 			bn::group_job j{};
 			j.kind = 3;
 			j.n = f.n / 2;
@@ -1004,48 +1023,27 @@ int group_eval(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const bn_kop
 		}
 		return jobs.size() <= cap;
 	};
-	const bool chained = plan_all_chained();
-	if (!chained) {
-		jobs.clear();
-		n_fused = n_fold_only = n_chains = 0;
-		std::vector<std::vector<char>> prefold; // per participating prover, per array
-		prefold.emplace_back(rq.m, 0);
-		plan_prefold(ctx, rq.m, rq.k, rq.pa, rq.pb, rq.lo, rq.hi, rq.row_len, ref, 0, jobs, prefold.back(), n_fused);
-		for (const auto &r : riders) {
-			prefold.emplace_back(r.s->m, 0);
-			plan_prefold(ctx, r.s->m, r.s->k, r.s->pa, r.s->pb, r.lo, r.hi, r.row_len, r.ref, r.slot0, jobs, prefold.back(), n_fused);
-		}
-		if (jobs.size() > (size_t)bn::kGroupMaxJobs || (int)jobs.size() > ctx->n_cu) return BN_OK; // (cannot happen: claims <= kGroupMaxJobs; the eager kernels answer)
-		std::vector<std::vector<char>> plain(g.folds.size());
-		for (size_t f = 0; f < g.folds.size(); f++) plain[f].assign(g.folds[f].count, 0);
-		for (uint32_t i = 0; i < rq.m; i++)
-			if (prefold[0][i]) plain[ref[i].f][ref[i].j] = 1;
-		for (size_t r = 0; r < riders.size(); r++)
-			for (uint32_t i = 0; i < riders[r].s->m; i++)
-				if (prefold[r + 1][i]) plain[riders[r].ref[i].f][riders[r].ref[i].j] = 1;
-		for (const auto &l : loose) plain[l.first][l.second] = 1;
-		for (size_t f = 0; f < g.folds.size(); f++) {
-			bn_ctx::group_fold part;
-			part.n = g.folds[f].n;
-			part.z = g.folds[f].z;
-			for (uint32_t j = 0; j < g.folds[f].count; j++)
-				if (plain[f][j]) {
-					part.x0[part.count] = g.folds[f].x0[j];
-					part.x1[part.count] = g.folds[f].x1[j];
-					part.src0[part.count] = g.folds[f].src0[j];
-					part.count++;
-				}
-			if (part.count) {
-				rc = launch_fold(ctx, part);
-				ctx->grp.flushed_folds--; // (not a flush: part of the round)
-				if (rc) return rc;
-				for (uint32_t j = 0; j < g.folds[f].count; j++)
-					if (plain[f][j]) ran[f][j] = 1;
-				g.prefolds++;
+	if (!plan_all(true) && !plan_all(false)) return BN_OK; // (the second cannot fail: one job per claim; the eager kernels answer)
+	if ((int)jobs.size() > ctx->n_cu) return BN_OK; // (fewer compute units than jobs; nothing has been enqueued)
+	for (size_t f = 0; f < g.folds.size(); f++) {
+		bn_ctx::group_fold part;
+		part.n = g.folds[f].n;
+		part.z = g.folds[f].z;
+		for (uint32_t j = 0; j < g.folds[f].count; j++)
+			if (plain[f][j]) {
+				part.x0[part.count] = g.folds[f].x0[j];
+				part.x1[part.count] = g.folds[f].x1[j];
+				part.src0[part.count] = g.folds[f].src0[j];
+				part.count++;
 			}
+		if (part.count) {
+			rc = launch_fold(ctx, part);
+			ctx->grp.flushed_folds--; // (not a flush: part of the round)
+			if (rc) return rc;
+			for (uint32_t j = 0; j < g.folds[f].count; j++)
+				if (plain[f][j]) ran[f][j] = 1;
+			g.prefolds++;
 		}
-	} else if ((int)jobs.size() > ctx->n_cu) {
-		return BN_OK; // (fewer compute units than jobs: the eager kernels answer; nothing has been enqueued)
 	}
 	for (const auto &r : riders) g.spec_jobs += r.s->k;
 	// ---- the launch

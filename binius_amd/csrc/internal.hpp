@@ -256,7 +256,8 @@ struct bn_ctx {
 	struct group_state {
 		bool enabled = true;   // BN_GROUP=0: every call takes the single-claim machinery / the eager kernels
 		bool speculate = true; // BN_GROUP_SPEC=0: a launch only carries the calling prover's claims
-		bool chains = true;    // BN_GROUP_CHAINS=0: shared arrays are folded by a plain launch in front of the group launch (round 5's first form)
+		uint64_t chain_min_rows = (uint64_t)1 << 21; // evaluation points per claim from which the jobs of a prover that depend on each other are chained
+		                                              // inside the launch; below: shared arrays are folded by a plain launch in front (BN_GROUP_CHAIN_MIN_LOG2; 63: never)
 		bool on = false;       // a group fold or evaluation happened since the last full flush: single-claim requests join in
 		std::vector<group_fold> folds;
 		std::vector<group_session> sessions;

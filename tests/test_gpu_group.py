@@ -27,7 +27,7 @@ class env:
     """environment switches that bn_ctx_create reads, for the contexts created inside the block"""
 
     def __init__(self, **kv):
-        self.kv = kv
+        self.kv = {k: v for k, v in kv.items() if v is not None}
 
     def __enter__(self):
         self.old = {k: os.environ.get(k) for k in self.kv}
@@ -87,15 +87,18 @@ def claim_sums(oracle, mls, comps):
 
 _ORACLE = {}
 CASES = [(12, 2, "piop"), (12, 4, "piop"), (12, 8, "piop"), (12, 4, "bipartite"), (18, 2, "piop"), (18, 4, "disjoint"), (18, 8, "piop"), (20, 2, "disjoint"),
-         (20, 4, "piop"), (20, 4, "bipartite"), (20, 8, "disjoint"), (22, 2, "piop"), (22, 4, "disjoint"), (9, 3, "piop"), (5, 2, "disjoint"), (3, 2, "piop")]
+         (20, 4, "piop"), (20, 4, "bipartite"), (20, 8, "disjoint"), (22, 2, "piop"), (22, 4, "disjoint"), (9, 3, "piop"), (5, 2, "disjoint"), (3, 2, "piop"),
+         (23, 4, "bipartite")]  # (the last one: large enough for the default to chain the first rounds' jobs)
 
 
-@pytest.mark.parametrize("group", [1, 0])
+@pytest.mark.parametrize("group", [2, 1, 0])
 @pytest.mark.parametrize("n_vars,k,kind", CASES)
 def test_multi_claim_prover_vs_oracle(oracle, n_vars, k, kind, group):
     """One BivariateSumcheckProver with k claims (SumcheckPlan = the C++ mirror's execute / fold / finish loop): all round
     polynomials and final evaluations equal the oracle's; the inputs are untouched; with the group path on, every round after
-    the first is ONE launch that folds and evaluates."""
+    the first is ONE launch that folds and evaluates.  group = 2: jobs that depend on each other are chained inside the launch
+    at every size (the library's default does that from 2^21 evaluation points per claim, where it pays); group = 1: the
+    default -- at these sizes the shared arrays are folded by a plain launch in front."""
     import binius_amd
     from binius_amd._host import SumcheckPlan
 
@@ -112,7 +115,7 @@ def test_multi_claim_prover_vs_oracle(oracle, n_vars, k, kind, group):
         sums = claim_sums(oracle, mls, comps)
         _ORACLE[key] = (sums, oracle_single(oracle, mls, n_vars, comps, sums, batch_coeff, challenges))
     sums, (want_coeffs, want_final) = _ORACLE[key]
-    with env(BN_GROUP=group):
+    with env(BN_GROUP=min(group, 1), BN_GROUP_CHAIN_MIN_LOG2=0 if group == 2 else None):
         with binius_amd.Context(0, m * n + m * (n // 2) + 4096) as hal:
             alloc = hal.dev_alloc()
             d = [upload(hal, alloc, x) for x in mls]
@@ -133,13 +136,18 @@ def test_multi_claim_prover_vs_oracle(oracle, n_vars, k, kind, group):
         # every execute() was answered on the group path: by a launch of the group kernel while the arrays are large, on the host
         # once they are small (hosted sessions: at most 2^12 elements per array, 2^8 on a host without VPCLMULQDQ)
         assert cnt["evals"] == n_vars and cnt["launches"] + cnt["hosted_evals"] == n_vars, cnt
-        # ... and every fold is a job of a group launch, none a launch of its own: claims over arrays of their own fused with the folds,
-        # shared arrays folded by the workgroups that then evaluate the claims over them (chains)
-        assert cnt["prefolds"] == 0, cnt
         if kind == "disjoint":
-            assert cnt["jobs_fused"] == k * max(0, cnt["launches"] - 1) and cnt["chains"] == 0, cnt
-        elif cnt["launches"] > 1:
-            assert cnt["chains"] >= cnt["launches"] - 1 and cnt["jobs_fused"] > 0, cnt
+            assert cnt["jobs_fused"] == k * max(0, cnt["launches"] - 1) and cnt["chains"] == 0 and cnt["prefolds"] == 0, cnt
+        elif group == 2:
+            # every fold is a job of a group launch, none a launch of its own: claims over arrays of their own fused with the folds,
+            # shared arrays folded by the workgroups that then evaluate the claims over them
+            assert cnt["prefolds"] == 0, cnt
+            if cnt["launches"] > 1:
+                assert cnt["chains"] >= cnt["launches"] - 1 and cnt["jobs_fused"] > 0, cnt
+        elif n_vars >= 23:
+            assert cnt["chains"] >= n_vars - 22 and cnt["prefolds"] > 0, cnt
+        else:
+            assert cnt["chains"] == 0 and cnt["jobs_fold"] == 0, cnt
         assert cnt["flushed_folds"] <= 1, cnt  # (at most the last fold, forced out by finish()'s reads)
     else:
         assert cnt["launches"] == 0
@@ -155,7 +163,7 @@ def batch_instance(oracle, sizes, ks, seed):
     return provers
 
 
-@pytest.mark.parametrize("group,spec", [(1, 1), (1, 0), (0, 0)])
+@pytest.mark.parametrize("group,spec", [(2, 1), (1, 1), (1, 0), (0, 0)])  # (group = 2: chains at every size, as in the test above)
 @pytest.mark.parametrize("sizes,ks", [([9, 9, 11, 12], [2, 1, 1, 3]), ([17, 17, 19, 20], [2, 1, 1, 2]), ([6, 8], [1, 1]), ([4, 13, 13], [0, 2, 1]), ([16, 18], [4, 2])])
 def test_front_loaded_batch_vs_oracle(oracle, sizes, ks, group, spec):
     """SumcheckBatchProver::run over several BivariateSumcheckProvers on ONE context, in the reference's order (execute on every
@@ -170,7 +178,7 @@ def test_front_loaded_batch_vs_oracle(oracle, sizes, ks, group, spec):
     stream = oracle.random_scalars(0xBA7C + sum(sizes), len(sizes) + max(sizes))
     batch_coeffs, challenges = stream[: len(sizes)], stream[len(sizes) :]
     total = sum(len(mls) << v for v, mls, _, _ in provers)
-    with env(BN_GROUP=group, BN_GROUP_SPEC=spec):
+    with env(BN_GROUP=min(group, 1), BN_GROUP_SPEC=spec, BN_GROUP_CHAIN_MIN_LOG2=0 if group == 2 else None):
         with binius_amd.Context(0, total + total // 2 + 4096) as hal:
             alloc = hal.dev_alloc()
             dev = [(v, [upload(hal, alloc, x) for x in mls], comps, sums) for v, mls, comps, sums in provers]
@@ -198,7 +206,7 @@ def test_front_loaded_batch_vs_oracle(oracle, sizes, ks, group, spec):
         assert cnt["launches"] <= max(sizes) + 3 * len(sizes), cnt
 
 
-@pytest.mark.parametrize("group", [1, 0])
+@pytest.mark.parametrize("group", [2, 1, 0])  # (2: chains at every size)
 @pytest.mark.parametrize("n,log_inv_rate,log_batch,arities", [(12, 1, 3, [4, 4]), (20, 1, 4, [4, 4, 4, 4]), (9, 2, 0, [3, 2]), (10, 1, 2, [])])
 def test_piop_prove_vs_oracle(oracle, n, log_inv_rate, log_batch, arities, group):
     """piop::prove (bnh_piop_prove = binius_amd/host/piop.hpp): committed multilinears of n-3, n-3, n-1 and n variables
@@ -229,7 +237,7 @@ def test_piop_prove_vs_oracle(oracle, n, log_inv_rate, log_batch, arities, group
     message = piop_ref.merge_multilins(committed, meta.total_vars)
     code_elems = 1 << (meta.total_vars + log_inv_rate)
     ml_elems = sum(x.shape[0] for x in committed) + sum(x.shape[0] for x in transparents)
-    with env(BN_GROUP=group):
+    with env(BN_GROUP=min(group, 1), BN_GROUP_CHAIN_MIN_LOG2=0 if group == 2 else None):
         with binius_amd.Context(0, message.shape[0] + 4 * code_elems + 2 * ml_elems + (1 << 16)) as hal:
             alloc = hal.dev_alloc()
             d_c = [(v, upload(hal, alloc, x)) for v, x in zip(n_varss, committed)]
@@ -322,7 +330,7 @@ def test_reference_piop_suite(oracle, n_varss, n_transparents, log_inv_rate, gro
     message = piop_ref.merge_multilins(committed, meta.total_vars)
     code_elems = 1 << (meta.total_vars + log_inv_rate)
     ml_elems = sum(x.shape[0] for x in committed) + sum(x.shape[0] for x in transparents)
-    with env(BN_GROUP=group):
+    with env(BN_GROUP=min(group, 1), BN_GROUP_CHAIN_MIN_LOG2=0 if group == 2 else None):
         with binius_amd.Context(0, message.shape[0] + 4 * code_elems + 2 * ml_elems + (1 << 16)) as hal:
             alloc = hal.dev_alloc()
             d_c = [(v, upload(hal, alloc, x)) for v, x in zip(n_varss, committed)]

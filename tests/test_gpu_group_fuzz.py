@@ -47,7 +47,10 @@ def test_group_call_sequences_three_way(monkeypatch, oracle, seed):
     monkeypatch.setenv("BN_NO_LAZY_FOLD", "1")
     eager = binius_amd.Context(0, arena)
     monkeypatch.delenv("BN_NO_LAZY_FOLD")
+    if seed % 2:  # (chains -- jobs of one launch that read what other jobs of it fold -- at every size; the default: from 2^21 points)
+        monkeypatch.setenv("BN_GROUP_CHAIN_MIN_LOG2", "0")
     lazy = binius_amd.Context(0, arena)
+    monkeypatch.delenv("BN_GROUP_CHAIN_MIN_LOG2", raising=False)
     threads = _threads()
     s_evals = oracle.ntt_s_evals(5, 12)
     try:
