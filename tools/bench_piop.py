@@ -95,7 +95,7 @@ def run_claims(args):
             c1 = hal.group_counters()
         fused_ms, fused_n = prof["fold_eval_mfma"]
         # fused rounds of one prove on the group path: r = n_vars .. 2 (the first launch of a prove only evaluates)
-        rec = {"bench": "claims", "n_vars": n_vars, "k": k, "m": m, "kind": args.kind, "group": group, "ms_per_prove": round(ms, 4),
+        rec = {"bench": "claims", "n_vars": n_vars, "k": k, "m": m, "kind": args.kind, "group": group, "chain_min_log2": os.environ.get("BN_GROUP_CHAIN_MIN_LOG2", "default"), "ms_per_prove": round(ms, 4),
                "whole_prove_frac_of_64mN": round(64.0 * m * n / (ms * 1e-3) / PEAK, 4), "verifier_check": bool(ok),
                "prof_ms": {kk: [round(v[0], 4), v[1]] for kk, v in prof.items() if v[1]},
                "group_counters_one_prove": {kk: c1[kk] - c0[kk] for kk in c1}}

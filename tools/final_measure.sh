@@ -26,6 +26,12 @@ BN_TWO_ROUND=0 python bench.py --n-vars 25 --steps 20 --warmup 3 --no-cpu-baseli
   python tools/bench_piop.py claims --n-vars 24 --k 4 --kind piop --steps 5
   python tools/bench_piop.py claims --n-vars 24 --k 4 --kind bipartite --steps 5
   python tools/bench_piop.py claims --n-vars 26 --k 4 --steps 3 --group 1
+  python tools/bench_piop.py claims --n-vars 26 --k 4 --kind bipartite --steps 3 --group 1
+  BN_GROUP_CHAIN_MIN_LOG2=63 python tools/bench_piop.py claims --n-vars 26 --k 4 --kind bipartite --steps 3 --group 1
+  python tools/bench_piop.py claims --n-vars 26 --k 4 --kind piop --steps 3 --group 1
+  BN_GROUP_CHAIN_MIN_LOG2=63 python tools/bench_piop.py claims --n-vars 26 --k 4 --kind piop --steps 3 --group 1
+  BN_GROUP_CHAIN_MIN_LOG2=0 python tools/bench_piop.py claims --n-vars 20 --k 4 --kind bipartite --steps 10 --group 1
+  python tools/bench_piop.py claims --n-vars 20 --k 4 --kind bipartite --steps 10 --group 1
   python tools/bench_piop.py claims --n-vars 24 --k 8 --steps 3 --group 1
   python tools/bench_piop.py claims --n-vars 16 --k 4 --steps 20
   python tools/bench_piop.py claims --n-vars 12 --k 8 --steps 20
