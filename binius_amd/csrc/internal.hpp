@@ -444,6 +444,10 @@ hipError_t launch_roundeval_mfma_split(hipStream_t s, int n_cu, const void *a, c
 hipError_t launch_foldeval_mfma(hipStream_t s, int n_cu, const foldeval_args &fa, uint64_t n_in, f128 z, f128 *d_out, const fin_fuse *fuse,
                                 const arm_args *armed = nullptr);
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (function, DEVICE): raised once per pair and process (and again if a
+// later launch asks for more) -- a second context on another device of the same process gets its own (kernels_stream.hip)
+hipError_t func_lds_limit(const void *fn, int bytes);
+
 // ---- kernels_group.hip: the product claims of a whole batch round of sumchecks as jobs of ONE launch; returns raw sums
 constexpr int kGroupMaxJobs = 32;
 struct group_job {

@@ -432,11 +432,9 @@ hipError_t launch_foldeval_tail(hipStream_t s, const foldeval_args &fa, uint64_t
 {
 	if (n_in < 8 || (n_in & 3) || !fz.counter || !fz.args.seq) return hipErrorNotSupported;
 	const size_t lds = (size_t)kTailWaves * kWaveQ * sizeof(uint4);
-	static bool attr_set = false;
-	if (!attr_set) {
-		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_foldeval_tail), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+	{
+		const hipError_t e = func_lds_limit(reinterpret_cast<const void *>(&k_foldeval_tail), (int)lds);
 		if (e != hipSuccess) return e;
-		attr_set = true;
 	}
 	hipLaunchKernelGGL(k_foldeval_tail, dim3(1), dim3(64 * kTailWaves), lds, s, fa, n_in, z, d_out, fz, d_cmd, d_status, tail_id);
 	return hipGetLastError();

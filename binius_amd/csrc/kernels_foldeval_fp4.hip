@@ -235,12 +235,12 @@ hipError_t launch_foldeval_fp4(hipStream_t s, int n_cu, const foldeval_args &fa_
 	unsigned grid = (unsigned)(n_tiles < (uint64_t)n_cu ? n_tiles : (uint64_t)n_cu);
 	if (grid_override && grid_override <= grid && (n_tiles + grid_override - 1) / grid_override <= (1ull << 14)) grid = grid_override;
 	constexpr unsigned lds = 2 * kFoldGroups * kTile4W * 4;
-	static const hipError_t attr = [] {
+	const hipError_t attr = [] { // (per device: func_lds_limit)
 		const void *fn[6] = {reinterpret_cast<const void *>(&k_foldeval_mfma_fp4<0, false>), reinterpret_cast<const void *>(&k_foldeval_mfma_fp4<0, true>),
 		                     reinterpret_cast<const void *>(&k_foldeval_mfma_fp4<1, false>), reinterpret_cast<const void *>(&k_foldeval_mfma_fp4<1, true>),
 		                     reinterpret_cast<const void *>(&k_foldeval_mfma_fp4<2, false>), reinterpret_cast<const void *>(&k_foldeval_mfma_fp4<2, true>)};
 		for (const void *f : fn) {
-			const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+			const hipError_t e = func_lds_limit(f, lds);
 			if (e != hipSuccess) return e;
 		}
 		return hipSuccess;

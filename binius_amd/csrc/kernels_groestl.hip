@@ -477,19 +477,15 @@ __global__ __launch_bounds__(kTopThreads) void k_groestl_top(uint4 *__restrict__
 
 static hipError_t set_lds_limits()
 {
-	static hipError_t once = [] {
-		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_groestl_leaves), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTableBytes);
-		if (e != hipSuccess) return e;
-		e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_groestl_layer), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTableBytes);
-		if (e != hipSuccess) return e;
-		e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_groestl_leaves_lanes), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTableBytes);
-		if (e != hipSuccess) return e;
-		e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_groestl_layer_lanes), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTableBytes);
-		if (e != hipSuccess) return e;
-		return hipFuncSetAttribute(reinterpret_cast<const void *>(k_groestl_top), hipFuncAttributeMaxDynamicSharedMemorySize,
-		                           (int)(kTableBytes + 48 * kTopMaxIn));
-	}();
-	return once;
+	hipError_t e = func_lds_limit(reinterpret_cast<const void *>(k_groestl_leaves), (int)kTableBytes);
+	if (e != hipSuccess) return e;
+	e = func_lds_limit(reinterpret_cast<const void *>(k_groestl_layer), (int)kTableBytes);
+	if (e != hipSuccess) return e;
+	e = func_lds_limit(reinterpret_cast<const void *>(k_groestl_leaves_lanes), (int)kTableBytes);
+	if (e != hipSuccess) return e;
+	e = func_lds_limit(reinterpret_cast<const void *>(k_groestl_layer_lanes), (int)kTableBytes);
+	if (e != hipSuccess) return e;
+	return func_lds_limit(reinterpret_cast<const void *>(k_groestl_top), (int)(kTableBytes + 48 * kTopMaxIn));
 }
 
 // up to this many hashes a launch uses the eight-lanes-per-hash kernels (BN_GROESTL_LANES_MAX overrides)

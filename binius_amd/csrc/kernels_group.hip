@@ -543,18 +543,13 @@ hipError_t launch_group(hipStream_t s, int n_cu, const group_job *jobs_in, uint3
 	// elements per array = 2^27 elements touched)
 	const bool nt = full && nt_min_log2 < 62 && total_elems >= (4ull << nt_min_log2);
 	constexpr unsigned lds = 2 * kFoldGroups * kTile4W * 4;
-	// (hipFuncSetAttribute is per device: once per device and process)
-	static bool attr_done[64] = {};
-	int dev = 0;
-	(void)hipGetDevice(&dev);
-	if (dev < 0 || dev >= 64 || !attr_done[dev]) {
+	{
 		const void *fn[4] = {reinterpret_cast<const void *>(&k_group_fp4<false, false>), reinterpret_cast<const void *>(&k_group_fp4<true, false>),
 		                     reinterpret_cast<const void *>(&k_group_fp4<true, true>), nullptr};
 		for (int i = 0; fn[i]; i++) {
-			const hipError_t e = hipFuncSetAttribute(fn[i], hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+			const hipError_t e = func_lds_limit(fn[i], lds);
 			if (e != hipSuccess) return e;
 		}
-		if (dev >= 0 && dev < 64) attr_done[dev] = true;
 	}
 	if (nt)
 		hipLaunchKernelGGL((k_group_fp4<true, true>), dim3(at), dim3(kThreads), lds, s, ga);

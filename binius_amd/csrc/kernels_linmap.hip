@@ -441,9 +441,9 @@ hipError_t launch_fold_right_mfma(hipStream_t s, int n_cu, const void *mat, uint
 		const uint64_t n_pairs = out_len / 64;
 		const dim3 grid((unsigned)(n_pairs < cap ? n_pairs : cap));
 		const size_t lds = (size_t)4 * 2 * (row_bits / 256) * 1040; // D = 4 slots of 2 T instruction strides
-		static const hipError_t a2 = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_linmap_ring<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 4 * 1040);
-		static const hipError_t a4 = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_linmap_ring<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 8 * 1040);
-		static const hipError_t a8 = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_linmap_ring<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 16 * 1040);
+		const hipError_t a2 = func_lds_limit(reinterpret_cast<const void *>(&k_linmap_ring<2>), 4 * 4 * 1040);
+		const hipError_t a4 = func_lds_limit(reinterpret_cast<const void *>(&k_linmap_ring<4>), 4 * 8 * 1040);
+		const hipError_t a8 = func_lds_limit(reinterpret_cast<const void *>(&k_linmap_ring<8>), 4 * 16 * 1040);
 		if (a2 != hipSuccess) return a2;
 		if (a4 != hipSuccess) return a4;
 		if (a8 != hipSuccess) return a8;
@@ -477,9 +477,9 @@ hipError_t launch_fold_left_mfma(hipStream_t s, int n_cu, const void *mat, uint3
 	const uint64_t n_pairs = out_len / 64, cap = (uint64_t)n_cu * 2;
 	const dim3 grid((unsigned)(n_pairs < cap ? n_pairs : cap));
 	const size_t lds = (size_t)4 * vec_len * 256;
-	static const hipError_t a2 = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_linmap_ring_left<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 16 * 256);
-	static const hipError_t a4 = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_linmap_ring_left<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32 * 256);
-	static const hipError_t a8 = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_linmap_ring_left<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 256);
+	const hipError_t a2 = func_lds_limit(reinterpret_cast<const void *>(&k_linmap_ring_left<2>), 4 * 16 * 256);
+	const hipError_t a4 = func_lds_limit(reinterpret_cast<const void *>(&k_linmap_ring_left<4>), 4 * 32 * 256);
+	const hipError_t a8 = func_lds_limit(reinterpret_cast<const void *>(&k_linmap_ring_left<8>), 4 * 64 * 256);
 	if (a2 != hipSuccess) return a2;
 	if (a4 != hipSuccess) return a4;
 	if (a8 != hipSuccess) return a8;

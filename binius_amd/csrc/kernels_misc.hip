@@ -226,7 +226,7 @@ static hipError_t run_fold_tab(hipStream_t s, const void *mat, const void *vec, 
 	constexpr int NB = 1 << IOTA, P = NB / 4, J = 256 / P;
 	const size_t lds = 65536 + (size_t)J * NB * 16;
 	const uint64_t blocks = (out_len + TH * R - 1) / (TH * R);
-	static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fold_tab<IOTA, LEFT, R, TH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); // (once per instantiation)
+	const hipError_t attr = func_lds_limit(reinterpret_cast<const void *>(&k_fold_tab<IOTA, LEFT, R, TH>), (int)lds);
 	if (attr != hipSuccess) return attr;
 	hipLaunchKernelGGL((k_fold_tab<IOTA, LEFT, R, TH>), dim3((unsigned)blocks), dim3(TH), lds, s, (const uint64_t *)mat, (const uint4 *)vec, vec_len,
 	                   (uint4 *)out, out_len);
@@ -524,13 +524,11 @@ hipError_t run_fri_multi(hipStream_t s, int n_cu, int C, const uint4 *src, uint4
 	for (int c = 0; c < C; c++) ntt = ntt || lv[c].s_row != nullptr;
 	const uint64_t n_wblocks = (n_out + 63) / 64;
 	if (ntt) {
-		static bool attr_done = false;
-		if (!attr_done) {
-			hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fri_pass_multi<2, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+		{
+			hipError_t e = func_lds_limit(reinterpret_cast<const void *>(&k_fri_pass_multi<2, true, 8>), 65536);
 			if (e != hipSuccess) return e;
-			e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fri_pass_multi<3, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+			e = func_lds_limit(reinterpret_cast<const void *>(&k_fri_pass_multi<3, true, 4>), 65536);
 			if (e != hipSuccess) return e;
-			attr_done = true;
 		}
 		// one workgroup per CU (the byte table)
 		if (C == 3) {

@@ -469,7 +469,7 @@ hipError_t launch_mul9(hipStream_t s, int n_cu, const void *a, uint64_t a_stride
 	// with the default level fusion, and a path the tests do not reach is not worth a fifth of its time)
 	if (dual_on && n_batches > cap * 4 && a_stride == 1 && b_stride == 1) {
 		constexpr size_t lds = (size_t)4 * 2 * kWaveQ4 * sizeof(uint4);
-		static const hipError_t attr1 = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mul9_dual<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		const hipError_t attr1 = func_lds_limit(reinterpret_cast<const void *>(&k_mul9_dual<1>), (int)lds);
 		if (attr1 != hipSuccess) return attr1;
 		const uint64_t n_steps = (n_batches + 1) / 2;
 		uint64_t blk = (n_steps + 3) / 4;

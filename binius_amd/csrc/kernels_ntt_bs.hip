@@ -634,14 +634,9 @@ static hipError_t run_ntt_bs(hipStream_t s, void *data, const uint64_t *h_s_eval
 	const uint32_t n_top = skip_rounds >= 5 ? 0 : 5 - skip_rounds;
 	const uint32_t n_low = skip_rounds > 5 ? NB - (skip_rounds - 5) : NB;
 	const size_t lds = (size_t)(1 << kTileLog) * kSetQ * sizeof(uint4);
-	static bool attr_set = false;
-	if (!attr_set) {
-		e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ntt_bs_pass<INV, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-		if (e == hipSuccess)
-			e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ntt_bs_pass<INV, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-		if (e != hipSuccess) return e;
-		attr_set = true;
-	}
+	e = func_lds_limit(reinterpret_cast<const void *>(&k_ntt_bs_pass<INV, false>), (int)lds);
+	if (e == hipSuccess) e = func_lds_limit(reinterpret_cast<const void *>(&k_ntt_bs_pass<INV, true>), (int)lds);
+	if (e != hipSuccess) return e;
 	// lower layers, at most 7 per pass: forward from NB-1 down to 0, inverse from 0 up to NB-1
 	std::vector<std::pair<uint32_t, uint32_t>> plan; // (l_lo, R), highest layers first
 	for (uint32_t hi = n_low; hi > 0;) {

@@ -284,11 +284,11 @@ static hipError_t run_tiled(hipStream_t s, int n_cu, bool inverse, void *data, c
 		const unsigned g = (unsigned)(P.n_tiles < cap ? P.n_tiles : cap);
 		hipError_t e;
 		if (inverse) {
-			e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ntt_tiled<T, TW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+			e = func_lds_limit(reinterpret_cast<const void *>(&k_ntt_tiled<T, TW, true>), (int)lds);
 			if (e != hipSuccess) return e;
 			hipLaunchKernelGGL((k_ntt_tiled<T, TW, true>), dim3(g), dim3(kTiledThreads), lds, s, (T *)data, d_mul8, d_s_evals, P);
 		} else {
-			e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ntt_tiled<T, TW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+			e = func_lds_limit(reinterpret_cast<const void *>(&k_ntt_tiled<T, TW, false>), (int)lds);
 			if (e != hipSuccess) return e;
 			hipLaunchKernelGGL((k_ntt_tiled<T, TW, false>), dim3(g), dim3(kTiledThreads), lds, s, (T *)data, d_mul8, d_s_evals, P);
 		}

@@ -303,10 +303,10 @@ static hipError_t launch_fp4(hipStream_t s, int n_cu, const void *a_hi, const vo
 		}();
 		unsigned ws_grid = (unsigned)n_cu;
 		if (grid_override && grid_override <= ws_grid && (n_tiles + grid_override - 1) / grid_override <= (1ull << 14)) ws_grid = grid_override;
-		static const hipError_t attr = [] {
-			hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_roundeval_fp4_ws<MIX, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+		const hipError_t attr = [] {
+			hipError_t e = func_lds_limit(reinterpret_cast<const void *>(&k_roundeval_fp4_ws<MIX, true>), lds);
 			if (e != hipSuccess) return e;
-			return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_roundeval_fp4_ws<MIX, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+			return func_lds_limit(reinterpret_cast<const void *>(&k_roundeval_fp4_ws<MIX, false>), lds);
 		}();
 		if (attr != hipSuccess) return attr;
 		if (nt)

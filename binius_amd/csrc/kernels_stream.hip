@@ -7,6 +7,9 @@
 // element (~100 VALU + 32 conflict-free ds_read_b128) stays well under the memory time.
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+#include <vector>
+
 #include "ctable.hpp"
 #include "internal.hpp"
 
@@ -441,12 +444,9 @@ hipError_t launch_tensor_expand(hipStream_t s, int n_cu, void *data, uint32_t lo
 		expand_coords rc{};
 		for (uint32_t q = 0; q < n_pass; q++) rc.r[q] = coords[q];
 		const size_t lds = ((size_t)16 << (log_n + n_pass));
-		static bool attr_set = false;
-		if (!attr_set) {
-			hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tensor_expand_head), hipFuncAttributeMaxDynamicSharedMemorySize,
-			                                   (int)((size_t)16 << kHeadLog));
+		{
+			const hipError_t e = func_lds_limit(reinterpret_cast<const void *>(&k_tensor_expand_head), (int)((size_t)16 << kHeadLog));
 			if (e != hipSuccess) return e;
-			attr_set = true;
 		}
 		hipLaunchKernelGGL(k_tensor_expand_head, dim3(1), dim3(1024), lds, s, (uint4 *)data, log_n, n_pass, rc);
 		hipError_t e = hipGetLastError();
@@ -472,6 +472,32 @@ hipError_t launch_tensor_expand(hipStream_t s, int n_cu, void *data, uint32_t lo
 		i += P;
 	}
 	return hipSuccess;
+}
+
+hipError_t func_lds_limit(const void *fn, int bytes)
+{
+	struct entry {
+		const void *fn;
+		int dev, bytes;
+	};
+	static std::mutex mu;
+	static std::vector<entry> done;
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess) {
+		(void)hipGetLastError();
+		dev = -1;
+	}
+	std::lock_guard<std::mutex> lk(mu);
+	for (auto &d : done)
+		if (d.fn == fn && d.dev == dev) {
+			if (d.bytes >= bytes) return hipSuccess;
+			const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+			if (e == hipSuccess) d.bytes = bytes;
+			return e;
+		}
+	const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+	if (e == hipSuccess && dev >= 0) done.push_back(entry{fn, dev, bytes});
+	return e;
 }
 
 } // namespace bn
