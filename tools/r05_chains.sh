@@ -3,8 +3,8 @@
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/chains; rm -rf $O; mkdir -p $O; cd $R
 timeout 900 python -m pytest tests/test_gpu_group.py tests/test_gpu_group_fuzz.py -x -q > $O/pytest.log 2>&1; echo "rc=$?" >> $O/pytest.log
 tail -5 $O/pytest.log
-for C in 1 0; do
-  export BN_GROUP_CHAINS=$C
+for C in 0 63; do
+  export BN_GROUP_CHAIN_MIN_LOG2=$C
   { python tools/bench_piop.py claims --n-vars 24 --k 4 --kind piop --steps 5 --group 1
     python tools/bench_piop.py claims --n-vars 24 --k 4 --kind bipartite --steps 5 --group 1
     python tools/bench_piop.py claims --n-vars 20 --k 4 --kind bipartite --steps 10 --group 1
@@ -16,7 +16,7 @@ for C in 1 0; do
 done
 python - <<'PY'
 import json
-for C in (1,0):
+for C in (0,63):
     for l in open('gpurun_out/chains/chains_%d.jsonl'%C):
         try: d=json.loads(l)
         except Exception: continue

@@ -1,7 +1,7 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT; cd $R
-for C in 1 0; do
-  BN_GROUP_CHAINS=$C tools/trace_cmd.sh ct_bip_$C python tools/bench_piop.py claims --n-vars 24 --k 4 --kind bipartite --group 1 --steps 1 --warmup 1 > /dev/null 2>&1
+for C in 0 63; do
+  BN_GROUP_CHAIN_MIN_LOG2=$C tools/trace_cmd.sh ct_bip_$C python tools/bench_piop.py claims --n-vars 24 --k 4 --kind bipartite --group 1 --steps 1 --warmup 1 > /dev/null 2>&1
   cd $R
   python - <<PY
 import json

@@ -1,8 +1,7 @@
 #!/bin/bash
-cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
-mkdir -p gpurun_out/r5j
-export TMPDIR=/tmp
-timeout 2400 python -m pytest tests -x -q -m gpu > gpurun_out/r5j/full.log 2>&1
-echo "rc=$?" >> gpurun_out/r5j/full.log
-tail -15 gpurun_out/r5j/full.log | cut -c1-300
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+# the whole GPU suite + smoke, then the round's measurement batch
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/verify; rm -rf $O; mkdir -p $O; cd $R
+timeout 1800 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1
+tail -3 $O/pytest.log; tail -1 $O/smoke.log
+bash tools/final_measure.sh
