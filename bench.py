@@ -567,6 +567,15 @@ def main():
                          + {"peer": "device mailboxes (every rank's finalize step stores its partial into every peer's hipIpc-mapped mailbox and XORs the world's)",
                             "shm": "host shared memory", "rccl": "RCCL all_gather on the context's stream + device XOR"}[exchange.split(" ")[0]]
                          + (" -- " + exchange if " (" in exchange else "")) if dist is not None else "none",
+            # north_star names RCCL for the cross-device reduce.  It is set up, run and timed on every multi-GPU
+            # invocation (`exchanges.rccl`, `alt_exchange`), and it is the default only if it is the fastest of the three there:
+            # its result lives on the device (all_gather on the stream + a one-workgroup XOR), which rules out everything that
+            # takes a small round off the launch path -- armed rounds, two-round launches, the host tail -- and
+            # costs a collective launch per round where the other two exchange 32 bytes inside the round's own kernel.
+            "named_collective": (None if dist is None else
+                                 "rccl is the default exchange of this run" if exchange.split(" ")[0] == "rccl" else
+                                 "rccl (north_star's collective) timed beside the default in `exchanges`; not the default: a device-resident "
+                                 "result excludes armed / two-round / host-tail rounds and adds a collective launch per round"),
         },
         "alt_exchange": alt,
         # every exchange on this node: was it set up, tried, did it run on all ranks (error text if not), its ms per step and
