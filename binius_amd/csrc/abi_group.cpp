@@ -357,7 +357,9 @@ void plan_prefold(const bn_ctx *ctx, uint32_t m, uint32_t k, const uint8_t *pa, 
 	for (uint32_t i = 0; i < m; i++) prefold[i] = (ref[i].f >= 0 && !fused_arr[i]) ? 1 : 0;
 }
 
-bn_ctx::group_session *session_for(bn_ctx *ctx, const request &rq, const fold_ref *ref)
+int unhost(bn_ctx *ctx, bn_ctx::group_session &s);
+
+bn_ctx::group_session *session_for(bn_ctx *ctx, const request &rq, const fold_ref *ref, int *rc_out)
 {
 	auto &ss = ctx->grp.sessions;
 	auto same_claims = [&](const bn_ctx::group_session &s) {
@@ -381,9 +383,21 @@ bn_ctx::group_session *session_for(bn_ctx *ctx, const request &rq, const fold_re
 		if (cont || same) return &s;
 	}
 	if (ss.size() >= kMaxSessions) {
-		size_t old = 0;
-		for (size_t i = 1; i < ss.size(); i++)
-			if (ss[i].stamp < ss[old].stamp) old = i;
+		// the least recently used description goes -- never one the host still owes a write-back for (its folded copies are the only
+		// place the caller's folds exist) unless every session is such a one, and then only after the write-back
+		size_t old = ss.size();
+		for (size_t i = 0; i < ss.size(); i++)
+			if (!ss[i].hosted && (old == ss.size() || ss[i].stamp < ss[old].stamp)) old = i;
+		if (old == ss.size()) {
+			old = 0;
+			for (size_t i = 1; i < ss.size(); i++)
+				if (ss[i].stamp < ss[old].stamp) old = i;
+			const int rc = unhost(ctx, ss[old]);
+			if (rc) {
+				*rc_out = rc;
+				return nullptr;
+			}
+		}
 		ss.erase(ss.begin() + (long)old);
 	}
 	ss.emplace_back();
@@ -849,7 +863,8 @@ int group_eval(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const bn_kop
 				prof_scope ps(ctx, BN_PROF_FOLD_EVAL8);
 				BN_HIP(bn::launch_group_mirror(ctx->stream, ma));
 			}
-			bn_ctx::group_session *hs = session_for(ctx, rq, ref); // (before the deferred folds it is matched against are retired)
+			bn_ctx::group_session *hs = session_for(ctx, rq, ref, &rc); // (before the deferred folds it is matched against are retired)
+			if (!hs) return rc;
 			// retire the folds the hand-over performed; arrays of those batches that the request does not name are folded plainly
 			std::vector<std::vector<char>> done(g.folds.size());
 			for (size_t f = 0; f < g.folds.size(); f++) done[f].assign(g.folds[f].count, 0);
@@ -917,7 +932,8 @@ int group_eval(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const bn_kop
 			return BN_OK;
 		}
 	}
-	bn_ctx::group_session *self = session_for(ctx, rq, ref);
+	bn_ctx::group_session *self = session_for(ctx, rq, ref, &rc);
+	if (!self) return rc;
 	// consumed[f][j]: array j of deferred fold f is brought up to date by this launch (a job of it, or a plain launch in front)
 	std::vector<std::vector<char>> consumed(g.folds.size());
 	for (size_t f = 0; f < g.folds.size(); f++) consumed[f].assign(g.folds[f].count, 0);

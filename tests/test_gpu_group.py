@@ -88,7 +88,8 @@ def claim_sums(oracle, mls, comps):
 _ORACLE = {}
 CASES = [(12, 2, "piop"), (12, 4, "piop"), (12, 8, "piop"), (12, 4, "bipartite"), (18, 2, "piop"), (18, 4, "disjoint"), (18, 8, "piop"), (20, 2, "disjoint"),
          (20, 4, "piop"), (20, 4, "bipartite"), (20, 8, "disjoint"), (22, 2, "piop"), (22, 4, "disjoint"), (9, 3, "piop"), (5, 2, "disjoint"), (3, 2, "piop"),
-         (23, 4, "bipartite")]  # (the last one: large enough for the default to chain the first rounds' jobs)
+         (23, 4, "bipartite"),  # (large enough for the default to chain the first rounds' jobs)
+         (24, 4, "disjoint")]  # (the shape bench.py times beside the headline as `claim_groups`, at its size)
 
 
 @pytest.mark.parametrize("group", [2, 1, 0])
@@ -304,6 +305,52 @@ def test_hosted_sessions_any_threshold(oracle, ht_log2):
             arm = hal.arm_counters()
         assert arm["ht_max"] == 0, "hosted sessions never started although the host tail is available"
     assert dumps[1][3]["hosted_started"] == 0
+
+
+def test_more_hosted_provers_than_sessions_keep_their_folds(oracle):
+    """A context remembers a bounded number of provers (sessions; the least recently used one is forgotten).  A prover that finished
+    on the host may still be owed the write-back of its folded arrays -- nobody has looked at that memory yet: forgetting it must
+    not lose those folds.  Twenty small provers, one after the other on one context, each finishing on the host; only then is every
+    folded buffer read: byte for byte what eager execution leaves, and every transcript the oracle's."""
+    import binius_amd
+    from binius_amd._host import SumcheckPlan
+
+    n_provers, n_vars = 20, 9
+    m, comps = claims_for("piop", 3)
+    n = 1 << n_vars
+    insts = []
+    for p in range(n_provers):
+        mls = [oracle.random_b128(0x5E550000 + 64 * p + j, n) for j in range(m)]
+        sums = claim_sums(oracle, mls, comps)
+        stream = oracle.random_scalars(0x5E55 + p, n_vars + 1)
+        insts.append((mls, sums, stream[0], stream[1:]))
+    dumps = []
+    for lazy in (1, 0):
+        with env(BN_NO_LAZY_FOLD=None if lazy else 1):
+            with binius_amd.Context(0, n_provers * (m * n + m * (n // 2)) + 4096) as hal:
+                alloc = hal.dev_alloc()
+                outs, bufs = [], []
+                for mls, sums, bc, ch in insts:
+                    d = [upload(hal, alloc, x) for x in mls]
+                    scratch = alloc.alloc(m * (n // 2))
+                    plan = SumcheckPlan(hal, n_vars, d, scratch, comps, sums, bc, ch)
+                    plan.run()
+                    outs.append((plan.round_coeffs(), plan.final_evals()))
+                    bufs.append((d, scratch))
+                cnt = hal.group_counters()
+                mem = [(hal.copy_d2h(scratch), [hal.copy_d2h(x) for x in d]) for d, scratch in bufs]
+                dumps.append((outs, mem, cnt))
+    for p, (mls, sums, bc, ch) in enumerate(insts):
+        want = oracle_single(oracle, mls, n_vars, comps, sums, bc, ch)
+        for which in (0, 1):
+            got = dumps[which][0][p]
+            assert [list(r) for r in got[0]] == [list(r) for r in want[0]] and list(got[1]) == list(want[1]), ("transcript", which, p)
+        assert np.array_equal(dumps[0][1][p][0], dumps[1][1][p][0]), "prover %d: folded buffers differ from what eager execution leaves" % p
+        for a, b, x in zip(dumps[0][1][p][1], dumps[1][1][p][1], mls):
+            assert np.array_equal(a, b) and np.array_equal(a, x)
+    c = dumps[0][2]
+    if c["hosted_started"]:  # (a host without carry-less multiplication hosts nothing at this size)
+        assert c["hosted_started"] >= n_provers and c["hosted_writebacks"] >= n_provers - 16, c
 
 
 @pytest.mark.parametrize("group", [1, 0])
