@@ -1041,25 +1041,62 @@ int group_eval(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const bn_kop
 	};
 	if (!plan_all(true) && !plan_all(false)) return BN_OK; // (the second cannot fail: one job per claim; the eager kernels answer)
 	if ((int)jobs.size() > ctx->n_cu) return BN_OK; // (fewer compute units than jobs; nothing has been enqueued)
-	for (size_t f = 0; f < g.folds.size(); f++) {
-		bn_ctx::group_fold part;
-		part.n = g.folds[f].n;
-		part.z = g.folds[f].z;
-		for (uint32_t j = 0; j < g.folds[f].count; j++)
-			if (plain[f][j]) {
-				part.x0[part.count] = g.folds[f].x0[j];
-				part.x1[part.count] = g.folds[f].x1[j];
-				part.src0[part.count] = g.folds[f].src0[j];
-				part.count++;
-			}
-		if (part.count) {
-			rc = launch_fold(ctx, part);
-			ctx->grp.flushed_folds--; // (not a flush: part of the round)
-			if (rc) return rc;
+	{
+		std::vector<bn_ctx::group_fold> parts;
+		std::vector<size_t> part_of;
+		for (size_t f = 0; f < g.folds.size(); f++) {
+			bn_ctx::group_fold part;
+			part.n = g.folds[f].n;
+			part.z = g.folds[f].z;
 			for (uint32_t j = 0; j < g.folds[f].count; j++)
-				if (plain[f][j]) ran[f][j] = 1;
-			g.prefolds++;
+				if (plain[f][j]) {
+					part.x0[part.count] = g.folds[f].x0[j];
+					part.x1[part.count] = g.folds[f].x1[j];
+					part.src0[part.count] = g.folds[f].src0[j];
+					part.count++;
+				}
+			if (part.count) {
+				parts.push_back(part);
+				part_of.push_back(f);
+			}
 		}
+		// the provers of a batch round fold by ONE challenge (front_loaded.rs:122-155): their plain folds -- arrays of different
+		// lengths -- are one launch while the whole is launch-bound
+		bool merged = parts.size() >= 2;
+		uint64_t arrays = 0, elems = 0;
+		for (const auto &pt : parts) {
+			merged = merged && pt.z == parts[0].z;
+			arrays += pt.count;
+			elems += (uint64_t)pt.count * pt.n;
+		}
+		merged = merged && arrays <= (uint64_t)bn::kFoldBatchMax && elems < ((uint64_t)1 << 25);
+		if (merged) {
+			bn::fold_batch fb{};
+			bn::fold_lengths fl{};
+			uint32_t c = 0;
+			for (const auto &pt : parts)
+				for (uint32_t i = 0; i < pt.count; i++, c++) {
+					fb.x0[c] = pt.x0[i];
+					fb.x1[c] = pt.x1[i];
+					fb.src0[c] = pt.src0[i] != pt.x0[i] ? pt.src0[i] : nullptr;
+					fl.n[c] = pt.n;
+				}
+			{
+				prof_scope ps(ctx, BN_PROF_FOLD);
+				BN_HIP(bn::launch_extrapolate_line_ragged(ctx->stream, ctx->n_cu, fb, fl, c, parts[0].z));
+			}
+			g.prefolds++;
+		} else {
+			for (const auto &pt : parts) {
+				rc = launch_fold(ctx, pt);
+				ctx->grp.flushed_folds--; // (not a flush: part of the round)
+				if (rc) return rc;
+				g.prefolds++;
+			}
+		}
+		for (size_t q = 0; q < parts.size(); q++)
+			for (uint32_t j = 0; j < g.folds[part_of[q]].count; j++)
+				if (plain[part_of[q]][j]) ran[part_of[q]][j] = 1;
 	}
 	for (const auto &r : riders) g.spec_jobs += r.s->k;
 	// ---- the launch

@@ -306,6 +306,11 @@ struct fold_batch {
 	const void *src0[kFoldBatchMax]; // nullptr: in place (evals_0 is read from x0); else evals_0 is read from here and written to x0
 };
 hipError_t launch_extrapolate_line_batch(hipStream_t s, int n_cu, const fold_batch &b, uint32_t count, uint64_t n, f128 z);
+struct fold_lengths {
+	uint64_t n[kFoldBatchMax];
+};
+// arrays of different lengths under one challenge (the folds of several provers of a batch round in one launch)
+hipError_t launch_extrapolate_line_ragged(hipStream_t s, int n_cu, const fold_batch &b, const fold_lengths &fl, uint32_t count, f128 z);
 hipError_t launch_fold_publish(hipStream_t s, void *const *x0, const void *const *src0, const void *const *x1, uint32_t count, uint32_t n,
                                f128 z, f128 *d_mail, uint64_t seq, uint32_t scale_mask = 0, f128 hi_scale = f128{0, 0});
 hipError_t launch_scale(hipStream_t s, int n_cu, void *x, uint64_t n, f128 c); // x[i] *= c

@@ -127,6 +127,55 @@ __global__ __launch_bounds__(256) void k_extrapolate_line_batch(fold_batch fb, u
 	}
 }
 
+// The same fold for arrays of DIFFERENT lengths under one challenge: the folds of several provers of a batch round (one
+// BivariateSumcheckProver per size, one challenge for all of them: prove/front_loaded.rs:122-155) in one launch.  blockIdx.y =
+// the array; the grid's x extent is sized for the longest one.
+template <int U>
+__global__ __launch_bounds__(256) void k_extrapolate_line_ragged(fold_batch fb, fold_lengths fl, f128 z)
+{
+	__shared__ ctable_smem tab;
+	ctable_build(tab, z);
+	uint4 *x0 = (uint4 *)fb.x0[blockIdx.y];
+	const uint4 *s0 = fb.src0[blockIdx.y] ? (const uint4 *)fb.src0[blockIdx.y] : (const uint4 *)x0;
+	const uint4 *x1 = (const uint4 *)fb.x1[blockIdx.y];
+	const uint64_t n = fl.n[blockIdx.y];
+	const uint64_t stride = (uint64_t)gridDim.x * 256;
+	uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+	for (; i + (U - 1) * stride < n; i += U * stride) {
+		uint4 a[U], b[U];
+#pragma unroll
+		for (int u = 0; u < U; u++) {
+			a[u] = s0[i + u * stride];
+			b[u] = x1[i + u * stride];
+		}
+#pragma unroll
+		for (int u = 0; u < U; u++)
+			x0[i + u * stride] = xor4(a[u], ctable_mul(tab, xor4(a[u], b[u])));
+	}
+	for (; i < n; i += stride) {
+		uint4 a = s0[i], b = x1[i];
+		x0[i] = xor4(a, ctable_mul(tab, xor4(a, b)));
+	}
+}
+
+hipError_t launch_extrapolate_line_ragged(hipStream_t s, int n_cu, const fold_batch &b, const fold_lengths &fl, uint32_t count, f128 z)
+{
+	if (count == 0 || count > (uint32_t)kFoldBatchMax) return count ? hipErrorNotSupported : hipSuccess;
+	uint64_t n_max = 0;
+	for (uint32_t i = 0; i < count; i++) n_max = fl.n[i] > n_max ? fl.n[i] : n_max;
+	if (n_max == 0) return hipSuccess;
+	if (n_max >= (1u << 16)) {
+		unsigned g = grid_for(n_max, 256 * 2, n_cu, 8);
+		g = (g + count - 1) / count;
+		if (g < 1) g = 1;
+		hipLaunchKernelGGL((k_extrapolate_line_ragged<2>), dim3(g, count), dim3(256), 0, s, b, fl, z);
+	} else {
+		unsigned g = grid_for(n_max, 256, n_cu, 8);
+		hipLaunchKernelGGL((k_extrapolate_line_ragged<1>), dim3(g, count), dim3(256), 0, s, b, fl, z);
+	}
+	return hipGetLastError();
+}
+
 hipError_t launch_fill(hipStream_t s, void *dst, uint64_t n, f128 v)
 {
 	if (n == 0) return hipSuccess;
