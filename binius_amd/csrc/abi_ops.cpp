@@ -291,6 +291,16 @@ int bn_gather_d2h(bn_ctx *ctx, const void *d_src, const uint64_t *h_offsets, uin
 	}
 	if (n_items == 0 || item_elems == 0) return BN_OK;
 	BN_REQUIRE(n_items <= (1ull << 24) && item_elems <= (1ull << 24) && n_items * item_elems <= (1ull << 26), "gather: too many elements for one call");
+	if (n_items == 1 && item_elems <= 64) {
+		// one short item -- the root of a tree just built (MerkleTreeProver::commit reads it every FRI commit round,
+		// fri/prove.rs:395-420): through the zero-copy mailbox, a spin on the sequence word instead of a stream synchronisation
+		// (flush_for_ranges above left no mirrored fold in the mailbox)
+		f128 vals[64];
+		const int rc = publish_vals(ctx, (const f128 *)d_src + h_offsets[0], 1, (uint32_t)item_elems, 0, 1, vals);
+		if (rc) return rc;
+		for (uint64_t e = 0; e < item_elems; e++) h_out[e] = bn_f128{vals[e].lo, vals[e].hi};
+		return BN_OK;
+	}
 	const size_t off_bytes = ((size_t)n_items * 8 + 15) & ~(size_t)15;
 	const size_t need = off_bytes + (size_t)n_items * item_elems * sizeof(f128);
 	if (need > ctx->gather_bytes) {
