@@ -17,14 +17,14 @@
 
 namespace cg = cooperative_groups;
 
-__global__ __launch_bounds__(768) void k_plain(volatile uint64_t *mail, uint64_t seq, unsigned *counter, int barriers)
+__global__ __launch_bounds__(768) void k_plain(volatile uint64_t *mail, uint64_t seq, unsigned *counter, int barriers, unsigned base)
 {
 	for (int b = 1; b <= barriers; b++) {
 		__syncthreads();
 		if (threadIdx.x == 0) {
 			__threadfence();
 			atomicAdd(counter, 1u);
-			const unsigned want = (unsigned)b * gridDim.x;
+			const unsigned want = base + (unsigned)b * gridDim.x; // (the counter only ever grows: no reset to race with)
 			unsigned spins = 0;
 			while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) {
 				if (++spins > (1u << 26)) break; // bounded
@@ -34,7 +34,6 @@ __global__ __launch_bounds__(768) void k_plain(volatile uint64_t *mail, uint64_t
 		__syncthreads();
 	}
 	if (threadIdx.x == 0 && blockIdx.x == 0) {
-		if (barriers) *counter = 0;
 		__hip_atomic_store((uint64_t *)mail, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 	}
 }
@@ -71,11 +70,13 @@ int main()
 			}
 		return true;
 	};
+	unsigned base = 0;
 	for (int barriers : {0, 1, 4}) {
 		auto t0 = std::chrono::steady_clock::now();
 		for (int i = 0; i < N; i++) {
 			++seq;
-			hipLaunchKernelGGL(k_plain, dim3(grid), dim3(768), 0, s, d, seq, d_counter, barriers);
+			hipLaunchKernelGGL(k_plain, dim3(grid), dim3(768), 0, s, d, seq, d_counter, barriers, base);
+			base += (unsigned)barriers * grid;
 			if (!wait(seq)) return 1;
 		}
 		auto t1 = std::chrono::steady_clock::now();
