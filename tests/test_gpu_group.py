@@ -307,6 +307,62 @@ def test_hosted_sessions_any_threshold(oracle, ht_log2):
     assert dumps[1][3]["hosted_started"] == 0
 
 
+@pytest.mark.parametrize("kind,chain_min", [("bipartite", None), ("piop", None), ("bipartite", 63)])
+def test_shared_claims_at_size_satisfy_the_verifier(kind, chain_min):
+    """The shapes with shared multilinears at 2^26 elements per array (4 - 8 GiB resident; inputs generated on the device: tensor
+    expansions of random points), where the library's default chains the first rounds' jobs inside the launch -- too large for the
+    oracle in test time, so the size-independent property is checked on the transcript the device produced: every round polynomial
+    satisfies P_r(0) + P_r(1) = the running claim (the claims from the device's own inner products), and the batched product of
+    the final evaluations is the last running sum -- the sumcheck verifier's equations (protocols/sumcheck/verify.rs), which tie
+    every round evaluation, every fold and the final reads together.  chain_min = 63: the same with plain fold launches."""
+    import binius_amd
+    from binius_amd import synthetic
+    from binius_amd._host import SumcheckPlan
+
+    F = binius_amd.HostField
+    n_vars, k = 26, 4
+    m, comps = claims_for(kind, k)
+    n = 1 << n_vars
+    with env(BN_GROUP_CHAIN_MIN_LOG2=chain_min):
+        with binius_amd.Context(0, m * n + m * (n // 2) + 4096) as hal:
+            alloc = hal.dev_alloc()
+            d = []
+            for j in range(m):
+                x = alloc.alloc(n)
+                hal.fill(x.slice(0, 1), 0x5A + j)
+                hal.tensor_expand(0, synthetic.random_scalars(0x26C0 + j, n_vars), x)
+                d.append(x)
+            scratch = alloc.alloc(m * (n // 2))
+            sums = [hal.inner_product(d[i], 7, d[j]) for i, j in comps]
+            stream = synthetic.random_scalars(0x26C1, n_vars + 1)
+            bc, ch = stream[0], stream[1:]
+            plan = SumcheckPlan(hal, n_vars, d, scratch, comps, sums, bc, ch)
+            plan.run()
+            coeffs, finals = plan.round_coeffs(), plan.final_evals()
+            cnt = hal.group_counters()
+
+    def horner(cs, x):
+        e = 0
+        for c in reversed(cs):
+            e = F.mul(e, x) ^ c
+        return e
+
+    running = horner(sums, bc)
+    for r in range(n_vars):
+        c = coeffs[r]
+        assert (c[0] ^ (c[0] ^ c[1] ^ c[2])) == running, "round %d: P(0) + P(1) is not the running claim" % r
+        running = horner(c, ch[r])
+    acc, p = 0, 1
+    for i, j in comps:
+        acc ^= F.mul(p, F.mul(finals[i], finals[j]))
+        p = F.mul(p, bc)
+    assert acc == running, "the final evaluations do not match the last round polynomial"
+    if chain_min is None:
+        assert cnt["chains"] >= 4 and cnt["jobs_fused"] > 0, cnt  # (rounds with 2^25 ... 2^22 points per claim... are chained)
+    else:
+        assert cnt["chains"] == 0 and cnt["prefolds"] > 0, cnt
+
+
 def test_more_hosted_provers_than_sessions_keep_their_folds(oracle):
     """A context remembers a bounded number of provers (sessions; the least recently used one is forgotten).  A prover that finished
     on the host may still be owed the write-back of its folded arrays -- nobody has looked at that memory yet: forgetting it must
