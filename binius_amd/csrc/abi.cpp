@@ -380,11 +380,10 @@ int flush_copies(bn_ctx *ctx)
 // disjoint -- a batch only joins either side while it is independent of everything waiting -- so the order is free.)
 int flush_pending(bn_ctx *ctx, bool keep_tail, bool publish_tiny, bool keep_shadow)
 {
-	if (ctx->grp.on || !ctx->grp.folds.empty()) {
+	{
+		// (also with nothing deferred: a hosted prover may be owed its write-back, sums computed ahead die)
 		const int rc = group_flush(ctx);
 		if (rc) return rc;
-	} else {
-		for (auto &s : ctx->grp.sessions) s.pre_valid = false;
 	}
 	return flush_legacy(ctx, keep_tail, publish_tiny, keep_shadow);
 }
@@ -645,6 +644,10 @@ int bn_ctx_create(int device, uint64_t arena_elems, bn_ctx **out)
 			const int v = atoi(l);
 			ctx->grp.ht_max = v <= 0 ? 0 : (uint64_t)1 << (v > 12 ? 12 : v);
 		}
+		if (const char *l = getenv("BN_GROUP_HT_WORK_LOG2")) {
+			const int v = atoi(l);
+			ctx->grp.ht_work = (uint64_t)1 << (v < 0 ? 0 : (v > 17 ? 17 : v));
+		}
 	}
 	if (const char *t = getenv("BN_TAIL_MAX_LOG2")) {
 		const int l = atoi(t);
@@ -803,6 +806,9 @@ int bn_ctx_destroy(bn_ctx *ctx)
 	if (ctx->d_ht_tag) hipFree(ctx->d_ht_tag);
 	if (ctx->h_tail) hipHostFree(ctx->h_tail);
 	if (ctx->grp.h_stage) hipHostFree(ctx->grp.h_stage);
+	if (ctx->grp.h_tables) hipHostFree(ctx->grp.h_tables);
+	if (ctx->grp.h_gmail) hipHostFree(ctx->grp.h_gmail);
+	if (ctx->grp.d_S) hipFree(ctx->grp.d_S);
 	if (ctx->shadow.S) hipFree(ctx->shadow.S);
 	if (ctx->ntt_cache) {
 		bn::ntt_bs_cache *nc = (bn::ntt_bs_cache *)ctx->ntt_cache;
@@ -1043,7 +1049,7 @@ int bn_copy_d2d(bn_ctx *ctx, const void *d_src, uint64_t src_len, void *d_dst, u
 	}
 	if (!group_independent(ctx, d_src, src_len, false) || !group_independent(ctx, d_dst, dst_len, true)) BN_FLUSH(ctx); // (ordered behind the deferred folds / hosted provers it touches)
 	group_note_write(ctx, d_dst, dst_len); // (sums computed ahead from what is overwritten are stale)
-	if (ctx->lazy_fold && !ctx->pend.active && ctx->pend_copies.size() < (size_t)bn::kFoldBatchMax) {
+	if (ctx->lazy_fold && !ctx->pend.active && ctx->pend_copies.size() < (size_t)bn::kFoldCallMax) { // (one per multilinear of the widest prover's first fold)
 		// deferred: a fold into d_dst may absorb it (see bn_ctx::pending_copy)
 		ctx->pend_copies.push_back({d_src, d_dst, src_len});
 		return BN_OK;
@@ -1176,11 +1182,22 @@ int bn_extrapolate_line_batch_scaled(bn_ctx *ctx, void *const *d_evals_0, const 
 {
 	BN_REQUIRE(ctx && z && d_evals_0 && d_evals_1, "null argument");
 	BN_ENTER(ctx);
-	BN_REQUIRE(count <= (uint32_t)bn::kFoldBatchMax, "too many slices in one extrapolate_line batch");
-	BN_REQUIRE(scale_mask == 0 || (hi_scale && (n & 1) == 0 && (count >= 32 || (scale_mask >> count) == 0)),
-	           "scaled fold: needs a scale, an even length and a mask within the batch");
+	BN_REQUIRE(count <= (uint32_t)bn::kFoldCallMax, "too many slices in one extrapolate_line batch");
+	BN_REQUIRE(scale_mask == 0 || (hi_scale && (n & 1) == 0 && count <= 32 && (count >= 32 || (scale_mask >> count) == 0)),
+	           "scaled fold: needs a scale, an even length and a mask within the batch (at most 32 slices)");
 	if (count == 0) return BN_OK;
 	ctx->mirror.valid = false;
+	// A batch wider than one launch's (a prover with more than kFoldBatchMax multilinears, piop/prove.rs:262-287) is the claim
+	// groups' (abi_group.cpp: deferred whole, folded by the jobs of the next evaluation's launch); where they do not apply it is
+	// the same folds in pieces of kFoldBatchMax, each through the machinery below.
+	if (count > (uint32_t)bn::kFoldBatchMax && !group_fold_applies(ctx, count, scale_mask)) {
+		for (uint32_t at = 0; at < count; at += (uint32_t)bn::kFoldBatchMax) {
+			const uint32_t c = count - at < (uint32_t)bn::kFoldBatchMax ? count - at : (uint32_t)bn::kFoldBatchMax;
+			const int rc_p = bn_extrapolate_line_batch_scaled(ctx, d_evals_0 + at, d_evals_1 + at, c, n, z, 0, nullptr);
+			if (rc_p) return rc_p;
+		}
+		return BN_OK;
+	}
 	// A fold is already deferred, the round evaluation of its output has just been answered from the precomputed sums of
 	// a two-round launch (abi_kernels.cpp), and this batch folds that output in place: keep BOTH -- the next round
 	// evaluation folds twice in one pass (kernels_foldeval8.hip).
@@ -1207,7 +1224,7 @@ int bn_extrapolate_line_batch_scaled(bn_ctx *ctx, void *const *d_evals_0, const 
 	}
 	// deferred copies whose destination is one of the evals_0 are absorbed (every one of them must
 	// be, otherwise they all run now, in issue order)
-	const void *src0[bn::kFoldBatchMax];
+	const void *src0[bn::kFoldCallMax];
 	for (uint32_t i = 0; i < count; i++) src0[i] = d_evals_0[i];
 	if (!ctx->pend_copies.empty() && !ctx->pend.active) {
 		size_t absorbed = 0;

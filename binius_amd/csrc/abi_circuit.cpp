@@ -535,10 +535,12 @@ int circuit_ip_run(bn_ctx *ctx, const ip_collector &col, uint64_t n, const void 
 	}
 	size_t at = 0;
 	while (at < jobs.size()) {
-		bn::group_job gj[bn::kGroupMaxJobs];
+		// (at most 32 jobs per launch: their 64 sums come back through the 64 value slots of the context's mailbox)
+		constexpr uint32_t kIpJobsPerLaunch = 32;
+		bn::group_job gj[kIpJobsPerLaunch];
 		uint32_t nj = 0, n_ip = 0;
 		const size_t first = at;
-		while (at < jobs.size() && nj < (uint32_t)bn::kGroupMaxJobs) {
+		while (at < jobs.size() && nj < kIpJobsPerLaunch) {
 			bn::group_job &g = gj[nj];
 			g = bn::group_job{};
 			g.kind = 2;
@@ -564,7 +566,11 @@ int circuit_ip_run(bn_ctx *ctx, const ip_collector &col, uint64_t n, const void 
 		const uint64_t seq = ++ctx->mail_seq;
 		{
 			prof_scope ps(ctx, BN_PROF_ROUND_EVAL_MFMA);
-			const hipError_t e = bn::launch_group(ctx->stream, ctx->n_cu, gj, nj, 2 * nj, ctx->d_result, ctx->d_mail, ctx->d_ticket, seq);
+			const int rc_a = group_res_alloc(ctx);
+			if (rc_a) return rc_a;
+			bn::group_tables *h_tb = (bn::group_tables *)ctx->grp.h_tables;
+			const bn::group_tables *d_tb = (const bn::group_tables *)ctx->grp.d_tables;
+			const hipError_t e = bn::launch_group(ctx->stream, ctx->n_cu, gj, nj, 2 * nj, ctx->d_result, ctx->d_mail, ctx->d_mail, ctx->d_ticket, seq, h_tb->jobs, d_tb->jobs);
 			if (e != hipSuccess) return bn::hip_fail(e, "launch_group (inner products of compiled circuits)");
 		}
 		volatile uint64_t *seqw = &ctx->h_mail[64].lo;

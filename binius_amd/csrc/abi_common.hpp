@@ -115,6 +115,8 @@ int circuit_multipass_sum(bn_ctx *ctx, const bn_expr *e, const void *const *rows
 int flush_legacy(bn_ctx *ctx, bool keep_tail = false, bool publish_tiny = false, bool keep_shadow = false);
 // is any of that state alive?
 bool legacy_state_active(const bn_ctx *ctx);
+// the pinned tables / accumulator slots / value mailbox of the group kernel's launches (allocated on first use)
+int group_res_alloc(bn_ctx *ctx);
 // a batch of folds can be deferred on the group path
 bool group_fold_applies(const bn_ctx *ctx, uint32_t count, uint32_t scale_mask);
 // [p, p + n) touches none of the arrays a deferred group fold reads or writes

@@ -25,35 +25,74 @@
 // what eager execution leaves -- and forgets the sums computed ahead.  A session is only a description (pointers and claim
 // indices); a stale one costs a wasted evaluation, never a wrong answer: sums computed ahead are used only for a request that
 // names exactly the arrays they were computed from, and die with any write into those arrays.
+#include <algorithm>
+#include <unordered_map>
+
 #include "abi_common.hpp"
 #include "hostmul.hpp"
 
 namespace bnabi {
 
 namespace {
-constexpr uint32_t kMaxArrays = 32;
+constexpr uint32_t kMaxArrays = (uint32_t)bn::kGroupMaxArrays; // multilinears of a prover (keccak's PCS prover has >= 100 of one size)
+constexpr uint32_t kMaxClaims = (uint32_t)bn::kGroupMaxClaims;
 constexpr size_t kMaxSessions = 16;
 
 inline const char *at(const void *p, uint64_t elems) { return (const char *)p + elems * sizeof(f128); }
 
 bool fold_touches(const bn_ctx::group_fold &f, const void *p, uint64_t n)
 {
+	if (!f.hull_hits(p, n)) return false;
 	for (uint32_t i = 0; i < f.count; i++)
 		if (ranges_overlap(p, n, f.x0[i], f.n) || ranges_overlap(p, n, f.x1[i], f.n) || ranges_overlap(p, n, f.src0[i], f.n)) return true;
 	return false;
 }
 
+// a deferred fold as plain launches (kFoldBatchMax arrays each: the batch rides in the kernel arguments)
 int launch_fold(bn_ctx *ctx, const bn_ctx::group_fold &f)
 {
-	bn::fold_batch fb{};
-	for (uint32_t i = 0; i < f.count; i++) {
-		fb.x0[i] = f.x0[i];
-		fb.x1[i] = f.x1[i];
-		fb.src0[i] = f.src0[i] != f.x0[i] ? f.src0[i] : nullptr; // (absorbed copy: read there, write here)
+	for (uint32_t at = 0; at < f.count; at += (uint32_t)bn::kFoldBatchMax) {
+		const uint32_t c = std::min<uint32_t>(f.count - at, (uint32_t)bn::kFoldBatchMax);
+		bn::fold_batch fb{};
+		for (uint32_t i = 0; i < c; i++) {
+			fb.x0[i] = f.x0[at + i];
+			fb.x1[i] = f.x1[at + i];
+			fb.src0[i] = f.src0[at + i] != f.x0[at + i] ? f.src0[at + i] : nullptr; // (absorbed copy: read there, write here)
+		}
+		prof_scope ps(ctx, BN_PROF_FOLD);
+		BN_HIP(bn::launch_extrapolate_line_batch(ctx->stream, ctx->n_cu, fb, c, f.n, f.z));
 	}
-	prof_scope ps(ctx, BN_PROF_FOLD);
-	BN_HIP(bn::launch_extrapolate_line_batch(ctx->stream, ctx->n_cu, fb, f.count, f.n, f.z));
 	ctx->grp.flushed_folds++;
+	return BN_OK;
+}
+
+// the pinned tables, accumulator slots and value mailbox of the group launches (allocated with the first of them)
+int res_alloc(bn_ctx *ctx)
+{
+	auto &g = ctx->grp;
+	if (g.h_tables && g.d_S && g.h_gmail) return BN_OK;
+	if (!g.h_tables) {
+		if (hipHostMalloc(&g.h_tables, sizeof(bn::group_tables), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+			(void)hipGetLastError();
+			g.h_tables = nullptr;
+			return bn::fail(BN_ERR_ALLOC, "claim groups: pinned job table");
+		}
+		std::memset(g.h_tables, 0, sizeof(bn::group_tables));
+		BN_HIP(hipHostGetDevicePointer(&g.d_tables, g.h_tables, 0));
+	}
+	if (!g.h_gmail) {
+		if (hipHostMalloc((void **)&g.h_gmail, sizeof(f128) * bn::kGroupMaxSlots, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+			(void)hipGetLastError();
+			g.h_gmail = nullptr;
+			return bn::fail(BN_ERR_ALLOC, "claim groups: pinned value mailbox");
+		}
+		std::memset(g.h_gmail, 0, sizeof(f128) * bn::kGroupMaxSlots);
+		BN_HIP(hipHostGetDevicePointer((void **)&g.d_gmail, g.h_gmail, 0));
+	}
+	if (!g.d_S) {
+		BN_HIP(hipMalloc((void **)&g.d_S, sizeof(f128) * bn::kGroupMaxSlots));
+		BN_HIP(hipMemsetAsync(g.d_S, 0, sizeof(f128) * bn::kGroupMaxSlots, ctx->stream));
+	}
 	return BN_OK;
 }
 
@@ -61,6 +100,7 @@ void drop_predictions_touching(bn_ctx *ctx, const void *p, uint64_t n)
 {
 	for (auto &s : ctx->grp.sessions) {
 		if (!s.pre_valid) continue;
+		if (!((const char *)p < s.pre_hull_e && s.pre_hull_b < (const char *)p + n * sizeof(f128))) continue;
 		for (uint32_t i = 0; i < s.m && s.pre_valid; i++)
 			if (ranges_overlap(p, n, s.pre_lo[i], s.pre_row_len) || ranges_overlap(p, n, s.pre_hi[i], s.pre_row_len)) s.pre_valid = false;
 	}
@@ -71,7 +111,7 @@ struct request {
 	uint32_t m = 0, k = 0;
 	uint64_t row_len = 0;
 	const void *lo[kMaxArrays] = {}, *hi[kMaxArrays] = {};
-	uint8_t pa[kMaxArrays] = {}, pb[kMaxArrays] = {};
+	uint16_t pa[kMaxClaims] = {}, pb[kMaxClaims] = {};
 	struct term {
 		uint32_t value, claim, at_inf;
 		f128 coeff;
@@ -92,12 +132,14 @@ bool parse(const bn_memmap *maps, uint32_t n_maps, const bn_kop *ops, uint32_t n
 		p = (const char *)maps[sl.buf].d_data + sl.off * sizeof(f128);
 		return true;
 	};
+	std::unordered_map<uint32_t, uint32_t> claim_index; // (a << 16 | b) -> claim
 	auto claim_of = [&](uint32_t a, uint32_t b) -> int {
-		for (uint32_t c = 0; c < rq.k; c++)
-			if (rq.pa[c] == a && rq.pb[c] == b) return (int)c;
-		if (rq.k >= kMaxArrays) return -1;
-		rq.pa[rq.k] = (uint8_t)a;
-		rq.pb[rq.k] = (uint8_t)b;
+		const auto it = claim_index.find(a << 16 | b);
+		if (it != claim_index.end()) return (int)it->second;
+		if (rq.k >= kMaxClaims) return -1;
+		rq.pa[rq.k] = (uint16_t)a;
+		rq.pb[rq.k] = (uint16_t)b;
+		claim_index.emplace(a << 16 | b, rq.k);
 		return (int)rq.k++;
 	};
 	// first pass: the arrays (every ADD of two mapped halves into a whole Local buffer) and the values
@@ -125,6 +167,10 @@ bool parse(const bn_memmap *maps, uint32_t n_maps, const bn_kop *ops, uint32_t n
 		}
 	}
 	if (rq.m == 0 || rq.row_len == 0) return false;
+	// two arrays may not alias each other (a fold writes one while a job reads the other)
+	std::unordered_map<const void *, uint32_t> by_hi, by_lo;
+	for (uint32_t i = 0; i < rq.m; i++)
+		if (!by_hi.emplace(rq.hi[i], i).second || !by_lo.emplace(rq.lo[i], i).second) return false;
 	// second pass, in order: a sum over Locals must come after the ADDs that define them
 	std::vector<char> defined(n_maps, 0);
 	for (uint32_t o = 0; o < n_ops; o++) {
@@ -149,10 +195,9 @@ bool parse(const bn_memmap *maps, uint32_t n_maps, const bn_kop *ops, uint32_t n
 			} else {
 				const char *p = nullptr;
 				if (!plain(sl, p)) return false;
-				arr[j] = -1;
-				for (uint32_t i = 0; i < rq.m; i++)
-					if (rq.hi[i] == p) arr[j] = (int)i; // the evaluation at 1 is the array's upper half
-				if (arr[j] < 0) return false;
+				const auto it = by_hi.find(p); // the evaluation at 1 is the array's upper half
+				if (it == by_hi.end()) return false;
+				arr[j] = (int)it->second;
 			}
 		}
 		if (n_local == 1) return false;
@@ -162,11 +207,7 @@ bool parse(const bn_memmap *maps, uint32_t n_maps, const bn_kop *ops, uint32_t n
 	}
 	for (uint32_t r = 0; r < n_ret; r++)
 		if (ret_values[r] >= rq.n_values) return false;
-	// two arrays may not alias each other (a fold writes one while a job reads the other)
-	for (uint32_t i = 0; i < rq.m; i++)
-		for (uint32_t j = 0; j < i; j++)
-			if (rq.lo[i] == rq.lo[j] || rq.hi[i] == rq.hi[j]) return false;
-	return rq.k > 0 && rq.k <= (uint32_t)bn::kGroupMaxJobs; // (a launch carries at most that many jobs: 64 accumulator slots)
+	return rq.k > 0 && rq.k <= kMaxClaims; // (two accumulator slots per claim, bn::kGroupMaxSlots per launch)
 }
 
 void answer(const request &rq, const f128 *raw, const uint32_t *ret_values, uint32_t n_ret, bn_f128 *h_out)
@@ -180,47 +221,64 @@ void answer(const request &rq, const f128 *raw, const uint32_t *ret_values, uint
 	for (uint32_t r = 0; r < n_ret; r++) h_out[r] = bn_f128{vals[ret_values[r]].lo, vals[ret_values[r]].hi};
 }
 
-// where array (lo, hi, row_len) comes out of a deferred fold: the batch and the index inside it
+// where array (lo, hi, row_len) comes out of a deferred fold: the batch and the index inside it.  The deferred folds are disjoint
+// (group_defer_fold), so an address is the output of at most one of them and the input of at most one: two hash maps, built once
+// per evaluation (a prover of the keccak width names > 100 arrays per call).
 struct fold_ref {
 	int f = -1, j = -1;
 };
-fold_ref find_output(const bn_ctx *ctx, const void *lo, const void *hi, uint64_t row_len)
-{
-	for (size_t f = 0; f < ctx->grp.folds.size(); f++) {
-		const auto &g = ctx->grp.folds[f];
-		if (g.n != 2 * row_len) continue;
-		for (uint32_t j = 0; j < g.count; j++)
-			if (g.x0[j] == lo && (const void *)at(lo, row_len) == hi) return fold_ref{(int)f, (int)j};
+struct fold_index {
+	std::unordered_map<const void *, fold_ref> by_out, by_in;
+	void build(const bn_ctx *ctx)
+	{
+		by_out.clear();
+		by_in.clear();
+		for (size_t f = 0; f < ctx->grp.folds.size(); f++) {
+			const auto &g = ctx->grp.folds[f];
+			for (uint32_t j = 0; j < g.count; j++) {
+				by_out.emplace(g.x0[j], fold_ref{(int)f, (int)j});
+				by_in.emplace(g.src0[j], fold_ref{(int)f, (int)j});
+			}
+		}
 	}
-	return fold_ref{};
-}
-fold_ref find_input(const bn_ctx *ctx, const void *lo, const void *hi, uint64_t row_len)
-{
-	for (size_t f = 0; f < ctx->grp.folds.size(); f++) {
-		const auto &g = ctx->grp.folds[f];
-		if (g.n != row_len) continue;
-		for (uint32_t j = 0; j < g.count; j++)
-			if (g.src0[j] == lo && g.x1[j] == hi) return fold_ref{(int)f, (int)j};
+	fold_ref output(const bn_ctx *ctx, const void *lo, const void *hi, uint64_t row_len) const
+	{
+		const auto it = by_out.find(lo);
+		if (it == by_out.end() || ctx->grp.folds[it->second.f].n != 2 * row_len || (const void *)at(lo, row_len) != hi) return fold_ref{};
+		return it->second;
 	}
-	return fold_ref{};
-}
+	fold_ref input(const bn_ctx *ctx, const void *lo, const void *hi, uint64_t row_len) const
+	{
+		const auto it = by_in.find(lo);
+		if (it == by_in.end()) return fold_ref{};
+		const auto &g = ctx->grp.folds[it->second.f];
+		if (g.n != row_len || g.x1[it->second.j] != hi) return fold_ref{};
+		return it->second;
+	}
+};
 
 // the jobs of one prover's evaluation: arrays (lo, hi) of row_len points each, array i coming out of deferred fold ref[i]
 // (f < 0: it is up to date in memory); appends the jobs (slot = slot0 + 2 * claim).
 //
 //   * a claim whose two arrays both wait for their fold (one challenge) and are not yet folded by another job: fold + evaluate
 //     (kind 0) -- a matching of the claim graph, the claims over arrays of degree one first (a prover with disjoint claims: all);
+//   * a claim ONE of whose arrays still waits while the other is folded by a kind-0 / kind-3 job or is up to date: fold that array
+//     and evaluate against the other as it is (kind 4) -- piop::prove's shape, every committed multilinear of a size against the
+//     few ring-switch transparents of that size (piop/prove.rs:262-287): one kind-0 job per transparent, a kind-4 job for
+//     every other committed column;
 //   * the arrays still waiting after that: fold only (kind 3), two per job;
-//   * every other claim: evaluate (kind 1) -- and where it reads an array that a job of THIS launch folds, the jobs concerned form
-//     a CHAIN: the same workgroups run the folding jobs and then the evaluating ones on the same tiles, so that a workgroup only
-//     ever reads back what it has written itself (kernels_group.hip).  Everything else stays a job of its own.
+//   * every other claim: evaluate (kind 1);
+//   * where a job reads an array that a job of THIS launch folds, the jobs concerned form a CHAIN -- folding jobs, then the
+//     kind-4 jobs, then the evaluating ones: the same workgroups run them on the same tiles, so that a workgroup only ever reads
+//     back what it has written itself (kernels_group.hip; `acquire` on the first job of the second and of the third part).
+//     Everything else stays a job of its own.
 //
 // false (nothing appended): more than `room` jobs -- the caller falls back to plan_prefold.
-bool plan_chained(const bn_ctx *ctx, uint32_t m, uint32_t k, const uint8_t *pa, const uint8_t *pb, const void *const *lo, const void *const *hi, uint64_t row_len,
+bool plan_chained(const bn_ctx *ctx, uint32_t m, uint32_t k, const uint16_t *pa, const uint16_t *pb, const void *const *lo, const void *const *hi, uint64_t row_len,
                   const fold_ref *ref, uint32_t slot0, size_t room, std::vector<bn::group_job> &jobs, uint64_t &n_fused, uint64_t &n_fold_only, uint64_t &n_chains)
 {
 	const auto &folds = ctx->grp.folds;
-	uint32_t deg[kMaxArrays] = {};
+	std::vector<uint32_t> deg(m, 0);
 	for (uint32_t c = 0; c < k; c++) {
 		deg[pa[c]]++;
 		deg[pb[c]]++;
@@ -237,15 +295,36 @@ bool plan_chained(const bn_ctx *ctx, uint32_t m, uint32_t k, const uint8_t *pa, 
 			fused_claim[c] = 1;
 			matched[pa[c]] = matched[pb[c]] = 1;
 		}
-	// read_back[i]: array i is folded by this launch and read by an evaluate job of it
+	// half[c]: 0 = no, 1 = the claim folds pa[c] and reads pb[c] as it is, 2 = the other way round; halved[i]: array i is folded by
+	// such a job.  The array read as it is must be final when the kind-4 jobs run: matched (folded by a kind-0 job, in front) or
+	// up to date -- neither is ever folded by a kind-4 job itself.  (After the matching every claim that is left has a matched
+	// or up-to-date array unless its two folds differ in their challenge.)
+	std::vector<char> half(k, 0), halved(m, 0);
+	for (uint32_t c = 0; c < k; c++) {
+		if (fused_claim[c] || pa[c] == pb[c]) continue;
+		for (int side = 0; side < 2 && !half[c]; side++) {
+			const uint32_t a = side ? pb[c] : pa[c], b = side ? pa[c] : pb[c];
+			if (ref[a].f < 0 || matched[a] || halved[a]) continue;
+			if (!(matched[b] || ref[b].f < 0)) continue;
+			half[c] = (char)(1 + side);
+			halved[a] = 1;
+		}
+	}
+	// read_back[i]: array i is folded by this launch and read as it is by a kind-4 or a kind-1 job of it
 	std::vector<char> read_back(m, 0);
-	for (uint32_t c = 0; c < k; c++)
-		if (!fused_claim[c])
-			for (uint32_t i : {(uint32_t)pa[c], (uint32_t)pb[c]})
-				if (ref[i].f >= 0) read_back[i] = 1;
+	for (uint32_t c = 0; c < k; c++) {
+		if (fused_claim[c]) continue;
+		if (half[c]) {
+			const uint32_t b = half[c] == 1 ? pb[c] : pa[c];
+			if (ref[b].f >= 0) read_back[b] = 1;
+			continue;
+		}
+		for (uint32_t i : {(uint32_t)pa[c], (uint32_t)pb[c]})
+			if (ref[i].f >= 0) read_back[i] = 1;
+	}
 	std::vector<uint32_t> left[2]; // arrays to fold only: [1] = read back (chain), [0] = not
 	for (uint32_t i = 0; i < m; i++)
-		if (ref[i].f >= 0 && !matched[i]) left[read_back[i] ? 1 : 0].push_back(i);
+		if (ref[i].f >= 0 && !matched[i] && !halved[i]) left[read_back[i] ? 1 : 0].push_back(i);
 	auto fold_only_jobs = [&](const std::vector<uint32_t> &v) {
 		// (two arrays per job where they share the challenge)
 		size_t n = 0;
@@ -264,7 +343,7 @@ bool plan_chained(const bn_ctx *ctx, uint32_t m, uint32_t k, const uint8_t *pa, 
 		j.out[sd] = f.x0[ref[i].j];
 		j.z = f.z;
 	};
-	std::vector<bn::group_job> chain, alone;
+	std::vector<bn::group_job> chain_w, chain_h, chain_e, alone;
 	for (uint32_t c = 0; c < k; c++) {
 		if (!fused_claim[c]) continue;
 		bn::group_job j{};
@@ -273,7 +352,7 @@ bool plan_chained(const bn_ctx *ctx, uint32_t m, uint32_t k, const uint8_t *pa, 
 		j.slot = slot0 + 2 * c;
 		fold_side(j, 0, pa[c]);
 		fold_side(j, 1, pb[c]);
-		(read_back[pa[c]] || read_back[pb[c]] ? chain : alone).push_back(j);
+		(read_back[pa[c]] || read_back[pb[c]] ? chain_w : alone).push_back(j);
 		n_fused++;
 	}
 	for (int rb = 0; rb < 2; rb++)
@@ -285,12 +364,24 @@ bool plan_chained(const bn_ctx *ctx, uint32_t m, uint32_t k, const uint8_t *pa, 
 			const bool two = q + 1 < left[rb].size() && folds[ref[left[rb][q]].f].z == folds[ref[left[rb][q + 1]].f].z;
 			if (two) fold_side(j, 1, left[rb][q + 1]);
 			q += two ? 2 : 1;
-			(rb ? chain : alone).push_back(j);
+			(rb ? chain_w : alone).push_back(j);
 			n_fold_only++;
 		}
-	bool first_reader = true;
 	for (uint32_t c = 0; c < k; c++) {
-		if (fused_claim[c]) continue;
+		if (!half[c]) continue;
+		const uint32_t a = half[c] == 1 ? pa[c] : pb[c], b = half[c] == 1 ? pb[c] : pa[c];
+		bn::group_job j{};
+		j.kind = 4;
+		j.n = row_len;
+		j.slot = slot0 + 2 * c;
+		fold_side(j, 0, a);
+		j.x0[1] = lo[b];
+		j.x1[1] = hi[b];
+		(ref[b].f >= 0 || read_back[a] ? chain_h : alone).push_back(j);
+		n_fused++;
+	}
+	for (uint32_t c = 0; c < k; c++) {
+		if (fused_claim[c] || half[c]) continue;
 		const uint32_t a = pa[c], b = pb[c];
 		bn::group_job j{};
 		j.kind = 1;
@@ -300,29 +391,30 @@ bool plan_chained(const bn_ctx *ctx, uint32_t m, uint32_t k, const uint8_t *pa, 
 		j.x1[0] = hi[a];
 		j.x0[1] = lo[b];
 		j.x1[1] = hi[b];
-		if (ref[a].f >= 0 || ref[b].f >= 0) {
-			j.acquire = first_reader ? 1 : 0;
-			first_reader = false;
-			chain.push_back(j);
-		} else {
-			alone.push_back(j);
-		}
+		(ref[a].f >= 0 || ref[b].f >= 0 ? chain_e : alone).push_back(j);
 	}
-	if (!chain.empty()) {
-		chain[0].chain = (uint32_t)chain.size() - 1;
-		jobs.insert(jobs.end(), chain.begin(), chain.end());
-		n_chains++;
+	if (!chain_w.empty() || !chain_h.empty() || !chain_e.empty()) {
+		// (a reading part's first job waits for the workgroup's own stores of everything in front of it -- unless nothing is)
+		if (!chain_h.empty() && !chain_w.empty()) chain_h[0].acquire = 1;
+		if (!chain_e.empty() && (!chain_w.empty() || !chain_h.empty())) chain_e[0].acquire = 1;
+		const size_t at = jobs.size();
+		jobs.insert(jobs.end(), chain_w.begin(), chain_w.end());
+		jobs.insert(jobs.end(), chain_h.begin(), chain_h.end());
+		jobs.insert(jobs.end(), chain_e.begin(), chain_e.end());
+		jobs[at].chain = (uint32_t)(jobs.size() - at) - 1;
+		if (jobs[at].chain) n_chains++;
 	}
 	jobs.insert(jobs.end(), alone.begin(), alone.end());
 	return true;
 }
 
-// the fallback (more jobs than a launch carries): only claims over arrays of degree one are fused; every other waiting array is
-// folded by a plain launch in front (prefold)
-void plan_prefold(const bn_ctx *ctx, uint32_t m, uint32_t k, const uint8_t *pa, const uint8_t *pb, const void *const *lo, const void *const *hi, uint64_t row_len,
+// without chains (arrays below the size where chains pay, or more jobs than a launch carries): claims over arrays of degree one
+// are fused (kind 0); a claim over an array of degree one and a shared one folds the former on the way (kind 4) -- the shared
+// array, like every other waiting array, is folded by a plain launch in front (prefold)
+void plan_prefold(const bn_ctx *ctx, uint32_t m, uint32_t k, const uint16_t *pa, const uint16_t *pb, const void *const *lo, const void *const *hi, uint64_t row_len,
                   const fold_ref *ref, uint32_t slot0, std::vector<bn::group_job> &jobs, std::vector<char> &prefold /*[m]*/, uint64_t &n_fused)
 {
-	uint32_t deg[kMaxArrays] = {};
+	std::vector<uint32_t> deg(m, 0);
 	for (uint32_t c = 0; c < k; c++) {
 		deg[pa[c]]++;
 		deg[pb[c]]++;
@@ -333,7 +425,8 @@ void plan_prefold(const bn_ctx *ctx, uint32_t m, uint32_t k, const uint8_t *pa, 
 		bn::group_job j{};
 		j.n = row_len;
 		j.slot = slot0 + 2 * c;
-		if (a != b && deg[a] == 1 && deg[b] == 1 && ref[a].f >= 0 && ref[b].f >= 0 && ctx->grp.folds[ref[a].f].z == ctx->grp.folds[ref[b].f].z) {
+		auto waits_alone = [&](uint32_t i) { return deg[i] == 1 && ref[i].f >= 0; };
+		if (a != b && waits_alone(a) && waits_alone(b) && ctx->grp.folds[ref[a].f].z == ctx->grp.folds[ref[b].f].z) {
 			const auto &fa = ctx->grp.folds[ref[a].f], &fb = ctx->grp.folds[ref[b].f];
 			j.kind = 0;
 			j.z = fa.z;
@@ -344,6 +437,19 @@ void plan_prefold(const bn_ctx *ctx, uint32_t m, uint32_t k, const uint8_t *pa, 
 			j.x1[1] = fb.x1[ref[b].j];
 			j.out[1] = fb.x0[ref[b].j];
 			fused_arr[a] = fused_arr[b] = 1;
+			n_fused++;
+		} else if (a != b && (waits_alone(a) || waits_alone(b))) {
+			// (the other array is shared, or up to date, or waits under another challenge: final by the time this launch runs)
+			const uint32_t own = waits_alone(a) ? a : b, other = own == a ? b : a;
+			const auto &fo = ctx->grp.folds[ref[own].f];
+			j.kind = 4;
+			j.z = fo.z;
+			j.x0[0] = fo.src0[ref[own].j];
+			j.x1[0] = fo.x1[ref[own].j];
+			j.out[0] = fo.x0[ref[own].j];
+			j.x0[1] = lo[other];
+			j.x1[1] = hi[other];
+			fused_arr[own] = 1;
 			n_fused++;
 		} else {
 			j.kind = 1;
@@ -409,14 +515,10 @@ void record(bn_ctx *ctx, bn_ctx::group_session &s, const request &rq)
 	s.m = rq.m;
 	s.k = rq.k;
 	s.row_len = rq.row_len;
-	for (uint32_t i = 0; i < rq.m; i++) {
-		s.lo[i] = rq.lo[i];
-		s.hi[i] = rq.hi[i];
-	}
-	for (uint32_t c = 0; c < rq.k; c++) {
-		s.pa[c] = rq.pa[c];
-		s.pb[c] = rq.pb[c];
-	}
+	s.lo.assign(rq.lo, rq.lo + rq.m);
+	s.hi.assign(rq.hi, rq.hi + rq.m);
+	s.pa.assign(rq.pa, rq.pa + rq.k);
+	s.pb.assign(rq.pb, rq.pb + rq.k);
 	s.pre_valid = false;
 	s.stamp = ++ctx->grp.stamp;
 }
@@ -467,10 +569,13 @@ int unhost(bn_ctx *ctx, bn_ctx::group_session &s)
 		bn::group_writeback_args a{};
 		a.count = s.m;
 		a.n0 = (uint32_t)s.h_n0;
+		// (the stream is idle: neither the staging's write-back half nor the write-back's pointer table is being read)
+		bn::group_tables *tb = (bn::group_tables *)ctx->grp.h_tables;
 		for (uint32_t j = 0; j < s.m; j++) {
 			std::memcpy(stg + 2 * (size_t)s.h_n0 * j, s.hy[j].data(), (size_t)s.h_n0 * 16);
-			a.out[j] = s.h_out[j];
+			tb->writeback.out[j] = s.h_out[j];
 		}
+		a.ptrs = &((const bn::group_tables *)ctx->grp.d_tables)->writeback;
 		a.staging = (const f128 *)((const char *)ctx->grp.d_stage + bn::kGroupTailMaxElems * sizeof(f128));
 		a.phi_inv = (const uint4 *)((const char *)ctx->d_phi + 512 * sizeof(f128));
 		__atomic_thread_fence(__ATOMIC_SEQ_CST);
@@ -505,7 +610,7 @@ int unhost_all(bn_ctx *ctx)
 
 void host_answer(bn_ctx *ctx, const bn_ctx::group_session &s, const request &rq, const uint32_t *ret_values, uint32_t n_ret, bn_f128 *h_out)
 {
-	f128 raw[64];
+	std::vector<f128> raw(2 * (size_t)rq.k);
 	const size_t half = (size_t)(s.h_len / 2);
 	for (uint32_t c = 0; c < rq.k; c++) {
 		bn::hp128 y1, yi;
@@ -513,7 +618,7 @@ void host_answer(bn_ctx *ctx, const bn_ctx::group_session &s, const request &rq,
 		raw[2 * c] = bn::hostpoly_to_tower(y1);
 		raw[2 * c + 1] = bn::hostpoly_to_tower(yi);
 	}
-	answer(rq, raw, ret_values, n_ret, h_out);
+	answer(rq, raw.data(), ret_values, n_ret, h_out);
 	ctx->grp.hosted_evals++;
 	ctx->grp.evals++;
 }
@@ -533,6 +638,8 @@ int wait_mail(bn_ctx *ctx, uint64_t seq)
 }
 } // namespace
 
+int group_res_alloc(bn_ctx *ctx) { return res_alloc(ctx); }
+
 bool legacy_state_active(const bn_ctx *ctx)
 {
 	return ctx->pend.active || ctx->pend2.active || ctx->arm.active || ctx->tail.active || ctx->ht.active || ctx->shadow.valid || ctx->pre.valid ||
@@ -546,6 +653,18 @@ bool group_fold_applies(const bn_ctx *ctx, uint32_t count, uint32_t scale_mask)
 	// (a lone batch of two arrays with nothing else waiting is the single-claim shape: the armed / two-round / host-tail machinery
 	// of abi.cpp keeps it)
 	return g.on || !g.folds.empty() || count != 2;
+}
+
+// `on` (single-claim calls join the group path) lasts as long as something of the group path is alive: it ends with a full flush,
+// and with a selective one that leaves no deferred fold, no hosted prover and no sums computed ahead -- a multi-claim prover that
+// has finished does not pull the single-claim provers after it off their armed / two-round / host-tail machinery
+static void group_settle(bn_ctx *ctx)
+{
+	auto &g = ctx->grp;
+	if (!g.on || !g.folds.empty()) return;
+	for (const auto &s : g.sessions)
+		if ((s.hosted && s.h_len > 1) || s.pre_valid) return; // (a hosted prover folded down to one element has finished: only its write-back is owed)
+	g.on = false;
 }
 
 bool group_independent(const bn_ctx *ctx, const void *p, uint64_t n, bool write)
@@ -562,15 +681,14 @@ static bool host_fold(bn_ctx *ctx, void *const *x0, const void *const *src0, con
 {
 	for (auto &s : ctx->grp.sessions) {
 		if (!s.hosted || s.m != count || s.h_len != 2 * n) continue;
-		int of[kMaxArrays]; // batch index -> session array
+		std::vector<int> of(count, -1); // batch index -> session array
+		std::vector<char> used(s.m, 0);
 		bool ok = true;
-		uint32_t used = 0;
 		for (uint32_t i = 0; i < count && ok; i++) {
-			of[i] = -1;
 			for (uint32_t j = 0; j < s.m; j++)
-				if (!((used >> j) & 1) && src0[i] == s.h_lo[j] && x1[i] == s.h_hi[j]) {
+				if (!used[j] && src0[i] == s.h_lo[j] && x1[i] == s.h_hi[j]) {
 					of[i] = (int)j;
-					used |= 1u << j;
+					used[j] = 1;
 					break;
 				}
 			ok = of[i] >= 0;
@@ -587,6 +705,7 @@ static bool host_fold(bn_ctx *ctx, void *const *x0, const void *const *src0, con
 		if (!ok) return false; // (the caller's general path writes the copies back and folds on the device)
 		if (s.h_levels == 0) {
 			s.h_n0 = n;
+			s.h_out.assign(s.m, nullptr);
 			for (uint32_t i = 0; i < count; i++) s.h_out[of[i]] = x0[i];
 		}
 		const bn::hp128 pz = bn::hostpoly_from_tower(z);
@@ -625,6 +744,7 @@ bool group_host_read(bn_ctx *ctx, const void *p, uint64_t n, bn_f128 *h_dst)
 				const f128 v = bn::hostpoly_to_tower(bn::hp128{s.hy[j][2 * (off + e)], s.hy[j][2 * (off + e) + 1]});
 				h_dst[e] = bn_f128{v.lo, v.hi};
 			}
+			group_settle(ctx); // (finish() of a hosted prover: with its last read nothing of the group path may be alive any more)
 			return true;
 		}
 	}
@@ -640,14 +760,9 @@ static int legacy_to_group(bn_ctx *ctx)
 	if (ctx->pend.active && !ctx->pend2.active && !ctx->pend.scale_mask && !ctx->ht.active && !ctx->tail.active && !(ctx->shadow.valid && ctx->shadow.fold_pending) &&
 	    ctx->pend.count <= kMaxArrays) {
 		const auto &pf = ctx->pend;
-		moved.count = pf.count;
 		moved.n = pf.n;
 		moved.z = pf.z;
-		for (uint32_t i = 0; i < pf.count; i++) {
-			moved.x0[i] = pf.x0[i];
-			moved.x1[i] = pf.x1[i];
-			moved.src0[i] = pf.src0[i];
-		}
+		for (uint32_t i = 0; i < pf.count; i++) moved.push(pf.x0[i], pf.x1[i], pf.src0[i]);
 		ctx->pend.active = false;
 		have = true;
 	}
@@ -667,40 +782,45 @@ int group_defer_fold(bn_ctx *ctx, void *const *x0, const void *const *src0, cons
 	bool clash = false;
 	for (uint32_t i = 0; i < count && !clash; i++)
 		clash = !group_independent(ctx, x0[i], n, true) || !group_independent(ctx, x1[i], n, false) || !group_independent(ctx, src0[i], n, false);
-	// ... and so is one that overlaps ITSELF across arrays (the jobs of a launch run concurrently)
-	for (uint32_t i = 0; i < count && !clash; i++)
-		for (uint32_t j = 0; j < count && !clash; j++) {
-			if (i == j) continue;
-			clash = ranges_overlap(x0[i], n, x0[j], n) || ranges_overlap(x0[i], n, x1[j], n) || ranges_overlap(x0[i], n, src0[j], n);
+	// ... and so is one that overlaps ITSELF: an output against any other range of the batch (the jobs of a launch run concurrently;
+	// an out-of-place fold whose output overlaps its own inputs).  One sweep over the ranges sorted by address: a range overlaps
+	// an earlier one exactly when it starts before the furthest end seen so far.
+	if (!clash) {
+		struct iv {
+			const char *b;
+			bool write;
+		};
+		std::vector<iv> v;
+		v.reserve(3 * (size_t)count);
+		for (uint32_t i = 0; i < count; i++) {
+			v.push_back(iv{(const char *)x0[i], true});
+			v.push_back(iv{(const char *)x1[i], false});
+			if (src0[i] != x0[i]) v.push_back(iv{(const char *)src0[i], false});
 		}
-	for (uint32_t i = 0; i < count && !clash; i++) // (an out-of-place fold whose output overlaps its own inputs)
-		clash = ranges_overlap(x0[i], n, x1[i], n) || (x0[i] != src0[i] && ranges_overlap(x0[i], n, src0[i], n));
+		std::sort(v.begin(), v.end(), [](const iv &a, const iv &b) { return a.b < b.b; });
+		const char *end_any = nullptr, *end_write = nullptr;
+		const size_t bytes = (size_t)n * sizeof(f128);
+		for (const iv &r : v) {
+			if (r.write ? (end_any && r.b < end_any) : (end_write && r.b < end_write)) {
+				clash = true;
+				break;
+			}
+			if (!end_any || r.b + bytes > end_any) end_any = r.b + bytes;
+			if (r.write && (!end_write || r.b + bytes > end_write)) end_write = r.b + bytes;
+		}
+	}
+	bn_ctx::group_fold f;
+	f.n = n;
+	f.z = z;
+	for (uint32_t i = 0; i < count; i++) f.push(x0[i], x1[i], src0[i]);
 	if (clash) {
 		rc = group_flush(ctx);
 		if (rc) return rc;
-		bn_ctx::group_fold f;
-		f.count = count;
-		f.n = n;
-		f.z = z;
-		for (uint32_t i = 0; i < count; i++) {
-			f.x0[i] = x0[i];
-			f.x1[i] = x1[i];
-			f.src0[i] = src0[i];
-		}
 		return launch_fold(ctx, f);
 	}
 	// the sums computed ahead describe arrays BEFORE this fold: a prover that folds without having asked for them has moved on
 	for (uint32_t i = 0; i < count; i++) drop_predictions_touching(ctx, x0[i], n);
-	bn_ctx::group_fold f;
-	f.count = count;
-	f.n = n;
-	f.z = z;
-	for (uint32_t i = 0; i < count; i++) {
-		f.x0[i] = x0[i];
-		f.x1[i] = x1[i];
-		f.src0[i] = src0[i];
-	}
-	g.folds.push_back(f);
+	g.folds.push_back(std::move(f));
 	g.on = true;
 	return BN_OK;
 }
@@ -736,13 +856,13 @@ int group_flush_touching(bn_ctx *ctx, const void *p, uint64_t n, bool publish_ti
 		if (fold_touches(g.folds[i], p, n)) {
 			const bn_ctx::group_fold f = g.folds[i];
 			g.folds.erase(g.folds.begin() + (long)i);
-			if (publish_tiny && (uint64_t)f.count * f.n <= 64 && !ctx->mirror.valid) {
+			if (publish_tiny && (uint64_t)f.count * f.n <= 64 && f.count <= (uint32_t)bn::kFoldBatchMax && !ctx->mirror.valid) {
 				// the caller is a host read of a handful of elements (finish(): one copy_d2h per multilinear, each a stream
 				// synchronisation otherwise): fold and mirror the results into the mailbox in one launch; the reads that follow are
 				// served from there (bn_copy_d2h)
 				const uint64_t seq = ++ctx->mail_seq;
 				prof_scope ps(ctx, BN_PROF_FOLD);
-				BN_HIP(bn::launch_fold_publish(ctx->stream, f.x0, f.src0, f.x1, f.count, (uint32_t)f.n, f.z, ctx->d_mail, seq));
+				BN_HIP(bn::launch_fold_publish(ctx->stream, f.x0.data(), f.src0.data(), f.x1.data(), f.count, (uint32_t)f.n, f.z, ctx->d_mail, seq));
 				ctx->grp.flushed_folds++;
 				ctx->mirror.valid = true;
 				ctx->mirror.host = false;
@@ -758,6 +878,7 @@ int group_flush_touching(bn_ctx *ctx, const void *p, uint64_t n, bool publish_ti
 			i++;
 		}
 	}
+	group_settle(ctx);
 	return BN_OK;
 }
 
@@ -790,7 +911,7 @@ int group_eval(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const bn_kop
 		for (uint32_t i = 0; i < rq.m && same; i++) same = s.pre_lo[i] == rq.lo[i] && s.pre_hi[i] == rq.hi[i];
 		for (uint32_t c = 0; c < rq.k && same; c++) same = s.pa[c] == rq.pa[c] && s.pb[c] == rq.pb[c];
 		if (!same) continue;
-		answer(rq, s.pre_raw, ret_values, n_ret, h_out);
+		answer(rq, s.pre_raw.data(), ret_values, n_ret, h_out);
 		record(ctx, s, rq);
 		g.spec_hits++;
 		g.evals++;
@@ -807,15 +928,18 @@ int group_eval(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const bn_kop
 		if (rc) return rc;
 	}
 	// ---- the request's arrays against the deferred folds
+	fold_index fidx;
+	fidx.build(ctx);
 	fold_ref ref[kMaxArrays];
 	for (uint32_t i = 0; i < rq.m; i++) {
-		ref[i] = find_output(ctx, rq.lo[i], rq.hi[i], rq.row_len);
+		ref[i] = fidx.output(ctx, rq.lo[i], rq.hi[i], rq.row_len);
 		if (ref[i].f < 0 && (!group_independent(ctx, rq.lo[i], rq.row_len, false) || !group_independent(ctx, rq.hi[i], rq.row_len, false))) {
 			// reads what a deferred fold touches, but not as that fold's output: those folds run first
 			rc = group_flush_touching(ctx, rq.lo[i], rq.row_len, false, /*write=*/false);
 			if (!rc) rc = group_flush_touching(ctx, rq.hi[i], rq.row_len, false, /*write=*/false);
 			if (rc) return rc;
-			for (uint32_t q = 0; q <= i; q++) ref[q] = find_output(ctx, rq.lo[q], rq.hi[q], rq.row_len); // (indices moved)
+			fidx.build(ctx); // (indices moved)
+			for (uint32_t q = 0; q <= i; q++) ref[q] = fidx.output(ctx, rq.lo[q], rq.hi[q], rq.row_len);
 		}
 	}
 	// a request that reads what a hosted prover's pending write-back covers (but is not that prover's expected call, answered above)
@@ -824,8 +948,12 @@ int group_eval(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const bn_kop
 		if (!rc) rc = unhost_touching(ctx, rq.hi[i], rq.row_len, false);
 		if (rc) return rc;
 	}
+	rc = group_res_alloc(ctx);
+	if (rc) return rc;
+	bn::group_tables *const h_tb = (bn::group_tables *)g.h_tables;
+	const bn::group_tables *const d_tb = (const bn::group_tables *)g.d_tables;
 	// ---- small enough to finish on the host?  (all arrays contiguous, their deferred folds -- if any -- with one challenge)
-	if (g.ht_max && 2 * rq.row_len <= g.ht_max && (uint64_t)rq.m * 2 * rq.row_len <= bn::kGroupTailMaxElems && stage_alloc(ctx) == BN_OK) {
+	if (g.ht_max && 2 * rq.row_len <= g.ht_max && (uint64_t)rq.m * 2 * rq.row_len <= std::min(g.ht_work, bn::kGroupTailMaxElems) && stage_alloc(ctx) == BN_OK) {
 		bool ok = true, any_fold = false;
 		f128 z{0, 0};
 		for (uint32_t i = 0; i < rq.m && ok; i++) {
@@ -837,6 +965,10 @@ int group_eval(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const bn_kop
 				any_fold = true;
 			}
 		}
+		// (the session first: finding room for it may write another hosted prover's copies back, and that can fail -- before anything
+		// of this hand-over has been enqueued, so that a failure leaves every deferred fold exactly as it was)
+		bn_ctx::group_session *hs = ok ? session_for(ctx, rq, ref, &rc) : nullptr;
+		if (ok && !hs) return rc;
 		if (ok) {
 			bn::group_mirror_args ma{};
 			ma.count = rq.m;
@@ -845,13 +977,16 @@ int group_eval(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const bn_kop
 			for (uint32_t i = 0; i < rq.m; i++) {
 				if (ref[i].f >= 0) {
 					const auto &f = g.folds[ref[i].f];
-					ma.src0[i] = f.src0[ref[i].j];
-					ma.x1[i] = f.x1[ref[i].j];
-					ma.out[i] = f.x0[ref[i].j];
+					h_tb->mirror.src0[i] = f.src0[ref[i].j];
+					h_tb->mirror.x1[i] = f.x1[ref[i].j];
+					h_tb->mirror.out[i] = f.x0[ref[i].j];
 				} else {
-					ma.src0[i] = rq.lo[i];
+					h_tb->mirror.src0[i] = rq.lo[i];
+					h_tb->mirror.x1[i] = nullptr;
+					h_tb->mirror.out[i] = nullptr;
 				}
 			}
+			ma.ptrs = &d_tb->mirror;
 			ma.staging = (f128 *)g.d_stage;
 			ma.phi_tab = (const uint4 *)ctx->d_phi;
 			ma.tag_acc = ctx->d_ht_tag;
@@ -861,10 +996,12 @@ int group_eval(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const bn_kop
 			ma.seq = ++ctx->mail_seq;
 			{
 				prof_scope ps(ctx, BN_PROF_FOLD_EVAL8);
-				BN_HIP(bn::launch_group_mirror(ctx->stream, ma));
+				const hipError_t e = bn::launch_group_mirror(ctx->stream, ma);
+				if (e != hipSuccess) {
+					--ctx->mail_seq; // (nothing was enqueued, nothing is retired)
+					return bn::hip_fail(e, "launch_group_mirror");
+				}
 			}
-			bn_ctx::group_session *hs = session_for(ctx, rq, ref, &rc); // (before the deferred folds it is matched against are retired)
-			if (!hs) return rc;
 			// retire the folds the hand-over performed; arrays of those batches that the request does not name are folded plainly
 			std::vector<std::vector<char>> done(g.folds.size());
 			for (size_t f = 0; f < g.folds.size(); f++) done[f].assign(g.folds[f].count, 0);
@@ -878,12 +1015,7 @@ int group_eval(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const bn_kop
 				rest.n = g.folds[f].n;
 				rest.z = g.folds[f].z;
 				for (uint32_t j = 0; j < g.folds[f].count; j++)
-					if (!done[f][j]) {
-						rest.x0[rest.count] = g.folds[f].x0[j];
-						rest.x1[rest.count] = g.folds[f].x1[j];
-						rest.src0[rest.count] = g.folds[f].src0[j];
-						rest.count++;
-					}
+					if (!done[f][j]) rest.push(g.folds[f].x0[j], g.folds[f].x1[j], g.folds[f].src0[j]);
 				g.folds.erase(g.folds.begin() + (long)f);
 				if (rest.count) {
 					rc = launch_fold(ctx, rest);
@@ -922,10 +1054,9 @@ int group_eval(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const bn_kop
 			hs->h_len = ma.n;
 			hs->h_levels = 0;
 			hs->h_n0 = 0;
-			for (uint32_t i = 0; i < rq.m; i++) {
-				hs->h_lo[i] = rq.lo[i];
-				hs->h_hi[i] = rq.hi[i];
-			}
+			hs->h_lo.assign(rq.lo, rq.lo + rq.m);
+			hs->h_hi.assign(rq.hi, rq.hi + rq.m);
+			hs->h_out.assign(rq.m, nullptr);
 			g.hosted_started++;
 			host_answer(ctx, *hs, rq, ret_values, n_ret, h_out);
 			*handled = true;
@@ -943,8 +1074,8 @@ int group_eval(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const bn_kop
 	struct rider {
 		bn_ctx::group_session *s;
 		uint32_t slot0;
-		fold_ref ref[kMaxArrays];
-		const void *lo[kMaxArrays], *hi[kMaxArrays];
+		std::vector<fold_ref> ref;
+		std::vector<const void *> lo, hi;
 		uint64_t row_len;
 	};
 	std::vector<rider> riders;
@@ -952,13 +1083,16 @@ int group_eval(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const bn_kop
 	if (g.speculate) {
 		for (auto &s : g.sessions) {
 			if (&s == self || s.hosted || s.k == 0 || s.row_len < 2) continue;
-			if (n_claims + s.k > (uint32_t)bn::kGroupMaxJobs || n_slots + 2 * s.k > 64) continue;
+			if (n_claims + s.k > (uint32_t)bn::kGroupMaxJobs || n_slots + 2 * s.k > (uint32_t)bn::kGroupMaxSlots) continue;
 			rider r{};
 			r.s = &s;
 			r.row_len = s.row_len / 2;
+			r.ref.resize(s.m);
+			r.lo.resize(s.m);
+			r.hi.resize(s.m);
 			bool ok = true;
 			for (uint32_t i = 0; i < s.m && ok; i++) {
-				r.ref[i] = find_input(ctx, s.lo[i], s.hi[i], s.row_len);
+				r.ref[i] = fidx.input(ctx, s.lo[i], s.hi[i], s.row_len);
 				ok = r.ref[i].f >= 0 && !consumed[r.ref[i].f][r.ref[i].j];
 				if (ok) {
 					r.lo[i] = g.folds[r.ref[i].f].x0[r.ref[i].j];
@@ -970,7 +1104,7 @@ int group_eval(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const bn_kop
 			n_slots += 2 * s.k;
 			n_claims += s.k;
 			for (uint32_t i = 0; i < s.m; i++) consumed[r.ref[i].f][r.ref[i].j] = 1;
-			riders.push_back(r);
+			riders.push_back(std::move(r));
 		}
 	}
 	// arrays of the participating provers' batches that appear in no request (an unconstrained column) are folded with them, so
@@ -996,12 +1130,12 @@ int group_eval(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const bn_kop
 	// Chains pay where the arrays are large -- the shared arrays' folds cost no pass of their own -- and lose where a launch is
 	// latency-bound: the jobs of a chain run one after the other on one set of workgroups (measured, 2 x 2 claims: 474 against
 	// 537 us at 2^24 elements per array, 152 against 143 at 2^22, 39 against 17 at 2^14; profiles/r05).  Per prover by size.
+	const size_t cap = (size_t)bn::kGroupMaxJobs; // (more jobs than workgroups: the launcher packs them, kernels_group.hip)
 	auto plan_all = [&](bool allow_chains) {
-		const size_t cap = (size_t)bn::kGroupMaxJobs;
 		jobs.clear();
 		n_fused = n_fold_only = n_chains = 0;
 		for (size_t f = 0; f < g.folds.size(); f++) plain[f].assign(g.folds[f].count, 0);
-		auto one = [&](uint32_t m, uint32_t k, const uint8_t *pa, const uint8_t *pb, const void *const *lo, const void *const *hi, uint64_t row_len, const fold_ref *rf,
+		auto one = [&](uint32_t m, uint32_t k, const uint16_t *pa, const uint16_t *pb, const void *const *lo, const void *const *hi, uint64_t row_len, const fold_ref *rf,
 		               uint32_t slot0) {
 			if (jobs.size() > cap) return false;
 			if (allow_chains && row_len >= g.chain_min_rows)
@@ -1014,7 +1148,7 @@ int group_eval(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const bn_kop
 		};
 		if (!one(rq.m, rq.k, rq.pa, rq.pb, rq.lo, rq.hi, rq.row_len, ref, 0)) return false;
 		for (const auto &r : riders)
-			if (!one(r.s->m, r.s->k, r.s->pa, r.s->pb, r.lo, r.hi, r.row_len, r.ref, r.slot0)) return false;
+			if (!one(r.s->m, r.s->k, r.s->pa.data(), r.s->pb.data(), r.lo.data(), r.hi.data(), r.row_len, r.ref.data(), r.slot0)) return false;
 		for (size_t q = 0; q < loose.size();) {
 			const auto &f = g.folds[loose[q].first];
 			if (!allow_chains || f.n / 2 < g.chain_min_rows || f.n < 2 || (f.n & 1)) {
@@ -1039,8 +1173,7 @@ int group_eval(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const bn_kop
 		}
 		return jobs.size() <= cap;
 	};
-	if (!plan_all(true) && !plan_all(false)) return BN_OK; // (the second cannot fail: one job per claim; the eager kernels answer)
-	if ((int)jobs.size() > ctx->n_cu) return BN_OK; // (fewer compute units than jobs; nothing has been enqueued)
+	if (!plan_all(true) && !plan_all(false)) return BN_OK; // (more jobs than a launch's table holds; nothing has been enqueued: the eager kernels answer)
 	{
 		std::vector<bn_ctx::group_fold> parts;
 		std::vector<size_t> part_of;
@@ -1049,14 +1182,9 @@ int group_eval(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const bn_kop
 			part.n = g.folds[f].n;
 			part.z = g.folds[f].z;
 			for (uint32_t j = 0; j < g.folds[f].count; j++)
-				if (plain[f][j]) {
-					part.x0[part.count] = g.folds[f].x0[j];
-					part.x1[part.count] = g.folds[f].x1[j];
-					part.src0[part.count] = g.folds[f].src0[j];
-					part.count++;
-				}
+				if (plain[f][j]) part.push(g.folds[f].x0[j], g.folds[f].x1[j], g.folds[f].src0[j]);
 			if (part.count) {
-				parts.push_back(part);
+				parts.push_back(std::move(part));
 				part_of.push_back(f);
 			}
 		}
@@ -1100,15 +1228,12 @@ int group_eval(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const bn_kop
 	}
 	for (const auto &r : riders) g.spec_jobs += r.s->k;
 	// ---- the launch
-	if (!ctx->s_clean) {
-		BN_HIP(hipMemsetAsync(ctx->d_result, 0, 64 * sizeof(f128), ctx->stream));
-		ctx->s_clean = true;
-	}
-	ctx->mirror.valid = false; // (the launch publishes into the mailbox slots a mirrored tiny fold lives in)
+	ctx->mirror.valid = false;
 	const uint64_t seq = ++ctx->mail_seq;
 	{
 		prof_scope ps(ctx, (n_fused || n_fold_only) ? BN_PROF_FOLD_EVAL_MFMA : BN_PROF_ROUND_EVAL_MFMA); // (a launch without a fold: round 0)
-		const hipError_t e = bn::launch_group(ctx->stream, ctx->n_cu, jobs.data(), (uint32_t)jobs.size(), n_slots, ctx->d_result, ctx->d_mail, ctx->d_ticket, seq);
+		const hipError_t e = bn::launch_group(ctx->stream, ctx->n_cu, jobs.data(), (uint32_t)jobs.size(), n_slots, g.d_S, g.d_gmail, ctx->d_mail, ctx->d_ticket, seq,
+		                                      h_tb->jobs, d_tb->jobs);
 		if (e != hipSuccess) {
 			// nothing was enqueued by the failed launch: the folds its jobs would have performed are still deferred; those a plain
 			// launch in front has performed (the fallback) are retired.  Then everything runs eagerly.
@@ -1119,14 +1244,9 @@ int group_eval(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const bn_kop
 				rest.n = g.folds[f].n;
 				rest.z = g.folds[f].z;
 				for (uint32_t j = 0; j < g.folds[f].count; j++)
-					if (!ran[f][j]) {
-						rest.x0[rest.count] = g.folds[f].x0[j];
-						rest.x1[rest.count] = g.folds[f].x1[j];
-						rest.src0[rest.count] = g.folds[f].src0[j];
-						rest.count++;
-					}
+					if (!ran[f][j]) rest.push(g.folds[f].x0[j], g.folds[f].x1[j], g.folds[f].src0[j]);
 				if (rest.count)
-					g.folds[f] = rest;
+					g.folds[f] = std::move(rest);
 				else
 					g.folds.erase(g.folds.begin() + (long)f);
 			}
@@ -1147,36 +1267,36 @@ int group_eval(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const bn_kop
 		rest.n = g.folds[f].n;
 		rest.z = g.folds[f].z;
 		for (uint32_t j = 0; j < g.folds[f].count; j++)
-			if (!consumed[f][j]) {
-				rest.x0[rest.count] = g.folds[f].x0[j];
-				rest.x1[rest.count] = g.folds[f].x1[j];
-				rest.src0[rest.count] = g.folds[f].src0[j];
-				rest.count++;
-			}
+			if (!consumed[f][j]) rest.push(g.folds[f].x0[j], g.folds[f].x1[j], g.folds[f].src0[j]);
 		if (rest.count)
-			g.folds[f] = rest;
+			g.folds[f] = std::move(rest);
 		else
 			g.folds.erase(g.folds.begin() + (long)f);
 	}
 	g.on = true;
 	rc = wait_mail(ctx, seq);
 	if (rc) return rc;
-	f128 raw[64];
+	std::vector<f128> raw(n_slots);
 	for (uint32_t i = 0; i < n_slots; i++) {
-		raw[i].lo = __atomic_load_n(&ctx->h_mail[i].lo, __ATOMIC_RELAXED);
-		raw[i].hi = __atomic_load_n(&ctx->h_mail[i].hi, __ATOMIC_RELAXED);
+		raw[i].lo = __atomic_load_n(&g.h_gmail[i].lo, __ATOMIC_RELAXED);
+		raw[i].hi = __atomic_load_n(&g.h_gmail[i].hi, __ATOMIC_RELAXED);
 	}
-	answer(rq, raw, ret_values, n_ret, h_out);
+	answer(rq, raw.data(), ret_values, n_ret, h_out);
 	record(ctx, *self, rq);
 	for (const auto &r : riders) {
 		bn_ctx::group_session &s = *r.s;
 		s.pre_valid = true;
 		s.pre_row_len = r.row_len;
-		for (uint32_t i = 0; i < s.m; i++) {
-			s.pre_lo[i] = r.lo[i];
-			s.pre_hi[i] = r.hi[i];
-		}
-		for (uint32_t c = 0; c < 2 * s.k; c++) s.pre_raw[c] = raw[r.slot0 + c];
+		s.pre_lo = r.lo;
+		s.pre_hi = r.hi;
+		s.pre_hull_b = s.pre_hull_e = nullptr;
+		for (uint32_t i = 0; i < s.m; i++)
+			for (const void *q : {r.lo[i], r.hi[i]}) {
+				const char *b0 = (const char *)q, *e0 = b0 + r.row_len * sizeof(f128);
+				if (!s.pre_hull_b || b0 < s.pre_hull_b) s.pre_hull_b = b0;
+				if (!s.pre_hull_e || e0 > s.pre_hull_e) s.pre_hull_e = e0;
+			}
+		s.pre_raw.assign(raw.begin() + r.slot0, raw.begin() + r.slot0 + 2 * s.k);
 	}
 	g.evals++;
 	*handled = true;

@@ -705,6 +705,43 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 	const bool was_clean_or_zeroed = ctx->s_clean;
 	ctx->s_clean = false; // until the finalize kernel of THIS call has re-zeroed the slots it used
 
+	// A kernel with more sums than one finalize step carries (64 accumulator slots, kFinMaxTerms terms -- a prover with more than
+	// sixteen claims whose evaluation the claim groups did not take: abi_group.cpp declined it or is switched off): the values so
+	// far come back to the host, the slots are re-zeroed by that finalize, and the kernel goes on from those values.  Rank-local
+	// (no peer exchange: the last finalize of the call reduces the totals).
+	auto drain = [&]() -> int {
+		bn::fin_args fa{};
+		fa.n_terms = (uint32_t)terms.size();
+		fa.n_values = n_values;
+		fa.n_ret = n_values;
+		for (size_t t = 0; t < terms.size(); t++) fa.terms[t] = terms[t];
+		for (uint32_t v = 0; v < n_values; v++) {
+			fa.init[v] = h_values[v];
+			fa.ret_ids[v] = v;
+		}
+		fa.n_slots = n_slots;
+		fa.seq = ++ctx->mail_seq;
+		ctx->mirror.valid = false;
+		BN_HIP(bn::launch_finalize(s, fa, d_S, d_rets, ctx->d_mail, nullptr));
+		volatile uint64_t *seqw = &ctx->h_mail[64].lo;
+		uint64_t spins = 0;
+		while (__atomic_load_n(seqw, __ATOMIC_ACQUIRE) != fa.seq) {
+			if (++spins > (1ull << 22)) {
+				BN_HIP(hipStreamSynchronize(s));
+				if (__atomic_load_n(seqw, __ATOMIC_ACQUIRE) != fa.seq) return bn::fail(BN_ERR_DEVICE, "device error: result mailbox was not published");
+				break;
+			}
+		}
+		for (uint32_t v = 0; v < n_values; v++) {
+			h_values[v].lo = __atomic_load_n(&ctx->h_mail[v].lo, __ATOMIC_RELAXED);
+			h_values[v].hi = __atomic_load_n(&ctx->h_mail[v].hi, __ATOMIC_RELAXED);
+		}
+		terms.clear();
+		n_slots = 0;
+		return BN_OK;
+	};
+	static_assert(bn::kFinMaxValues <= bn::kFinMaxRets, "a drain returns every value");
+
 	for (uint32_t o = 0; o < n_ops; o++) {
 		const bn_kop &op = ops[o];
 		switch (op.kind) {
@@ -749,7 +786,10 @@ int bn_kernel_launch(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const 
 				BN_REQUIRE(op.rows[r].len == row_len, "sum_composition_evals: rows differ in length");
 				BN_REQUIRE(op.rows[r].off + op.rows[r].len <= buf_len[op.rows[r].buf], "sum_composition_evals: slice out of range");
 			}
-			BN_REQUIRE(n_slots + 2 <= 64, "too many sum_composition_evals in one kernel");
+			if (n_slots + 2 > 64 || terms.size() + 2 > (size_t)bn::kFinMaxTerms) {
+				rc = drain();
+				if (rc) return rc;
+			}
 			const uint32_t slot = n_slots;
 			if (op.expr->shape == bn_expr::PRODUCT) {
 				// fused pairing: if the NEXT sum op uses the same expression and its factors are the

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <initializer_list>
 #include <string>
 #include <mutex>
 #include <vector>
@@ -22,6 +23,18 @@ struct bn_expr {
 };
 
 namespace bn {
+// ---- the widths the deferral machinery is sized for (one place; the static_asserts below tie them together)
+constexpr int kFoldBatchMax = 32;    // arrays of ONE plain fold launch (fold_batch rides in the kernel-argument block) and of the single-claim slot bn_ctx::pend
+constexpr int kFoldCallMax = 256;    // arrays of one bn_extrapolate_line_batch CALL (the shims' FOLD_BATCH_MAX): split into launches of kFoldBatchMax where it runs eagerly
+constexpr int kGroupMaxArrays = 256; // multilinears of one prover on the claim-group path (abi_group.cpp) = arrays of one deferred group fold
+constexpr int kGroupMaxClaims = 384; // product claims of one prover on that path (keccak: every committed column against up to three evaluation points)
+constexpr int kGroupMaxJobs = 1024;  // jobs of one launch of kernels_group.hip (the table lives in pinned memory, not in the kernel arguments)
+constexpr int kGroupMaxSlots = 1024; // accumulator slots of one launch: two per claim, the calling prover's and the riders'
+constexpr int kGroupMaxGrid = 512;   // workgroups of one launch (the head-of-workgroup table in the kernel arguments)
+static_assert(kFoldCallMax == kGroupMaxArrays, "a prover's fold arrives as ONE batch: hosted sessions fold whole batches");
+static_assert(kFoldCallMax == BN_FOLD_CALL_MAX, "include/binius_amd.h states the limit the shims split at");
+static_assert(kGroupMaxArrays <= kGroupMaxJobs && 2 * kGroupMaxClaims <= kGroupMaxSlots && kGroupMaxClaims <= kGroupMaxJobs, "group widths");
+static_assert(kFoldBatchMax <= kFoldCallMax && kFoldBatchMax <= 32, "bn_ctx::pending_fold::scale_mask is a 32-bit mask over the batch");
 constexpr int kPeerMaxWorld = 16; // ranks of one node that can share a peer exchange (finalize.hpp)
 constexpr uint64_t kHtMaxM = 4096; // largest array (elements) a host tail can take over (abi_kernels.cpp)
 // What a host tail (abi_kernels.cpp) leaves for the device to catch up with: the host folded its copy of two small arrays in place
@@ -73,9 +86,9 @@ struct bn_ctx {
 		bn::f128 z{0, 0};
 		uint32_t scale_mask = 0; // bit i: the upper half of folded array i is multiplied by hi_scale (bn_extrapolate_line_batch_scaled)
 		bn::f128 hi_scale{0, 0};
-		void *x0[32] = {};        // evals_0: written in place ...   (32 = bn::kFoldBatchMax, declared below)
-		const void *x1[32] = {};
-		const void *src0[32] = {}; // ... and read from here (== x0 unless a deferred copy_d2d fed it)
+		void *x0[bn::kFoldBatchMax] = {};        // evals_0: written in place ...
+		const void *x1[bn::kFoldBatchMax] = {};
+		const void *src0[bn::kFoldBatchMax] = {}; // ... and read from here (== x0 unless a deferred copy_d2d fed it)
 	} pend;
 	// a SECOND deferred fold, chained in place on pend's output: exists only between the call that answered a round from
 	// the precomputed sums below and the next round evaluation, which then folds twice (kernels_foldeval8.hip)
@@ -146,8 +159,8 @@ struct bn_ctx {
 		bool host = false; // the values were computed on the host (host_vals): nothing to wait for
 		uint64_t seq = 0;
 		uint32_t count = 0, n = 0;
-		const void *ptr[32] = {};
-		bn::f128 host_vals[32] = {};
+		const void *ptr[bn::kFoldBatchMax] = {};
+		bn::f128 host_vals[bn::kFoldBatchMax] = {};
 	} mirror;
 	// The four elements per array that the LAST two-round launch of a sumcheck leaves (kernels_foldeval8.hip publishes them
 	// beside its sums): the two folds that remain are six host products, so the caller's read of the final evaluations does
@@ -227,19 +240,33 @@ struct bn_ctx {
 		uint32_t count = 0;
 		uint64_t n = 0; // elements per half = elements of the folded array
 		bn::f128 z{0, 0};
-		void *x0[32] = {};
-		const void *x1[32] = {};
-		const void *src0[32] = {};
+		std::vector<void *> x0;         // count entries each (at most bn::kGroupMaxArrays)
+		std::vector<const void *> x1, src0;
+		const char *hull_b = nullptr, *hull_e = nullptr; // every byte the batch reads or writes lies in [hull_b, hull_e): the quick "does not touch" test
+		void push(void *o, const void *hi, const void *lo) // (n is set)
+		{
+			x0.push_back(o);
+			x1.push_back(hi);
+			src0.push_back(lo);
+			count++;
+			for (const void *p : {(const void *)o, hi, lo}) {
+				const char *b = (const char *)p, *e = b + n * sizeof(bn::f128);
+				if (!hull_b || b < hull_b) hull_b = b;
+				if (!hull_e || e > hull_e) hull_e = e;
+			}
+		}
+		bool hull_hits(const void *p, uint64_t elems) const { return (const char *)p < hull_e && hull_b < (const char *)p + elems * sizeof(bn::f128); }
 	};
 	struct group_session {
-		uint32_t m = 0, k = 0;                      // arrays, product claims
+		uint32_t m = 0, k = 0;                      // arrays (<= bn::kGroupMaxArrays), product claims (<= bn::kGroupMaxClaims)
 		uint64_t row_len = 0;                       // points of the last evaluation
-		const void *lo[32] = {}, *hi[32] = {};      // the arrays' halves at the last evaluation (what the prover's next fold reads)
-		uint8_t pa[32] = {}, pb[32] = {};           // the claims, as indices into the arrays
+		std::vector<const void *> lo, hi;           // [m] the arrays' halves at the last evaluation (what the prover's next fold reads)
+		std::vector<uint16_t> pa, pb;               // [k] the claims, as indices into the arrays
 		bool pre_valid = false;                     // the raw sums of the NEXT evaluation were computed ahead ...
 		uint64_t pre_row_len = 0;                   // ... of these halves
-		const void *pre_lo[32] = {}, *pre_hi[32] = {};
-		bn::f128 pre_raw[64] = {};                  // claim c: [2 c] at 1, [2 c + 1] at infinity
+		std::vector<const void *> pre_lo, pre_hi;   // [m]
+		const char *pre_hull_b = nullptr, *pre_hull_e = nullptr; // hull of those halves
+		std::vector<bn::f128> pre_raw;              // [2 k] claim c: [2 c] at 1, [2 c + 1] at infinity
 		uint64_t stamp = 0;
 		// hosted: the prover's arrays are small enough that its remaining rounds are host arithmetic (abi_group.cpp "hosted
 		// sessions"): hy[j] = array j in the power basis of hostmul_clmul.cpp (2 words per element), folded in place exactly as
@@ -247,10 +274,10 @@ struct bn_ctx {
 		// where the first host fold wrote) when anybody looks at the memory
 		bool hosted = false;
 		uint64_t h_len = 0;                         // elements per array now
-		const void *h_lo[32] = {}, *h_hi[32] = {};  // device addresses of the current arrays' halves: what the next calls must name
+		std::vector<const void *> h_lo, h_hi;       // [m] device addresses of the current arrays' halves: what the next calls must name
 		uint32_t h_levels = 0;                      // folds performed on the host and not yet on the device
 		uint64_t h_n0 = 0;
-		void *h_out[32] = {};
+		std::vector<void *> h_out;                  // [m]
 		std::vector<std::vector<uint64_t>> hy;
 	};
 	struct group_state {
@@ -264,8 +291,17 @@ struct bn_ctx {
 		uint64_t stamp = 0;
 		uint64_t launches = 0, jobs_fused = 0, jobs_eval = 0, prefolds = 0, spec_jobs = 0, spec_hits = 0, evals = 0, flushed_folds = 0, jobs_fold = 0, chain_count = 0;
 		uint64_t ht_max = 0;   // largest array (elements) a hosted session starts with (0: off; BN_GROUP_HT_MAX_LOG2)
+		uint64_t ht_work = 8 * 4096; // ... and the most elements over all its arrays (bn::kGroupTailWorkElems; BN_GROUP_HT_WORK_LOG2)
 		void *h_stage = nullptr, *d_stage = nullptr; // pinned staging, 2 x kGroupTailMaxElems elements: hand-over | write-back
 		uint64_t hosted_started = 0, hosted_evals = 0, hosted_folds = 0, hosted_writebacks = 0;
+		// what a launch of kernels_group.hip reads besides its kernel arguments -- the job table, the pointer tables of a hand-over and
+		// of a write-back -- lives in ONE pinned, device-mapped block (bn::group_tables): written by the host right before the launch,
+		// read by the workgroups over the bus.  Every launch that reads the job table or the hand-over's pointers is awaited by its
+		// caller (the mailbox) before the next one is prepared; the write-back's pointers are rewritten only behind a stream
+		// synchronisation (abi_group.cpp unhost).
+		void *h_tables = nullptr, *d_tables = nullptr;
+		bn::f128 *d_S = nullptr;                     // kGroupMaxSlots accumulator slots (zero between launches)
+		bn::f128 *h_gmail = nullptr, *d_gmail = nullptr; // pinned: the raw sums of a launch, kGroupMaxSlots values (the sequence word stays in h_mail[64])
 	} grp;
 	// cross-rank reduction inside the finalize step (bn_peer_*, finalize.hpp peer_exchange)
 	struct peer_state {
@@ -299,7 +335,6 @@ hipError_t launch_fill(hipStream_t s, void *dst, uint64_t n, f128 v);
 hipError_t launch_add_assign(hipStream_t s, void *dst, const void *src, uint64_t n);
 hipError_t launch_add(hipStream_t s, void *dst, const void *src1, const void *src2, uint64_t n);
 hipError_t launch_extrapolate_line(hipStream_t s, int n_cu, void *evals_0, const void *evals_1, uint64_t n, f128 z);
-constexpr int kFoldBatchMax = 32; // (bn_ctx::pending_fold, bn_ctx::mirror_state and the shims' FOLD_BATCH_MAX follow)
 struct fold_batch {
 	void *x0[kFoldBatchMax];
 	const void *x1[kFoldBatchMax];
@@ -454,7 +489,6 @@ hipError_t launch_foldeval_mfma(hipStream_t s, int n_cu, const foldeval_args &fa
 hipError_t func_lds_limit(const void *fn, int bytes);
 
 // ---- kernels_group.hip: the product claims of a whole batch round of sumchecks as jobs of ONE launch; returns raw sums
-constexpr int kGroupMaxJobs = 32;
 struct group_job {
 	const void *x0[2], *x1[2]; // kind 0: lower / upper half of the two arrays BEFORE the fold (2 n elements each); kind 1: lower half (evaluations
 	                           // at 0) / upper half (evaluations at 1) of the two arrays as they are (n elements each)
@@ -473,10 +507,23 @@ struct group_job {
 // hosted provers (abi_group.cpp): hand-over of a prover's arrays to the host (with its deferred fold performed on the way) and the
 // write-back of the host's folded copies
 constexpr uint64_t kGroupTailMaxElems = 32 * 4096; // elements of one hand-over / write-back: the pinned staging holds that many
+// ... and a prover is handed over once its arrays together are at most this many elements: the host's rounds cost products in
+// proportion (claims x points), the device's a launch each -- eight arrays of 4096 elements or a hundred of 256 (measured, 50
+// claims over 100 arrays at 2^22: 10.1 ms from 256 elements per array on, 10.9 ms from 1024)
+constexpr uint64_t kGroupTailWorkElems = 8 * 4096;
+// the pinned block behind bn_ctx::group_state::h_tables / d_tables
+struct group_ptr_table {
+	const void *src0[kGroupMaxArrays]; // x1[j] != null: the fold's inputs (n elements each), its output goes to out[j]; x1[j] == null: the array itself
+	const void *x1[kGroupMaxArrays];
+	void *out[kGroupMaxArrays];
+};
+struct group_tables {
+	group_job jobs[kGroupMaxJobs]; // of the launch in flight, sorted by first workgroup
+	group_ptr_table mirror;        // of the hand-over in flight
+	group_ptr_table writeback;     // of the last write-back (only `out` is used)
+};
 struct group_mirror_args {
-	const void *src0[kGroupMaxJobs]; // x1[j] != null: the fold's inputs (n elements each), its output goes to out[j]; x1[j] == null: the array itself
-	const void *x1[kGroupMaxJobs];
-	void *out[kGroupMaxJobs];
+	const group_ptr_table *ptrs; // device view of the pinned pointer table
 	f128 z;
 	uint32_t count, n;   // arrays, elements per array handed over
 	f128 *staging;       // pinned host memory (device view): staging[j * n + i] = Phi(y_j[i])
@@ -488,14 +535,17 @@ struct group_mirror_args {
 };
 hipError_t launch_group_mirror(hipStream_t s, const group_mirror_args &a);
 struct group_writeback_args {
-	void *out[kGroupMaxJobs];
+	const group_ptr_table *ptrs; // device view; out[j] = where array j's first n0 elements belong
 	uint32_t count, n0;
 	const f128 *staging;  // pinned host memory (device view): the host's copies, power basis
 	const uint4 *phi_inv; // nibble table of the inverse basis change
 };
 hipError_t launch_group_writeback(hipStream_t s, const group_writeback_args &a);
-hipError_t launch_group(hipStream_t s, int n_cu, const group_job *jobs, uint32_t n_jobs, uint32_t n_slots, f128 *d_S, f128 *d_mail, unsigned *d_counter,
-                        uint64_t seq);
+// jobs_in[0 .. n_jobs) (n_jobs <= kGroupMaxJobs): dealt out to workgroups, sorted and written to h_table (pinned; d_table = its device view),
+// which the launch reads.  The raw sums S[0 .. n_slots) (n_slots <= kGroupMaxSlots; zero before, zero after) go to d_vals[0 .. n_slots),
+// then the sequence number to d_mail[64].
+hipError_t launch_group(hipStream_t s, int n_cu, const group_job *jobs_in, uint32_t n_jobs, uint32_t n_slots, f128 *d_S, f128 *d_vals, f128 *d_mail,
+                        unsigned *d_counter, uint64_t seq, group_job *h_table, const group_job *d_table);
 
 // ---- kernels_hal.hip: general forms of the old HAL's round calculation and lerp fold (abi_hal.cpp)
 constexpr int kHalMaxMl = 16, kHalMaxEv = 8, kHalMaxPts = 13;

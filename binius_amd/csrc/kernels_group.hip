@@ -10,7 +10,11 @@
 //            circuits for all evaluation points of an old-HAL request in one launch, abi_hal.cpp; C = null: one product;
 //            B or D = null: the all-ones row, i.e. the plain sum of A or C)
 //   kind 3   the fold of kind 0 for one or two arrays and nothing else (an array that several claims share is folded ONCE, by a
-//            kind-0 job of one of its claims or by a kind-3 job; the other claims over it are kind-1 jobs)
+//            kind-0 job of one of its claims or by a kind-3 job; the other claims over it are kind-1 / kind-4 jobs)
+//   kind 4   kind 0 for the FIRST array only: a is folded on the way, b is read as it is (its halves b_0 | b_1, like kind 1) -- a claim
+//            whose second multilinear is shared with other claims (piop::prove pairs every committed multilinear of a size with
+//            the few ring-switch transparents of that size: a star around each transparent) folds its own array and reads the
+//            shared one, already folded by an earlier job of the chain or up to date
 //
 // Chains.  A kind-1 job may read what a kind-0 / kind-3 job of the SAME launch writes -- the folds are in place, so a workgroup
 // that evaluated such a claim while another one folded the array would read half-folded memory.  Jobs that depend on each other
@@ -32,11 +36,13 @@
 // prover whose execute() has not been called yet can be computed in the same launch (abi_group.cpp).
 //
 // Algorithmic bytes per job: kind 0 read 16 * 2 * N + write 8 * 2 * N = 48 N (24 * m * N summed over a prover's disjoint claims);
-// kind 1 read 16 * 2 * (N / 2) = 16 N; kind 3 24 N per array.
+// kind 1 read 16 * 2 * (N / 2) = 16 N; kind 3 24 N per array; kind 4 24 N + 8 N.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstddef>
 #include <cstdlib>
+#include <vector>
 
 #include "ctable.hpp"
 #include "gram_fp4.hpp"
@@ -73,38 +79,43 @@ constexpr unsigned kGramWaves = 4;  // waves 0 .. 3: the Gram k-steps (one per S
 constexpr unsigned kFoldGroups = 2; // waves 4 .. 11: two groups of four waves, a tile per group
 constexpr unsigned kThreads = 64 * kGramWaves * (1 + kFoldGroups);
 
-// everything but the job table; the table follows in the same kernel-argument block and is indexed through the
-// kernarg segment pointer (a by-value array indexed with a run-time job number would be copied to scratch)
+// The kernel arguments.  The job table itself is NOT among them (256 jobs of 96 bytes: six times what a kernel-argument block
+// holds): it lies in pinned, device-mapped memory (internal.hpp group_tables) that the host fills right before the launch, and
+// a workgroup reads the one job it works on -- and the followers of its chain -- from there with scalar loads.  Which job that
+// is comes from head_of_wg: two 16-bit job numbers per word, indexed by workgroup.
 struct group_kargs {
-	group_job jobs[kGroupMaxJobs];
+	uint32_t head_of_wg[kGroupMaxGrid / 2];
+	const group_job *table;
 	f128 *S;           // accumulator slots (zero before the launch, zero after it)
-	f128 *mail;        // pinned mailbox: [0, n_slots) the raw sums, word 64 the sequence number
+	f128 *vals;        // pinned: [0, n_slots) the raw sums
+	f128 *mail;        // pinned mailbox: word 64 the sequence number
 	unsigned *counter; // device-scope ticket (zero between launches)
 	uint64_t seq;
 	uint32_t n_jobs, n_slots, prio, pad;
 };
 
-// the job table as it lies in the kernel-argument segment (scalar loads with a run-time index; the host pass of the compiler
-// never executes this)
-__device__ __forceinline__ const group_job *job_table()
+// read-only views for SCALAR loads with a run-time index: the kernel-argument segment and the pinned job table are both memory
+// nobody writes while the launch runs (address space 4 = constant: a load through it with a uniform address is an s_load, its
+// result lives in scalar registers -- through a generic pointer the compiler would issue vector loads and carry every pointer
+// of the job as a 64-bit vector value through the tile loops)
+typedef const group_job __attribute__((address_space(4))) *cjob_ptr;
+typedef const uint32_t __attribute__((address_space(4))) *cu32_ptr;
+__device__ __forceinline__ cu32_ptr kernarg_words()
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-	return (const group_job *)__builtin_amdgcn_kernarg_segment_ptr();
+	return (cu32_ptr)__builtin_amdgcn_kernarg_segment_ptr();
 #else
 	return nullptr;
 #endif
 }
-
-// element `idx` of a small by-value pointer array (a run-time index into a kernel argument: read through a volatile-free loop of
-// selects, so that the array is not copied to scratch)
-template <class P>
-__device__ __forceinline__ const void *job_ptr(P const (&arr)[kGroupMaxJobs], uint32_t idx)
+__device__ __forceinline__ cjob_ptr as_const_jobs(const group_job *p)
 {
-	const void *r = nullptr;
-#pragma unroll
-	for (uint32_t q = 0; q < (uint32_t)kGroupMaxJobs; q++)
-		if (q == idx) r = (const void *)arr[q];
-	return r;
+#if defined(__HIP_DEVICE_COMPILE__)
+	return (cjob_ptr)p;
+#else
+	(void)p;
+	return nullptr;
+#endif
 }
 
 } // namespace
@@ -126,7 +137,8 @@ struct group_wg {
 template <int KIND, bool FULL, bool NT>
 __device__ __forceinline__ void group_loops(const group_wg &w, uint32_t *T_dyn, ctable_smem &tab, gram_parity &Gc, uint32_t prio, bool build)
 {
-	constexpr bool kFolds = KIND == 0 || KIND == 3; // the job folds its arrays (KIND 3: and nothing else -- no staging, no Gram work, no sums)
+	constexpr bool kFolds = KIND == 0 || KIND == 3 || KIND == 4; // the job folds its arrays (KIND 3: and nothing else -- no staging, no Gram work, no sums;
+	                                                                // KIND 4: its first array only, the second is read as it is)
 	constexpr bool kTwoAhead = KIND == 1 || KIND == 2;
 	// (the thread index behind an opaque move: everything derived from it -- roles, lane offsets -- is recomputed per job of a chain
 	// instead of being hoisted out of the kernel's job loop and kept in registers across all four loop bodies)
@@ -162,6 +174,11 @@ __device__ __forceinline__ void group_loops(const group_wg &w, uint32_t *T_dyn, 
 		const uint32_t o = in_range(t) ? vo : 0u; // (a lane past the end reads the tile's first element: in range, never used)
 		if constexpr (kFolds) {
 			if (KIND == 3 && q >= 2 && w.X0[1] == nullptr) return; // (uniform) a fold-only job of ONE array
+			if (KIND == 4 && q >= 2) { // the second array as it is: X0 = its lower half (evaluations at 0), X1 = its upper half
+				const uint64_t e1 = (uint64_t)(tbase + t) * kTP * 16;
+				dst0[q] = gq_load<NT>(reinterpret_cast<const uint4 *>((q & 1 ? w.X1[1] : w.X0[1]) + e1 + o));
+				return;
+			}
 			const uint64_t e = ((q & 1 ? n : 0) + (uint64_t)(tbase + t) * kTP) * 16; // (uniform)
 			dst0[q] = gq_load<NT>(reinterpret_cast<const uint4 *>(w.X0[q >> 1] + e + o));
 			x1[q] = gq_load<NT>(reinterpret_cast<const uint4 *>(w.X1[q >> 1] + e + o));
@@ -223,13 +240,16 @@ __device__ __forceinline__ void group_loops(const group_wg &w, uint32_t *T_dyn, 
 #pragma unroll
 					for (int q = 0; q < 4; q++) {
 						if (q >= nq) break;
-						f[q] = ctable_mul_acc<8, true>(tab, xor4(x0[q], x1[q]), x0[q]);
+						if (KIND == 4 && q >= 2)
+							f[q] = x0[q];
+						else
+							f[q] = ctable_mul_acc<8, true>(tab, xor4(x0[q], x1[q]), x0[q]);
 						load1(tn, q); // this quadrant of the group's next tile flies from here on
 					}
 					if (FULL || ok) {
 #pragma unroll
 						for (int q = 0; q < 4; q++) {
-							if (q >= nq) break;
+							if (q >= nq || (KIND == 4 && q >= 2)) break;
 							gq_store<NT>(reinterpret_cast<uint4 *>(w.OUT[q >> 1] + (q & 1 ? n * 16 : 0) + pt16 + vo), f[q]);
 						}
 					}
@@ -304,14 +324,12 @@ __global__ __launch_bounds__(kThreads, 1) void k_group_fp4(group_kargs ga)
 	const unsigned lane = threadIdx.x & 63;
 	const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
-	// ---- this workgroup's job (uniform): the table is sorted by wg_begin; followers of a chain (wg_count = 0) belong to the job in
-	// front of them
-	static_assert(offsetof(group_kargs, jobs) == 0, "the job table leads the kernel-argument block");
-	const group_job *const jt = job_table();
-	unsigned ji = 0;
-	for (unsigned i = 1; i < ga.n_jobs; i++)
-		if (jt[i].wg_count != 0 && blockIdx.x >= jt[i].wg_begin) ji = i;
-	const group_job *const head = jt + ji;
+	// ---- this workgroup's job (uniform): the head of its chain, or the lone job, from the table in the kernel arguments; the job
+	// itself (and the followers of the chain) from the pinned table
+	static_assert(offsetof(group_kargs, head_of_wg) == 0, "the head-of-workgroup table leads the kernel-argument block");
+	const uint32_t hw = kernarg_words()[blockIdx.x >> 1];
+	const unsigned ji = (blockIdx.x & 1) ? hw >> 16 : hw & 0xFFFFu;
+	const cjob_ptr head = as_const_jobs(ga.table) + ji;
 	const uint32_t G = head->wg_count, b = blockIdx.x - head->wg_begin;
 	const bool xcd_order = (G & 7) == 0 && (head->wg_begin & 7) == 0;
 	const unsigned n_sub = 1 + head->chain;
@@ -322,7 +340,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_group_fp4(group_kargs ga)
 	f128 z_built{0, 0};
 	bool have_table = false;
 	for (unsigned sub = 0; sub < n_sub; sub++) {
-		const group_job *const jb = head + sub;
+		const cjob_ptr jb = head + sub;
 		if (jb->acquire) {
 			// this workgroup's own stores of the chain's earlier jobs (folded arrays, in place) are read back by this job: all of
 			// them have reached the L2 (vmcnt), and the vector cache forgets the lines it loaded before they were written
@@ -332,7 +350,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_group_fp4(group_kargs ga)
 		}
 		group_wg w;
 		w.n = jb->n; // evaluation points of the job
-		w.z = jb->z;
+		w.z = f128{jb->z.lo, jb->z.hi};
 		for (int sd = 0; sd < 2; sd++) {
 			w.X0[sd] = reinterpret_cast<const char *>(jb->x0[sd]);
 			w.X1[sd] = reinterpret_cast<const char *>(jb->x1[sd]);
@@ -355,12 +373,14 @@ __global__ __launch_bounds__(kThreads, 1) void k_group_fp4(group_kargs ga)
 		w.adj = (ga.prio >> 2) & 1;
 		const uint32_t kind = jb->kind; // (uniform)
 		const bool build = !have_table || !(z_built == w.z);
-		if (kind == 0 || kind == 3) {
+		if (kind == 0 || kind == 3 || kind == 4) {
 			z_built = w.z;
 			have_table = true;
 		}
 		if (kind == 0)
 			group_loops<0, FULL, NT>(w, T_dyn, tab, Gc, ga.prio, build);
+		else if (kind == 4)
+			group_loops<4, FULL, NT>(w, T_dyn, tab, Gc, ga.prio, build);
 		else if (kind == 1)
 			group_loops<1, FULL, NT>(w, T_dyn, tab, Gc, ga.prio, false);
 		else if (kind == 2)
@@ -405,18 +425,20 @@ __global__ __launch_bounds__(kThreads, 1) void k_group_fp4(group_kargs ga)
 	}
 	__syncthreads();
 	if (is_last) {
-		// (n_slots <= 64: everything below happens in wave 0, whose drain orders the value stores before the sequence word --
-		// posted writes to one destination keep their order; finalize.hpp)
-		if (tid < ga.n_slots) {
-			f128 v;
-			v.lo = __hip_atomic_load(&ga.S[tid].lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			v.hi = __hip_atomic_load(&ga.S[tid].hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			__hip_atomic_store(&ga.mail[tid].lo, v.lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-			__hip_atomic_store(&ga.mail[tid].hi, v.hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-			__hip_atomic_store(&ga.S[tid].lo, (uint64_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			__hip_atomic_store(&ga.S[tid].hi, (uint64_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		// (everything below happens in wave 0, whose drain orders the value stores before the sequence word -- posted writes to one
+		// destination keep their order; finalize.hpp)
+		if (tid < 64) {
+			for (unsigned i = tid; i < ga.n_slots; i += 64) {
+				f128 v;
+				v.lo = __hip_atomic_load(&ga.S[i].lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				v.hi = __hip_atomic_load(&ga.S[i].hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				__hip_atomic_store(&ga.vals[i].lo, v.lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+				__hip_atomic_store(&ga.vals[i].hi, v.hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+				__hip_atomic_store(&ga.S[i].lo, (uint64_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				__hip_atomic_store(&ga.S[i].hi, (uint64_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		}
-		if (tid < 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		if (tid == 0) {
 			__hip_atomic_store(&ga.mail[64].lo, ga.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 			__hip_atomic_store(ga.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -427,104 +449,220 @@ __global__ __launch_bounds__(kThreads, 1) void k_group_fp4(group_kargs ga)
 // Deals the workgroups of one launch out to the UNITS of the job list -- a job with its chain (jobs_in[i].chain followers directly
 // behind it), or a lone job -- in proportion to their traffic, eight at a time where a unit gets at least eight so that its tiles
 // keep the XCD-aware order; sorts the table by first workgroup and launches.  jobs[i].slot is the caller's; wg_begin / wg_count are
-// filled in here.  Every job: n >= 1; all jobs of a chain: the same n; kind 0 / 3 jobs write out[] (2 n elements each).
-hipError_t launch_group(hipStream_t s, int n_cu, const group_job *jobs_in, uint32_t n_jobs, uint32_t n_slots, f128 *d_S, f128 *d_mail, unsigned *d_counter,
-                        uint64_t seq)
+// filled in here.  Every job: n >= 1; all jobs of a chain: the same n; kind 0 / 3 / 4 jobs write out[] (2 n elements each).
+//
+// PACKED launches.  With more units than a launch has workgroups to give each a sensible share (a prover of the keccak width: a
+// hundred claims and more, piop/prove.rs:262-287), the units are packed into U super-units of n_cu / U workgroups each, U a power
+// of two: every workgroup of a super-unit runs ALL its jobs one after the other, each job on the workgroup's share of that
+// job's tiles -- the chain mechanism of the kernel, used for jobs that do not depend on each other (chains that do stay whole
+// and in order inside one super-unit).  Against one unit per job this costs a parity reduction per job and workgroup (~2 us) and
+// buys (1) any number of jobs per launch, (2) balance -- 100 equal jobs on 256 workgroups are 2.56 workgroups each, i.e. 78 % of the
+// chip busy; as 4 super-units of 25 jobs on 64 workgroups they are 100 % --, (3) the XCD-aware tile order (ranges in multiples of
+// eight), and (4) every workgroup of the chip walks the jobs in the same order, so that an array shared by many claims (a
+// transparent against every committed column) is re-read while it is still in the Infinity Cache.  U is chosen by a cost
+// model (time per pair of tiles by job kind at the measured per-CU rate, fixed cost per job) over the longest super-unit.
+namespace {
+struct pack_item {
+	uint32_t first, len;
+	double weight;
+};
+inline double pair_us(const group_job &j) // one pair of tiles (512 points) of this job on one workgroup at ~ 5 TB/s / 256 CUs: microseconds
 {
-	if (n_jobs == 0 || n_jobs > (uint32_t)kGroupMaxJobs || n_slots > 64) return hipErrorNotSupported;
+	const bool one = j.kind == 3 && !j.x0[1];
+	switch (j.kind) {
+	case 0: return 5.0;              // 192 B per point
+	case 3: return one ? 2.5 : 5.0;
+	case 4: return 3.4;              // 128 B per point
+	default: return 1.7;             // 64 B per point
+	}
+}
+// what a further job costs a workgroup besides its tiles: the pipeline of loads, staging and Gram steps drains and refills, the
+// parity words are reduced (measured: 50 equal jobs as 2 x 25 at 0.45 of the HBM peak against 0.52 for 64 jobs of 4 workgroups each)
+inline double fixed_us(const group_job &j) { return j.kind == 3 ? 3.0 : 10.0; }
+} // namespace
+
+hipError_t launch_group(hipStream_t s, int n_cu, const group_job *jobs_in, uint32_t n_jobs, uint32_t n_slots, f128 *d_S, f128 *d_vals, f128 *d_mail,
+                        unsigned *d_counter, uint64_t seq, group_job *h_table, const group_job *d_table)
+{
+	if (n_jobs == 0 || n_jobs > (uint32_t)kGroupMaxJobs || n_slots > (uint32_t)kGroupMaxSlots || !h_table || !d_table) return hipErrorNotSupported;
+	if (n_cu > kGroupMaxGrid) n_cu = kGroupMaxGrid;
 	static const uint32_t prio = [] {
 		const char *e = bn::settled_knob("BN_FE_FP4_PRIO");
 		return e ? (uint32_t)atoi(e) & 3u : 3u;
 	}();
-	group_kargs ga{};
+	static group_kargs ga_zero{};
+	group_kargs ga = ga_zero;
 	bool full = true;
 	uint64_t total_elems = 0;
-	double w[kGroupMaxJobs], W = 0;
-	uint32_t tiles[kGroupMaxJobs], cap[kGroupMaxJobs], cnt[kGroupMaxJobs], first[kGroupMaxJobs], len[kGroupMaxJobs];
-	uint32_t n_units = 0;
+	std::vector<double> w;
+	std::vector<uint32_t> tiles, cap, cnt, first, len;
+	double W = 0;
+	uint32_t n_units = 0, max_tiles = 0;
 	for (uint32_t i = 0; i < n_jobs;) {
 		const uint32_t l = 1 + jobs_in[i].chain;
 		if (i + l > n_jobs) return hipErrorInvalidValue;
-		const uint32_t u = n_units++;
-		first[u] = i;
-		len[u] = l;
-		w[u] = 0;
+		n_units++;
+		first.push_back(i);
+		len.push_back(l);
+		double wu = 0;
 		const uint64_t nt = (jobs_in[i].n + kTP - 1) / kTP;
 		for (uint32_t q = i; q < i + l; q++) {
 			const group_job &j = jobs_in[q];
-			if (j.n == 0 || j.kind > 3 || (j.kind != 3 && j.slot + 2 > n_slots) || j.n != jobs_in[i].n || (q > i && j.chain)) return hipErrorInvalidValue;
+			if (j.n == 0 || j.kind > 4 || (j.kind != 3 && j.slot + 2 > n_slots) || j.n != jobs_in[i].n || (q > i && j.chain)) return hipErrorInvalidValue;
 			if (q == i && j.acquire) return hipErrorInvalidValue; // (nothing in front of it to read back)
 			if (j.n % kTP) full = false;
 			const bool one = j.kind == 3 && !j.x0[1];
-			w[u] += (double)nt * (j.kind == 0 ? 3.0 : j.kind == 3 ? (one ? 1.5 : 3.0) : 1.0);
-			total_elems += j.n * (j.kind == 0 ? 8 : j.kind == 3 ? (one ? 3 : 6) : 4);
+			wu += (double)nt * (j.kind == 0 ? 3.0 : j.kind == 3 ? (one ? 1.5 : 3.0) : j.kind == 4 ? 2.0 : 1.0);
+			total_elems += j.n * (j.kind == 0 ? 8 : j.kind == 3 ? (one ? 3 : 6) : j.kind == 4 ? 6 : 4);
 		}
 		if (nt > (1ull << 14) * (uint64_t)n_cu) return hipErrorNotSupported; // 2^22 points per workgroup and job: the f32 counts stay exact
-		tiles[u] = (uint32_t)nt;
-		cap[u] = (uint32_t)(nt >= 2 ? nt / 2 : 1); // a workgroup wants a pair of tiles
-		W += w[u];
+		w.push_back(wu);
+		tiles.push_back((uint32_t)nt);
+		cap.push_back((uint32_t)(nt >= 2 ? nt / 2 : 1)); // a workgroup wants a pair of tiles
+		if ((uint32_t)nt > max_tiles) max_tiles = (uint32_t)nt;
+		W += wu;
 		i += l;
 	}
-	if (n_cu < (int)n_units) return hipErrorNotSupported;
-	// first pass: the proportional share, rounded down (to a multiple of eight from eight on), at least the workgroups the
-	// exactness bound asks for, at most one per pair of tiles
-	uint32_t used = 0;
-	for (uint32_t i = 0; i < n_units; i++) {
-		uint32_t c = (uint32_t)((double)n_cu * w[i] / W);
-		if (c >= 8) c &= ~7u;
-		const uint32_t need = (tiles[i] + (1u << 14) - 1) >> 14;
-		if (c < need) c = need;
-		if (c > cap[i]) c = cap[i];
-		if (c < 1) c = 1;
-		cnt[i] = c;
-		used += c;
-	}
-	// (minimums can overshoot only with very many very uneven units: take from the largest)
-	while (used > (uint32_t)n_cu) {
-		uint32_t big = 0;
-		for (uint32_t i = 1; i < n_units; i++)
-			if (cnt[i] > cnt[big]) big = i;
-		if (cnt[big] <= 1) return hipErrorNotSupported;
-		const uint32_t need = (tiles[big] + (1u << 14) - 1) >> 14;
-		if (cnt[big] - 1 < need) return hipErrorNotSupported;
-		cnt[big]--;
-		used--;
-	}
-	// the rest goes to whoever has the most work per workgroup, eight at a time for units in multiples of eight
-	for (;;) {
-		int best = -1;
-		double best_load = 0;
+	uint32_t at = 0;
+	bool packed = n_units > 32 || (int)n_units > n_cu;
+	// (one unit per job where that is no worse by the same model: every unit its proportional share of the workgroups)
+	double unpacked_cost = -1;
+	if (packed && (int)n_units <= n_cu) {
+		unpacked_cost = 0;
 		for (uint32_t i = 0; i < n_units; i++) {
-			const uint32_t step = (cnt[i] >= 8 && (cnt[i] & 7) == 0) ? 8 : 1;
-			if (cnt[i] + step > cap[i] || used + step > (uint32_t)n_cu) continue;
-			const double load = w[i] / cnt[i];
-			if (load > best_load) {
-				best_load = load;
-				best = (int)i;
+			uint32_t c = (uint32_t)((double)n_cu * w[i] / W);
+			if (c < 1) c = 1;
+			if (c > cap[i]) c = cap[i];
+			double cu = 0;
+			for (uint32_t q = first[i]; q < first[i] + len[i]; q++) cu += (double)(((uint64_t)tiles[i] + 2 * c - 1) / (2 * c)) * pair_us(jobs_in[q]) + fixed_us(jobs_in[q]);
+			if (cu > unpacked_cost) unpacked_cost = cu;
+		}
+	}
+	uint32_t best_U = 0;
+	double best_cost = 0;
+	std::vector<uint32_t> best_assign;
+	if (packed) {
+		// ---- U super-units of g = n_cu / U workgroups; items (units) dealt out heaviest first to the least loaded super-unit
+		std::vector<uint32_t> by_weight(n_units);
+		for (uint32_t i = 0; i < n_units; i++) by_weight[i] = i;
+		std::stable_sort(by_weight.begin(), by_weight.end(), [&](uint32_t a, uint32_t b) { return w[a] > w[b]; });
+		const uint32_t g_min = (max_tiles + (1u << 14) - 1) >> 14; // the exactness bound
+		std::vector<uint32_t> assign(n_units);
+		for (uint32_t U = 1; U <= (uint32_t)n_cu && U <= n_units; U <<= 1) {
+			const uint32_t g = (uint32_t)n_cu / U;
+			if (g < g_min || g == 0) break;
+			std::vector<double> load(U, 0.0), cost(U, 0.0);
+			for (uint32_t o = 0; o < n_units; o++) {
+				const uint32_t it = by_weight[o];
+				uint32_t u = 0;
+				for (uint32_t q = 1; q < U; q++)
+					if (load[q] < load[u]) u = q;
+				assign[it] = u;
+				load[u] += w[it];
+				for (uint32_t q = first[it]; q < first[it] + len[it]; q++) {
+					const uint64_t steps = ((uint64_t)tiles[it] + 2 * g - 1) / (2 * g);
+					cost[u] += (double)steps * pair_us(jobs_in[q]) + fixed_us(jobs_in[q]);
+				}
+			}
+			double c = 0;
+			for (uint32_t u = 0; u < U; u++)
+				if (cost[u] > c) c = cost[u];
+			if (!best_U || c < best_cost) {
+				best_U = U;
+				best_cost = c;
+				best_assign = assign;
 			}
 		}
-		if (best < 0) break;
-		const uint32_t step = (cnt[best] >= 8 && (cnt[best] & 7) == 0) ? 8 : 1;
-		cnt[best] += step;
-		used += step;
+		if (!best_U && unpacked_cost < 0) return hipErrorNotSupported;
+		if (unpacked_cost >= 0 && (!best_U || unpacked_cost <= best_cost)) packed = false;
 	}
-	// table order: the units whose count is a multiple of eight first (their ranges then start on multiples of eight)
-	uint32_t order[kGroupMaxJobs], no = 0;
-	for (uint32_t i = 0; i < n_units; i++)
-		if ((cnt[i] & 7) == 0) order[no++] = i;
-	for (uint32_t i = 0; i < n_units; i++)
-		if ((cnt[i] & 7) != 0) order[no++] = i;
-	uint32_t at = 0, k = 0;
-	for (uint32_t o = 0; o < n_units; o++) {
-		const uint32_t u = order[o];
-		for (uint32_t q = 0; q < len[u]; q++, k++) {
-			ga.jobs[k] = jobs_in[first[u] + q];
-			ga.jobs[k].wg_begin = at;
-			ga.jobs[k].wg_count = q == 0 ? cnt[u] : 0;
+	if (packed) {
+		const uint32_t U = best_U, g = (uint32_t)n_cu / U;
+		uint32_t k = 0;
+		for (uint32_t u = 0; u < U; u++) {
+			const uint32_t head = k;
+			for (uint32_t it = 0; it < n_units; it++) { // (in the caller's order: a chain's jobs stay in order)
+				if (best_assign[it] != u) continue;
+				for (uint32_t q = 0; q < len[it]; q++, k++) {
+					h_table[k] = jobs_in[first[it] + q];
+					h_table[k].wg_begin = u * g;
+					h_table[k].wg_count = 0;
+					h_table[k].chain = 0;
+				}
+			}
+			if (k == head) continue; // (more super-units than items cannot happen: U <= n_units and the heaviest-first deal fills every one)
+			h_table[head].wg_count = g;
+			h_table[head].chain = k - head - 1;
+			for (uint32_t x = u * g; x < (u + 1) * g; x++) ga.head_of_wg[x >> 1] |= head << (16 * (x & 1));
 		}
-		at += cnt[u];
+		at = U * g;
+	} else {
+		if (n_cu < (int)n_units) return hipErrorNotSupported;
+		cnt.assign(n_units, 0);
+		// first pass: the proportional share, rounded down (to a multiple of eight from eight on), at least the workgroups the
+		// exactness bound asks for, at most one per pair of tiles
+		uint32_t used = 0;
+		for (uint32_t i = 0; i < n_units; i++) {
+			uint32_t c = (uint32_t)((double)n_cu * w[i] / W);
+			if (c >= 8) c &= ~7u;
+			const uint32_t need = (tiles[i] + (1u << 14) - 1) >> 14;
+			if (c < need) c = need;
+			if (c > cap[i]) c = cap[i];
+			if (c < 1) c = 1;
+			cnt[i] = c;
+			used += c;
+		}
+		// (minimums can overshoot only with very many very uneven units: take from the largest)
+		while (used > (uint32_t)n_cu) {
+			uint32_t big = 0;
+			for (uint32_t i = 1; i < n_units; i++)
+				if (cnt[i] > cnt[big]) big = i;
+			if (cnt[big] <= 1) return hipErrorNotSupported;
+			const uint32_t need = (tiles[big] + (1u << 14) - 1) >> 14;
+			if (cnt[big] - 1 < need) return hipErrorNotSupported;
+			cnt[big]--;
+			used--;
+		}
+		// the rest goes to whoever has the most work per workgroup, eight at a time for units in multiples of eight
+		for (;;) {
+			int best = -1;
+			double best_load = 0;
+			for (uint32_t i = 0; i < n_units; i++) {
+				const uint32_t step = (cnt[i] >= 8 && (cnt[i] & 7) == 0) ? 8 : 1;
+				if (cnt[i] + step > cap[i] || used + step > (uint32_t)n_cu) continue;
+				const double load = w[i] / cnt[i];
+				if (load > best_load) {
+					best_load = load;
+					best = (int)i;
+				}
+			}
+			if (best < 0) break;
+			const uint32_t step = (cnt[best] >= 8 && (cnt[best] & 7) == 0) ? 8 : 1;
+			cnt[best] += step;
+			used += step;
+		}
+		// table order: the units whose count is a multiple of eight first (their ranges then start on multiples of eight)
+		std::vector<uint32_t> order;
+		for (uint32_t i = 0; i < n_units; i++)
+			if ((cnt[i] & 7) == 0) order.push_back(i);
+		for (uint32_t i = 0; i < n_units; i++)
+			if ((cnt[i] & 7) != 0) order.push_back(i);
+		uint32_t k = 0;
+		for (uint32_t o = 0; o < n_units; o++) {
+			const uint32_t u = order[o];
+			for (uint32_t g = at; g < at + cnt[u]; g++) ga.head_of_wg[g >> 1] |= k << (16 * (g & 1));
+			for (uint32_t q = 0; q < len[u]; q++, k++) {
+				h_table[k] = jobs_in[first[u] + q];
+				h_table[k].wg_begin = at;
+				h_table[k].wg_count = q == 0 ? cnt[u] : 0;
+			}
+			at += cnt[u];
+		}
 	}
+	__atomic_thread_fence(__ATOMIC_SEQ_CST); // (the table is in memory before the doorbell rings)
+	ga.table = d_table;
 	ga.S = d_S;
+	ga.vals = d_vals;
 	ga.mail = d_mail;
 	ga.counter = d_counter;
 	ga.seq = seq;
@@ -576,31 +714,41 @@ __device__ __forceinline__ uint64_t gt_mix(uint64_t lo, uint64_t hi, uint64_t id
 }
 } // namespace
 
+// (the pointers of the arrays a workgroup touches -- consecutive ones, at most 256 -- come from the pinned pointer table into shared
+// memory once per workgroup)
 __global__ __launch_bounds__(256) void k_group_mirror(group_mirror_args a)
 {
 	__shared__ ctable_smem tab;
 	__shared__ uint4 phi_T[512];
 	__shared__ uint64_t wtag[4];
 	__shared__ unsigned is_last;
+	__shared__ const void *p_src0[256], *p_x1[256];
+	__shared__ void *p_out[256];
 	const unsigned tid = threadIdx.x;
-	const uint64_t g = (uint64_t)blockIdx.x * 256 + tid, total = (uint64_t)a.count * a.n;
+	const uint64_t g0 = (uint64_t)blockIdx.x * 256, g = g0 + tid, total = (uint64_t)a.count * a.n;
 	const bool act = g < total;
-	const uint32_t arr = act ? (uint32_t)(g / a.n) : 0, i = act ? (uint32_t)(g - (uint64_t)arr * a.n) : 0;
-	const uint4 *src0 = reinterpret_cast<const uint4 *>(job_ptr(a.src0, arr)), *x1 = reinterpret_cast<const uint4 *>(job_ptr(a.x1, arr));
+	const uint32_t arr0 = (uint32_t)(g0 / a.n);
+	const uint32_t arr = act ? (uint32_t)(g / a.n) : arr0, i = act ? (uint32_t)(g - (uint64_t)arr * a.n) : 0;
+	if (arr0 + tid < a.count && (uint64_t)(arr0 + tid) * a.n < g0 + 256) {
+		p_src0[tid] = a.ptrs->src0[arr0 + tid];
+		p_x1[tid] = a.ptrs->x1[arr0 + tid];
+		p_out[tid] = a.ptrs->out[arr0 + tid];
+	}
+	phi_T[tid] = a.phi_tab[tid];
+	phi_T[tid + 256] = a.phi_tab[tid + 256];
+	ctable_build(tab, a.z); // (ends with a barrier: phi_T and the pointers are complete too)
+	const uint4 *src0 = reinterpret_cast<const uint4 *>(p_src0[arr - arr0]), *x1 = reinterpret_cast<const uint4 *>(p_x1[arr - arr0]);
 	uint4 v0{0, 0, 0, 0}, v1{0, 0, 0, 0};
 	if (act) {
 		v0 = src0[i];
 		if (x1) v1 = x1[i];
 	}
-	phi_T[tid] = a.phi_tab[tid];
-	phi_T[tid + 256] = a.phi_tab[tid + 256];
-	ctable_build(tab, a.z); // (ends with a barrier: phi_T is complete too)
 	uint64_t tag = 0;
 	if (act) {
 		uint4 y = v0;
 		if (x1) {
 			y = xor4(v0, ctable_mul(tab, xor4(v0, v1)));
-			reinterpret_cast<uint4 *>(const_cast<void *>(job_ptr(a.out, arr)))[i] = y;
+			reinterpret_cast<uint4 *>(p_out[arr - arr0])[i] = y;
 		}
 		const uint4 py = ctable_mul(*reinterpret_cast<const ctable_smem *>(phi_T), y);
 		reinterpret_cast<uint4 *>(a.staging)[g] = py;
@@ -630,8 +778,10 @@ __global__ __launch_bounds__(256) void k_group_mirror(group_mirror_args a)
 
 hipError_t launch_group_mirror(hipStream_t s, const group_mirror_args &a)
 {
-	if (a.count == 0 || a.count > (uint32_t)kGroupMaxJobs || a.n == 0 || (uint64_t)a.count * a.n > kGroupTailMaxElems || !a.staging || !a.phi_tab || !a.tag_acc || !a.counter || !a.mail)
+	if (a.count == 0 || a.count > (uint32_t)kGroupMaxArrays || a.n == 0 || (uint64_t)a.count * a.n > kGroupTailMaxElems || !a.ptrs || !a.staging || !a.phi_tab ||
+	    !a.tag_acc || !a.counter || !a.mail)
 		return hipErrorNotSupported;
+	__atomic_thread_fence(__ATOMIC_SEQ_CST); // (the pointer table is in memory before the doorbell rings)
 	hipLaunchKernelGGL(k_group_mirror, dim3((unsigned)(((uint64_t)a.count * a.n + 255) / 256)), dim3(256), 0, s, a);
 	return hipGetLastError();
 }
@@ -642,21 +792,26 @@ hipError_t launch_group_mirror(hipStream_t s, const group_mirror_args &a)
 __global__ __launch_bounds__(256) void k_group_writeback(group_writeback_args a)
 {
 	__shared__ uint4 T[512];
+	__shared__ void *p_out[256];
 	const unsigned tid = threadIdx.x;
-	const uint64_t g = (uint64_t)blockIdx.x * 256 + tid, total = (uint64_t)a.count * a.n0;
+	const uint64_t g0 = (uint64_t)blockIdx.x * 256, g = g0 + tid, total = (uint64_t)a.count * a.n0;
 	const bool act = g < total;
-	const uint32_t arr = act ? (uint32_t)(g / a.n0) : 0, i = act ? (uint32_t)(g - (uint64_t)arr * a.n0) : 0;
+	const uint32_t arr0 = (uint32_t)(g0 / a.n0);
+	const uint32_t arr = act ? (uint32_t)(g / a.n0) : arr0, i = act ? (uint32_t)(g - (uint64_t)arr * a.n0) : 0;
+	if (arr0 + tid < a.count && (uint64_t)(arr0 + tid) * a.n0 < g0 + 256) p_out[tid] = a.ptrs->out[arr0 + tid];
 	uint4 v{0, 0, 0, 0};
 	if (act) v = reinterpret_cast<const uint4 *>(a.staging)[g];
 	T[tid] = a.phi_inv[tid];
 	T[tid + 256] = a.phi_inv[tid + 256];
 	__syncthreads();
-	if (act) reinterpret_cast<uint4 *>(const_cast<void *>(job_ptr(a.out, arr)))[i] = ctable_mul(*reinterpret_cast<const ctable_smem *>(T), v);
+	if (act) reinterpret_cast<uint4 *>(p_out[arr - arr0])[i] = ctable_mul(*reinterpret_cast<const ctable_smem *>(T), v);
 }
 
 hipError_t launch_group_writeback(hipStream_t s, const group_writeback_args &a)
 {
-	if (a.count == 0 || a.count > (uint32_t)kGroupMaxJobs || a.n0 == 0 || (uint64_t)a.count * a.n0 > kGroupTailMaxElems || !a.staging || !a.phi_inv) return hipErrorNotSupported;
+	if (a.count == 0 || a.count > (uint32_t)kGroupMaxArrays || a.n0 == 0 || (uint64_t)a.count * a.n0 > kGroupTailMaxElems || !a.ptrs || !a.staging || !a.phi_inv)
+		return hipErrorNotSupported;
+	__atomic_thread_fence(__ATOMIC_SEQ_CST);
 	hipLaunchKernelGGL(k_group_writeback, dim3((unsigned)(((uint64_t)a.count * a.n0 + 255) / 256)), dim3(256), 0, s, a);
 	return hipGetLastError();
 }

@@ -433,10 +433,20 @@ public:
 		op.value = accumulator.id;
 		op.scalar = batch_coeff.raw();
 		op.expr = composition.handle();
-		rows_.emplace_back();
-		for (const auto &r : inputs.rows()) rows_.back().push_back(r.raw());
+		// (a prover with k claims passes the SAME batch of m rows k times in a row, v3/bivariate_product.rs:355-399: the recorded ops
+		// share one copy of it -- compared by content, a new batch may live where the last one did)
+		bool same = !rows_.empty() && rows_.back().size() == inputs.n_rows();
+		for (size_t i = 0; same && i < inputs.n_rows(); i++) {
+			const bn_kslice a = inputs.row(i).raw(), &b = rows_.back()[i];
+			same = a.buf == b.buf && a.off == b.off && a.len == b.len;
+		}
+		if (!same) {
+			rows_.emplace_back();
+			rows_.back().reserve(inputs.n_rows());
+			for (const auto &r : inputs.rows()) rows_.back().push_back(r.raw());
+		}
 		op.n_rows = (uint32_t)inputs.n_rows();
-		row_index_.push_back(ops_.size());
+		row_index_.push_back({ops_.size(), rows_.size() - 1});
 		ops_.push_back(op);
 		keep_.push_back(composition);
 	}
@@ -464,14 +474,14 @@ public:
 	// finalise row pointers (vectors may have moved while recording)
 	std::vector<bn_kop> &finish()
 	{
-		for (size_t i = 0; i < row_index_.size(); i++) ops_[row_index_[i]].rows = rows_[i].data();
+		for (const auto &ri : row_index_) ops_[ri.first].rows = rows_[ri.second].data();
 		return ops_;
 	}
 
 private:
 	std::vector<bn_kop> ops_;
 	std::vector<std::vector<bn_kslice>> rows_;
-	std::vector<size_t> row_index_;
+	std::vector<std::pair<size_t, size_t>> row_index_; // (op, its rows_ entry)
 	std::vector<ExprEval> keep_;
 	uint32_t n_values_ = 0;
 };
@@ -660,8 +670,10 @@ private:
 			size_t j = i;
 			uint32_t mask = 0;
 			B128 hs{};
-			while (j < todo.size() && e0.size() < 32 /* bn::kFoldBatchMax */ && todo[j].len == todo[i].len && todo[j].z == todo[i].z &&
-			       !(todo[j].scaled && mask && !(todo[j].hi_scale == hs))) {
+			// (BN_FOLD_CALL_MAX slices per call -- a whole prover's fold is ONE deferred batch on the backend; a batch that carries
+			// scaled slices stays within the 32 bits of the mask)
+			while (j < todo.size() && e0.size() < (size_t)BN_FOLD_CALL_MAX && !((mask || todo[j].scaled) && e0.size() >= 32) && todo[j].len == todo[i].len &&
+			       todo[j].z == todo[i].z && !(todo[j].scaled && mask && !(todo[j].hi_scale == hs))) {
 				if (todo[j].scaled) {
 					mask |= 1u << e0.size();
 					hs = todo[j].hi_scale;

@@ -59,8 +59,9 @@ pub struct Mi355xExec<'a> {
 
 unsafe impl Send for Mi355xExec<'_> {}
 
-/// Largest batch `bn_extrapolate_line_batch` accepts (binius_amd/csrc/internal.hpp kFoldBatchMax).
-const FOLD_BATCH_MAX: usize = 32;
+/// Largest batch `bn_extrapolate_line_batch` accepts (include/binius_amd.h BN_FOLD_CALL_MAX = binius_amd/csrc/internal.hpp
+/// kFoldCallMax): the fold of a whole prover -- every multilinear of one size -- is one call, which the backend defers as one batch.
+const FOLD_BATCH_MAX: usize = 256;
 
 impl<'a> Mi355xExec<'a> {
 	pub(crate) fn new(ctx: *mut bn_ctx) -> Self {

@@ -98,7 +98,10 @@ int bn_extrapolate_line(bn_ctx *ctx, void *d_evals_0, uint64_t n0, const void *d
                         const bn_f128 *z);
 /* `count` extrapolate_line calls with the same z and length issued inside one executor `map` scope
  * (ComputeLayerExecutor::map, layer.rs:126; the fold of all multilinears of a round,
- * v3/bivariate_product.rs:217-228) as a single launch.  count <= 8 per call. */
+ * v3/bivariate_product.rs:217-228) as one call.  count <= BN_FOLD_CALL_MAX per call: a BivariateSumcheckProver of the PCS
+ * prover holds every committed multilinear of one size and its transparents (piop/prove.rs:262-287: >= 100 for keccak), and
+ * the backend defers the whole fold as one batch whose arrays the next round evaluation's launch folds on the way. */
+#define BN_FOLD_CALL_MAX 256
 int bn_extrapolate_line_batch(bn_ctx *ctx, void *const *d_evals_0, const void *const *d_evals_1, uint32_t count, uint64_t n,
                               const bn_f128 *z);
 /* Extension (not a trait method): the same batch fold, after which the UPPER half of every folded array i with bit i of

@@ -43,6 +43,11 @@ def claims_for(kind, k):
         return 2 * k, [(i, k + i) for i in range(k)]
     if kind == "piop":
         return 2 * k, [(i, k + i) for i in range(k - 1)] + [(0, 2 * k - 1)]
+    if kind == "star":  # k committed multilinears against ONE transparent
+        return k + 1, [(i, k) for i in range(k)]
+    if kind == "keccak":  # k committed columns against three transparents: every column at one point, half at a second, a quarter at a third
+        c, t = k, 3
+        return c + t, [(i, c + i % t) for i in range(c)] + [(i, c + (i + 1) % t) for i in range(0, c, 2)] + [(i, c + (i + 2) % t) for i in range(0, c, 4)]
     c = int(round(k ** 0.5))
     return 2 * c, [(i, c + j) for i in range(c) for j in range(c)]
 
@@ -95,7 +100,7 @@ def run_claims(args):
             c1 = hal.group_counters()
         fused_ms, fused_n = prof["fold_eval_mfma"]
         # fused rounds of one prove on the group path: r = n_vars .. 2 (the first launch of a prove only evaluates)
-        rec = {"bench": "claims", "n_vars": n_vars, "k": k, "m": m, "kind": args.kind, "group": group, "chain_min_log2": os.environ.get("BN_GROUP_CHAIN_MIN_LOG2", "default"), "ms_per_prove": round(ms, 4),
+        rec = {"bench": "claims", "n_vars": n_vars, "k": len(comps), "m": m, "kind": args.kind, "group": group, "chain_min_log2": os.environ.get("BN_GROUP_CHAIN_MIN_LOG2", "default"), "ms_per_prove": round(ms, 4),
                "whole_prove_frac_of_64mN": round(64.0 * m * n / (ms * 1e-3) / PEAK, 4), "verifier_check": bool(ok),
                "prof_ms": {kk: [round(v[0], 4), v[1]] for kk, v in prof.items() if v[1]},
                "group_counters_one_prove": {kk: c1[kk] - c0[kk] for kk in c1}}
