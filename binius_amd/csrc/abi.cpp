@@ -598,6 +598,7 @@ int bn_ctx_create(int device, uint64_t arena_elems, bn_ctx **out)
 	if (const char *a = getenv("BN_CIRCUIT_MULTIPASS")) ctx->circuit_multipass = atoi(a) != 0;
 	if (const char *a = getenv("BN_GROUP")) ctx->grp.enabled = atoi(a) != 0;
 	if (const char *a = getenv("BN_GROUP_SPEC")) ctx->grp.speculate = atoi(a) != 0;
+	ctx->grp.prof = getenv("BN_GROUP_PROF") != nullptr;
 	if (const char *a = getenv("BN_GROUP_CHAIN_MIN_LOG2")) ctx->grp.chain_min_rows = atoi(a) >= 63 ? ~(uint64_t)0 : (uint64_t)1 << (atoi(a) < 0 ? 0 : atoi(a));
 	BN_HIP(hipMalloc((void **)&ctx->d_flag, sizeof(unsigned)));
 	BN_HIP(hipMemset(ctx->d_flag, 0, sizeof(unsigned)));
@@ -789,6 +790,12 @@ int bn_ctx_destroy(bn_ctx *ctx)
 	if (!ctx)
 		return BN_OK;
 	hipSetDevice(ctx->device);
+	if (ctx->grp.prof) {
+		static const char *names[] = {"parse", "match", "plan", "launch", "wait", "answer", "hosted", "defer_fold"};
+		fprintf(stderr, "[bn group prof] host us by phase:");
+		for (int i = 0; i < bn_ctx::group_state::P_N; i++) fprintf(stderr, " %s %.1f (%llu)", names[i], ctx->grp.prof_ns[i] / 1e3, (unsigned long long)ctx->grp.prof_calls[i]);
+		fprintf(stderr, "\n");
+	}
 	arm_cancel(ctx);
 	if (ctx->stream)
 		hipStreamSynchronize(ctx->stream);

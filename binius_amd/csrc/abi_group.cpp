@@ -28,12 +28,31 @@
 #include <algorithm>
 #include <unordered_map>
 
+#include <chrono>
+
 #include "abi_common.hpp"
 #include "hostmul.hpp"
 
 namespace bnabi {
 
 namespace {
+// BN_GROUP_PROF=1: laps of the host's clock, charged to the phases of bn_ctx::group_state
+struct phase_clock {
+	bn_ctx::group_state &g;
+	std::chrono::steady_clock::time_point t;
+	explicit phase_clock(bn_ctx::group_state &gs) : g(gs)
+	{
+		if (g.prof) t = std::chrono::steady_clock::now();
+	}
+	void lap(int phase)
+	{
+		if (!g.prof) return;
+		const auto now = std::chrono::steady_clock::now();
+		g.prof_ns[phase] += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(now - t).count();
+		g.prof_calls[phase]++;
+		t = now;
+	}
+};
 constexpr uint32_t kMaxArrays = (uint32_t)bn::kGroupMaxArrays; // multilinears of a prover (keccak's PCS prover has >= 100 of one size)
 constexpr uint32_t kMaxClaims = (uint32_t)bn::kGroupMaxClaims;
 constexpr size_t kMaxSessions = 16;
@@ -132,14 +151,38 @@ bool parse(const bn_memmap *maps, uint32_t n_maps, const bn_kop *ops, uint32_t n
 		p = (const char *)maps[sl.buf].d_data + sl.off * sizeof(f128);
 		return true;
 	};
-	std::unordered_map<uint32_t, uint32_t> claim_index; // (a << 16 | b) -> claim
+	// (a, b) -> claim.  The reference records the claims in ONE order, first at 1, then at infinity (v3/bivariate_product.rs:355-399):
+	// a cursor that walks the claims found so far answers every look-up of the second half; whatever it misses goes through a
+	// linear search (few claims) or a hash map built on the first miss (many) -- this parser runs in front of EVERY kernel launch,
+	// the single-claim benchmark's included, and allocates nothing for it
+	std::unordered_map<uint32_t, uint32_t> claim_index;
+	bool claim_index_built = false;
+	uint32_t cursor = 0;
 	auto claim_of = [&](uint32_t a, uint32_t b) -> int {
-		const auto it = claim_index.find(a << 16 | b);
-		if (it != claim_index.end()) return (int)it->second;
+		if (cursor < rq.k && rq.pa[cursor] == a && rq.pb[cursor] == b) return (int)cursor++;
+		if (rq.k <= 16) {
+			for (uint32_t c = 0; c < rq.k; c++)
+				if (rq.pa[c] == a && rq.pb[c] == b) {
+					cursor = c + 1;
+					return (int)c;
+				}
+		} else {
+			if (!claim_index_built) {
+				claim_index.reserve(2 * (size_t)kMaxClaims);
+				for (uint32_t c = 0; c < rq.k; c++) claim_index.emplace((uint32_t)rq.pa[c] << 16 | rq.pb[c], c);
+				claim_index_built = true;
+			}
+			const auto it = claim_index.find(a << 16 | b);
+			if (it != claim_index.end()) {
+				cursor = it->second + 1;
+				return (int)it->second;
+			}
+		}
 		if (rq.k >= kMaxClaims) return -1;
 		rq.pa[rq.k] = (uint16_t)a;
 		rq.pb[rq.k] = (uint16_t)b;
-		claim_index.emplace(a << 16 | b, rq.k);
+		if (claim_index_built) claim_index.emplace(a << 16 | b, rq.k);
+		cursor = 0; // (a new claim: the first half of the list is still being written)
 		return (int)rq.k++;
 	};
 	// first pass: the arrays (every ADD of two mapped halves into a whole Local buffer) and the values
@@ -167,10 +210,34 @@ bool parse(const bn_memmap *maps, uint32_t n_maps, const bn_kop *ops, uint32_t n
 		}
 	}
 	if (rq.m == 0 || rq.row_len == 0) return false;
-	// two arrays may not alias each other (a fold writes one while a job reads the other)
-	std::unordered_map<const void *, uint32_t> by_hi, by_lo;
-	for (uint32_t i = 0; i < rq.m; i++)
-		if (!by_hi.emplace(rq.hi[i], i).second || !by_lo.emplace(rq.lo[i], i).second) return false;
+	// two arrays may not alias each other (a fold writes one while a job reads the other); and the way back from an upper half to
+	// its array: a few arrays -- compare them all; many -- sorted by address
+	std::vector<std::pair<const void *, uint32_t>> hi_sorted;
+	if (rq.m <= 16) {
+		for (uint32_t i = 0; i < rq.m; i++)
+			for (uint32_t j = 0; j < i; j++)
+				if (rq.lo[i] == rq.lo[j] || rq.hi[i] == rq.hi[j]) return false;
+	} else {
+		std::vector<const void *> lo_sorted(rq.lo, rq.lo + rq.m);
+		std::sort(lo_sorted.begin(), lo_sorted.end());
+		hi_sorted.reserve(rq.m);
+		for (uint32_t i = 0; i < rq.m; i++) hi_sorted.push_back({rq.hi[i], i});
+		std::sort(hi_sorted.begin(), hi_sorted.end());
+		for (uint32_t i = 1; i < rq.m; i++)
+			if (lo_sorted[i] == lo_sorted[i - 1] || hi_sorted[i].first == hi_sorted[i - 1].first) return false;
+	}
+	uint32_t hi_last[2] = {0, 0}; // (per factor: the array of the previous claim -- the next claim names the one after it, or the same)
+	auto array_of_hi = [&](const void *p, int j) -> int {
+		if (hi_last[j] + 1 < rq.m && rq.hi[hi_last[j] + 1] == p) return (int)hi_last[j] + 1;
+		if (rq.hi[hi_last[j]] == p) return (int)hi_last[j];
+		if (rq.m <= 16) {
+			for (uint32_t i = 0; i < rq.m; i++)
+				if (rq.hi[i] == p) return (int)i;
+			return -1;
+		}
+		const auto it = std::lower_bound(hi_sorted.begin(), hi_sorted.end(), std::make_pair(p, (uint32_t)0));
+		return it != hi_sorted.end() && it->first == p ? (int)it->second : -1;
+	};
 	// second pass, in order: a sum over Locals must come after the ADDs that define them
 	std::vector<char> defined(n_maps, 0);
 	for (uint32_t o = 0; o < n_ops; o++) {
@@ -195,9 +262,9 @@ bool parse(const bn_memmap *maps, uint32_t n_maps, const bn_kop *ops, uint32_t n
 			} else {
 				const char *p = nullptr;
 				if (!plain(sl, p)) return false;
-				const auto it = by_hi.find(p); // the evaluation at 1 is the array's upper half
-				if (it == by_hi.end()) return false;
-				arr[j] = (int)it->second;
+				arr[j] = array_of_hi(p, j); // the evaluation at 1 is the array's upper half
+				if (arr[j] < 0) return false;
+				hi_last[j] = (uint32_t)arr[j];
 			}
 		}
 		if (n_local == 1) return false;
@@ -229,10 +296,21 @@ struct fold_ref {
 };
 struct fold_index {
 	std::unordered_map<const void *, fold_ref> by_out, by_in;
+	bool built = false;
+	fold_ref hint; // where the previous look-up was answered: the next array of a prover is the next entry of the same batch, as a rule
+	void reset()
+	{
+		built = false;
+		hint = fold_ref{};
+	}
 	void build(const bn_ctx *ctx)
 	{
 		by_out.clear();
 		by_in.clear();
+		size_t total = 0;
+		for (const auto &g : ctx->grp.folds) total += g.count;
+		by_out.reserve(2 * total);
+		by_in.reserve(2 * total);
 		for (size_t f = 0; f < ctx->grp.folds.size(); f++) {
 			const auto &g = ctx->grp.folds[f];
 			for (uint32_t j = 0; j < g.count; j++) {
@@ -240,20 +318,49 @@ struct fold_index {
 				by_in.emplace(g.src0[j], fold_ref{(int)f, (int)j});
 			}
 		}
+		built = true;
 	}
-	fold_ref output(const bn_ctx *ctx, const void *lo, const void *hi, uint64_t row_len) const
+	template <class Match>
+	bool try_hint(const bn_ctx *ctx, Match &&match, fold_ref &out)
 	{
+		const auto &folds = ctx->grp.folds;
+		for (int step = 1; step >= 0; step--) { // the entry after the last answer, then the first entry of the next batch
+			fold_ref c = hint;
+			if (c.f < 0) c = fold_ref{0, -1};
+			if (step) {
+				c.j++;
+			} else {
+				c.f++;
+				c.j = 0;
+			}
+			if (c.f < (int)folds.size() && c.j < (int)folds[c.f].count && match(folds[c.f], (uint32_t)c.j)) {
+				out = hint = c;
+				return true;
+			}
+		}
+		return false;
+	}
+	fold_ref output(const bn_ctx *ctx, const void *lo, const void *hi, uint64_t row_len)
+	{
+		if (ctx->grp.folds.empty()) return fold_ref{};
+		fold_ref r;
+		if (try_hint(ctx, [&](const bn_ctx::group_fold &g, uint32_t j) { return g.x0[j] == lo && g.n == 2 * row_len && (const void *)at(lo, row_len) == hi; }, r)) return r;
+		if (!built) build(ctx);
 		const auto it = by_out.find(lo);
 		if (it == by_out.end() || ctx->grp.folds[it->second.f].n != 2 * row_len || (const void *)at(lo, row_len) != hi) return fold_ref{};
-		return it->second;
+		return hint = it->second;
 	}
-	fold_ref input(const bn_ctx *ctx, const void *lo, const void *hi, uint64_t row_len) const
+	fold_ref input(const bn_ctx *ctx, const void *lo, const void *hi, uint64_t row_len)
 	{
+		if (ctx->grp.folds.empty()) return fold_ref{};
+		fold_ref r;
+		if (try_hint(ctx, [&](const bn_ctx::group_fold &g, uint32_t j) { return g.src0[j] == lo && g.n == row_len && g.x1[j] == hi; }, r)) return r;
+		if (!built) build(ctx);
 		const auto it = by_in.find(lo);
 		if (it == by_in.end()) return fold_ref{};
 		const auto &g = ctx->grp.folds[it->second.f];
 		if (g.n != row_len || g.x1[it->second.j] != hi) return fold_ref{};
-		return it->second;
+		return hint = it->second;
 	}
 };
 
@@ -774,6 +881,10 @@ static int legacy_to_group(bn_ctx *ctx)
 
 int group_defer_fold(bn_ctx *ctx, void *const *x0, const void *const *src0, const void *const *x1, uint32_t count, uint64_t n, f128 z)
 {
+	struct lap_on_exit {
+		phase_clock pc;
+		~lap_on_exit() { pc.lap(bn_ctx::group_state::P_DEFER); }
+	} timer{phase_clock(ctx->grp)};
 	int rc = legacy_to_group(ctx);
 	if (rc) return rc;
 	auto &g = ctx->grp;
@@ -797,7 +908,8 @@ int group_defer_fold(bn_ctx *ctx, void *const *x0, const void *const *src0, cons
 			v.push_back(iv{(const char *)x1[i], false});
 			if (src0[i] != x0[i]) v.push_back(iv{(const char *)src0[i], false});
 		}
-		std::sort(v.begin(), v.end(), [](const iv &a, const iv &b) { return a.b < b.b; });
+		if (!std::is_sorted(v.begin(), v.end(), [](const iv &a, const iv &b) { return a.b < b.b; }))
+			std::sort(v.begin(), v.end(), [](const iv &a, const iv &b) { return a.b < b.b; });
 		const char *end_any = nullptr, *end_write = nullptr;
 		const size_t bytes = (size_t)n * sizeof(f128);
 		for (const iv &r : v) {
@@ -890,8 +1002,10 @@ int group_eval(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const bn_kop
 	*handled = false;
 	auto &g = ctx->grp;
 	if (!g.enabled || !ctx->lazy_fold || ctx->peer.active || ctx->tail_max_n_in || !h_out) return BN_OK;
+	phase_clock pc(g);
 	request rq;
 	if (!parse(maps, n_maps, ops, n_ops, ret_values, n_ret, rq)) return BN_OK;
+	pc.lap(bn_ctx::group_state::P_PARSE);
 	// ---- a hosted prover's evaluation of exactly its current halves: host arithmetic
 	for (auto &s : g.sessions) {
 		if (!s.hosted || s.m != rq.m || s.k != rq.k || s.h_len != 2 * rq.row_len) continue;
@@ -902,6 +1016,7 @@ int group_eval(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const bn_kop
 		host_answer(ctx, s, rq, ret_values, n_ret, h_out);
 		s.stamp = ++g.stamp;
 		*handled = true;
+		pc.lap(bn_ctx::group_state::P_HOSTED);
 		return BN_OK;
 	}
 	// ---- sums computed ahead for exactly this request?
@@ -929,7 +1044,6 @@ int group_eval(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const bn_kop
 	}
 	// ---- the request's arrays against the deferred folds
 	fold_index fidx;
-	fidx.build(ctx);
 	fold_ref ref[kMaxArrays];
 	for (uint32_t i = 0; i < rq.m; i++) {
 		ref[i] = fidx.output(ctx, rq.lo[i], rq.hi[i], rq.row_len);
@@ -938,7 +1052,7 @@ int group_eval(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const bn_kop
 			rc = group_flush_touching(ctx, rq.lo[i], rq.row_len, false, /*write=*/false);
 			if (!rc) rc = group_flush_touching(ctx, rq.hi[i], rq.row_len, false, /*write=*/false);
 			if (rc) return rc;
-			fidx.build(ctx); // (indices moved)
+			fidx.reset(); // (indices moved)
 			for (uint32_t q = 0; q <= i; q++) ref[q] = fidx.output(ctx, rq.lo[q], rq.hi[q], rq.row_len);
 		}
 	}
@@ -950,6 +1064,7 @@ int group_eval(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const bn_kop
 	}
 	rc = group_res_alloc(ctx);
 	if (rc) return rc;
+	pc.lap(bn_ctx::group_state::P_MATCH);
 	bn::group_tables *const h_tb = (bn::group_tables *)g.h_tables;
 	const bn::group_tables *const d_tb = (const bn::group_tables *)g.d_tables;
 	// ---- small enough to finish on the host?  (all arrays contiguous, their deferred folds -- if any -- with one challenge)
@@ -1060,6 +1175,7 @@ int group_eval(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const bn_kop
 			g.hosted_started++;
 			host_answer(ctx, *hs, rq, ret_values, n_ret, h_out);
 			*handled = true;
+			pc.lap(bn_ctx::group_state::P_HOSTED);
 			return BN_OK;
 		}
 	}
@@ -1091,6 +1207,7 @@ int group_eval(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const bn_kop
 			r.lo.resize(s.m);
 			r.hi.resize(s.m);
 			bool ok = true;
+			fidx.hint = fold_ref{};
 			for (uint32_t i = 0; i < s.m && ok; i++) {
 				r.ref[i] = fidx.input(ctx, s.lo[i], s.hi[i], s.row_len);
 				ok = r.ref[i].f >= 0 && !consumed[r.ref[i].f][r.ref[i].j];
@@ -1227,6 +1344,7 @@ int group_eval(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const bn_kop
 				if (plain[part_of[q]][j]) ran[part_of[q]][j] = 1;
 	}
 	for (const auto &r : riders) g.spec_jobs += r.s->k;
+	pc.lap(bn_ctx::group_state::P_PLAN);
 	// ---- the launch
 	ctx->mirror.valid = false;
 	const uint64_t seq = ++ctx->mail_seq;
@@ -1274,8 +1392,10 @@ int group_eval(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const bn_kop
 			g.folds.erase(g.folds.begin() + (long)f);
 	}
 	g.on = true;
+	pc.lap(bn_ctx::group_state::P_LAUNCH);
 	rc = wait_mail(ctx, seq);
 	if (rc) return rc;
+	pc.lap(bn_ctx::group_state::P_WAIT);
 	std::vector<f128> raw(n_slots);
 	for (uint32_t i = 0; i < n_slots; i++) {
 		raw[i].lo = __atomic_load_n(&g.h_gmail[i].lo, __ATOMIC_RELAXED);
@@ -1300,6 +1420,7 @@ int group_eval(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const bn_kop
 	}
 	g.evals++;
 	*handled = true;
+	pc.lap(bn_ctx::group_state::P_ANSWER);
 	return BN_OK;
 }
 

@@ -106,6 +106,81 @@ int materialise(bn_ctx *ctx, uint32_t order, uint32_t n_vars, const bn_hal_multi
 	return BN_OK;
 }
 
+// A request wider than one pass of the code below carries (a constraint set's zerocheck: one evaluator per constraint over every
+// column of the table, core/src/constraint_system/prove.rs:431-505 -- keccak: a hundred compositions over two hundred
+// multilinears, each composition reading four or five of them): the evaluators are dealt out, in order, to parts of at most
+// kHalMaxEv evaluators that together read at most kHalMaxMl multilinears and ask for at most 32 values; every part is the same call
+// with its compositions' variables renumbered to the multilinears it reads.  The results are those of the whole: an evaluator's
+// values depend on nothing but its own compositions and multilinears (sumcheck_round_calculation.rs:85-330).
+int round_evals_in_parts(bn_ctx *ctx, uint32_t order, uint32_t n_vars, const void *d_tensor_query, uint32_t query_vars, const bn_hal_multilinear *mls, uint32_t n_mls,
+                         const bn_hal_evaluator *evs, uint32_t n_evs, const bn_f128 *h_points, uint32_t n_points, bn_f128 *h_out)
+{
+	uint32_t pt_hi_all = 0;
+	for (uint32_t e = 0; e < n_evs; e++) {
+		BN_REQUIRE(evs[e].composition && evs[e].composition_at_infinity, "evaluator without a composition");
+		BN_REQUIRE(evs[e].eval_point_start <= evs[e].eval_point_end, "empty evaluation point range");
+		BN_REQUIRE(evs[e].composition->n_vars <= n_mls && evs[e].composition_at_infinity->n_vars <= n_mls,
+		           "composition uses more variables than there are multilinears");
+		if (evs[e].eval_point_end > pt_hi_all) pt_hi_all = evs[e].eval_point_end;
+	}
+	BN_REQUIRE(n_points == (pt_hi_all > 3 ? pt_hi_all - 3 : 0), "nontrivial evaluation points: incorrect length");
+	std::vector<int> local_of(n_mls, -1);
+	size_t out_at = 0;
+	uint32_t e0 = 0;
+	while (e0 < n_evs) {
+		std::vector<uint32_t> used;
+		uint32_t e1 = e0, pts = 0, pt_hi = 0;
+		while (e1 < n_evs && e1 - e0 < (uint32_t)bn::kHalMaxEv) {
+			std::vector<uint32_t> fresh;
+			for (const bn_expr *c : {(const bn_expr *)evs[e1].composition, (const bn_expr *)evs[e1].composition_at_infinity})
+				for (const bn_step &st : c->steps)
+					if (st.kind == BN_STEP_VAR && local_of[st.a] < 0 && std::find(fresh.begin(), fresh.end(), st.a) == fresh.end()) fresh.push_back(st.a);
+			const uint32_t cnt = evs[e1].eval_point_end - evs[e1].eval_point_start;
+			const bool fits = used.size() + fresh.size() <= (size_t)bn::kHalMaxMl && pts + cnt <= 32;
+			if (!fits && e1 > e0) break;
+			BN_REQUIRE(fits, "one evaluator reads more multilinears or asks for more values than a pass carries");
+			for (uint32_t v : fresh) {
+				local_of[v] = (int)used.size();
+				used.push_back(v);
+			}
+			pts += cnt;
+			if (evs[e1].eval_point_end > pt_hi) pt_hi = evs[e1].eval_point_end;
+			e1++;
+		}
+		std::vector<bn_hal_multilinear> part_mls;
+		for (uint32_t v : used) part_mls.push_back(mls[v]);
+		std::vector<bn_expr *> owned;
+		std::vector<bn_hal_evaluator> part_evs;
+		int rc = BN_OK;
+		for (uint32_t e = e0; e < e1 && !rc; e++) {
+			bn_hal_evaluator pe = evs[e];
+			for (int which = 0; which < 2 && !rc; which++) {
+				const bn_expr *c = which ? evs[e].composition_at_infinity : evs[e].composition;
+				std::vector<bn_step> steps = c->steps;
+				for (bn_step &st : steps)
+					if (st.kind == BN_STEP_VAR) st.a = (uint32_t)local_of[st.a];
+				bn_expr *re = nullptr;
+				rc = bn_expr_compile(ctx, steps.data(), steps.size(), &re);
+				if (rc) break;
+				owned.push_back(re);
+				(which ? pe.composition_at_infinity : pe.composition) = re;
+			}
+			part_evs.push_back(pe);
+		}
+		std::vector<bn_f128> part_out(pts ? pts : 1);
+		if (!rc)
+			rc = bn_hal_round_evals(ctx, order, n_vars, d_tensor_query, query_vars, part_mls.data(), (uint32_t)part_mls.size(), part_evs.data(), (uint32_t)part_evs.size(),
+			                        h_points, pt_hi > 3 ? pt_hi - 3 : 0, part_out.data());
+		for (bn_expr *x : owned) bn_expr_free(x);
+		if (rc) return rc;
+		for (uint32_t i = 0; i < pts; i++) h_out[out_at + i] = part_out[i];
+		out_at += pts;
+		for (uint32_t v : used) local_of[v] = -1;
+		e0 = e1;
+	}
+	return BN_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -119,7 +194,12 @@ int bn_hal_round_evals(bn_ctx *ctx, uint32_t order, uint32_t n_vars, const void 
 	BN_FLUSH(ctx);
 	BN_REQUIRE(order == BN_ORDER_LOW_TO_HIGH || order == BN_ORDER_HIGH_TO_LOW, "unknown evaluation order");
 	BN_REQUIRE(n_vars > 0 && n_vars < 40, "computing round evaluations requires at least a single variable");
-	BN_REQUIRE(n_mls <= (uint32_t)bn::kHalMaxMl && n_evs <= (uint32_t)bn::kHalMaxEv, "too many multilinears or evaluators in one call");
+	{
+		uint32_t pts = 0;
+		for (uint32_t e = 0; e < n_evs; e++) pts += evs[e].eval_point_end > evs[e].eval_point_start ? evs[e].eval_point_end - evs[e].eval_point_start : 0;
+		if (n_mls > (uint32_t)bn::kHalMaxMl || n_evs > (uint32_t)bn::kHalMaxEv || pts > 32)
+			return round_evals_in_parts(ctx, order, n_vars, d_tensor_query, query_vars, mls, n_mls, evs, n_evs, h_points, n_points, h_out);
+	}
 	uint32_t pt_lo = 0, pt_hi = 0, total = 0;
 	for (uint32_t e = 0; e < n_evs; e++) {
 		BN_REQUIRE(evs[e].composition && evs[e].composition_at_infinity, "evaluator without a composition");

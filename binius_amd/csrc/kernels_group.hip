@@ -496,6 +496,11 @@ hipError_t launch_group(hipStream_t s, int n_cu, const group_job *jobs_in, uint3
 	uint64_t total_elems = 0;
 	std::vector<double> w;
 	std::vector<uint32_t> tiles, cap, cnt, first, len;
+	w.reserve(n_jobs);
+	tiles.reserve(n_jobs);
+	cap.reserve(n_jobs);
+	first.reserve(n_jobs);
+	len.reserve(n_jobs);
 	double W = 0;
 	uint32_t n_units = 0, max_tiles = 0;
 	for (uint32_t i = 0; i < n_jobs;) {
@@ -527,7 +532,7 @@ hipError_t launch_group(hipStream_t s, int n_cu, const group_job *jobs_in, uint3
 	bool packed = n_units > 32 || (int)n_units > n_cu;
 	// (one unit per job where that is no worse by the same model: every unit its proportional share of the workgroups)
 	double unpacked_cost = -1;
-	if (packed && (int)n_units <= n_cu) {
+	if (packed && (int)n_units <= n_cu) { // (cheap: one pass over the jobs)
 		unpacked_cost = 0;
 		for (uint32_t i = 0; i < n_units; i++) {
 			uint32_t c = (uint32_t)((double)n_cu * w[i] / W);
@@ -541,7 +546,23 @@ hipError_t launch_group(hipStream_t s, int n_cu, const group_job *jobs_in, uint3
 	uint32_t best_U = 0;
 	double best_cost = 0;
 	std::vector<uint32_t> best_assign;
-	if (packed) {
+	// (a prover's rounds repeat one shape with halving sizes: the decision for "these many units of this much weight on this many
+	// tiles" is remembered -- the model costs ~10 us of host time per launch at a hundred units)
+	struct decision {
+		uint32_t n_units = 0, max_tiles = 0, U = 0;
+		int n_cu = 0;
+		double W = 0;
+		bool packed = false;
+		std::vector<uint32_t> assign;
+	};
+	static thread_local decision last;
+	const bool remembered = packed && last.n_units == n_units && last.max_tiles == max_tiles && last.W == W && last.n_cu == n_cu && getenv("BN_GROUP_PACK_U") == nullptr;
+	if (remembered) {
+		packed = last.packed;
+		best_U = last.U;
+		best_assign = last.assign;
+	}
+	if (packed && !remembered) {
 		// ---- U super-units of g = n_cu / U workgroups; items (units) dealt out heaviest first to the least loaded super-unit
 		std::vector<uint32_t> by_weight(n_units);
 		for (uint32_t i = 0; i < n_units; i++) by_weight[i] = i;
@@ -575,6 +596,34 @@ hipError_t launch_group(hipStream_t s, int n_cu, const group_job *jobs_in, uint3
 		}
 		if (!best_U && unpacked_cost < 0) return hipErrorNotSupported;
 		if (unpacked_cost >= 0 && (!best_U || unpacked_cost <= best_cost)) packed = false;
+		static const int force_u = [] { // (BN_GROUP_PACK_U, live, an experiment's switch: that many super-units; -1: one unit per job)
+			const char *e = getenv("BN_GROUP_PACK_U");
+			return e ? atoi(e) : 0;
+		}();
+		if (force_u < 0 && unpacked_cost >= 0) packed = false;
+		if (force_u > 0 && (uint32_t)force_u <= n_units && (uint32_t)n_cu / (uint32_t)force_u >= (g_min ? g_min : 1)) {
+			packed = true;
+			best_U = (uint32_t)force_u;
+			std::vector<double> load(best_U, 0.0);
+			best_assign.assign(n_units, 0);
+			for (uint32_t o = 0; o < n_units; o++) {
+				const uint32_t it = by_weight[o];
+				uint32_t u = 0;
+				for (uint32_t q = 1; q < best_U; q++)
+					if (load[q] < load[u]) u = q;
+				best_assign[it] = u;
+				load[u] += w[it];
+			}
+		}
+	}
+	if (!remembered && (n_units > 32 || (int)n_units > n_cu)) {
+		last.n_units = n_units;
+		last.n_cu = n_cu;
+		last.max_tiles = max_tiles;
+		last.W = W;
+		last.packed = packed;
+		last.U = best_U;
+		last.assign = best_assign;
 	}
 	if (packed) {
 		const uint32_t U = best_U, g = (uint32_t)n_cu / U;
@@ -679,7 +728,13 @@ hipError_t launch_group(hipStream_t s, int n_cu, const group_job *jobs_in, uint3
 	}();
 	// streaming accesses once the launch's arrays cannot stay in the caches anyway (the single-claim kernels' threshold is 2^25
 	// elements per array = 2^27 elements touched)
-	const bool nt = full && nt_min_log2 < 62 && total_elems >= (4ull << nt_min_log2);
+	// (BN_GROUP_NT_MIN_LOG2, live: the same threshold for launches of the group kernel only -- an experiment's switch)
+	static const int nt_group_log2 = [] {
+		const char *e = getenv("BN_GROUP_NT_MIN_LOG2");
+		return e ? atoi(e) : -1;
+	}();
+	const int nt_log2 = nt_group_log2 >= 0 ? nt_group_log2 : nt_min_log2;
+	const bool nt = full && nt_log2 < 62 && total_elems >= (4ull << nt_log2);
 	constexpr unsigned lds = 2 * kFoldGroups * kTile4W * 4;
 	{
 		const void *fn[4] = {reinterpret_cast<const void *>(&k_group_fp4<false, false>), reinterpret_cast<const void *>(&k_group_fp4<true, false>),

@@ -136,6 +136,35 @@ public:
 	{
 		bool any_transparent_left = false;
 		const bn_f128 z = challenge.raw();
+		// High-to-Low order, every multilinear Folded and full: the fold is evals_0 += z (evals_1 - evals_0) on the halves, in place
+		// (sumcheck_folding.rs:218-232 = extrapolate_line, compute/src/layer.rs:421) -- ALL multilinears of the call as one batch of the
+		// ComputeLayer instead of a launch per multilinear (a constraint set's zerocheck folds every column of its table each round)
+		if (evaluation_order == EvaluationOrder::HighToLow && n_vars >= 1) {
+			bool plain = !multilinears.empty();
+			for (const auto &m : multilinears)
+				plain = plain && m.kind == SumcheckMultilinear::Folded && m.large_field_folded_evals.len_ == (size_t)1 << n_vars;
+			if (plain) {
+				struct Args {
+					FSliceMut evals_0;
+					FSlice evals_1;
+				};
+				std::vector<Args> prepared;
+				for (auto &m : multilinears) {
+					auto halves = ComputeMemory::split_half_mut(FSliceMut{const_cast<void *>(m.large_field_folded_evals.ptr), m.large_field_folded_evals.len_});
+					prepared.push_back(Args{halves.first, ComputeMemory::to_const(halves.second)});
+				}
+				hal_.execute([&](ComputeLayerExecutor &exec) {
+					exec.map(prepared.begin(), prepared.end(), [&](ComputeLayerExecutor &e, Args &a) {
+						e.extrapolate_line(a.evals_0, a.evals_1, challenge);
+						return 0;
+					});
+					return std::vector<B128>{};
+				});
+				for (size_t i = 0; i < multilinears.size(); i++)
+					multilinears[i] = SumcheckMultilinear::folded(FSlice{prepared[i].evals_0.ptr, prepared[i].evals_0.len_}, multilinears[i].suffix_eval);
+				return false;
+			}
+		}
 		for (auto &m : multilinears) {
 			if (m.kind == SumcheckMultilinear::Transparent && m.switchover_round > 0) {
 				m.switchover_round--;

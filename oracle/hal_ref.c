@@ -56,7 +56,9 @@ int ref_hal_round_evals(int order, uint32_t n_vars, const ref_b128 *tensor_query
 	size_t total = 0;
 	for (uint32_t e = 0; e < n_evs; e++) total += evs[e].eval_point_end - evs[e].eval_point_start;
 	memset(out, 0, total * sizeof(ref_b128));
-	ref_b128 e0[64], e1[64], row[64];
+	/* (one value per multilinear: a constraint set's zerocheck passes every column of its table, prove.rs:431-505) */
+	ref_b128 *e0 = (ref_b128 *)calloc(3 * (size_t)(n_mls ? n_mls : 1), sizeof(ref_b128));
+	ref_b128 *e1 = e0 + (n_mls ? n_mls : 1), *row = e1 + (n_mls ? n_mls : 1);
 	for (uint64_t i = 0; i < half && !rc; i++) {
 		for (uint32_t k = 0; k < n_mls; k++) {
 			/* the substituted variable is the lowest one (LowToHigh: pairs 2i, 2i+1, round_calculation.rs:443-464)
@@ -92,6 +94,7 @@ int ref_hal_round_evals(int order, uint32_t n_vars, const ref_b128 *tensor_query
 	}
 	for (uint32_t k = 0; k < n_mls; k++) free(virt[k]);
 	free(virt);
+	free(e0);
 	return rc;
 }
 
