@@ -63,6 +63,11 @@ def host_lib():
             C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(F128), C.c_uint32, C.POINTER(F128), C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32,
             C.POINTER(C.c_uint32), C.POINTER(F128), C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_double),
         ]
+        L.bnh_eqind_sumcheck_prove.restype = C.c_int
+        L.bnh_eqind_sumcheck_prove.argtypes = [
+            C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p), C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p, C.POINTER(C.c_uint32),
+            C.POINTER(F128), C.POINTER(F128), C.c_void_p, C.c_uint64, C.POINTER(F128), C.POINTER(F128), C.POINTER(F128), C.POINTER(F128),
+        ]
         L.bnh_rccl_open.argtypes = [C.c_char_p]
         L.bnh_rccl_unique_id.argtypes = [C.c_void_p]
         L.bnh_rccl_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
@@ -345,6 +350,47 @@ class PiopPlan:
                 out.append((kind, [from_f128(self.scalars[at_s + j]) for j in range(cnt)]))
                 at_s += cnt
         return out
+
+
+class EqIndPlan:
+    """EqIndSumcheckProver over the old HAL (bnh_eqind_sumcheck_prove = binius_amd/host/eq_ind.hpp;
+    crates/core/src/protocols/sumcheck/prove/eq_ind.rs:378-644): the zerocheck of a constraint set, one composition (degree 2)
+    per constraint over ALL multilinears, High-to-Low.  multilins: device slices of 2^n_vars elements, FOLDED IN PLACE by run();
+    compositions: list of (steps, steps_of_the_leading_form) in compile_expr's notation; sums: one claimed sum per composition;
+    eq_scratch: device slice of >= 2^(n_vars - 1) elements."""
+
+    def __init__(self, hal, n_vars, multilins, compositions, sums, eq_ind_challenges, eq_scratch, batch_coeff, challenges):
+        from ._ffi import make_steps
+
+        self.hal, self.n_vars, self.m = hal, n_vars, len(multilins)
+        self._keep = (multilins, eq_scratch)
+        self.ptrs = (C.c_void_p * max(1, self.m))(*[x.ptr for x in multilins])
+        self.n_comps = len(compositions)
+        flat = [st for c, _ in compositions for st in c]
+        flat_inf = [st for _, ci in compositions for st in ci]
+        self.steps, self.steps_inf = make_steps(flat) if flat else None, make_steps(flat_inf) if flat_inf else None
+        self.n_steps = (C.c_uint32 * max(1, self.n_comps))(*[len(c) for c, _ in compositions])
+        self.n_steps_inf = (C.c_uint32 * max(1, self.n_comps))(*[len(ci) for _, ci in compositions])
+        self.sums = _f128_array(list(sums) if sums else [0])
+        assert len(eq_ind_challenges) == n_vars and len(challenges) >= n_vars
+        self.eqc, self.ch = _f128_array(list(eq_ind_challenges)), _f128_array(list(challenges))
+        self.bc = to_f128(batch_coeff)
+        self.eq_scratch = eq_scratch
+        self.coeffs = (F128 * (4 * n_vars))()
+        self.final = (F128 * (self.m + 1))()
+
+    def run(self):
+        rc = host_lib().bnh_eqind_sumcheck_prove(
+            self.hal._h, self.n_vars, self.m, self.ptrs, self.n_comps, C.cast(self.steps, C.c_void_p), self.n_steps, C.cast(self.steps_inf, C.c_void_p),
+            self.n_steps_inf, self.sums, self.eqc, self.eq_scratch.ptr, self.eq_scratch.len, C.byref(self.bc), self.ch, self.coeffs, self.final)
+        if rc != 0:
+            raise BnError(rc, host_lib().bnh_last_error().decode())
+
+    def round_coeffs(self):
+        return [[from_f128(self.coeffs[4 * r + i]) for i in range(4)] for r in range(self.n_vars)]
+
+    def final_evals(self):
+        return [from_f128(self.final[j]) for j in range(self.m + 1)]
 
 
 class ShmExchange:

@@ -302,6 +302,13 @@ public:
 		return n;
 	}
 	const std::vector<bn_step> &steps() const { return steps_; }
+	// a circuit given as its step list (ArithCircuit::steps, math/src/arith_expr.rs:200-226): what crosses the C boundary
+	static ArithCircuit from_steps(std::vector<bn_step> steps)
+	{
+		ArithCircuit c;
+		c.steps_ = std::move(steps);
+		return c;
+	}
 
 private:
 	static bn_step step(uint32_t kind, uint32_t a, uint64_t b, B128 c)

@@ -24,6 +24,7 @@
 #include <chrono>
 #include <cstring>
 
+#include "eq_ind.hpp"
 #include "fri.hpp"
 #include "piop.hpp"
 #include "sumcheck.hpp"
@@ -797,6 +798,65 @@ int bnh_batch_sumcheck_prove(bn_ctx *ctx, uint32_t n_provers, const uint32_t *pr
 				for (const B128 &v : it.scalars) final_evals_out[fe++] = v.raw();
 			}
 		}
+		return 0;
+	} catch (const Error &e) {
+		g_err = e.what();
+		return (int)e.kind();
+	} catch (const std::exception &e) {
+		g_err = e.what();
+		return BN_ERR_CORE_LIB;
+	}
+}
+
+// EqIndSumcheckProver (crates/core/src/protocols/sumcheck/prove/eq_ind.rs:378-644; binius_amd/host/eq_ind.hpp) over the old HAL
+// (binius_hal::ComputationBackend -> bn_hal_round_evals / the ComputeLayer's folds), High-to-Low, compositions of degree 2: the
+// zerocheck of a constraint set -- one composition per constraint over ALL multilinears of the table
+// (core/src/constraint_system/prove.rs:431-505).
+//   d_multilins[n_mls]: 2^n_vars elements each, FOLDED IN PLACE;  steps / steps_inf: the n_comps compositions and their leading
+//   forms, concatenated (n_steps[c] / n_steps_inf[c] steps each);  sums[n_comps];  eq_ind_challenges[n_vars];
+//   d_eq_ind: 2^(n_vars - 1) elements of scratch for the indicator's partial evaluations (expanded here, eq_ind.rs:430-446)
+//   round_coeffs_out[4 * n_vars]; final_evals_out[n_mls + 1] (the last one: the indicator's prefix evaluation)
+int bnh_eqind_sumcheck_prove(bn_ctx *ctx, uint32_t n_vars, uint32_t n_mls, void *const *d_multilins, uint32_t n_comps, const bn_step *steps,
+                             const uint32_t *n_steps, const bn_step *steps_inf, const uint32_t *n_steps_inf, const bn_f128 *sums,
+                             const bn_f128 *eq_ind_challenges, void *d_eq_ind, uint64_t eq_ind_elems, const bn_f128 *batch_coeff, const bn_f128 *challenges,
+                             bn_f128 *round_coeffs_out, bn_f128 *final_evals_out)
+{
+	try {
+		if (!ctx || (!d_multilins && n_mls) || (n_comps && (!steps || !n_steps || !steps_inf || !n_steps_inf || !sums)) || !eq_ind_challenges || !d_eq_ind || !batch_coeff ||
+		    !challenges || !round_coeffs_out || !final_evals_out)
+			throw Error(Error::InputValidation, "null argument");
+		if (n_vars == 0 || n_vars >= 40) throw Error(Error::InputValidation, "n_vars out of range");
+		if (eq_ind_elems < ((uint64_t)1 << (n_vars - 1))) throw Error(Error::InputValidation, "the indicator's scratch holds fewer than 2^(n_vars - 1) elements");
+		ComputeLayer hal(ctx);
+		Mi355xBackend backend(hal);
+		DeviceBumpAllocator dev_alloc(FSliceMut{d_eq_ind, (size_t)eq_ind_elems});
+		std::vector<SumcheckMultilinear> mls;
+		for (uint32_t j = 0; j < n_mls; j++) mls.push_back(SumcheckMultilinear::folded(FSlice{d_multilins[j], (size_t)1 << n_vars}));
+		std::vector<EqIndComposition> comps;
+		std::vector<B128> sv;
+		size_t at = 0, at_inf = 0;
+		for (uint32_t c = 0; c < n_comps; c++) {
+			EqIndComposition ec;
+			ec.composition = hal.compile_expr(ArithCircuit::from_steps(std::vector<bn_step>(steps + at, steps + at + n_steps[c])));
+			ec.composition_at_infinity = hal.compile_expr(ArithCircuit::from_steps(std::vector<bn_step>(steps_inf + at_inf, steps_inf + at_inf + n_steps_inf[c])));
+			at += n_steps[c];
+			at_inf += n_steps_inf[c];
+			comps.push_back(ec);
+			sv.emplace_back(sums[c].lo, sums[c].hi);
+		}
+		std::vector<B128> eqc;
+		for (uint32_t i = 0; i < n_vars; i++) eqc.emplace_back(eq_ind_challenges[i].lo, eq_ind_challenges[i].hi);
+		// eq_ind_expand, High-to-Low: the tensor expansion of all challenges but the last (eq_ind.rs:430-446)
+		const FSlice table = backend.tensor_product_full_query(std::vector<B128>(eqc.begin(), eqc.end() - 1), dev_alloc);
+		EqIndSumcheckProver prover(hal, backend, dev_alloc, n_vars, std::move(mls), std::move(comps), std::move(sv), eqc, FSliceMut{const_cast<void *>(table.ptr), table.len_});
+		const B128 bc(batch_coeff->lo, batch_coeff->hi);
+		for (uint32_t r = 0; r < n_vars; r++) {
+			const std::vector<B128> rc = prover.execute(bc);
+			for (size_t i = 0; i < 4; i++) round_coeffs_out[4 * r + i] = rc[i].raw();
+			prover.fold(B128(challenges[r].lo, challenges[r].hi));
+		}
+		const std::vector<B128> fin = prover.finish();
+		for (size_t j = 0; j < fin.size(); j++) final_evals_out[j] = fin[j].raw();
 		return 0;
 	} catch (const Error &e) {
 		g_err = e.what();

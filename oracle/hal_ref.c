@@ -35,7 +35,7 @@ int ref_hal_round_evals(int order, uint32_t n_vars, const ref_b128 *tensor_query
                         const ref_hal_multilinear *mls, uint32_t n_mls, const ref_hal_evaluator *evs, uint32_t n_evs,
                         const ref_b128 *nontrivial_points, uint32_t n_points, ref_b128 *out)
 {
-	if (n_vars == 0 || n_mls > 64) return 1;
+	if (n_vars == 0) return 1;
 	/* union of the evaluation point ranges; the nontrivial points must cover indices 3.. (round_calculation.rs:113-125) */
 	uint32_t pt_lo = 0, pt_hi = 0;
 	for (uint32_t e = 0; e < n_evs; e++) {

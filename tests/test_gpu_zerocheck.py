@@ -1,0 +1,59 @@
+"""GPU parity of the zerocheck of a constraint set through the old HAL (VERDICT r5 missing 2): EqIndSumcheckProver
+(crates/core/src/protocols/sumcheck/prove/eq_ind.rs:378-644) as the C++ mirror binius_amd/host/eq_ind.hpp drives it --
+sumcheck_compute_round_evals with ONE evaluator per constraint over ALL multilinears of the table, the fold of every
+multilinear, the fold of the indicator's partial evaluations -- for the keccak table's constraint set
+(m3/src/gadgets/hash/keccak/stacked.rs:142-151, 340-363: 50 constraints over 102 multilinears for one batch of rounds, 100 over
+204 for the three of the permutation) and a small mixed one; every round polynomial and final evaluation against the oracle's
+restatement (oracle/zerocheck_ref.py, pinned by tests/test_oracle_zerocheck.py), bit for bit."""
+import numpy as np
+import pytest
+
+from test_gpu_hal import upload
+from test_gpu_hal_wide import keccak_constraints
+
+pytestmark = pytest.mark.gpu
+
+
+def run_both(oracle, n_vars, mls, comps, seed):
+    import binius_amd
+    from binius_amd._host import EqIndPlan
+    from oracle import zerocheck_ref
+
+    m = len(mls)
+    stream = oracle.random_scalars(seed, 2 * n_vars + 1 + len(comps))
+    eqc, ch, bc, sums = stream[:n_vars], stream[n_vars : 2 * n_vars], stream[2 * n_vars], stream[2 * n_vars + 1 :]
+    # (the claimed sums only enter through R'(0) = (sum - alpha R'(1)) / (1 - alpha): any values exercise the same arithmetic, and
+    # a table of random columns satisfies no constraint anyway)
+    want = zerocheck_ref.eqind_sumcheck_prove(mls, n_vars, comps, sums, eqc, bc, ch)
+    n = 1 << n_vars
+    with binius_amd.Context(0, (m + 2) * n + (1 << 16)) as hal:
+        alloc = hal.dev_alloc()
+        d = [upload(hal, alloc, x) for x in mls]
+        scratch = alloc.alloc(max(1, n // 2) + 64)
+        plan = EqIndPlan(hal, n_vars, d, comps, sums, eqc, scratch, bc, ch)
+        plan.run()
+        got = (plan.round_coeffs(), plan.final_evals())
+        # the multilinears were folded in place: their first elements are the final evaluations
+        for j in (0, m - 1):
+            assert oracle.arr_to_ints(hal.copy_d2h(d[j].slice(0, 1)))[0] == want[1][j]
+    for r in range(n_vars):
+        assert got[0][r] == want[0][r], "round %d differs from the oracle" % r
+    assert got[1] == want[1]
+
+
+@pytest.mark.parametrize("n_vars,n_batches", [(1, 1), (4, 1), (9, 3), (13, 1), (16, 1)])
+def test_keccak_zerocheck_vs_oracle(oracle, n_vars, n_batches):
+    n_mls, cons = keccak_constraints(n_batches)
+    mls = [oracle.random_b128(0x2E00000 + 256 * n_vars + j, 1 << n_vars) for j in range(n_mls)]
+    run_both(oracle, n_vars, mls, cons, 0x2E10 + n_vars)
+
+
+@pytest.mark.parametrize("n_vars", [2, 6, 11])
+def test_small_mixed_zerocheck_vs_oracle(oracle, n_vars):
+    comps = [
+        ([("var", 0), ("var", 1), ("mul", 0, 1), ("var", 2), ("add", 2, 3)], [("var", 0), ("var", 1), ("mul", 0, 1)]),
+        ([("var", 3), ("var", 4), ("add", 0, 1), ("var", 5), ("mul", 2, 3)], [("var", 3), ("var", 4), ("add", 0, 1), ("var", 5), ("mul", 2, 3)]),
+        ([("var", 2), ("var", 5), ("mul", 0, 1), ("var", 0), ("add", 2, 3), ("const", 0x1234567890ABCDEF1122334455667788), ("add", 4, 5)], [("var", 2), ("var", 5), ("mul", 0, 1)]),
+    ]
+    mls = [oracle.random_b128(0x2E20000 + 16 * n_vars + j, 1 << n_vars) for j in range(6)]
+    run_both(oracle, n_vars, mls, comps, 0x2E30 + n_vars)
