@@ -599,6 +599,7 @@ int bn_ctx_create(int device, uint64_t arena_elems, bn_ctx **out)
 	if (const char *a = getenv("BN_GROUP")) ctx->grp.enabled = atoi(a) != 0;
 	if (const char *a = getenv("BN_GROUP_SPEC")) ctx->grp.speculate = atoi(a) != 0;
 	ctx->grp.prof = getenv("BN_GROUP_PROF") != nullptr;
+	if (const char *a = getenv("BN_HAL_EQ_SET")) ctx->hal_eq_set = atoi(a) != 0;
 	if (const char *a = getenv("BN_GROUP_CHAIN_MIN_LOG2")) ctx->grp.chain_min_rows = atoi(a) >= 63 ? ~(uint64_t)0 : (uint64_t)1 << (atoi(a) < 0 ? 0 : atoi(a));
 	BN_HIP(hipMalloc((void **)&ctx->d_flag, sizeof(unsigned)));
 	BN_HIP(hipMemset(ctx->d_flag, 0, sizeof(unsigned)));
@@ -802,6 +803,7 @@ int bn_ctx_destroy(bn_ctx *ctx)
 	peer_release(ctx);
 	if (ctx->d_arm_relay) hipFree(ctx->d_arm_relay);
 	if (ctx->hal_const) hipFree(ctx->hal_const);
+	if (ctx->h_mul_jobs) hipHostFree(ctx->h_mul_jobs);
 	if (ctx->side) {
 		hipStreamSynchronize(ctx->side);
 		hipStreamDestroy(ctx->side);
@@ -1151,9 +1153,18 @@ int bn_expr_compile(bn_ctx *ctx, const bn_step *steps, uint64_t n_steps, bn_expr
 }
 
 
+} // extern "C"
+namespace bn {
+static std::atomic<uint64_t> g_expr_epoch{1};
+uint64_t expr_epoch() { return g_expr_epoch.load(std::memory_order_relaxed); }
+void expr_epoch_bump() { g_expr_epoch.fetch_add(1, std::memory_order_relaxed); }
+} // namespace bn
+extern "C" {
+
 int bn_expr_free(bn_expr *expr)
 {
 	if (!expr) return BN_OK;
+	bn::expr_epoch_bump();
 	if (expr->d_steps) hipFree(expr->d_steps);
 	delete expr;
 	return BN_OK;

@@ -13,6 +13,7 @@
 // kernels): the reference does the same thing subcube by subcube to save memory
 // (sumcheck_round_calculation.rs:404-418, 496-518).
 #include <algorithm>
+#include <memory>
 #include <map>
 
 #include "abi_common.hpp"
@@ -23,11 +24,9 @@ namespace {
 // An ArithCircuit as a sum of monomials  coeff * prod(vars)  over GF(2^128) (variables may repeat: a^2 * b is the
 // multiset {a, a, b}).  Empty result = too large for the routed path (more than kMaxTerms monomials / degree > 3 / a
 // power above 3): the caller falls back to the interpreter kernel.
-struct monomial {
-	std::vector<uint32_t> vars; // sorted
-	f128 coeff;
-};
+typedef bn_expr::monomial monomial;
 constexpr size_t kMaxTerms = 12;
+int hal_const_tables(bn_ctx *ctx, uint64_t half);
 bool expand_poly(const bn_expr *e, std::vector<monomial> &out)
 {
 	typedef std::map<std::vector<uint32_t>, f128> poly;
@@ -103,6 +102,247 @@ int materialise(bn_ctx *ctx, uint32_t order, uint32_t n_vars, const bn_hal_multi
 		BN_HIP(bn::launch_fold_right(ctx->stream, ctx->n_cu, ml.d_evals, ml.tower_level, q, q_len, dst, out_len));
 	else
 		BN_HIP(bn::launch_fold_left(ctx->stream, ctx->n_cu, ml.d_evals, ml.tower_level, q, q_len, dst, out_len));
+	return BN_OK;
+}
+
+// the expansion of a compiled circuit, computed once per bn_expr (nullptr: not a polynomial the routed paths take)
+const std::vector<monomial> *poly_of(const bn_expr *e)
+{
+	if (e->poly_state == 0) e->poly_state = expand_poly(e, e->poly) ? 1 : 2;
+	return e->poly_state == 1 ? &e->poly : nullptr;
+}
+
+// ---- a constraint set's zerocheck in TWO launches per round --------------------------------------------------------------------
+// The reference hands sumcheck_compute_round_evals one equality-indicator evaluator per constraint over every column of the table
+// (core/src/constraint_system/prove.rs:431-505; keccak: 100 constraints of degree 2 over 204 columns), evaluation points 1 and
+// infinity, High-to-Low, every multilinear Folded and full.  With every composition a sum of monomials of at most two columns,
+//     S_e(1) = sum_t coeff_t <eq, prod(vars_t)(upper halves)>,   S_e(inf) = sum_t' coeff_t' <eq, prod(vars_t')(lower + upper halves)>
+// and every DISTINCT monomial of the whole set is ONE evaluate job (kind 1: both sums at once) of ONE launch of the claim groups'
+// kernel (kernels_group.hip):   {}      (0 | 1) against (0 | eq)       {v}    (v_lo | v_hi) against (0 | eq)
+//                               {u, w}  (E_lo | E_hi) against (w_lo | w_hi)  with  E = eq (.) u  on both halves of u
+// -- eq (.) (u_lo + u_hi) = E_lo + E_hi, so the job's sum at infinity is the three-factor sum the evaluator asks for.  The scaled
+// columns E are one launch of the batched element-wise product (kernels_mul9.hip k_mul9_jobs) in front; which column of a product
+// is scaled is a greedy vertex cover of the products' graph (keccak's chi rows are five-cycles: three scaled columns per row
+// instead of five).  The coefficients are applied to the 16-byte sums on the host.  The plan (monomials, cover, terms per
+// evaluator) is kept while the same compiled compositions come back.
+struct eq_set_plan {
+	std::vector<const bn_expr *> key; // (composition, composition_at_infinity) per evaluator
+	uint64_t epoch = 0;               // bn::expr_epoch() when the plan was made: no expression has been freed since
+	uint32_t n_mls = 0;
+	struct mono {
+		int u = -1, w = -1; // {}: -1, -1; {v}: v, -1; {u, w}: u = the scaled column
+	};
+	std::vector<mono> monos;
+	std::vector<uint32_t> scaled; // columns with an E array, in E order
+	std::vector<int> e_of;        // column -> its E index (-1: none)
+	struct term {
+		uint32_t mono;
+		f128 coeff;
+	};
+	std::vector<std::vector<term>> t1, tinf; // per evaluator
+};
+constexpr uint32_t kEqSetMaxScaled = 256; // (two element-wise jobs each: the pinned table holds 512)
+constexpr uint32_t kEqSetMaxMonos = 4096;
+
+std::shared_ptr<eq_set_plan> make_eq_set_plan(const bn_hal_evaluator *evs, uint32_t n_evs, uint32_t n_mls)
+{
+	auto pl = std::make_shared<eq_set_plan>();
+	pl->n_mls = n_mls;
+	pl->epoch = bn::expr_epoch();
+	std::map<std::vector<uint32_t>, uint32_t> index;
+	pl->t1.resize(n_evs);
+	pl->tinf.resize(n_evs);
+	for (uint32_t e = 0; e < n_evs; e++) {
+		pl->key.push_back(evs[e].composition);
+		pl->key.push_back(evs[e].composition_at_infinity);
+		for (int which = 0; which < 2; which++) {
+			const std::vector<monomial> *p = poly_of(which ? evs[e].composition_at_infinity : evs[e].composition);
+			if (!p) return nullptr;
+			for (const monomial &t : *p) {
+				if (t.vars.size() > 2) return nullptr;
+				for (uint32_t v : t.vars)
+					if (v >= n_mls) return nullptr;
+				auto it = index.find(t.vars);
+				if (it == index.end()) {
+					if (pl->monos.size() >= kEqSetMaxMonos) return nullptr;
+					eq_set_plan::mono m;
+					if (t.vars.size() >= 1) m.u = (int)t.vars[0];
+					if (t.vars.size() == 2) m.w = (int)t.vars[1];
+					it = index.emplace(t.vars, (uint32_t)pl->monos.size()).first;
+					pl->monos.push_back(m);
+				}
+				(which ? pl->tinf[e] : pl->t1[e]).push_back(eq_set_plan::term{it->second, t.coeff});
+			}
+		}
+	}
+	// which column of every product carries the indicator: the column in the most products not yet covered, again and again
+	pl->e_of.assign(n_mls, -1);
+	std::vector<char> covered(pl->monos.size(), 0);
+	for (;;) {
+		std::vector<uint32_t> cnt(n_mls, 0);
+		bool any = false;
+		for (size_t i = 0; i < pl->monos.size(); i++) {
+			const auto &m = pl->monos[i];
+			if (m.w < 0 || covered[i]) continue;
+			any = true;
+			cnt[m.u]++;
+			if (m.w != m.u) cnt[m.w]++;
+		}
+		if (!any) break;
+		uint32_t best = 0;
+		for (uint32_t v = 1; v < n_mls; v++)
+			if (cnt[v] > cnt[best]) best = v;
+		if (pl->scaled.size() >= kEqSetMaxScaled) return nullptr;
+		pl->e_of[best] = (int)pl->scaled.size();
+		pl->scaled.push_back(best);
+		for (size_t i = 0; i < pl->monos.size(); i++) {
+			auto &m = pl->monos[i];
+			if (m.w < 0 || covered[i] || (m.u != (int)best && m.w != (int)best)) continue;
+			if (m.w == (int)best) std::swap(m.u, m.w); // u = the scaled one
+			covered[i] = 1;
+		}
+	}
+	return pl;
+}
+
+constexpr int kEqSetDeclined = -2000; // (internal: not this shape -- the caller goes on with the general code)
+int round_evals_eq_set(bn_ctx *ctx, uint32_t n_vars, const bn_hal_multilinear *mls, uint32_t n_mls, const bn_hal_evaluator *evs, uint32_t n_evs, bn_f128 *h_out)
+{
+	const uint64_t full = (uint64_t)1 << n_vars, half = full >> 1;
+	const void *eq = n_evs ? evs[0].d_eq_ind : nullptr;
+	if (!eq || !ctx->grp.enabled) return kEqSetDeclined;
+	for (uint32_t k = 0; k < n_mls; k++)
+		if (mls[k].kind != BN_HAL_ML_FOLDED || mls[k].len < full || !mls[k].d_evals) return kEqSetDeclined;
+	for (uint32_t e = 0; e < n_evs; e++)
+		if (evs[e].d_eq_ind != eq || evs[e].eval_point_start < 1 || evs[e].eval_point_end > 3 || !evs[e].composition || !evs[e].composition_at_infinity)
+			return kEqSetDeclined;
+	// ---- the plan: the last one, if the same compiled compositions came back
+	std::shared_ptr<eq_set_plan> pl = std::static_pointer_cast<eq_set_plan>(ctx->hal_set_plan);
+	bool same = pl && pl->epoch == bn::expr_epoch() && pl->n_mls == n_mls && pl->key.size() == 2 * (size_t)n_evs;
+	for (uint32_t e = 0; e < n_evs && same; e++) same = pl->key[2 * e] == evs[e].composition && pl->key[2 * e + 1] == evs[e].composition_at_infinity;
+	if (!same) {
+		pl = make_eq_set_plan(evs, n_evs, n_mls);
+		ctx->hal_set_plan = pl; // (nullptr: the next call plans again -- and declines again)
+		if (!pl) return kEqSetDeclined;
+	}
+	int rc = hal_const_tables(ctx, half);
+	if (rc) return rc;
+	rc = group_res_alloc(ctx);
+	if (rc) return rc;
+	const char *ones = (const char *)ctx->hal_const, *zeros = ones + ctx->hal_const_half * sizeof(f128);
+	// ---- E = eq (.) u on both halves, for every scaled column: one launch
+	char *E = nullptr;
+	if (!pl->scaled.empty()) {
+		E = (char *)bn::ctx_scratch(ctx, pl->scaled.size() * full * sizeof(f128));
+		if (!E) return kEqSetDeclined; // (no room: the general code needs less)
+		if (!ctx->h_mul_jobs) {
+			if (hipHostMalloc(&ctx->h_mul_jobs, 2 * kEqSetMaxScaled * sizeof(bn::mul9_job), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+				(void)hipGetLastError();
+				ctx->h_mul_jobs = nullptr;
+				return kEqSetDeclined;
+			}
+			BN_HIP(hipHostGetDevicePointer(&ctx->d_mul_jobs, ctx->h_mul_jobs, 0));
+		}
+		bn::mul9_job *mj = (bn::mul9_job *)ctx->h_mul_jobs;
+		for (size_t k = 0; k < pl->scaled.size(); k++) {
+			const char *u = (const char *)mls[pl->scaled[k]].d_evals;
+			char *out = E + k * full * sizeof(f128);
+			mj[2 * k] = bn::mul9_job{u, eq, out};
+			mj[2 * k + 1] = bn::mul9_job{u + half * sizeof(f128), eq, out + half * sizeof(f128)};
+		}
+		prof_scope ps(ctx, BN_PROF_OTHER);
+		BN_HIP(bn::launch_mul9_jobs(ctx->stream, ctx->n_cu, (const bn::mul9_job *)ctx->d_mul_jobs, (uint32_t)(2 * pl->scaled.size()), half));
+	}
+	// ---- every distinct monomial an evaluate job; as many launches as the slots ask for (two per job)
+	std::vector<f128> sums(2 * pl->monos.size());
+	bn::group_tables *h_tb = (bn::group_tables *)ctx->grp.h_tables;
+	const bn::group_tables *d_tb = (const bn::group_tables *)ctx->grp.d_tables;
+	const size_t per_launch = std::min<size_t>((size_t)bn::kGroupMaxJobs, (size_t)bn::kGroupMaxSlots / 2);
+	std::vector<bn::group_job> jobs;
+	for (size_t at = 0; at < pl->monos.size(); at += per_launch) {
+		const size_t cnt = std::min(per_launch, pl->monos.size() - at);
+		jobs.assign(cnt, bn::group_job{});
+		for (size_t i = 0; i < cnt; i++) {
+			const auto &m = pl->monos[at + i];
+			bn::group_job &j = jobs[i];
+			j.kind = 1;
+			j.n = half;
+			j.slot = (uint32_t)(2 * i);
+			if (m.w >= 0) {
+				const char *Ek = E + (size_t)pl->e_of[m.u] * full * sizeof(f128);
+				const char *w = (const char *)mls[m.w].d_evals;
+				j.x0[0] = Ek;
+				j.x1[0] = Ek + half * sizeof(f128);
+				j.x0[1] = w;
+				j.x1[1] = w + half * sizeof(f128);
+			} else {
+				const char *v = m.u >= 0 ? (const char *)mls[m.u].d_evals : nullptr;
+				j.x0[0] = v ? v : zeros;
+				j.x1[0] = v ? v + half * sizeof(f128) : ones;
+				j.x0[1] = zeros;
+				j.x1[1] = eq;
+			}
+		}
+		ctx->mirror.valid = false;
+		const uint64_t seq = ++ctx->mail_seq;
+		{
+			prof_scope ps(ctx, BN_PROF_ROUND_EVAL_MFMA);
+			const hipError_t e = bn::launch_group(ctx->stream, ctx->n_cu, jobs.data(), (uint32_t)cnt, (uint32_t)(2 * cnt), ctx->grp.d_S, ctx->grp.d_gmail, ctx->d_mail,
+			                                      ctx->d_ticket, seq, h_tb->jobs, d_tb->jobs);
+			if (e != hipSuccess) {
+				--ctx->mail_seq;
+				(void)hipGetLastError();
+				if (e == hipErrorNotSupported && at == 0) return kEqSetDeclined;
+				return bn::hip_fail(e, "launch_group (constraint set)");
+			}
+		}
+		volatile uint64_t *seqw = &ctx->h_mail[64].lo;
+		uint64_t spins = 0;
+		while (__atomic_load_n(seqw, __ATOMIC_ACQUIRE) != seq) {
+			if (++spins > (1ull << 22)) {
+				BN_HIP(hipStreamSynchronize(ctx->stream));
+				if (__atomic_load_n(seqw, __ATOMIC_ACQUIRE) != seq) return bn::fail(BN_ERR_DEVICE, "device error: result mailbox was not published");
+				break;
+			}
+		}
+		for (size_t i = 0; i < 2 * cnt; i++) {
+			sums[2 * at + i].lo = __atomic_load_n(&ctx->grp.h_gmail[i].lo, __ATOMIC_RELAXED);
+			sums[2 * at + i].hi = __atomic_load_n(&ctx->grp.h_gmail[i].hi, __ATOMIC_RELAXED);
+		}
+	}
+	// ---- the evaluators' values: coefficient x sum, the sum at 1 or at infinity
+	size_t off = 0;
+	for (uint32_t e = 0; e < n_evs; e++)
+		for (uint32_t p = evs[e].eval_point_start; p < evs[e].eval_point_end; p++, off++) {
+			f128 v = bn::f128_zero();
+			for (const auto &t : (p == 1 ? pl->t1[e] : pl->tinf[e])) {
+				const f128 sv = sums[2 * t.mono + (p - 1)];
+				v ^= (t.coeff == bn::f128_one()) ? sv : bn::mul_host(t.coeff, sv);
+			}
+			h_out[off] = bn_f128{v.lo, v.hi};
+		}
+	return BN_OK;
+}
+
+// all-ones | all-zeros tables of at least `half` elements each (ones at hal_const, zeros hal_const_half elements behind it): filled
+// once for the largest size asked for so far and kept in the context -- the rounds of a sumcheck ask for halving sizes
+int hal_const_tables(bn_ctx *ctx, uint64_t half)
+{
+	if (ctx->hal_const && ctx->hal_const_half >= half) return BN_OK;
+	if (ctx->hal_const) {
+		BN_HIP(hipStreamSynchronize(ctx->stream));
+		BN_HIP(hipFree(ctx->hal_const));
+		ctx->hal_const = nullptr;
+		ctx->hal_const_half = 0;
+	}
+	if (hipMalloc(&ctx->hal_const, 2 * half * sizeof(f128)) != hipSuccess) {
+		(void)hipGetLastError();
+		ctx->hal_const = nullptr;
+		return bn::fail(BN_ERR_ALLOC, "allocation error: allocator is out of memory (constant tables of the round evaluation)");
+	}
+	BN_HIP(bn::launch_fill(ctx->stream, ctx->hal_const, half, bn::f128_one()));
+	BN_HIP(hipMemsetAsync((char *)ctx->hal_const + half * sizeof(f128), 0, half * sizeof(f128), ctx->stream));
+	ctx->hal_const_half = half;
 	return BN_OK;
 }
 
@@ -197,8 +437,13 @@ int bn_hal_round_evals(bn_ctx *ctx, uint32_t order, uint32_t n_vars, const void 
 	{
 		uint32_t pts = 0;
 		for (uint32_t e = 0; e < n_evs; e++) pts += evs[e].eval_point_end > evs[e].eval_point_start ? evs[e].eval_point_end - evs[e].eval_point_start : 0;
-		if (n_mls > (uint32_t)bn::kHalMaxMl || n_evs > (uint32_t)bn::kHalMaxEv || pts > 32)
+		if (n_mls > (uint32_t)bn::kHalMaxMl || n_evs > (uint32_t)bn::kHalMaxEv || pts > 32) {
+			if (order == BN_ORDER_HIGH_TO_LOW && n_points == 0 && ctx->hal_eq_set) {
+				const int rc_s = round_evals_eq_set(ctx, n_vars, mls, n_mls, evs, n_evs, h_out);
+				if (rc_s != kEqSetDeclined) return rc_s;
+			}
 			return round_evals_in_parts(ctx, order, n_vars, d_tensor_query, query_vars, mls, n_mls, evs, n_evs, h_points, n_points, h_out);
+		}
 	}
 	uint32_t pt_lo = 0, pt_hi = 0, total = 0;
 	for (uint32_t e = 0; e < n_evs; e++) {
@@ -303,24 +548,7 @@ int bn_hal_round_evals(bn_ctx *ctx, uint32_t order, uint32_t n_vars, const void 
 	// (x indicator table) is ONE pass of the ComputeLayer's product-sum kernels, which return the sums at both points;
 	// the coefficients are applied to the 16-byte sums on the host.
 	// all-ones | all-zeros tables of `half` elements, filled once per size and kept in the context
-	auto const_tables = [&]() -> int {
-		if (ctx->hal_const_half == half) return BN_OK;
-		if (ctx->hal_const) {
-			BN_HIP(hipStreamSynchronize(ctx->stream));
-			BN_HIP(hipFree(ctx->hal_const));
-			ctx->hal_const = nullptr;
-			ctx->hal_const_half = 0;
-		}
-		if (hipMalloc(&ctx->hal_const, 2 * half * sizeof(f128)) != hipSuccess) {
-			(void)hipGetLastError();
-			ctx->hal_const = nullptr;
-			return bn::fail(BN_ERR_ALLOC, "allocation error: allocator is out of memory (constant tables of the round evaluation)");
-		}
-		BN_HIP(bn::launch_fill(ctx->stream, ctx->hal_const, half, bn::f128_one()));
-		BN_HIP(hipMemsetAsync((char *)ctx->hal_const + half * sizeof(f128), 0, half * sizeof(f128), ctx->stream));
-		ctx->hal_const_half = half;
-		return BN_OK;
-	};
+	auto const_tables = [&]() -> int { return hal_const_tables(ctx, half); };
 	struct term_job {
 		std::vector<uint32_t> vars;
 		const void *eq;
@@ -364,7 +592,7 @@ int bn_hal_round_evals(bn_ctx *ctx, uint32_t order, uint32_t n_vars, const void 
 				if (rc) return rc;
 			}
 			ones = (char *)ctx->hal_const;
-			zeros = ones + half * sizeof(f128);
+			zeros = ones + ctx->hal_const_half * sizeof(f128);
 		}
 	}
 	if (fast) {

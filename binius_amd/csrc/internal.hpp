@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include <initializer_list>
+#include <memory>
 #include <string>
 #include <mutex>
 #include <vector>
@@ -20,6 +21,14 @@ struct bn_expr {
 	std::vector<uint32_t> product_vars; // PRODUCT: var indices multiplied together (in order)
 	mutable bn_step *d_steps = nullptr; // device copy for the interpreter kernels (uploaded on first use)
 	int device = 0;
+	// the circuit as a sum of monomials coeff * prod(vars) (abi_hal.cpp expand_poly), computed on first use by the old HAL's routed
+	// paths: 0 = not yet, 1 = `poly` holds it, 2 = too large / not a polynomial the routed paths take
+	struct monomial {
+		std::vector<uint32_t> vars; // sorted; variables may repeat
+		bn::f128 coeff;
+	};
+	mutable int poly_state = 0;
+	mutable std::vector<monomial> poly;
 };
 
 namespace bn {
@@ -196,6 +205,12 @@ struct bn_ctx {
 	// all-ones | all-zeros tables of the old HAL's routed round evaluation (abi_hal.cpp): filled once per size, kept
 	void *hal_const = nullptr;
 	uint64_t hal_const_half = 0; // elements per table
+	// wide constraint-set requests of the old HAL (abi_hal.cpp round_evals_eq_set): the element-wise products' job table (pinned,
+	// device-mapped) and the plan of the last request (which monomials, which columns are scaled by the indicator), reused while
+	// the same compiled compositions come back round after round
+	bool hal_eq_set = true; // BN_HAL_EQ_SET=0: such requests are dealt out to parts of the general code instead
+	void *h_mul_jobs = nullptr, *d_mul_jobs = nullptr;
+	std::shared_ptr<void> hal_set_plan;
 	// pinned, device-mapped staging of bn_gather_d2h: offsets in, gathered items out (grown on demand)
 	void *h_gather = nullptr, *d_gather = nullptr;
 	size_t gather_bytes = 0;
@@ -321,6 +336,9 @@ struct bn_ctx {
 namespace bn {
 
 constexpr int kResultSlots = 256;
+// bumped by every bn_expr_free: whatever remembers compiled expressions by address (abi_hal.cpp's plans) forgets them
+uint64_t expr_epoch();
+void expr_epoch_bump();
 
 void set_error(const std::string &msg);
 int fail(int code, const std::string &msg);
@@ -622,6 +640,13 @@ hipError_t launch_ntt(hipStream_t s, bool inverse, void *data, uint32_t elem_lev
                       const uint64_t *d_s_evals, uint32_t log_domain, uint32_t log_x, uint32_t log_y, uint32_t log_z,
                       uint64_t coset, uint32_t coset_bits, uint32_t skip_rounds);
 
+// ---- kernels_mul9.hip: many element-wise products of equal length in ONE launch: out_j[i] = a_j[i] * b_j[i], i < n (the job table in
+// pinned, device-mapped memory; the old HAL's wide zerocheck requests scale a column by the indicator table once per round)
+struct mul9_job {
+	const void *a, *b;
+	void *out;
+};
+hipError_t launch_mul9_jobs(hipStream_t s, int n_cu, const mul9_job *d_jobs, uint32_t n_jobs, uint64_t n);
 // ---- kernels_mul9.hip: out[i] = a[i*a_stride] * b[b_off + i*b_stride], bit-sliced
 // up to four adjacent levels of pairwise_product_reduce in one launch of the element-wise product (kernels_mul9.hip:
 // k_mul9_tree): level l (0-based) = products of adjacent pairs of lv[l - 1] (level 0: of `in`), n0 >> l of them, to lv[l]

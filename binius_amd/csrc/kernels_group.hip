@@ -42,6 +42,8 @@
 #include <algorithm>
 #include <cstddef>
 #include <cstdlib>
+#include <functional>
+#include <queue>
 #include <vector>
 
 #include "ctable.hpp"
@@ -572,14 +574,18 @@ hipError_t launch_group(hipStream_t s, int n_cu, const group_job *jobs_in, uint3
 		for (uint32_t U = 1; U <= (uint32_t)n_cu && U <= n_units; U <<= 1) {
 			const uint32_t g = (uint32_t)n_cu / U;
 			if (g < g_min || g == 0) break;
-			std::vector<double> load(U, 0.0), cost(U, 0.0);
+			std::vector<double> cost(U, 0.0);
+			// (least loaded super-unit first: a heap -- a constraint set's request is hundreds of units)
+			typedef std::pair<double, uint32_t> lu;
+			std::priority_queue<lu, std::vector<lu>, std::greater<lu>> heap;
+			for (uint32_t q = 0; q < U; q++) heap.push(lu{0.0, q});
 			for (uint32_t o = 0; o < n_units; o++) {
 				const uint32_t it = by_weight[o];
-				uint32_t u = 0;
-				for (uint32_t q = 1; q < U; q++)
-					if (load[q] < load[u]) u = q;
+				const lu top = heap.top();
+				heap.pop();
+				const uint32_t u = top.second;
 				assign[it] = u;
-				load[u] += w[it];
+				heap.push(lu{top.first + w[it], u});
 				for (uint32_t q = first[it]; q < first[it] + len[it]; q++) {
 					const uint64_t steps = ((uint64_t)tiles[it] + 2 * g - 1) / (2 * g);
 					cost[u] += (double)steps * pair_us(jobs_in[q]) + fixed_us(jobs_in[q]);

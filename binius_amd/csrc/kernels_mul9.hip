@@ -451,6 +451,41 @@ __global__ __launch_bounds__(256, 2) void k_mul9_tree(mul9_tree_args args)
 	}
 }
 
+// n_jobs products of n elements each in one launch: wave-batches are dealt out over (job, batch) pairs; a wave's job pointers are
+// read from the table (pinned memory) and held in scalar registers
+__global__ __launch_bounds__(256, 2) void k_mul9_jobs(const mul9_job *__restrict__ jobs, uint32_t n_jobs, uint64_t n)
+{
+	__shared__ uint4 tile[4][kWaveQ4];
+	const unsigned wave = threadIdx.x >> 6;
+	mul9_wave<1> mw;
+	mw.init(tile[wave]);
+	const uint64_t per_job = (n + kWB - 1) / kWB, total = per_job * n_jobs;
+	const uint64_t n_waves = (uint64_t)gridDim.x * 4;
+	for (uint64_t bt = (uint64_t)blockIdx.x * 4 + wave; bt < total; bt += n_waves) {
+		const uint32_t j = (uint32_t)(bt / per_job);
+		const uint64_t e0 = (bt - (uint64_t)j * per_job) * kWB;
+		auto uni = [](const void *p) { // (uniform per wave: into scalar registers)
+			const uint64_t v = (uint64_t)p;
+			return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32);
+		};
+		const uint32_t *a = (const uint32_t *)uni(jobs[j].a), *b = (const uint32_t *)uni(jobs[j].b);
+		uint32_t *out = (uint32_t *)uni(jobs[j].out);
+		mw.batch(a, b, out, e0, n);
+	}
+}
+
+hipError_t launch_mul9_jobs(hipStream_t s, int n_cu, const mul9_job *d_jobs, uint32_t n_jobs, uint64_t n)
+{
+	if (n_jobs == 0 || n == 0) return hipSuccess;
+	const uint64_t total = ((n + kWB - 1) / kWB) * n_jobs;
+	uint64_t blocks = (total + 3) / 4;
+	const uint64_t cap = (uint64_t)n_cu * 2;
+	if (blocks > cap) blocks = cap;
+	__atomic_thread_fence(__ATOMIC_SEQ_CST); // (the table is in memory before the doorbell rings)
+	hipLaunchKernelGGL(k_mul9_jobs, dim3((unsigned)blocks), dim3(256), 0, s, d_jobs, n_jobs, n);
+	return hipGetLastError();
+}
+
 hipError_t launch_mul9(hipStream_t s, int n_cu, const void *a, uint64_t a_stride, const void *b, uint64_t b_stride, uint64_t b_off,
                        void *out, uint64_t n)
 {
