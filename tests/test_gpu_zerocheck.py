@@ -57,3 +57,35 @@ def test_small_mixed_zerocheck_vs_oracle(oracle, n_vars):
     ]
     mls = [oracle.random_b128(0x2E20000 + 16 * n_vars + j, 1 << n_vars) for j in range(6)]
     run_both(oracle, n_vars, mls, comps, 0x2E30 + n_vars)
+
+
+@pytest.mark.parametrize("log_perms", [4, 9])
+def test_keccak_replay_at_reduced_size(oracle, log_perms):
+    """tools/bench_keccak_replay.py (the HAL traffic of constraint_system::prove for the keccak table -- BASELINE config 4: zerocheck
+    of the 100-constraint set over the old HAL, ring switch, commit, piop::prove of the 175-claim prover with FRI interleaved) at
+    2^4 / 2^9 permutations: the verifier's equations hold on both transcripts, and both equal the oracle's restatements
+    (oracle/zerocheck_ref.py, oracle/piop_ref.py) bit for bit."""
+    import argparse
+    import importlib.util
+    import os
+
+    from oracle import piop_ref, zerocheck_ref
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_keccak_replay", os.path.join(root, "tools", "bench_keccak_replay.py"))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+
+    def checker(d):
+        v = d["n_vars"]
+        want = zerocheck_ref.eqind_sumcheck_prove(d["zerocheck_multilinears"], v, d["constraints"], d["zerocheck_sums"], d["eq_ind_challenges"],
+                                                  d["zerocheck_batch_coeff"], d["zerocheck_challenges"])
+        commitment, items, _, _ = piop_ref.piop_prove(d["committed"], d["transparents"], d["claims"], d["fri_params"], d["piop_batch_coeffs"], d["piop_challenges"],
+                                                      threads=max(1, len(os.sched_getaffinity(0))), fast=v >= 16)
+        return {"zerocheck_transcript_equal": want == d["zerocheck_transcript"],
+                "piop_transcript_equal": d["commitment"] == commitment and d["piop_transcript"] == items}
+
+    rec = tool.replay(argparse.Namespace(log_perms=log_perms, steps=1, log_inv_rate=1, log_batch=4, arity=4), checker)
+    assert rec["verifier_check"] == {"zerocheck": True, "piop_sumcheck": True}
+    assert rec["oracle_check"] == {"zerocheck_transcript_equal": True, "piop_transcript_equal": True}
+    assert rec["zerocheck"] == {"multilinears": 204, "constraints": 100} and rec["piop"]["claims"] == 175
