@@ -40,7 +40,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstddef>
+#include <cstdio>
 #include <cstdlib>
 #include <functional>
 #include <queue>
@@ -750,6 +752,19 @@ hipError_t launch_group(hipStream_t s, int n_cu, const group_job *jobs_in, uint3
 			if (e != hipSuccess) return e;
 		}
 	}
+	static const bool prof_launch = getenv("BN_GROUP_PROF") != nullptr; // (diagnostic: host time of the runtime's launch call itself)
+	const auto t_l0 = prof_launch ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point{};
+	struct launch_timer {
+		bool on;
+		std::chrono::steady_clock::time_point t0;
+		~launch_timer()
+		{
+			if (!on) return;
+			static uint64_t ns = 0, calls = 0;
+			ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+			if ((++calls & 63) == 0) fprintf(stderr, "[bn group prof] hipLaunchKernel of the group kernel: %.2f us per call over %llu calls\n", ns / 1e3 / calls, (unsigned long long)calls);
+		}
+	} lt{prof_launch, t_l0};
 	if (nt)
 		hipLaunchKernelGGL((k_group_fp4<true, true>), dim3(at), dim3(kThreads), lds, s, ga);
 	else if (full)

@@ -81,6 +81,23 @@ def test_bench_bare_gpus_2_spawns_its_own_ranks():
     assert r["n_gpus"] == 2 and r["verifier_check"] is True and r["config"]["n_vars_local"] == 16
 
 
+def test_bench_bare_gpus_8_at_n20_on_one_device():
+    """the command the driver's scaling run issues for eight GPUs -- `python bench.py --gpus 8`, no launcher --
+    with all eight ranks on device 0 (BN_ALL_ON_GPU0=1; the only multi-rank run a one-GPU box allows): eight ranks are spawned,
+    the line says n_gpus 8, the sharded prover's transcript satisfies the verifier and its digest is the single-GPU digest of the
+    same 2^20 instance."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update({"BN_ALL_ON_GPU0": "1", "BN_PG_BACKEND": "gloo"})
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "8", "--steps", "2", "--warmup", "1", "--n-vars", "20", "--no-cpu-baseline"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert out.returncode == 0 and lines, out.stdout[-2000:] + out.stderr[-2000:]
+    r = json.loads(lines[-1])
+    assert r["n_gpus"] == 8 and r["verifier_check"] is True and r["config"]["n_vars_local"] == 17 and r["config"]["n_vars_global"] == 20
+    one = _run([sys.executable, "bench.py", "--steps", "1", "--warmup", "1", "--n-vars", "20", "--no-cpu-baseline", "--no-claim-groups"], {})
+    assert one["transcript_digest"] == r["transcript_digest"]
+
+
 @pytest.mark.parametrize("exchange", ["shm", "rccl", "peer"])
 def test_bench_sharded_code_path_world1(exchange):
     r = _run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--n-vars", "15", "--no-cpu-baseline"],

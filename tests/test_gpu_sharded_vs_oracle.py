@@ -135,7 +135,11 @@ def _worker_body(rank, world, port, n_global, m, comps, q, exchange="shm"):
 
 @pytest.mark.parametrize(
     "world,n_global,m,comps",
-    [(2, 10, 2, [(0, 1)]), (4, 11, 2, [(0, 1)]), (2, 9, 3, [(0, 1), (2, 0)]), (4, 12, 3, [(0, 1), (2, 0)]), (2, 21, 2, [(0, 1)]), (4, 22, 2, [(0, 1)])],
+    [(2, 10, 2, [(0, 1)]), (4, 11, 2, [(0, 1)]), (2, 9, 3, [(0, 1), (2, 0)]), (4, 12, 3, [(0, 1), (2, 0)]), (2, 21, 2, [(0, 1)]), (4, 22, 2, [(0, 1)]),
+     # a sharded MULTI-claim prover (four disjoint claims and one over shared multilinears, eight multilinears): with the partials
+     # meeting in shared memory every rank's evaluations take the claim-group path (one launch per round); under the device-side peer
+     # exchange the groups stand aside (abi_group.cpp: the kernels' finalize step carries the exchange) and the eager kernels answer
+     (2, 15, 8, [(0, 4), (1, 5), (2, 6), (3, 7), (0, 7)]), (4, 18, 8, [(0, 4), (1, 5), (2, 6), (3, 7), (0, 7)])],
 )
 @pytest.mark.parametrize("exchange", ["shm", "peer"])
 def test_sharded_hip_prover_matches_unsharded_oracle(world, n_global, m, comps, exchange):
