@@ -56,7 +56,7 @@ struct prof_scope {
 // BN_SHADOW_DEBUG=1: one line on stderr whenever the MLE-check shadow is made, used, missed or dropped (diagnostic)
 inline bool shadow_debug()
 {
-	static const bool on = bn::settled_knob("BN_SHADOW_DEBUG") != nullptr;
+	static const bool on = std::getenv("BN_SHADOW_DEBUG") != nullptr; // (a live diagnostic, not a measurement knob)
 	return on;
 }
 #define BN_SHDBG(...)                         \

@@ -18,6 +18,8 @@
 #pragma once
 #include <cstdlib>
 #include <stdint.h>
+#include <cstdio>
+#include <cstdlib>
 
 #if defined(__HIPCC__)
 #define BN_HD __host__ __device__
@@ -28,12 +30,14 @@
 namespace bn {
 // Measurement knobs of rounds 1 - 4 whose A/B is settled (profiles/DEAD_ENDS.md): the shipped library runs their
 // defaults and does not read them from the environment; a measurement build (tools/*.hip, -DBN_MEASUREMENT_KNOBS) still does.
+// A shipped library that finds one of them SET says so once per knob on stderr -- an A/B script run against it would otherwise
+// compare the default with itself and report "no difference" (ADVICE r5).
 inline const char *settled_knob(const char *name)
 {
 #ifdef BN_MEASUREMENT_KNOBS
 	return std::getenv(name);
 #else
-	(void)name;
+	if (std::getenv(name)) std::fprintf(stderr, "[binius_amd] %s is set but this build ignores the settled measurement knobs (build with `make BN_KNOBS=1`)\n", name);
 	return nullptr;
 #endif
 }

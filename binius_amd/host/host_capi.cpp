@@ -668,6 +668,14 @@ int bnh_piop_prove(bn_ctx *ctx, uint32_t n_committed, const uint32_t *committed_
 	try {
 		if (!ctx || !commitment_out || !items_out || !n_items_out || !scalars_out || !n_scalars_out || !digests_out || !n_digests_out)
 			throw Error(Error::InputValidation, "null argument");
+		if ((n_committed && (!committed_n_vars || !d_committed)) || (n_transparent && (!transparent_n_vars || !d_transparent)) || (n_claims && (!claims || !claim_sums)) ||
+		    (n_arities && !fold_arities) || !d_message || (n_batch_coeffs && !batch_coeffs) || (n_challenges && !challenges))
+			throw Error(Error::InputValidation, "null argument");
+		for (uint32_t i = 0; i < n_committed; i++)
+			if (committed_n_vars[i] >= 48 || !d_committed[i]) throw Error(Error::InputValidation, "committed multilinear: null, or its number of variables out of range (< 48)");
+		for (uint32_t i = 0; i < n_transparent; i++)
+			if (transparent_n_vars[i] >= 48 || !d_transparent[i]) throw Error(Error::InputValidation, "transparent multilinear: null, or its number of variables out of range (< 48)");
+		if (log_dim + log_batch_size + log_inv_rate >= 48) throw Error(Error::InputValidation, "FRI parameters out of range");
 		ComputeLayer hal(ctx);
 		DeviceBumpAllocator dev_alloc(FSliceMut{d_scratch, (size_t)scratch_elems});
 		std::vector<size_t> n_varss;
@@ -757,10 +765,21 @@ int bnh_batch_sumcheck_prove(bn_ctx *ctx, uint32_t n_provers, const uint32_t *pr
                              bn_f128 *round_proofs_out, bn_f128 *final_evals_out)
 {
 	try {
+		// (public entry point: every pointer it dereferences and every shift amount it derives is checked first -- ADVICE r5)
+		if (!ctx || (n_provers && (!prover_desc || !batch_coeffs)) || !challenges || !round_proofs_out || !final_evals_out || (!d_scratch && scratch_elems))
+			throw Error(Error::InputValidation, "null argument");
+		size_t total_m = 0, total_c = 0;
+		for (uint32_t i = 0; i < n_provers; i++) {
+			if (prover_desc[3 * i] >= 48) throw Error(Error::InputValidation, "a prover's number of variables is out of range (< 48)");
+			if (i && prover_desc[3 * i] < prover_desc[3 * (i - 1)]) throw Error(Error::InputValidation, "ClaimsOutOfOrder: provers ascend by number of variables");
+			total_m += prover_desc[3 * i + 1];
+			total_c += prover_desc[3 * i + 2];
+		}
+		if ((total_m && !d_multilins) || (total_c && (!comp_indices || !sums))) throw Error(Error::InputValidation, "null argument");
+		for (size_t j = 0; j < total_m; j++)
+			if (!d_multilins[j]) throw Error(Error::InputValidation, "null multilinear");
 		ComputeLayer hal(ctx);
 		DeviceBumpAllocator dev_alloc(FSliceMut{d_scratch, (size_t)scratch_elems});
-		size_t total_m = 0;
-		for (uint32_t i = 0; i < n_provers; i++) total_m += prover_desc[3 * i + 1];
 		std::vector<B128> host_mem(total_m + 8);
 		HostBumpAllocator host_alloc(HostSliceMut{host_mem.data(), host_mem.size()});
 		std::vector<std::unique_ptr<BivariateSumcheckProver>> provers;
