@@ -70,7 +70,22 @@ bool fold_touches(const bn_ctx::group_fold &f, const void *p, uint64_t n)
 // a deferred fold as plain launches (kFoldBatchMax arrays each: the batch rides in the kernel arguments)
 int launch_fold(bn_ctx *ctx, const bn_ctx::group_fold &f)
 {
-	for (uint32_t at = 0; at < f.count; at += (uint32_t)bn::kFoldBatchMax) {
+	uint32_t at = 0;
+	// (more than one launch's worth: 128 arrays at a time through the wide form)
+	while (f.count - at > (uint32_t)bn::kFoldBatchMax) {
+		const uint32_t c = std::min<uint32_t>(f.count - at, (uint32_t)bn::kFoldWideMax);
+		static bn::fold_batch_wide fw_zero{};
+		bn::fold_batch_wide fw = fw_zero;
+		for (uint32_t i = 0; i < c; i++) {
+			fw.x0[i] = f.x0[at + i];
+			fw.x1[i] = f.x1[at + i];
+			fw.src0[i] = f.src0[at + i] != f.x0[at + i] ? f.src0[at + i] : nullptr;
+		}
+		prof_scope ps(ctx, BN_PROF_FOLD);
+		BN_HIP(bn::launch_extrapolate_line_wide(ctx->stream, ctx->n_cu, fw, c, f.n, f.z));
+		at += c;
+	}
+	for (; at < f.count; at += (uint32_t)bn::kFoldBatchMax) {
 		const uint32_t c = std::min<uint32_t>(f.count - at, (uint32_t)bn::kFoldBatchMax);
 		bn::fold_batch fb{};
 		for (uint32_t i = 0; i < c; i++) {
@@ -1068,7 +1083,10 @@ int group_eval(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const bn_kop
 	bn::group_tables *const h_tb = (bn::group_tables *)g.h_tables;
 	const bn::group_tables *const d_tb = (const bn::group_tables *)g.d_tables;
 	// ---- small enough to finish on the host?  (all arrays contiguous, their deferred folds -- if any -- with one challenge)
-	if (g.ht_max && 2 * rq.row_len <= g.ht_max && (uint64_t)rq.m * 2 * rq.row_len <= std::min(g.ht_work, bn::kGroupTailMaxElems) && stage_alloc(ctx) == BN_OK) {
+	// (the host's rounds cost products in proportion to (claims + arrays / 2) x elements: eight arrays under four claims of 4096
+	// elements each is the measured break-even, bn::kGroupTailWorkElems)
+	if (g.ht_max && 2 * rq.row_len <= g.ht_max && (uint64_t)rq.m * 2 * rq.row_len <= bn::kGroupTailMaxElems &&
+	    ((uint64_t)rq.k + (rq.m + 1) / 2) * 2 * rq.row_len <= g.ht_work && stage_alloc(ctx) == BN_OK) {
 		bool ok = true, any_fold = false;
 		f128 z{0, 0};
 		for (uint32_t i = 0; i < rq.m && ok; i++) {

@@ -27,41 +27,69 @@ namespace {
 typedef bn_expr::monomial monomial;
 constexpr size_t kMaxTerms = 12;
 int hal_const_tables(bn_ctx *ctx, uint64_t half);
+// (flat: a polynomial is a short vector of terms kept sorted by their variables -- a constraint set compiles two hundred of these
+// per prove, and ordered maps of vectors cost a prove's zerocheck milliseconds of allocations)
 bool expand_poly(const bn_expr *e, std::vector<monomial> &out)
 {
-	typedef std::map<std::vector<uint32_t>, f128> poly;
-	std::vector<poly> val(e->steps.size());
-	auto add_term = [](poly &p, const std::vector<uint32_t> &v, f128 c) {
-		if (c == bn::f128_zero()) return;
-		auto it = p.find(v);
-		if (it == p.end()) {
-			p.emplace(v, c);
-		} else {
-			it->second ^= c;
-			if (it->second == bn::f128_zero()) p.erase(it);
-		}
+	struct term {
+		uint32_t n = 0, v[3] = {0, 0, 0};
+		f128 c{0, 0};
+	};
+	typedef std::vector<term> poly;
+	auto less = [](const term &x, const term &y) {
+		if (x.n != y.n) return x.n < y.n;
+		for (uint32_t i = 0; i < x.n; i++)
+			if (x.v[i] != y.v[i]) return x.v[i] < y.v[i];
+		return false;
+	};
+	auto same = [](const term &x, const term &y) { return x.n == y.n && (x.n < 1 || x.v[0] == y.v[0]) && (x.n < 2 || x.v[1] == y.v[1]) && (x.n < 3 || x.v[2] == y.v[2]); };
+	auto add_term = [&](poly &p, const term &t) {
+		if (t.c == bn::f128_zero()) return;
+		for (size_t i = 0; i < p.size(); i++)
+			if (same(p[i], t)) {
+				p[i].c ^= t.c;
+				if (p[i].c == bn::f128_zero()) p.erase(p.begin() + (long)i);
+				return;
+			}
+		p.push_back(t);
 	};
 	auto mul = [&](const poly &x, const poly &y, poly &r) -> bool {
-		for (const auto &tx : x)
-			for (const auto &ty : y) {
-				std::vector<uint32_t> v = tx.first;
-				v.insert(v.end(), ty.first.begin(), ty.first.end());
-				std::sort(v.begin(), v.end());
-				if (v.size() > 3) return false;
-				add_term(r, v, bn::mul_host(tx.second, ty.second));
+		for (const term &tx : x)
+			for (const term &ty : y) {
+				if (tx.n + ty.n > 3) return false;
+				term t;
+				t.n = tx.n + ty.n;
+				for (uint32_t i = 0; i < tx.n; i++) t.v[i] = tx.v[i];
+				for (uint32_t i = 0; i < ty.n; i++) t.v[tx.n + i] = ty.v[i];
+				std::sort(t.v, t.v + t.n);
+				t.c = (tx.c == bn::f128_one()) ? ty.c : (ty.c == bn::f128_one()) ? tx.c : bn::mul_host(tx.c, ty.c);
+				add_term(r, t);
 			}
 		return r.size() <= 4 * kMaxTerms;
 	};
+	std::vector<poly> val(e->steps.size());
 	for (size_t i = 0; i < e->steps.size(); i++) {
 		const bn_step &st = e->steps[i];
 		poly &r = val[i];
 		switch (st.kind) {
-		case BN_STEP_VAR: r[{st.a}] = bn::f128_one(); break;
-		case BN_STEP_CONST: add_term(r, {}, f128{st.cst.lo, st.cst.hi}); break;
+		case BN_STEP_VAR: {
+			term t;
+			t.n = 1;
+			t.v[0] = st.a;
+			t.c = bn::f128_one();
+			r.push_back(t);
+			break;
+		}
+		case BN_STEP_CONST: {
+			term t;
+			t.c = f128{st.cst.lo, st.cst.hi};
+			add_term(r, t);
+			break;
+		}
 		case BN_STEP_ADD:
 			if (st.a >= i || st.b >= i) return false;
 			r = val[st.a];
-			for (const auto &t : val[st.b]) add_term(r, t.first, t.second);
+			for (const term &t : val[st.b]) add_term(r, t);
 			break;
 		case BN_STEP_MUL:
 			if (st.a >= i || st.b >= i) return false;
@@ -70,7 +98,9 @@ bool expand_poly(const bn_expr *e, std::vector<monomial> &out)
 		case BN_STEP_POW: {
 			if (st.a >= i || st.b > 3) return false;
 			poly acc;
-			acc[{}] = bn::f128_one();
+			term one;
+			one.c = bn::f128_one();
+			acc.push_back(one);
 			for (uint64_t k = 0; k < st.b; k++) {
 				poly nxt;
 				if (!mul(acc, val[st.a], nxt)) return false;
@@ -84,7 +114,9 @@ bool expand_poly(const bn_expr *e, std::vector<monomial> &out)
 	}
 	out.clear();
 	if (e->steps.empty()) return true;
-	for (const auto &t : val.back()) out.push_back(monomial{t.first, t.second});
+	poly fin = val.back();
+	std::sort(fin.begin(), fin.end(), less); // (the order the callers' job lists were built in: shorter monomials first, then by variable)
+	for (const term &t : fin) out.push_back(monomial{std::vector<uint32_t>(t.v, t.v + t.n), t.c});
 	return out.size() <= kMaxTerms;
 }
 
@@ -117,10 +149,11 @@ const std::vector<monomial> *poly_of(const bn_expr *e)
 // (core/src/constraint_system/prove.rs:431-505; keccak: 100 constraints of degree 2 over 204 columns), evaluation points 1 and
 // infinity, High-to-Low, every multilinear Folded and full.  With every composition a sum of monomials of at most two columns,
 //     S_e(1) = sum_t coeff_t <eq, prod(vars_t)(upper halves)>,   S_e(inf) = sum_t' coeff_t' <eq, prod(vars_t')(lower + upper halves)>
-// and every DISTINCT monomial of the whole set is ONE evaluate job (kind 1: both sums at once) of ONE launch of the claim groups'
-// kernel (kernels_group.hip):   {}      (0 | 1) against (0 | eq)       {v}    (v_lo | v_hi) against (0 | eq)
-//                               {u, w}  (E_lo | E_hi) against (w_lo | w_hi)  with  E = eq (.) u  on both halves of u
-// -- eq (.) (u_lo + u_hi) = E_lo + E_hi, so the job's sum at infinity is the three-factor sum the evaluator asks for.  The scaled
+// and every DISTINCT monomial of the whole set is a job of ONE launch of the claim groups' kernel (kernels_group.hip):
+//     {u, w}   an evaluate job (kind 1: both sums at once) over (E_lo | E_hi) and (w_lo | w_hi), with E = eq (.) u on both halves of u
+//              -- eq (.) (u_lo + u_hi) = E_lo + E_hi, so its sum at infinity is the three-factor sum the evaluator asks for;
+//     {v}, {}  plain inner products with the indicator, two to a job (kind 2): <v_hi, eq> for the sum at 1 -- and <v_lo, eq> beside
+//              it only where some composition's form at infinity holds the monomial (a leading form of degree 2 holds none).  The scaled
 // columns E are one launch of the batched element-wise product (kernels_mul9.hip k_mul9_jobs) in front; which column of a product
 // is scaled is a greedy vertex cover of the products' graph (keccak's chi rows are five-cycles: three scaled columns per row
 // instead of five).  The coefficients are applied to the 16-byte sums on the host.  The plan (monomials, cover, terms per
@@ -131,7 +164,17 @@ struct eq_set_plan {
 	uint32_t n_mls = 0;
 	struct mono {
 		int u = -1, w = -1; // {}: -1, -1; {v}: v, -1; {u, w}: u = the scaled column
+		bool at_inf = false; // some evaluator's form at infinity holds it
+		uint32_t s1 = 0, s_lo = 0; // where its sums come back: products: s1 = at 1, s1 + 1 = at infinity; others: s1 = <hi, eq>, s_lo = <lo, eq> (at_inf only)
 	};
+	struct row_product { // a kind-2 entry: <column half, eq>
+		int v;           // the column (-1: the all-ones row)
+		bool upper;
+		uint32_t slot;
+	};
+	std::vector<uint32_t> products; // monos with two columns, in job order
+	std::vector<row_product> rows;
+	uint32_t n_slots = 0;
 	std::vector<mono> monos;
 	std::vector<uint32_t> scaled; // columns with an E array, in E order
 	std::vector<int> e_of;        // column -> its E index (-1: none)
@@ -172,6 +215,7 @@ std::shared_ptr<eq_set_plan> make_eq_set_plan(const bn_hal_evaluator *evs, uint3
 					pl->monos.push_back(m);
 				}
 				(which ? pl->tinf[e] : pl->t1[e]).push_back(eq_set_plan::term{it->second, t.coeff});
+				if (which) pl->monos[it->second].at_inf = true;
 			}
 		}
 	}
@@ -202,6 +246,24 @@ std::shared_ptr<eq_set_plan> make_eq_set_plan(const bn_hal_evaluator *evs, uint3
 			covered[i] = 1;
 		}
 	}
+	// the jobs' slots: two per product, one per row product
+	for (size_t i = 0; i < pl->monos.size(); i++)
+		if (pl->monos[i].w >= 0) {
+			pl->monos[i].s1 = pl->n_slots;
+			pl->n_slots += 2;
+			pl->products.push_back((uint32_t)i);
+		}
+	for (size_t i = 0; i < pl->monos.size(); i++) {
+		auto &m = pl->monos[i];
+		if (m.w >= 0) continue;
+		m.s1 = pl->n_slots++;
+		pl->rows.push_back(eq_set_plan::row_product{m.u, true, m.s1});
+		if (m.at_inf && m.u >= 0) { // (the all-ones row is the same at both points)
+			m.s_lo = pl->n_slots++;
+			pl->rows.push_back(eq_set_plan::row_product{m.u, false, m.s_lo});
+		}
+	}
+	if (pl->n_slots + 1 > (uint32_t)bn::kGroupMaxSlots || pl->products.size() + (pl->rows.size() + 1) / 2 > (size_t)bn::kGroupMaxJobs) return nullptr;
 	return pl;
 }
 
@@ -253,46 +315,57 @@ int round_evals_eq_set(bn_ctx *ctx, uint32_t n_vars, const bn_hal_multilinear *m
 		prof_scope ps(ctx, BN_PROF_OTHER);
 		BN_HIP(bn::launch_mul9_jobs(ctx->stream, ctx->n_cu, (const bn::mul9_job *)ctx->d_mul_jobs, (uint32_t)(2 * pl->scaled.size()), half));
 	}
-	// ---- every distinct monomial an evaluate job; as many launches as the slots ask for (two per job)
-	std::vector<f128> sums(2 * pl->monos.size());
+	// ---- ONE launch: the products as evaluate jobs, the row products two to a job
+	std::vector<f128> sums(pl->n_slots);
 	bn::group_tables *h_tb = (bn::group_tables *)ctx->grp.h_tables;
 	const bn::group_tables *d_tb = (const bn::group_tables *)ctx->grp.d_tables;
-	const size_t per_launch = std::min<size_t>((size_t)bn::kGroupMaxJobs, (size_t)bn::kGroupMaxSlots / 2);
 	std::vector<bn::group_job> jobs;
-	for (size_t at = 0; at < pl->monos.size(); at += per_launch) {
-		const size_t cnt = std::min(per_launch, pl->monos.size() - at);
-		jobs.assign(cnt, bn::group_job{});
-		for (size_t i = 0; i < cnt; i++) {
-			const auto &m = pl->monos[at + i];
-			bn::group_job &j = jobs[i];
-			j.kind = 1;
-			j.n = half;
-			j.slot = (uint32_t)(2 * i);
-			if (m.w >= 0) {
-				const char *Ek = E + (size_t)pl->e_of[m.u] * full * sizeof(f128);
-				const char *w = (const char *)mls[m.w].d_evals;
-				j.x0[0] = Ek;
-				j.x1[0] = Ek + half * sizeof(f128);
-				j.x0[1] = w;
-				j.x1[1] = w + half * sizeof(f128);
-			} else {
-				const char *v = m.u >= 0 ? (const char *)mls[m.u].d_evals : nullptr;
-				j.x0[0] = v ? v : zeros;
-				j.x1[0] = v ? v + half * sizeof(f128) : ones;
-				j.x0[1] = zeros;
-				j.x1[1] = eq;
-			}
+	jobs.reserve(pl->products.size() + (pl->rows.size() + 1) / 2);
+	for (uint32_t mi : pl->products) {
+		const auto &m = pl->monos[mi];
+		bn::group_job j{};
+		j.kind = 1;
+		j.n = half;
+		j.slot = m.s1;
+		const char *Ek = E + (size_t)pl->e_of[m.u] * full * sizeof(f128);
+		const char *w = (const char *)mls[m.w].d_evals;
+		j.x0[0] = Ek;
+		j.x1[0] = Ek + half * sizeof(f128);
+		j.x0[1] = w;
+		j.x1[1] = w + half * sizeof(f128);
+		jobs.push_back(j);
+	}
+	(void)zeros;
+	auto row_ptr = [&](const eq_set_plan::row_product &r) -> const char * {
+		if (r.v < 0) return ones;
+		return (const char *)mls[r.v].d_evals + (r.upper ? half * sizeof(f128) : 0);
+	};
+	for (size_t q = 0; q < pl->rows.size(); q += 2) {
+		// (kind 2 writes S[slot] and S[slot + 1]: the two row products of a job have adjacent slots by construction)
+		bn::group_job j{};
+		j.kind = 2;
+		j.n = half;
+		j.slot = pl->rows[q].slot;
+		j.x0[0] = row_ptr(pl->rows[q]);
+		j.x0[1] = eq;
+		if (q + 1 < pl->rows.size()) {
+			j.x1[0] = row_ptr(pl->rows[q + 1]);
+			j.x1[1] = eq;
 		}
+		jobs.push_back(j);
+	}
+	if (!jobs.empty()) {
 		ctx->mirror.valid = false;
 		const uint64_t seq = ++ctx->mail_seq;
 		{
 			prof_scope ps(ctx, BN_PROF_ROUND_EVAL_MFMA);
-			const hipError_t e = bn::launch_group(ctx->stream, ctx->n_cu, jobs.data(), (uint32_t)cnt, (uint32_t)(2 * cnt), ctx->grp.d_S, ctx->grp.d_gmail, ctx->d_mail,
+			// (an odd last row product leaves its job's second slot unused: one slot more than the plan counts)
+			const hipError_t e = bn::launch_group(ctx->stream, ctx->n_cu, jobs.data(), (uint32_t)jobs.size(), pl->n_slots + 1, ctx->grp.d_S, ctx->grp.d_gmail, ctx->d_mail,
 			                                      ctx->d_ticket, seq, h_tb->jobs, d_tb->jobs);
 			if (e != hipSuccess) {
 				--ctx->mail_seq;
 				(void)hipGetLastError();
-				if (e == hipErrorNotSupported && at == 0) return kEqSetDeclined;
+				if (e == hipErrorNotSupported) return kEqSetDeclined;
 				return bn::hip_fail(e, "launch_group (constraint set)");
 			}
 		}
@@ -305,9 +378,9 @@ int round_evals_eq_set(bn_ctx *ctx, uint32_t n_vars, const bn_hal_multilinear *m
 				break;
 			}
 		}
-		for (size_t i = 0; i < 2 * cnt; i++) {
-			sums[2 * at + i].lo = __atomic_load_n(&ctx->grp.h_gmail[i].lo, __ATOMIC_RELAXED);
-			sums[2 * at + i].hi = __atomic_load_n(&ctx->grp.h_gmail[i].hi, __ATOMIC_RELAXED);
+		for (uint32_t i = 0; i < pl->n_slots; i++) {
+			sums[i].lo = __atomic_load_n(&ctx->grp.h_gmail[i].lo, __ATOMIC_RELAXED);
+			sums[i].hi = __atomic_load_n(&ctx->grp.h_gmail[i].hi, __ATOMIC_RELAXED);
 		}
 	}
 	// ---- the evaluators' values: coefficient x sum, the sum at 1 or at infinity
@@ -316,7 +389,14 @@ int round_evals_eq_set(bn_ctx *ctx, uint32_t n_vars, const bn_hal_multilinear *m
 		for (uint32_t p = evs[e].eval_point_start; p < evs[e].eval_point_end; p++, off++) {
 			f128 v = bn::f128_zero();
 			for (const auto &t : (p == 1 ? pl->t1[e] : pl->tinf[e])) {
-				const f128 sv = sums[2 * t.mono + (p - 1)];
+				const auto &m = pl->monos[t.mono];
+				f128 sv = sums[m.s1];
+				if (p == 2) {
+					if (m.w >= 0)
+						sv = sums[m.s1 + 1];
+					else if (m.u >= 0)
+						sv = sv ^ sums[m.s_lo]; // <v_lo + v_hi, eq>
+				}
 				v ^= (t.coeff == bn::f128_one()) ? sv : bn::mul_host(t.coeff, sv);
 			}
 			h_out[off] = bn_f128{v.lo, v.hi};

@@ -363,6 +363,13 @@ struct fold_batch {
 	const void *src0[kFoldBatchMax]; // nullptr: in place (evals_0 is read from x0); else evals_0 is read from here and written to x0
 };
 hipError_t launch_extrapolate_line_batch(hipStream_t s, int n_cu, const fold_batch &b, uint32_t count, uint64_t n, f128 z);
+constexpr int kFoldWideMax = 128; // arrays of one wide fold launch (the batch rides in the kernel arguments: 3 KiB of the 4)
+struct fold_batch_wide {
+	void *x0[kFoldWideMax];
+	const void *x1[kFoldWideMax];
+	const void *src0[kFoldWideMax]; // as fold_batch
+};
+hipError_t launch_extrapolate_line_wide(hipStream_t s, int n_cu, const fold_batch_wide &b, uint32_t count, uint64_t n, f128 z);
 struct fold_lengths {
 	uint64_t n[kFoldBatchMax];
 };

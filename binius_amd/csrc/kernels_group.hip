@@ -559,8 +559,11 @@ hipError_t launch_group(hipStream_t s, int n_cu, const group_job *jobs_in, uint3
 		bool packed = false;
 		std::vector<uint32_t> assign;
 	};
-	static thread_local decision last;
-	const bool remembered = packed && last.n_units == n_units && last.max_tiles == max_tiles && last.W == W && last.n_cu == n_cu && getenv("BN_GROUP_PACK_U") == nullptr;
+	// (one entry per round size: a prove walks max_tiles down by halves, the next prove of the shape finds every one of them)
+	static thread_local std::vector<decision> remembered_decisions(64);
+	decision &last = remembered_decisions[(n_units * 31u + max_tiles * 7u + (uint32_t)n_cu) & 63u];
+	static const bool pack_forced = getenv("BN_GROUP_PACK_U") != nullptr;
+	const bool remembered = packed && last.n_units == n_units && last.max_tiles == max_tiles && last.W == W && last.n_cu == n_cu && !pack_forced;
 	if (remembered) {
 		packed = last.packed;
 		best_U = last.U;

@@ -241,6 +241,56 @@ hipError_t launch_extrapolate_line_batch(hipStream_t s, int n_cu, const fold_bat
 	return hipGetLastError();
 }
 
+// The same batch fold for up to kFoldWideMax arrays per launch (3 KiB of kernel arguments): the deferred fold of a prover of the
+// keccak width when it has to run by itself (abi_group.cpp launch_fold: a flush, or the arrays a group launch does not fold)
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void k_extrapolate_line_wide(fold_batch_wide fb, uint64_t n, f128 z)
+{
+	__shared__ ctable_smem tab;
+	ctable_build(tab, z);
+	uint4 *x0 = (uint4 *)fb.x0[blockIdx.y];
+	const uint4 *s0 = fb.src0[blockIdx.y] ? (const uint4 *)fb.src0[blockIdx.y] : (const uint4 *)x0;
+	const uint4 *x1 = (const uint4 *)fb.x1[blockIdx.y];
+	const uint64_t stride = (uint64_t)gridDim.x * 256;
+	uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+	for (; i + (U - 1) * stride < n; i += U * stride) {
+		uint4 a[U], b[U];
+#pragma unroll
+		for (int u = 0; u < U; u++) {
+			a[u] = ld16<NT>(&s0[i + u * stride]);
+			b[u] = ld16<NT>(&x1[i + u * stride]);
+		}
+#pragma unroll
+		for (int u = 0; u < U; u++)
+			st16<NT>(&x0[i + u * stride], xor4(a[u], ctable_mul(tab, xor4(a[u], b[u]))));
+	}
+	for (; i < n; i += stride) {
+		uint4 a = s0[i], b = x1[i];
+		x0[i] = xor4(a, ctable_mul(tab, xor4(a, b)));
+	}
+}
+
+hipError_t launch_extrapolate_line_wide(hipStream_t s, int n_cu, const fold_batch_wide &b, uint32_t count, uint64_t n, f128 z)
+{
+	if (n == 0 || count == 0) return hipSuccess;
+	if (count > (uint32_t)kFoldWideMax) return hipErrorNotSupported;
+	if (n * count >= (1u << 25)) {
+		unsigned g = (2 * n_cu + count - 1) / count;
+		hipLaunchKernelGGL((k_extrapolate_line_wide<2, true>), dim3(g, count), dim3(256), 0, s, b, n, z);
+	} else if (n >= (1u << 16)) {
+		unsigned g = grid_for(n, 256 * 2, n_cu, 8);
+		g = (g + count - 1) / count;
+		if (g < 1) g = 1;
+		hipLaunchKernelGGL((k_extrapolate_line_wide<2, false>), dim3(g, count), dim3(256), 0, s, b, n, z);
+	} else {
+		unsigned g = grid_for(n, 256, n_cu, 8);
+		g = (g + count - 1) / count; // (a hundred arrays of a few thousand elements: a workgroup or two each)
+		if (g < 1) g = 1;
+		hipLaunchKernelGGL((k_extrapolate_line_wide<1, false>), dim3(g, count), dim3(256), 0, s, b, n, z);
+	}
+	return hipGetLastError();
+}
+
 // A tiny fold batch (count * n <= 64 elements) whose results the host is about to read: fold in
 // place and mirror every folded element into the pinned host mailbox (mail[arr * n + i]), then the
 // sequence word.  The host-side copy_d2h calls that follow are served from the mailbox.

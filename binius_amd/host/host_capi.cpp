@@ -869,11 +869,21 @@ int bnh_eqind_sumcheck_prove(bn_ctx *ctx, uint32_t n_vars, uint32_t n_mls, void 
 		const FSlice table = backend.tensor_product_full_query(std::vector<B128>(eqc.begin(), eqc.end() - 1), dev_alloc);
 		EqIndSumcheckProver prover(hal, backend, dev_alloc, n_vars, std::move(mls), std::move(comps), std::move(sv), eqc, FSliceMut{const_cast<void *>(table.ptr), table.len_});
 		const B128 bc(batch_coeff->lo, batch_coeff->hi);
+		const bool prof = AbiProf::on(); // BNH_PROF=1: wall time of execute / fold over all rounds (diagnostic)
+		double us_exec = 0, us_fold = 0;
+		auto now = [] { return std::chrono::steady_clock::now(); };
 		for (uint32_t r = 0; r < n_vars; r++) {
+			const auto t0 = prof ? now() : std::chrono::steady_clock::time_point{};
 			const std::vector<B128> rc = prover.execute(bc);
+			const auto t1 = prof ? now() : t0;
 			for (size_t i = 0; i < 4; i++) round_coeffs_out[4 * r + i] = rc[i].raw();
 			prover.fold(B128(challenges[r].lo, challenges[r].hi));
+			if (prof) {
+				us_exec += std::chrono::duration<double, std::micro>(t1 - t0).count();
+				us_fold += std::chrono::duration<double, std::micro>(now() - t1).count();
+			}
 		}
+		if (prof) fprintf(stderr, "[bnh prof] eq-ind sumcheck, %u rounds, %u multilinears, %u compositions: execute %.1f us, fold %.1f us\n", n_vars, n_mls, n_comps, us_exec, us_fold);
 		const std::vector<B128> fin = prover.finish();
 		for (size_t j = 0; j < fin.size(); j++) final_evals_out[j] = fin[j].raw();
 		return 0;
