@@ -44,7 +44,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
-PMC_FILE = os.path.join("profiles", "r05", "bench_pmc.json")  # tools/pmc_bench.sh: FETCH_SIZE / WRITE_SIZE passes of this command
+PMC_FILE = os.path.join("profiles", "r06", "bench_pmc.json")  # tools/pmc_bench.sh: FETCH_SIZE / WRITE_SIZE passes of this command
 
 
 def csrc_sha16():
@@ -500,7 +500,7 @@ def main():
     }
     # HBM traffic of the dominant kernel: PMC counters cannot be collected inside this process, so the
     # value comes from the committed counters-only rocprofv3 passes OF THIS COMMAND (tools/pmc_bench.sh ->
-    # profiles/r05/bench_pmc.json: FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, average bytes per launch
+    # profiles/r06/bench_pmc.json: FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, average bytes per launch
     # of the kernel symbol, with the commit of the build it was taken on); null for a workload it does not hold
     try:
         pmc = json.load(open(os.path.join(ROOT, PMC_FILE)))

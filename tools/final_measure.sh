@@ -1,5 +1,5 @@
 #!/bin/bash
-# the round's measurement batch (run through gpurun from the repo root); results in gpurun_out/final/, copied to profiles/r05/
+# the round's measurement batch (run through gpurun from the repo root); results in gpurun_out/final/, copied to profiles/r06/
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/final
 rm -rf $O; mkdir -p $O
@@ -10,7 +10,7 @@ cd $R
 BUILD=$(cat $R/tools/.build_id 2>/dev/null || python -c "import bench; print(bench.csrc_sha16())")
 tools/pmc_bench.sh $BUILD 28 24 > $O/pmc_bench.log 2>&1
 cp $R/gpurun_out/bench_pmc.json $O/bench_pmc.json
-mkdir -p $R/profiles/r05; cp $R/gpurun_out/bench_pmc.json $R/profiles/r05/bench_pmc.json
+mkdir -p $R/profiles/r06; cp $R/gpurun_out/bench_pmc.json $R/profiles/r06/bench_pmc.json
 python bench.py > $O/bench_n28.json 2> $O/bench_n28.stderr
 python bench.py --n-vars 24 --steps 20 --warmup 3 > $O/bench_n24.json 2> $O/bench_n24.stderr
 python bench.py --n-vars 25 --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_n25_one_shard_of_eight.json 2>/dev/null
@@ -20,7 +20,22 @@ BN_HOST_TAIL=0 python bench.py --n-vars 25 --steps 20 --warmup 3 --no-cpu-baseli
 BN_HOST_TAIL=0 python bench.py --n-vars 20 --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_n20_BN_HOST_TAIL_0.json 2>/dev/null
 BN_TWO_ROUND=0 python bench.py --n-vars 24 --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_n24_BN_TWO_ROUND_0.json 2>/dev/null
 BN_TWO_ROUND=0 python bench.py --n-vars 25 --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_n25_BN_TWO_ROUND_0.json 2>/dev/null
-# ---- round 5: the PCS prover's call shape (claim groups on / off)
+# ---- round 6: the keccak width (claim groups at 50 / 64 / 175 claims), the replay of config 4's HAL traffic
+{ python tools/bench_piop.py claims --n-vars 22 --k 50 --steps 5 --group 1
+  python tools/bench_piop.py claims --n-vars 22 --k 64 --steps 5 --group 1
+  python tools/bench_piop.py claims --n-vars 22 --k 50 --kind piop --steps 5 --group 1
+  python tools/bench_piop.py claims --n-vars 22 --k 100 --kind keccak --steps 5 --group 1
+  python tools/bench_piop.py claims --n-vars 22 --k 40 --kind star --steps 5 --group 1
+  python tools/bench_piop.py claims --n-vars 18 --k 50 --steps 10 --group 1
+  python tools/bench_piop.py claims --n-vars 18 --k 100 --kind keccak --steps 10 --group 1; } > $O/claims_wide.jsonl 2> $O/claims_wide.stderr
+python tools/bench_keccak_replay.py --log-perms 16 --steps 3 > $O/keccak_replay.json 2> $O/keccak_replay.stderr
+python tools/bench_keccak_replay.py --log-perms 12 --steps 3 > $O/keccak_replay_2p12.json 2>/dev/null
+BN_HAL_EQ_SET=0 python tools/bench_keccak_replay.py --log-perms 16 --steps 1 > $O/keccak_replay_BN_HAL_EQ_SET_0.json 2>/dev/null
+tools/trace_cmd.sh final/trace_claims50 python tools/bench_piop.py claims --n-vars 22 --k 50 --group 1 --steps 2 --warmup 1 > /dev/null 2>&1
+cp $O/trace_claims50/kernel_stats.csv $O/claims_n22_k50_kernel_stats.csv; cp $O/trace_claims50/per_launch.jsonl $O/claims_n22_k50_per_launch.jsonl; rm -rf $O/trace_claims50
+tools/trace_cmd.sh final/trace_replay python tools/bench_keccak_replay.py --log-perms 16 --steps 1 > /dev/null 2>&1
+cp $O/trace_replay/kernel_stats.csv $O/keccak_replay_kernel_stats.csv; cp $O/trace_replay/per_launch.jsonl $O/keccak_replay_per_launch.jsonl; rm -rf $O/trace_replay
+# ---- the PCS prover's call shape (claim groups on / off), round 5's list
 { python tools/bench_piop.py claims --n-vars 20 --k 4 --steps 10
   python tools/bench_piop.py claims --n-vars 24 --k 4 --steps 5
   python tools/bench_piop.py claims --n-vars 24 --k 4 --kind piop --steps 5
