@@ -218,14 +218,26 @@ impl KernelExecutor<B128> for Recorder {
 		batch_coeff: B128,
 		accumulator: &mut Self::Value,
 	) -> Result<(), Error> {
-		let rows: Box<[bn_kslice]> = inputs.iter().map(KSlice::raw).collect();
+		// A prover with k claims passes the SAME batch of m rows k times in a row (v3/bivariate_product.rs:355-399): the recorded
+		// ops share one copy of it (compared by content) -- at keccak's width that is 100 x 100 slices per round otherwise.
+		let same = self.row_lists.last().is_some_and(|last| {
+			last.len() == inputs.n_rows()
+				&& last.iter().zip(inputs.iter()).all(|(a, b)| {
+					let b = b.raw();
+					a.buf == b.buf && a.off == b.off && a.len == b.len
+				})
+		});
+		if !same {
+			let rows: Box<[bn_kslice]> = inputs.iter().map(KSlice::raw).collect();
+			self.row_lists.push(rows);
+		}
+		let rows = self.row_lists.last().expect("pushed above");
 		let mut op = Self::blank_op(ffi::BN_KOP_SUM_COMPOSITION);
 		op.value = accumulator.0;
 		op.scalar = to_ffi(batch_coeff);
 		op.expr = composition.as_ptr();
 		op.n_rows = rows.len() as u32;
 		op.rows = rows.as_ptr();
-		self.row_lists.push(rows);
 		self.ops.push(op);
 		Ok(())
 	}
