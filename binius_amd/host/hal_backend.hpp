@@ -252,8 +252,26 @@ public:
 	{
 		if (n_vars_ != 0) throw Error(Error::InputValidation, "ExpectedFold");
 		std::vector<B128> out;
-		for (const auto &m : multilinears_) {
+		for (const auto &m : multilinears_)
 			if (m.kind != SumcheckMultilinear::Folded) throw Error(Error::InputValidation, "multilinear still transparent at finish");
+		// (a table's worth of multilinears: their first evaluations in ONE gather -- one kernel, one synchronisation -- instead of a
+		// copy_d2h and a synchronisation each; addresses relative to the lowest one)
+		if (multilinears_.size() > 4) {
+			const char *base = nullptr;
+			for (const auto &m : multilinears_)
+				if (m.large_field_folded_evals.len_ && (!base || (const char *)m.large_field_folded_evals.ptr < base)) base = (const char *)m.large_field_folded_evals.ptr;
+			if (base) {
+				std::vector<uint64_t> offs;
+				for (const auto &m : multilinears_)
+					if (m.large_field_folded_evals.len_) offs.push_back((uint64_t)((const char *)m.large_field_folded_evals.ptr - base) / sizeof(B128));
+				std::vector<B128> vals(offs.size());
+				check(bn_gather_d2h(hal.raw_ctx(), base, offs.data(), offs.size(), 1, reinterpret_cast<bn_f128 *>(vals.data())));
+				size_t at = 0;
+				for (const auto &m : multilinears_) out.push_back(m.large_field_folded_evals.len_ ? vals[at++] : m.suffix_eval);
+				return out;
+			}
+		}
+		for (const auto &m : multilinears_) {
 			if (m.large_field_folded_evals.len_ == 0) {
 				out.push_back(m.suffix_eval);
 			} else {
