@@ -562,7 +562,7 @@ hipError_t launch_group(hipStream_t s, int n_cu, const group_job *jobs_in, uint3
 	// (one entry per round size: a prove walks max_tiles down by halves, the next prove of the shape finds every one of them)
 	static thread_local std::vector<decision> remembered_decisions(64);
 	decision &last = remembered_decisions[(n_units * 31u + max_tiles * 7u + (uint32_t)n_cu) & 63u];
-	static const bool pack_forced = getenv("BN_GROUP_PACK_U") != nullptr;
+	static const bool pack_forced = bn::settled_knob("BN_GROUP_PACK_U") != nullptr;
 	const bool remembered = packed && last.n_units == n_units && last.max_tiles == max_tiles && last.W == W && last.n_cu == n_cu && !pack_forced;
 	if (remembered) {
 		packed = last.packed;
@@ -607,8 +607,8 @@ hipError_t launch_group(hipStream_t s, int n_cu, const group_job *jobs_in, uint3
 		}
 		if (!best_U && unpacked_cost < 0) return hipErrorNotSupported;
 		if (unpacked_cost >= 0 && (!best_U || unpacked_cost <= best_cost)) packed = false;
-		static const int force_u = [] { // (BN_GROUP_PACK_U, live, an experiment's switch: that many super-units; -1: one unit per job)
-			const char *e = getenv("BN_GROUP_PACK_U");
+		static const int force_u = [] { // (BN_GROUP_PACK_U, measurement builds: that many super-units; -1: one unit per job -- tools/r06_pack_sweep.sh)
+			const char *e = bn::settled_knob("BN_GROUP_PACK_U");
 			return e ? atoi(e) : 0;
 		}();
 		if (force_u < 0 && unpacked_cost >= 0) packed = false;
@@ -739,9 +739,10 @@ hipError_t launch_group(hipStream_t s, int n_cu, const group_job *jobs_in, uint3
 	}();
 	// streaming accesses once the launch's arrays cannot stay in the caches anyway (the single-claim kernels' threshold is 2^25
 	// elements per array = 2^27 elements touched)
-	// (BN_GROUP_NT_MIN_LOG2, live: the same threshold for launches of the group kernel only -- an experiment's switch)
+	// (BN_GROUP_NT_MIN_LOG2, measurement builds: the same threshold for launches of the group kernel only; A/B of round 6 within the
+	// noise in both directions, profiles/r06/README.md)
 	static const int nt_group_log2 = [] {
-		const char *e = getenv("BN_GROUP_NT_MIN_LOG2");
+		const char *e = bn::settled_knob("BN_GROUP_NT_MIN_LOG2");
 		return e ? atoi(e) : -1;
 	}();
 	const int nt_log2 = nt_group_log2 >= 0 ? nt_group_log2 : nt_min_log2;

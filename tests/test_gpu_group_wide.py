@@ -2,7 +2,7 @@
 multilinears of one size and their transparents into ONE BivariateSumcheckProver (crates/core/src/piop/prove.rs:262-287); the
 keccak gadget alone commits 25 state_in + 25 state_out columns of one size plus intermediates
 (crates/m3/src/gadgets/hash/keccak/stacked.rs:105,292): k >= 50 claims over m >= 100 multilinears.  The group path
-(csrc/abi_group.cpp, kernels_group.hip) carries up to 256 multilinears and 128 claims per prover -- job table, accumulator slots
+(csrc/abi_group.cpp, kernels_group.hip) carries up to 256 multilinears and 384 claims per prover -- job table, accumulator slots
 and value mailbox in memory instead of the kernel-argument block.  Every transcript against the oracle's, bit for bit; the fast
 path is asserted from the context's counters (one group launch per round, no plain fold launches)."""
 import numpy as np

@@ -1,4 +1,5 @@
 #!/bin/bash
+# NEEDS a measurement build (make -C binius_amd/csrc clean && make -C binius_amd/csrc BN_KNOBS=1): the shipped library ignores the knob and says so.
 # round 6: the super-unit count of packed group launches (kernels_group.hip launch_group), forced through BN_GROUP_PACK_U:
 # fused-launch time of a 50-claim prover at 2^22 by U (-1: one unit per job)
 for u in -1 1 2 4 8 16 32; do
