@@ -222,11 +222,11 @@ def replay(args, checker=None):
             profile = it == args.steps  # (the last pass under the event profiler: kernel time and launches; its wall time is not kept)
             tgt = {} if profile else phases
             reset_zc()
-            c0 = hal.group_counters()
             with phase(hal, tgt, "zerocheck", profile):
                 zplan.run()
             with phase(hal, tgt, "ring_switch", profile):
                 ring_switch()
+            c0 = hal.group_counters()
             with phase(hal, tgt, "commit+piop_prove", profile):
                 commit_ms, prove_ms = pplan.run()
             c1 = hal.group_counters()
