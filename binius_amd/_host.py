@@ -66,7 +66,7 @@ def host_lib():
         L.bnh_eqind_sumcheck_prove.restype = C.c_int
         L.bnh_eqind_sumcheck_prove.argtypes = [
             C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p), C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p, C.POINTER(C.c_uint32),
-            C.POINTER(F128), C.POINTER(F128), C.c_void_p, C.c_uint64, C.POINTER(F128), C.POINTER(F128), C.POINTER(F128), C.POINTER(F128),
+            C.POINTER(C.c_uint32), C.POINTER(F128), C.POINTER(F128), C.c_void_p, C.c_uint64, C.POINTER(F128), C.POINTER(F128), C.POINTER(F128), C.POINTER(F128),
         ]
         L.bnh_rccl_open.argtypes = [C.c_char_p]
         L.bnh_rccl_unique_id.argtypes = [C.c_void_p]
@@ -354,14 +354,15 @@ class PiopPlan:
 
 class EqIndPlan:
     """EqIndSumcheckProver over the old HAL (bnh_eqind_sumcheck_prove = binius_amd/host/eq_ind.hpp;
-    crates/core/src/protocols/sumcheck/prove/eq_ind.rs:378-644): the zerocheck of a constraint set, one composition (degree 2)
+    crates/core/src/protocols/sumcheck/prove/eq_ind.rs:378-644): the zerocheck of a constraint set, one composition (degree 1 or 2: `degrees`, default all 2)
     per constraint over ALL multilinears, High-to-Low.  multilins: device slices of 2^n_vars elements, FOLDED IN PLACE by run();
     compositions: list of (steps, steps_of_the_leading_form) in compile_expr's notation; sums: one claimed sum per composition;
     eq_scratch: device slice of >= 2^(n_vars - 1) elements."""
 
-    def __init__(self, hal, n_vars, multilins, compositions, sums, eq_ind_challenges, eq_scratch, batch_coeff, challenges):
+    def __init__(self, hal, n_vars, multilins, compositions, sums, eq_ind_challenges, eq_scratch, batch_coeff, challenges, degrees=None):
         from ._ffi import make_steps
 
+        self.degrees = (C.c_uint32 * max(1, len(compositions)))(*(degrees if degrees is not None else [2] * len(compositions)))
         self.hal, self.n_vars, self.m = hal, n_vars, len(multilins)
         self._keep = (multilins, eq_scratch)
         self.ptrs = (C.c_void_p * max(1, self.m))(*[x.ptr for x in multilins])
@@ -382,7 +383,7 @@ class EqIndPlan:
     def run(self):
         rc = host_lib().bnh_eqind_sumcheck_prove(
             self.hal._h, self.n_vars, self.m, self.ptrs, self.n_comps, C.cast(self.steps, C.c_void_p), self.n_steps, C.cast(self.steps_inf, C.c_void_p),
-            self.n_steps_inf, self.sums, self.eqc, self.eq_scratch.ptr, self.eq_scratch.len, C.byref(self.bc), self.ch, self.coeffs, self.final)
+            self.n_steps_inf, self.degrees, self.sums, self.eqc, self.eq_scratch.ptr, self.eq_scratch.len, C.byref(self.bc), self.ch, self.coeffs, self.final)
         if rc != 0:
             raise BnError(rc, host_lib().bnh_last_error().decode())
 

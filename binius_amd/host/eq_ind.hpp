@@ -1,8 +1,8 @@
 // binius_amd/host/eq_ind.hpp -- C++ mirror of the caller of the OLD hardware abstraction layer that a constraint system's
 // zerocheck runs on: EqIndSumcheckProver (crates/core/src/protocols/sumcheck/prove/eq_ind.rs:378-644) over ProverState
-// (prove/prover_state.rs:57-265; hal_backend.hpp), in the evaluation order High-to-Low, for compositions of degree <= 2 -- the
-// degree of every constraint of the tables SURVEY.md names (u32_add, keccak: m3/src/gadgets/hash/keccak/stacked.rs:142-151,
-// 340-363), for which the round evaluations are asked at X = 1 and infinity only (eq_ind.rs:664-668) and the interpolation needs
+// (prove/prover_state.rs:57-265; hal_backend.hpp), in the evaluation order High-to-Low, for compositions of degree 1 and 2 -- the
+// degrees of the constraints of the tables SURVEY.md names (u32_add, keccak: m3/src/gadgets/hash/keccak/stacked.rs:142-151,
+// 340-363), for which the round evaluations are asked at X = 1 and (degree 2) infinity only (eq_ind.rs:664-668) and the interpolation needs
 // no evaluation domain.
 //
 //   execute(batch_coeff)   eq_ind.rs:534-611   one evaluator per composition over ALL multilinears (sumcheck_compute_round_evals,
@@ -22,6 +22,7 @@ namespace binius_amd {
 
 struct EqIndComposition {
 	ExprEval composition, composition_at_infinity; // the second = ArithCircuit::leading_term (eq_ind.rs:559-560)
+	size_t degree = 2;                             // CompositionPoly::degree: 1 or 2 (evaluation points 1 ..= degree, eq_ind.rs:664-668)
 };
 
 class EqIndSumcheckProver {
@@ -51,8 +52,9 @@ public:
 			SumcheckEvaluator e;
 			e.composition = c.composition;
 			e.composition_at_infinity = c.composition_at_infinity;
+			if (c.degree != 1 && c.degree != 2) throw SumcheckError("InvalidArgs(this mirror interpolates compositions of degree 1 and 2)");
 			e.eval_point_start = 1; // (:664-668: 1 ..= degree)
-			e.eval_point_end = 3;
+			e.eval_point_end = 1 + c.degree;
 			e.eq_ind_partial_evals = eq;
 			evaluators.push_back(e);
 		}
@@ -63,7 +65,8 @@ public:
 		std::vector<B128> batched(3, B128::ZERO());
 		B128 scale = B128::ONE();
 		for (size_t c = 0; c < compositions_.size(); c++) {
-			const B128 y1 = round_evals[c].evals[0], yinf = round_evals[c].evals[1];
+			// (degree 1: the prime polynomial is linear -- no evaluation at infinity is asked for, its leading coefficient is zero)
+			const B128 y1 = round_evals[c].evals[0], yinf = compositions_[c].degree == 2 ? round_evals[c].evals[1] : B128::ZERO();
 			const B128 y0 = (sums_[c] + y1 * alpha) * denom_inv;
 			prime_coeffs_[c] = {y0, y1 + y0 + yinf, yinf};
 			for (size_t i = 0; i < 3; i++) batched[i] = batched[i] + prime_coeffs_[c][i] * scale;

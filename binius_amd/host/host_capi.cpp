@@ -836,7 +836,7 @@ int bnh_batch_sumcheck_prove(bn_ctx *ctx, uint32_t n_provers, const uint32_t *pr
 //   d_eq_ind: 2^(n_vars - 1) elements of scratch for the indicator's partial evaluations (expanded here, eq_ind.rs:430-446)
 //   round_coeffs_out[4 * n_vars]; final_evals_out[n_mls + 1] (the last one: the indicator's prefix evaluation)
 int bnh_eqind_sumcheck_prove(bn_ctx *ctx, uint32_t n_vars, uint32_t n_mls, void *const *d_multilins, uint32_t n_comps, const bn_step *steps,
-                             const uint32_t *n_steps, const bn_step *steps_inf, const uint32_t *n_steps_inf, const bn_f128 *sums,
+                             const uint32_t *n_steps, const bn_step *steps_inf, const uint32_t *n_steps_inf, const uint32_t *degrees, const bn_f128 *sums,
                              const bn_f128 *eq_ind_challenges, void *d_eq_ind, uint64_t eq_ind_elems, const bn_f128 *batch_coeff, const bn_f128 *challenges,
                              bn_f128 *round_coeffs_out, bn_f128 *final_evals_out)
 {
@@ -860,6 +860,7 @@ int bnh_eqind_sumcheck_prove(bn_ctx *ctx, uint32_t n_vars, uint32_t n_mls, void 
 			ec.composition_at_infinity = hal.compile_expr(ArithCircuit::from_steps(std::vector<bn_step>(steps_inf + at_inf, steps_inf + at_inf + n_steps_inf[c])));
 			at += n_steps[c];
 			at_inf += n_steps_inf[c];
+			ec.degree = degrees ? degrees[c] : 2;
 			comps.push_back(ec);
 			sv.emplace_back(sums[c].lo, sums[c].hi);
 		}

@@ -122,7 +122,7 @@ int bnh_piop_prove(bn_ctx *ctx, uint32_t n_committed, const uint32_t *committed_
 
 /* EqIndSumcheckProver (crates/core/src/protocols/sumcheck/prove/eq_ind.rs:378-644) through the C++ mirror binius_amd/host/eq_ind.hpp,
  * over the old HAL (binius_hal::ComputationBackend: bn_hal_round_evals + the ComputeLayer's folds), evaluation order High-to-Low,
- * compositions of degree 2: the zerocheck of a constraint set -- ONE composition per constraint over ALL multilinears of the
+ * compositions of degree 1 or 2 (degrees[c]; NULL: all 2): the zerocheck of a constraint set -- ONE composition per constraint over ALL multilinears of the
  * table (core/src/constraint_system/prove.rs:431-505).
  *   d_multilins[n_mls]: 2^n_vars elements each, FOLDED IN PLACE;  steps / steps_inf: the compositions and their leading forms
  *   (ArithCircuit::leading_term), concatenated, n_steps[c] / n_steps_inf[c] steps each;  sums[n_comps]: the claimed sums
@@ -130,7 +130,7 @@ int bnh_piop_prove(bn_ctx *ctx, uint32_t n_committed, const uint32_t *committed_
  *   round_coeffs_out[4 * n_vars]: the batched round polynomials (degree 3);  final_evals_out[n_mls + 1]: the multilinears'
  *   evaluations at the challenges, then the indicator's prefix evaluation (eq_ind.rs:639-643) */
 int bnh_eqind_sumcheck_prove(bn_ctx *ctx, uint32_t n_vars, uint32_t n_mls, void *const *d_multilins, uint32_t n_comps, const bn_step *steps,
-                             const uint32_t *n_steps, const bn_step *steps_inf, const uint32_t *n_steps_inf, const bn_f128 *sums,
+                             const uint32_t *n_steps, const bn_step *steps_inf, const uint32_t *n_steps_inf, const uint32_t *degrees, const bn_f128 *sums,
                              const bn_f128 *eq_ind_challenges, void *d_eq_ind, uint64_t eq_ind_elems, const bn_f128 *batch_coeff, const bn_f128 *challenges,
                              bn_f128 *round_coeffs_out, bn_f128 *final_evals_out);
 

@@ -14,7 +14,7 @@ from test_gpu_hal_wide import keccak_constraints
 pytestmark = pytest.mark.gpu
 
 
-def run_both(oracle, n_vars, mls, comps, seed):
+def run_both(oracle, n_vars, mls, comps, seed, degrees=None):
     import binius_amd
     from binius_amd._host import EqIndPlan
     from oracle import zerocheck_ref
@@ -24,13 +24,13 @@ def run_both(oracle, n_vars, mls, comps, seed):
     eqc, ch, bc, sums = stream[:n_vars], stream[n_vars : 2 * n_vars], stream[2 * n_vars], stream[2 * n_vars + 1 :]
     # (the claimed sums only enter through R'(0) = (sum - alpha R'(1)) / (1 - alpha): any values exercise the same arithmetic, and
     # a table of random columns satisfies no constraint anyway)
-    want = zerocheck_ref.eqind_sumcheck_prove(mls, n_vars, comps, sums, eqc, bc, ch)
+    want = zerocheck_ref.eqind_sumcheck_prove(mls, n_vars, comps, sums, eqc, bc, ch, degrees)
     n = 1 << n_vars
     with binius_amd.Context(0, (m + 2) * n + (1 << 16)) as hal:
         alloc = hal.dev_alloc()
         d = [upload(hal, alloc, x) for x in mls]
         scratch = alloc.alloc(max(1, n // 2) + 64)
-        plan = EqIndPlan(hal, n_vars, d, comps, sums, eqc, scratch, bc, ch)
+        plan = EqIndPlan(hal, n_vars, d, comps, sums, eqc, scratch, bc, ch, degrees)
         plan.run()
         got = (plan.round_coeffs(), plan.final_evals())
         # the multilinears were folded in place: their first elements are the final evaluations
@@ -59,6 +59,59 @@ def test_small_mixed_zerocheck_vs_oracle(oracle, n_vars):
     run_both(oracle, n_vars, mls, comps, 0x2E30 + n_vars)
 
 
+@pytest.mark.parametrize("n_vars", [1, 3, 8, 12])
+def test_mixed_degree_zerocheck_vs_oracle(oracle, n_vars):
+    """Compositions of degree 1 beside degree 2 (the u32_add table's zout constraint beside its carry constraint,
+    m3/src/gadgets/add.rs:95-110): the linear ones are evaluated at X = 1 only (eq_ind.rs:664-668) and interpolated from two values."""
+    prod = [("var", 0), ("var", 2), ("add", 0, 1), ("var", 1), ("var", 2), ("add", 3, 4), ("mul", 2, 5)]
+    comps = [
+        (prod + [("var", 2), ("add", 6, 7), ("var", 3), ("add", 8, 9)], prod),
+        ([("var", 0), ("var", 1), ("add", 0, 1), ("var", 2), ("add", 2, 3), ("var", 4), ("add", 4, 5)],) * 2,
+        ([("var", 3), ("const", 0x1234567890ABCDEF1122334455667788), ("mul", 0, 1), ("var", 4), ("add", 2, 3)], [("var", 3), ("const", 0x1234567890ABCDEF1122334455667788), ("mul", 0, 1), ("var", 4), ("add", 2, 3)]),
+        ([("var", 4), ("var", 1), ("mul", 0, 1)],) * 2,
+    ]
+    mls = [oracle.random_b128(0x2E40000 + 16 * n_vars + j, 1 << n_vars) for j in range(5)]
+    run_both(oracle, n_vars, mls, comps, 0x2E50 + n_vars, [2, 1, 1, 2])
+
+
+def _replay_tool():
+    import importlib.util
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_keccak_replay", os.path.join(root, "tools", "bench_keccak_replay.py"))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    return tool
+
+
+def _replay_checker(d):
+    import os
+
+    from oracle import piop_ref, zerocheck_ref
+
+    v = d["n_vars"]
+    want = zerocheck_ref.eqind_sumcheck_prove(d["zerocheck_multilinears"], v, d["constraints"], d["zerocheck_sums"], d["eq_ind_challenges"],
+                                              d["zerocheck_batch_coeff"], d["zerocheck_challenges"], d["degrees"])
+    commitment, items, _, _ = piop_ref.piop_prove(d["committed"], d["transparents"], d["claims"], d["fri_params"], d["piop_batch_coeffs"], d["piop_challenges"],
+                                                  threads=max(1, len(os.sched_getaffinity(0))), fast=v >= 16)
+    return {"zerocheck_transcript_equal": want == d["zerocheck_transcript"],
+            "piop_transcript_equal": d["commitment"] == commitment and d["piop_transcript"] == items}
+
+
+@pytest.mark.parametrize("log_rows", [10, 14])
+def test_u32_add_replay(oracle, log_rows):
+    """BASELINE config 1 (examples/u32_add.rs, 2^10 additions -- at its actual size -- and 2^14): the HAL traffic of its proof through
+    the same tool: zerocheck of the carry (degree 2) and zout (degree 1) constraints over 5 multilinears, commit of the 4 columns,
+    piop::prove of the 5-claim prover; verifier's equations, and both transcripts equal to the oracle's bit for bit."""
+    import argparse
+
+    rec = _replay_tool().replay(argparse.Namespace(table="u32_add", log_rows=log_rows, log_perms=None, steps=1, log_inv_rate=1, log_batch=4, arity=4), _replay_checker)
+    assert rec["verifier_check"] == {"zerocheck": True, "piop_sumcheck": True}
+    assert rec["oracle_check"] == {"zerocheck_transcript_equal": True, "piop_transcript_equal": True}
+    assert rec["zerocheck"] == {"multilinears": 5, "constraints": 2} and rec["piop"]["claims"] == 5 and rec["n_vars_packed"] == log_rows - 2
+
+
 @pytest.mark.parametrize("log_perms", [4, 9])
 def test_keccak_replay_at_reduced_size(oracle, log_perms):
     """tools/bench_keccak_replay.py (the HAL traffic of constraint_system::prove for the keccak table -- BASELINE config 4: zerocheck
@@ -66,26 +119,8 @@ def test_keccak_replay_at_reduced_size(oracle, log_perms):
     2^4 / 2^9 permutations: the verifier's equations hold on both transcripts, and both equal the oracle's restatements
     (oracle/zerocheck_ref.py, oracle/piop_ref.py) bit for bit."""
     import argparse
-    import importlib.util
-    import os
 
-    from oracle import piop_ref, zerocheck_ref
-
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    spec = importlib.util.spec_from_file_location("bench_keccak_replay", os.path.join(root, "tools", "bench_keccak_replay.py"))
-    tool = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(tool)
-
-    def checker(d):
-        v = d["n_vars"]
-        want = zerocheck_ref.eqind_sumcheck_prove(d["zerocheck_multilinears"], v, d["constraints"], d["zerocheck_sums"], d["eq_ind_challenges"],
-                                                  d["zerocheck_batch_coeff"], d["zerocheck_challenges"])
-        commitment, items, _, _ = piop_ref.piop_prove(d["committed"], d["transparents"], d["claims"], d["fri_params"], d["piop_batch_coeffs"], d["piop_challenges"],
-                                                      threads=max(1, len(os.sched_getaffinity(0))), fast=v >= 16)
-        return {"zerocheck_transcript_equal": want == d["zerocheck_transcript"],
-                "piop_transcript_equal": d["commitment"] == commitment and d["piop_transcript"] == items}
-
-    rec = tool.replay(argparse.Namespace(log_perms=log_perms, steps=1, log_inv_rate=1, log_batch=4, arity=4), checker)
+    rec = _replay_tool().replay(argparse.Namespace(log_perms=log_perms, steps=1, log_inv_rate=1, log_batch=4, arity=4), _replay_checker)
     assert rec["verifier_check"] == {"zerocheck": True, "piop_sumcheck": True}
     assert rec["oracle_check"] == {"zerocheck_transcript_equal": True, "piop_transcript_equal": True}
     assert rec["zerocheck"] == {"multilinears": 204, "constraints": 100} and rec["piop"]["claims"] == 175

@@ -6,18 +6,25 @@ first).  CPU only."""
 import pytest
 
 
+DEGREE_2 = [
+    ([("var", 0), ("var", 1), ("mul", 0, 1), ("var", 2), ("add", 2, 3)], [("var", 0), ("var", 1), ("mul", 0, 1)]),
+    ([("var", 3), ("var", 4), ("add", 0, 1), ("var", 5), ("mul", 2, 3)], [("var", 3), ("var", 4), ("add", 0, 1), ("var", 5), ("mul", 2, 3)]),
+    ([("var", 1), ("const", 1), ("add", 0, 1), ("var", 2), ("mul", 2, 3), ("var", 0), ("add", 4, 5), ("var", 4), ("add", 6, 7)], [("var", 1), ("var", 2), ("mul", 0, 1)]),
+]
+# (the u32_add table's zout constraint, m3/src/gadgets/add.rs:104-110, between two of degree 2; a linear one with a constant factor)
+LINEAR = [("var", 0), ("var", 1), ("add", 0, 1), ("var", 2), ("add", 2, 3), ("var", 4), ("add", 4, 5)]
+SCALED = [("var", 3), ("const", 0x1234567890ABCDEF1122334455667788), ("mul", 0, 1), ("var", 5), ("add", 2, 3)]
+MIXED = [DEGREE_2[0], (LINEAR, LINEAR), DEGREE_2[1], (SCALED, SCALED)]
+
+
 @pytest.mark.parametrize("n_vars", [1, 2, 5, 7])
-def test_restatement_satisfies_the_verifier(oracle, n_vars):
+@pytest.mark.parametrize("comps,degrees", [(DEGREE_2, None), (MIXED, [2, 1, 2, 1])], ids=["degree2", "mixed"])
+def test_restatement_satisfies_the_verifier(oracle, n_vars, comps, degrees):
     from oracle import zerocheck_ref as z
 
     o = oracle
     m = 6
     mls = [o.random_b128(0x2C00 + 16 * n_vars + j, 1 << n_vars) for j in range(m)]
-    comps = [
-        ([("var", 0), ("var", 1), ("mul", 0, 1), ("var", 2), ("add", 2, 3)], [("var", 0), ("var", 1), ("mul", 0, 1)]),
-        ([("var", 3), ("var", 4), ("add", 0, 1), ("var", 5), ("mul", 2, 3)], [("var", 3), ("var", 4), ("add", 0, 1), ("var", 5), ("mul", 2, 3)]),
-        ([("var", 1), ("const", 1), ("add", 0, 1), ("var", 2), ("mul", 2, 3), ("var", 0), ("add", 4, 5), ("var", 4), ("add", 6, 7)], [("var", 1), ("var", 2), ("mul", 0, 1)]),
-    ]
     eqc, ch, bc = o.random_scalars(0x2C10 + n_vars, n_vars), o.random_scalars(0x2C20 + n_vars, n_vars), o.random_scalars(0x2C30, 1)[0]
     eq_full = o.arr(1 << n_vars)
     eq_full[0] = o.ints_to_arr([1])[0]
@@ -30,7 +37,7 @@ def test_restatement_satisfies_the_verifier(oracle, n_vars):
         for i in range(1 << n_vars):
             s ^= o.mul(eqi[i], o.circuit_eval(c, [v[i] for v in vals]))
         sums.append(s)
-    coeffs, fin = z.eqind_sumcheck_prove(mls, n_vars, comps, sums, eqc, bc, ch)
+    coeffs, fin = z.eqind_sumcheck_prove(mls, n_vars, comps, sums, eqc, bc, ch, degrees)
     running = o.evaluate_univariate(sums, bc)
     for r in range(n_vars):
         c = coeffs[r]

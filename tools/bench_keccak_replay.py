@@ -31,7 +31,16 @@ claim, the last claim is the batched compositions of the final evaluations times
 the batched products of the final evaluations).  Bit-exact parity of both transcripts with the oracle's restatements at reduced
 sizes is tests/test_gpu_zerocheck.py::test_keccak_replay_at_reduced_size, which runs this file's `replay()` with a checker.
 
-  python tools/bench_keccak_replay.py --log-perms 16 [--steps 2]      one JSON line: per-phase ms, kernel ms, launches"""
+`--table u32_add` replays BASELINE config 1 the same way (examples/u32_add.rs: 2^10 additions; m3/src/gadgets/add.rs:25-137 with
+commit_zout): 4 committed columns of 32 bits per row (xin, yin, cout, zout), i.e. 2^(log_rows - 2) packed elements each; the
+zerocheck over 5 multilinears (the four and cin = cout shifted left by one, a virtual column) with the constraints
+carry_out: (xin + cin)(yin + cin) + cin - cout (degree 2) and zout: xin + yin + cin - zout (degree 1 -- evaluated at X = 1 only,
+eq_ind.rs:664-668); piop::prove over the 4 committed multilinears and 2 transparents (cout is opened at the zerocheck's point and at
+the shifted one): 5 claims.  At this size everything is launch latency -- the line is there so that config 1 has been run, not
+for its rate.
+
+  python tools/bench_keccak_replay.py --log-perms 16 [--steps 2]      one JSON line: per-phase ms, kernel ms, launches
+  python tools/bench_keccak_replay.py --table u32_add --log-rows 10"""
 import argparse
 import json
 import os
@@ -41,7 +50,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 
-N_COMMITTED, N_TRANSPARENT = 100, 3
+N_COMMITTED, N_TRANSPARENT = 100, 3  # (the keccak table's)
 
 
 def keccak_constraints(n_batches=3):
@@ -67,6 +76,26 @@ def keccak_constraints(n_batches=3):
 
 def piop_claims(c=N_COMMITTED, t=N_TRANSPARENT):
     return [(i, i % t) for i in range(c)] + [(i, (i + 1) % t) for i in range(0, c, 2)] + [(i, (i + 2) % t) for i in range(0, c, 4)]
+
+
+def u32_add_constraints():
+    """zerocheck multilinears 0 xin, 1 yin, 2 cin, 3 cout, 4 zout (m3/src/gadgets/add.rs:95-110; characteristic 2: minus is plus)"""
+    prod = [("var", 0), ("var", 2), ("add", 0, 1), ("var", 1), ("var", 2), ("add", 3, 4), ("mul", 2, 5)]
+    carry = prod + [("var", 2), ("add", 6, 7), ("var", 3), ("add", 8, 9)]
+    zout = [("var", 0), ("var", 1), ("add", 0, 1), ("var", 2), ("add", 2, 3), ("var", 4), ("add", 4, 5)]
+    return 5, [(carry, prod), (zout, zout)]
+
+
+def table(name):
+    """the table's shape: one-bit cells per row (log2), committed columns, ring-switch transparents, the zerocheck's multilinears and
+    constraints (with their degrees), the PIOP prover's claims (committed index, transparent index)"""
+    if name == "keccak":
+        n_z, cons = keccak_constraints()
+        return dict(name=name, cells_log2=9, n_committed=N_COMMITTED, n_transparent=N_TRANSPARENT, n_z=n_z, constraints=cons, degrees=[2] * len(cons), claims=piop_claims())
+    if name == "u32_add":
+        n_z, cons = u32_add_constraints()
+        return dict(name=name, cells_log2=5, n_committed=4, n_transparent=2, n_z=n_z, constraints=cons, degrees=[2, 1], claims=[(0, 0), (1, 0), (2, 0), (3, 0), (2, 1)])
+    raise ValueError("unknown table %r" % name)
 
 
 def circuit_eval(F, steps, query):
@@ -134,10 +163,14 @@ def replay(args, checker=None):
     from binius_amd._host import EqIndPlan, FRIParams, PiopPlan
 
     F = binius_amd.HostField
-    v = args.log_perms + 2  # 512 one-bit cells per row = 4 elements of GF(2^128)
+    tb = table(getattr(args, "table", "keccak"))
+    log_rows = args.log_perms if getattr(args, "log_rows", None) is None else args.log_rows
+    v = log_rows + tb["cells_log2"] - 7  # (keccak: 512 one-bit cells per row = 4 elements of GF(2^128); u32_add: 32 = a quarter of one)
+    if v < 1:
+        raise ValueError("the table needs at least 2^%d rows" % (8 - tb["cells_log2"]))
     n = 1 << v
-    n_z, cons = keccak_constraints()
-    claims_ct = piop_claims()
+    n_z, cons, degrees, claims_ct = tb["n_z"], tb["constraints"], tb["degrees"], tb["claims"]
+    N_COMMITTED, N_TRANSPARENT = tb["n_committed"], tb["n_transparent"]
     total_vars = (N_COMMITTED * n - 1).bit_length()
     arities = []
     while sum(arities) + args.arity < total_vars:
@@ -146,7 +179,7 @@ def replay(args, checker=None):
     code_elems = 1 << (total_vars + args.log_inv_rate)
     ml_elems = (N_COMMITTED + N_TRANSPARENT) * n
     arena = (1 << total_vars) + 4 * code_elems + 3 * ml_elems + (n_z + 2) * n + (1 << 18)
-    rec = {"bench": "keccak_replay", "log_perms": args.log_perms, "n_vars_packed": v, "committed": N_COMMITTED, "zerocheck": {"multilinears": n_z, "constraints": len(cons)},
+    rec = {"bench": tb["name"] + "_replay", "log_perms" if tb["name"] == "keccak" else "log_rows": log_rows, "n_vars_packed": v, "committed": N_COMMITTED, "zerocheck": {"multilinears": n_z, "constraints": len(cons)},
            "piop": {"multilinears": N_COMMITTED + N_TRANSPARENT, "claims": len(claims_ct), "total_vars": total_vars,
                     "fri": {"log_inv_rate": args.log_inv_rate, "log_batch": args.log_batch, "arities": arities}}}
     phases = {}
@@ -162,7 +195,7 @@ def replay(args, checker=None):
 
         def reset_zc():
             for j, d in enumerate(zc):
-                hal.copy_d2d(zc_src[(j * 5 + j // 7) % len(zc_src)], d)
+                hal.copy_d2d(zc_src[j if n_z <= len(zc_src) else (j * 5 + j // 7) % len(zc_src)], d)
 
         reset_zc()
         # the claimed sums: S_c(0), S_c(1) of the prime polynomial from the old HAL itself (evaluation points 0 and 1), then
@@ -178,7 +211,7 @@ def replay(args, checker=None):
         for c, ci in exprs:
             c.free()
             ci.free()
-        zplan = EqIndPlan(hal, v, zc, cons, zsums, eqc, eq_scratch, zbc, zch)
+        zplan = EqIndPlan(hal, v, zc, cons, zsums, eqc, eq_scratch, zbc, zch, degrees)
         # ---- ring switch inputs
         rs_z = [synthetic.random_scalars(0x3500 + j, v) for j in range(N_TRANSPARENT)]
         rs_vec = alloc.alloc(128)
@@ -273,7 +306,7 @@ def replay(args, checker=None):
             reset_zc()
             rec["oracle_check"] = checker(dict(
                 n_vars=v, committed=[hal.copy_d2h(s) for s in committed], transparents=[hal.copy_d2h(s) for s in transparents],
-                zerocheck_multilinears=[hal.copy_d2h(s) for s in zc], constraints=cons, zerocheck_sums=zsums, eq_ind_challenges=eqc, zerocheck_batch_coeff=zbc,
+                zerocheck_multilinears=[hal.copy_d2h(s) for s in zc], constraints=cons, degrees=degrees, zerocheck_sums=zsums, eq_ind_challenges=eqc, zerocheck_batch_coeff=zbc,
                 zerocheck_challenges=zch, zerocheck_transcript=(zco, zfin), claims=claims, fri_params=p, piop_batch_coeffs=pbcs, piop_challenges=pchs,
                 commitment=bytes(pplan.commitment), piop_transcript=items))
     return rec
@@ -281,7 +314,9 @@ def replay(args, checker=None):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--log-perms", type=int, default=16, help="log2 of the number of permutations (the table's rows); config 4: 16")
+    ap.add_argument("--table", choices=["keccak", "u32_add"], default="keccak")
+    ap.add_argument("--log-perms", type=int, default=16, help="log2 of the number of permutations (the keccak table's rows); config 4: 16")
+    ap.add_argument("--log-rows", type=int, default=None, help="log2 of the table's rows (overrides --log-perms); config 1: --table u32_add --log-rows 10")
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--log-inv-rate", type=int, default=1)
     ap.add_argument("--log-batch", type=int, default=4)
