@@ -792,7 +792,7 @@ int bn_ctx_destroy(bn_ctx *ctx)
 		return BN_OK;
 	hipSetDevice(ctx->device);
 	if (ctx->grp.prof) {
-		static const char *names[] = {"parse", "match", "plan", "launch", "wait", "answer", "hosted", "defer_fold"};
+		static const char *names[] = {"parse", "match", "plan", "launch", "wait", "answer", "hosted", "defer_fold", "hosted_start_wait", "hosted_start_copy", "hosted_fold"};
 		fprintf(stderr, "[bn group prof] host us by phase:");
 		for (int i = 0; i < bn_ctx::group_state::P_N; i++) fprintf(stderr, " %s %.1f (%llu)", names[i], ctx->grp.prof_ns[i] / 1e3, (unsigned long long)ctx->grp.prof_calls[i]);
 		fprintf(stderr, "\n");

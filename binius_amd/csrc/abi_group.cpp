@@ -798,6 +798,41 @@ bool group_independent(const bn_ctx *ctx, const void *p, uint64_t n, bool write)
 	return true;
 }
 
+// Does a fold batch overlap ITSELF: an output against any other range of the batch (another array's output, lower or upper half; its
+// own upper half; its own lower half when the fold is out of place)?  One sweep over the ranges sorted by address: a range overlaps
+// an earlier one exactly when it starts before the furthest end seen so far (all ranges are n elements long).
+static bool batch_overlaps_itself(void *const *x0, const void *const *src0, const void *const *x1, uint32_t count, uint64_t n)
+{
+	struct iv {
+		const char *b;
+		bool write;
+	};
+	iv small[96];
+	std::vector<iv> big;
+	iv *v = small;
+	if (3 * (size_t)count > sizeof(small) / sizeof(small[0])) {
+		big.resize(3 * (size_t)count);
+		v = big.data();
+	}
+	size_t cnt = 0;
+	for (uint32_t i = 0; i < count; i++) {
+		v[cnt++] = iv{(const char *)x0[i], true};
+		v[cnt++] = iv{(const char *)x1[i], false};
+		if (src0[i] != x0[i]) v[cnt++] = iv{(const char *)src0[i], false};
+	}
+	const auto less = [](const iv &a, const iv &b) { return a.b < b.b; };
+	if (!std::is_sorted(v, v + cnt, less)) std::sort(v, v + cnt, less);
+	const char *end_any = nullptr, *end_write = nullptr;
+	const size_t bytes = (size_t)n * sizeof(f128);
+	for (size_t q = 0; q < cnt; q++) {
+		const iv &r = v[q];
+		if (r.write ? (end_any && r.b < end_any) : (end_write && r.b < end_write)) return true;
+		if (!end_any || r.b + bytes > end_any) end_any = r.b + bytes;
+		if (r.write && (!end_write || r.b + bytes > end_write)) end_write = r.b + bytes;
+	}
+	return false;
+}
+
 // The fold batch is the fold of a hosted prover's current arrays: performed on the host's copies (true), or not the expected call.
 static bool host_fold(bn_ctx *ctx, void *const *x0, const void *const *src0, const void *const *x1, uint32_t count, uint64_t n, f128 z)
 {
@@ -818,12 +853,9 @@ static bool host_fold(bn_ctx *ctx, void *const *x0, const void *const *src0, con
 		if (!ok) continue;
 		// later folds are in place on the previous output (what the write-back of the host copies assumes); no output may overlap
 		// what the batch reads of ANOTHER array or the upper half of its own
-		for (uint32_t i = 0; i < count && ok; i++) {
+		for (uint32_t i = 0; i < count && ok; i++)
 			if (s.h_levels > 0 && x0[i] != src0[i]) ok = false;
-			if (ranges_overlap(x0[i], n, x1[i], n) || (x0[i] != src0[i] && ranges_overlap(x0[i], n, src0[i], n))) ok = false;
-			for (uint32_t q = 0; q < count && ok; q++)
-				if (q != i && (ranges_overlap(x0[i], n, x0[q], n) || ranges_overlap(x0[i], n, src0[q], n) || ranges_overlap(x0[i], n, x1[q], n))) ok = false;
-		}
+		ok = ok && !batch_overlaps_itself(x0, src0, x1, count, n); // (a sweep: a hundred arrays were 30 000 pairwise checks per round)
 		if (!ok) return false; // (the caller's general path writes the copies back and folds on the device)
 		if (s.h_levels == 0) {
 			s.h_n0 = n;
@@ -903,7 +935,10 @@ int group_defer_fold(bn_ctx *ctx, void *const *x0, const void *const *src0, cons
 	int rc = legacy_to_group(ctx);
 	if (rc) return rc;
 	auto &g = ctx->grp;
-	if (host_fold(ctx, x0, src0, x1, count, n, z)) return BN_OK; // (a hosted prover's fold: performed on the host's copies)
+	if (host_fold(ctx, x0, src0, x1, count, n, z)) { // (a hosted prover's fold: performed on the host's copies)
+		timer.pc.lap(bn_ctx::group_state::P_HOST_FOLD);
+		return BN_OK;
+	}
 	// a batch whose arrays overlap what a waiting batch reads or writes is ordered behind it: the waiting ones run first
 	bool clash = false;
 	for (uint32_t i = 0; i < count && !clash; i++)
@@ -911,31 +946,7 @@ int group_defer_fold(bn_ctx *ctx, void *const *x0, const void *const *src0, cons
 	// ... and so is one that overlaps ITSELF: an output against any other range of the batch (the jobs of a launch run concurrently;
 	// an out-of-place fold whose output overlaps its own inputs).  One sweep over the ranges sorted by address: a range overlaps
 	// an earlier one exactly when it starts before the furthest end seen so far.
-	if (!clash) {
-		struct iv {
-			const char *b;
-			bool write;
-		};
-		std::vector<iv> v;
-		v.reserve(3 * (size_t)count);
-		for (uint32_t i = 0; i < count; i++) {
-			v.push_back(iv{(const char *)x0[i], true});
-			v.push_back(iv{(const char *)x1[i], false});
-			if (src0[i] != x0[i]) v.push_back(iv{(const char *)src0[i], false});
-		}
-		if (!std::is_sorted(v.begin(), v.end(), [](const iv &a, const iv &b) { return a.b < b.b; }))
-			std::sort(v.begin(), v.end(), [](const iv &a, const iv &b) { return a.b < b.b; });
-		const char *end_any = nullptr, *end_write = nullptr;
-		const size_t bytes = (size_t)n * sizeof(f128);
-		for (const iv &r : v) {
-			if (r.write ? (end_any && r.b < end_any) : (end_write && r.b < end_write)) {
-				clash = true;
-				break;
-			}
-			if (!end_any || r.b + bytes > end_any) end_any = r.b + bytes;
-			if (r.write && (!end_write || r.b + bytes > end_write)) end_write = r.b + bytes;
-		}
-	}
+	if (!clash) clash = batch_overlaps_itself(x0, src0, x1, count, n);
 	bn_ctx::group_fold f;
 	f.n = n;
 	f.z = z;
@@ -1159,30 +1170,33 @@ int group_eval(bn_ctx *ctx, const bn_memmap *maps, uint32_t n_maps, const bn_kop
 			g.on = true;
 			rc = wait_mail(ctx, ma.seq);
 			if (rc) return rc;
+			pc.lap(bn_ctx::group_state::P_HOST_WAIT);
 			// the staging validates itself (kernels_group.hip k_group_mirror): accepted only when the tag computed from what is read is
 			// the tag the kernel published
 			record(ctx, *hs, rq);
-			hs->hy.assign(rq.m, std::vector<uint64_t>());
-			const uint64_t total = (uint64_t)rq.m * ma.n;
+			hs->hy.resize(rq.m); // (the copies keep their capacity from prove to prove)
+			for (uint32_t j = 0; j < rq.m; j++) hs->hy[j].resize(2 * (size_t)ma.n);
 			const uint64_t *src = (const uint64_t *)g.h_stage;
 			bool valid = false;
 			for (int tries = 0; tries < 4096 && !valid; tries++) {
 				if (tries == 2048) BN_HIP(hipStreamSynchronize(ctx->stream));
 				const uint64_t want = __atomic_load_n(&ctx->h_mail[66].lo, __ATOMIC_ACQUIRE);
-				uint64_t t = ma.seq;
-				for (uint32_t j = 0; j < rq.m; j++) hs->hy[j].resize(2 * (size_t)ma.n);
-				for (uint64_t idx = 0; idx < total; idx++) {
-					const uint64_t lo = __atomic_load_n(&src[2 * idx], __ATOMIC_RELAXED), hi = __atomic_load_n(&src[2 * idx + 1], __ATOMIC_RELAXED);
-					const uint32_t j = (uint32_t)(idx / ma.n);
-					const uint64_t i = idx - (uint64_t)j * ma.n;
-					hs->hy[j][2 * i] = lo;
-					hs->hy[j][2 * i + 1] = hi;
-					const unsigned r1 = (unsigned)(idx & 63), r2 = (unsigned)((idx * 7 + 17) & 63);
-					t ^= ((lo << r1) | (r1 ? lo >> (64 - r1) : 0)) ^ ((hi << r2) | (r2 ? hi >> (64 - r2) : 0)) ^ (idx + 1) * 0x9E3779B97F4A7C15ull;
+				uint64_t t = ma.seq, idx = 0;
+				for (uint32_t j = 0; j < rq.m; j++) {
+					uint64_t *dst = hs->hy[j].data();
+					const uint64_t *sj = src + 2 * (uint64_t)j * ma.n;
+					for (uint64_t i = 0; i < ma.n; i++, idx++) {
+						const uint64_t lo = __atomic_load_n(&sj[2 * i], __ATOMIC_RELAXED), hi = __atomic_load_n(&sj[2 * i + 1], __ATOMIC_RELAXED);
+						dst[2 * i] = lo;
+						dst[2 * i + 1] = hi;
+						const unsigned r1 = (unsigned)(idx & 63), r2 = (unsigned)((idx * 7 + 17) & 63);
+						t ^= ((lo << r1) | (lo >> ((64 - r1) & 63))) ^ ((hi << r2) | (hi >> ((64 - r2) & 63))) ^ (idx + 1) * 0x9E3779B97F4A7C15ull;
+					}
 				}
 				valid = t == want;
 			}
 			if (!valid) return bn::fail(BN_ERR_DEVICE, "device error: a hosted prover's staging never became consistent");
+			pc.lap(bn_ctx::group_state::P_HOST_COPY);
 			hs->hosted = true;
 			hs->h_len = ma.n;
 			hs->h_levels = 0;

@@ -316,7 +316,7 @@ struct bn_ctx {
 		// synchronisation (abi_group.cpp unhost).
 		void *h_tables = nullptr, *d_tables = nullptr;
 		// BN_GROUP_PROF=1 (diagnostic): host nanoseconds by phase of the group path, printed when the context is destroyed
-		enum { P_PARSE = 0, P_MATCH, P_PLAN, P_LAUNCH, P_WAIT, P_ANSWER, P_HOSTED, P_DEFER, P_N };
+		enum { P_PARSE = 0, P_MATCH, P_PLAN, P_LAUNCH, P_WAIT, P_ANSWER, P_HOSTED, P_DEFER, P_HOST_WAIT, P_HOST_COPY, P_HOST_FOLD, P_N };
 		bool prof = false;
 		uint64_t prof_ns[P_N] = {}, prof_calls[P_N] = {};
 		bn::f128 *d_S = nullptr;                     // kGroupMaxSlots accumulator slots (zero between launches)

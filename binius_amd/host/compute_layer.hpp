@@ -24,6 +24,7 @@
 // except O(1) protocol scalars through bn_scalar_mul.
 #pragma once
 
+#include <atomic>
 #include <chrono>
 #include <cstdint>
 #include <cstdlib>
@@ -199,7 +200,7 @@ struct SubfieldSlice {
 template <class Slice>
 class SlicesBatch {
 public:
-	SlicesBatch(std::vector<Slice> rows, size_t row_len) : rows_(std::move(rows)), row_len_(row_len)
+	SlicesBatch(std::vector<Slice> rows, size_t row_len) : rows_(std::move(rows)), row_len_(row_len), id_(next_id())
 	{
 		for (const auto &r : rows_)
 			if (r.len() != row_len) throw std::invalid_argument("SlicesBatch: row length mismatch");
@@ -208,10 +209,19 @@ public:
 	size_t row_len() const { return row_len_; }
 	const Slice &row(size_t i) const { return rows_[i]; }
 	const std::vector<Slice> &rows() const { return rows_; }
+	// A batch is immutable: equal ids <=> the same rows (copies keep the id of what they copy).  Lets a recorder see that k ops
+	// in a row were handed the same batch without comparing k x m rows.
+	uint64_t id() const { return id_; }
 
 private:
+	static uint64_t next_id()
+	{
+		static std::atomic<uint64_t> counter{0};
+		return ++counter;
+	}
 	std::vector<Slice> rows_;
 	size_t row_len_;
+	uint64_t id_;
 };
 
 // ---------------------------------------------------------------------------------------- alloc
@@ -441,13 +451,10 @@ public:
 		op.scalar = batch_coeff.raw();
 		op.expr = composition.handle();
 		// (a prover with k claims passes the SAME batch of m rows k times in a row, v3/bivariate_product.rs:355-399: the recorded ops
-		// share one copy of it -- compared by content, a new batch may live where the last one did)
-		bool same = !rows_.empty() && rows_.back().size() == inputs.n_rows();
-		for (size_t i = 0; same && i < inputs.n_rows(); i++) {
-			const bn_kslice a = inputs.row(i).raw(), &b = rows_.back()[i];
-			same = a.buf == b.buf && a.off == b.off && a.len == b.len;
-		}
+		// share one copy of it -- told by the batch's id, not its address: a new batch may live where the last one did)
+		const bool same = !rows_.empty() && last_batch_id_ == inputs.id();
 		if (!same) {
+			last_batch_id_ = inputs.id();
 			rows_.emplace_back();
 			rows_.back().reserve(inputs.n_rows());
 			for (const auto &r : inputs.rows()) rows_.back().push_back(r.raw());
@@ -490,6 +497,7 @@ private:
 	std::vector<std::vector<bn_kslice>> rows_;
 	std::vector<std::pair<size_t, size_t>> row_index_; // (op, its rows_ entry)
 	std::vector<ExprEval> keep_;
+	uint64_t last_batch_id_ = 0;
 	uint32_t n_values_ = 0;
 };
 
