@@ -846,6 +846,9 @@ int bnh_eqind_sumcheck_prove(bn_ctx *ctx, uint32_t n_vars, uint32_t n_mls, void 
 			throw Error(Error::InputValidation, "null argument");
 		if (n_vars == 0 || n_vars >= 40) throw Error(Error::InputValidation, "n_vars out of range");
 		if (eq_ind_elems < ((uint64_t)1 << (n_vars - 1))) throw Error(Error::InputValidation, "the indicator's scratch holds fewer than 2^(n_vars - 1) elements");
+		const bool prof = AbiProf::on(); // BNH_PROF=1: wall time of the set-up, of execute / fold over all rounds, of finish (diagnostic)
+		auto now = [] { return std::chrono::steady_clock::now(); };
+		const auto t_begin = now();
 		ComputeLayer hal(ctx);
 		Mi355xBackend backend(hal);
 		DeviceBumpAllocator dev_alloc(FSliceMut{d_eq_ind, (size_t)eq_ind_elems});
@@ -870,9 +873,8 @@ int bnh_eqind_sumcheck_prove(bn_ctx *ctx, uint32_t n_vars, uint32_t n_mls, void 
 		const FSlice table = backend.tensor_product_full_query(std::vector<B128>(eqc.begin(), eqc.end() - 1), dev_alloc);
 		EqIndSumcheckProver prover(hal, backend, dev_alloc, n_vars, std::move(mls), std::move(comps), std::move(sv), eqc, FSliceMut{const_cast<void *>(table.ptr), table.len_});
 		const B128 bc(batch_coeff->lo, batch_coeff->hi);
-		const bool prof = AbiProf::on(); // BNH_PROF=1: wall time of execute / fold over all rounds (diagnostic)
 		double us_exec = 0, us_fold = 0;
-		auto now = [] { return std::chrono::steady_clock::now(); };
+		const auto t_setup = now();
 		for (uint32_t r = 0; r < n_vars; r++) {
 			const auto t0 = prof ? now() : std::chrono::steady_clock::time_point{};
 			const std::vector<B128> rc = prover.execute(bc);
@@ -884,9 +886,13 @@ int bnh_eqind_sumcheck_prove(bn_ctx *ctx, uint32_t n_vars, uint32_t n_mls, void 
 				us_fold += std::chrono::duration<double, std::micro>(now() - t1).count();
 			}
 		}
-		if (prof) fprintf(stderr, "[bnh prof] eq-ind sumcheck, %u rounds, %u multilinears, %u compositions: execute %.1f us, fold %.1f us\n", n_vars, n_mls, n_comps, us_exec, us_fold);
+		const auto t_rounds = now();
 		const std::vector<B128> fin = prover.finish();
 		for (size_t j = 0; j < fin.size(); j++) final_evals_out[j] = fin[j].raw();
+		if (prof)
+			fprintf(stderr, "[bnh prof] eq-ind sumcheck, %u rounds, %u multilinears, %u compositions: set-up %.1f us, execute %.1f us, fold %.1f us, finish %.1f us\n", n_vars,
+			        n_mls, n_comps, std::chrono::duration<double, std::micro>(t_setup - t_begin).count(), us_exec, us_fold,
+			        std::chrono::duration<double, std::micro>(now() - t_rounds).count());
 		return 0;
 	} catch (const Error &e) {
 		g_err = e.what();

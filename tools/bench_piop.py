@@ -64,9 +64,14 @@ def run_claims(args):
     out = []
     for group in ([1, 0] if args.group < 0 else [args.group]):
         os.environ["BN_GROUP"] = str(group)
-        with binius_amd.Context(0, m * n + m * (n // 2) + 4096) as hal:
+        pad = int(os.environ.get("BENCH_PAD_ELEMS", "0"))  # (experiment: arrays NOT at power-of-two strides from each other)
+        with binius_amd.Context(0, m * n + m * (n // 2) + 4096 + m * pad) as hal:
             alloc = hal.dev_alloc()
-            d = [device_random(hal, alloc, F, 0xB1A5 + j, n_vars) for j in range(m)]
+            d = []
+            for j in range(m):
+                d.append(device_random(hal, alloc, F, 0xB1A5 + j, n_vars))
+                if pad:
+                    alloc.alloc(pad)
             scratch = alloc.alloc(m * (n // 2))
             sums = [hal.inner_product(d[i], 7, d[j]) for i, j in comps]
             stream = synthetic.random_scalars(0xC4A1, n_vars + 1)
