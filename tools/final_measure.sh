@@ -31,6 +31,10 @@ BN_TWO_ROUND=0 python bench.py --n-vars 25 --steps 20 --warmup 3 --no-cpu-baseli
 python tools/bench_keccak_replay.py --log-perms 16 --steps 3 > $O/keccak_replay.json 2> $O/keccak_replay.stderr
 python tools/bench_keccak_replay.py --log-perms 12 --steps 3 > $O/keccak_replay_2p12.json 2>/dev/null
 BN_HAL_EQ_SET=0 python tools/bench_keccak_replay.py --log-perms 16 --steps 1 > $O/keccak_replay_BN_HAL_EQ_SET_0.json 2>/dev/null
+python tools/bench_keccak_replay.py --table u32_add --log-rows 10 --steps 3 > $O/replay_u32_add_2e10.json 2>/dev/null
+python tools/bench_keccak_replay.py --table u32_add --log-rows 20 --steps 3 > $O/replay_u32_add_2e20.json 2>/dev/null
+bash tools/r06_k_sweep.sh > $O/k_sweep_balanced.txt 2>&1
+bash tools/r06_k50_host.sh > $O/k50_host_phases.txt 2>&1
 tools/trace_cmd.sh final/trace_claims50 python tools/bench_piop.py claims --n-vars 22 --k 50 --group 1 --steps 2 --warmup 1 > /dev/null 2>&1
 cp $O/trace_claims50/kernel_stats.csv $O/claims_n22_k50_kernel_stats.csv; cp $O/trace_claims50/per_launch.jsonl $O/claims_n22_k50_per_launch.jsonl; rm -rf $O/trace_claims50
 tools/trace_cmd.sh final/trace_replay python tools/bench_keccak_replay.py --log-perms 16 --steps 1 > /dev/null 2>&1
