@@ -600,6 +600,7 @@ int bn_ctx_create(int device, uint64_t arena_elems, bn_ctx **out)
 	if (const char *a = getenv("BN_GROUP_SPEC")) ctx->grp.speculate = atoi(a) != 0;
 	ctx->grp.prof = getenv("BN_GROUP_PROF") != nullptr;
 	if (const char *a = getenv("BN_HAL_EQ_SET")) ctx->hal_eq_set = atoi(a) != 0;
+	if (const char *a = getenv("BN_HAL_COEF")) ctx->hal_coef = atoi(a) != 0;
 	if (const char *a = getenv("BN_GROUP_CHAIN_MIN_LOG2")) ctx->grp.chain_min_rows = atoi(a) >= 63 ? ~(uint64_t)0 : (uint64_t)1 << (atoi(a) < 0 ? 0 : atoi(a));
 	BN_HIP(hipMalloc((void **)&ctx->d_flag, sizeof(unsigned)));
 	BN_HIP(hipMemset(ctx->d_flag, 0, sizeof(unsigned)));

@@ -404,6 +404,342 @@ int round_evals_eq_set(bn_ctx *ctx, uint32_t n_vars, const bn_hal_multilinear *m
 	return BN_OK;
 }
 
+// ---- compositions of degree <= 3 at ANY evaluation points: the round polynomial's COEFFICIENTS from bilinear sums ---------------------
+// High-to-Low, every multilinear Folded and full: v(X) = v_lo + X dv (dv = v_lo + v_hi), so a monomial's sum over the half cube is a
+// polynomial in X whose coefficients are sums of products of HALVES -- no row is ever brought to a domain point z on the device (the
+// general code below multiplies every row by z through nibble tables, once per point), and any number of domain points costs the
+// same: the 16-byte coefficients meet z on the host.  With [x, y] = sum_i x[i] y[i] over the half cube:
+//     {v}        k0 = [v_lo, e]   k1 = [dv, e]                                   (e = the indicator, or the all-ones row)
+//     {u, w}     k0 = [u_lo, w_lo]   k2 = [du, dw]   P(1) = [u_hi, w_hi]   k1 = P(1) + k0 + k2
+//     {a, b, c}  T0 = a_lo (.) b_lo, T1 = a_hi (.) b_hi, Ti = da (.) db  (element-wise, ONE launch of k_mul9_jobs for every distinct pair
+//                of the request: the Karatsuba triple of a (.) b as a polynomial in X)
+//                P(1) = [T1, c_hi]   k3 = [Ti, dc]   k0 = [T0, c_lo]   k2 = [Ti, c_hi] + [T0 + T1, dc]   k1 = P(1) + k0 + k2 + k3
+// (a (.) b = T0 + X (T0 + T1 + Ti) + X^2 Ti; multiply by c_lo + X dc and collect).  Under an equality indicator the first column of
+// every monomial is scaled by it first (both halves: eq (.) du = E_lo + E_hi), as the constraint-set path above does.  Every bracket is
+// a job of ONE launch of the claim groups' kernel: [x_hi, y_hi] and [dx, dy] together are an evaluate job (kind 1), a lone bracket half
+// a kind-2 job.  So a request is at most three launches (indicator scaling, products, sums) whatever its points and compositions.
+// Reference: sumcheck_round_calculation.rs:85-330 evaluates the composition at every point of every vertex pair instead.
+constexpr int kCoefDeclined = -2001; // (internal: not this shape)
+constexpr uint32_t kCoefMaxMulJobs = 2 * kEqSetMaxScaled; // the pinned element-wise job table
+int round_evals_coef(bn_ctx *ctx, uint32_t n_vars, const bn_hal_multilinear *mls, uint32_t n_mls, const bn_hal_evaluator *evs, uint32_t n_evs, const bn_f128 *h_points,
+                     uint32_t n_points, bn_f128 *h_out)
+{
+	if (!ctx->grp.enabled || n_vars < 2 || n_evs == 0) return kCoefDeclined;
+	const uint64_t full = (uint64_t)1 << n_vars, half = full >> 1;
+	for (uint32_t k = 0; k < n_mls; k++)
+		if (mls[k].kind != BN_HAL_ML_FOLDED || mls[k].len < full || !mls[k].d_evals) return kCoefDeclined;
+	const void *eq = evs[0].d_eq_ind;
+	uint32_t pt_hi = 0, total = 0;
+	for (uint32_t e = 0; e < n_evs; e++) {
+		if (evs[e].d_eq_ind != eq || !evs[e].composition || !evs[e].composition_at_infinity || evs[e].eval_point_start < 1 || evs[e].eval_point_start > evs[e].eval_point_end)
+			return kCoefDeclined;
+		if (evs[e].composition->n_vars > n_mls || evs[e].composition_at_infinity->n_vars > n_mls) return kCoefDeclined;
+		pt_hi = std::max(pt_hi, evs[e].eval_point_end);
+		total += evs[e].eval_point_end - evs[e].eval_point_start;
+	}
+	if (n_points != (pt_hi > 3 ? pt_hi - 3 : 0) || (n_points && !h_points) || total == 0) return kCoefDeclined; // (the general code reports the error)
+	const bool has_z = pt_hi > 3;
+	// ---- the distinct monomials of the request
+	struct mono {
+		uint32_t n = 0, v[3] = {0, 0, 0};
+		bool in1 = false, in_inf = false; // some evaluator wants it at 1 / a domain point; at infinity
+		int pair = -1;                    // n = 3: its product triple
+		uint32_t s_a = 0, s_b = 0, s_c = 0; // first slots of its jobs
+	};
+	struct term {
+		uint32_t mono;
+		f128 coeff;
+	};
+	std::vector<mono> monos;
+	std::map<std::vector<uint32_t>, uint32_t> index;
+	std::vector<std::vector<term>> t1(n_evs), tinf(n_evs);
+	uint32_t deg_max = 0;
+	for (uint32_t e = 0; e < n_evs; e++) {
+		const bool want1 = (evs[e].eval_point_start <= 1 && evs[e].eval_point_end > 1) || evs[e].eval_point_end > 3, want_inf = evs[e].eval_point_start <= 2 && evs[e].eval_point_end > 2;
+		for (int which = 0; which < 2; which++) {
+			if (!(which ? want_inf : want1)) continue;
+			const std::vector<monomial> *p = poly_of(which ? evs[e].composition_at_infinity : evs[e].composition);
+			if (!p) return kCoefDeclined;
+			for (const monomial &t : *p) {
+				if (t.vars.size() > 3) return kCoefDeclined;
+				for (uint32_t v : t.vars)
+					if (v >= n_mls) return kCoefDeclined;
+				auto it = index.find(t.vars);
+				if (it == index.end()) {
+					mono m;
+					m.n = (uint32_t)t.vars.size();
+					for (uint32_t i = 0; i < m.n; i++) m.v[i] = t.vars[i];
+					it = index.emplace(t.vars, (uint32_t)monos.size()).first;
+					monos.push_back(m);
+					deg_max = std::max(deg_max, m.n);
+				}
+				(which ? tinf[e] : t1[e]).push_back(term{it->second, t.coeff});
+				(which ? monos[it->second].in_inf : monos[it->second].in1) = true;
+			}
+		}
+	}
+	// (points 1 and infinity of compositions of degree <= 2 are what the routed code and the constraint-set path above are tuned for)
+	if (!has_z && deg_max < 3) return kCoefDeclined;
+	// ---- scaled columns (under an indicator: the first column of every monomial of two or three), product triples
+	std::vector<int> e_of(n_mls, -1);
+	std::vector<uint32_t> scaled;
+	struct triple {
+		uint32_t x, y; // columns; x is the scaled one under an indicator
+		bool t0 = false, t1 = false, ti = false;
+	};
+	std::vector<triple> pairs;
+	std::map<std::pair<uint32_t, uint32_t>, int> pair_index;
+	for (mono &m : monos) {
+		if (m.n < 2) continue;
+		if (eq && e_of[m.v[0]] < 0) {
+			e_of[m.v[0]] = (int)scaled.size();
+			scaled.push_back(m.v[0]);
+		}
+		if (m.n == 3) {
+			auto key = std::make_pair(m.v[0], m.v[1]);
+			auto it = pair_index.find(key);
+			if (it == pair_index.end()) {
+				it = pair_index.emplace(key, (int)pairs.size()).first;
+				pairs.push_back(triple{m.v[0], m.v[1]});
+			}
+			m.pair = it->second;
+			triple &tp = pairs[(size_t)m.pair];
+			tp.t1 = tp.t1 || m.in1;
+			tp.t0 = tp.t0 || (m.in1 && has_z);
+			tp.ti = tp.ti || m.in_inf || (m.in1 && has_z);
+		}
+	}
+	if (2 * scaled.size() + 3 * pairs.size() > kCoefMaxMulJobs) return kCoefDeclined;
+	// ---- the jobs of the sums' launch and their slots: evaluate jobs (two slots each) first, then the lone brackets two to a job
+	struct bracket {
+		const void *x, *y;
+	};
+	std::vector<bn::group_job> jobs;
+	std::vector<bracket> rows;
+	uint32_t n_eval_jobs = 0, n_rows = 0, n_lone = 0;
+	for (const mono &m : monos) n_eval_jobs += m.n == 2 ? 1 : 0; // (a first count: is there a launch for the lone sums to ride on)
+	for (const mono &m : monos)
+		if (m.n == 3 && (m.in_inf || (m.in1 && has_z))) n_eval_jobs++;
+	// the sum of a lone row without an indicator: at streaming speed into its slot (k_xor_sum), which the sums' launch publishes with
+	// its own -- from 2^20 points a bracket with the all-ones row (twice the bytes, and Gram products of ones) costs more than a launch
+	const bool lone_direct = !eq && half >= ((uint64_t)1 << 20) && n_eval_jobs > 0;
+	n_eval_jobs = 0;
+	for (const mono &m : monos) {
+		if (m.n == 0) n_rows += eq ? 1 : 0;
+		if (m.n == 1) (lone_direct ? n_lone : n_rows) += 2;
+		if (m.n == 2) n_eval_jobs += 1, n_rows += (has_z && m.in1) ? 1 : 0;
+		if (m.n == 3) {
+			if (m.in1) has_z ? n_eval_jobs++ : n_rows++;
+			if (m.in_inf || (m.in1 && has_z)) n_eval_jobs++;
+			if (m.in1 && has_z) n_rows++;
+		}
+	}
+	const uint32_t rows_base = 2 * n_eval_jobs, lone_base = rows_base + n_rows + (n_rows & 1), n_slots = lone_base + n_lone;
+	if (n_slots + 1 > (uint32_t)bn::kGroupMaxSlots || n_eval_jobs + (n_rows + 1) / 2 > (uint32_t)bn::kGroupMaxJobs) return kCoefDeclined;
+	if (n_eval_jobs + n_rows == 0) { // (constants without an indicator: every sum over the half cube is zero)
+		for (uint32_t i = 0; i < total; i++) h_out[i] = bn_f128{0, 0};
+		return BN_OK;
+	}
+	int rc = hal_const_tables(ctx, half);
+	if (rc) return rc;
+	rc = group_res_alloc(ctx);
+	if (rc) return rc;
+	const char *ones = (const char *)ctx->hal_const, *zeros = ones + ctx->hal_const_half * sizeof(f128);
+	const size_t hb = half * sizeof(f128);
+	char *scr = nullptr;
+	if (!scaled.empty() || !pairs.empty()) {
+		scr = (char *)bn::ctx_scratch(ctx, (scaled.size() * 2 + pairs.size() * 3) * hb);
+		if (!scr) return kCoefDeclined; // (no room: the general code reports it or needs less)
+		if (!ctx->h_mul_jobs) {
+			if (hipHostMalloc(&ctx->h_mul_jobs, kCoefMaxMulJobs * sizeof(bn::mul9_job), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+				(void)hipGetLastError();
+				ctx->h_mul_jobs = nullptr;
+				return kCoefDeclined;
+			}
+			BN_HIP(hipHostGetDevicePointer(&ctx->d_mul_jobs, ctx->h_mul_jobs, 0));
+		}
+	}
+	char *E = scr, *T = scr + scaled.size() * 2 * hb;
+	auto lo_of = [&](uint32_t v, bool maybe_scaled) -> const char * {
+		return (maybe_scaled && eq) ? E + (size_t)e_of[v] * 2 * hb : (const char *)mls[v].d_evals;
+	};
+	// ---- element-wise launches: the indicator's columns, then the product triples (the second reads what the first wrote: its jobs sit
+	// behind the first launch's in the pinned table, which the first launch may still be reading)
+	bn::mul9_job *mj = (bn::mul9_job *)ctx->h_mul_jobs;
+	uint32_t n_mj = 0;
+	if (!scaled.empty()) {
+		for (size_t k = 0; k < scaled.size(); k++) {
+			const char *u = (const char *)mls[scaled[k]].d_evals;
+			char *out = E + k * 2 * hb;
+			mj[n_mj++] = bn::mul9_job{u, eq, out, nullptr, nullptr};
+			mj[n_mj++] = bn::mul9_job{u + hb, eq, out + hb, nullptr, nullptr};
+		}
+		prof_scope ps(ctx, BN_PROF_OTHER);
+		BN_HIP(bn::launch_mul9_jobs(ctx->stream, ctx->n_cu, (const bn::mul9_job *)ctx->d_mul_jobs, n_mj, half));
+	}
+	if (!pairs.empty()) {
+		const uint32_t first = n_mj;
+		for (size_t k = 0; k < pairs.size(); k++) {
+			const triple &tp = pairs[k];
+			const char *x = lo_of(tp.x, true), *y = (const char *)mls[tp.y].d_evals;
+			char *out = T + k * 3 * hb;
+			if (tp.t0) mj[n_mj++] = bn::mul9_job{x, y, out, nullptr, nullptr};
+			if (tp.t1) mj[n_mj++] = bn::mul9_job{x + hb, y + hb, out + hb, nullptr, nullptr};
+			if (tp.ti) mj[n_mj++] = bn::mul9_job{x, y, out + 2 * hb, x + hb, y + hb};
+		}
+		prof_scope ps(ctx, BN_PROF_OTHER);
+		BN_HIP(bn::launch_mul9_jobs(ctx->stream, ctx->n_cu, (const bn::mul9_job *)ctx->d_mul_jobs + first, n_mj - first, half));
+	}
+	// ---- the sums
+	uint32_t next_eval = 0, next_lone = 0;
+	auto eval_job = [&](const void *x_lo, const void *x_hi, const void *y_lo, const void *y_hi) -> uint32_t {
+		bn::group_job j{};
+		j.kind = 1;
+		j.n = half;
+		j.slot = 2 * next_eval++;
+		j.x0[0] = x_lo;
+		j.x1[0] = x_hi;
+		j.x0[1] = y_lo;
+		j.x1[1] = y_hi;
+		jobs.push_back(j);
+		return j.slot;
+	};
+	auto row = [&](const void *x, const void *y) -> uint32_t {
+		rows.push_back(bracket{x, y});
+		return rows_base + (uint32_t)rows.size() - 1;
+	};
+	const void *e_row = eq ? eq : (const void *)ones;
+	for (mono &m : monos) {
+		if (m.n == 0) {
+			if (eq) m.s_a = row(ones, eq);
+		} else if (m.n == 1) {
+			const char *v = (const char *)mls[m.v[0]].d_evals;
+			if (lone_direct) {
+				m.s_a = lone_base + next_lone++;
+				m.s_b = lone_base + next_lone++;
+				prof_scope ps(ctx, BN_PROF_OTHER);
+				BN_HIP(bn::launch_xor_sum(ctx->stream, ctx->n_cu, v + hb, half, ctx->grp.d_S + m.s_a));
+				BN_HIP(bn::launch_xor_sum(ctx->stream, ctx->n_cu, v, half, ctx->grp.d_S + m.s_b));
+			} else {
+				m.s_a = row(v + hb, e_row);
+				m.s_b = row(v, e_row);
+			}
+		} else if (m.n == 2) {
+			const char *u = lo_of(m.v[0], true), *w = (const char *)mls[m.v[1]].d_evals;
+			m.s_a = eval_job(u, u + hb, w, w + hb);
+			if (has_z && m.in1) m.s_c = row(u, w);
+		} else {
+			const char *t0 = T + (size_t)m.pair * 3 * hb, *t1p = t0 + hb, *ti = t0 + 2 * hb, *c = (const char *)mls[m.v[2]].d_evals;
+			if (m.in1) m.s_a = has_z ? eval_job(t0, t1p, c, c + hb) : row(t1p, c + hb);
+			if (m.in_inf || (m.in1 && has_z)) m.s_b = eval_job(zeros, ti, c, c + hb);
+			if (m.in1 && has_z) m.s_c = row(t0, c);
+		}
+	}
+	for (size_t q = 0; q < rows.size(); q += 2) {
+		bn::group_job j{};
+		j.kind = 2;
+		j.n = half;
+		j.slot = rows_base + (uint32_t)q;
+		j.x0[0] = rows[q].x;
+		j.x0[1] = rows[q].y;
+		if (q + 1 < rows.size()) {
+			j.x1[0] = rows[q + 1].x;
+			j.x1[1] = rows[q + 1].y;
+		}
+		jobs.push_back(j);
+	}
+	std::vector<f128> S(n_slots + 1, bn::f128_zero());
+	{
+		bn::group_tables *h_tb = (bn::group_tables *)ctx->grp.h_tables;
+		const bn::group_tables *d_tb = (const bn::group_tables *)ctx->grp.d_tables;
+		ctx->mirror.valid = false;
+		const uint64_t seq = ++ctx->mail_seq;
+		{
+			prof_scope ps(ctx, BN_PROF_ROUND_EVAL_MFMA);
+			const hipError_t le = bn::launch_group(ctx->stream, ctx->n_cu, jobs.data(), (uint32_t)jobs.size(), n_slots + 1, ctx->grp.d_S, ctx->grp.d_gmail, ctx->d_mail,
+			                                       ctx->d_ticket, seq, h_tb->jobs, d_tb->jobs);
+			if (le != hipSuccess) {
+				--ctx->mail_seq;
+				(void)hipGetLastError();
+				if (next_lone) BN_HIP(hipMemsetAsync(ctx->grp.d_S + lone_base, 0, next_lone * sizeof(f128), ctx->stream)); // (the slots are zero between launches)
+				if (le == hipErrorNotSupported) return kCoefDeclined; // (the element-wise launches wrote scratch only)
+				return bn::hip_fail(le, "launch_group (coefficient form)");
+			}
+			ctx->grp.launches++;
+			ctx->grp.jobs_eval += jobs.size();
+		}
+		volatile uint64_t *seqw = &ctx->h_mail[64].lo;
+		uint64_t spins = 0;
+		while (__atomic_load_n(seqw, __ATOMIC_ACQUIRE) != seq) {
+			if (++spins > (1ull << 22)) {
+				BN_HIP(hipStreamSynchronize(ctx->stream));
+				if (__atomic_load_n(seqw, __ATOMIC_ACQUIRE) != seq) return bn::fail(BN_ERR_DEVICE, "device error: result mailbox was not published");
+				break;
+			}
+		}
+		for (uint32_t i = 0; i < n_slots; i++) {
+			S[i].lo = __atomic_load_n(&ctx->grp.h_gmail[i].lo, __ATOMIC_RELAXED);
+			S[i].hi = __atomic_load_n(&ctx->grp.h_gmail[i].hi, __ATOMIC_RELAXED);
+		}
+	}
+	// ---- coefficients k0 .. k_deg and P(1) per monomial, then the evaluators' values
+	struct coefs {
+		f128 k[4], p1;
+	};
+	std::vector<coefs> cf(monos.size());
+	for (size_t i = 0; i < monos.size(); i++) {
+		const mono &m = monos[i];
+		coefs &c = cf[i];
+		for (auto &x : c.k) x = bn::f128_zero();
+		c.p1 = bn::f128_zero();
+		if (m.n == 0) {
+			if (eq) c.k[0] = c.p1 = S[m.s_a];
+		} else if (m.n == 1) {
+			c.p1 = S[m.s_a];
+			c.k[0] = S[m.s_b];
+			c.k[1] = S[m.s_a] ^ S[m.s_b];
+		} else if (m.n == 2) {
+			c.p1 = S[m.s_a];
+			c.k[2] = S[m.s_a + 1];
+			if (has_z && m.in1) {
+				c.k[0] = S[m.s_c];
+				c.k[1] = c.p1 ^ c.k[0] ^ c.k[2];
+			}
+		} else {
+			if (m.in1) c.p1 = S[m.s_a];
+			if (m.in_inf || (m.in1 && has_z)) c.k[3] = S[m.s_b + 1];
+			if (m.in1 && has_z) {
+				c.k[0] = S[m.s_c];
+				c.k[2] = S[m.s_b] ^ S[m.s_a + 1];
+				c.k[1] = c.p1 ^ c.k[0] ^ c.k[2] ^ c.k[3];
+			}
+		}
+	}
+	size_t off = 0;
+	for (uint32_t e = 0; e < n_evs; e++)
+		for (uint32_t p = evs[e].eval_point_start; p < evs[e].eval_point_end; p++, off++) {
+			f128 v = bn::f128_zero();
+			if (p == 2) {
+				for (const term &t : tinf[e]) {
+					const f128 sv = cf[t.mono].k[monos[t.mono].n];
+					v ^= (t.coeff == bn::f128_one()) ? sv : bn::mul_host(t.coeff, sv);
+				}
+			} else if (p == 1) {
+				for (const term &t : t1[e]) v ^= (t.coeff == bn::f128_one()) ? cf[t.mono].p1 : bn::mul_host(t.coeff, cf[t.mono].p1);
+			} else {
+				// Horner in z over the coefficient sums of the whole composition (coefficients first: four products per point)
+				f128 K[4] = {bn::f128_zero(), bn::f128_zero(), bn::f128_zero(), bn::f128_zero()};
+				for (const term &t : t1[e])
+					for (uint32_t d = 0; d <= monos[t.mono].n; d++) K[d] ^= (t.coeff == bn::f128_one()) ? cf[t.mono].k[d] : bn::mul_host(t.coeff, cf[t.mono].k[d]);
+				const f128 z = to_f(&h_points[p - 3]);
+				v = K[3];
+				for (int d = 2; d >= 0; d--) v = bn::mul_host(v, z) ^ K[d];
+			}
+			h_out[off] = bn_f128{v.lo, v.hi};
+		}
+	return BN_OK;
+}
+
 // all-ones | all-zeros tables of at least `half` elements each (ones at hal_const, zeros hal_const_half elements behind it): filled
 // once for the largest size asked for so far and kept in the context -- the rounds of a sumcheck ask for halving sizes
 int hal_const_tables(bn_ctx *ctx, uint64_t half)
@@ -514,6 +850,12 @@ int bn_hal_round_evals(bn_ctx *ctx, uint32_t order, uint32_t n_vars, const void 
 	BN_FLUSH(ctx);
 	BN_REQUIRE(order == BN_ORDER_LOW_TO_HIGH || order == BN_ORDER_HIGH_TO_LOW, "unknown evaluation order");
 	BN_REQUIRE(n_vars > 0 && n_vars < 40, "computing round evaluations requires at least a single variable");
+	if (order == BN_ORDER_HIGH_TO_LOW && ctx->hal_coef) {
+		// compositions of degree <= 3 over full Folded multilinears at domain points (or of degree 3 at 1 / infinity): the round
+		// polynomial's coefficients from bilinear sums, at most three launches whatever the width of the request
+		const int rc_c = round_evals_coef(ctx, n_vars, mls, n_mls, evs, n_evs, h_points, n_points, h_out);
+		if (rc_c != kCoefDeclined) return rc_c;
+	}
 	{
 		uint32_t pts = 0;
 		for (uint32_t e = 0; e < n_evs; e++) pts += evs[e].eval_point_end > evs[e].eval_point_start ? evs[e].eval_point_end - evs[e].eval_point_start : 0;

@@ -209,6 +209,7 @@ struct bn_ctx {
 	// device-mapped) and the plan of the last request (which monomials, which columns are scaled by the indicator), reused while
 	// the same compiled compositions come back round after round
 	bool hal_eq_set = true; // BN_HAL_EQ_SET=0: such requests are dealt out to parts of the general code instead
+	bool hal_coef = true;   // BN_HAL_COEF=0: degree-3 / domain-point requests keep the general code (rows + compiled circuits)
 	void *h_mul_jobs = nullptr, *d_mul_jobs = nullptr;
 	std::shared_ptr<void> hal_set_plan;
 	// pinned, device-mapped staging of bn_gather_d2h: offsets in, gathered items out (grown on demand)
@@ -652,6 +653,7 @@ hipError_t launch_ntt(hipStream_t s, bool inverse, void *data, uint32_t elem_lev
 struct mul9_job {
 	const void *a, *b;
 	void *out;
+	const void *a2, *b2; // both null: out = a * b; both set: out = (a + a2) * (b + b2)
 };
 hipError_t launch_mul9_jobs(hipStream_t s, int n_cu, const mul9_job *d_jobs, uint32_t n_jobs, uint64_t n);
 // ---- kernels_mul9.hip: out[i] = a[i*a_stride] * b[b_off + i*b_stride], bit-sliced

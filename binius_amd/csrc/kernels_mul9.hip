@@ -97,8 +97,10 @@ struct mul9_wave {
 	// The slot offsets of the rebuild phase are recomputed per batch from (setX, setY, setW, g) behind
 	// an opaque copy of g: hoisted out of the loop they are 15 more live registers across the
 	// multiplication and push the kernel into scratch (measured: 55 us per batch instead of ~5).
+	// a2 / b2 set: the operands are sums of two rows each, (a + a2) * (b + b2), added as they are loaded (the old HAL's products of
+	// differences a_lo + a_hi, abi_hal.cpp round_evals_coef)
 	__device__ __forceinline__ void batch(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b, uint32_t *__restrict__ out, uint64_t e0,
-	                                      uint64_t limit)
+	                                      uint64_t limit, const uint32_t *__restrict__ a2 = nullptr, const uint32_t *__restrict__ b2 = nullptr)
 	{
 		constexpr uint64_t stride_w = (uint64_t)STRIDE << 2; // in 32-bit words
 		const uint32_t *src = ((c & 4) ? b : a) + w;
@@ -111,6 +113,12 @@ struct mul9_wave {
 #pragma unroll
 			for (int j = 0; j < 32; j++)
 				r[j] = p[(uint64_t)j * 7 * stride_w];
+			if (a2) { // (uniform per wave: one copy of the code serves both forms)
+				const uint32_t *p2 = ((c & 4) ? b2 : a2) + w + base * stride_w;
+#pragma unroll
+				for (int j = 0; j < 32; j++)
+					r[j] ^= p2[(uint64_t)j * 7 * stride_w];
+			}
 		} else {
 			// ragged last batch: 8 rows at a time so only a few guarded addresses are live at once
 #pragma unroll
@@ -119,7 +127,8 @@ struct mul9_wave {
 				for (int j = j0; j < j0 + 8; j++) {
 					const uint64_t e = base + 7 * (uint64_t)j;
 					const bool ok = e < limit;
-					const uint32_t v = src[ok ? e * stride_w : 0];
+					uint32_t v = src[ok ? e * stride_w : 0];
+					if (a2) v ^= (((c & 4) ? b2 : a2) + w)[ok ? e * stride_w : 0];
 					r[j] = ok ? v : 0u;
 				}
 				__builtin_amdgcn_sched_barrier(0);
@@ -235,7 +244,7 @@ struct mul9_wave {
 	// (Textually a variant of `batch` on purpose: the same statements in the same scopes.  Splitting `batch` into two
 	// functions took the kernel from 192 registers to 256 + 44 spilled -- the schedule of the product is that close to the edge.)
 	__device__ __forceinline__ void batch2(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b, uint32_t *__restrict__ out, uint64_t e0,
-	                                      uint64_t limit)
+	                                      uint64_t limit, const uint32_t *__restrict__ a2 = nullptr, const uint32_t *__restrict__ b2 = nullptr)
 	{
 		constexpr uint64_t stride_w = (uint64_t)STRIDE << 2; // in 32-bit words
 		uint4 *const wt0 = this->wt;
@@ -253,6 +262,12 @@ struct mul9_wave {
 #pragma unroll
 			for (int j = 0; j < 32; j++)
 				r[j] = p[(uint64_t)j * 7 * stride_w];
+			if (a2) { // (uniform per wave: one copy of the code serves both forms)
+				const uint32_t *p2 = ((c & 4) ? b2 : a2) + w + base * stride_w;
+#pragma unroll
+				for (int j = 0; j < 32; j++)
+					r[j] ^= p2[(uint64_t)j * 7 * stride_w];
+			}
 		} else {
 			// ragged last batch: 8 rows at a time so only a few guarded addresses are live at once
 #pragma unroll
@@ -261,7 +276,8 @@ struct mul9_wave {
 				for (int j = j0; j < j0 + 8; j++) {
 					const uint64_t e = base + 7 * (uint64_t)j;
 					const bool ok = e < limit;
-					const uint32_t v = src[ok ? e * stride_w : 0];
+					uint32_t v = src[ok ? e * stride_w : 0];
+					if (a2) v ^= (((c & 4) ? b2 : a2) + w)[ok ? e * stride_w : 0];
 					r[j] = ok ? v : 0u;
 				}
 				__builtin_amdgcn_sched_barrier(0);
@@ -461,6 +477,10 @@ __global__ __launch_bounds__(256, 2) void k_mul9_jobs(const mul9_job *__restrict
 	mw.init(tile[wave]);
 	const uint64_t per_job = (n + kWB - 1) / kWB, total = per_job * n_jobs;
 	const uint64_t n_waves = (uint64_t)gridDim.x * 4;
+	// (the table is pinned host memory: a wave reads a job's pointers once, when it moves on to that job)
+	uint32_t cur = ~0u;
+	const uint32_t *a = nullptr, *b = nullptr, *a2 = nullptr, *b2 = nullptr;
+	uint32_t *out = nullptr;
 	for (uint64_t bt = (uint64_t)blockIdx.x * 4 + wave; bt < total; bt += n_waves) {
 		const uint32_t j = (uint32_t)(bt / per_job);
 		const uint64_t e0 = (bt - (uint64_t)j * per_job) * kWB;
@@ -468,9 +488,49 @@ __global__ __launch_bounds__(256, 2) void k_mul9_jobs(const mul9_job *__restrict
 			const uint64_t v = (uint64_t)p;
 			return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32);
 		};
-		const uint32_t *a = (const uint32_t *)uni(jobs[j].a), *b = (const uint32_t *)uni(jobs[j].b);
-		uint32_t *out = (uint32_t *)uni(jobs[j].out);
-		mw.batch(a, b, out, e0, n);
+		if (j != cur) {
+			cur = j;
+			a = (const uint32_t *)uni(jobs[j].a);
+			b = (const uint32_t *)uni(jobs[j].b);
+			out = (uint32_t *)uni(jobs[j].out);
+			a2 = (const uint32_t *)uni(jobs[j].a2);
+			b2 = (const uint32_t *)uni(jobs[j].b2);
+		}
+		mw.batch(a, b, out, e0, n, a2, b2);
+	}
+}
+
+// the same with two wave-batches per rebuild (batch2: a fifth fewer instructions per product), for launches with more batches than
+// wave slots
+__global__ __launch_bounds__(256, 2) void k_mul9_jobs_dual(const mul9_job *__restrict__ jobs, uint32_t n_jobs, uint64_t n)
+{
+	extern __shared__ uint4 tile2[];
+	const unsigned wave = threadIdx.x >> 6;
+	mul9_wave<1> mw;
+	mw.init(tile2 + wave * 2 * kWaveQ4);
+	if ((threadIdx.x & 63) < kQ)
+		tile2[wave * 2 * kWaveQ4 + kWaveQ4 + kZero * kQ + (threadIdx.x & 63)] = uint4{0, 0, 0, 0}; // the second region's zero block
+	const uint64_t per_job = (n + 2 * kWB - 1) / (2 * kWB), total = per_job * n_jobs;
+	const uint64_t n_waves = (uint64_t)gridDim.x * 4;
+	uint32_t cur = ~0u;
+	const uint32_t *a = nullptr, *b = nullptr, *a2 = nullptr, *b2 = nullptr;
+	uint32_t *out = nullptr;
+	for (uint64_t st = (uint64_t)blockIdx.x * 4 + wave; st < total; st += n_waves) {
+		const uint32_t j = (uint32_t)(st / per_job);
+		const uint64_t e0 = (st - (uint64_t)j * per_job) * 2 * kWB;
+		auto uni = [](const void *p) {
+			const uint64_t v = (uint64_t)p;
+			return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32);
+		};
+		if (j != cur) {
+			cur = j;
+			a = (const uint32_t *)uni(jobs[j].a);
+			b = (const uint32_t *)uni(jobs[j].b);
+			out = (uint32_t *)uni(jobs[j].out);
+			a2 = (const uint32_t *)uni(jobs[j].a2);
+			b2 = (const uint32_t *)uni(jobs[j].b2);
+		}
+		mw.batch2(a, b, out, e0, n, a2, b2);
 	}
 }
 
@@ -482,6 +542,16 @@ hipError_t launch_mul9_jobs(hipStream_t s, int n_cu, const mul9_job *d_jobs, uin
 	const uint64_t cap = (uint64_t)n_cu * 2;
 	if (blocks > cap) blocks = cap;
 	__atomic_thread_fence(__ATOMIC_SEQ_CST); // (the table is in memory before the doorbell rings)
+	if (total > cap * 4) {
+		constexpr size_t lds = (size_t)4 * 2 * kWaveQ4 * sizeof(uint4);
+		const hipError_t attr1 = func_lds_limit(reinterpret_cast<const void *>(&k_mul9_jobs_dual), (int)lds);
+		if (attr1 != hipSuccess) return attr1;
+		const uint64_t steps = ((n + 2 * kWB - 1) / (2 * kWB)) * n_jobs;
+		uint64_t blk = (steps + 3) / 4;
+		if (blk > cap) blk = cap;
+		hipLaunchKernelGGL(k_mul9_jobs_dual, dim3((unsigned)blk), dim3(256), lds, s, d_jobs, n_jobs, n);
+		return hipGetLastError();
+	}
 	hipLaunchKernelGGL(k_mul9_jobs, dim3((unsigned)blocks), dim3(256), 0, s, d_jobs, n_jobs, n);
 	return hipGetLastError();
 }

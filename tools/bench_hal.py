@@ -51,9 +51,9 @@ timed("hal_round_evals a*b + c at X = 1, inf, n_vars=%d (routed)" % nv,
       lambda: hal.hal_round_evals(1, nv, None, full(3, nv), [{"composition": AB_C, "composition_at_infinity": AB, "start": 1, "end": 3, "eq_ind": None}], []), 48 * n)
 ng = a.n_vars_general
 pts = synthetic.random_scalars(5, 1)
-timed("hal_round_evals a*b*c + a at X = 1, inf, z (round 3: interpreter kernel; now rows + compiled circuits), n_vars=%d" % ng,
+timed("hal_round_evals a*b*c + a at X = 1, inf, z (coefficient form: products + one sums launch; BN_HAL_COEF=0: rows + compiled circuits), n_vars=%d" % ng,
       lambda: hal.hal_round_evals(1, ng, None, full(3, ng), [{"composition": ABC_A, "composition_at_infinity": ABC, "start": 1, "end": 4, "eq_ind": None}], pts), 48 << ng)
-timed("hal_round_evals a*b*c + a at X = 1, inf, z (rows + compiled circuits), n_vars=%d" % nv,
+timed("hal_round_evals a*b*c + a at X = 1, inf, z (coefficient form; BN_HAL_COEF=0: rows + compiled circuits), n_vars=%d" % nv,
       lambda: hal.hal_round_evals(1, nv, None, full(3, nv), [{"composition": ABC_A, "composition_at_infinity": ABC, "start": 1, "end": 4, "eq_ind": None}], pts), 48 << nv)
 timed("hal_round_evals a*b at X = 1, inf, High-to-Low, n_vars=%d (routed)" % ng,
       lambda: hal.hal_round_evals(1, ng, None, full(2, ng), [{"composition": AB, "composition_at_infinity": AB, "start": 1, "end": 3, "eq_ind": None}], []), 32 << ng)
