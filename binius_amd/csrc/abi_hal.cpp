@@ -859,12 +859,16 @@ int bn_hal_round_evals(bn_ctx *ctx, uint32_t order, uint32_t n_vars, const void 
 	{
 		uint32_t pts = 0;
 		for (uint32_t e = 0; e < n_evs; e++) pts += evs[e].eval_point_end > evs[e].eval_point_start ? evs[e].eval_point_end - evs[e].eval_point_start : 0;
-		if (n_mls > (uint32_t)bn::kHalMaxMl || n_evs > (uint32_t)bn::kHalMaxEv || pts > 32) {
+		const bool wide = n_mls > (uint32_t)bn::kHalMaxMl || n_evs > (uint32_t)bn::kHalMaxEv || pts > 32;
+		// (a narrow request under an indicator takes the constraint set's two launches too: the routed code below runs one pass per
+		// monomial and reads a lone column's lower half beside an all-zeros table -- measured, (a b + c) eq: n = 13 48 -> 39 us,
+		// n = 20 96 -> 77 us, n = 24 0.62 -> 0.60 ms, where the 2^24 products of the scaling are what is left)
+		if (wide || (n_evs && evs[0].d_eq_ind)) {
 			if (order == BN_ORDER_HIGH_TO_LOW && n_points == 0 && ctx->hal_eq_set) {
 				const int rc_s = round_evals_eq_set(ctx, n_vars, mls, n_mls, evs, n_evs, h_out);
 				if (rc_s != kEqSetDeclined) return rc_s;
 			}
-			return round_evals_in_parts(ctx, order, n_vars, d_tensor_query, query_vars, mls, n_mls, evs, n_evs, h_points, n_points, h_out);
+			if (wide) return round_evals_in_parts(ctx, order, n_vars, d_tensor_query, query_vars, mls, n_mls, evs, n_evs, h_points, n_points, h_out);
 		}
 	}
 	uint32_t pt_lo = 0, pt_hi = 0, total = 0;
