@@ -116,7 +116,7 @@ def test_round_evals_fast_shape_three_factors(hal, oracle, n_vars, with_eq):
     assert got == want
 
 
-@pytest.mark.parametrize("n_vars", [2, 5, 11, 18])
+@pytest.mark.parametrize("n_vars", [2, 5, 11, 18, 19])
 def test_round_evals_routed_sums_of_products(hal, oracle, n_vars):
     """Compositions that are sums of monomials (a * b + c, a * b * c + a, K * b^3 + a, a * b + K, a single variable),
     with and without an equality indicator, at X = 1 and infinity over full multilinears: one product-sum pass per
@@ -137,6 +137,7 @@ def test_round_evals_routed_sums_of_products(hal, oracle, n_vars):
         {"steps": ab_plus_k, "steps_inf": AB, "start": 1, "end": 3, "eq_ind": None},
         {"steps": lin, "steps_inf": lin, "start": 1, "end": 3, "eq_ind": eq},
         {"steps": kab, "steps_inf": kab, "start": 1, "end": 3, "eq_ind": None},
+        {"steps": lin, "steps_inf": lin, "start": 1, "end": 3, "eq_ind": None},  # (a lone column at both points: streaming sums from 2^18 points)
     ]
     got, want = both(hal, oracle, 1, n_vars, None, [("folded", v, 0) for v in x], evaluators, [])
     assert got == want

@@ -45,10 +45,11 @@ full = lambda k, nv: [("folded", d[j].slice(0, 1 << nv), 0) for j in range(k)]
 nv = a.n_vars
 timed("hal_round_evals a*b at X = 1, inf, High-to-Low, n_vars=%d (routed: matrix-core kernel)" % nv,
       lambda: hal.hal_round_evals(1, nv, None, full(2, nv), [{"composition": AB, "composition_at_infinity": AB, "start": 1, "end": 3, "eq_ind": None}], []), 32 * n)
-timed("hal_round_evals (a*b + c) * eq at X = 1, inf, n_vars=%d (routed: two product-sum passes)" % nv,
+timed("hal_round_evals (a*b + c) * eq at X = 1, inf, n_vars=%d (the constraint set's two launches: indicator scaling + sums)" % nv,
       lambda: hal.hal_round_evals(1, nv, None, full(3, nv), [{"composition": AB_C, "composition_at_infinity": AB, "start": 1, "end": 3, "eq_ind": eq}], []), 48 * n + 8 * n)
-timed("hal_round_evals a*b + c at X = 1, inf, n_vars=%d (routed)" % nv,
-      lambda: hal.hal_round_evals(1, nv, None, full(3, nv), [{"composition": AB_C, "composition_at_infinity": AB, "start": 1, "end": 3, "eq_ind": None}], []), 48 * n)
+# (c enters at X = 1 only: its upper half -- 40 bytes per point of the cube, not 48)
+timed("hal_round_evals a*b + c at X = 1, inf, n_vars=%d (routed; c: a streaming sum of its upper half)" % nv,
+      lambda: hal.hal_round_evals(1, nv, None, full(3, nv), [{"composition": AB_C, "composition_at_infinity": AB, "start": 1, "end": 3, "eq_ind": None}], []), 40 * n)
 ng = a.n_vars_general
 pts = synthetic.random_scalars(5, 1)
 timed("hal_round_evals a*b*c + a at X = 1, inf, z (coefficient form: products + one sums launch; BN_HAL_COEF=0: rows + compiled circuits), n_vars=%d" % ng,
