@@ -13,6 +13,7 @@
 // kernels): the reference does the same thing subcube by subcube to save memory
 // (sumcheck_round_calculation.rs:404-418, 496-518).
 #include <algorithm>
+#include <chrono>
 #include <memory>
 #include <map>
 
@@ -273,6 +274,16 @@ int round_evals_eq_set(bn_ctx *ctx, uint32_t n_vars, const bn_hal_multilinear *m
 	const uint64_t full = (uint64_t)1 << n_vars, half = full >> 1;
 	const void *eq = n_evs ? evs[0].d_eq_ind : nullptr;
 	if (!eq || !ctx->grp.enabled) return kEqSetDeclined;
+	// BN_GROUP_PROF=1 (diagnostic): host microseconds of this path by phase, printed every 64 calls
+	static thread_local double prof_us[6] = {0, 0, 0, 0, 0, 0};
+	static thread_local uint64_t prof_calls = 0;
+	auto t_lap = std::chrono::steady_clock::now();
+	auto lap = [&](int ph) {
+		if (!ctx->grp.prof) return;
+		const auto now = std::chrono::steady_clock::now();
+		prof_us[ph] += std::chrono::duration<double, std::micro>(now - t_lap).count();
+		t_lap = now;
+	};
 	for (uint32_t k = 0; k < n_mls; k++)
 		if (mls[k].kind != BN_HAL_ML_FOLDED || mls[k].len < full || !mls[k].d_evals) return kEqSetDeclined;
 	for (uint32_t e = 0; e < n_evs; e++)
@@ -287,6 +298,7 @@ int round_evals_eq_set(bn_ctx *ctx, uint32_t n_vars, const bn_hal_multilinear *m
 		ctx->hal_set_plan = pl; // (nullptr: the next call plans again -- and declines again)
 		if (!pl) return kEqSetDeclined;
 	}
+	lap(0);
 	int rc = hal_const_tables(ctx, half);
 	if (rc) return rc;
 	rc = group_res_alloc(ctx);
@@ -315,6 +327,7 @@ int round_evals_eq_set(bn_ctx *ctx, uint32_t n_vars, const bn_hal_multilinear *m
 		prof_scope ps(ctx, BN_PROF_OTHER);
 		BN_HIP(bn::launch_mul9_jobs(ctx->stream, ctx->n_cu, (const bn::mul9_job *)ctx->d_mul_jobs, (uint32_t)(2 * pl->scaled.size()), half));
 	}
+	lap(1);
 	// ---- ONE launch: the products as evaluate jobs, the row products two to a job
 	std::vector<f128> sums(pl->n_slots);
 	bn::group_tables *h_tb = (bn::group_tables *)ctx->grp.h_tables;
@@ -354,6 +367,7 @@ int round_evals_eq_set(bn_ctx *ctx, uint32_t n_vars, const bn_hal_multilinear *m
 		}
 		jobs.push_back(j);
 	}
+	lap(2);
 	if (!jobs.empty()) {
 		ctx->mirror.valid = false;
 		const uint64_t seq = ++ctx->mail_seq;
@@ -369,6 +383,7 @@ int round_evals_eq_set(bn_ctx *ctx, uint32_t n_vars, const bn_hal_multilinear *m
 				return bn::hip_fail(e, "launch_group (constraint set)");
 			}
 		}
+		lap(3);
 		volatile uint64_t *seqw = &ctx->h_mail[64].lo;
 		uint64_t spins = 0;
 		while (__atomic_load_n(seqw, __ATOMIC_ACQUIRE) != seq) {
@@ -378,6 +393,7 @@ int round_evals_eq_set(bn_ctx *ctx, uint32_t n_vars, const bn_hal_multilinear *m
 				break;
 			}
 		}
+		lap(4);
 		for (uint32_t i = 0; i < pl->n_slots; i++) {
 			sums[i].lo = __atomic_load_n(&ctx->grp.h_gmail[i].lo, __ATOMIC_RELAXED);
 			sums[i].hi = __atomic_load_n(&ctx->grp.h_gmail[i].hi, __ATOMIC_RELAXED);
@@ -401,6 +417,10 @@ int round_evals_eq_set(bn_ctx *ctx, uint32_t n_vars, const bn_hal_multilinear *m
 			}
 			h_out[off] = bn_f128{v.lo, v.hi};
 		}
+	lap(5);
+	if (ctx->grp.prof && (++prof_calls & 63) == 0)
+		fprintf(stderr, "[bn eq-set prof] %llu calls, host us: plan %.1f, tables + scaling launch %.1f, jobs %.1f, sums launch %.1f, wait %.1f, read + values %.1f\n",
+		        (unsigned long long)prof_calls, prof_us[0], prof_us[1], prof_us[2], prof_us[3], prof_us[4], prof_us[5]);
 	return BN_OK;
 }
 

@@ -45,6 +45,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <functional>
+#include <cstring>
 #include <queue>
 #include <vector>
 
@@ -490,6 +491,15 @@ hipError_t launch_group(hipStream_t s, int n_cu, const group_job *jobs_in, uint3
 {
 	if (n_jobs == 0 || n_jobs > (uint32_t)kGroupMaxJobs || n_slots > (uint32_t)kGroupMaxSlots || !h_table || !d_table) return hipErrorNotSupported;
 	if (n_cu > kGroupMaxGrid) n_cu = kGroupMaxGrid;
+	static const bool prof_launch = getenv("BN_GROUP_PROF") != nullptr; // (diagnostic: host time of this function by step, and of the runtime's launch call itself)
+	static double prof_step_us[3] = {0, 0, 0};
+	auto t_step = prof_launch ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point{};
+	auto step_lap = [&](int i) {
+		if (!prof_launch) return;
+		const auto now = std::chrono::steady_clock::now();
+		prof_step_us[i] += std::chrono::duration<double, std::micro>(now - t_step).count();
+		t_step = now;
+	};
 	static const uint32_t prio = [] {
 		const char *e = bn::settled_knob("BN_FE_FP4_PRIO");
 		return e ? (uint32_t)atoi(e) & 3u : 3u;
@@ -636,23 +646,35 @@ hipError_t launch_group(hipStream_t s, int n_cu, const group_job *jobs_in, uint3
 		last.U = best_U;
 		last.assign = best_assign;
 	}
+	step_lap(0);
+	static thread_local std::vector<group_job> staged;
+	if (staged.size() < n_jobs) staged.resize(n_jobs);
 	if (packed) {
 		const uint32_t U = best_U, g = (uint32_t)n_cu / U;
+		// the items of every super-unit, in the caller's order (a chain's jobs stay in order): one counting pass -- a scan of all items
+		// per super-unit was 20 us of host time per launch at three hundred jobs on 128 super-units
+		std::vector<uint32_t> u_begin(U + 1, 0), by_unit(n_units);
+		for (uint32_t it = 0; it < n_units; it++) u_begin[best_assign[it] + 1]++;
+		for (uint32_t u = 0; u < U; u++) u_begin[u + 1] += u_begin[u];
+		{
+			std::vector<uint32_t> fill(u_begin.begin(), u_begin.end() - 1);
+			for (uint32_t it = 0; it < n_units; it++) by_unit[fill[best_assign[it]]++] = it;
+		}
 		uint32_t k = 0;
 		for (uint32_t u = 0; u < U; u++) {
 			const uint32_t head = k;
-			for (uint32_t it = 0; it < n_units; it++) { // (in the caller's order: a chain's jobs stay in order)
-				if (best_assign[it] != u) continue;
+			for (uint32_t o = u_begin[u]; o < u_begin[u + 1]; o++) {
+				const uint32_t it = by_unit[o];
 				for (uint32_t q = 0; q < len[it]; q++, k++) {
-					h_table[k] = jobs_in[first[it] + q];
-					h_table[k].wg_begin = u * g;
-					h_table[k].wg_count = 0;
-					h_table[k].chain = 0;
+					staged[k] = jobs_in[first[it] + q];
+					staged[k].wg_begin = u * g;
+					staged[k].wg_count = 0;
+					staged[k].chain = 0;
 				}
 			}
 			if (k == head) continue; // (more super-units than items cannot happen: U <= n_units and the heaviest-first deal fills every one)
-			h_table[head].wg_count = g;
-			h_table[head].chain = k - head - 1;
+			staged[head].wg_count = g;
+			staged[head].chain = k - head - 1;
 			for (uint32_t x = u * g; x < (u + 1) * g; x++) ga.head_of_wg[x >> 1] |= head << (16 * (x & 1));
 		}
 		at = U * g;
@@ -690,22 +712,22 @@ hipError_t launch_group(hipStream_t s, int n_cu, const group_job *jobs_in, uint3
 				used--;
 			}
 			// the rest goes to whoever has the most work per workgroup (round8: eight at a time for units in multiples of eight)
-			for (;;) {
-				int best = -1;
-				double best_load = 0;
-				for (uint32_t i = 0; i < n_units; i++) {
+			// (a heap: the heaviest load first, the lower index among equals -- a unit that cannot grow any more never can again, counts
+			// and `used` only rise; the scan of all units per workgroup handed out was 25 us of host time per launch at 175 units)
+			{
+				typedef std::pair<double, uint32_t> lu; // (load, n_units - 1 - index)
+				std::priority_queue<lu> heap;
+				for (uint32_t i = 0; i < n_units; i++)
+					if (w[i] > 0) heap.push(lu{w[i] / c_out[i], n_units - 1 - i});
+				while (!heap.empty() && used < (uint32_t)n_cu) {
+					const uint32_t i = n_units - 1 - heap.top().second;
+					heap.pop();
 					const uint32_t step = (round8 && c_out[i] >= 8 && (c_out[i] & 7) == 0) ? 8 : 1;
 					if (c_out[i] + step > cap[i] || used + step > (uint32_t)n_cu) continue;
-					const double load = w[i] / c_out[i];
-					if (load > best_load) {
-						best_load = load;
-						best = (int)i;
-					}
+					c_out[i] += step;
+					used += step;
+					heap.push(lu{w[i] / c_out[i], n_units - 1 - i});
 				}
-				if (best < 0) break;
-				const uint32_t step = (round8 && c_out[best] >= 8 && (c_out[best] & 7) == 0) ? 8 : 1;
-				c_out[best] += step;
-				used += step;
 			}
 			max_load = 0;
 			for (uint32_t i = 0; i < n_units; i++)
@@ -728,14 +750,19 @@ hipError_t launch_group(hipStream_t s, int n_cu, const group_job *jobs_in, uint3
 			const uint32_t u = order[o];
 			for (uint32_t g = at; g < at + cnt[u]; g++) ga.head_of_wg[g >> 1] |= k << (16 * (g & 1));
 			for (uint32_t q = 0; q < len[u]; q++, k++) {
-				h_table[k] = jobs_in[first[u] + q];
-				h_table[k].wg_begin = at;
-				h_table[k].wg_count = q == 0 ? cnt[u] : 0;
+				staged[k] = jobs_in[first[u] + q];
+				staged[k].wg_begin = at;
+				staged[k].wg_count = q == 0 ? cnt[u] : 0;
 			}
 			at += cnt[u];
 		}
 	}
+	// (the table is put together in ordinary memory and goes to the pinned block in one sequential copy: the block is written once,
+	// front to back, never read or patched by the host)
+	step_lap(1);
+	std::memcpy(h_table, staged.data(), (size_t)n_jobs * sizeof(group_job));
 	__atomic_thread_fence(__ATOMIC_SEQ_CST); // (the table is in memory before the doorbell rings)
+	step_lap(2);
 	ga.table = d_table;
 	ga.S = d_S;
 	ga.vals = d_vals;
@@ -772,7 +799,6 @@ hipError_t launch_group(hipStream_t s, int n_cu, const group_job *jobs_in, uint3
 			if (e != hipSuccess) return e;
 		}
 	}
-	static const bool prof_launch = getenv("BN_GROUP_PROF") != nullptr; // (diagnostic: host time of the runtime's launch call itself)
 	const auto t_l0 = prof_launch ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point{};
 	struct launch_timer {
 		bool on;
@@ -782,7 +808,9 @@ hipError_t launch_group(hipStream_t s, int n_cu, const group_job *jobs_in, uint3
 			if (!on) return;
 			static uint64_t ns = 0, calls = 0;
 			ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
-			if ((++calls & 63) == 0) fprintf(stderr, "[bn group prof] hipLaunchKernel of the group kernel: %.2f us per call over %llu calls\n", ns / 1e3 / calls, (unsigned long long)calls);
+			if ((++calls & 63) == 0)
+				fprintf(stderr, "[bn group prof] hipLaunchKernel of the group kernel: %.2f us per call over %llu calls; in front of it, us per call: weights + decision %.2f, dealing %.2f, table copy %.2f\n",
+				        ns / 1e3 / calls, (unsigned long long)calls, prof_step_us[0] / calls, prof_step_us[1] / calls, prof_step_us[2] / calls);
 		}
 	} lt{prof_launch, t_l0};
 	if (nt)
