@@ -73,6 +73,13 @@ BN_TWO_ROUND=0 python tools/small_rounds.py > $O/small_rounds_BN_TWO_ROUND_0.jso
 BN_HOST_TAIL=0 python tools/small_rounds.py > $O/small_rounds_BN_HOST_TAIL_0.jsonl 2>&1
 python tools/bench_pairwise.py > $O/pairwise.jsonl 2>&1
 python tools/bench_hal.py > $O/hal.jsonl 2>&1
+# the old HAL's degree-3 requests: coefficient form beside the general code (BN_HAL_COEF=0), one / three domain points, with an indicator
+{ for eq in 0 1; do for p in 1 3; do
+    python tools/bench_hal_cubic.py --eq $eq --points $p
+    BN_HAL_COEF=0 python tools/bench_hal_cubic.py --eq $eq --points $p
+  done; done; } > $O/hal_cubic.jsonl 2> $O/hal_cubic.stderr
+tools/trace_cmd.sh final/trace_cubic python tools/bench_hal_cubic.py --n-vars 24 --reps 2 > /dev/null 2>&1
+cp $O/trace_cubic/per_launch.jsonl $O/hal_cubic_n24_per_launch.jsonl; rm -rf $O/trace_cubic
 tools/trace_bench.sh final/trace_n28 --n-vars 28 --steps 3 --warmup 1 --no-cpu-baseline --no-claim-groups > /dev/null 2>&1
 tools/trace_bench.sh final/trace_n24 --n-vars 24 --steps 5 --warmup 2 --no-cpu-baseline --no-claim-groups > /dev/null 2>&1
 for t in trace_n28 trace_n24; do cp $O/$t/kernel_stats.csv $O/bench_${t#trace_}_kernel_stats.csv; cp $O/$t/per_launch.jsonl $O/per_launch_${t#trace_}.jsonl; cp $O/$t/bench_line.json $O/bench_${t#trace_}_under_rocprof.json; done
