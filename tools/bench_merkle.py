@@ -37,8 +37,9 @@ for batch in a.batches:
     t_leaf = timed(lambda: hal.groestl256_leaves(data, batch, leaves))
     nxt = nodes.slice(2 * n_leaves, 3 * n_leaves)
     t_layer = timed(lambda: hal.groestl256_compress_layer(leaves, nxt)) if n_leaves >= 2 else 0.0
-    # permutations: a leaf = 2 * (full blocks + 1 padding block) + 1 (output transformation); a tree node = 1
-    perms = n_leaves * (2 * (batch // 4 + 1) + 1) + (n_leaves - 1)
+    # permutations: a leaf = 2 * (full blocks + 1 padding block) + 1 (output transformation) -- one fewer where the leaf is whole blocks
+    # (batch % 4 == 0: Q of the constant padding block is computed once per lane, not per leaf); a tree node = 1
+    perms = n_leaves * (2 * (batch // 4 + 1) + 1 - (1 if batch % 4 == 0 else 0)) + (n_leaves - 1)
     print(json.dumps({
         "op": "merkle_build 2^%d elems, batch %d (2^%d leaves)" % (a.log_n, batch, n_leaves.bit_length() - 1),
         "ms": round(t_all, 4), "leaves_ms": round(t_leaf, 4), "first_layer_ms": round(t_layer, 4),
