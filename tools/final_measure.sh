@@ -68,6 +68,7 @@ tools/bench_mlecheck_quick.sh > $O/mlecheck_prover.jsonl 2>&1
 BN_MLECHECK_SHADOW=0 tools/bench_mlecheck_quick.sh > $O/mlecheck_prover_BN_MLECHECK_SHADOW_0.jsonl 2>&1
 python tools/profile_ntt.py --reps 3 > $O/ntt_2p24_b32.txt 2>&1
 python tools/bench_fri_commit.py > $O/fri_commit.jsonl 2>&1
+python tools/bench_merkle.py --log-n 24 --batches 4 16 64 > $O/merkle.jsonl 2>&1
 python tools/small_rounds.py > $O/small_rounds.jsonl 2>&1
 BN_TWO_ROUND=0 python tools/small_rounds.py > $O/small_rounds_BN_TWO_ROUND_0.jsonl 2>&1
 BN_HOST_TAIL=0 python tools/small_rounds.py > $O/small_rounds_BN_HOST_TAIL_0.jsonl 2>&1
