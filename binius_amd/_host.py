@@ -354,7 +354,7 @@ class PiopPlan:
 
 class EqIndPlan:
     """EqIndSumcheckProver over the old HAL (bnh_eqind_sumcheck_prove = binius_amd/host/eq_ind.hpp;
-    crates/core/src/protocols/sumcheck/prove/eq_ind.rs:378-644): the zerocheck of a constraint set, one composition (degree 1 or 2: `degrees`, default all 2)
+    crates/core/src/protocols/sumcheck/prove/eq_ind.rs:378-644): the zerocheck of a constraint set, one composition (degree 1 .. 8: `degrees`, default all 2)
     per constraint over ALL multilinears, High-to-Low.  multilins: device slices of 2^n_vars elements, FOLDED IN PLACE by run();
     compositions: list of (steps, steps_of_the_leading_form) in compile_expr's notation; sums: one claimed sum per composition;
     eq_scratch: device slice of >= 2^(n_vars - 1) elements."""
@@ -377,7 +377,8 @@ class EqIndPlan:
         self.eqc, self.ch = _f128_array(list(eq_ind_challenges)), _f128_array(list(challenges))
         self.bc = to_f128(batch_coeff)
         self.eq_scratch = eq_scratch
-        self.coeffs = (F128 * (4 * n_vars))()
+        self.per_round = 2 + max([2] + [int(d) for d in (degrees or [])])  # the round polynomials' coefficients: the largest degree (>= 2) + 2
+        self.coeffs = (F128 * (self.per_round * n_vars))()
         self.final = (F128 * (self.m + 1))()
 
     def run(self):
@@ -388,7 +389,7 @@ class EqIndPlan:
             raise BnError(rc, host_lib().bnh_last_error().decode())
 
     def round_coeffs(self):
-        return [[from_f128(self.coeffs[4 * r + i]) for i in range(4)] for r in range(self.n_vars)]
+        return [[from_f128(self.coeffs[self.per_round * r + i]) for i in range(self.per_round)] for r in range(self.n_vars)]
 
     def final_evals(self):
         return [from_f128(self.final[j]) for j in range(self.m + 1)]

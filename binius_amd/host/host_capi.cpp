@@ -834,7 +834,8 @@ int bnh_batch_sumcheck_prove(bn_ctx *ctx, uint32_t n_provers, const uint32_t *pr
 //   d_multilins[n_mls]: 2^n_vars elements each, FOLDED IN PLACE;  steps / steps_inf: the n_comps compositions and their leading
 //   forms, concatenated (n_steps[c] / n_steps_inf[c] steps each);  sums[n_comps];  eq_ind_challenges[n_vars];
 //   d_eq_ind: 2^(n_vars - 1) elements of scratch for the indicator's partial evaluations (expanded here, eq_ind.rs:430-446)
-//   round_coeffs_out[4 * n_vars]; final_evals_out[n_mls + 1] (the last one: the indicator's prefix evaluation)
+//   round_coeffs_out[(D + 2) * n_vars], D = max(2, largest degree): the round polynomials have degree D + 1 (D = 2 for the tables'
+//   constraints: four coefficients per round); final_evals_out[n_mls + 1] (the last one: the indicator's prefix evaluation)
 int bnh_eqind_sumcheck_prove(bn_ctx *ctx, uint32_t n_vars, uint32_t n_mls, void *const *d_multilins, uint32_t n_comps, const bn_step *steps,
                              const uint32_t *n_steps, const bn_step *steps_inf, const uint32_t *n_steps_inf, const uint32_t *degrees, const bn_f128 *sums,
                              const bn_f128 *eq_ind_challenges, void *d_eq_ind, uint64_t eq_ind_elems, const bn_f128 *batch_coeff, const bn_f128 *challenges,
@@ -879,7 +880,7 @@ int bnh_eqind_sumcheck_prove(bn_ctx *ctx, uint32_t n_vars, uint32_t n_mls, void 
 			const auto t0 = prof ? now() : std::chrono::steady_clock::time_point{};
 			const std::vector<B128> rc = prover.execute(bc);
 			const auto t1 = prof ? now() : t0;
-			for (size_t i = 0; i < 4; i++) round_coeffs_out[4 * r + i] = rc[i].raw();
+			for (size_t i = 0; i < rc.size(); i++) round_coeffs_out[rc.size() * r + i] = rc[i].raw();
 			prover.fold(B128(challenges[r].lo, challenges[r].hi));
 			if (prof) {
 				us_exec += std::chrono::duration<double, std::micro>(t1 - t0).count();

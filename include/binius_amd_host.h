@@ -122,12 +122,14 @@ int bnh_piop_prove(bn_ctx *ctx, uint32_t n_committed, const uint32_t *committed_
 
 /* EqIndSumcheckProver (crates/core/src/protocols/sumcheck/prove/eq_ind.rs:378-644) through the C++ mirror binius_amd/host/eq_ind.hpp,
  * over the old HAL (binius_hal::ComputationBackend: bn_hal_round_evals + the ComputeLayer's folds), evaluation order High-to-Low,
- * compositions of degree 1 or 2 (degrees[c]; NULL: all 2): the zerocheck of a constraint set -- ONE composition per constraint over ALL multilinears of the
- * table (core/src/constraint_system/prove.rs:431-505).
+ * compositions of degree 1 .. 8 (degrees[c]; NULL: all 2; evaluation points 1 ..= degree: 1, infinity, the points 2, 3, ... of the default
+ * interpolation domain, eq_ind.rs:664-668, math/src/univariate.rs:60-99): the zerocheck of a constraint set -- ONE composition per
+ * constraint over ALL multilinears of the table (core/src/constraint_system/prove.rs:431-505).
  *   d_multilins[n_mls]: 2^n_vars elements each, FOLDED IN PLACE;  steps / steps_inf: the compositions and their leading forms
  *   (ArithCircuit::leading_term), concatenated, n_steps[c] / n_steps_inf[c] steps each;  sums[n_comps]: the claimed sums
  *   eq_ind_challenges[n_vars];  d_eq_ind: >= 2^(n_vars - 1) elements of scratch (the indicator's partial evaluations)
- *   round_coeffs_out[4 * n_vars]: the batched round polynomials (degree 3);  final_evals_out[n_mls + 1]: the multilinears'
+ *   round_coeffs_out[(D + 2) * n_vars], D = max(2, largest degree): the batched round polynomials (degree D + 1; the tables'
+ *   constraints: D = 2, four coefficients per round);  final_evals_out[n_mls + 1]: the multilinears'
  *   evaluations at the challenges, then the indicator's prefix evaluation (eq_ind.rs:639-643) */
 int bnh_eqind_sumcheck_prove(bn_ctx *ctx, uint32_t n_vars, uint32_t n_mls, void *const *d_multilins, uint32_t n_comps, const bn_step *steps,
                              const uint32_t *n_steps, const bn_step *steps_inf, const uint32_t *n_steps_inf, const uint32_t *degrees, const bn_f128 *sums,

@@ -74,6 +74,27 @@ def test_mixed_degree_zerocheck_vs_oracle(oracle, n_vars):
     run_both(oracle, n_vars, mls, comps, 0x2E50 + n_vars, [2, 1, 1, 2])
 
 
+@pytest.mark.parametrize("n_vars", [1, 2, 5, 9, 13, 17])
+@pytest.mark.parametrize("max_degree", [3, 4])
+def test_higher_degree_zerocheck_vs_oracle(oracle, n_vars, max_degree):
+    """Constraints of degree 3 (and 4) beside lower ones: evaluation points 1, infinity and the points 2 (, 3) of the interpolation
+    domain (eq_ind.rs:664-668), the prime polynomials interpolated through the domain with its infinity row (univariate.rs:227-236).
+    The degree-3 set's round evaluations are the old HAL's coefficient-form requests; degree 4 takes the general
+    code.  Whole transcripts against the oracle's restatement, itself pinned by the verifier's equations (test_oracle_zerocheck.py)."""
+    abc = [("var", 0), ("var", 1), ("mul", 0, 1), ("var", 2), ("mul", 2, 3)]
+    abc_plus = abc + [("var", 3), ("var", 4), ("mul", 5, 6), ("add", 4, 7), ("var", 5), ("add", 8, 9)]
+    ab_c = [("var", 0), ("var", 1), ("mul", 0, 1), ("var", 2), ("add", 2, 3)]
+    lin = [("var", 0), ("var", 1), ("add", 0, 1), ("var", 4), ("add", 2, 3)]
+    abcd = [("var", 2), ("var", 3), ("mul", 0, 1), ("var", 4), ("mul", 2, 3), ("var", 5), ("mul", 4, 5)]
+    comps = [(abc_plus, abc), (ab_c, [("var", 0), ("var", 1), ("mul", 0, 1)]), (lin, lin), (abc, abc)]
+    degrees = [3, 2, 1, 3]
+    if max_degree == 4:
+        comps.append((abcd + [("var", 0), ("add", 6, 7)], abcd))
+        degrees.append(4)
+    mls = [oracle.random_b128(0x2E60000 + 16 * n_vars + j, 1 << n_vars) for j in range(6)]
+    run_both(oracle, n_vars, mls, comps, 0x2E70 + n_vars + 64 * max_degree, degrees)
+
+
 def _replay_tool():
     import importlib.util
     import os

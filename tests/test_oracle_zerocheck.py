@@ -15,10 +15,17 @@ DEGREE_2 = [
 LINEAR = [("var", 0), ("var", 1), ("add", 0, 1), ("var", 2), ("add", 2, 3), ("var", 4), ("add", 4, 5)]
 SCALED = [("var", 3), ("const", 0x1234567890ABCDEF1122334455667788), ("mul", 0, 1), ("var", 5), ("add", 2, 3)]
 MIXED = [DEGREE_2[0], (LINEAR, LINEAR), DEGREE_2[1], (SCALED, SCALED)]
+# degree 3 and 4 (evaluation points 1, infinity, 2 and 3 of the interpolation domain: eq_ind.rs:664-668, math/src/univariate.rs:60-99)
+ABC = [("var", 0), ("var", 1), ("mul", 0, 1), ("var", 2), ("mul", 2, 3)]
+ABC_PLUS = ABC + [("var", 3), ("var", 4), ("mul", 5, 6), ("add", 4, 7), ("var", 5), ("add", 8, 9)]
+ABCD = [("var", 2), ("var", 3), ("mul", 0, 1), ("var", 4), ("mul", 2, 3), ("var", 5), ("mul", 4, 5)]
+ABCD_PLUS = ABCD + [("var", 0), ("add", 6, 7)]
+CUBIC = [(ABC_PLUS, ABC), DEGREE_2[0], (LINEAR, LINEAR), (ABC, ABC)]
+QUARTIC = [(ABCD_PLUS, ABCD), (ABC_PLUS, ABC), DEGREE_2[1]]
 
 
 @pytest.mark.parametrize("n_vars", [1, 2, 5, 7])
-@pytest.mark.parametrize("comps,degrees", [(DEGREE_2, None), (MIXED, [2, 1, 2, 1])], ids=["degree2", "mixed"])
+@pytest.mark.parametrize("comps,degrees", [(DEGREE_2, None), (MIXED, [2, 1, 2, 1]), (CUBIC, [3, 2, 1, 3]), (QUARTIC, [4, 3, 2])], ids=["degree2", "mixed", "cubic", "quartic"])
 def test_restatement_satisfies_the_verifier(oracle, n_vars, comps, degrees):
     from oracle import zerocheck_ref as z
 
@@ -41,7 +48,10 @@ def test_restatement_satisfies_the_verifier(oracle, n_vars, comps, degrees):
     running = o.evaluate_univariate(sums, bc)
     for r in range(n_vars):
         c = coeffs[r]
-        assert c[0] ^ (c[0] ^ c[1] ^ c[2] ^ c[3]) == running, "round %d: P(0) + P(1) is not the running claim" % r
+        p1 = 0
+        for v in c:
+            p1 ^= v
+        assert len(c) == 2 + max([2] + (degrees or [])) and c[0] ^ p1 == running, "round %d: P(0) + P(1) is not the running claim" % r
         running = o.evaluate_univariate(c, ch[r])
     acc, p = 0, 1
     for c, _ in comps:

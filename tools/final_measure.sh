@@ -79,6 +79,7 @@ python tools/bench_hal.py > $O/hal.jsonl 2>&1
     python tools/bench_hal_cubic.py --eq $eq --points $p
     BN_HAL_COEF=0 python tools/bench_hal_cubic.py --eq $eq --points $p
   done; done; } > $O/hal_cubic.jsonl 2> $O/hal_cubic.stderr
+{ for n in 20 16; do python tools/bench_zerocheck_cubic.py --n-vars $n; BN_HAL_COEF=0 python tools/bench_zerocheck_cubic.py --n-vars $n; done; } > $O/zerocheck_cubic.jsonl 2>/dev/null
 tools/trace_cmd.sh final/trace_cubic python tools/bench_hal_cubic.py --n-vars 24 --reps 2 > /dev/null 2>&1
 cp $O/trace_cubic/per_launch.jsonl $O/hal_cubic_n24_per_launch.jsonl; rm -rf $O/trace_cubic
 tools/trace_bench.sh final/trace_n28 --n-vars 28 --steps 3 --warmup 1 --no-cpu-baseline --no-claim-groups > /dev/null 2>&1
